@@ -1,0 +1,314 @@
+#!/usr/bin/env python
+"""Freeze outputs of the UNMODIFIED reference as golden vectors.
+
+Run in the survey container only (needs /root/reference):
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+                                           # and thepayne_amd/data/highav_table.json
+
+Inputs are regenerated from seeds by ``thepayne_amd.synth`` on both sides, so
+the fixtures hold seeds, theta vectors and the reference's OUTPUTS only (plus
+the noisy observed spectra, so they do not drift with numpy's RNG).  The
+reference source itself is never copied.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim as rs  # noqa: E402
+
+rs.install()
+from thepayne_amd import synth  # noqa: E402
+
+import scipy  # noqa: E402
+from Payne.predict import ystpred, predictspec, predictsed, highred  # noqa: E402
+from Payne.fitting.likelihood import likelihood  # noqa: E402
+from Payne.fitting.prior import prior  # noqa: E402
+from Payne.fitting.fitstar import lnprobfn  # noqa: E402
+from Payne.fitting.fitutils import polycalc, airtovacuum  # noqa: E402
+from Payne.utils import smoothing  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+VERS = dict(numpy=np.__version__, scipy=scipy.__version__)
+
+SPEC_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
+ALL_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R',
+            'log(R)', 'Dist', 'log(A)', 'Av', 'Rv', 'CarbonScale']
+
+
+def save(name, **arrs):
+    arrs["versions"] = np.array(json.dumps(VERS))
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path + ".npz" if not path.endswith(".npz") else path) / 1e3))
+
+
+def fitpars_for(on, npoly=0):
+    names = list(ALL_PARS) + ['pc_%d' % i for i in range(npoly)]
+    bools = {p: (p in on or p.startswith('pc_')) for p in names}
+    return [names, bools]
+
+
+# ------------------------------------------------------------------ G1
+def g1_ann():
+    labels = np.array([
+        [5770, 4.44, 0.0, 0.0], [3500, 0.0, -2.5, -0.2], [8000, 5.5, 0.5, 0.6], [3500, 5.5, -2.5, 0.6],
+        [8000, 0.0, 0.5, -0.2], [4500, 2.5, -1.0, 0.2], [6500, 4.0, -0.5, 0.0], [5000, 4.6, 0.2, 0.1],
+        [7200, 3.9, -2.0, 0.4], [4100, 1.2, 0.3, -0.1], [5772, 4.438, 0.01, 0.02], [6000, 4.0, 0.0, 0.0],
+        [3600, 5.0, -0.3, 0.3], [7900, 4.3, 0.45, 0.55], [5200, 3.3, -1.7, 0.25], [6800, 4.9, 0.1, -0.15]])
+    out = {"labels": labels}
+    net = synth.make_yst_net(npix=256, H=48, seed=3)
+    rs.register_yst('/g1/yst.h5', net)
+    PP = ystpred.PayneSpecPredict(nnpath='/g1/yst.h5', NNtype='YST1')
+    out["yst"] = np.array([PP.predictspec(list(l)) for l in labels])
+    # Teff/1000 convention of ystpred.py:76-79
+    netk = synth.make_yst_net(npix=256, H=48, seed=3)
+    netk["x_min"][0] /= 1000.0
+    netk["x_max"][0] /= 1000.0
+    rs.register_yst('/g1/ystk.h5', netk)
+    PPk = ystpred.PayneSpecPredict(nnpath='/g1/ystk.h5', NNtype='YST1')
+    out["yst_kfix"] = np.array([PPk.predictspec(list(l)) for l in labels])
+    # 5-label (vmic) network
+    net5 = synth.make_yst_net(npix=256, H=48, seed=4, D=5)
+    rs.register_yst('/g1/yst5.h5', net5)
+    PP5 = ystpred.PayneSpecPredict(nnpath='/g1/yst5.h5', NNtype='YST1')
+    lab5 = np.hstack([labels, np.linspace(0.5, 2.5, len(labels))[:, None]])
+    out["labels5"] = lab5
+    out["yst5"] = np.array([PP5.predictspec(list(l)) for l in lab5])
+    for kind in ("LinNet", "SMLP"):
+        tn = synth.make_torch_net(kind, npix=256, seed=7)
+        rs.register_torchnet('/g1/%s.h5' % kind, tn)
+        P = predictspec.PayneSpecPredict(nnpath='/g1/%s.h5' % kind, NNtype=kind)
+        out[kind.lower()] = np.array([P.predictspec(list(l)) for l in labels])
+    save("g1_ann", **out)
+
+
+# ------------------------------------------------------------------ G2/G3
+def g2_getspec():
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    rs.register_yst('/g2/yst.h5', net)
+    PP = ystpred.PayneSpecPredict(nnpath='/g2/yst.h5', NNtype='YST1')
+    obs = synth.obs_grid(net["wavelength"], 900, inset=1.0)
+    lab = dict(Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
+    rows = []
+    for vrad in (-300.0, -10.0, 0.0, 10.0, 300.0):
+        for vrot in (0.0, 1e-3, 0.5, 5.0, 50.0):
+            for R in (10000.0, 30000.0):
+                rows.append((vrad, vrot, R))
+    for vrad in (0.0, 10.0):
+        for vrot in (0.0, 5.0):
+            for R in (40000.0, np.nan):        # above the ANN's own R -> NaN ; NaN -> plain interp
+                rows.append((vrad, vrot, R))
+    rows = np.array(rows)
+    final, after_rot, masks = [], {}, []
+    raw = PP.predictspec([lab['Teff'], lab['logg'], lab['feh'], lab['afe']])
+    for vrad, vrot, R in rows:
+        with np.errstate(all="ignore"):
+            w, f = PP.getspec(rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=2.355 * R, outwave=obs, **lab)
+        final.append(f)
+        if vrot not in after_rot:
+            w1, f1 = PP.getspec(rot_vel=vrot, **lab)
+            after_rot[vrot] = f1
+        # G3: the data-dependent mask of the R stage (smoothing.py:631-647)
+        mw = net["wavelength"] * (1.0 + vrad / ystpred.speedoflight) if vrad != 0.0 else net["wavelength"]
+        if np.isfinite(R):
+            m = smoothing.mask_wave(mw, width=2.355 * R, outwave=obs)
+            masks.append((int(np.argmax(m)), int(m.sum())))
+        else:
+            masks.append((-1, -1))
+    vr = np.array(sorted(after_rot))
+    save("g2_getspec", theta_rows=rows, labels=np.array([lab['Teff'], lab['logg'], lab['feh'], lab['afe']]),
+         obs_wave=obs, raw=raw, vrot_values=vr, after_rot=np.array([after_rot[v] for v in vr]),
+         final=np.array(final), mask_first_count=np.array(masks))
+
+
+# ------------------------------------------------------------------ G4
+def _spec_problem(cfg, seed_noise=0, H=300, modpoly=False):
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=H, seed=0)
+    path = '/g4/yst_%d.h5' % cfg["npix"]
+    rs.register_yst(path, net)
+    PP = ystpred.PayneSpecPredict(nnpath=path, NNtype='YST1')
+    obs = synth.obs_grid(net["wavelength"], cfg["nobs"])
+    T = synth.TRUTH
+    _, clean = PP.getspec(Teff=T["Teff"], logg=T["logg"], feh=T["feh"], afe=T["afe"], rad_vel=T["vrad"],
+                          rot_vel=T["vrot"], vmic=np.nan, inst_R=2.355 * T["inst_R"], outwave=obs)
+    rng = np.random.default_rng(seed_noise)
+    flux = clean + rng.normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    return net, path, obs, flux, eflux
+
+
+def g4_lnlike():
+    cfg = synth.CONFIGS["C2"]
+    net, path, obs, flux, eflux = _spec_problem(cfg)
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+               'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {}}
+    fitpars = fitpars_for(SPEC_PARS)
+    runbools = [True, False, False, False, False]
+    L = likelihood(fitargs, fitpars, runbools)
+    P = prior(fitargs, synth.demo_priordict(), fitpars, runbools)
+    rng = np.random.default_rng(1)
+    u = rng.uniform(size=(512, 7))
+    theta = np.array([P.priortrans(ui) for ui in u])
+    lnl = np.array([L.lnlikefn(t) for t in theta])
+    lnp = np.array([lnprobfn(t, L, P) for t in theta])
+    save("g4_lnlike_c2", u=u, theta=theta, lnlike=lnl, lnprob=lnp, obs_wave=obs, obs_flux=flux, obs_eflux=eflux)
+
+    # modpoly (3 Chebyshev blaze coefficients) on a smaller problem
+    cfg = synth.CONFIGS["small"]
+    net, path, obs, flux, eflux = _spec_problem(cfg, H=64)
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+               'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {}}
+    fitpars = fitpars_for(SPEC_PARS, npoly=3)
+    runbools = [True, False, True, False, False]
+    pd = synth.demo_priordict()
+    pd['blaze_coeff'] = [[0.0, 0.05], [0.0, 0.02], [0.0, 0.01]]
+    L = likelihood(fitargs, fitpars, runbools)
+    P = prior(fitargs, pd, fitpars, runbools)
+    u = np.random.default_rng(2).uniform(size=(64, 10))
+    theta = np.array([P.priortrans(ui) for ui in u])
+    lnl = np.array([L.lnlikefn(t) for t in theta])
+    save("g4_lnlike_modpoly", u=u, theta=theta, lnlike=lnl, obs_wave=obs, obs_flux=flux, obs_eflux=eflux)
+
+    # joint spectrum + photometry (photscale: log(A), Av) and (log(R), Dist, Av)
+    phot = synth.make_phot_nets()
+    rs.register_phot('/g4/phot/', phot)
+    obs_phot = {f: [5.0 + 0.1 * i, 0.05] for i, f in enumerate(phot["filters"])}
+    for tag, photscale, on in (("scaled", True, SPEC_PARS + ['log(A)', 'Av']),
+                               ("dist", False, SPEC_PARS + ['log(R)', 'Dist', 'Av'])):
+        fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+                   'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {},
+                   'photANNpath': '/g4/phot/', 'obs_phot': obs_phot}
+        fitpars = fitpars_for(on)
+        runbools = [True, True, False, photscale, False]
+        pd = synth.demo_priordict()
+        pd['log(A)'] = {'pv_uniform': [-3.0, 7.0]}
+        pd['Av'] = {'pv_uniform': [0.0, 7.0]}          # reaches the av >= 5 branch
+        pd['log(R)'] = {'pv_uniform': [-0.5, 0.5]}
+        pd['Dist'] = {'pv_uniform': [10.0, 1000.0]}
+        L = likelihood(fitargs, fitpars, runbools)
+        P = prior(fitargs, pd, fitpars, runbools)
+        nd = len(L.fitpars_i)
+        u = np.random.default_rng(3).uniform(size=(64, nd))
+        theta = np.array([P.priortrans(ui) for ui in u])
+        lnl = np.array([L.lnlikefn(t) for t in theta])
+        save("g4_lnlike_joint_" + tag, u=u, theta=theta, lnlike=lnl, fitpars_i=np.array(L.fitpars_i),
+             obs_wave=obs, obs_flux=flux, obs_eflux=eflux,
+             obs_mag=np.array([v[0] for v in obs_phot.values()]), obs_magerr=np.array([v[1] for v in obs_phot.values()]))
+
+
+# ------------------------------------------------------------------ G5
+def g5_sed():
+    phot = synth.make_phot_nets()
+    rs.register_phot('/g5/phot/', phot)
+    S = predictsed.FastPayneSEDPredict(usebands=phot["filters"], nnpath='/g5/phot/')
+    rng = np.random.default_rng(5)
+    n = 24
+    pars = np.column_stack([
+        np.log10(rng.uniform(3500, 9000, n)), rng.uniform(0, 5, n), rng.uniform(-2, 0.5, n), rng.uniform(-0.2, 0.6, n),
+        np.concatenate([rng.uniform(0, 4.9, n - 8), rng.uniform(5.0, 9.0, 8)]),   # av, last 8 use the high-Av branch
+        rng.uniform(2.5, 4.5, n), rng.uniform(-1, 1, n), rng.uniform(10, 5000, n), rng.uniform(-2, 3, n)])
+    pars[n - 8, 4] = 5.0       # exactly on the branch boundary
+    m_dist = np.array([S.sed(logt=p[0], logg=p[1], feh=p[2], afe=p[3], av=p[4], rv=p[5], logl=p[6], dist=p[7]) for p in pars])
+    m_scal = np.array([S.sed(logt=p[0], logg=p[1], feh=p[2], afe=p[3], av=p[4], rv=p[5], logA=p[8]) for p in pars])
+    bc = np.array([S.anns.eval([10.0 ** p[0], p[1], p[2], p[3], p[4], p[5]]) for p in pars])
+    save("g5_sed", pars=pars, mags_dist=m_dist, mags_scaled=m_scal, bc=bc, hiav=np.array(S.HiAv.Avlist, dtype=float))
+    # the high-Av coefficient table is DATA the product needs too
+    H = highred.highAv(list(predictsed._ALLFILTERS))
+    table = {f: [None if not np.isfinite(v) else float(v) for v in row]
+             for f, row in zip(predictsed._ALLFILTERS, H.Avlist)}
+    os.makedirs(os.path.join(ROOT, "thepayne_amd", "data"), exist_ok=True)
+    with open(os.path.join(ROOT, "thepayne_amd", "data", "highav_table.json"), "w") as fh:
+        json.dump({"columns": ["a1", "b1", "a2", "b2", "c2"], "filters": table}, fh, indent=0)
+
+
+# ------------------------------------------------------------------ G6
+def g6_prior():
+    u = np.array([0.0, 1e-6, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1 - 1e-9, 1.0])
+    out = {"u": u}
+    fitargs = {'fixedpars': {}}
+    kinds = {
+        "uniform": {'pv_uniform': [4000.0, 8000.0]},
+        "uniform_rev": {'pv_uniform': [8000.0, 4000.0]},
+        "gaussian": {'pv_gaussian': [5770.0, 100.0]},
+        "tgaussian": {'pv_tgaussian': [25000.0, 37000.0, 28800.0, 1000.0]},
+        "exp": {'pv_exp': [0.0, 2.0]},
+        "texp": {'pv_texp': [0.0, 10.0, 2.0]},
+        "default": None,
+    }
+    for par in ('Teff', 'Inst_R', 'Vrot'):
+        for kname, spec in kinds.items():
+            pd = {} if spec is None else {par: spec}
+            fitpars = fitpars_for([par])
+            with np.errstate(all="ignore"):
+                P = prior(fitargs, pd, fitpars, [True, False, False, False, False])
+                out["spec_%s_%s" % (par, kname)] = np.array([P.priortrans([ui])[0] for ui in u], dtype=float)
+    for par in ('log(A)', 'Av', 'Dist', 'log(R)', 'Rv'):
+        for kname in ("uniform", "gaussian", "tgaussian", "exp", "default"):
+            spec = kinds[kname]
+            pd = {} if spec is None else {par: spec}
+            fitpars = fitpars_for([par])
+            with np.errstate(all="ignore"):
+                P = prior(fitargs, pd, fitpars, [False, True, False, True, False])
+                out["phot_%s_%s" % (par, kname)] = np.array([P.priortrans([ui])[0] for ui in u], dtype=float)
+    # phot-only run transforms the four atmosphere labels too (prior.py:200-229)
+    fitpars = fitpars_for(['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'log(A)', 'Av'])
+    pd = {'Teff': {'pv_gaussian': [5770.0, 200.0]}, 'Av': {'pv_uniform': [0.0, 1.0]}}
+    P = prior(fitargs, pd, fitpars, [False, True, False, True, False])
+    U = np.random.default_rng(6).uniform(size=(16, 6))
+    out["photonly_u"] = U
+    out["photonly_theta"] = np.array([P.priortrans(ui) for ui in U], dtype=float)
+    # blaze coefficients (prior.py:180-191)
+    fitpars = fitpars_for(SPEC_PARS, npoly=4)
+    pd = synth.demo_priordict()
+    pd['blaze_coeff'] = [[0.0, 0.5], [0.1, 0.2], [-0.05, 0.1], [0.0, 0.01]]
+    P = prior(fitargs, pd, fitpars, [True, False, True, False, False])
+    U = np.random.default_rng(7).uniform(size=(16, 11))
+    out["blaze_u"] = U
+    out["blaze_theta"] = np.array([P.priortrans(ui) for ui in U], dtype=float)
+    # additive ln-priors (prior.py:274-465).  NB a 'gaussian'/'uniform' prior on an
+    # atmosphere label in a JOINT run raises KeyError in the reference
+    # (lnprior_phot only fills pardict_i['Teff'...] when there is no spectrum,
+    # prior.py:431-435 vs :451), so the joint case carries a phot prior only.
+    fitpars = fitpars_for(SPEC_PARS)
+    pd = synth.demo_priordict()
+    pd['Teff']['gaussian'] = [5770.0, 50.0]
+    pd['[Fe/H]']['uniform'] = [-0.05, 0.08]
+    P = prior(fitargs, pd, fitpars, [True, False, False, False, False])
+    U = np.random.default_rng(8).uniform(size=(32, 7))
+    th = np.array([P.priortrans(ui) for ui in U], dtype=float)
+    out["lnprior_spec_u"] = U
+    out["lnprior_spec_theta"] = th
+    out["lnprior_spec"] = np.array([P.lnpriorfn(list(t)) for t in th], dtype=float)
+    fitpars = fitpars_for(SPEC_PARS + ['log(A)', 'Av'])
+    pd = synth.demo_priordict()
+    pd['Av'] = {'pv_uniform': [0.0, 1.0], 'gaussian': [0.1, 0.05], 'uniform': [0.02, 0.9]}
+    pd['log(A)'] = {'pv_uniform': [-3.0, 7.0]}
+    P = prior(fitargs, pd, fitpars, [True, True, False, True, False])
+    U = np.random.default_rng(9).uniform(size=(32, 9))
+    th = np.array([P.priortrans(ui) for ui in U], dtype=float)
+    out["lnprior_joint_u"] = U
+    out["lnprior_joint_theta"] = th
+    out["lnprior_joint"] = np.array([P.lnpriorfn(list(t)) for t in th], dtype=float)
+    save("g6_prior", **out)
+
+
+# ------------------------------------------------------------------ G7
+def g7_misc():
+    w = np.linspace(5153.0, 5241.0, 500)
+    coefs = np.array([[1.0, 0.0, 0.0], [0.9, 0.05, -0.02], [1.1, -0.3, 0.2], [0.75, 1.0, 1.0]])
+    air = np.linspace(3800.0, 9000.0, 64)
+    save("g7_misc", wave=w, coefs=coefs, poly=np.array([polycalc(c, w) for c in coefs]),
+         air=air, vac=airtovacuum(air))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7"]
+    for k in which:
+        {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc}[k]()

@@ -1,0 +1,114 @@
+"""The numpy oracle against golden vectors frozen from the reference itself
+(oracle/gen_golden.py).  fp64 both sides -> tolerance 1e-12 (YST1 path);
+torch-fp32 nets (LinNet/SMLP) to 2e-6."""
+import numpy as np
+import pytest
+
+import oracle as O
+from thepayne_amd import synth
+
+SPEC_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
+
+
+def test_g1_yst_forward(golden):
+    g = golden("g1_ann")
+    net = synth.make_yst_net(npix=256, H=48, seed=3)
+    got = np.array([O.yst_forward(net, l) for l in g["labels"]])
+    np.testing.assert_allclose(got, g["yst"], rtol=0, atol=1e-12)
+    # the Teff/1000 convention is repaired at load (ystpred.py:76-79) -> same outputs
+    np.testing.assert_allclose(g["yst_kfix"], g["yst"], rtol=0, atol=1e-12)
+    net5 = synth.make_yst_net(npix=256, H=48, seed=4, D=5)
+    got5 = np.array([O.yst_forward(net5, l) for l in g["labels5"]])
+    np.testing.assert_allclose(got5, g["yst5"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["LinNet", "SMLP"])
+def test_g1_torch_nets(golden, kind):
+    g = golden("g1_ann")
+    net = synth.make_torch_net(kind, npix=256, seed=7)
+    got = np.array([O.torchnet_forward(net, l) for l in g["labels"]])
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, g[kind.lower()], rtol=0, atol=2e-6)
+
+
+def test_g2_getspec_stages_and_masks(golden):
+    g = golden("g2_getspec")
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    lab = dict(zip(("Teff", "logg", "feh", "afe"), g["labels"]))
+    obs = g["obs_wave"]
+    np.testing.assert_allclose(O.yst_forward(net, g["labels"]), g["raw"], atol=1e-12)
+    for v, ref in zip(g["vrot_values"], g["after_rot"]):
+        _, f = O.getspec(net, rot_vel=float(v), **lab)
+        np.testing.assert_allclose(f, ref, rtol=0, atol=1e-12, equal_nan=True)
+    n_nan_rows = 0
+    for (vrad, vrot, R), ref, (first, count) in zip(g["theta_rows"], g["final"], g["mask_first_count"]):
+        with np.errstate(all="ignore"):
+            _, f = O.getspec(net, rad_vel=float(vrad), rot_vel=float(vrot), vmic=np.nan,
+                             inst_R=2.355 * float(R), outwave=obs, **lab)
+        assert np.array_equal(np.isnan(f), np.isnan(ref))
+        np.testing.assert_allclose(f, ref, rtol=0, atol=1e-12, equal_nan=True)
+        n_nan_rows += int(np.isnan(ref).any())
+        if np.isfinite(R):
+            mw = net["wavelength"] * (1.0 + vrad / O.C_KMS_DOPPLER) if vrad != 0 else net["wavelength"]
+            m = O.mask_range(mw, 2.355 * R, obs)
+            assert (int(np.argmax(m)), int(m.sum())) == (first, count)
+    assert n_nan_rows >= 4          # the fixture really exercises the NaN contracts
+
+
+def _c2_like(golden, name):
+    g = golden(name)
+    return g
+
+
+def test_g4_lnlike_c2(golden):
+    g = golden("g4_lnlike_c2")
+    cfg = synth.CONFIGS["C2"]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    L = O.OracleLikelihood(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], SPEC_PARS)
+    idx = np.arange(0, 512, 4)                  # 128 of the 512 draws keeps the CPU suite quick
+    got = np.array([L.lnlikefn(g["theta"][i]) for i in idx])
+    np.testing.assert_allclose(got, g["lnlike"][idx], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(g["lnprob"], g["lnlike"], rtol=0, atol=0)   # demo priors add 0.0
+    got_p = np.array([O.lnprobfn(g["theta"][i], L) for i in idx[:8]])
+    np.testing.assert_allclose(got_p, g["lnprob"][idx[:8]], rtol=1e-12, atol=1e-9)
+
+
+def test_g4_lnlike_modpoly(golden):
+    g = golden("g4_lnlike_modpoly")
+    cfg = synth.CONFIGS["small"]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=64, seed=0)
+    L = O.OracleLikelihood(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"],
+                           SPEC_PARS + ["pc_0", "pc_1", "pc_2"], modpoly=True)
+    got = np.array([L.lnlikefn(t) for t in g["theta"]])
+    np.testing.assert_allclose(got, g["lnlike"], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,photscale", [("scaled", True), ("dist", False)])
+def test_g4_lnlike_joint(golden, tag, photscale):
+    g = golden("g4_lnlike_joint_" + tag)
+    cfg = synth.CONFIGS["small"]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=64, seed=0)
+    phot = synth.make_phot_nets()
+    phot["hiav"] = golden("g5_sed")["hiav"]
+    obs_phot = {f: (m, e) for f, m, e in zip(phot["filters"], g["obs_mag"], g["obs_magerr"])}
+    L = O.OracleLikelihood(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], [str(s) for s in g["fitpars_i"]],
+                           phot=phot, obs_phot=obs_phot, photscale=photscale)
+    got = np.array([L.lnlikefn(t) for t in g["theta"]])
+    assert (g["theta"][:, list(g["fitpars_i"]).index("Av")] >= 5.0).any()
+    np.testing.assert_allclose(got, g["lnlike"], rtol=1e-12, atol=1e-9)
+
+
+def test_g5_sed(golden):
+    g = golden("g5_sed")
+    phot = synth.make_phot_nets()
+    phot["hiav"] = g["hiav"]
+    for p, md, ms, bc in zip(g["pars"], g["mags_dist"], g["mags_scaled"], g["bc"]):
+        np.testing.assert_allclose(O.fastann_forward(phot, [10.0 ** p[0], p[1], p[2], p[3], p[4], p[5]]), bc, atol=1e-12)
+        np.testing.assert_allclose(O.sed_mags(phot, p[0], p[1], p[2], p[3], av=p[4], rv=p[5], logl=p[6], dist=p[7]), md, atol=1e-11)
+        np.testing.assert_allclose(O.sed_mags(phot, p[0], p[1], p[2], p[3], av=p[4], rv=p[5], logA=p[8]), ms, atol=1e-11)
+
+
+def test_g7_polycalc(golden):
+    g = golden("g7_misc")
+    for c, ref in zip(g["coefs"], g["poly"]):
+        np.testing.assert_allclose(O.polycalc(c, g["wave"]), ref, atol=1e-14)
