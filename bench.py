@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark: likelihood evaluations / second (BASELINE.json).
+
+Workload C2: one star, 4096-pixel 2x300 YST1 ANN, 3600 observed
+pixels, a batch of 512 candidate parameter vectors (the sampler's live points) per
+step.  A step = one pass of the hot path (ANN forward -> vsini/Doppler/instrument
+smoothing -> chi^2) over the batch, theta already resident in HBM.  With --gpus N
+every rank fits its own synthetic star (weak scaling, no data-path collective);
+posterior-style summaries are all-gathered over RCCL once after the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|small]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from thepayne_amd import synth  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA = vector peak (spec)
+PEAK_HBM_GBS = 8000.0
+
+
+def alg_flops_per_eval(D, H, N):
+    """2(DH + H^2 + HN) + 2 stages x 2 transforms x 2.5 N log2 N + 60 N."""
+    L = np.log2(N)
+    return 2.0 * (D * H + H * H + H * N) + 2 * 2 * 2.5 * N * L + 60.0 * N
+
+
+# ----------------------------------------------------------------------------
+# CPU baseline: the oracle in the reference's calling pattern (one theta per
+# lnprobfn call, fp64 numpy), one process per core.  Runs BEFORE the GPU is touched.
+# ----------------------------------------------------------------------------
+def _cpu_worker(args):
+    cfg_name, n_eval, seed = args
+    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cfg = synth.CONFIGS[cfg_name]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    obs = synth.obs_grid(net["wavelength"], cfg["nobs"])
+    T = synth.TRUTH
+    _, clean = O.getspec(net, Teff=T["Teff"], logg=T["logg"], feh=T["feh"], afe=T["afe"], rad_vel=T["vrad"],
+                         rot_vel=T["vrot"], vmic=np.nan, inst_R=2.355 * T["inst_R"], outwave=obs)
+    flux = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
+    L = O.OracleLikelihood(net, obs, flux, np.full(len(obs), 0.01),
+                           ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R'])
+    th = synth.draw_candidates(n_eval, seed=100 + seed)
+    O.lnprobfn(th[0], L)                      # warm
+    t0 = time.perf_counter()
+    for t in th:
+        O.lnprobfn(t, L)
+    return n_eval, time.perf_counter() - t0
+
+
+def cpu_baseline(cfg_name, target_s=12.0):
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    # size the sample from a short probe so the leg takes ~target_s
+    n0, dt0 = _cpu_worker((cfg_name, 8, 0))
+    per = dt0 / n0
+    n_eval = int(max(16, min(20000, target_s / per)))
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    ctx = mp.get_context("spawn")             # never fork a process that may hold a GPU
+    with ctx.Pool(cores) as pool:
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, [(cfg_name, n_eval, i) for i in range(cores)])
+        wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return dict(value=total / busy, unit="likelihood-evals/s", cores=cores, kind="port",
+                per_core=float(np.mean([r[0] / r[1] for r in res])),
+                sample="%d lnprobfn calls per process x %d processes of the numpy oracle (one theta per call, "
+                       "fp64, same %s workload); %.1f s wall" % (n_eval, cores, cfg_name, wall))
+
+
+# ----------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    cfg = dict(synth.CONFIGS[args.config])
+    B = args.batch or cfg["batch"]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.config)
+
+    import torch
+    import torch.distributed as dist
+    from thepayne_amd import nnio
+    from thepayne_amd.engine import PayneEngine
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- this rank's star (seed = rank): same ANN replicated, own noise + truth jitter
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    net = nnio.normalize_spec_net(raw)
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    eng0 = PayneEngine(net, obs=(obs,), b_max=1, device=local_rank)
+    T = synth.TRUTH
+    rng = np.random.default_rng(rank)
+    truth = np.full((1, eng0.ncols), np.nan)
+    truth[0, :8] = [T["Teff"] + 20.0 * rank, T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], np.nan, T["inst_R"]]
+    clean = eng0.predict_batch(truth, stage=2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+    flux = clean + rng.normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    eng0.close()
+    eng = PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank)
+    th7 = synth.draw_candidates(B, seed=1 + rank)
+    theta = eng.make_theta(B)
+    theta[:, 0:6] = torch.as_tensor(th7[:, 0:6], device=theta.device)
+    theta[:, 7] = torch.as_tensor(th7[:, 6], device=theta.device)
+    lnl = torch.empty(B, dtype=torch.float64, device=theta.device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.lnlike_batch(theta, out=lnl)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.lnlike_batch(theta, out=lnl)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=theta.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert torch.isfinite(lnl).all(), "non-finite lnL in the benchmark batch"
+
+    # ---- per-kernel device time (HIP events on the launch stream), same K steps replayed
+    kern = None
+    if not args.no_kernel_timing:
+        eng.profile(True)
+        for _ in range(args.steps):
+            eng.lnlike_batch(theta, out=lnl)
+        torch.cuda.synchronize()
+        kern = eng.profile_read()
+        eng.profile(False)
+
+    # ---- the one collective of the multi-star job: gather per-star summaries (RCCL)
+    summary = torch.stack([lnl.max(), lnl.mean(), lnl.std(), theta[lnl.argmax(), 0], theta[lnl.argmax(), 1]])
+    if world > 1:
+        gathered = [torch.empty_like(summary) for _ in range(world)]
+        dist.all_gather(gathered, summary)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    D, H, N = net["layers"][0][0].shape[1], net["layers"][0][0].shape[0], cfg["npix"]
+    evals = world * B * args.steps
+    out = {
+        "metric": "likelihood-evals/sec (4k-pixel ANN, 512 live points)",
+        "value": evals / dt, "unit": "likelihood-evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels, batch of %d "
+                               "candidate vectors per step (dynesty live points)" % (args.config, N, H, cfg["nobs"], B),
+                   "batch": B, "npix": N, "nobs": cfg["nobs"], "hidden": H, "stars": world,
+                   "parallelism": "1 star per GPU, no data-path collective"},
+    }
+    if kern is not None:
+        per = {k: (1e3 * v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}      # us per launch
+        # dominant kernel decides the roofline line
+        flops = {"dense_out": 2.0 * B * H * N, "post": B * (2 * 2 * 2.5 * N * np.log2(N) + 60.0 * N)}
+        dom = max(("dense_out", "post"), key=lambda k: per[k])
+        ach = flops[dom] / (per[dom] * 1e-6) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "payne_dense_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
+                           "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                           "traffic": None, "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
+        out["kernels_us"] = per
+        out["alg_flops_per_eval"] = alg_flops_per_eval(D, H, N)
+        out["whole_path_tflops"] = alg_flops_per_eval(D, H, N) * B / (sum(per.values()) * 1e-6) / 1e12
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

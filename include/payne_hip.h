@@ -1,0 +1,171 @@
+/* payne_hip.h -- C ABI of libpayne_hip.so: the MI355X (gfx950) implementation of
+ * ThePayne's nested-sampling likelihood hot path, evaluated in batch.
+ *
+ * Each entry point names the reference interface (pacargile/ThePayne, paths relative
+ * to the reference root) it stands in for.  The reference is pure Python with no FFI
+ * of its own; this is the boundary a maintainer binds with ctypes.
+ *
+ * Conventions
+ *  - plain C, no torch/HIP types in signatures (`stream` is a hipStream_t passed as
+ *    void*; NULL = the default stream);
+ *  - return 0 on success, a negative PAYNE_E_* code on failure; never throws;
+ *    payne_last_error() gives the message;
+ *  - pointers documented "device" are fp32/fp64 arrays in the memory of the context's
+ *    GPU, owned by the caller and alive for as long as the context uses them (weights,
+ *    theta, outputs); pointers documented "host" are read during the call only;
+ *  - batch calls enqueue work on `stream` and do not synchronise; the caller
+ *    synchronises the stream before reading an output buffer;
+ *  - a context is bound to one device and is not thread-safe (the reference's callers,
+ *    dynesty's sampling loop, are single-threaded: Payne/fitting/fitstar.py:309-338);
+ *  - NaN in -> NaN out at the same places as the reference.
+ */
+#ifndef PAYNE_HIP_H
+#define PAYNE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAYNE_ABI_VERSION 1
+
+#define PAYNE_OK 0
+#define PAYNE_E_INVALID (-1)     /* bad argument / descriptor */
+#define PAYNE_E_UNSUPPORTED (-2) /* valid in the reference, not (yet) by this library */
+#define PAYNE_E_HIP (-3)         /* HIP runtime error */
+#define PAYNE_E_BATCH (-4)       /* B exceeds opts.b_max */
+
+/* activation codes */
+#define PAYNE_ACT_NONE 0
+#define PAYNE_ACT_LRELU 1   /* z*(z>0) + 0.01*z*(z<0)  Payne/predict/ystpred.py:41-45 */
+#define PAYNE_ACT_SIGMOID 2 /* torch.sigmoid            Payne/train/NNmodels.py:155-160 */
+
+#define PAYNE_MAX_LAYERS 8
+#define PAYNE_MAX_LABELS 5
+#define PAYNE_MAX_POLY 12
+
+/* One dense layer y = act(W x + b); W is [n_out][n_in] row-major fp32 exactly as the
+ * reference stores it (w_array_k / model/linK.weight / model/features.K.weight). */
+typedef struct payne_layer {
+  const float* w; /* device [n_out*n_in] */
+  const float* b; /* device [n_out] */
+  int n_in, n_out;
+  int act; /* activation applied to this layer's OUTPUT */
+} payne_layer;
+
+/* The spectral emulator: replaces ystpred.Net (Payne/predict/ystpred.py:18-58) and
+ * predictspec.ANN + NNmodels.{LinNet,SMLP} (Payne/predict/predictspec.py:29-74,
+ * Payne/train/NNmodels.py:92-168).  YST1: 3 layers lrelu,lrelu,none; SMLP: 4 layers
+ * lrelu x3,none; LinNet: 6 layers sigmoid x5,none.  Input encoding for all of them:
+ * (x - xmin)/(xmax - xmin) - 0.5. */
+typedef struct payne_model_desc {
+  int n_layers; /* >= 2 */
+  payne_layer layers[PAYNE_MAX_LAYERS];
+  int n_labels;             /* 4: Teff,logg,[Fe/H],[a/Fe]; 5: + vmic */
+  const double* xmin;       /* host [n_labels] (Teff in K: apply ystpred.py:76-79 first) */
+  const double* xmax;       /* host [n_labels] */
+  int npix;                 /* == layers[n_layers-1].n_out */
+  const double* wavelength; /* host [npix], strictly increasing, Angstrom */
+  double resolution;        /* sigma-based R of the ANN (file key 'resolution') */
+} payne_model_desc;
+
+/* The observed spectrum: fitargs['obs_wave_fit','obs_flux_fit','obs_eflux_fit']
+ * (Payne/fitting/fitstar.py:71-98).  flux/eflux may be NULL (predict-only context). */
+typedef struct payne_obs_desc {
+  int nobs;
+  const double* wave;  /* host [nobs] */
+  const double* flux;  /* host [nobs] or NULL */
+  const double* eflux; /* host [nobs] or NULL */
+} payne_obs_desc;
+
+/* Photometric emulator: the stacked per-filter nets of photANN.fastANN
+ * (Payne/predict/photANN.py:95-131) + highAv table (Payne/predict/highred.py:4-25)
+ * + observed magnitudes fitargs['obs_phot'] (Payne/fitting/likelihood.py:109-112). */
+typedef struct payne_phot_desc {
+  int n_filters, hidden;
+  const float* w1; /* device [F][H][6] */
+  const float* b1; /* device [F][H]    */
+  const float* w2; /* device [F][H][H] */
+  const float* b2; /* device [F][H]    */
+  const float* w3; /* device [F][H]    */
+  const float* b3; /* device [F]       */
+  const double* xmin;    /* host [6] */
+  const double* xmax;    /* host [6] */
+  const double* hiav;    /* host [F][5] = a1,b1,a2,b2,c2 (NaN rows allowed) or NULL */
+  const double* obs_mag; /* host [F] or NULL */
+  const double* obs_err; /* host [F] or NULL */
+} payne_phot_desc;
+
+typedef struct payne_opts {
+  int b_max;     /* largest batch any call will pass (workspaces are sized for it) */
+  int npoly;     /* Chebyshev blaze coefficients pc_0.. in theta (0 = modpoly off) */
+  int photscale; /* 1: phot block carries log(A) (genphot_scaled); 0: log(R), Dist (genphot) */
+} payne_opts;
+
+typedef struct payne_ctx payne_ctx;
+
+int payne_version(void);
+
+/* Build a context on `device` (HIP ordinal).  model may be NULL for a photometry-only
+ * fit, obs NULL if no observed grid is bound yet, phot NULL without photometry.
+ * Replaces likelihood.__init__ -> GenMod._initspecnn/_initphotnn
+ * (Payne/fitting/likelihood.py:7-40, Payne/fitting/genmod.py:15-43). */
+int payne_ctx_create(const payne_model_desc* model, const payne_obs_desc* obs,
+                     const payne_phot_desc* phot, const payne_opts* opts, int device,
+                     payne_ctx** out);
+
+/* Re-bind the observed grid (the `outwave` of getspec / a new spectrum). */
+int payne_ctx_set_obs(payne_ctx* ctx, const payne_obs_desc* obs);
+
+void payne_ctx_destroy(payne_ctx* ctx);
+
+/* Message for the last failure on ctx (ctx == NULL: last create failure). */
+const char* payne_last_error(const payne_ctx* ctx);
+
+/* Number of fp64 columns of one theta row: 8 + npoly + 4.
+ *   0 Teff  1 log(g)  2 [Fe/H]  3 [a/Fe]  4 Vrad  5 Vrot  6 Vmic  7 Inst_R
+ *   8.. pc_0..pc_{npoly-1}
+ *   then  log(A) | log(R),  Dist,  Av,  Rv
+ * i.e. `specpars` followed by `photpars` of likelihood.lnlikefn
+ * (Payne/fitting/likelihood.py:50-72); NaN = "absent" exactly as there. */
+int payne_theta_cols(const payne_ctx* ctx);
+
+/* lnL for B parameter vectors: likelihood.lnlike over a batch
+ * (Payne/fitting/likelihood.py:84-117 -> genmod.py:58-108 -> ystpred.py:119-277).
+ * Inst_R is the sampled FWHM-based value; the 2.355 factor of genmod.py:82-85 is
+ * applied inside.  theta: device fp64 [B][payne_theta_cols]; lnl: device fp64 [B]. */
+int payne_lnlike_batch(payne_ctx* ctx, const double* theta, int B, double* lnl, void* stream);
+
+/* Model spectra for B parameter vectors.
+ *   stage 0: raw ANN output on the ANN grid          (predictspec, ystpred.py:84-99)
+ *   stage 1: after rotational broadening, ANN grid   (ystpred.py:211-224)
+ *   stage 2: getspec on the bound observed grid      (ystpred.py:226-277)
+ *   stage 3: genspec = stage 2 x Chebyshev blaze     (genmod.py:103-106)
+ * flags bit 0 (PAYNE_F_FWHM_R): theta[7] is FWHM-based (genspec semantics, x2.355);
+ * otherwise it is the sigma-based R handed to getspec.
+ * out: device fp32 [B][ld_out]; ld_out >= npix (stages 0,1) or nobs (stages 2,3). */
+#define PAYNE_F_FWHM_R 1u
+int payne_predict_batch(payne_ctx* ctx, const double* theta, int B, int stage, unsigned flags,
+                        float* out, int ld_out, void* stream);
+
+/* Magnitudes for B parameter vectors: FastPayneSEDPredict.sed
+ * (Payne/predict/predictsed.py:75-103).  pars: device fp64 [B][9] =
+ * logt, logg, feh, afe, av, rv, logl, dist, logA  (NaN = kwarg absent; the
+ * (logl, dist) form wins over logA as in the reference).  mags: device fp64 [B][F]. */
+int payne_sed_batch(payne_ctx* ctx, const double* pars, int B, double* mags, void* stream);
+
+/* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
+const char* payne_kernel_name(int which);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around every kernel
+ * the batch calls enqueue (measurement aid for bench.py; no reference counterpart).
+ * payne_profile(ctx, 1) clears the totals and starts recording, (ctx, 0) stops.
+ * payne_profile_read waits for the recorded events and returns the accumulated
+ * device time and launch count of one kind:
+ *   0 output dense layer | 1 post kernel | 2 sed kernel | 3 hidden dense layers. */
+int payne_profile(payne_ctx* ctx, int enable);
+int payne_profile_read(payne_ctx* ctx, int kind, double* total_ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAYNE_HIP_H */

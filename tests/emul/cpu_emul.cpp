@@ -1,0 +1,55 @@
+// cpu_emul.cpp -- host execution of the SAME phase code the gfx950 post_kernel runs
+// (thepayne_amd/csrc/post_core.hpp + post_seq.hpp), with the workgroup's threads
+// stepped serially between barriers.  Test infrastructure: lets the CPU suite (and
+// -fsanitize builds) check the pipeline against the oracle without a GPU.  It is not
+// part of the product and nothing in thepayne_amd/ loads it.
+#include <cstring>
+#include <vector>
+
+#include "../../thepayne_amd/csrc/host_tables.hpp"
+#include "../../thepayne_amd/csrc/post_seq.hpp"
+
+using namespace payne;
+
+struct HostExec {
+  int nthr;
+  template <class F> void par(F&& f) { for (int t = 0; t < nthr; ++t) f(t, nthr); }
+  void imin(int* p, int v) { if (v < *p) *p = v; }
+  void imax(int* p, int v) { if (v > *p) *p = v; }
+};
+
+extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const double* obs_wave,
+                               const double* obs_flux, const double* obs_eflux, int nobs, int npoly,
+                               const double* theta, int ncols, int B, double instr_factor,
+                               const float* raw_m1, int out_stage, float* out, int ld_out,
+                               double* chi2, int* info, int nthreads) {
+  HostTables H;
+  int rc = build_model_tables(wave, npix, H);
+  if (rc) return rc;
+  build_obs_tables(obs_wave, obs_flux, obs_eflux, nobs, H);
+  PostTables T;
+  std::memset(&T, 0, sizeof(T));
+  T.npix = npix; T.nobs = nobs; T.n1 = H.n1; T.nmax = H.nmax;
+  T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data();
+  T.rs1_idx = H.rs1_idx.data(); T.rs1_frac = H.rs1_frac.data();
+  T.bk1_idx = H.bk1_idx.data(); T.bk1_frac = H.bk1_frac.data();
+  T.vs_val = H.vs_val;
+  T.lnobs = H.lnobs.data(); T.xcheb = H.xcheb.data();
+  T.obs_f1 = H.has_flux ? H.obs_f1.data() : nullptr;
+  T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
+  T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
+  T.geo_inv_dln = H.geo_inv_dln; T.npoly = npoly;
+  HostExec ex{nthreads};
+  std::vector<float> a(H.n1), b(H.n1);
+  std::vector<double> red(nthreads + 16);
+  for (int c = 0; c < B; ++c) {
+    CandState S;
+    std::memset(&S, 0, sizeof(S));
+    double x2 = 0.0;
+    run_candidate(ex, T, theta + (size_t)c * ncols, instr_factor, raw_m1 + (size_t)c * npix, a.data(), b.data(), S,
+                  red.data(), out ? out + (size_t)c * ld_out : nullptr, out_stage, &x2);
+    if (chi2) chi2[c] = x2;
+    if (info) { info[3 * c] = S.i0; info[3 * c + 1] = S.i1 - S.i0; info[3 * c + 2] = S.n2; }
+  }
+  return 0;
+}

@@ -1,0 +1,103 @@
+"""ctypes binding of libpayne_hip.so (include/payne_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or does
+not export the ABI, importing the engine raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpayne_hip.so")
+
+PAYNE_MAX_LAYERS = 8
+ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
+F_FWHM_R = 1
+ABI_VERSION = 1
+
+SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_destroy", "payne_last_error",
+           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_kernel_name",
+           "payne_profile", "payne_profile_read"]
+
+_dp = C.POINTER(C.c_double)
+
+
+class Layer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("n_in", C.c_int), ("n_out", C.c_int), ("act", C.c_int)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("layers", Layer * PAYNE_MAX_LAYERS), ("n_labels", C.c_int),
+                ("xmin", _dp), ("xmax", _dp), ("npix", C.c_int), ("wavelength", _dp), ("resolution", C.c_double)]
+
+
+class ObsDesc(C.Structure):
+    _fields_ = [("nobs", C.c_int), ("wave", _dp), ("flux", _dp), ("eflux", _dp)]
+
+
+class PhotDesc(C.Structure):
+    _fields_ = [("n_filters", C.c_int), ("hidden", C.c_int),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p),
+                ("xmin", _dp), ("xmax", _dp), ("hiav", _dp), ("obs_mag", _dp), ("obs_err", _dp)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("b_max", C.c_int), ("npoly", C.c_int), ("photscale", C.c_int)]
+
+
+class PayneLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and type the library.  torch is imported first so that this
+    process holds a single HIP runtime (libamdhip64.so.7) shared with the
+    tensors whose pointers we pass."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must precede the dlopen; see docstring)
+    path = path or os.environ.get("PAYNE_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise PayneLibraryError(
+            "%s not found: build it with `python -m thepayne_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % path)
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise PayneLibraryError("cannot load %s: %s" % (path, e))
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise PayneLibraryError("%s lacks symbols %s" % (path, missing))
+    ctxp = C.c_void_p
+    lib.payne_version.restype = C.c_int
+    lib.payne_ctx_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(ObsDesc), C.POINTER(PhotDesc),
+                                     C.POINTER(Opts), C.c_int, C.POINTER(ctxp)]
+    lib.payne_ctx_create.restype = C.c_int
+    lib.payne_ctx_set_obs.argtypes = [ctxp, C.POINTER(ObsDesc)]
+    lib.payne_ctx_set_obs.restype = C.c_int
+    lib.payne_ctx_destroy.argtypes = [ctxp]
+    lib.payne_ctx_destroy.restype = None
+    lib.payne_last_error.argtypes = [ctxp]
+    lib.payne_last_error.restype = C.c_char_p
+    lib.payne_theta_cols.argtypes = [ctxp]
+    lib.payne_theta_cols.restype = C.c_int
+    lib.payne_lnlike_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.payne_lnlike_batch.restype = C.c_int
+    lib.payne_predict_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int, C.c_void_p]
+    lib.payne_predict_batch.restype = C.c_int
+    lib.payne_sed_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.payne_sed_batch.restype = C.c_int
+    lib.payne_profile.argtypes = [ctxp, C.c_int]
+    lib.payne_profile.restype = C.c_int
+    lib.payne_profile_read.argtypes = [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    lib.payne_profile_read.restype = C.c_int
+    lib.payne_kernel_name.argtypes = [C.c_int]
+    lib.payne_kernel_name.restype = C.c_char_p
+    if lib.payne_version() != ABI_VERSION:
+        raise PayneLibraryError("ABI version %d != %d" % (lib.payne_version(), ABI_VERSION))
+    _lib = lib
+    return lib

@@ -1,0 +1,105 @@
+// host_tables.hpp -- theta-independent tables of the spectrum pipeline, built once
+// per context on the host in fp64 (plain C++; shared by the HIP library and the CPU
+// emulation).  They restate, for the static grids, what the reference recomputes on
+// every call: resample_wave's pow-2 log grid and the two np.interp index/weight maps of
+// the vsini stage (Payne/utils/smoothing.py:649-668, :300-312), ln(lambda) of the ANN
+// and observed grids, polycalc's abscissa (Payne/fitting/fitutils.py:11-15) and the
+// FFT twiddles.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "post_core.hpp"
+
+namespace payne {
+
+struct HostTables {
+  int npix = 0, nobs = 0, n1 = 0, nmax = 0;
+  std::vector<double> lnlam, lam, lnobs, xcheb;
+  std::vector<c32> tw;
+  std::vector<int> rs1_idx, bk1_idx;
+  std::vector<float> rs1_frac, bk1_frac, obs_f1, obs_ivar;
+  double vs_val = 0, obs_min = 0, obs_max = 0, geo_inv_dln = 0;
+  bool has_flux = false;
+};
+
+// numpy.linspace(start, stop, n)
+inline void linspace(double start, double stop, int n, std::vector<double>& y) {
+  y.resize(n);
+  const double step = (stop - start) / (double)(n - 1);
+  for (int j = 0; j < n; ++j) y[j] = (double)j * step + start;
+  y[n - 1] = stop;
+}
+
+// index/weight of np.interp(x, xp, .) for one x; nan_outside mirrors left=right=NaN
+inline void interp_map(double x, const std::vector<double>& xp, bool nan_outside, int& idx, float& frac) {
+  const int n = (int)xp.size();
+  if (nan_outside && (x < xp[0] || x > xp[n - 1])) { idx = -1; frac = 0.f; return; }
+  if (x <= xp[0]) { idx = 0; frac = 0.f; return; }
+  if (x >= xp[n - 1]) { idx = n - 2; frac = 1.f; return; }
+  int k = (int)(std::upper_bound(xp.begin(), xp.end(), x) - xp.begin()) - 1;   // xp[k] <= x < xp[k+1]
+  idx = k;
+  frac = (float)((x - xp[k]) / (xp[k + 1] - xp[k]));
+}
+
+// returns 0 on success, <0 if the wavelength grid is unusable
+inline int build_model_tables(const double* wave, int npix, HostTables& H) {
+  if (npix < 16) return -1;
+  for (int i = 1; i < npix; ++i)
+    if (!(wave[i] > wave[i - 1])) return -2;             // must be strictly increasing
+  H.npix = npix;
+  H.n1 = pow2ceil(npix);
+  H.nmax = H.n1;
+  H.lam.assign(wave, wave + npix);
+  H.lnlam.resize(npix);
+  for (int i = 0; i < npix; ++i) H.lnlam[i] = std::log(wave[i]);
+  H.geo_inv_dln = (double)(npix - 1) / (H.lnlam[npix - 1] - H.lnlam[0]);
+  // vsini grid: w = exp(linspace(ln wmin, ln wmax, n1))
+  std::vector<double> lnw, w(H.n1);
+  linspace(std::log(wave[0]), std::log(wave[npix - 1]), H.n1, lnw);
+  for (int j = 0; j < H.n1; ++j) w[j] = std::exp(lnw[j]);
+  H.rs1_idx.resize(H.n1); H.rs1_frac.resize(H.n1);
+  for (int j = 0; j < H.n1; ++j) interp_map(w[j], H.lam, false, H.rs1_idx[j], H.rs1_frac[j]);
+  H.bk1_idx.resize(npix); H.bk1_frac.resize(npix);
+  for (int i = 0; i < npix; ++i) interp_map(wave[i], w, true, H.bk1_idx[i], H.bk1_frac[i]);
+  // dv = ckms * median(diff(log(w)))   (smoothing.py:306-307)
+  std::vector<double> d(H.n1 - 1);
+  for (int j = 0; j + 1 < H.n1; ++j) d[j] = std::log(w[j + 1]) - std::log(w[j]);
+  std::sort(d.begin(), d.end());
+  const int m = (int)d.size();
+  const double med = (m & 1) ? d[m / 2] : 0.5 * (d[m / 2 - 1] + d[m / 2]);
+  H.vs_val = 1.0 / ((double)H.n1 * (kCkms * med));
+  H.tw.resize(H.nmax);
+  for (int j = 0; j < H.nmax; ++j) {
+    const double a = 2.0 * kPi * (double)j / (double)H.nmax;
+    H.tw[j] = {(float)std::cos(a), (float)(-std::sin(a))};
+  }
+  return 0;
+}
+
+inline int build_obs_tables(const double* wave, const double* flux, const double* eflux, int nobs, HostTables& H) {
+  H.nobs = nobs;
+  H.lnobs.resize(nobs); H.xcheb.resize(nobs);
+  if (nobs <= 0) return 0;
+  double mn = wave[0], mx = wave[0];
+  for (int i = 0; i < nobs; ++i) { mn = std::min(mn, wave[i]); mx = std::max(mx, wave[i]); }
+  H.obs_min = mn; H.obs_max = mx;
+  double xmax = 0.0;
+  for (int i = 0; i < nobs; ++i) xmax = std::max(xmax, wave[i] - mn);
+  for (int i = 0; i < nobs; ++i) {
+    H.lnobs[i] = std::log(wave[i]);
+    H.xcheb[i] = 2.0 * ((wave[i] - mn) / xmax) - 1.0;   // fitutils.py:13-14
+  }
+  H.has_flux = (flux != nullptr) && (eflux != nullptr);
+  if (H.has_flux) {
+    H.obs_f1.resize(nobs); H.obs_ivar.resize(nobs);
+    for (int i = 0; i < nobs; ++i) {
+      H.obs_f1[i] = (float)(flux[i] - 1.0);
+      H.obs_ivar[i] = (float)(1.0 / (eflux[i] * eflux[i]));
+    }
+  }
+  return 0;
+}
+
+}  // namespace payne

@@ -1,0 +1,716 @@
+// payne_hip.hip -- gfx950 kernels + the C ABI of include/payne_hip.h.
+//
+// Kernels (all hand-written for CDNA4, wave64):
+//   payne_dense_kernel  fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain) dense layer
+//                       Y = act(X W^T + b) over the batch of candidates; LDS-tiled 64xBNx32,
+//                       register-prefetch double buffering, XCD-aware tile order.  With FUSE_L0
+//                       the A operand is produced on the fly from theta: label encoding
+//                       (ystpred.py:47-50) + first layer + activation, so a YST1 forward pass
+//                       (ystpred.py:52-58) is two launches.
+//   payne_post_kernel   one 256-thread workgroup per candidate; the spectrum lives in LDS from
+//                       the ANN output to chi^2: vsini FFT stage, Doppler, masked pow-2
+//                       resample, Gaussian FFT stage, interpolation to the observed grid,
+//                       blaze, chi^2 (phases in post_core.hpp, order in post_seq.hpp).
+//   payne_sed_kernel    one wave per (candidate, filter): the stacked photometric nets of
+//                       photANN.fastANN + highAv + the magnitude formulae of predictsed.py.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/payne_hip.h"
+#include "host_tables.hpp"
+#include "post_seq.hpp"
+
+using namespace payne;
+
+// ============================================================================
+// dense layer on the matrix cores
+// ============================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DenseParams {
+  const float* X; int ldx;     // [B][ldx] activations (ignored with FUSE_L0)
+  const float* W; int K;       // [N][K] row-major, K % 4 == 0
+  const float* bias;           // [N]
+  float* Y; int ldy;           // [B][ldy]
+  int B, N;
+  float bias_shift;            // subtracted from the bias (kBase on the output layer)
+  int act;
+  int grid_m, grid_n;
+  // fused first layer (FUSE_L0): A[r][k] = act0(b0[k] + sum_d W0[k][d] * xhat[r][d])
+  const double* theta; int ld_theta;
+  const float* W0; const float* b0; int n_labels; int act0;
+  int K0;                      // real width of the first layer (W0 has K0 rows)
+  double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
+};
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  if (act == PAYNE_ACT_LRELU) return z > 0.f ? z : (z < 0.f ? 0.01f * z : z * 0.f);  // NaN stays NaN, 0 -> 0
+  if (act == PAYNE_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));
+  return z;
+}
+
+template <int BM, int BN, bool FUSE_L0>
+__global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
+  constexpr int BK = 32, PITCH = BK + 4;            // +4 floats: conflict-free ds_read_b128 fragments
+  constexpr int WM = BM / 2, WN = BN / 2;           // 2x2 waves
+  constexpr int TM = WM / 32, TN = WN / 32;         // 32x32 MFMA tiles per wave
+  constexpr int A_F4 = BM * (BK / 4) / 256, B_F4 = BN * (BK / 4) / 256;
+  __shared__ __attribute__((aligned(16))) float As[2][BM * PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * PITCH];
+  __shared__ float Xh[FUSE_L0 ? BM * PAYNE_MAX_LABELS : 4];
+
+  // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+  // XCD a contiguous run of tiles (m fastest): its L2 then holds 1/8 of W and all of X.
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+  const int m0 = (t % p.grid_m) * BM, n0 = (t / p.grid_m) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+  if (FUSE_L0) {
+    for (int idx = tid; idx < BM * p.n_labels; idx += 256) {
+      const int r = idx / p.n_labels, d = idx - r * p.n_labels, row = m0 + r;
+      float v = 0.f;
+      if (row < p.B) {
+        const double x = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)];   // label 4 = Vmic (col 6)
+        v = (float)((x - p.xmin[d]) / p.xden[d] - 0.5);
+      }
+      Xh[r * PAYNE_MAX_LABELS + d] = v;
+    }
+    __syncthreads();
+  }
+
+  float4 ra[A_F4], rb[B_F4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + i * 256, r = idx >> 3, k = k0 + (idx & 7) * 4, row = m0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FUSE_L0) {
+        if (k < p.K0) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = 0.f;
+            if (k + j < p.K0) {
+              float z = p.b0[k + j];
+              for (int d = 0; d < p.n_labels; ++d) z = fmaf(p.W0[(k + j) * p.n_labels + d], Xh[r * PAYNE_MAX_LABELS + d], z);
+              o[j] = act_apply(z, p.act0);
+            }
+          }
+          v = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      } else if (row < p.B && k < p.K) {
+        v = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + k);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + i * 256, r = idx >> 3, k = k0 + (idx & 7) * 4, col = n0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col < p.N && k < p.K) v = *reinterpret_cast<const float4*>(p.W + (size_t)col * p.K + k);
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<float4*>(&As[buf][(idx >> 3) * PITCH + (idx & 7) * 4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<float4*>(&Bs[buf][(idx >> 3) * PITCH + (idx & 7) * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) load_tiles((it + 1) * BK);
+    // A lane (row = lane&31, half = lane>>5) reads 4 consecutive k; MFMA step s then
+    // contracts k = {8kk + s, 8kk + 4 + s} -- the same k set on both operands.
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const float4*>(&As[buf][(wm0 + i * 32 + (lane & 31)) * PITCH + kk * 8 + 4 * (lane >> 5)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const float4*>(&Bs[buf][(wn0 + j * 32 + (lane & 31)) * PITCH + kk * 8 + 4 * (lane >> 5)]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (it + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + j * 32 + (lane & 31);
+    if (col >= p.N) continue;
+    const float bv = p.bias[col] - p.bias_shift;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[i][j][r] + bv, p.act);
+      }
+  }
+}
+
+// ============================================================================
+// per-candidate spectrum pipeline
+// ============================================================================
+struct PostArgs {
+  const double* theta; int ld_theta;
+  double instr_factor;
+  const float* raw; int ld_raw;
+  float* out; int ld_out; int out_stage;
+  double* lnl;                       // [B] or null
+  const double* mags; int n_filters; // SED magnitudes of this batch (null: no photometry)
+  const double* obs_mag; const double* obs_err;
+};
+
+struct DevExec {
+  template <class F>
+  __device__ __forceinline__ void par(F&& f) {
+    f((int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
+  }
+  __device__ __forceinline__ void imin(int* p, int v) { atomicMin(p, v); }
+  __device__ __forceinline__ void imax(int* p, int v) { atomicMax(p, v); }
+};
+
+__device__ __forceinline__ double sed_chi2(const double* mags, const double* obs, const double* err, int F) {
+  double s = 0.0;   // likelihood.py:109-112
+  for (int f = 0; f < F; ++f) { const double d = mags[f] - obs[f]; s += (d * d) / (err[f] * err[f]); }
+  return s;
+}
+
+__global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* bufA = reinterpret_cast<float*>(smem);
+  float* bufB = bufA + T.n1;
+  double* red = reinterpret_cast<double*>(bufB + T.n1);        // [256 + 16 + 1]
+  CandState* S = reinterpret_cast<CandState*>(red + 256 + 16 + 1);
+  const int b = blockIdx.x;
+  DevExec ex;
+  run_candidate(ex, T, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw, bufA, bufB,
+                *S, red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, &red[256 + 16]);
+  if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
+    double x2 = red[256 + 16];
+    if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+    a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
+  }
+}
+
+// photometry-only fits: lnL = -0.5 chi2_sed
+__global__ void payne_photonly_kernel(const double* mags, const double* obs, const double* err, int F, int B, double* lnl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) lnl[b] = -0.5 * sed_chi2(mags + (size_t)b * F, obs, err, F);
+}
+
+// ============================================================================
+// photometric SED
+// ============================================================================
+struct PhotTables {
+  int F, H;
+  const float *w1, *b1, *w2t, *b2, *w3, *b3;   // w2t: [F][k][h] (transposed for coalesced lanes)
+  double xmin[6], xden[6];
+  const double* hiav;                           // device [F][5] or null
+};
+
+// mode 0: in = [logt,logg,feh,afe,av,rv,logl,dist,logA] (sed kwargs, NaN = absent)
+// mode 1: in = theta row; phot block at column `off` = [logA | logR, Dist, Av, Rv]
+__global__ void __launch_bounds__(64) payne_sed_kernel(PhotTables P, const double* in, int ld, int mode, int off,
+                                                       int photscale, double* mags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* a1 = reinterpret_cast<double*>(smem);
+  double* a2 = a1 + P.H;
+  const int f = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const double* r = in + (size_t)b * ld;
+  const double nan = __builtin_nan("");
+  double logt, logg, feh, afe, av, rv, logl = nan, dist = nan, logA = nan;
+  if (mode == 0) {
+    logt = r[0]; logg = r[1]; feh = r[2]; afe = r[3]; av = r[4]; rv = r[5]; logl = r[6]; dist = r[7]; logA = r[8];
+  } else {
+    logt = log10(r[0]); logg = r[1]; feh = r[2]; afe = r[3];      // genmod.py:124,172
+    av = r[off + 2]; rv = 3.1;                                    // Rv never honoured: likelihood.py:104-106
+    if (photscale) logA = r[off];                                 // genphot_scaled, genmod.py:157-187
+    else { logl = 2.0 * r[off] + 4.0 * (logt - log10(5770.0)); dist = r[off + 1]; }   // genphot, genmod.py:126
+  }
+  double x[6] = {pow(10.0, logt), logg, feh, afe, av, rv};        // predictsed.py:84
+  const bool hi = !(av < 5.0);                                    // predictsed.py:86-90
+  if (hi) { x[4] = 0.0; x[5] = 3.1; }
+  double xs[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) xs[d] = (x[d] - P.xmin[d]) / P.xden[d];   // photANN.py:118-120 (no -0.5)
+  const int H = P.H;
+  for (int h = lane; h < H; h += 64) {
+    double z = (double)P.b1[f * H + h];
+    const float* w = P.w1 + (size_t)(f * H + h) * 6;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) z += (double)w[d] * xs[d];
+    a1[h] = 1.0 / (1.0 + exp(-z));
+  }
+  __syncthreads();
+  for (int h = lane; h < H; h += 64) {
+    double z = (double)P.b2[f * H + h];
+    const float* w = P.w2t + (size_t)f * H * H + h;
+    for (int k = 0; k < H; ++k) z += (double)w[(size_t)k * H] * a1[k];
+    a2[h] = 1.0 / (1.0 + exp(-z));
+  }
+  __syncthreads();
+  double part = 0.0;
+  for (int h = lane; h < H; h += 64) part += (double)P.w3[f * H + h] * a2[h];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+  if (lane == 0) {
+    double BC = part + (double)P.b3[f];
+    if (hi) {                                                     // highred.py:19-25
+      const double* c = P.hiav ? P.hiav + 5 * f : nullptr;
+      const double offv = c ? (c[0] + c[1] * av * (c[2] + c[3] * rv + c[4] * (rv * rv))) : nan;
+      BC = BC - offv;
+    }
+    double m;
+    if (!(logl != logl) && !(dist != dist)) m = -2.5 * logl + 4.74 - BC + (5.0 * log10(dist) - 5.0);
+    else if (!(logA != logA)) m = 5.0 * logA - 10.0 * (logt - log10(5770.0)) - 0.26 - BC;
+    else m = nan;
+    mags[(size_t)b * P.F + f] = m;
+  }
+}
+
+// ============================================================================
+// context
+// ============================================================================
+static std::string g_create_error;
+
+struct payne_ctx {
+  int device = 0;
+  payne_opts opts{};
+  std::string err;
+  std::vector<void*> owned;       // freed at destroy
+  std::vector<void*> obs_owned;   // freed when the observed grid is re-bound
+  // spectral model
+  bool has_model = false;
+  int n_layers = 0;
+  payne_layer layers[PAYNE_MAX_LAYERS];
+  int n_labels = 0;
+  double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
+  HostTables H;
+  PostTables T{};
+  float* hid[2] = {nullptr, nullptr};
+  int ld_hid = 0;
+  float* raw = nullptr;
+  size_t post_lds = 0;
+  bool obs_bound = false;
+  // photometry
+  bool has_phot = false, has_obs_phot = false;
+  PhotTables P{};
+  double* mags_ws = nullptr;
+  double *obs_mag = nullptr, *obs_err = nullptr;
+  int ncols = 0;
+  // optional per-kernel HIP-event timing (payne_profile): kinds 0 output dense layer,
+  // 1 post, 2 sed, 3 hidden dense layers
+  bool prof = false;
+  struct ProfRec { hipEvent_t e0, e1; int kind; };
+  std::vector<ProfRec> prof_pool;
+  size_t prof_used = 0;
+  double prof_ms[4] = {0, 0, 0, 0};
+  long long prof_n[4] = {0, 0, 0, 0};
+};
+
+// RAII bracket: records an event pair around one launch on the launch stream.
+struct ProfScope {
+  payne_ctx* c; hipStream_t s; payne_ctx::ProfRec* r = nullptr;
+  ProfScope(payne_ctx* c_, hipStream_t s_, int kind) : c(c_), s(s_) {
+    if (!c->prof) return;
+    if (c->prof_used == c->prof_pool.size()) {
+      payne_ctx::ProfRec n{};
+      if (hipEventCreate(&n.e0) != hipSuccess || hipEventCreate(&n.e1) != hipSuccess) return;
+      c->prof_pool.push_back(n);
+    }
+    r = &c->prof_pool[c->prof_used++];
+    r->kind = kind;
+    (void)hipEventRecord(r->e0, s);
+  }
+  ~ProfScope() { if (r) (void)hipEventRecord(r->e1, s); }
+};
+
+#define HIPCHK(ctx, call)                                                                 \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+      return PAYNE_E_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+
+template <class V>
+static int upload(payne_ctx* c, const std::vector<V>& v, const V** out, std::vector<void*>& bag) {
+  void* d = nullptr;
+  size_t bytes = v.size() * sizeof(V);
+  if (bytes == 0) { *out = nullptr; return PAYNE_OK; }
+  HIPCHK(c, hipMalloc(&d, bytes));
+  bag.push_back(d);
+  HIPCHK(c, hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+  *out = reinterpret_cast<const V*>(d);
+  return PAYNE_OK;
+}
+template <class V>
+static int dev_alloc(payne_ctx* c, size_t n, V** out, std::vector<void*>& bag, bool zero = true) {
+  void* d = nullptr;
+  HIPCHK(c, hipMalloc(&d, n * sizeof(V)));
+  bag.push_back(d);
+  if (zero) HIPCHK(c, hipMemset(d, 0, n * sizeof(V)));
+  *out = reinterpret_cast<V*>(d);
+  return PAYNE_OK;
+}
+
+static int fail(payne_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
+  for (void* p : c->obs_owned) (void)hipFree(p);
+  c->obs_owned.clear();
+  c->obs_bound = false;
+  c->T.nobs = 0; c->T.lnobs = nullptr; c->T.xcheb = nullptr; c->T.obs_f1 = nullptr; c->T.obs_ivar = nullptr;
+  if (!obs || obs->nobs <= 0) return PAYNE_OK;
+  if (!obs->wave) return fail(c, PAYNE_E_INVALID, "obs.wave is NULL");
+  if ((obs->flux == nullptr) != (obs->eflux == nullptr)) return fail(c, PAYNE_E_INVALID, "obs.flux and obs.eflux must both be given or both NULL");
+  build_obs_tables(obs->wave, obs->flux, obs->eflux, obs->nobs, c->H);
+  int rc;
+  if ((rc = upload(c, c->H.lnobs, &c->T.lnobs, c->obs_owned))) return rc;
+  if ((rc = upload(c, c->H.xcheb, &c->T.xcheb, c->obs_owned))) return rc;
+  if (c->H.has_flux) {
+    if ((rc = upload(c, c->H.obs_f1, &c->T.obs_f1, c->obs_owned))) return rc;
+    if ((rc = upload(c, c->H.obs_ivar, &c->T.obs_ivar, c->obs_owned))) return rc;
+  }
+  c->T.nobs = obs->nobs;
+  c->T.obs_min = c->H.obs_min;
+  c->T.obs_max = c->H.obs_max;
+  c->obs_bound = true;
+  return PAYNE_OK;
+}
+
+extern "C" int payne_version(void) { return PAYNE_ABI_VERSION; }
+
+extern "C" const char* payne_last_error(const payne_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int payne_theta_cols(const payne_ctx* ctx) { return ctx ? ctx->ncols : PAYNE_E_INVALID; }
+
+extern "C" const char* payne_kernel_name(int which) {
+  switch (which) {
+    case 0: return "payne_dense_kernel";
+    case 1: return "payne_post_kernel";
+    case 2: return "payne_sed_kernel";
+    default: return "";
+  }
+}
+
+extern "C" void payne_ctx_destroy(payne_ctx* c) {
+  if (!c) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(c->device);
+  for (void* p : c->owned) (void)hipFree(p);
+  for (void* p : c->obs_owned) (void)hipFree(p);
+  for (auto& r : c->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  (void)hipSetDevice(prev);
+  delete c;
+}
+
+extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_desc* obs, const payne_phot_desc* phot,
+                                const payne_opts* opts, int device, payne_ctx** out) {
+  if (!out) return fail(nullptr, PAYNE_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!opts || opts->b_max <= 0) return fail(nullptr, PAYNE_E_INVALID, "opts.b_max must be > 0");
+  if (opts->npoly < 0 || opts->npoly > PAYNE_MAX_POLY) return fail(nullptr, PAYNE_E_INVALID, "opts.npoly out of range");
+  if (!model && !phot) return fail(nullptr, PAYNE_E_INVALID, "need a spectral model and/or a photometric model");
+  hipError_t he = hipSetDevice(device);
+  if (he != hipSuccess) return fail(nullptr, PAYNE_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
+  payne_ctx* c = new payne_ctx();
+  c->device = device;
+  c->opts = *opts;
+  c->ncols = 8 + opts->npoly + 4;
+  int rc = PAYNE_OK;
+  auto bail = [&](int code) { g_create_error = c->err; payne_ctx_destroy(c); return code; };
+
+  if (model) {
+    if (model->n_layers < 2 || model->n_layers > PAYNE_MAX_LAYERS) return bail(fail(c, PAYNE_E_INVALID, "model.n_layers must be 2..8"));
+    if (model->n_labels < 1 || model->n_labels > PAYNE_MAX_LABELS) return bail(fail(c, PAYNE_E_INVALID, "model.n_labels must be 1..5"));
+    if (!model->xmin || !model->xmax || !model->wavelength) return bail(fail(c, PAYNE_E_INVALID, "model.xmin/xmax/wavelength missing"));
+    if (model->layers[0].n_in != model->n_labels) return bail(fail(c, PAYNE_E_INVALID, "first layer n_in != n_labels"));
+    if (model->layers[model->n_layers - 1].n_out != model->npix) return bail(fail(c, PAYNE_E_INVALID, "last layer n_out != npix"));
+    int maxh = 0;
+    for (int l = 0; l < model->n_layers; ++l) {
+      const payne_layer& L = model->layers[l];
+      if (!L.w || !L.b || L.n_in <= 0 || L.n_out <= 0) return bail(fail(c, PAYNE_E_INVALID, "layer with null weights or bad shape"));
+      if (l > 0 && L.n_in != model->layers[l - 1].n_out) return bail(fail(c, PAYNE_E_INVALID, "layer shapes do not chain"));
+      c->layers[l] = L;
+      if (l > 0 && (L.n_in & 3)) {   // float4 tile loads need K % 4 == 0: keep a zero-padded copy
+        const int Kp = (L.n_in + 3) & ~3;
+        float* wp = nullptr;
+        if ((rc = dev_alloc(c, (size_t)L.n_out * Kp, &wp, c->owned))) return bail(rc);
+        he = hipMemcpy2D(wp, (size_t)Kp * 4, L.w, (size_t)L.n_in * 4, (size_t)L.n_in * 4, L.n_out, hipMemcpyDeviceToDevice);
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(he)));
+        c->layers[l].w = wp;
+        c->layers[l].n_in = Kp;     // padded K (extra columns are zero)
+      }
+      if (l + 1 < model->n_layers) maxh = std::max(maxh, L.n_out);
+    }
+    c->n_layers = model->n_layers;
+    c->n_labels = model->n_labels;
+    for (int d = 0; d < model->n_labels; ++d) { c->xmin[d] = model->xmin[d]; c->xden[d] = model->xmax[d] - model->xmin[d]; }
+    rc = build_model_tables(model->wavelength, model->npix, c->H);
+    if (rc == -1) return bail(fail(c, PAYNE_E_INVALID, "model.npix must be >= 16"));
+    if (rc == -2) return bail(fail(c, PAYNE_E_INVALID, "model.wavelength must be strictly increasing"));
+    if (c->H.n1 > 16384) return bail(fail(c, PAYNE_E_UNSUPPORTED, "npix > 16384: spectrum does not fit the LDS-resident pipeline"));
+    PostTables& T = c->T;
+    T.npix = c->H.npix; T.n1 = c->H.n1; T.nmax = c->H.nmax; T.vs_val = c->H.vs_val;
+    T.r_ann = model->resolution; T.geo_inv_dln = c->H.geo_inv_dln; T.npoly = opts->npoly;
+    if ((rc = upload(c, c->H.lnlam, &T.lnlam, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.lam, &T.lam, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.tw, &T.tw, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.rs1_idx, &T.rs1_idx, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.rs1_frac, &T.rs1_frac, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.bk1_idx, &T.bk1_idx, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.bk1_frac, &T.bk1_frac, c->owned))) return bail(rc);
+    c->ld_hid = (maxh + 31) & ~31;
+    if (model->n_layers > 2) {
+      if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[0], c->owned))) return bail(rc);
+      if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
+    }
+    if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
+    c->post_lds = (size_t)T.n1 * 8 + (256 + 16 + 1) * 8 + sizeof(CandState) + 16;
+    he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
+    if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
+    c->has_model = true;
+    if ((rc = bind_obs(c, obs))) return bail(rc);
+  }
+
+  if (phot) {
+    if (phot->n_filters <= 0 || phot->hidden <= 0 || phot->hidden > 2048) return bail(fail(c, PAYNE_E_INVALID, "phot.n_filters/hidden out of range"));
+    if (!phot->w1 || !phot->b1 || !phot->w2 || !phot->b2 || !phot->w3 || !phot->b3 || !phot->xmin || !phot->xmax)
+      return bail(fail(c, PAYNE_E_INVALID, "phot descriptor has NULL members"));
+    PhotTables& P = c->P;
+    const int F = phot->n_filters, H = phot->hidden;
+    P.F = F; P.H = H;
+    P.w1 = phot->w1; P.b1 = phot->b1; P.b2 = phot->b2; P.w3 = phot->w3; P.b3 = phot->b3;
+    for (int d = 0; d < 6; ++d) { P.xmin[d] = phot->xmin[d]; P.xden[d] = phot->xmax[d] - phot->xmin[d]; }
+    {   // w2 -> [F][k][h] so that lanes (h) read consecutive addresses
+      std::vector<float> w2((size_t)F * H * H), w2t((size_t)F * H * H);
+      he = hipMemcpy(w2.data(), phot->w2, w2.size() * 4, hipMemcpyDeviceToHost);
+      if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(w2): ") + hipGetErrorString(he)));
+      for (int f = 0; f < F; ++f)
+        for (int h = 0; h < H; ++h)
+          for (int k = 0; k < H; ++k) w2t[((size_t)f * H + k) * H + h] = w2[((size_t)f * H + h) * H + k];
+      if ((rc = upload(c, w2t, &P.w2t, c->owned))) return bail(rc);
+    }
+    if (phot->hiav) {
+      std::vector<double> hv(phot->hiav, phot->hiav + (size_t)F * 5);
+      if ((rc = upload(c, hv, &P.hiav, c->owned))) return bail(rc);
+    }
+    if (phot->obs_mag && phot->obs_err) {
+      std::vector<double> m(phot->obs_mag, phot->obs_mag + F), e(phot->obs_err, phot->obs_err + F);
+      const double *dm, *de;
+      if ((rc = upload(c, m, &dm, c->owned))) return bail(rc);
+      if ((rc = upload(c, e, &de, c->owned))) return bail(rc);
+      c->obs_mag = const_cast<double*>(dm); c->obs_err = const_cast<double*>(de);
+      c->has_obs_phot = true;
+    }
+    if ((rc = dev_alloc(c, (size_t)opts->b_max * F, &c->mags_ws, c->owned))) return bail(rc);
+    if ((size_t)H * 16 > 48 * 1024) {
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_sed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H * 16);
+      if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute(sed): ") + hipGetErrorString(he)));
+    }
+    c->has_phot = true;
+  }
+  *out = c;
+  return PAYNE_OK;
+}
+
+extern "C" int payne_ctx_set_obs(payne_ctx* c, const payne_obs_desc* obs) {
+  if (!c) return PAYNE_E_INVALID;
+  if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (prev != c->device) (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();           // no kernel may still read the old tables
+  int rc = bind_obs(c, obs);
+  if (prev != c->device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+// ---- launches --------------------------------------------------------------
+template <int BM, int BN, bool FUSE>
+static void launch_dense(DenseParams& p, hipStream_t s) {
+  p.grid_m = (p.B + BM - 1) / BM;
+  p.grid_n = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((payne_dense_kernel<BM, BN, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
+}
+
+// ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
+static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
+  const int n = c->n_layers;
+  for (int l = 1; l < n; ++l) {
+    DenseParams p{};
+    const payne_layer& L = c->layers[l];
+    const bool last = (l == n - 1);
+    p.W = L.w; p.K = L.n_in; p.bias = L.b; p.N = L.n_out; p.B = B; p.act = L.act;
+    p.bias_shift = last ? kBase : 0.f;
+    p.Y = last ? c->raw : c->hid[(l - 1) & 1];
+    p.ldy = last ? c->T.npix : c->ld_hid;
+    if (l == 1) {
+      const payne_layer& L0 = c->layers[0];
+      p.theta = theta; p.ld_theta = c->ncols;
+      p.W0 = L0.w; p.b0 = L0.b; p.n_labels = c->n_labels; p.act0 = L0.act; p.K0 = L0.n_out;
+      for (int d = 0; d < c->n_labels; ++d) { p.xmin[d] = c->xmin[d]; p.xden[d] = c->xden[d]; }
+      ProfScope ps(c, s, last ? 0 : 3);
+      launch_dense<64, 64, true>(p, s);
+    } else {
+      p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
+      ProfScope ps(c, s, last ? 0 : 3);
+      launch_dense<64, 64, false>(p, s);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("dense launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+static int check_call(payne_ctx* c, const void* in, int B, const void* out) {
+  if (!c) return PAYNE_E_INVALID;
+  if (!in || !out) return fail(c, PAYNE_E_INVALID, "NULL input/output pointer");
+  if (B <= 0) return fail(c, PAYNE_E_INVALID, "B must be > 0");
+  if (B > c->opts.b_max) return fail(c, PAYNE_E_BATCH, "B exceeds opts.b_max");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != c->device) {
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  }
+  return PAYNE_OK;
+}
+
+static int run_sed(payne_ctx* c, const double* in, int ld, int mode, int B, double* mags, hipStream_t s) {
+  {
+    ProfScope ps(c, s, 2);
+    hipLaunchKernelGGL(payne_sed_kernel, dim3(c->P.F, B), dim3(64), (size_t)c->P.H * 16, s, c->P, in, ld, mode,
+                       8 + c->opts.npoly, c->opts.photscale, mags);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("sed launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+static int run_post(payne_ctx* c, const double* theta, int B, double instr_factor, int stage, float* out, int ld_out,
+                    double* lnl, bool with_phot, hipStream_t s) {
+  PostArgs a{};
+  a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = instr_factor;
+  a.raw = c->raw; a.ld_raw = c->T.npix;
+  a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
+  if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
+  {
+    ProfScope ps(c, s, 1);
+    hipLaunchKernelGGL(payne_post_kernel, dim3(B), dim3(256), c->post_lds, s, c->T, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("post launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+extern "C" int payne_lnlike_batch(payne_ctx* c, const double* theta, int B, double* lnl, void* stream) {
+  int rc = check_call(c, theta, B, lnl);
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (c->has_phot && !c->has_obs_phot) return fail(c, PAYNE_E_INVALID, "photometric model without observed magnitudes");
+  if (c->has_model) {
+    if (!c->obs_bound || !c->T.obs_f1) return fail(c, PAYNE_E_INVALID, "no observed spectrum (flux, eflux) bound");
+    if ((rc = run_ann(c, theta, B, s))) return rc;
+  }
+  if (c->has_phot && (rc = run_sed(c, theta, c->ncols, 1, B, c->mags_ws, s))) return rc;
+  if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s);
+  hipLaunchKernelGGL(payne_photonly_kernel, dim3((B + 127) / 128), dim3(128), 0, s, c->mags_ws, c->obs_mag, c->obs_err, c->P.F, B, lnl);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("photonly launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+extern "C" int payne_predict_batch(payne_ctx* c, const double* theta, int B, int stage, unsigned flags, float* out,
+                                   int ld_out, void* stream) {
+  int rc = check_call(c, theta, B, out);
+  if (rc) return rc;
+  if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
+  if (stage < 0 || stage > 3) return fail(c, PAYNE_E_INVALID, "stage must be 0..3");
+  if (stage >= 2 && !c->obs_bound) return fail(c, PAYNE_E_INVALID, "no observed grid bound");
+  if (ld_out < (stage >= 2 ? c->T.nobs : c->T.npix)) return fail(c, PAYNE_E_INVALID, "ld_out too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((rc = run_ann(c, theta, B, s))) return rc;
+  return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage, out, ld_out, nullptr, false, s);
+}
+
+extern "C" int payne_sed_batch(payne_ctx* c, const double* pars, int B, double* mags, void* stream) {
+  int rc = check_call(c, pars, B, mags);
+  if (rc) return rc;
+  if (!c->has_phot) return fail(c, PAYNE_E_INVALID, "context has no photometric model");
+  return run_sed(c, pars, 9, 0, B, mags, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- per-kernel timing ---------------------------------------------------------
+extern "C" int payne_profile(payne_ctx* c, int enable) {
+  if (!c) return PAYNE_E_INVALID;
+  c->prof = enable != 0;
+  if (enable) {
+    c->prof_used = 0;
+    for (int k = 0; k < 4; ++k) { c->prof_ms[k] = 0.0; c->prof_n[k] = 0; }
+  }
+  return PAYNE_OK;
+}
+
+extern "C" int payne_profile_read(payne_ctx* c, int kind, double* total_ms, long long* launches) {
+  if (!c || kind < 0 || kind > 3) return PAYNE_E_INVALID;
+  for (size_t i = 0; i < c->prof_used; ++i) {
+    auto& r = c->prof_pool[i];
+    float ms = 0.f;
+    HIPCHK(c, hipEventSynchronize(r.e1));
+    HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+    c->prof_ms[r.kind] += ms;
+    c->prof_n[r.kind] += 1;
+  }
+  c->prof_used = 0;
+  if (total_ms) *total_ms = c->prof_ms[kind];
+  if (launches) *launches = c->prof_n[kind];
+  return PAYNE_OK;
+}

@@ -1,0 +1,380 @@
+// post_core.hpp -- per-candidate spectrum pipeline of the likelihood hot path,
+// written as barrier-separated PHASES so that the same source runs
+//   * on gfx950 inside post_kernel (one 256-thread workgroup per candidate, all
+//     spectra resident in LDS), and
+//   * on the host (csrc/cpu_emul.cpp: phases executed for tid = 0..NT-1 in turn)
+//     as a bit-faithful emulation used by the CPU tests and sanitizer builds.
+//
+// What it computes (reference: /root/reference, restated in oracle/payne_oracle.py):
+//   raw ANN spectrum  ->  [vsini FFT broadening, Payne/predict/ystpred.py:211-224,
+//   Payne/utils/smoothing.py:293-312,610-629]  ->  Doppler shift (ystpred.py:226-232)
+//   ->  data-dependent mask + log-lambda pow-2 resample + Gaussian FFT smoothing to the
+//   instrument R + interpolation onto the observed grid (smoothing.py:103-115,131-169,
+//   252-291,588-608,631-668)  ->  [Chebyshev blaze, Payne/fitting/fitutils.py:11-20]
+//   ->  chi^2 (Payne/fitting/likelihood.py:95-97).
+//
+// Numerics: flux arithmetic is fp32 on a spectrum shifted by -1 (normalised spectra
+// live near 1; every linear stage has unit DC gain, so f -> f-1 commutes with the
+// pipeline and buys ~20x smaller rounding error).  Wavelength arithmetic is fp64 in
+// ln(lambda): the interpolation weight (x-x_k)/(x_{k+1}-x_k) is evaluated as
+// expm1(u)/expm1(v) ~ (u/v)(1+(u-v)/2) from fp64 differences of logs, so there is no
+// per-pixel exp() and no fp32 wavelength anywhere.  Fourier tapers
+// are evaluated in fp64 (vsini taper cancels catastrophically in fp32, 7.3-2).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define PAYNE_HD __host__ __device__ __forceinline__
+#else
+#define PAYNE_HD inline
+#endif
+
+namespace payne {
+
+constexpr double kCkms = 2.998e5;            // smoothing.py:16
+constexpr double kCDoppler = 299792.458;     // ystpred.py:11-12
+constexpr double kPi = 3.141592653589793;
+constexpr float kBase = 1.0f;                // the flux shift
+
+struct c32 { float x, y; };
+PAYNE_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+PAYNE_HD c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+PAYNE_HD c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+PAYNE_HD c32 cconj(c32 a) { return {a.x, -a.y}; }
+PAYNE_HD c32 cscale(c32 a, float s) { return {a.x * s, a.y * s}; }
+PAYNE_HD c32 cmul_negi(c32 a) { return {a.y, -a.x}; }   // a * (-i)
+PAYNE_HD c32 cmul_posi(c32 a) { return {-a.y, a.x}; }   // a * (+i)
+
+// ---------------------------------------------------------------------------
+// Static (per-context) tables, all device-resident; built once on the host.
+// ---------------------------------------------------------------------------
+struct PostTables {
+  int npix;            // ANN pixels
+  int nobs;            // observed pixels (0: no obs grid bound)
+  int n1;              // pow2ceil(npix): vsini FFT length
+  int nmax;            // twiddle table length (= largest real FFT length)
+  const double* lnlam;     // [npix]  ln(lambda_ANN)
+  const double* lam;       // [npix]  lambda_ANN (exact mask test)
+  const c32* tw;           // [nmax]  exp(-2 pi i j / nmax)
+  // vsini stage maps (theta-independent, smoothing.py:649-668 + :311)
+  const int* rs1_idx;      // [n1]   source pixel k of resampled point j
+  const float* rs1_frac;   // [n1]   weight of pixel k+1
+  const int* bk1_idx;      // [npix] source point j of ANN pixel i (-1: NaN)
+  const float* bk1_frac;   // [npix]
+  double vs_val;           // 1/(n1*dv1): rfftfreq spacing of the vsini grid
+  // observed grid
+  const double* lnobs;     // [nobs] ln(obs wave)
+  const double* xcheb;     // [nobs] polycalc abscissa in [-1,1]
+  const float* obs_f1;     // [nobs] obs flux - 1
+  const float* obs_ivar;   // [nobs] 1/eflux^2
+  double obs_min, obs_max; // min/max of obs wave (mask_wave limits)
+  double r_ann;            // sigma-based R of the ANN
+  double geo_inv_dln;      // 1/mean(d lnlam): index guess for the resamplers
+  int npoly;               // blaze coefficients (0: off)
+};
+
+// Per-candidate scalars, shared by the workgroup (lives in LDS).
+struct CandState {
+  double one_plus;   // 1 + rv/c
+  double dop;        // ln(one_plus)
+  double lnmin, lnmax, step, inv_step;
+  double vs_a;       // 2 pi sigma        (vsini)
+  double g_a;        // -2 pi^2 sigma^2   (gauss)
+  double g_val;      // 1/(n2*dv2)
+  double poly[12];
+  int do_rot, do_smooth;
+  int i0, i1, n2;
+  int bad;           // window too small for an FFT -> NaN result
+};
+
+// ---------------------------------------------------------------------------
+// Radix-2/4/8 Stockham passes on M complex points held in LDS.
+// Thread i owns butterfly i of M/R: reads src[i + r*M/R], twiddles by
+// exp(-2 pi i k r/(pR)) (k = i mod p), writes dst[(i-k)R + k + r p].
+// ---------------------------------------------------------------------------
+PAYNE_HD void dft2(c32* u) { c32 a = u[0], b = u[1]; u[0] = cadd(a, b); u[1] = csub(a, b); }
+PAYNE_HD void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
+  c32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmul_negi(csub(a1, a3));
+  a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+}
+PAYNE_HD void dft8(c32* u) {
+  c32 e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
+  dft4(e0, e1, e2, e3); dft4(o0, o1, o2, o3);
+  const float h = 0.70710678118654752f;
+  c32 w1o = {h * (o1.x + o1.y), h * (o1.y - o1.x)};       // o1 * (1-i)/sqrt2
+  c32 w2o = cmul_negi(o2);                                // o2 * (-i)
+  c32 w3o = {h * (o3.y - o3.x), -h * (o3.x + o3.y)};      // o3 * (-1-i)/sqrt2
+  u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
+  u[1] = cadd(e1, w1o); u[5] = csub(e1, w1o);
+  u[2] = cadd(e2, w2o); u[6] = csub(e2, w2o);
+  u[3] = cadd(e3, w3o); u[7] = csub(e3, w3o);
+}
+
+template <int R>
+PAYNE_HD void fft_pass(int tid, int nthr, const c32* src, c32* dst, int M, int p,
+                       const c32* tw, int tw_n, bool conj_out) {
+  const int nb = M / R;
+  for (int i = tid; i < nb; i += nthr) {
+    const int k = i & (p - 1);
+    c32 u[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = src[i + r * nb];
+    if (p > 1) {
+      const int ts = tw_n / (p * R);
+#pragma unroll
+      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
+    }
+    if (R == 8) dft8(u);
+    else if (R == 4) dft4(u[0], u[1], u[2], u[3]);
+    else dft2(u);
+    const int j = (i - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[j + r * p] = conj_out ? cconj(u[r]) : u[r];
+  }
+}
+
+// Radix of the pass that starts at sub-length p for an M-point transform.
+PAYNE_HD int pass_radix(int M, int p) { int rem = M / p; return rem >= 8 ? 8 : rem; }
+
+// ---------------------------------------------------------------------------
+// Tapers.
+// ---------------------------------------------------------------------------
+PAYNE_HD double vsini_taper(double vs_a, double vs_val, int k) {
+  // smoothing.py:612-620 (ss[0] hack irrelevant: sb[0] is overwritten with 1)
+  if (k == 0) return 1.0;
+  double ub = vs_a * ((double)k * vs_val);
+  double s, c;
+#ifdef __HIP_DEVICE_COMPILE__
+  sincos(ub, &s, &c);
+#else
+  s = sin(ub); c = cos(ub);
+#endif
+  double u2 = ub * ub;
+  return j1(ub) / ub - 3.0 * c / (2.0 * u2) + 3.0 * s / (2.0 * (u2 * ub));
+}
+PAYNE_HD float gauss_taper(double g_a, double g_val, int k) {
+  // smoothing.py:598-599: exp(-2 pi^2 sigma^2 ss^2), ss = k/(n dv)
+  double ss = (double)k * g_val;
+  return expf((float)(g_a * (ss * ss)));
+}
+
+// Middle step of a real convolution done with a half-length complex FFT.
+// In: Z = FFT_M(z), z[n] = s[2n] + i s[2n+1].  Out (in place): Y with
+// FFT_M(Y) = conj(z'), z'[n] = s'[2n] + i s'[2n+1], s' = irfft(rfft(s) * taper).
+// Thread handles the conjugate pair (k, M-k); tw_n-th roots supply exp(-2 pi i k/2M).
+template <bool VSINI>
+PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* tw, int tw_n,
+                               double ta, double tval) {
+  const int ts = tw_n / (2 * M);
+  const float g = 0.25f / (float)M;
+  for (int k = tid; k <= M / 2; k += nthr) {
+    const int mk = M - k;
+    float tk = VSINI ? (float)vsini_taper(ta, tval, k) : gauss_taper(ta, tval, k);
+    float tm = VSINI ? (float)vsini_taper(ta, tval, mk) : gauss_taper(ta, tval, mk);
+    if (k == 0) {
+      c32 z0 = Z[0];
+      float x0 = tk * (z0.x + z0.y), xm = tm * (z0.x - z0.y);
+      Z[0] = {0.5f * (x0 + xm) / (float)M, -0.5f * (x0 - xm) / (float)M};
+    } else if (k == mk) {
+      Z[k] = cscale(cconj(Z[k]), tk / (float)M);
+    } else {
+      c32 zk = Z[k], zm = cconj(Z[mk]);
+      c32 w = tw[k * ts];
+      c32 A = cadd(zk, zm);
+      c32 C = cmul(w, cmul_negi(csub(zk, zm)));
+      c32 S1 = cscale(cadd(A, C), tk * g), S2 = cscale(csub(A, C), tm * g);
+      c32 E = cadd(S1, S2);
+      c32 O = cmul(cconj(w), csub(S1, S2));
+      c32 iO = cmul_posi(O);
+      Z[k] = cconj(cadd(E, iO));
+      Z[mk] = csub(E, iO);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Search helpers (monotone fp64 arrays).
+// ---------------------------------------------------------------------------
+// k in [lo, hi-2] with x[k] <= v < x[k+1] (clamped at the ends), from a guess.
+PAYNE_HD int locate(const double* x, int lo, int hi, double v, int guess) {
+  int k = guess < lo ? lo : (guess > hi - 2 ? hi - 2 : guess);
+  while (k > lo && v < x[k]) --k;
+  while (k < hi - 2 && v >= x[k + 1]) ++k;
+  return k;
+}
+// interpolation weight from log-space offsets: expm1(u)/expm1(v)
+PAYNE_HD float lerp_weight(double u, double v) {
+  float uf = (float)u, vf = (float)v;
+  return (uf / vf) * (1.0f + 0.5f * (uf - vf));
+}
+PAYNE_HD float nanf_() { return __builtin_nanf(""); }
+PAYNE_HD float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
+PAYNE_HD int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// ---------------------------------------------------------------------------
+// Phases.  `spec`/`work` are the two LDS spectra buffers (n1 floats each).
+// ---------------------------------------------------------------------------
+
+// P0: per-candidate scalars from theta (one thread) + reset of the mask bounds.
+// theta columns: 0 Teff 1 logg 2 FeH 3 aFe 4 Vrad 5 Vrot 6 Vmic 7 Inst_R 8.. pc_*
+PAYNE_HD void phase_setup(int tid, const PostTables& T, const double* th, double instr_factor,
+                          CandState& S) {
+  if (tid != 0) return;
+  const double rv = th[4], vrot = th[5];
+  S.do_rot = (vrot != 0.0);                       // ystpred.py:214 (NaN passes)
+  S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);   // smoothing.py:297,614
+  S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;   // ystpred.py:228-232
+  S.dop = log(S.one_plus);
+  const double Rs = th[7] * instr_factor;         // genmod.py:82-85
+  S.do_smooth = (Rs > 0.0);                       // ystpred.py:238-240 (false for NaN)
+  S.i0 = T.npix; S.i1 = -1; S.n2 = 0; S.bad = 0;
+  if (S.do_smooth) {
+    const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;   // smoothing.py:107,113
+    const double sig = sqrt(sig_out * sig_out - inres * inres);   // :271 (NaN if negative)
+    S.g_a = -2.0 * (kPi * kPi) * (sig * sig);
+  }
+  for (int i = 0; i < T.npoly && i < 12; ++i) S.poly[i] = th[8 + i];
+}
+
+// P1: load the raw ANN spectrum (already shifted by -1) into LDS.
+PAYNE_HD void phase_load(int tid, int nthr, const PostTables& T, const float* raw, float* spec) {
+  for (int i = tid; i < T.npix; i += nthr) spec[i] = raw[i];
+}
+
+// vsini a: resample onto the pow-2 log grid (static map) into `work`.
+PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const float* spec, float* work) {
+  for (int j = tid; j < T.n1; j += nthr) {
+    int k = T.rs1_idx[j];
+    float a = nan_to_zero(spec[k]), b = nan_to_zero(spec[k + 1]);   // nan_to_num(nan=1.0), smoothing.py:138
+    work[j] = a + (b - a) * T.rs1_frac[j];
+  }
+}
+// vsini c: back onto the ANN grid (left/right = NaN), into `spec`.
+PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float* work, float* spec) {
+  for (int i = tid; i < T.npix; i += nthr) {
+    int j = T.bk1_idx[i];
+    float v;
+    if (j < 0) v = nanf_();
+    else { float a = work[j], b = work[j + 1]; v = a + (b - a) * T.bk1_frac[i]; }
+    spec[i] = v;
+  }
+}
+// vsini d: spec[0]=spec[1]; spec[-1]=spec[-2]  (ystpred.py:223-224)
+PAYNE_HD void phase_rot_edges(int tid, const PostTables& T, float* spec) {
+  if (tid == 0) spec[0] = spec[1];
+  if (tid == 1) spec[T.npix - 1] = spec[T.npix - 2];
+}
+
+// R a: data-dependent mask (smoothing.py:631-647), exact fp64 products as numpy.
+// Each thread scans its pixels; bounds merge through LDS atomics / serial min-max.
+PAYNE_HD void phase_mask_scan(int tid, int nthr, const PostTables& T, const double* th,
+                              double instr_factor, const CandState& S, int& lo_i, int& hi_i) {
+  lo_i = T.npix; hi_i = -1;
+  const double Rs = th[7] * instr_factor;
+  const double pad = 20.0 / Rs;
+  const double wl = T.obs_min * (1.0 + pad * -1.0), wh = T.obs_max * (1.0 + pad * 1.0);
+  for (int i = tid; i < T.npix; i += nthr) {
+    double w = T.lam[i] * S.one_plus;
+    if ((w > wl) && (w < wh)) { if (i < lo_i) lo_i = i; if (i > hi_i) hi_i = i; }
+  }
+}
+// R b: window scalars (one thread): resample_wave's grid (smoothing.py:654-661)
+PAYNE_HD void phase_window(int tid, const PostTables& T, CandState& S) {
+  if (tid != 0) return;
+  int n = S.i1 - S.i0 + 1;
+  if (S.i1 < 0) n = 0;
+  S.i1 = S.i0 + n;                     // exclusive from here on
+  if (n < 8) { S.bad = 1; S.n2 = 8; return; }
+  S.n2 = pow2ceil(n);
+  S.lnmin = log(T.lam[S.i0] * S.one_plus);
+  S.lnmax = log(T.lam[S.i1 - 1] * S.one_plus);
+  S.step = (S.lnmax - S.lnmin) / (double)(S.n2 - 1);     // np.linspace
+  S.inv_step = 1.0 / S.step;
+  S.g_val = 1.0 / ((double)S.n2 * (kCkms * S.step));     // rfftfreq(n, d=dv), dv = ckms*median(diff(ln w))
+}
+// R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
+PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S,
+                               const float* spec, float* work) {
+  const double base = T.lnlam[S.i0];
+  for (int j = tid; j < S.n2; j += nthr) {
+    double lw = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
+    double v = lw - S.dop;                               // position on the unshifted ANN grid
+    int guess = S.i0 + (int)((v - base) * T.geo_inv_dln);
+    int k = locate(T.lnlam, S.i0, S.i1, v, guess);
+    double u = v - T.lnlam[k], dv = T.lnlam[k + 1] - T.lnlam[k];
+    float a = nan_to_zero(spec[k]), b = nan_to_zero(spec[k + 1]);
+    float out;
+    if (u <= 0.0) out = a;                               // np.interp clamps (default left/right)
+    else if (u >= dv) out = b;
+    else out = a + (b - a) * lerp_weight(u, dv);
+    work[j] = out;
+  }
+}
+
+// Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
+// `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
+// (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
+PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S,
+                          const float* conv, float* out, int out_stage) {
+  double acc = 0.0;
+  const bool cheb = T.npoly > 0;
+  for (int i = tid; i < T.nobs; i += nthr) {
+    const double lo = T.lnobs[i];
+    float m1;
+    if (S.bad) m1 = nanf_();
+    else if (S.do_smooth) {
+      if (lo < S.lnmin || lo > S.lnmax) m1 = nanf_();    // np.interp(left=nan, right=nan)
+      else {
+        int j = (int)((lo - S.lnmin) * S.inv_step);
+        if (j > S.n2 - 2) j = S.n2 - 2;
+        double xj = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
+        double u = lo - xj;
+        if (u < 0.0 && j > 0) { --j; u += S.step; }
+        else if (u >= S.step && j < S.n2 - 2) { ++j; u -= S.step; }
+        float a = conv[j], b = conv[j + 1];
+        float w = lerp_weight(u, S.step);
+        w = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
+        m1 = a + (b - a) * w;
+      }
+    } else {
+      double v = lo - S.dop;
+      if (v < T.lnlam[0] || v > T.lnlam[T.npix - 1]) m1 = nanf_();
+      else {
+        int guess = (int)((v - T.lnlam[0]) * T.geo_inv_dln);
+        int k = locate(T.lnlam, 0, T.npix, v, guess);
+        double u = v - T.lnlam[k], dv = T.lnlam[k + 1] - T.lnlam[k];
+        float a = conv[k], b = conv[k + 1];
+        float w = lerp_weight(u, dv);
+        w = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
+        m1 = a + (b - a) * w;
+      }
+    }
+    float pm1 = 0.f, p = 1.f;
+    if (cheb) {   // numpy.polynomial.chebyshev.chebval (Clenshaw), fitutils.py:11-20
+      const double x = T.xcheb[i];
+      double c0, c1;
+      const int nc = T.npoly;
+      if (nc == 1) { c0 = S.poly[0]; c1 = 0.0; }
+      else if (nc == 2) { c0 = S.poly[0]; c1 = S.poly[1]; }
+      else {
+        const double x2 = 2.0 * x;
+        c0 = S.poly[nc - 2]; c1 = S.poly[nc - 1];
+        for (int q = 3; q <= nc; ++q) { double t = c0; c0 = S.poly[nc - q] - c1; c1 = t + c1 * x2; }
+      }
+      double pv = c0 + c1 * x;
+      p = (float)pv; pm1 = (float)(pv - 1.0);
+    }
+    if (out) {
+      if (out_stage == 3) out[i] = (m1 + kBase) * p;     // genspec (with blaze)
+      else out[i] = m1 + kBase;                           // getspec
+    }
+    if (T.obs_f1) {
+      float d = cheb ? (m1 * p + (pm1 - T.obs_f1[i])) : (m1 - T.obs_f1[i]);
+      acc += (double)(d * d * T.obs_ivar[i]);
+    }
+  }
+  return acc;
+}
+
+}  // namespace payne
