@@ -153,6 +153,11 @@ int payne_predict_batch(payne_ctx* ctx, const double* theta, int B, int stage, u
  * (logl, dist) form wins over logA as in the reference).  mags: device fp64 [B][F]. */
 int payne_sed_batch(payne_ctx* ctx, const double* pars, int B, double* mags, void* stream);
 
+/* Bolometric corrections for B label vectors: fastANN.eval
+ * (Payne/predict/photANN.py:125-131).  x: device fp64 [B][6] = Teff, logg, feh, afe,
+ * av, rv; bc: device fp64 [B][F]. */
+int payne_bc_batch(payne_ctx* ctx, const double* x, int B, double* bc, void* stream);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

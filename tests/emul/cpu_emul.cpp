@@ -22,23 +22,24 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
                                const double* obs_flux, const double* obs_eflux, int nobs, int npoly,
                                const double* theta, int ncols, int B, double instr_factor,
                                const float* raw_m1, int out_stage, float* out, int ld_out,
-                               double* chi2, int* info, int nthreads) {
+                               double* chi2, int* info, int nthreads, int force_general) {
   HostTables H;
   int rc = build_model_tables(wave, npix, H);
   if (rc) return rc;
   build_obs_tables(obs_wave, obs_flux, obs_eflux, nobs, H);
   PostTables T;
   std::memset(&T, 0, sizeof(T));
-  T.npix = npix; T.nobs = nobs; T.n1 = H.n1; T.nmax = H.nmax;
+  fill_model_scalars(H, T);
+  T.nobs = nobs; T.vs_tab = H.vs_tab.data();
   T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data();
   T.rs1_idx = H.rs1_idx.data(); T.rs1_frac = H.rs1_frac.data();
   T.bk1_idx = H.bk1_idx.data(); T.bk1_frac = H.bk1_frac.data();
-  T.vs_val = H.vs_val;
   T.lnobs = H.lnobs.data(); T.xcheb = H.xcheb.data();
   T.obs_f1 = H.has_flux ? H.obs_f1.data() : nullptr;
   T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
-  T.geo_inv_dln = H.geo_inv_dln; T.npoly = npoly;
+  T.npoly = npoly;
+  if (force_general) T.geo = 0;
   HostExec ex{nthreads};
   std::vector<float> a(H.n1), b(H.n1);
   std::vector<double> red(nthreads + 16);

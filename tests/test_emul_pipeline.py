@@ -1,0 +1,148 @@
+"""The per-candidate pipeline source that runs on the GPU (thepayne_amd/csrc/post_core.hpp,
+post_seq.hpp), executed on the host by tests/emul/cpu_emul.cpp, against the reference's
+golden vectors and the oracle.  This is the CPU-side check of the kernel LOGIC (and the
+target of sanitizer builds); the GPU tests check the kernel itself."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from thepayne_amd import synth
+from helpers import lnl_tol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp, fp, ip = (ctypes.POINTER(t) for t in (ctypes.c_double, ctypes.c_float, ctypes.c_int))
+
+
+@pytest.fixture(scope="module")
+def emul():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    lib = ctypes.CDLL(ge.build_emul())
+
+    def P(a, t):
+        return a.ctypes.data_as(t) if a is not None else None
+
+    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=256):
+        theta8 = np.atleast_2d(theta8)
+        B, npix = len(theta8), len(net["wavelength"])
+        raw = np.array([O.yst_forward(net, t[:4]) - 1.0 for t in theta8]).astype(np.float32)
+        th = np.ascontiguousarray(theta8 if pcs is None else np.hstack([theta8, pcs]), dtype=np.float64)
+        nout = npix if stage in (0, 1) else len(obs)
+        out = np.zeros((B, nout), np.float32)
+        chi2, info = np.zeros(B), np.zeros((B, 3), np.int32)
+        rc = lib.payne_emul_post(P(net["wavelength"], dp), npix, ctypes.c_double(net["resolution"]), P(obs, dp),
+                                 P(flux, dp), P(eflux, dp), len(obs), npoly, P(th, dp), th.shape[1], B,
+                                 ctypes.c_double(factor), P(raw, fp), stage, P(out, fp), nout, P(chi2, dp), P(info, ip),
+                                 nthreads, general)
+        assert rc == 0
+        return out, chi2, info
+    return run
+
+
+def _th8(th7):
+    th7 = np.atleast_2d(th7)
+    return np.column_stack([th7[:, :6], np.full(len(th7), np.nan), th7[:, 6]])
+
+
+@pytest.mark.parametrize("general", [0, 1])
+def test_c2_lnlike_matches_reference_golden(emul, golden, general):
+    g = golden("g4_lnlike_c2")
+    cfg = synth.CONFIGS["C2"]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    idx = np.arange(0, 512, 16)
+    _, chi2, info = emul(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], _th8(g["theta"][idx]), -1, general=general)
+    ref = g["lnlike"][idx]
+    assert np.all(np.abs(-0.5 * chi2 - ref) <= lnl_tol(ref))
+    assert np.abs(-0.5 * chi2 - ref).max() < 1e-3        # in practice ~1e-4
+    assert (info[:, 2] == 4096).all() and (info[:, 1] > 3800).all()
+
+
+@pytest.mark.parametrize("general", [0, 1])
+def test_getspec_grid_matches_reference_golden(emul, golden, general):
+    g = golden("g2_getspec")
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    lab, rows = g["labels"], g["theta_rows"]
+    th8 = np.array([[lab[0], lab[1], lab[2], lab[3], r[0], r[1], np.nan, r[2]] for r in rows])
+    out, _, info = emul(net, g["obs_wave"], None, None, th8, 2, general=general)
+    assert np.array_equal(np.isnan(out), np.isnan(g["final"]))
+    assert np.nanmax(np.abs(out - g["final"])) <= 1e-6
+    ok = np.isfinite(rows[:, 2])
+    assert np.array_equal(info[ok, 0], g["mask_first_count"][ok, 0])
+    assert np.array_equal(info[ok, 1], g["mask_first_count"][ok, 1])
+    for v, ref in zip(g["vrot_values"], g["after_rot"]):
+        t = th8[:1].copy(); t[0, 5] = v
+        o, _, _ = emul(net, g["obs_wave"], None, None, t, 1, general=general)
+        assert np.abs(o[0] - ref).max() <= 1e-6, v
+
+
+def test_modpoly_matches_reference_golden(emul, golden):
+    g = golden("g4_lnlike_modpoly")
+    cfg = synth.CONFIGS["small"]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=64, seed=0)
+    th = g["theta"]
+    _, chi2, _ = emul(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], _th8(th[:, :7]), -1, npoly=3, pcs=th[:, 7:10])
+    assert np.all(np.abs(-0.5 * chi2 - g["lnlike"]) <= lnl_tol(g["lnlike"]))
+
+
+@pytest.mark.parametrize("npix,nobs,nthreads", [(300, 250, 64), (777, 600, 256), (2048, 1800, 128), (5000, 4000, 256)])
+def test_ragged_sizes_vs_oracle(emul, npix, nobs, nthreads):
+    """npix not a power of two (the vsini grid is then a genuine resampling), few threads."""
+    net = synth.make_yst_net(npix=npix, H=24, seed=21, line_depth=0.2)
+    span = net["wavelength"][-1] - net["wavelength"][0]
+    obs = synth.obs_grid(net["wavelength"], nobs, inset=0.06 * span)
+    th7 = synth.draw_candidates(6, seed=npix)
+    ref = np.array([O.genspec(net, list(_th8(t)[0]), outwave=obs)[1] for t in th7])
+    out, _, _ = emul(net, obs, None, None, _th8(th7), 2, nthreads=nthreads)
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    assert np.nanmax(np.abs(out - ref)) <= 1e-6
+
+
+def test_nonuniform_ann_grid_vs_oracle(emul):
+    """A non-geometric ANN wavelength grid takes the search path automatically."""
+    net = synth.make_yst_net(npix=1500, H=24, seed=22, line_depth=0.2)
+    rng = np.random.default_rng(0)
+    w = net["wavelength"]
+    net["wavelength"] = w + 0.3 * np.diff(w).mean() * rng.uniform(-1, 1, len(w))
+    obs = synth.obs_grid(net["wavelength"], 1200, inset=2.0)
+    th7 = synth.draw_candidates(6, seed=3)
+    ref = np.array([O.genspec(net, list(_th8(t)[0]), outwave=obs)[1] for t in th7])
+    out, _, _ = emul(net, obs, None, None, _th8(th7), 2)
+    assert np.nanmax(np.abs(out - ref)) <= 1e-6
+
+
+def test_emulator_under_address_and_ub_sanitizers(tmp_path):
+    """Sanitizers run on the CPU build only (no GPU ASan on this pool)."""
+    exe = tmp_path / "emul_san"
+    main = tmp_path / "main.cpp"
+    main.write_text(r'''
+#include <cmath>
+#include <cstdio>
+#include <vector>
+extern "C" int payne_emul_post(const double*, int, double, const double*, const double*, const double*, int, int,
+    const double*, int, int, double, const float*, int, float*, int, double*, int*, int, int);
+int main() {
+  const int npix = 700, nobs = 500, B = 3;
+  std::vector<double> w(npix), ow(nobs), fl(nobs, 1.0), ef(nobs, 0.01), th(B * 8);
+  for (int i = 0; i < npix; ++i) w[i] = 5150.0 * std::pow(1.0 + 1.0 / (3 * 32000 * 2.3548), i);
+  for (int i = 0; i < nobs; ++i) ow[i] = w[20] + (w[npix - 21] - w[20]) * i / (nobs - 1.0);
+  std::vector<float> raw(B * npix);
+  for (int i = 0; i < B * npix; ++i) raw[i] = 0.05f * std::sin(0.05f * i);
+  for (int b = 0; b < B; ++b) { double* t = &th[b * 8]; t[0]=5770; t[1]=4.4; t[2]=0; t[3]=0; t[4]=10.0*b; t[5]=b; t[6]=NAN; t[7]=25000+2000*b; }
+  std::vector<float> out(B * nobs); std::vector<double> chi(B); std::vector<int> info(3 * B);
+  int rc = payne_emul_post(w.data(), npix, 32000 * 2.3548, ow.data(), fl.data(), ef.data(), nobs, 0, th.data(), 8, B, 2.355,
+                           raw.data(), 2, out.data(), nobs, chi.data(), info.data(), 256, 0);
+  std::printf("rc=%d chi=%g\n", rc, chi[1]);
+  return rc;
+}''')
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           str(main), os.path.join(ROOT, "tests", "emul", "cpu_emul.cpp"), "-o", str(exe)]
+    subprocess.run(cmd, check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "rc=0" in res.stdout

@@ -127,7 +127,7 @@ def test_lnlike_vs_oracle_shapes(Engine, npix, nobs, H, B):
     """Ragged sizes: npix not a power of two, hidden width not a multiple of 4/32,
     batch not a multiple of the tile; big spectra up to the LDS limit."""
     raw = synth.make_yst_net(npix=npix, H=H, seed=11, line_depth=0.1)
-    obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.02 * (raw["wavelength"][-1] - raw["wavelength"][0]))
+    obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.06 * (raw["wavelength"][-1] - raw["wavelength"][0]))
     th7 = synth.draw_candidates(B, seed=npix)
     ref_flux = np.array([O.genspec(raw, list(theta_full(t)[0, :8]), outwave=obs)[1] for t in th7])
     rng = np.random.default_rng(3)
@@ -138,9 +138,12 @@ def test_lnlike_vs_oracle_shapes(Engine, npix, nobs, H, B):
     assert np.array_equal(np.isnan(got), np.isnan(ref_flux))
     assert np.nanmax(np.abs(got - ref_flux)) <= FLUX_TOL
     L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
-    ref = np.array([L.lnlikefn(t) for t in th7])
+    with np.errstate(all="ignore"):
+        ref = np.array([L.lnlikefn(t) for t in th7])
     lnl = eng.lnlike_batch(theta_full(th7)).cpu().numpy()
-    assert np.all(np.abs(lnl - ref) <= lnl_tol(ref))
+    assert np.array_equal(np.isnan(lnl), np.isnan(ref))
+    ok = np.isfinite(ref)
+    assert ok.sum() >= B - 2 and np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok]))
 
 
 def test_nan_and_branch_semantics_vs_oracle(Engine):
@@ -186,7 +189,10 @@ def test_full_size_properties(Engine):
     eng = Engine(net, obs=(obs, flux, eflux), b_max=512)
     th = theta_full(synth.draw_candidates(512, seed=9))
     lnl = eng.lnlike_batch(th).cpu().numpy()
-    assert np.isfinite(lnl).all()
+    # an Inst_R draw above the ANN's own resolution is NaN by contract: rare tail of the prior
+    fin = np.isfinite(lnl)
+    assert fin.sum() >= 508 and np.array_equal(~fin, th[:, 7] * 2.355 > raw["resolution"])
+    th, lnl = th[fin], lnl[fin]
     # chi^2 recomputed on the host from the predicted spectra agrees with the fused reduction
     spec = eng.predict_batch(th, stage=3, fwhm_R=True).cpu().numpy().astype(np.float64)
     chi = -0.5 * (((spec - flux) / eflux) ** 2).sum(axis=1)

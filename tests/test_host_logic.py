@@ -1,0 +1,130 @@
+"""Host-side logic (no GPU): prior transforms / ln-priors and helpers against golden
+vectors frozen from the reference; the C-ABI library loads and exports its symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from thepayne_amd import synth
+from thepayne_amd.fitting.prior import prior
+from thepayne_amd.fitting import fitutils
+
+ALL_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R',
+            'log(R)', 'Dist', 'log(A)', 'Av', 'Rv', 'CarbonScale']
+SPEC_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fitpars_for(on, npoly=0):
+    names = list(ALL_PARS) + ['pc_%d' % i for i in range(npoly)]
+    return [names, {p: (p in on or p.startswith('pc_')) for p in names}]
+
+
+KINDS = {
+    "uniform": {'pv_uniform': [4000.0, 8000.0]}, "uniform_rev": {'pv_uniform': [8000.0, 4000.0]},
+    "gaussian": {'pv_gaussian': [5770.0, 100.0]}, "tgaussian": {'pv_tgaussian': [25000.0, 37000.0, 28800.0, 1000.0]},
+    "exp": {'pv_exp': [0.0, 2.0]}, "texp": {'pv_texp': [0.0, 10.0, 2.0]}, "default": None,
+}
+
+
+def test_priortrans_every_kind(golden):
+    g = golden("g6_prior")
+    u = g["u"]
+    fitargs = {'fixedpars': {}}
+    for key in g.files:
+        m = re.match(r"(spec|phot)_(.+)_(uniform_rev|uniform|gaussian|tgaussian|exp|texp|default)$", key)
+        if not m:
+            continue
+        which, par, kname = m.groups()
+        pd = {} if KINDS[kname] is None else {par: KINDS[kname]}
+        rb = [True, False, False, False, False] if which == "spec" else [False, True, False, True, False]
+        P = prior(fitargs, pd, fitpars_for([par]), rb)
+        with np.errstate(all="ignore"):
+            got = np.array([P.priortrans([ui])[0] for ui in u], dtype=float)
+            got_b = P.priortrans_batch(u[:, None])[:, 0]
+        np.testing.assert_allclose(got, g[key], rtol=1e-13, atol=0, err_msg=key)
+        np.testing.assert_allclose(got_b, g[key], rtol=1e-13, atol=0, err_msg=key + " (batch)")
+
+
+def test_priortrans_photonly_and_blaze(golden):
+    g = golden("g6_prior")
+    fitargs = {'fixedpars': {}}
+    P = prior(fitargs, {'Teff': {'pv_gaussian': [5770.0, 200.0]}, 'Av': {'pv_uniform': [0.0, 1.0]}},
+              fitpars_for(['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'log(A)', 'Av']), [False, True, False, True, False])
+    np.testing.assert_allclose(P.priortrans_batch(g["photonly_u"]), g["photonly_theta"], rtol=1e-13)
+    pd = synth.demo_priordict()
+    pd['blaze_coeff'] = [[0.0, 0.5], [0.1, 0.2], [-0.05, 0.1], [0.0, 0.01]]
+    P = prior(fitargs, pd, fitpars_for(SPEC_PARS, npoly=4), [True, False, True, False, False])
+    np.testing.assert_allclose(P.priortrans_batch(g["blaze_u"]), g["blaze_theta"], rtol=1e-13)
+    np.testing.assert_allclose(np.array([P.priortrans(u) for u in g["blaze_u"]]), g["blaze_theta"], rtol=1e-13)
+
+
+def test_lnprior_additional(golden):
+    g = golden("g6_prior")
+    fitargs = {'fixedpars': {}}
+    pd = synth.demo_priordict()
+    pd['Teff']['gaussian'] = [5770.0, 50.0]
+    pd['[Fe/H]']['uniform'] = [-0.05, 0.08]
+    P = prior(fitargs, pd, fitpars_for(SPEC_PARS), [True, False, False, False, False])
+    np.testing.assert_allclose(P.priortrans_batch(g["lnprior_spec_u"]), g["lnprior_spec_theta"], rtol=1e-13)
+    got = P.lnprior_batch(g["lnprior_spec_theta"])
+    assert np.array_equal(np.isinf(got), np.isinf(g["lnprior_spec"])) and np.isinf(got).any()
+    ok = np.isfinite(got)
+    np.testing.assert_allclose(got[ok], g["lnprior_spec"][ok], rtol=1e-13)
+    pd = synth.demo_priordict()
+    pd['Av'] = {'pv_uniform': [0.0, 1.0], 'gaussian': [0.1, 0.05], 'uniform': [0.02, 0.9]}
+    pd['log(A)'] = {'pv_uniform': [-3.0, 7.0]}
+    P = prior(fitargs, pd, fitpars_for(SPEC_PARS + ['log(A)', 'Av']), [True, True, False, True, False])
+    got = P.lnprior_batch(g["lnprior_joint_theta"])
+    assert np.array_equal(np.isinf(got), np.isinf(g["lnprior_joint"]))
+    ok = np.isfinite(got)
+    np.testing.assert_allclose(got[ok], g["lnprior_joint"][ok], rtol=1e-13)
+    # demo priors: no additional priors -> exactly 0.0 (prior.py:364-365)
+    P = prior(fitargs, synth.demo_priordict(), fitpars_for(SPEC_PARS), [True, False, False, False, False])
+    assert P.lnpriorfn([5770.0, 4.4, 0, 0, 10, 3, 28000.0]) == 0.0
+
+
+def test_advanced_priors_are_refused():
+    with pytest.raises(NotImplementedError):
+        prior({'fixedpars': {}}, {'IMF': {'IMF_type': 'Kroupa'}}, fitpars_for(SPEC_PARS), [True, False, False, False, False])
+
+
+def test_fitutils(golden):
+    g = golden("g7_misc")
+    for c, ref in zip(g["coefs"], g["poly"]):
+        np.testing.assert_allclose(fitutils.polycalc(c, g["wave"]), ref, atol=1e-14)
+    np.testing.assert_allclose(fitutils.airtovacuum(g["air"]), g["vac"], rtol=1e-14)
+    np.testing.assert_allclose(fitutils.vacuumtoair(fitutils.airtovacuum(g["air"])), g["air"], rtol=2e-8)
+
+
+def test_c_abi_library_loads_and_exports_the_header():
+    """Every function include/payne_hip.h declares is exported by the built library
+    (no compute calls here: no GPU)."""
+    from thepayne_amd.build import build_lib
+    from thepayne_amd import _lib
+    path = build_lib()
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "payne_hip.h")).read()
+    declared = set(re.findall(r"\b(payne_[a-z_]+)\s*\(", hdr))
+    declared -= {"payne_ctx"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    L = _lib.load(path)
+    assert L.payne_version() == _lib.ABI_VERSION
+    assert L.payne_kernel_name(1) == b"payne_post_kernel"
+    # struct layouts agree with the header's field order (sizes on LP64)
+    assert ctypes.sizeof(_lib.Layer) == 32 and ctypes.sizeof(_lib.Opts) == 12
+    assert ctypes.sizeof(_lib.ModelDesc) == 8 + 8 * 32 + 8 + 8 + 8 + 8 + 8 + 8
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from thepayne_amd.engine import PayneEngine
+    from thepayne_amd import nnio
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PayneEngine(nnio.normalize_spec_net(synth.make_yst_net(npix=256, H=16)))

@@ -15,7 +15,7 @@ F_FWHM_R = 1
 ABI_VERSION = 1
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_destroy", "payne_last_error",
-           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_kernel_name",
+           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
            "payne_profile", "payne_profile_read"]
 
 _dp = C.POINTER(C.c_double)
@@ -91,6 +91,8 @@ def load(path=None):
     lib.payne_predict_batch.restype = C.c_int
     lib.payne_sed_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.payne_sed_batch.restype = C.c_int
+    lib.payne_bc_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.payne_bc_batch.restype = C.c_int
     lib.payne_profile.argtypes = [ctxp, C.c_int]
     lib.payne_profile.restype = C.c_int
     lib.payne_profile_read.argtypes = [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]

@@ -35,6 +35,20 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+DIAG_LIB = os.path.join(HERE, "libpayne_hip_diag.so")
+
+
+def build_diag(verbose=False):
+    """Diagnostic twin with per-phase cycle stamps in the post kernel (-DPAYNE_STAMPS);
+    used by tools/post_stamps.py only, never by the product path."""
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-DPAYNE_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", DIAG_LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
+    return DIAG_LIB
+
+
 def build_lib(force=False, verbose=False):
     """Compile csrc/*.hip -> thepayne_amd/libpayne_hip.so; returns the path."""
     if not force and not _stale():

@@ -22,7 +22,17 @@ struct HostTables {
   std::vector<float> rs1_frac, bk1_frac, obs_f1, obs_ivar;
   double vs_val = 0, obs_min = 0, obs_max = 0, geo_inv_dln = 0;
   bool has_flux = false;
+  int geo = 0;
+  double ln0 = 0, dln = 0, ln_last = 0;
+  std::vector<double> vs_tab;
 };
+
+// copy the model-side scalars into the device-facing struct (pointers are set by the owner)
+inline void fill_model_scalars(const HostTables& H, PostTables& T) {
+  T.npix = H.npix; T.n1 = H.n1; T.nmax = H.nmax; T.vs_val = H.vs_val;
+  T.geo_inv_dln = H.geo_inv_dln; T.geo = H.geo; T.ln0 = H.ln0; T.dln = H.dln; T.ln_last = H.ln_last;
+  T.vs_tab_n = (int)H.vs_tab.size();
+}
 
 // numpy.linspace(start, stop, n)
 inline void linspace(double start, double stop, int n, std::vector<double>& y) {
@@ -55,6 +65,30 @@ inline int build_model_tables(const double* wave, int npix, HostTables& H) {
   H.lnlam.resize(npix);
   for (int i = 0; i < npix; ++i) H.lnlam[i] = std::log(wave[i]);
   H.geo_inv_dln = (double)(npix - 1) / (H.lnlam[npix - 1] - H.lnlam[0]);
+  H.ln0 = H.lnlam[0]; H.ln_last = H.lnlam[npix - 1];
+  H.dln = (H.ln_last - H.ln0) / (double)(npix - 1);
+  double dev = 0.0;
+  for (int i = 0; i < npix; ++i) dev = std::max(dev, std::fabs(H.lnlam[i] - (H.ln0 + (double)i * H.dln)));
+  H.geo = (dev < 1e-12) ? 1 : 0;            // < 3e-7 of a pixel even at R ~ 1e5
+  // vsini taper table sb(i*h), i = 0 .. kVsTabMax/h + 2
+  const int nt = (int)(kVsTabMax / kVsTabStep) + 3;
+  H.vs_tab.resize(nt);
+  H.vs_tab[0] = 1.0;
+  for (int i = 1; i < nt; ++i) {
+    const double u = (double)i * kVsTabStep;
+    // below u ~ 0.3 the closed form cancels catastrophically even in fp64 (terms ~ 1/u^2):
+    // use the even power series sb = sum_n c_n u^(2n), c_n from J1(u)/u and 3(sin u - u cos u)/(2u^3)
+    if (u < 0.5) {
+      const double z = u * u;
+      // J1(u)/u = 1/2 - z/16 + z^2/384 - z^3/18432 + z^4/1474560 - ...
+      // 3(sin u - u cos u)/(2 u^3) = 1/2 - z/20 + z^2/560 - z^3/30240 + z^4/2661120 - ...
+      const double a = 0.5 + z * (-1.0 / 16 + z * (1.0 / 384 + z * (-1.0 / 18432 + z * (1.0 / 1474560 + z * (-1.0 / 176947200)))));
+      const double b = 0.5 + z * (-1.0 / 20 + z * (1.0 / 560 + z * (-1.0 / 30240 + z * (1.0 / 2661120 + z * (-1.0 / 345945600)))));
+      H.vs_tab[i] = a + b;
+    } else {
+      H.vs_tab[i] = vsini_sb_exact(u);
+    }
+  }
   // vsini grid: w = exp(linspace(ln wmin, ln wmax, n1))
   std::vector<double> lnw, w(H.n1);
   linspace(std::log(wave[0]), std::log(wave[npix - 1]), H.n1, lnw);

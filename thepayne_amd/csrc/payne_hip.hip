@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -187,6 +188,82 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
   }
 }
 
+
+// ----------------------------------------------------------------------------
+// Hidden layers are tiny GEMMs ([B x H] x [H x H], ~0.1 GFLOP): one wave per 16x16 output
+// tile (hundreds of independent waves) with v_mfma_f32_16x16x4_f32, fragments read straight
+// from L2 as float4 (lane (r, g) holds 4 consecutive k of row r at offset 4g; MFMA step t
+// contracts k = {4g + t}, identically on both operands), two accumulators to cover the
+// 40-cycle dependent-issue latency.  No LDS, no barriers: latency ~ K/4 MFMAs.
+// ----------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool FUSE_L0>
+__global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
+  const int tm = blockIdx.x / p.grid_n, tn = blockIdx.x - tm * p.grid_n;
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+  const int row = tm * 16 + r, col = tn * 16 + r;
+  const bool rowok = row < p.B, colok = col < p.N;
+  float xh[PAYNE_MAX_LABELS];
+  if (FUSE_L0) {
+#pragma unroll
+    for (int d = 0; d < PAYNE_MAX_LABELS; ++d) {
+      xh[d] = 0.f;
+      if (d < p.n_labels && rowok) {
+        const double x = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)];
+        xh[d] = (float)((x - p.xmin[d]) / p.xden[d] - 0.5);
+      }
+    }
+  }
+  f32x4_t acc[2];
+  acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float* wrow = p.W + (size_t)(colok ? col : 0) * p.K;
+  const float* xrow = FUSE_L0 ? nullptr : p.X + (size_t)(rowok ? row : 0) * p.ldx;
+#pragma unroll 2
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + h * 16 + 4 * g;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (k < p.K) {
+        if (colok) b = *reinterpret_cast<const float4*>(wrow + k);
+        if (FUSE_L0) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = 0.f;
+            if (k + j < p.K0 && rowok) {
+              float z = p.b0[k + j];
+              const float* w0 = p.W0 + (size_t)(k + j) * p.n_labels;
+#pragma unroll
+              for (int d = 0; d < PAYNE_MAX_LABELS; ++d)
+                if (d < p.n_labels) z = fmaf(w0[d], xh[d], z);
+              o[j] = act_apply(z, p.act0);
+            }
+          }
+          a = make_float4(o[0], o[1], o[2], o[3]);
+        } else if (rowok) {
+          a = *reinterpret_cast<const float4*>(xrow + k);
+        }
+      }
+      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[h], 0, 0, 0);
+      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[h], 0, 0, 0);
+      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[h], 0, 0, 0);
+      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[h], 0, 0, 0);
+    }
+  }
+  // C/D map of the 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg
+  if (colok) {
+    const float bv = p.bias[col] - p.bias_shift;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int orow = tm * 16 + 4 * g + q;
+      if (orow < p.B) p.Y[(size_t)orow * p.ldy + col] = act_apply(acc[0][q] + acc[1][q] + bv, p.act);
+    }
+  }
+}
+
 // ============================================================================
 // per-candidate spectrum pipeline
 // ============================================================================
@@ -198,13 +275,22 @@ struct PostArgs {
   double* lnl;                       // [B] or null
   const double* mags; int n_filters; // SED magnitudes of this batch (null: no photometry)
   const double* obs_mag; const double* obs_err;
+  unsigned long long* stamps;        // diagnostic build: [B][64] cycle stamps (slot 0 = count)
 };
 
 struct DevExec {
+#ifdef PAYNE_STAMPS
+  // diagnostic build only (libpayne_hip_diag.so): cycle stamp after every phase barrier
+  unsigned long long* stamps = nullptr;
+  int nst = 0;
+#endif
   template <class F>
   __device__ __forceinline__ void par(F&& f) {
     f((int)threadIdx.x, (int)blockDim.x);
     __syncthreads();
+#ifdef PAYNE_STAMPS
+    if (stamps && threadIdx.x == 0 && nst < 63) stamps[++nst] = __builtin_amdgcn_s_memtime();
+#endif
   }
   __device__ __forceinline__ void imin(int* p, int v) { atomicMin(p, v); }
   __device__ __forceinline__ void imax(int* p, int v) { atomicMax(p, v); }
@@ -224,6 +310,13 @@ __global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs 
   CandState* S = reinterpret_cast<CandState*>(red + 256 + 16 + 1);
   const int b = blockIdx.x;
   DevExec ex;
+#ifdef PAYNE_STAMPS
+  if (a.stamps) {
+    ex.stamps = a.stamps + (size_t)b * 64;
+    if (threadIdx.x == 0) { ex.stamps[1] = __builtin_amdgcn_s_memtime(); }
+    ex.nst = 1;
+  }
+#endif
   run_candidate(ex, T, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw, bufA, bufB,
                 *S, red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, &red[256 + 16]);
   if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
@@ -231,6 +324,9 @@ __global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs 
     if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
     a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
   }
+#ifdef PAYNE_STAMPS
+  if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
+#endif
 }
 
 // photometry-only fits: lnL = -0.5 chi2_sed
@@ -251,6 +347,8 @@ struct PhotTables {
 
 // mode 0: in = [logt,logg,feh,afe,av,rv,logl,dist,logA] (sed kwargs, NaN = absent)
 // mode 1: in = theta row; phot block at column `off` = [logA | logR, Dist, Av, Rv]
+// mode 2: in = [Teff,logg,feh,afe,av,rv]; output = the bolometric corrections themselves
+//         (fastANN.eval, photANN.py:125-131: no high-Av branch, no magnitude formula)
 __global__ void __launch_bounds__(64) payne_sed_kernel(PhotTables P, const double* in, int ld, int mode, int off,
                                                        int photscale, double* mags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -262,14 +360,16 @@ __global__ void __launch_bounds__(64) payne_sed_kernel(PhotTables P, const doubl
   double logt, logg, feh, afe, av, rv, logl = nan, dist = nan, logA = nan;
   if (mode == 0) {
     logt = r[0]; logg = r[1]; feh = r[2]; afe = r[3]; av = r[4]; rv = r[5]; logl = r[6]; dist = r[7]; logA = r[8];
+  } else if (mode == 2) {
+    logt = nan; logg = r[1]; feh = r[2]; afe = r[3]; av = r[4]; rv = r[5];
   } else {
     logt = log10(r[0]); logg = r[1]; feh = r[2]; afe = r[3];      // genmod.py:124,172
     av = r[off + 2]; rv = 3.1;                                    // Rv never honoured: likelihood.py:104-106
     if (photscale) logA = r[off];                                 // genphot_scaled, genmod.py:157-187
     else { logl = 2.0 * r[off] + 4.0 * (logt - log10(5770.0)); dist = r[off + 1]; }   // genphot, genmod.py:126
   }
-  double x[6] = {pow(10.0, logt), logg, feh, afe, av, rv};        // predictsed.py:84
-  const bool hi = !(av < 5.0);                                    // predictsed.py:86-90
+  double x[6] = {mode == 2 ? r[0] : pow(10.0, logt), logg, feh, afe, av, rv};   // predictsed.py:84
+  const bool hi = (mode != 2) && !(av < 5.0);                     // predictsed.py:86-90
   if (hi) { x[4] = 0.0; x[5] = 3.1; }
   double xs[6];
 #pragma unroll
@@ -302,7 +402,8 @@ __global__ void __launch_bounds__(64) payne_sed_kernel(PhotTables P, const doubl
       BC = BC - offv;
     }
     double m;
-    if (!(logl != logl) && !(dist != dist)) m = -2.5 * logl + 4.74 - BC + (5.0 * log10(dist) - 5.0);
+    if (mode == 2) m = BC;
+    else if (!(logl != logl) && !(dist != dist)) m = -2.5 * logl + 4.74 - BC + (5.0 * log10(dist) - 5.0);
     else if (!(logA != logA)) m = 5.0 * logA - 10.0 * (logt - log10(5770.0)) - 0.26 - BC;
     else m = nan;
     mags[(size_t)b * P.F + f] = m;
@@ -498,8 +599,9 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if (rc == -2) return bail(fail(c, PAYNE_E_INVALID, "model.wavelength must be strictly increasing"));
     if (c->H.n1 > 16384) return bail(fail(c, PAYNE_E_UNSUPPORTED, "npix > 16384: spectrum does not fit the LDS-resident pipeline"));
     PostTables& T = c->T;
-    T.npix = c->H.npix; T.n1 = c->H.n1; T.nmax = c->H.nmax; T.vs_val = c->H.vs_val;
-    T.r_ann = model->resolution; T.geo_inv_dln = c->H.geo_inv_dln; T.npoly = opts->npoly;
+    fill_model_scalars(c->H, T);
+    T.r_ann = model->resolution; T.npoly = opts->npoly;
+    if ((rc = upload(c, c->H.vs_tab, &T.vs_tab, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lnlam, &T.lnlam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lam, &T.lam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.tw, &T.tw, c->owned))) return bail(rc);
@@ -581,6 +683,19 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
   hipLaunchKernelGGL((payne_dense_kernel<BM, BN, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
 }
 
+static int out_tile_choice() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+template <bool FUSE>
+static void launch_small(DenseParams& p, hipStream_t s) {
+  p.grid_m = (p.B + 15) / 16;
+  p.grid_n = (p.N + 15) / 16;
+  hipLaunchKernelGGL((payne_dense_small_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(64), 0, s, p);
+}
+
 // ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
 static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
   const int n = c->n_layers;
@@ -592,17 +707,22 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
     p.bias_shift = last ? kBase : 0.f;
     p.Y = last ? c->raw : c->hid[(l - 1) & 1];
     p.ldy = last ? c->T.npix : c->ld_hid;
+    ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
       const payne_layer& L0 = c->layers[0];
       p.theta = theta; p.ld_theta = c->ncols;
       p.W0 = L0.w; p.b0 = L0.b; p.n_labels = c->n_labels; p.act0 = L0.act; p.K0 = L0.n_out;
       for (int d = 0; d < c->n_labels; ++d) { p.xmin[d] = c->xmin[d]; p.xden[d] = c->xden[d]; }
-      ProfScope ps(c, s, last ? 0 : 3);
-      launch_dense<64, 64, true>(p, s);
+      if (last) launch_dense<64, 64, true>(p, s);
+      else launch_small<true>(p, s);
     } else {
       p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
-      ProfScope ps(c, s, last ? 0 : 3);
-      launch_dense<64, 64, false>(p, s);
+      if (!last) launch_small<false>(p, s);
+      else switch (out_tile_choice()) {
+        case 1: launch_dense<128, 64, false>(p, s); break;
+        case 2: launch_dense<64, 128, false>(p, s); break;
+        default: launch_dense<64, 64, false>(p, s); break;
+      }
     }
   }
   hipError_t e = hipGetLastError();
@@ -688,6 +808,13 @@ extern "C" int payne_sed_batch(payne_ctx* c, const double* pars, int B, double* 
   return run_sed(c, pars, 9, 0, B, mags, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int payne_bc_batch(payne_ctx* c, const double* x, int B, double* bc, void* stream) {
+  int rc = check_call(c, x, B, bc);
+  if (rc) return rc;
+  if (!c->has_phot) return fail(c, PAYNE_E_INVALID, "context has no photometric model");
+  return run_sed(c, x, 6, 2, B, bc, reinterpret_cast<hipStream_t>(stream));
+}
+
 // ---- per-kernel timing ---------------------------------------------------------
 extern "C" int payne_profile(payne_ctx* c, int enable) {
   if (!c) return PAYNE_E_INVALID;
@@ -714,3 +841,26 @@ extern "C" int payne_profile_read(payne_ctx* c, int kind, double* total_ms, long
   if (launches) *launches = c->prof_n[kind];
   return PAYNE_OK;
 }
+
+#ifdef PAYNE_STAMPS
+// Diagnostic build only: one lnlike batch with per-phase cycle stamps of the post kernel.
+// stamps: host [B][64] (slot 0 = number of stamps, slots 1.. = s_memtime after each barrier).
+extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, unsigned long long* stamps_host) {
+  int rc = check_call(c, theta, B, stamps_host);
+  if (rc) return rc;
+  unsigned long long* d = nullptr;
+  double* lnl = nullptr;
+  HIPCHK(c, hipMalloc(&d, (size_t)B * 64 * 8));
+  HIPCHK(c, hipMalloc(&lnl, (size_t)B * 8));
+  HIPCHK(c, hipMemset(d, 0, (size_t)B * 64 * 8));
+  if ((rc = run_ann(c, theta, B, nullptr))) return rc;
+  PostArgs a{};
+  a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
+  a.out_stage = -1; a.lnl = lnl; a.stamps = d;
+  hipLaunchKernelGGL(payne_post_kernel, dim3(B), dim3(256), c->post_lds, nullptr, c->T, a);
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d); (void)hipFree(lnl);
+  return PAYNE_OK;
+}
+#endif

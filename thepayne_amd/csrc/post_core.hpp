@@ -72,7 +72,17 @@ struct PostTables {
   double r_ann;            // sigma-based R of the ANN
   double geo_inv_dln;      // 1/mean(d lnlam): index guess for the resamplers
   int npoly;               // blaze coefficients (0: off)
+  // geometric ANN grid (readc3k construction): ln lam_k = ln0 + k*dln to < 1e-12, so
+  // pixel positions come from arithmetic instead of dependent loads of lnlam[]
+  int geo;
+  double ln0, dln, ln_last;   // ln0 = lnlam[0], ln_last = lnlam[npix-1] (always set)
+  // vsini taper sb(u) tabulated at u = i*kVsTabStep (host, fp64); cubic interpolation
+  const double* vs_tab;
+  int vs_tab_n;
 };
+
+constexpr double kVsTabStep = 1.0 / 64.0;
+constexpr double kVsTabMax = 256.0;
 
 // Per-candidate scalars, shared by the workgroup (lives in LDS).
 struct CandState {
@@ -140,10 +150,8 @@ PAYNE_HD int pass_radix(int M, int p) { int rem = M / p; return rem >= 8 ? 8 : r
 // ---------------------------------------------------------------------------
 // Tapers.
 // ---------------------------------------------------------------------------
-PAYNE_HD double vsini_taper(double vs_a, double vs_val, int k) {
-  // smoothing.py:612-620 (ss[0] hack irrelevant: sb[0] is overwritten with 1)
-  if (k == 0) return 1.0;
-  double ub = vs_a * ((double)k * vs_val);
+// sb(ub) of smoothing.py:616-617 evaluated directly in fp64
+PAYNE_HD double vsini_sb_exact(double ub) {
   double s, c;
 #ifdef __HIP_DEVICE_COMPILE__
   sincos(ub, &s, &c);
@@ -152,6 +160,23 @@ PAYNE_HD double vsini_taper(double vs_a, double vs_val, int k) {
 #endif
   double u2 = ub * ub;
   return j1(ub) / ub - 3.0 * c / (2.0 * u2) + 3.0 * s / (2.0 * (u2 * ub));
+}
+// 4-point Lagrange interpolation in the host-built table (|error| < 1e-9); sb is even in u.
+PAYNE_HD double vsini_sb_table(const double* tab, double ub) {
+  const double t = ub * (1.0 / kVsTabStep);
+  const int i = (int)t;
+  const double f = t - (double)i;
+  const double ym = tab[i > 0 ? i - 1 : 1], y0 = tab[i], y1 = tab[i + 1], y2 = tab[i + 2];
+  const double fm1 = f - 1.0, fm2 = f - 2.0, fp1 = f + 1.0;
+  return (-f * fm1 * fm2 * (1.0 / 6.0)) * ym + (fp1 * fm1 * fm2 * 0.5) * y0 + (-fp1 * f * fm2 * 0.5) * y1 +
+         (fp1 * f * fm1 * (1.0 / 6.0)) * y2;
+}
+PAYNE_HD double vsini_taper(const double* tab, double vs_a, double vs_val, int k) {
+  // smoothing.py:612-620 (ss[0] hack irrelevant: sb[0] is overwritten with 1)
+  if (k == 0) return 1.0;
+  const double ub = vs_a * ((double)k * vs_val);
+  if (tab && ub < kVsTabMax) return vsini_sb_table(tab, ub);
+  return vsini_sb_exact(ub);          // NaN/huge arguments and the far tail
 }
 PAYNE_HD float gauss_taper(double g_a, double g_val, int k) {
   // smoothing.py:598-599: exp(-2 pi^2 sigma^2 ss^2), ss = k/(n dv)
@@ -165,13 +190,13 @@ PAYNE_HD float gauss_taper(double g_a, double g_val, int k) {
 // Thread handles the conjugate pair (k, M-k); tw_n-th roots supply exp(-2 pi i k/2M).
 template <bool VSINI>
 PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* tw, int tw_n,
-                               double ta, double tval) {
+                               double ta, double tval, const double* vs_tab) {
   const int ts = tw_n / (2 * M);
   const float g = 0.25f / (float)M;
   for (int k = tid; k <= M / 2; k += nthr) {
     const int mk = M - k;
-    float tk = VSINI ? (float)vsini_taper(ta, tval, k) : gauss_taper(ta, tval, k);
-    float tm = VSINI ? (float)vsini_taper(ta, tval, mk) : gauss_taper(ta, tval, mk);
+    float tk = VSINI ? (float)vsini_taper(vs_tab, ta, tval, k) : gauss_taper(ta, tval, k);
+    float tm = VSINI ? (float)vsini_taper(vs_tab, ta, tval, mk) : gauss_taper(ta, tval, mk);
     if (k == 0) {
       c32 z0 = Z[0];
       float x0 = tk * (z0.x + z0.y), xm = tm * (z0.x - z0.y);
@@ -203,6 +228,24 @@ PAYNE_HD int locate(const double* x, int lo, int hi, double v, int guess) {
   while (k < hi - 2 && v >= x[k + 1]) ++k;
   return k;
 }
+// Position of ln-wavelength v on the ANN grid restricted to pixels [lo, hi): pixel k with
+// lnlam[k] <= v < lnlam[k+1] (clamped), u = v - lnlam[k], dv = lnlam[k+1] - lnlam[k].
+PAYNE_HD void grid_locate(const PostTables& T, int lo, int hi, double v, int& k, double& u, double& dv) {
+  if (T.geo) {
+    k = (int)((v - T.ln0) * T.geo_inv_dln);
+    k = k < lo ? lo : (k > hi - 2 ? hi - 2 : k);
+    u = v - (T.ln0 + (double)k * T.dln);
+    dv = T.dln;
+    if (u < 0.0 && k > lo) { --k; u += dv; }
+    else if (u >= dv && k < hi - 2) { ++k; u -= dv; }
+  } else {
+    const int guess = lo + (int)((v - T.lnlam[lo]) * T.geo_inv_dln);
+    k = locate(T.lnlam, lo, hi, v, guess);
+    u = v - T.lnlam[k];
+    dv = T.lnlam[k + 1] - T.lnlam[k];
+  }
+}
+
 // interpolation weight from log-space offsets: expm1(u)/expm1(v)
 PAYNE_HD float lerp_weight(double u, double v) {
   float uf = (float)u, vf = (float)v;
@@ -296,13 +339,11 @@ PAYNE_HD void phase_window(int tid, const PostTables& T, CandState& S) {
 // R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
 PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S,
                                const float* spec, float* work) {
-  const double base = T.lnlam[S.i0];
   for (int j = tid; j < S.n2; j += nthr) {
     double lw = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
     double v = lw - S.dop;                               // position on the unshifted ANN grid
-    int guess = S.i0 + (int)((v - base) * T.geo_inv_dln);
-    int k = locate(T.lnlam, S.i0, S.i1, v, guess);
-    double u = v - T.lnlam[k], dv = T.lnlam[k + 1] - T.lnlam[k];
+    int k; double u, dv;
+    grid_locate(T, S.i0, S.i1, v, k, u, dv);
     float a = nan_to_zero(spec[k]), b = nan_to_zero(spec[k + 1]);
     float out;
     if (u <= 0.0) out = a;                               // np.interp clamps (default left/right)
@@ -339,11 +380,10 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
       }
     } else {
       double v = lo - S.dop;
-      if (v < T.lnlam[0] || v > T.lnlam[T.npix - 1]) m1 = nanf_();
+      if (v < T.ln0 || v > T.ln_last) m1 = nanf_();
       else {
-        int guess = (int)((v - T.lnlam[0]) * T.geo_inv_dln);
-        int k = locate(T.lnlam, 0, T.npix, v, guess);
-        double u = v - T.lnlam[k], dv = T.lnlam[k + 1] - T.lnlam[k];
+        int k; double u, dv;
+        grid_locate(T, 0, T.npix, v, k, u, dv);
         float a = conv[k], b = conv[k + 1];
         float w = lerp_weight(u, dv);
         w = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);

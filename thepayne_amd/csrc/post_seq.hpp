@@ -49,7 +49,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const double* th, doub
     ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
     const int M = T.n1 / 2;
     c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, T.tw, T.nmax, false);
-    ex.par([&](int t, int n) { rfft_taper_phase<true>(t, n, z, M, T.tw, T.nmax, S.vs_a, T.vs_val); });
+    ex.par([&](int t, int n) { rfft_taper_phase<true>(t, n, z, M, T.tw, T.nmax, S.vs_a, T.vs_val, T.vs_tab); });
     c32* zo = ((float*)z == bufA) ? (c32*)bufB : (c32*)bufA;
     c32* y = fft_run(ex, z, zo, M, T.tw, T.nmax, true);
     float* conv = (float*)y;
@@ -75,7 +75,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const double* th, doub
       ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, spec, work); });
       const int M = S.n2 / 2;
       c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, T.tw, T.nmax, false);
-      ex.par([&](int t, int n) { rfft_taper_phase<false>(t, n, z, M, T.tw, T.nmax, S.g_a, S.g_val); });
+      ex.par([&](int t, int n) { rfft_taper_phase<false>(t, n, z, M, T.tw, T.nmax, S.g_a, S.g_val, nullptr); });
       c32* zo = ((float*)z == bufA) ? (c32*)bufB : (c32*)bufA;
       on_grid = (const float*)fft_run(ex, z, zo, M, T.tw, T.nmax, true);
     }

@@ -56,7 +56,8 @@ class PayneEngine(object):
         self.b_max = int(b_max)
         self.npoly = int(npoly)
         self.photscale = bool(photscale)
-        self._keep = []          # tensors / arrays whose memory the context references
+        self._keep = []          # device tensors whose memory the context references
+        self._host_keep = []     # host arrays referenced by descriptors during a call
         self._ctx = C.c_void_p()
         self.spec_net = spec_net
         self.phot = phot
@@ -71,6 +72,7 @@ class PayneEngine(object):
             pdesc = self._phot_desc(phot, obs_phot)
         opts = _lib.Opts(self.b_max, self.npoly, int(self.photscale))
         rc = self.lib.payne_ctx_create(mdesc, odesc, pdesc, C.byref(opts), self.device.index, C.byref(self._ctx))
+        self._release_host()
         if rc != 0:
             raise RuntimeError("payne_ctx_create failed (%d): %s" % (rc, self.lib.payne_last_error(None).decode()))
         self.ncols = self.lib.payne_theta_cols(self._ctx)
@@ -83,8 +85,15 @@ class PayneEngine(object):
         return t
 
     def _host(self, a):
-        # read by the library during the call only; the ctypes pointer made from it keeps it alive
-        return np.ascontiguousarray(a, dtype=np.float64)
+        # Host arrays are read by the library during the create/set_obs call only, but a pointer
+        # stored in a ctypes Structure field does NOT keep its numpy array alive: hold them here
+        # until the call has returned (_release_host).
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self._host_keep.append(a)
+        return a
+
+    def _release_host(self):
+        self._host_keep = []
 
     def _model_desc(self, net):
         d = _lib.ModelDesc()
@@ -115,7 +124,7 @@ class PayneEngine(object):
             d.flux = _dptr(self._host(flux))
             d.eflux = _dptr(self._host(eflux))
         self.nobs = d.nobs
-        self.obs_wave = wave
+        self.obs_wave = wave.copy()
         return d
 
     def _phot_desc(self, phot, obs_phot):
@@ -165,6 +174,7 @@ class PayneEngine(object):
         """Re-bind the observed grid (payne_ctx_set_obs)."""
         d = self._obs_desc(wave, flux, eflux)
         rc = self.lib.payne_ctx_set_obs(self._ctx, C.byref(d))
+        self._release_host()
         if rc != 0:
             self._err(rc, "payne_ctx_set_obs")
 
@@ -211,6 +221,18 @@ class PayneEngine(object):
             rc = self.lib.payne_sed_batch(self._ctx, t[s:s + n].data_ptr(), n, out[s:s + n].data_ptr(), self._stream())
             if rc != 0:
                 self._err(rc, "payne_sed_batch")
+        return out
+
+    def bc_batch(self, x):
+        """Bolometric corrections [B, F] fp64 for x [B, 6] = Teff,logg,feh,afe,av,rv."""
+        t = self._theta(x, 6)
+        B = t.shape[0]
+        out = self.torch.empty((B, self.n_filters), dtype=self.torch.float64, device=self.device)
+        for s in range(0, B, self.b_max):
+            n = min(self.b_max, B - s)
+            rc = self.lib.payne_bc_batch(self._ctx, t[s:s + n].data_ptr(), n, out[s:s + n].data_ptr(), self._stream())
+            if rc != 0:
+                self._err(rc, "payne_bc_batch")
         return out
 
     def profile(self, enable):

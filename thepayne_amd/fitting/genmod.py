@@ -1,0 +1,121 @@
+"""Model generation: mirrors Payne/fitting/genmod.py (GenMod).
+
+One ``PayneEngine`` carries the spectral emulator, the observed grid and the photometric
+emulator of a fit; ``genspec`` / ``genphot`` / ``genphot_scaled`` evaluate one parameter
+list through it (API parity, B = 1) and the ``*_batch`` methods are what the batched
+likelihood uses."""
+import numpy as np
+
+from .. import nnio
+from ..engine import PayneEngine
+
+
+class GenMod(object):
+    def __init__(self, *arg, **kwargs):
+        self.verbose = kwargs.get('verbose', False)
+        self.device = kwargs.get('device', None)
+        self.b_max = kwargs.get('b_max', 512)
+        self._spec_net = None
+        self._phot = None
+        self._obs = None
+        self._obs_phot = None
+        self._npoly = 0
+        self._photscale = False
+        self._engine = None
+        self.filterarray = None
+
+    # -- configuration (engine is (re)built lazily from these) -------------------
+    def _initspecnn(self, nnpath=None, **kwargs):
+        """genmod.py:15-32: NNtype 'YST1' -> ystpred layout, anything else -> predictspec."""
+        self.NNtype = kwargs.get('NNtype', 'YST1')
+        if kwargs.get('Cnnpath', None) is not None:
+            raise NotImplementedError("continuum ANN (Cnnpath) is not built")
+        self._spec_net = nnio.load_spec_net(nnpath, self.NNtype)
+        self._engine = None
+
+    def _initphotnn(self, filterarray, nnpath=None):
+        """genmod.py:35-43."""
+        from ..predict.predictsed import _ALLFILTERS
+        self.filterarray = list(filterarray) if filterarray is not None else list(_ALLFILTERS)
+        self._phot = nnio.load_phot_nets(self.filterarray, nnpath)
+        self._engine = None
+
+    def configure(self, obs=None, obs_phot=None, npoly=0, photscale=False):
+        """Bind the data side of the fit (observed spectrum / magnitudes, blaze order)."""
+        self._obs, self._obs_phot, self._npoly, self._photscale = obs, obs_phot, int(npoly), bool(photscale)
+        self._engine = None
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = PayneEngine(self._spec_net, obs=self._obs, phot=self._phot, obs_phot=self._obs_phot,
+                                       npoly=self._npoly, photscale=self._photscale, b_max=self.b_max,
+                                       device=self.device)
+        return self._engine
+
+    # -- reference API (one parameter list) --------------------------------------
+    def genspec(self, pars, outwave=None, verbose=False, modpoly=False, carbon_bool=False):
+        """(wave, flux) for pars = [Teff, logg, FeH, aFe, Vrad, Vrot, Vmic, Inst_R, pc...]
+        (genmod.py:58-108).  Inst_R is FWHM-based; the 2.355 factor is applied on the GPU."""
+        pars = list(pars)
+        if not isinstance(pars[7], float):
+            raise NotImplementedError("LSF-vector Inst_R is not built yet")
+        eng = self.engine
+        polycoef = pars[8:] if modpoly else []
+        if modpoly and len(polycoef) != eng.npoly:
+            raise ValueError("engine configured for %d blaze coefficients, got %d" % (eng.npoly, len(polycoef)))
+        th = np.full((1, eng.ncols), np.nan)
+        th[0, :8] = pars[:8]
+        if modpoly:
+            th[0, 8:8 + eng.npoly] = polycoef
+        if outwave is not None:
+            outwave = np.ascontiguousarray(outwave, dtype=np.float64)
+            if self._obs is None or outwave is not self._obs[0]:
+                if eng.nobs != len(outwave) or not np.array_equal(eng.obs_wave, outwave):
+                    raise ValueError("genspec(outwave=...) must be the grid bound with configure(obs=...)")
+            flux = eng.predict_batch(th, stage=3 if modpoly else 2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+            return outwave, flux
+        raise NotImplementedError("genspec without outwave: use PayneSpecPredict.getspec")
+
+    def _phot_theta(self, pars, scaled):
+        eng = self.engine
+        th = np.full((1, eng.ncols), np.nan)
+        th[0, 0:4] = pars[0:4]
+        off = eng.phot_off
+        if scaled:
+            th[0, off], th[0, off + 2] = pars[4], pars[5]
+        else:
+            th[0, off], th[0, off + 1], th[0, off + 2] = pars[4], pars[5], pars[6]
+        return th
+
+    def _sed_rows(self, theta_full, scaled):
+        """theta rows -> the 9 sed() kwargs per row (genmod.py:110-187)."""
+        eng = self.engine
+        off = eng.phot_off
+        th = np.asarray(theta_full, dtype=np.float64)
+        logt = np.log10(th[:, 0])
+        rows = np.full((th.shape[0], 9), np.nan)
+        rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3] = logt, th[:, 1], th[:, 2], th[:, 3]
+        rows[:, 4], rows[:, 5] = th[:, off + 2], 3.1
+        if scaled:
+            rows[:, 8] = th[:, off]
+        else:
+            rows[:, 6] = 2.0 * th[:, off] + 4.0 * (logt - np.log10(5770.0))
+            rows[:, 7] = th[:, off + 1]
+        return rows
+
+    def genphot(self, pars, rvfree=False, verbose=False):
+        """{filter: mag} from [Teff, logg, FeH, aFe, logR, Dist, Av(, Rv)] (genmod.py:110-155)."""
+        rows = self._sed_rows(self._phot_theta(pars, False), False)
+        if rvfree:
+            rows[:, 5] = pars[7]
+        sed = self.engine.sed_batch(rows).cpu().numpy()[0]
+        return {ff: m for m, ff in zip(sed, self.filterarray)}
+
+    def genphot_scaled(self, pars, rvfree=False, verbose=False):
+        """{filter: mag} from [Teff, logg, FeH, aFe, logA, Av(, Rv)] (genmod.py:157-187)."""
+        rows = self._sed_rows(self._phot_theta(pars, True), True)
+        if rvfree:
+            rows[:, 5] = pars[6]
+        sed = self.engine.sed_batch(rows).cpu().numpy()[0]
+        return {ff: m for m, ff in zip(sed, self.filterarray)}

@@ -1,0 +1,148 @@
+"""Shared implementation of the two spectral predictors.
+
+``Payne.predict.ystpred.PayneSpecPredict`` (numpy YST1 net) and
+``Payne.predict.predictspec.PayneSpecPredict`` (torch LinNet/SMLP) have the same
+``getspec`` body (Payne/predict/ystpred.py:119-277 == predictspec.py:136-294); here
+both are one class whose arithmetic runs in the HIP engine.  New: ``getspec_batch``.
+"""
+import numpy as np
+
+from .. import nnio
+from ..engine import PayneEngine
+
+speedoflight = 299792.458            # scipy.constants.c / 1000 (ystpred.py:11-12)
+
+
+class SpecANN(object):
+    """The emulator object the reference exposes as ``.anns``: ``Net``
+    (ystpred.py:18-58) / ``ANN`` (predictspec.py:29-74).  ``eval(labels)`` returns
+    the raw ANN spectrum on ``wavelength``."""
+
+    def __init__(self, nnpath, NNtype, b_max=256, device=None):
+        self.nnpath = nnpath
+        self.NNtype = NNtype
+        self.net = nnio.load_spec_net(nnpath, NNtype)
+        self.xmin = self.net["xmin"]
+        self.xmax = self.net["xmax"]
+        self.wavelength = self.net["wavelength"]
+        self.resolution = self.net["resolution"]
+        self.engine = PayneEngine(self.net, b_max=b_max, device=device)
+        self.n_labels = self.engine.n_labels
+
+    def _theta(self, labels):
+        labels = np.atleast_2d(np.asarray(labels, dtype=np.float64))
+        if labels.shape[1] != self.n_labels:
+            raise ValueError("this ANN takes %d labels, got %d" % (self.n_labels, labels.shape[1]))
+        th = np.full((labels.shape[0], self.engine.ncols), np.nan)
+        th[:, 0:4] = labels[:, 0:4]
+        if self.n_labels == 5:
+            th[:, 6] = labels[:, 4]
+        th[:, 4:6] = 0.0
+        return th
+
+    def eval(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        out = self.engine.predict_batch(self._theta(x), stage=0).cpu().numpy()
+        out = out.astype(np.float64) if self.NNtype in ("YST1", "YST2") else out
+        return out[0] if x.ndim == 1 else out
+
+
+class PayneSpecPredict(object):
+    """Predict spectra from a Payne-learned ANN (drop-in for the reference class)."""
+
+    default_NNtype = "YST1"
+
+    def __init__(self, nnpath=None, **kwargs):
+        self.NN = {}
+        if nnpath is None:
+            raise IOError("no default ANN ships with this build (the reference's data/ is empty too, "
+                          "README.md:45); pass nnpath=")
+        self.nnpath = nnpath
+        self.NNtype = kwargs.get('NNtype', self.default_NNtype)
+        self.anns = SpecANN(self.nnpath, self.NNtype, b_max=kwargs.get('b_max', 256), device=kwargs.get('device'))
+        self.Cnnpath = kwargs.get('Cnnpath', None)
+        if self.Cnnpath is not None:
+            raise NotImplementedError("continuum ANN (Cnnpath, ystpred.py:191-209) is not wired into FitPayne "
+                                      "in the reference and is not built here yet")
+        self.Canns = None
+        self._bound = None
+
+    # -- reference API -----------------------------------------------------------
+    def predictspec(self, labels):
+        """Raw ANN flux for [Teff, log(g), [Fe/H], [alpha/Fe] (, vmic)] (ystpred.py:84-99)."""
+        return self.anns.eval(labels)
+
+    def predictcont(self, labels):
+        raise NotImplementedError("continuum ANN not built (see __init__)")
+
+    @staticmethod
+    def _labels_from_kwargs(kwargs):
+        """Aliases and defaults of ystpred.py:132-165."""
+        if 'Teff' in kwargs:
+            teff = kwargs['Teff']
+        elif 'logt' in kwargs:
+            teff = 10.0 ** kwargs['logt']
+        else:
+            teff = 5770.0
+        logg = kwargs['log(g)'] if 'log(g)' in kwargs else kwargs.get('logg', 4.44)
+        feh = kwargs['[Fe/H]'] if '[Fe/H]' in kwargs else kwargs.get('feh', 0.0)
+        afe = 0.0
+        for k in ('[alpha/Fe]', '[a/Fe]', 'aFe', 'afe'):
+            if k in kwargs:
+                afe = kwargs[k]
+                break
+        return teff, logg, feh, afe
+
+    def _bind(self, outwave):
+        key = (len(outwave), float(outwave[0]), float(outwave[-1]), hash(outwave.tobytes()))
+        if self._bound != key:
+            self.anns.engine.set_obs(outwave)
+            self._bound = key
+
+    def getspec(self, **kwargs):
+        """(wave, flux) for one parameter set; kwargs as the reference's getspec."""
+        self.inputdict = {}
+        teff, logg, feh, afe = self._labels_from_kwargs(kwargs)
+        self.inputdict.update(teff=teff, logg=logg, feh=feh, afe=afe)
+        vmic = kwargs.get('vmic', np.nan)
+        vmic = vmic if (vmic is not None and np.isfinite(vmic)) else np.nan
+        self.inputdict['vmic'] = vmic
+        outwave = kwargs.get('outwave', None)
+        rot_vel = kwargs.get('rot_vel', 0.0)
+        rad_vel = kwargs.get('rad_vel', 0.0)
+        has_R = 'inst_R' in kwargs
+        inst_R = kwargs.get('inst_R', np.nan)
+        if has_R and not isinstance(inst_R, float):
+            raise NotImplementedError("LSF-vector inst_R (ystpred.py:248-269) is not built yet; pass a float "
+                                      "(np.float64 counts, np.float32/int do not -- as in the reference)")
+        eng = self.anns.engine
+        th = np.full((1, eng.ncols), np.nan)
+        th[0, :8] = [teff, logg, feh, afe, rad_vel, rot_vel, vmic, inst_R if has_R else np.nan]
+        modwave = self.anns.wavelength
+        if rad_vel != 0.0:
+            modwave = modwave * (1.0 + (rad_vel / speedoflight))
+        if outwave is None:
+            if has_R and inst_R > 0.0:
+                # smoothspec(outwave=None) -> output on the (shifted) model grid itself
+                self._bind(np.ascontiguousarray(modwave))
+                return modwave, eng.predict_batch(th, stage=2).cpu().numpy()[0].astype(np.float64)
+            return modwave, eng.predict_batch(th, stage=1).cpu().numpy()[0].astype(np.float64)
+        outwave = np.ascontiguousarray(outwave, dtype=np.float64)
+        self._bind(outwave)
+        return outwave, eng.predict_batch(th, stage=2).cpu().numpy()[0].astype(np.float64)
+
+    def smoothspec(self, wave, spec, sigma, outwave=None, **kwargs):
+        raise NotImplementedError("free-standing smoothspec on arbitrary spectra is not part of the batched path; "
+                                  "use getspec(rot_vel=..., inst_R=...)")
+
+    # -- new: batch API ------------------------------------------------------------
+    def getspec_batch(self, theta8, outwave, stage=2):
+        """theta8[B, 8] = Teff, logg, FeH, aFe, Vrad, Vrot, Vmic, inst_R (sigma-based R as
+        in getspec) -> flux[B, len(outwave)] (fp32 device tensor)."""
+        eng = self.anns.engine
+        theta8 = np.atleast_2d(theta8)
+        th = np.full((theta8.shape[0], eng.ncols), np.nan)
+        th[:, :8] = theta8
+        if stage >= 2:
+            self._bind(np.ascontiguousarray(outwave, dtype=np.float64))
+        return eng.predict_batch(th, stage=stage)
