@@ -39,7 +39,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
   T.npoly = npoly;
-  if (force_general) T.geo = 0;
+  if (force_general) { T.geo = 0; T.rot_identity = 0; }
   HostExec ex{nthreads};
   std::vector<float> a(H.n1), b(H.n1);
   std::vector<double> red(nthreads + 16);
@@ -47,7 +47,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
     CandState S;
     std::memset(&S, 0, sizeof(S));
     double x2 = 0.0;
-    run_candidate(ex, T, theta + (size_t)c * ncols, instr_factor, raw_m1 + (size_t)c * npix, a.data(), b.data(), S,
+    run_candidate(ex, T, T.tw, theta + (size_t)c * ncols, instr_factor, raw_m1 + (size_t)c * npix, a.data(), b.data(), S,
                   red.data(), out ? out + (size_t)c * ld_out : nullptr, out_stage, &x2);
     if (chi2) chi2[c] = x2;
     if (info) { info[3 * c] = S.i0; info[3 * c + 1] = S.i1 - S.i0; info[3 * c + 2] = S.n2; }

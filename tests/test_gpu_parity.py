@@ -106,7 +106,10 @@ def test_lnlike_joint_against_reference_golden(Engine, golden, tag, photscale):
     for j, n in enumerate(names):
         th[:, col[n]] = g["theta"][:, j]
     lnl = eng.lnlike_batch(th).cpu().numpy()
-    assert np.all(np.abs(lnl - g["lnlike"]) <= lnl_tol(g["lnlike"])), np.abs(lnl - g["lnlike"]).max()
+    ref = g["lnlike"]
+    assert np.array_equal(np.isnan(lnl), np.isnan(ref))          # one draw has Inst_R above the ANN's R -> NaN
+    ok = np.isfinite(ref)
+    assert np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok])), np.abs(lnl[ok] - ref[ok]).max()
 
 
 def test_sed_against_reference_golden(Engine, golden):

@@ -22,7 +22,7 @@ struct HostTables {
   std::vector<float> rs1_frac, bk1_frac, obs_f1, obs_ivar;
   double vs_val = 0, obs_min = 0, obs_max = 0, geo_inv_dln = 0;
   bool has_flux = false;
-  int geo = 0;
+  int geo = 0, rot_identity = 0;
   double ln0 = 0, dln = 0, ln_last = 0;
   std::vector<double> vs_tab;
 };
@@ -32,6 +32,7 @@ inline void fill_model_scalars(const HostTables& H, PostTables& T) {
   T.npix = H.npix; T.n1 = H.n1; T.nmax = H.nmax; T.vs_val = H.vs_val;
   T.geo_inv_dln = H.geo_inv_dln; T.geo = H.geo; T.ln0 = H.ln0; T.dln = H.dln; T.ln_last = H.ln_last;
   T.vs_tab_n = (int)H.vs_tab.size();
+  T.rot_identity = H.rot_identity;
 }
 
 // numpy.linspace(start, stop, n)
@@ -97,6 +98,20 @@ inline int build_model_tables(const double* wave, int npix, HostTables& H) {
   for (int j = 0; j < H.n1; ++j) interp_map(w[j], H.lam, false, H.rs1_idx[j], H.rs1_frac[j]);
   H.bk1_idx.resize(npix); H.bk1_frac.resize(npix);
   for (int i = 0; i < npix; ++i) interp_map(wave[i], w, true, H.bk1_idx[i], H.bk1_frac[i]);
+  // identity maps?  (geometric grid, npix a power of two: the resampled grid IS the ANN grid up
+  // to fp64 rounding; weights within 1e-9 of 0/1 change nothing in fp32)
+  H.rot_identity = (H.n1 == npix) ? 1 : 0;
+  for (int j = 0; j < H.n1 && H.rot_identity; ++j) {
+    const int src = H.rs1_idx[j] + (H.rs1_frac[j] > 0.5f ? 1 : 0);
+    const float off = H.rs1_frac[j] > 0.5f ? 1.f - H.rs1_frac[j] : H.rs1_frac[j];
+    if (src != j || off > 1e-9f) H.rot_identity = 0;
+  }
+  for (int i = 1; i + 1 < npix && H.rot_identity; ++i) {      // end points are overwritten afterwards
+    if (H.bk1_idx[i] < 0) { H.rot_identity = 0; break; }
+    const int src = H.bk1_idx[i] + (H.bk1_frac[i] > 0.5f ? 1 : 0);
+    const float off = H.bk1_frac[i] > 0.5f ? 1.f - H.bk1_frac[i] : H.bk1_frac[i];
+    if (src != i || off > 1e-9f) H.rot_identity = 0;
+  }
   // dv = ckms * median(diff(log(w)))   (smoothing.py:306-307)
   std::vector<double> d(H.n1 - 1);
   for (int j = 0; j + 1 < H.n1; ++j) d[j] = std::log(w[j + 1]) - std::log(w[j]);

@@ -229,17 +229,26 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
       if (k < p.K) {
         if (colok) b = *reinterpret_cast<const float4*>(wrow + k);
         if (FUSE_L0) {
-          float o[4];
+          float o[4] = {0.f, 0.f, 0.f, 0.f};
+          if (rowok && p.n_labels == 4 && k + 3 < p.K0) {          // common case: 5 wide loads per step
+            const float4 bb = *reinterpret_cast<const float4*>(p.b0 + k);
+            const float4* w0 = reinterpret_cast<const float4*>(p.W0 + (size_t)k * 4);
+            const float4 w0a = w0[0], w0b = w0[1], w0c = w0[2], w0d = w0[3];
+            o[0] = act_apply(fmaf(w0a.w, xh[3], fmaf(w0a.z, xh[2], fmaf(w0a.y, xh[1], fmaf(w0a.x, xh[0], bb.x)))), p.act0);
+            o[1] = act_apply(fmaf(w0b.w, xh[3], fmaf(w0b.z, xh[2], fmaf(w0b.y, xh[1], fmaf(w0b.x, xh[0], bb.y)))), p.act0);
+            o[2] = act_apply(fmaf(w0c.w, xh[3], fmaf(w0c.z, xh[2], fmaf(w0c.y, xh[1], fmaf(w0c.x, xh[0], bb.z)))), p.act0);
+            o[3] = act_apply(fmaf(w0d.w, xh[3], fmaf(w0d.z, xh[2], fmaf(w0d.y, xh[1], fmaf(w0d.x, xh[0], bb.w)))), p.act0);
+          } else if (rowok) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            o[j] = 0.f;
-            if (k + j < p.K0 && rowok) {
-              float z = p.b0[k + j];
-              const float* w0 = p.W0 + (size_t)(k + j) * p.n_labels;
+            for (int j = 0; j < 4; ++j) {
+              if (k + j < p.K0) {
+                float z = p.b0[k + j];
+                const float* w0 = p.W0 + (size_t)(k + j) * p.n_labels;
 #pragma unroll
-              for (int d = 0; d < PAYNE_MAX_LABELS; ++d)
-                if (d < p.n_labels) z = fmaf(w0[d], xh[d], z);
-              o[j] = act_apply(z, p.act0);
+                for (int d = 0; d < PAYNE_MAX_LABELS; ++d)
+                  if (d < p.n_labels) z = fmaf(w0[d], xh[d], z);
+                o[j] = act_apply(z, p.act0);
+              }
             }
           }
           a = make_float4(o[0], o[1], o[2], o[3]);
@@ -302,12 +311,20 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
   return s;
 }
 
+template <bool TW_LDS>
 __global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* bufA = reinterpret_cast<float*>(smem);
   float* bufB = bufA + T.n1;
   double* red = reinterpret_cast<double*>(bufB + T.n1);        // [256 + 16 + 1]
   CandState* S = reinterpret_cast<CandState*>(red + 256 + 16 + 1);
+  const c32* tw = T.tw;
+  if (TW_LDS) {   // first half circle of the twiddles into LDS (the FFT passes then never leave the CU)
+    c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
+    const int half = T.nmax >> 1;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) twl[i] = T.tw[i];
+    tw = twl;                                                 // made visible by the first phase barrier
+  }
   const int b = blockIdx.x;
   DevExec ex;
 #ifdef PAYNE_STAMPS
@@ -317,7 +334,7 @@ __global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs 
     ex.nst = 1;
   }
 #endif
-  run_candidate(ex, T, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw, bufA, bufB,
+  run_candidate(ex, T, tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw, bufA, bufB,
                 *S, red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, &red[256 + 16]);
   if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
     double x2 = red[256 + 16];
@@ -433,6 +450,7 @@ struct payne_ctx {
   int ld_hid = 0;
   float* raw = nullptr;
   size_t post_lds = 0;
+  bool post_tw_lds = false;
   bool obs_bound = false;
   // photometry
   bool has_phot = false, has_obs_phot = false;
@@ -615,8 +633,14 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
-    c->post_lds = (size_t)T.n1 * 8 + (256 + 16 + 1) * 8 + sizeof(CandState) + 16;
-    he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
+    c->post_lds = (size_t)T.n1 * 8 + (256 + 16 + 1) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
+    // twiddles in LDS while two workgroups still fit a CU (160 KiB); larger spectra read them from L2
+    c->post_tw_lds = (c->post_lds + (size_t)T.n1 * 4) <= 80 * 1024;
+    if (getenv("PAYNE_TW_GLOBAL")) c->post_tw_lds = false;
+    if (c->post_tw_lds) c->post_lds += (size_t)T.n1 * 4;
+    he = c->post_tw_lds
+             ? hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds)
+             : hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     c->has_model = true;
     if ((rc = bind_obs(c, obs))) return bail(rc);
@@ -764,7 +788,8 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
   {
     ProfScope ps(c, s, 1);
-    hipLaunchKernelGGL(payne_post_kernel, dim3(B), dim3(256), c->post_lds, s, c->T, a);
+    if (c->post_tw_lds) hipLaunchKernelGGL(payne_post_kernel<true>, dim3(B), dim3(256), c->post_lds, s, c->T, a);
+    else hipLaunchKernelGGL(payne_post_kernel<false>, dim3(B), dim3(256), c->post_lds, s, c->T, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("post launch: ") + hipGetErrorString(e));
@@ -857,7 +882,8 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d;
-  hipLaunchKernelGGL(payne_post_kernel, dim3(B), dim3(256), c->post_lds, nullptr, c->T, a);
+  if (c->post_tw_lds) hipLaunchKernelGGL(payne_post_kernel<true>, dim3(B), dim3(256), c->post_lds, nullptr, c->T, a);
+  else hipLaunchKernelGGL(payne_post_kernel<false>, dim3(B), dim3(256), c->post_lds, nullptr, c->T, a);
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(d); (void)hipFree(lnl);

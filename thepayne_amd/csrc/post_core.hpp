@@ -79,6 +79,7 @@ struct PostTables {
   // vsini taper sb(u) tabulated at u = i*kVsTabStep (host, fp64); cubic interpolation
   const double* vs_tab;
   int vs_tab_n;
+  int rot_identity;    // the vsini resampling maps are the identity (to fp32): skip them
 };
 
 constexpr double kVsTabStep = 1.0 / 64.0;
@@ -121,10 +122,17 @@ PAYNE_HD void dft8(c32* u) {
   u[3] = cadd(e3, w3o); u[7] = csub(e3, w3o);
 }
 
+// Twiddle exp(-2 pi i j / tw_n) from a table holding the first half circle only.
+PAYNE_HD c32 tw_get(const c32* tw, int half, int j) {
+  const c32 w = tw[j & (half - 1)];
+  return (j & half) ? c32{-w.x, -w.y} : w;
+}
+
 template <int R>
-PAYNE_HD void fft_pass(int tid, int nthr, const c32* src, c32* dst, int M, int p,
-                       const c32* tw, int tw_n, bool conj_out) {
+PAYNE_HD void fft_pass(int tid, int nthr, const c32* __restrict__ src, c32* __restrict__ dst, int M, int p,
+                       const c32* __restrict__ tw, int tw_n, bool conj_out) {
   const int nb = M / R;
+  const int half = tw_n >> 1;
   for (int i = tid; i < nb; i += nthr) {
     const int k = i & (p - 1);
     c32 u[R];
@@ -132,8 +140,11 @@ PAYNE_HD void fft_pass(int tid, int nthr, const c32* src, c32* dst, int M, int p
     for (int r = 0; r < R; ++r) u[r] = src[i + r * nb];
     if (p > 1) {
       const int ts = tw_n / (p * R);
+      c32 w[R];
 #pragma unroll
-      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
+      for (int r = 1; r < R; ++r) w[r] = tw_get(tw, half, (k * r) * ts);
+#pragma unroll
+      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
     }
     if (R == 8) dft8(u);
     else if (R == 4) dft4(u[0], u[1], u[2], u[3]);
@@ -162,7 +173,7 @@ PAYNE_HD double vsini_sb_exact(double ub) {
   return j1(ub) / ub - 3.0 * c / (2.0 * u2) + 3.0 * s / (2.0 * (u2 * ub));
 }
 // 4-point Lagrange interpolation in the host-built table (|error| < 1e-9); sb is even in u.
-PAYNE_HD double vsini_sb_table(const double* tab, double ub) {
+PAYNE_HD double vsini_sb_table(const double* __restrict__ tab, double ub) {
   const double t = ub * (1.0 / kVsTabStep);
   const int i = (int)t;
   const double f = t - (double)i;
@@ -187,34 +198,53 @@ PAYNE_HD float gauss_taper(double g_a, double g_val, int k) {
 // Middle step of a real convolution done with a half-length complex FFT.
 // In: Z = FFT_M(z), z[n] = s[2n] + i s[2n+1].  Out (in place): Y with
 // FFT_M(Y) = conj(z'), z'[n] = s'[2n] + i s'[2n+1], s' = irfft(rfft(s) * taper).
-// Thread handles the conjugate pair (k, M-k); tw_n-th roots supply exp(-2 pi i k/2M).
+// A thread owns conjugate pairs (k, M-k), k = 1..M/2-1, PU at a time (all loads of the PU
+// pairs are issued before any store: the pairs are disjoint, so this is safe in place);
+// the two self-conjugate bins k = 0 and k = M/2 go to the last two threads.
 template <bool VSINI>
-PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* tw, int tw_n,
+PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __restrict__ tw, int tw_n,
                                double ta, double tval, const double* vs_tab) {
+  constexpr int PU = 4;
   const int ts = tw_n / (2 * M);
-  const float g = 0.25f / (float)M;
-  for (int k = tid; k <= M / 2; k += nthr) {
-    const int mk = M - k;
-    float tk = VSINI ? (float)vsini_taper(vs_tab, ta, tval, k) : gauss_taper(ta, tval, k);
-    float tm = VSINI ? (float)vsini_taper(vs_tab, ta, tval, mk) : gauss_taper(ta, tval, mk);
-    if (k == 0) {
-      c32 z0 = Z[0];
-      float x0 = tk * (z0.x + z0.y), xm = tm * (z0.x - z0.y);
-      Z[0] = {0.5f * (x0 + xm) / (float)M, -0.5f * (x0 - xm) / (float)M};
-    } else if (k == mk) {
-      Z[k] = cscale(cconj(Z[k]), tk / (float)M);
-    } else {
-      c32 zk = Z[k], zm = cconj(Z[mk]);
-      c32 w = tw[k * ts];
-      c32 A = cadd(zk, zm);
-      c32 C = cmul(w, cmul_negi(csub(zk, zm)));
-      c32 S1 = cscale(cadd(A, C), tk * g), S2 = cscale(csub(A, C), tm * g);
-      c32 E = cadd(S1, S2);
-      c32 O = cmul(cconj(w), csub(S1, S2));
-      c32 iO = cmul_posi(O);
-      Z[k] = cconj(cadd(E, iO));
-      Z[mk] = csub(E, iO);
+  const float g = 0.25f / (float)M, invM = 1.0f / (float)M;
+  const int npair = M / 2 - 1;                        // k = 1 .. M/2-1
+  for (int base = tid; base < npair; base += PU * nthr) {
+    c32 zk[PU], zm[PU], w[PU];
+    float tk[PU], tm[PU];
+#pragma unroll
+    for (int q = 0; q < PU; ++q) {
+      const int k = 1 + base + q * nthr;
+      if (k <= npair) {
+        zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * ts];
+        tk[q] = VSINI ? (float)vsini_taper(vs_tab, ta, tval, k) : gauss_taper(ta, tval, k);
+        tm[q] = VSINI ? (float)vsini_taper(vs_tab, ta, tval, M - k) : gauss_taper(ta, tval, M - k);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < PU; ++q) {
+      const int k = 1 + base + q * nthr;
+      if (k <= npair) {
+        const c32 A = cadd(zk[q], zm[q]);
+        const c32 C = cmul(w[q], cmul_negi(csub(zk[q], zm[q])));
+        const c32 S1 = cscale(cadd(A, C), tk[q] * g), S2 = cscale(csub(A, C), tm[q] * g);
+        const c32 E = cadd(S1, S2);
+        const c32 iO = cmul_posi(cmul(cconj(w[q]), csub(S1, S2)));
+        Z[k] = cconj(cadd(E, iO));
+        Z[M - k] = csub(E, iO);
+      }
+    }
+  }
+  if (tid == nthr - 1) {                               // k = 0 with k = M (real bins X[0], X[M])
+    const float t0 = VSINI ? (float)vsini_taper(vs_tab, ta, tval, 0) : gauss_taper(ta, tval, 0);
+    const float tM = VSINI ? (float)vsini_taper(vs_tab, ta, tval, M) : gauss_taper(ta, tval, M);
+    const c32 z0 = Z[0];
+    const float x0 = t0 * (z0.x + z0.y), xm = tM * (z0.x - z0.y);
+    Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+  }
+  if (tid == (nthr > 1 ? nthr - 2 : 0) && M >= 2) {    // k = M/2 (self-conjugate)
+    const int k = M / 2;
+    const float th = VSINI ? (float)vsini_taper(vs_tab, ta, tval, k) : gauss_taper(ta, tval, k);
+    Z[k] = cscale(cconj(Z[k]), th * invM);
   }
 }
 
@@ -256,51 +286,112 @@ PAYNE_HD float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
 PAYNE_HD int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 // ---------------------------------------------------------------------------
-// Phases.  `spec`/`work` are the two LDS spectra buffers (n1 floats each).
+// Phases.  `spec`/`work` are the two LDS spectra buffers (n1 floats each).  Loops that
+// read one LDS buffer and write the other are written "load U items, then store U
+// items" so that the U gathers are in flight together (the kernel runs 2 waves per
+// SIMD: latency is hidden by ILP, not by occupancy).
 // ---------------------------------------------------------------------------
+constexpr int kU = 4;
 
-// P0: per-candidate scalars from theta (one thread) + reset of the mask bounds.
+// P0: per-candidate scalars from theta.  The independent fp64 chains (log / sqrt / the
+// instrument width) are given to the first thread of different waves so they overlap.
 // theta columns: 0 Teff 1 logg 2 FeH 3 aFe 4 Vrad 5 Vrot 6 Vmic 7 Inst_R 8.. pc_*
-PAYNE_HD void phase_setup(int tid, const PostTables& T, const double* th, double instr_factor,
+PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* th, double instr_factor,
                           CandState& S) {
-  if (tid != 0) return;
-  const double rv = th[4], vrot = th[5];
-  S.do_rot = (vrot != 0.0);                       // ystpred.py:214 (NaN passes)
-  S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);   // smoothing.py:297,614
-  S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;   // ystpred.py:228-232
-  S.dop = log(S.one_plus);
-  const double Rs = th[7] * instr_factor;         // genmod.py:82-85
-  S.do_smooth = (Rs > 0.0);                       // ystpred.py:238-240 (false for NaN)
-  S.i0 = T.npix; S.i1 = -1; S.n2 = 0; S.bad = 0;
-  if (S.do_smooth) {
-    const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;   // smoothing.py:107,113
-    const double sig = sqrt(sig_out * sig_out - inres * inres);   // :271 (NaN if negative)
-    S.g_a = -2.0 * (kPi * kPi) * (sig * sig);
+  const int lanes = nthr >= 256 ? 64 : 0;            // 0: everything on thread 0 (small / emulated groups)
+  if (tid == 0) {
+    const double rv = th[4];
+    S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;   // ystpred.py:228-232
+    S.dop = log(S.one_plus);
   }
-  for (int i = 0; i < T.npoly && i < 12; ++i) S.poly[i] = th[8 + i];
+  if (tid == lanes) {
+    const double vrot = th[5];
+    S.do_rot = (vrot != 0.0);                       // ystpred.py:214 (NaN passes)
+    S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);   // smoothing.py:297,614
+    S.i0 = T.npix; S.i1 = -1; S.n2 = 0; S.bad = 0;
+  }
+  if (tid == 2 * lanes) {
+    const double Rs = th[7] * instr_factor;         // genmod.py:82-85
+    S.do_smooth = (Rs > 0.0);                       // ystpred.py:238-240 (false for NaN)
+    S.g_a = 0.0;
+    if (Rs > 0.0) {
+      const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;   // smoothing.py:107,113
+      const double sig = sqrt(sig_out * sig_out - inres * inres);   // :271 (NaN if negative)
+      S.g_a = -2.0 * (kPi * kPi) * (sig * sig);
+    }
+  }
+  if (tid == 3 * lanes)
+    for (int i = 0; i < T.npoly && i < 12; ++i) S.poly[i] = th[8 + i];
 }
 
 // P1: load the raw ANN spectrum (already shifted by -1) into LDS.
-PAYNE_HD void phase_load(int tid, int nthr, const PostTables& T, const float* raw, float* spec) {
-  for (int i = tid; i < T.npix; i += nthr) spec[i] = raw[i];
-}
-
-// vsini a: resample onto the pow-2 log grid (static map) into `work`.
-PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const float* spec, float* work) {
-  for (int j = tid; j < T.n1; j += nthr) {
-    int k = T.rs1_idx[j];
-    float a = nan_to_zero(spec[k]), b = nan_to_zero(spec[k + 1]);   // nan_to_num(nan=1.0), smoothing.py:138
-    work[j] = a + (b - a) * T.rs1_frac[j];
+PAYNE_HD void phase_load(int tid, int nthr, const PostTables& T, const float* __restrict__ raw,
+                         float* __restrict__ spec) {
+  if (((T.npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0)) {
+    const int n4 = T.npix >> 2;
+    for (int base = tid; base < n4; base += kU * nthr) {
+      float v[kU][4];
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int i = base + q * nthr;
+        if (i < n4) { v[q][0] = raw[4 * i]; v[q][1] = raw[4 * i + 1]; v[q][2] = raw[4 * i + 2]; v[q][3] = raw[4 * i + 3]; }
+      }
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int i = base + q * nthr;
+        if (i < n4) { spec[4 * i] = v[q][0]; spec[4 * i + 1] = v[q][1]; spec[4 * i + 2] = v[q][2]; spec[4 * i + 3] = v[q][3]; }
+      }
+    }
+  } else {
+    for (int i = tid; i < T.npix; i += nthr) spec[i] = raw[i];
   }
 }
-// vsini c: back onto the ANN grid (left/right = NaN), into `spec`.
-PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float* work, float* spec) {
-  for (int i = tid; i < T.npix; i += nthr) {
-    int j = T.bk1_idx[i];
-    float v;
-    if (j < 0) v = nanf_();
-    else { float a = work[j], b = work[j + 1]; v = a + (b - a) * T.bk1_frac[i]; }
-    spec[i] = v;
+
+// vsini a: resample onto the pow-2 log grid (static map) into `work`; an identity map
+// (geometric grid with npix a power of two) degenerates to a NaN-scrubbing copy.
+PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const float* __restrict__ spec,
+                                 float* __restrict__ work) {
+  for (int base = tid; base < T.n1; base += kU * nthr) {
+    float a[kU], b[kU], f[kU];
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int j = base + q * nthr;
+      if (j < T.n1) {
+        if (T.rot_identity) { a[q] = spec[j]; b[q] = a[q]; f[q] = 0.f; }
+        else { const int k = T.rs1_idx[j]; f[q] = T.rs1_frac[j]; a[q] = spec[k]; b[q] = spec[k + 1]; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int j = base + q * nthr;
+      if (j < T.n1) {
+        const float aa = nan_to_zero(a[q]), bb = nan_to_zero(b[q]);   // nan_to_num(nan=1.0), smoothing.py:138
+        work[j] = aa + (bb - aa) * f[q];
+      }
+    }
+  }
+}
+// vsini c: back onto the ANN grid (left/right = NaN), into `spec` (skipped for identity maps:
+// the convolved buffer then IS the spectrum on the ANN grid).
+PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float* __restrict__ work,
+                             float* __restrict__ spec) {
+  for (int base = tid; base < T.npix; base += kU * nthr) {
+    float a[kU], b[kU], f[kU];
+    int jj[kU];
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = base + q * nthr;
+      if (i < T.npix) {
+        jj[q] = T.bk1_idx[i]; f[q] = T.bk1_frac[i];
+        const int j = jj[q] < 0 ? 0 : jj[q];
+        a[q] = work[j]; b[q] = work[j + 1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = base + q * nthr;
+      if (i < T.npix) spec[i] = (jj[q] < 0) ? nanf_() : a[q] + (b[q] - a[q]) * f[q];
+    }
   }
 }
 // vsini d: spec[0]=spec[1]; spec[-1]=spec[-2]  (ystpred.py:223-224)
@@ -309,20 +400,39 @@ PAYNE_HD void phase_rot_edges(int tid, const PostTables& T, float* spec) {
   if (tid == 1) spec[T.npix - 1] = spec[T.npix - 2];
 }
 
-// R a: data-dependent mask (smoothing.py:631-647), exact fp64 products as numpy.
-// Each thread scans its pixels; bounds merge through LDS atomics / serial min-max.
+// R a: data-dependent mask (smoothing.py:631-647), exact fp64 products as numpy.  The
+// ANN grid is increasing, so the mask is one run of pixels: the thread that sees the run
+// start (end) writes S.i0 (S.i1, inclusive) -- exactly one writer each, no atomics.
 PAYNE_HD void phase_mask_scan(int tid, int nthr, const PostTables& T, const double* th,
-                              double instr_factor, const CandState& S, int& lo_i, int& hi_i) {
-  lo_i = T.npix; hi_i = -1;
+                              double instr_factor, CandState& S) {
   const double Rs = th[7] * instr_factor;
   const double pad = 20.0 / Rs;
   const double wl = T.obs_min * (1.0 + pad * -1.0), wh = T.obs_max * (1.0 + pad * 1.0);
-  for (int i = tid; i < T.npix; i += nthr) {
-    double w = T.lam[i] * S.one_plus;
-    if ((w > wl) && (w < wh)) { if (i < lo_i) lo_i = i; if (i > hi_i) hi_i = i; }
+  const double op = S.one_plus;
+  for (int base = tid; base < T.npix; base += kU * nthr) {
+    double wc[kU], wp[kU];
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = base + q * nthr;
+      if (i < T.npix) { wc[q] = T.lam[i]; wp[q] = T.lam[i > 0 ? i - 1 : 0]; }
+    }
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = base + q * nthr;
+      if (i < T.npix) {
+        const double c = wc[q] * op, p = wp[q] * op;
+        const bool in_c = (c > wl) && (c < wh);
+        const bool in_p = (i > 0) && (p > wl) && (p < wh);
+        if (in_c && !in_p) S.i0 = i;
+        if (!in_c && in_p) S.i1 = i - 1;
+        if (in_c && i == T.npix - 1) S.i1 = i;
+      }
+    }
   }
 }
-// R b: window scalars (one thread): resample_wave's grid (smoothing.py:654-661)
+// R b: window scalars (one thread): resample_wave's grid (smoothing.py:654-661).
+// ln(lam_k (1+rv/c)) is taken as lnlam[k] + dop (differs from log of the rounded product
+// by < 2e-16, i.e. < 1e-10 pixel: the grid and the interpolation depend on it continuously).
 PAYNE_HD void phase_window(int tid, const PostTables& T, CandState& S) {
   if (tid != 0) return;
   int n = S.i1 - S.i0 + 1;
@@ -330,26 +440,37 @@ PAYNE_HD void phase_window(int tid, const PostTables& T, CandState& S) {
   S.i1 = S.i0 + n;                     // exclusive from here on
   if (n < 8) { S.bad = 1; S.n2 = 8; return; }
   S.n2 = pow2ceil(n);
-  S.lnmin = log(T.lam[S.i0] * S.one_plus);
-  S.lnmax = log(T.lam[S.i1 - 1] * S.one_plus);
+  S.lnmin = T.lnlam[S.i0] + S.dop;
+  S.lnmax = T.lnlam[S.i1 - 1] + S.dop;
   S.step = (S.lnmax - S.lnmin) / (double)(S.n2 - 1);     // np.linspace
   S.inv_step = 1.0 / S.step;
   S.g_val = 1.0 / ((double)S.n2 * (kCkms * S.step));     // rfftfreq(n, d=dv), dv = ckms*median(diff(ln w))
 }
 // R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
 PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S,
-                               const float* spec, float* work) {
-  for (int j = tid; j < S.n2; j += nthr) {
-    double lw = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
-    double v = lw - S.dop;                               // position on the unshifted ANN grid
-    int k; double u, dv;
-    grid_locate(T, S.i0, S.i1, v, k, u, dv);
-    float a = nan_to_zero(spec[k]), b = nan_to_zero(spec[k + 1]);
-    float out;
-    if (u <= 0.0) out = a;                               // np.interp clamps (default left/right)
-    else if (u >= dv) out = b;
-    else out = a + (b - a) * lerp_weight(u, dv);
-    work[j] = out;
+                               const float* __restrict__ spec, float* __restrict__ work) {
+  for (int base = tid; base < S.n2; base += kU * nthr) {
+    float a[kU], b[kU], w[kU];
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int j = base + q * nthr;
+      if (j < S.n2) {
+        const double lw = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
+        const double v = lw - S.dop;                       // position on the unshifted ANN grid
+        int k; double u, dv;
+        grid_locate(T, S.i0, S.i1, v, k, u, dv);
+        a[q] = spec[k]; b[q] = spec[k + 1];
+        w[q] = (u <= 0.0) ? 0.f : ((u >= dv) ? 1.f : lerp_weight(u, dv));   // np.interp clamps (default left/right)
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int j = base + q * nthr;
+      if (j < S.n2) {
+        const float aa = nan_to_zero(a[q]), bb = nan_to_zero(b[q]);
+        work[j] = (w[q] == 0.f) ? aa : ((w[q] == 1.f) ? bb : aa + (bb - aa) * w[q]);
+      }
+    }
   }
 }
 
@@ -357,61 +478,73 @@ PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const Can
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
 PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S,
-                          const float* conv, float* out, int out_stage) {
+                          const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
   double acc = 0.0;
   const bool cheb = T.npoly > 0;
-  for (int i = tid; i < T.nobs; i += nthr) {
-    const double lo = T.lnobs[i];
-    float m1;
-    if (S.bad) m1 = nanf_();
-    else if (S.do_smooth) {
-      if (lo < S.lnmin || lo > S.lnmax) m1 = nanf_();    // np.interp(left=nan, right=nan)
-      else {
-        int j = (int)((lo - S.lnmin) * S.inv_step);
-        if (j > S.n2 - 2) j = S.n2 - 2;
-        double xj = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
-        double u = lo - xj;
-        if (u < 0.0 && j > 0) { --j; u += S.step; }
-        else if (u >= S.step && j < S.n2 - 2) { ++j; u -= S.step; }
-        float a = conv[j], b = conv[j + 1];
-        float w = lerp_weight(u, S.step);
-        w = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
-        m1 = a + (b - a) * w;
-      }
-    } else {
-      double v = lo - S.dop;
-      if (v < T.ln0 || v > T.ln_last) m1 = nanf_();
-      else {
-        int k; double u, dv;
-        grid_locate(T, 0, T.npix, v, k, u, dv);
-        float a = conv[k], b = conv[k + 1];
-        float w = lerp_weight(u, dv);
-        w = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
-        m1 = a + (b - a) * w;
+  for (int base = tid; base < T.nobs; base += kU * nthr) {
+    float a[kU], b[kU], w[kU], of1[kU], iv[kU];
+    double xc[kU];
+    bool nanv[kU];
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = base + q * nthr;
+      if (i < T.nobs) {
+        const double lo = T.lnobs[i];
+        if (T.obs_f1) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }
+        if (cheb) xc[q] = T.xcheb[i];
+        nanv[q] = false; a[q] = 0.f; b[q] = 0.f; w[q] = 0.f;
+        if (S.bad) nanv[q] = true;
+        else if (S.do_smooth) {
+          if (lo < S.lnmin || lo > S.lnmax) nanv[q] = true;   // np.interp(left=nan, right=nan)
+          else {
+            int j = (int)((lo - S.lnmin) * S.inv_step);
+            if (j > S.n2 - 2) j = S.n2 - 2;
+            double u = lo - ((double)j * S.step + S.lnmin);
+            if (u < 0.0 && j > 0) { --j; u += S.step; }
+            else if (u >= S.step && j < S.n2 - 2) { ++j; u -= S.step; }
+            a[q] = conv[j]; b[q] = conv[j + 1];
+            const float ww = lerp_weight(u, S.step);
+            w[q] = ww < 0.f ? 0.f : (ww > 1.f ? 1.f : ww);
+          }
+        } else {
+          const double v = lo - S.dop;
+          if (v < T.ln0 || v > T.ln_last) nanv[q] = true;
+          else {
+            int k; double u, dv;
+            grid_locate(T, 0, T.npix, v, k, u, dv);
+            a[q] = conv[k]; b[q] = conv[k + 1];
+            const float ww = lerp_weight(u, dv);
+            w[q] = ww < 0.f ? 0.f : (ww > 1.f ? 1.f : ww);
+          }
+        }
       }
     }
-    float pm1 = 0.f, p = 1.f;
-    if (cheb) {   // numpy.polynomial.chebyshev.chebval (Clenshaw), fitutils.py:11-20
-      const double x = T.xcheb[i];
-      double c0, c1;
-      const int nc = T.npoly;
-      if (nc == 1) { c0 = S.poly[0]; c1 = 0.0; }
-      else if (nc == 2) { c0 = S.poly[0]; c1 = S.poly[1]; }
-      else {
-        const double x2 = 2.0 * x;
-        c0 = S.poly[nc - 2]; c1 = S.poly[nc - 1];
-        for (int q = 3; q <= nc; ++q) { double t = c0; c0 = S.poly[nc - q] - c1; c1 = t + c1 * x2; }
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = base + q * nthr;
+      if (i < T.nobs) {
+        const float m1 = nanv[q] ? nanf_() : a[q] + (b[q] - a[q]) * w[q];
+        float pm1 = 0.f, p = 1.f;
+        if (cheb) {   // numpy.polynomial.chebyshev.chebval (Clenshaw), fitutils.py:11-20
+          const double x = xc[q];
+          double c0, c1;
+          const int nc = T.npoly;
+          if (nc == 1) { c0 = S.poly[0]; c1 = 0.0; }
+          else if (nc == 2) { c0 = S.poly[0]; c1 = S.poly[1]; }
+          else {
+            const double x2 = 2.0 * x;
+            c0 = S.poly[nc - 2]; c1 = S.poly[nc - 1];
+            for (int r = 3; r <= nc; ++r) { double t = c0; c0 = S.poly[nc - r] - c1; c1 = t + c1 * x2; }
+          }
+          const double pv = c0 + c1 * x;
+          p = (float)pv; pm1 = (float)(pv - 1.0);
+        }
+        if (out) out[i] = (out_stage == 3) ? (m1 + kBase) * p : (m1 + kBase);   // genspec / getspec
+        if (T.obs_f1) {
+          const float d = cheb ? (m1 * p + (pm1 - of1[q])) : (m1 - of1[q]);
+          acc += (double)(d * d * iv[q]);
+        }
       }
-      double pv = c0 + c1 * x;
-      p = (float)pv; pm1 = (float)(pv - 1.0);
-    }
-    if (out) {
-      if (out_stage == 3) out[i] = (m1 + kBase) * p;     // genspec (with blaze)
-      else out[i] = m1 + kBase;                           // getspec
-    }
-    if (T.obs_f1) {
-      float d = cheb ? (m1 * p + (pm1 - T.obs_f1[i])) : (m1 - T.obs_f1[i]);
-      acc += (double)(d * d * T.obs_ivar[i]);
     }
   }
   return acc;

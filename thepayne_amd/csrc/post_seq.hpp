@@ -32,11 +32,11 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
 
 // out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze)
 template <class Ex>
-PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const double* th, double instr_factor,
+PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* tw, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
                              float* out, int out_stage, double* chi2_out) {
   ex.par([&](int t, int n) {
-    phase_setup(t, T, th, instr_factor, S);
+    phase_setup(t, n, T, th, instr_factor, S);
     phase_load(t, n, T, raw, bufA);
   });
   float* spec = bufA;
@@ -48,13 +48,14 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const double* th, doub
   if (S.do_rot) {
     ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
     const int M = T.n1 / 2;
-    c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, T.tw, T.nmax, false);
-    ex.par([&](int t, int n) { rfft_taper_phase<true>(t, n, z, M, T.tw, T.nmax, S.vs_a, T.vs_val, T.vs_tab); });
+    c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, tw, T.nmax, false);
+    ex.par([&](int t, int n) { rfft_taper_phase<true>(t, n, z, M, tw, T.nmax, S.vs_a, T.vs_val, T.vs_tab); });
     c32* zo = ((float*)z == bufA) ? (c32*)bufB : (c32*)bufA;
-    c32* y = fft_run(ex, z, zo, M, T.tw, T.nmax, true);
+    c32* y = fft_run(ex, z, zo, M, tw, T.nmax, true);
     float* conv = (float*)y;
     float* dst = (conv == bufA) ? bufB : bufA;
-    ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); });
+    if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }          // conv IS on the ANN grid
+    else ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); });
     ex.par([&](int t, int n) { phase_rot_edges(t, T, dst); });
     spec = dst;
     work = conv;
@@ -65,19 +66,15 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const double* th, doub
   }
   const float* on_grid = spec;
   if (S.do_smooth) {
-    ex.par([&](int t, int n) {
-      int lo, hi;
-      phase_mask_scan(t, n, T, th, instr_factor, S, lo, hi);
-      if (hi >= 0) { ex.imin(&S.i0, lo); ex.imax(&S.i1, hi); }
-    });
+    ex.par([&](int t, int n) { phase_mask_scan(t, n, T, th, instr_factor, S); });
     ex.par([&](int t, int n) { phase_window(t, T, S); });
     if (!S.bad) {
       ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, spec, work); });
       const int M = S.n2 / 2;
-      c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, T.tw, T.nmax, false);
-      ex.par([&](int t, int n) { rfft_taper_phase<false>(t, n, z, M, T.tw, T.nmax, S.g_a, S.g_val, nullptr); });
+      c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, tw, T.nmax, false);
+      ex.par([&](int t, int n) { rfft_taper_phase<false>(t, n, z, M, tw, T.nmax, S.g_a, S.g_val, nullptr); });
       c32* zo = ((float*)z == bufA) ? (c32*)bufB : (c32*)bufA;
-      on_grid = (const float*)fft_run(ex, z, zo, M, T.tw, T.nmax, true);
+      on_grid = (const float*)fft_run(ex, z, zo, M, tw, T.nmax, true);
     }
   }
   ex.par([&](int t, int n) { red[t] = phase_obs(t, n, T, S, on_grid, out, out_stage); });

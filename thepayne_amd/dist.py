@@ -1,0 +1,82 @@
+"""Multi-GPU: independent stars, one process per GPU, one collective.
+
+The likelihood of one star needs no exchange between GPUs, so a batch of stars shards
+embarrassingly: rank r fits stars r, r+W, r+2W, ... on its own MI355X with the ANN
+weights replicated (5-80 MB).  The only collective is the gather of each star's
+fixed-length posterior summary (~50 doubles) at the end, over RCCL/xGMI through
+``torch.distributed`` (backend "nccl" on ROCm; "gloo" on CPU for the tests).  The
+payload is latency-bound (< 1 KiB per star), so there is nothing to bucket or overlap.
+"""
+import os
+
+import numpy as np
+
+__all__ = ["init_from_env", "shard", "gather_summaries", "fit_stars", "finalize"]
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns
+    (rank, world, local_rank); a no-op single-process setup when WORLD_SIZE is unset/1."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, world, local_rank
+
+
+def shard(n_items, rank, world):
+    """Indices of the items rank owns (round-robin: item i -> rank i % world)."""
+    return list(range(rank, n_items, world))
+
+
+def gather_summaries(local, n_total, rank, world, length):
+    """local: {star index: summary[length]} of this rank -> [n_total, length] on every rank."""
+    import torch
+    import torch.distributed as dist
+    out = np.full((n_total, length), np.nan)
+    for i, s in local.items():
+        out[i] = s
+    if world == 1:
+        return out
+    per = (n_total + world - 1) // world
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    mine = torch.full((per, length + 1), float("nan"), dtype=torch.float64, device=dev)
+    for j, i in enumerate(sorted(local)):
+        mine[j, 0] = float(i)
+        mine[j, 1:] = torch.as_tensor(np.asarray(local[i], dtype=np.float64), device=dev)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)                      # the one collective of the job
+    for b in bufs:
+        b = b.cpu().numpy()
+        for row in b:
+            if np.isfinite(row[0]):
+                out[int(row[0])] = row[1:]
+    return out
+
+
+def fit_stars(stars, fit_fn, summary_length, backend=None):
+    """Fit ``stars`` (any list of per-star inputs) sharded over the ranks; ``fit_fn(star,
+    index)`` returns that star's summary vector.  Every rank gets the full table."""
+    rank, world, _ = init_from_env(backend)
+    local = {i: np.asarray(fit_fn(stars[i], i), dtype=np.float64) for i in shard(len(stars), rank, world)}
+    return gather_summaries(local, len(stars), rank, world, summary_length)
+
+
+def finalize():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,0 +1,238 @@
+"""Fit orchestration: mirrors Payne/fitting/fitstar.py (FitPayne, lnprobfn).
+
+``FitPayne().run(inputdict=...)`` takes the reference's nested ``inputdict`` unchanged
+(schema: Payne/fitting/fitstar.py:31-37, 71-194, 262-271) and returns the sampler
+object.  The sampling loop is the reference's ``_runsampler`` (fitstar.py:260-463) with
+dynesty replaced by the batched driver in ``thepayne_amd.sampler``: prior transform,
+likelihood and ln-prior are evaluated for a whole queue of proposals per call, the
+likelihood on the GPU.  The text output keeps the reference's format (one row per dead
+point, header ``Iter <pars> log(lk) log(vol) log(wt) h nc log(z) delta(log(z))``).
+"""
+import sys
+from datetime import datetime
+
+import numpy as np
+
+from .fitutils import airtovacuum
+from ..sampler import NestedSampler
+
+__all__ = ["FitPayne", "lnprobfn", "lnprob_batch"]
+
+_ALL_FITPARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R',
+                'log(R)', 'Dist', 'log(A)', 'Av', 'Rv', 'CarbonScale']
+
+
+def lnprobfn(pars, likeobj, priorobj):
+    """Scalar posterior callable handed to a sampler (fitstar.py:647-659)."""
+    lnlike = likeobj.lnlikefn(pars)
+    if lnlike == -np.inf:
+        return -np.inf
+    lnprior = priorobj.lnpriorfn(likeobj.parsdict)
+    if lnprior == -np.inf:
+        return -np.inf
+    return lnprior + lnlike
+
+
+def lnprob_batch(theta, likeobj, priorobj):
+    """theta[B, ndim] -> lnprior + lnlike [B]; -inf where either is -inf."""
+    theta = np.atleast_2d(theta)
+    lnp = priorobj.lnprior_batch(theta)
+    lnl = likeobj.lnlike_batch(theta)
+    out = lnp + lnl
+    out[(lnl == -np.inf) | (lnp == -np.inf)] = -np.inf
+    return out
+
+
+class FitPayne(object):
+    def __init__(self, **kwargs):
+        from .likelihood import likelihood
+        from .prior import prior
+        self.prior = prior
+        self.likelihood = likelihood
+        self.device = kwargs.get('device', None)
+
+    # ---------------------------------------------------------------- inputdict
+    def run(self, *args, **kwargs):
+        self.verbose = kwargs.get('verbose', True)
+        if 'inputdict' not in kwargs:
+            print('NO USER DEFINED INPUT DICT, NOTHING TO FIT!')
+            raise IOError
+        inputdict = kwargs['inputdict']
+        self.priordict = inputdict.get('priordict', {})
+        self.output = inputdict.get('output', 'Test.dat')
+        self.samplerdict = inputdict.get('sampler', {})
+        fa = self.fitargs = {}
+        self.spec_bool = self.phot_bool = self.modpoly_bool = self.photscale_bool = self.carbon_bool = False
+        self.fitpars = list(_ALL_FITPARS)
+        self.fitpars_bool = {pp: False for pp in self.fitpars}
+
+        if 'spec' in inputdict:
+            spec = inputdict['spec']
+            if self.verbose:
+                print('... fitting spectrum')
+            self.spec_bool = True
+            fa['obs_wave'] = np.asarray(spec['obs_wave'])
+            fa['obs_flux'] = np.asarray(spec['obs_flux'])
+            fa['obs_eflux'] = np.asarray(spec['obs_eflux'])
+            fa['specANNpath'] = inputdict.get('specANNpath', None)
+            fa['NNtype'] = inputdict.get('NNtype', 'LinNet')
+            keep = slice(None)
+            if 'wave_minmax' in spec:
+                fa['wave_minmax'] = spec['wave_minmax']
+                keep = (fa['obs_wave'] >= spec['wave_minmax'][0]) & (fa['obs_wave'] <= spec['wave_minmax'][1])
+            for k in ('wave', 'flux', 'eflux'):
+                fa['obs_%s_fit' % k] = fa['obs_' + k][keep]
+            if spec.get('convertair', True):
+                fa['obs_wave_fit'] = airtovacuum(fa['obs_wave_fit'])
+            on = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
+            if fa['NNtype'] == 'YST2':
+                on.append('Vmic')
+            for pp in on:
+                self.fitpars_bool[pp] = True
+            if spec.get('modpoly', False):
+                self.modpoly_bool = True
+                if 'blaze_coeff' in self.priordict:
+                    self.polycoefarr = self.priordict['blaze_coeff']
+                    self.polyorder = len(self.polycoefarr)
+                else:
+                    self.polyorder = spec['polyorder'] + 1 if 'polyorder' in spec else 3
+                    self.polysigma = spec.get('polysigma', 1.0) if 'polyorder' in spec else 1.0
+                    self.polycoefarr = [[0.0, self.polysigma] for _ in range(self.polyorder)]
+                    self.priordict['blaze_coeff'] = self.polycoefarr
+                if self.verbose:
+                    print('... Fitting a Blaze function with polyoder: {0}'.format(self.polyorder))
+                fa['norm_polyorder'] = self.polyorder
+                for ii in range(self.polyorder):
+                    self.fitpars.append('pc_{}'.format(ii))
+                    self.fitpars_bool['pc_{}'.format(ii)] = True
+                span = fa['obs_wave_fit'] - fa['obs_wave_fit'].min()
+                fa['obs_wave_fit_norm'] = 2.0 * (span / span.max()) - 1.0
+
+        if 'phot' in inputdict:
+            fa['photANNpath'] = inputdict.get('photANNpath', None)
+            self.phot_bool = True
+            for pp in ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Av']:
+                self.fitpars_bool[pp] = True
+            fa['obs_phot'] = {kk: inputdict['phot'][kk] for kk in inputdict['phot'].keys()}
+            self.photscale_bool = inputdict.get('photscale', False)
+            if self.photscale_bool:
+                self.fitpars_bool['log(A)'] = True
+            else:
+                self.fitpars_bool['log(R)'] = True
+                self.fitpars_bool['Dist'] = True
+            self.Rvfree_bool = inputdict.get('Rvfree', False)
+            if self.Rvfree_bool:
+                self.fitpars_bool['Rv'] = True
+
+        fa['fixedpars'] = {}
+        for kk, spec in self.priordict.items():
+            if isinstance(spec, dict) and 'fixed' in spec:
+                fa['fixedpars'][kk] = spec['fixed']
+                self.fitpars_bool[kk] = False
+
+        return self({'fitargs': fa, 'fitpars': [self.fitpars, self.fitpars_bool], 'sampler': self.samplerdict,
+                     'priordict': self.priordict,
+                     'runbools': [self.spec_bool, self.phot_bool, self.modpoly_bool, self.photscale_bool,
+                                  self.carbon_bool]})
+
+    def __call__(self, indicts):
+        return self.run_dynesty(indicts)
+
+    # ---------------------------------------------------------------- sampling
+    def run_dynesty(self, indicts):
+        fitargs, fitpars = indicts['fitargs'], indicts['fitpars']
+        samplerdict, runbools = indicts['sampler'], indicts['runbools']
+        self.ndim = sum(1 for pp in fitpars[0] if fitpars[1][pp])
+        self.priorobj = self.prior(fitargs, indicts['priordict'], fitpars, runbools)
+        nlive = samplerdict.get('npoints', 200)
+        self.likeobj = self.likelihood(fitargs, fitpars, runbools, device=self.device,
+                                       b_max=max(64, int(samplerdict.get('queue_size', nlive))))
+        kind = samplerdict.get('samplertype', 'Static')
+        if kind == 'Static':
+            return self._runsampler(samplerdict)
+        if kind == 'Dynamic':
+            raise NotImplementedError("samplertype 'Dynamic' (fitstar.py:466-645) is not built yet; use 'Static'")
+        print('Did not understand sampler type, return nothing')
+        return None
+
+    def _initoutput(self, parnames):
+        self.outff = open(self.output, 'w')
+        self.outff.write('Iter ')
+        for pp in parnames:
+            self.outff.write('{} '.format(pp))
+        self.outff.write('log(lk) log(vol) log(wt) h nc log(z) delta(log(z))')
+        self.outff.write('\n')
+
+    def _row(self, it, vstar, results):
+        """One output row.  The reference writes ``likeobj.parsdict`` of the LAST evaluated
+        point (fitstar.py:348); with batched evaluation that is
+        meaningless, so the dead point ``vstar`` itself is written."""
+        pars = {pp: vv for pp, vv in zip(self.likeobj.fitpars_i, vstar)}
+        pars.update(self.fitargs_fixed)
+        (loglstar, logvol, logwt, h, nc, logz, delta_logz) = results
+        self.outff.write('{0} '.format(it))
+        self.outff.write(' '.join([str(pars[q]) for q in self.parnames]))
+        self.outff.write(' {0} {1} {2} {3} {4} {5} {6} '.format(loglstar, logvol, logwt, h, nc, logz, delta_logz))
+        self.outff.write('\n')
+
+    def _runsampler(self, samplerdict):
+        npoints = samplerdict.get('npoints', 200)
+        bound = samplerdict.get('samplerbounds', 'multi')
+        samplemethod = samplerdict.get('samplemethod', 'unif')
+        delta_logz_final = samplerdict.get('delta_logz_final', 0.01)
+        flushnum = samplerdict.get('flushnum', 10)
+        numwalks = samplerdict.get('walks', 25)
+        maxiter = samplerdict.get('maxiter', sys.maxsize)
+        maxcall = samplerdict.get('maxcall', sys.maxsize)
+        seed = samplerdict.get('seed', None)
+        starttime = datetime.now()
+        if self.verbose:
+            print('Static batched nested sampler w/ {0} sampler, {1} walks, {2} number of samples, Ndim = {3}, '
+                  'and w/ stopping criteria of dlog(z) = {4}: {5}'.format(
+                      samplemethod, numwalks, npoints, self.ndim, delta_logz_final, starttime))
+            print('Max Iter: {0} / Max Call: {1}'.format(maxiter, maxcall))
+        sys.stdout.flush()
+        sampler = NestedSampler(
+            lnprob_batch, self.priorobj.priortrans_batch, self.ndim,
+            logl_args=[self.likeobj, self.priorobj], nlive=npoints, bound=bound, sample=samplemethod,
+            bootstrap=samplerdict.get('bootstrap', 0), walks=numwalks, slices=samplerdict.get('slices', 5),
+            batched=True, queue_size=samplerdict.get('queue_size', npoints),
+            rstate=np.random.default_rng(seed))
+        self.parnames = list(self.likeobj.fitpars_i) + list(self.fitargs['fixedpars'].keys())
+        self.fitargs_fixed = dict(self.fitargs['fixedpars'])
+        self._initoutput(self.parnames)
+        ncall, nit = 0, 0
+        t_iter = datetime.now()
+        dts = []
+        print('Start Sampling @ {}'.format(t_iter))
+        for it, results in enumerate(sampler.sample(dlogz=delta_logz_final, maxiter=maxiter, maxcall=maxcall)):
+            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
+             h, nc, worst_it, propidx, propiter, eff, delta_logz) = results
+            self._row(it, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
+            ncall += nc
+            nit = it
+            dts.append((datetime.now() - t_iter).total_seconds() / float(nc))
+            t_iter = datetime.now()
+            if ((it % flushnum) == 0) or (it == maxiter):
+                self.outff.flush()
+                if self.verbose:
+                    logzerr = np.sqrt(logzvar) if logzvar > 0. else np.nan
+                    sys.stdout.write("\riter: {0:d} | nc: {1:d} | ncall: {2:d} | eff(%): {3:6.3f} | "
+                                     "logz: {4:6.3f} +/- {5:6.3f} | loglk: {6:6.3f} | dlogz: {7:6.3f} > {8:6.3f}   | "
+                                     "mean(time):  {9:7.5f} | time: {10} \n".format(
+                                         nit, nc, ncall, eff, logz, logzerr, loglstar, delta_logz, delta_logz_final,
+                                         np.mean(dts), datetime.now()))
+                    sys.stdout.flush()
+                    dts = []
+            if it == maxiter:
+                break
+        for it2, results in enumerate(sampler.add_live_points()):
+            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
+             h, nc, worst_it, boundidx, bounditer, eff, delta_logz) = results
+            self._row(nit + it2, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
+            ncall += nc
+        self.outff.close()
+        if self.verbose:
+            sys.stdout.write('\n')
+            print('RUN TIME: {0}'.format(datetime.now() - starttime))
+        return sampler
