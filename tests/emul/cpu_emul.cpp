@@ -14,9 +14,15 @@ using namespace payne;
 struct HostExec {
   int nthr;
   template <class F> void par(F&& f) { for (int t = 0; t < nthr; ++t) f(t, nthr); }
-  void imin(int* p, int v) { if (v < *p) *p = v; }
-  void imax(int* p, int v) { if (v > *p) *p = v; }
+  int nthreads() const { return nthr; }
 };
+
+// the same instantiation choice the GPU launcher makes (compile-time FFT geometry needs 256 threads)
+template <int LOG2N>
+static void run_one(HostExec& ex, const PostTables& T, const double* th, double factor, const float* raw, float* a,
+                    float* b, CandState& S, double* red, float* out, int stage, double* x2) {
+  run_candidate<LOG2N, 256>(ex, T, T.tw, th, factor, raw, a, b, S, red, out, stage, x2);
+}
 
 extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const double* obs_wave,
                                const double* obs_flux, const double* obs_eflux, int nobs, int npoly,
@@ -30,7 +36,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   PostTables T;
   std::memset(&T, 0, sizeof(T));
   fill_model_scalars(H, T);
-  T.nobs = nobs; T.vs_tab = H.vs_tab.data();
+  T.nobs = nobs; T.vs_tab = H.vs_tab32.data();
   T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data();
   T.rs1_idx = H.rs1_idx.data(); T.rs1_frac = H.rs1_frac.data();
   T.bk1_idx = H.bk1_idx.data(); T.bk1_frac = H.bk1_frac.data();
@@ -42,15 +48,31 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   if (force_general) { T.geo = 0; T.rot_identity = 0; }
   HostExec ex{nthreads};
   std::vector<float> a(H.n1), b(H.n1);
-  std::vector<double> red(nthreads + 16);
+  std::vector<double> red(scratch_doubles(nthreads));
+  const bool fixed = (nthreads == 256) && !force_general;
   for (int c = 0; c < B; ++c) {
     CandState S;
     std::memset(&S, 0, sizeof(S));
     double x2 = 0.0;
-    run_candidate(ex, T, T.tw, theta + (size_t)c * ncols, instr_factor, raw_m1 + (size_t)c * npix, a.data(), b.data(), S,
-                  red.data(), out ? out + (size_t)c * ld_out : nullptr, out_stage, &x2);
+    const double* th = theta + (size_t)c * ncols;
+    const float* rw = raw_m1 + (size_t)c * npix;
+    float* o = out ? out + (size_t)c * ld_out : nullptr;
+    if (fixed && H.n1 == 4096) run_one<12>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    else if (fixed && H.n1 == 2048) run_one<11>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    else if (fixed && H.n1 == 1024) run_one<10>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    else if (fixed && H.n1 == 8192) run_one<13>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    else run_candidate<0, 256>(ex, T, T.tw, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     if (chi2) chi2[c] = x2;
-    if (info) { info[3 * c] = S.i0; info[3 * c + 1] = S.i1 - S.i0; info[3 * c + 2] = S.n2; }
+    if (info) {   // mask first / count / FFT length, recomputed the way the kernel derives them
+      info[3 * c] = info[3 * c + 1] = info[3 * c + 2] = -1;
+      if (S.do_smooth && out_stage != 0 && out_stage != 1) {
+        int* cnt = reinterpret_cast<int*>(red.data() + nthreads);
+        Window W = make_window(T, S, cnt, n_slots(nthreads));
+        int below = 0, notabove = 0;
+        for (int s = 0; s < n_slots(nthreads); ++s) { below += cnt[s] & 0xffff; notabove += cnt[s] >> 16; }
+        info[3 * c] = below; info[3 * c + 1] = notabove - below; info[3 * c + 2] = W.n2;
+      }
+    }
   }
   return 0;
 }

@@ -24,14 +24,15 @@ struct HostTables {
   bool has_flux = false;
   int geo = 0, rot_identity = 0;
   double ln0 = 0, dln = 0, ln_last = 0;
-  std::vector<double> vs_tab;
+  std::vector<double> vs_tab;      // fp64 table sb(i*kVsTabStep)
+  std::vector<float> vs_tab32;     // what the kernel interpolates
 };
 
 // copy the model-side scalars into the device-facing struct (pointers are set by the owner)
 inline void fill_model_scalars(const HostTables& H, PostTables& T) {
   T.npix = H.npix; T.n1 = H.n1; T.nmax = H.nmax; T.vs_val = H.vs_val;
   T.geo_inv_dln = H.geo_inv_dln; T.geo = H.geo; T.ln0 = H.ln0; T.dln = H.dln; T.ln_last = H.ln_last;
-  T.vs_tab_n = (int)H.vs_tab.size();
+  T.vs_tab_n = (int)H.vs_tab32.size();
   T.rot_identity = H.rot_identity;
 }
 
@@ -90,6 +91,7 @@ inline int build_model_tables(const double* wave, int npix, HostTables& H) {
       H.vs_tab[i] = vsini_sb_exact(u);
     }
   }
+  H.vs_tab32.assign(H.vs_tab.begin(), H.vs_tab.end());
   // vsini grid: w = exp(linspace(ln wmin, ln wmax, n1))
   std::vector<double> lnw, w(H.n1);
   linspace(std::log(wave[0]), std::log(wave[npix - 1]), H.n1, lnw);

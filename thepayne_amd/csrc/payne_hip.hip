@@ -301,8 +301,7 @@ struct DevExec {
     if (stamps && threadIdx.x == 0 && nst < 63) stamps[++nst] = __builtin_amdgcn_s_memtime();
 #endif
   }
-  __device__ __forceinline__ void imin(int* p, int v) { atomicMin(p, v); }
-  __device__ __forceinline__ void imax(int* p, int v) { atomicMax(p, v); }
+  __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
 };
 
 __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs, const double* err, int F) {
@@ -311,19 +310,23 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
   return s;
 }
 
-template <bool TW_LDS>
-__global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs a) {
+constexpr int kPostThreads = 256;
+
+template <int LOG2N, bool TW_LDS>
+__global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables* __restrict__ Tp, PostArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const PostTables& T = *Tp;                                   // uniform address: scalar loads
+  const int n1 = T.n1;
   float* bufA = reinterpret_cast<float*>(smem);
-  float* bufB = bufA + T.n1;
-  double* red = reinterpret_cast<double*>(bufB + T.n1);        // [256 + 16 + 1]
-  CandState* S = reinterpret_cast<CandState*>(red + 256 + 16 + 1);
+  float* bufB = bufA + n1;
+  double* red = reinterpret_cast<double*>(bufB + n1);          // scratch_doubles(256)
+  CandState* S = reinterpret_cast<CandState*>(red + scratch_doubles(kPostThreads));
   const c32* tw = T.tw;
-  if (TW_LDS) {   // first half circle of the twiddles into LDS (the FFT passes then never leave the CU)
+  if (TW_LDS) {   // full twiddle circle into LDS: the FFT passes then never leave the CU
     c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
-    const int half = T.nmax >> 1;
-    for (int i = threadIdx.x; i < half; i += blockDim.x) twl[i] = T.tw[i];
-    tw = twl;                                                 // made visible by the first phase barrier
+    const c32* __restrict__ g = T.tw;
+    for (int i = threadIdx.x; i < n1; i += kPostThreads) twl[i] = g[i];
+    tw = twl;                                                  // made visible by the first phase barrier
   }
   const int b = blockIdx.x;
   DevExec ex;
@@ -334,16 +337,35 @@ __global__ void __launch_bounds__(256) payne_post_kernel(PostTables T, PostArgs 
     ex.nst = 1;
   }
 #endif
-  run_candidate(ex, T, tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw, bufA, bufB,
-                *S, red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, &red[256 + 16]);
+  double* chi2 = red + scratch_doubles(kPostThreads) - 1;
+  run_candidate<LOG2N, kPostThreads>(ex, T, tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red,
+                                     a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2);
   if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
-    double x2 = red[256 + 16];
+    double x2 = *chi2;
     if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
     a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
   }
 #ifdef PAYNE_STAMPS
   if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
 #endif
+}
+
+typedef void (*post_kernel_fn)(const PostTables*, PostArgs);
+// compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
+static post_kernel_fn pick_post_kernel(int n1, bool tw_lds) {
+  if (tw_lds) {
+    switch (n1) {
+      case 1024: return payne_post_kernel<10, true>;
+      case 2048: return payne_post_kernel<11, true>;
+      case 4096: return payne_post_kernel<12, true>;
+      default: return payne_post_kernel<0, true>;
+    }
+  }
+  switch (n1) {
+    case 8192: return payne_post_kernel<13, false>;
+    default: return payne_post_kernel<0, false>;
+  }
 }
 
 // photometry-only fits: lnL = -0.5 chi2_sed
@@ -451,6 +473,8 @@ struct payne_ctx {
   float* raw = nullptr;
   size_t post_lds = 0;
   bool post_tw_lds = false;
+  PostTables* d_T = nullptr;          // device copy of T (kernel argument)
+  post_kernel_fn post_fn = nullptr;
   bool obs_bound = false;
   // photometry
   bool has_phot = false, has_obs_phot = false;
@@ -520,12 +544,18 @@ static int fail(payne_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
+static int sync_tables(payne_ctx* c) {
+  if (!c->d_T) return PAYNE_OK;
+  HIPCHK(c, hipMemcpy(c->d_T, &c->T, sizeof(PostTables), hipMemcpyHostToDevice));
+  return PAYNE_OK;
+}
+
 static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   for (void* p : c->obs_owned) (void)hipFree(p);
   c->obs_owned.clear();
   c->obs_bound = false;
   c->T.nobs = 0; c->T.lnobs = nullptr; c->T.xcheb = nullptr; c->T.obs_f1 = nullptr; c->T.obs_ivar = nullptr;
-  if (!obs || obs->nobs <= 0) return PAYNE_OK;
+  if (!obs || obs->nobs <= 0) return sync_tables(c);
   if (!obs->wave) return fail(c, PAYNE_E_INVALID, "obs.wave is NULL");
   if ((obs->flux == nullptr) != (obs->eflux == nullptr)) return fail(c, PAYNE_E_INVALID, "obs.flux and obs.eflux must both be given or both NULL");
   build_obs_tables(obs->wave, obs->flux, obs->eflux, obs->nobs, c->H);
@@ -540,7 +570,7 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   c->T.obs_min = c->H.obs_min;
   c->T.obs_max = c->H.obs_max;
   c->obs_bound = true;
-  return PAYNE_OK;
+  return sync_tables(c);
 }
 
 extern "C" int payne_version(void) { return PAYNE_ABI_VERSION; }
@@ -619,7 +649,8 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     PostTables& T = c->T;
     fill_model_scalars(c->H, T);
     T.r_ann = model->resolution; T.npoly = opts->npoly;
-    if ((rc = upload(c, c->H.vs_tab, &T.vs_tab, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.vs_tab32, &T.vs_tab, c->owned))) return bail(rc);
+    if ((rc = dev_alloc(c, 1, &c->d_T, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lnlam, &T.lnlam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lam, &T.lam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.tw, &T.tw, c->owned))) return bail(rc);
@@ -633,14 +664,13 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
-    c->post_lds = (size_t)T.n1 * 8 + (256 + 16 + 1) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
+    c->post_lds = (size_t)T.n1 * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
     // twiddles in LDS while two workgroups still fit a CU (160 KiB); larger spectra read them from L2
-    c->post_tw_lds = (c->post_lds + (size_t)T.n1 * 4) <= 80 * 1024;
+    c->post_tw_lds = (c->post_lds + (size_t)T.n1 * 8) <= 80 * 1024;
     if (getenv("PAYNE_TW_GLOBAL")) c->post_tw_lds = false;
-    if (c->post_tw_lds) c->post_lds += (size_t)T.n1 * 4;
-    he = c->post_tw_lds
-             ? hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds)
-             : hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
+    if (c->post_tw_lds) c->post_lds += (size_t)T.n1 * 8;
+    c->post_fn = pick_post_kernel(getenv("PAYNE_POST_GENERIC") ? 0 : T.n1, c->post_tw_lds);
+    he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     c->has_model = true;
     if ((rc = bind_obs(c, obs))) return bail(rc);
@@ -788,8 +818,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
   {
     ProfScope ps(c, s, 1);
-    if (c->post_tw_lds) hipLaunchKernelGGL(payne_post_kernel<true>, dim3(B), dim3(256), c->post_lds, s, c->T, a);
-    else hipLaunchKernelGGL(payne_post_kernel<false>, dim3(B), dim3(256), c->post_lds, s, c->T, a);
+    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, (const PostTables*)c->d_T, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("post launch: ") + hipGetErrorString(e));
@@ -882,8 +911,7 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d;
-  if (c->post_tw_lds) hipLaunchKernelGGL(payne_post_kernel<true>, dim3(B), dim3(256), c->post_lds, nullptr, c->T, a);
-  else hipLaunchKernelGGL(payne_post_kernel<false>, dim3(B), dim3(256), c->post_lds, nullptr, c->T, a);
+  hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, (const PostTables*)c->d_T, a);
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(d); (void)hipFree(lnl);

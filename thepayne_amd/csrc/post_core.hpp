@@ -1,9 +1,9 @@
 // post_core.hpp -- per-candidate spectrum pipeline of the likelihood hot path,
 // written as barrier-separated PHASES so that the same source runs
-//   * on gfx950 inside post_kernel (one 256-thread workgroup per candidate, all
-//     spectra resident in LDS), and
-//   * on the host (csrc/cpu_emul.cpp: phases executed for tid = 0..NT-1 in turn)
-//     as a bit-faithful emulation used by the CPU tests and sanitizer builds.
+//   * on gfx950 inside payne_post_kernel (one 256-thread workgroup per candidate, the
+//     spectrum resident in LDS from the ANN output to chi^2), and
+//   * on the host (tests/emul/cpu_emul.cpp: phases executed for tid = 0..NT-1 in turn)
+//     as the CPU-side check of the kernel logic (also under ASan/UBSan).
 //
 // What it computes (reference: /root/reference, restated in oracle/payne_oracle.py):
 //   raw ANN spectrum  ->  [vsini FFT broadening, Payne/predict/ystpred.py:211-224,
@@ -16,18 +16,25 @@
 // Numerics: flux arithmetic is fp32 on a spectrum shifted by -1 (normalised spectra
 // live near 1; every linear stage has unit DC gain, so f -> f-1 commutes with the
 // pipeline and buys ~20x smaller rounding error).  Wavelength arithmetic is fp64 in
-// ln(lambda): the interpolation weight (x-x_k)/(x_{k+1}-x_k) is evaluated as
-// expm1(u)/expm1(v) ~ (u/v)(1+(u-v)/2) from fp64 differences of logs, so there is no
-// per-pixel exp() and no fp32 wavelength anywhere.  Fourier tapers
-// are evaluated in fp64 (vsini taper cancels catastrophically in fp32, 7.3-2).
+// ln(lambda): a pixel position is t = (ln x - ln x_0)/dln evaluated with ONE fp64 fma,
+// k = floor(t), f = t - k, and the np.interp weight (x-x_k)/(x_{k+1}-x_k) =
+// expm1(f v)/expm1(v) ~ f (1 + v (f-1)/2); no per-pixel exp(), no fp32 wavelength
+// (SURVEY.md 7.3-1).  The vsini taper (catastrophic cancellation in fp32, 7.3-2) comes
+// from a table built on the host in fp64.
+//
+// The kernel is VALU-issue bound (2 waves per SIMD, ~25 barrier phases): every phase is
+// written to minimise instructions per pixel -- compile-time FFT geometry, no integer
+// multiplies or fp64 divisions in loops, wave ballots instead of atomics.
 #pragma once
 #include <math.h>
 #include <stdint.h>
 
 #ifdef __HIPCC__
 #define PAYNE_HD __host__ __device__ __forceinline__
+#define PAYNE_HD_COLD __host__ __device__ __attribute__((noinline))
 #else
 #define PAYNE_HD inline
+#define PAYNE_HD_COLD inline
 #endif
 
 namespace payne {
@@ -36,6 +43,8 @@ constexpr double kCkms = 2.998e5;            // smoothing.py:16
 constexpr double kCDoppler = 299792.458;     // ystpred.py:11-12
 constexpr double kPi = 3.141592653589793;
 constexpr float kBase = 1.0f;                // the flux shift
+constexpr double kVsTabStep = 1.0 / 64.0;    // vsini taper table spacing in u
+constexpr double kVsTabMax = 256.0;
 
 struct c32 { float x, y; };
 PAYNE_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -45,18 +54,22 @@ PAYNE_HD c32 cconj(c32 a) { return {a.x, -a.y}; }
 PAYNE_HD c32 cscale(c32 a, float s) { return {a.x * s, a.y * s}; }
 PAYNE_HD c32 cmul_negi(c32 a) { return {a.y, -a.x}; }   // a * (-i)
 PAYNE_HD c32 cmul_posi(c32 a) { return {-a.y, a.x}; }   // a * (+i)
+PAYNE_HD float nanf_() { return __builtin_nanf(""); }
+PAYNE_HD float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
+PAYNE_HD int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 // ---------------------------------------------------------------------------
-// Static (per-context) tables, all device-resident; built once on the host.
+// Static (per-context) tables, all device-resident; built once on the host
+// (host_tables.hpp).
 // ---------------------------------------------------------------------------
 struct PostTables {
   int npix;            // ANN pixels
   int nobs;            // observed pixels (0: no obs grid bound)
-  int n1;              // pow2ceil(npix): vsini FFT length
-  int nmax;            // twiddle table length (= largest real FFT length)
+  int n1;              // pow2ceil(npix): vsini FFT length (real points)
+  int nmax;            // twiddle table length (== n1)
   const double* lnlam;     // [npix]  ln(lambda_ANN)
   const double* lam;       // [npix]  lambda_ANN (exact mask test)
-  const c32* tw;           // [nmax]  exp(-2 pi i j / nmax)
+  const c32* tw;           // [nmax]  exp(-2 pi i j / nmax), full circle
   // vsini stage maps (theta-independent, smoothing.py:649-668 + :311)
   const int* rs1_idx;      // [n1]   source pixel k of resampled point j
   const float* rs1_frac;   // [n1]   weight of pixel k+1
@@ -70,37 +83,51 @@ struct PostTables {
   const float* obs_ivar;   // [nobs] 1/eflux^2
   double obs_min, obs_max; // min/max of obs wave (mask_wave limits)
   double r_ann;            // sigma-based R of the ANN
-  double geo_inv_dln;      // 1/mean(d lnlam): index guess for the resamplers
+  double geo_inv_dln;      // 1/mean(d lnlam)
   int npoly;               // blaze coefficients (0: off)
   // geometric ANN grid (readc3k construction): ln lam_k = ln0 + k*dln to < 1e-12, so
   // pixel positions come from arithmetic instead of dependent loads of lnlam[]
   int geo;
   double ln0, dln, ln_last;   // ln0 = lnlam[0], ln_last = lnlam[npix-1] (always set)
-  // vsini taper sb(u) tabulated at u = i*kVsTabStep (host, fp64); cubic interpolation
-  const double* vs_tab;
+  const float* vs_tab;        // vsini taper sb(i*kVsTabStep), fp32 copy of the fp64 host table
   int vs_tab_n;
   int rot_identity;    // the vsini resampling maps are the identity (to fp32): skip them
 };
 
-constexpr double kVsTabStep = 1.0 / 64.0;
-constexpr double kVsTabMax = 256.0;
-
-// Per-candidate scalars, shared by the workgroup (lives in LDS).
+// Per-candidate scalars from theta, shared by the workgroup (lives in LDS).
 struct CandState {
   double one_plus;   // 1 + rv/c
   double dop;        // ln(one_plus)
-  double lnmin, lnmax, step, inv_step;
   double vs_a;       // 2 pi sigma        (vsini)
   double g_a;        // -2 pi^2 sigma^2   (gauss)
-  double g_val;      // 1/(n2*dv2)
+  double wl, wh;     // mask limits (smoothing.py:631-647)
   double poly[12];
   int do_rot, do_smooth;
-  int i0, i1, n2;
-  int bad;           // window too small for an FFT -> NaN result
 };
 
+// The R-stage window of one candidate, derived (redundantly, by every thread) from the
+// mask bounds: resample_wave's grid (smoothing.py:654-661) and the two position maps.
+struct Window {
+  double lnmin, lnmax;   // ln of the first / last masked, Doppler-shifted ANN pixel
+  double rsA, rsB;       // ANN-pixel position of resampled point j: t = j*rsA + rsB   (geo grids)
+  double step;           // d ln(lambda) of the resampled grid
+  double obA, obB;       // resampled-grid position of obs pixel i: t = lnobs_i*obA + obB
+  float hs_ann, hs_step; // half grid steps: weight = f (1 + hs (f-1))
+  float g_c2;            // Gaussian taper = exp2(g_c2 k^2)
+  int i0, i1;            // masked pixels [i0, i1)
+  int n2;                // FFT length of the R stage
+  int bad;               // window too small for an FFT -> NaN result
+};
+
+#ifdef __HIP_DEVICE_COMPILE__
+constexpr int kSlotShift = 6;        // one partial per wave (ballot / shuffle reductions)
+#else
+constexpr int kSlotShift = 0;        // host emulation: one partial per thread
+#endif
+PAYNE_HD int n_slots(int nthr) { return nthr >> kSlotShift; }
+
 // ---------------------------------------------------------------------------
-// Radix-2/4/8 Stockham passes on M complex points held in LDS.
+// FFT: Stockham radix-2/4/8 passes on M complex points held in LDS.
 // Thread i owns butterfly i of M/R: reads src[i + r*M/R], twiddles by
 // exp(-2 pi i k r/(pR)) (k = i mod p), writes dst[(i-k)R + k + r p].
 // ---------------------------------------------------------------------------
@@ -121,18 +148,17 @@ PAYNE_HD void dft8(c32* u) {
   u[2] = cadd(e2, w2o); u[6] = csub(e2, w2o);
   u[3] = cadd(e3, w3o); u[7] = csub(e3, w3o);
 }
-
-// Twiddle exp(-2 pi i j / tw_n) from a table holding the first half circle only.
-PAYNE_HD c32 tw_get(const c32* tw, int half, int j) {
-  const c32 w = tw[j & (half - 1)];
-  return (j & half) ? c32{-w.x, -w.y} : w;
+template <int R> PAYNE_HD void dftR(c32* u) {
+  if (R == 8) dft8(u);
+  else if (R == 4) dft4(u[0], u[1], u[2], u[3]);
+  else dft2(u);
 }
 
+// Runtime-geometry pass (any M, p; any thread count).
 template <int R>
 PAYNE_HD void fft_pass(int tid, int nthr, const c32* __restrict__ src, c32* __restrict__ dst, int M, int p,
                        const c32* __restrict__ tw, int tw_n, bool conj_out) {
   const int nb = M / R;
-  const int half = tw_n >> 1;
   for (int i = tid; i < nb; i += nthr) {
     const int k = i & (p - 1);
     c32 u[R];
@@ -140,29 +166,52 @@ PAYNE_HD void fft_pass(int tid, int nthr, const c32* __restrict__ src, c32* __re
     for (int r = 0; r < R; ++r) u[r] = src[i + r * nb];
     if (p > 1) {
       const int ts = tw_n / (p * R);
-      c32 w[R];
 #pragma unroll
-      for (int r = 1; r < R; ++r) w[r] = tw_get(tw, half, (k * r) * ts);
-#pragma unroll
-      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
+      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
     }
-    if (R == 8) dft8(u);
-    else if (R == 4) dft4(u[0], u[1], u[2], u[3]);
-    else dft2(u);
+    dftR<R>(u);
     const int j = (i - k) * R + k;
 #pragma unroll
     for (int r = 0; r < R; ++r) dst[j + r * p] = conj_out ? cconj(u[r]) : u[r];
   }
 }
-
-// Radix of the pass that starts at sub-length p for an M-point transform.
 PAYNE_HD int pass_radix(int M, int p) { int rem = M / p; return rem >= 8 ? 8 : rem; }
+
+// Compile-time-geometry pass: M points, sub-length P, NT threads, twiddle table of 2M
+// entries.  Strides, trip counts and twiddle steps fold to immediates.
+template <int R, int M, int P, bool CONJ, int NT>
+PAYNE_HD void fft_pass_fixed(int tid, const c32* __restrict__ src, c32* __restrict__ dst,
+                             const c32* __restrict__ tw) {
+  constexpr int NB = M / R, TS = (2 * M) / (P * R);
+#pragma unroll
+  for (int i0 = 0; i0 < NB; i0 += NT) {
+    const int i = i0 + tid;
+    if ((NB % NT) != 0 && i >= NB) break;
+    const int k = i & (P - 1);
+    c32 u[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = src[i + r * NB];
+    if (P > 1) {
+      c32 w[R];
+#pragma unroll
+      for (int r = 1; r < R; ++r) w[r] = tw[(k * r) * TS];
+#pragma unroll
+      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
+    }
+    dftR<R>(u);
+    const int j = (i - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[j + r * P] = CONJ ? cconj(u[r]) : u[r];
+  }
+}
 
 // ---------------------------------------------------------------------------
 // Tapers.
 // ---------------------------------------------------------------------------
-// sb(ub) of smoothing.py:616-617 evaluated directly in fp64
-PAYNE_HD double vsini_sb_exact(double ub) {
+// sb(ub) of smoothing.py:616-617 evaluated directly in fp64 (host table build, far tail).
+// Cold on the GPU (only beyond the table): kept out of line so its fp64 j1/sincos bodies
+// are not replicated into every taper call site.
+PAYNE_HD_COLD double vsini_sb_exact(double ub) {
   double s, c;
 #ifdef __HIP_DEVICE_COMPILE__
   sincos(ub, &s, &c);
@@ -172,27 +221,36 @@ PAYNE_HD double vsini_sb_exact(double ub) {
   double u2 = ub * ub;
   return j1(ub) / ub - 3.0 * c / (2.0 * u2) + 3.0 * s / (2.0 * (u2 * ub));
 }
-// 4-point Lagrange interpolation in the host-built table (|error| < 1e-9); sb is even in u.
-PAYNE_HD double vsini_sb_table(const double* __restrict__ tab, double ub) {
-  const double t = ub * (1.0 / kVsTabStep);
+// smoothing.py:612-620 for bin k: 4-point Lagrange interpolation in the host-built table
+// (fp64-accurate values stored as fp32; the factor multiplies Fourier amplitudes of the
+// SHIFTED spectrum, so 6e-8 on it is ~1e-9 in flux); sb is even in u; sb[0] = 1.
+PAYNE_HD float vsini_taper(const float* __restrict__ tab, int tab_n, double vs_c64, double vs_c, int k) {
+  if (k == 0) return 1.0f;
+  const double t = (double)k * vs_c64;                   // u / kVsTabStep
+  if (!(t < (double)(tab_n - 3))) return (float)vsini_sb_exact((double)k * vs_c);   // NaN / far tail
   const int i = (int)t;
-  const double f = t - (double)i;
-  const double ym = tab[i > 0 ? i - 1 : 1], y0 = tab[i], y1 = tab[i + 1], y2 = tab[i + 2];
-  const double fm1 = f - 1.0, fm2 = f - 2.0, fp1 = f + 1.0;
-  return (-f * fm1 * fm2 * (1.0 / 6.0)) * ym + (fp1 * fm1 * fm2 * 0.5) * y0 + (-fp1 * f * fm2 * 0.5) * y1 +
-         (fp1 * f * fm1 * (1.0 / 6.0)) * y2;
+  const float f = (float)(t - (double)i);
+  const float ym = tab[i > 0 ? i - 1 : 1], y0 = tab[i], y1 = tab[i + 1], y2 = tab[i + 2];
+  const float fm1 = f - 1.0f, fm2 = f - 2.0f, fp1 = f + 1.0f;
+  return (-f * fm1 * fm2 * (1.0f / 6.0f)) * ym + (fp1 * fm1 * fm2 * 0.5f) * y0 + (-fp1 * f * fm2 * 0.5f) * y1 +
+         (fp1 * f * fm1 * (1.0f / 6.0f)) * y2;
 }
-PAYNE_HD double vsini_taper(const double* tab, double vs_a, double vs_val, int k) {
-  // smoothing.py:612-620 (ss[0] hack irrelevant: sb[0] is overwritten with 1)
-  if (k == 0) return 1.0;
-  const double ub = vs_a * ((double)k * vs_val);
-  if (tab && ub < kVsTabMax) return vsini_sb_table(tab, ub);
-  return vsini_sb_exact(ub);          // NaN/huge arguments and the far tail
+// smoothing.py:598-599: exp(-2 pi^2 sigma^2 ss^2), ss = k/(n dv), as exp2(c2 k^2)
+PAYNE_HD float gauss_taper(float g_c2, int k) {
+  const float kf = (float)k;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_exp2f(g_c2 * (kf * kf));      // v_exp_f32
+#else
+  return exp2f(g_c2 * (kf * kf));
+#endif
 }
-PAYNE_HD float gauss_taper(double g_a, double g_val, int k) {
-  // smoothing.py:598-599: exp(-2 pi^2 sigma^2 ss^2), ss = k/(n dv)
-  double ss = (double)k * g_val;
-  return expf((float)(g_a * (ss * ss)));
+
+struct TaperArgs {
+  const float* vs_tab; int vs_tab_n; double vs_c64, vs_c;   // vsini
+  float g_c2;                                               // gauss
+};
+template <bool VSINI> PAYNE_HD float taper_at(const TaperArgs& a, int k) {
+  return VSINI ? vsini_taper(a.vs_tab, a.vs_tab_n, a.vs_c64, a.vs_c, k) : gauss_taper(a.g_c2, k);
 }
 
 // Middle step of a real convolution done with a half-length complex FFT.
@@ -201,12 +259,12 @@ PAYNE_HD float gauss_taper(double g_a, double g_val, int k) {
 // A thread owns conjugate pairs (k, M-k), k = 1..M/2-1, PU at a time (all loads of the PU
 // pairs are issued before any store: the pairs are disjoint, so this is safe in place);
 // the two self-conjugate bins k = 0 and k = M/2 go to the last two threads.
+// tw_step = (twiddle table length)/(2M): exp(-2 pi i k/2M) = tw[k*tw_step].
 template <bool VSINI>
-PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __restrict__ tw, int tw_n,
-                               double ta, double tval, const double* vs_tab) {
+PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __restrict__ tw, int tw_step,
+                               const TaperArgs& ta) {
   constexpr int PU = 4;
-  const int ts = tw_n / (2 * M);
-  const float g = 0.25f / (float)M, invM = 1.0f / (float)M;
+  const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const int npair = M / 2 - 1;                        // k = 1 .. M/2-1
   for (int base = tid; base < npair; base += PU * nthr) {
     c32 zk[PU], zm[PU], w[PU];
@@ -215,9 +273,9 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
     for (int q = 0; q < PU; ++q) {
       const int k = 1 + base + q * nthr;
       if (k <= npair) {
-        zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * ts];
-        tk[q] = VSINI ? (float)vsini_taper(vs_tab, ta, tval, k) : gauss_taper(ta, tval, k);
-        tm[q] = VSINI ? (float)vsini_taper(vs_tab, ta, tval, M - k) : gauss_taper(ta, tval, M - k);
+        zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * tw_step];
+        tk[q] = taper_at<VSINI>(ta, k);
+        tm[q] = taper_at<VSINI>(ta, M - k);
       }
     }
 #pragma unroll
@@ -235,21 +293,19 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
     }
   }
   if (tid == nthr - 1) {                               // k = 0 with k = M (real bins X[0], X[M])
-    const float t0 = VSINI ? (float)vsini_taper(vs_tab, ta, tval, 0) : gauss_taper(ta, tval, 0);
-    const float tM = VSINI ? (float)vsini_taper(vs_tab, ta, tval, M) : gauss_taper(ta, tval, M);
+    const float t0 = taper_at<VSINI>(ta, 0), tM = taper_at<VSINI>(ta, M);
     const c32 z0 = Z[0];
     const float x0 = t0 * (z0.x + z0.y), xm = tM * (z0.x - z0.y);
     Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
   }
   if (tid == (nthr > 1 ? nthr - 2 : 0) && M >= 2) {    // k = M/2 (self-conjugate)
     const int k = M / 2;
-    const float th = VSINI ? (float)vsini_taper(vs_tab, ta, tval, k) : gauss_taper(ta, tval, k);
-    Z[k] = cscale(cconj(Z[k]), th * invM);
+    Z[k] = cscale(cconj(Z[k]), taper_at<VSINI>(ta, k) * invM);
   }
 }
 
 // ---------------------------------------------------------------------------
-// Search helpers (monotone fp64 arrays).
+// Grid positions.
 // ---------------------------------------------------------------------------
 // k in [lo, hi-2] with x[k] <= v < x[k+1] (clamped at the ends), from a guess.
 PAYNE_HD int locate(const double* x, int lo, int hi, double v, int guess) {
@@ -258,43 +314,35 @@ PAYNE_HD int locate(const double* x, int lo, int hi, double v, int guess) {
   while (k < hi - 2 && v >= x[k + 1]) ++k;
   return k;
 }
-// Position of ln-wavelength v on the ANN grid restricted to pixels [lo, hi): pixel k with
-// lnlam[k] <= v < lnlam[k+1] (clamped), u = v - lnlam[k], dv = lnlam[k+1] - lnlam[k].
-PAYNE_HD void grid_locate(const PostTables& T, int lo, int hi, double v, int& k, double& u, double& dv) {
-  if (T.geo) {
-    k = (int)((v - T.ln0) * T.geo_inv_dln);
-    k = k < lo ? lo : (k > hi - 2 ? hi - 2 : k);
-    u = v - (T.ln0 + (double)k * T.dln);
-    dv = T.dln;
-    if (u < 0.0 && k > lo) { --k; u += dv; }
-    else if (u >= dv && k < hi - 2) { ++k; u -= dv; }
-  } else {
-    const int guess = lo + (int)((v - T.lnlam[lo]) * T.geo_inv_dln);
-    k = locate(T.lnlam, lo, hi, v, guess);
-    u = v - T.lnlam[k];
-    dv = T.lnlam[k + 1] - T.lnlam[k];
-  }
+// Non-geometric ANN grids: pixel k of [lo,hi) with lnlam[k] <= v < lnlam[k+1] (clamped) and
+// the np.interp weight of pixel k+1 for ln-wavelength v (clamped to [0,1]).
+PAYNE_HD void search_locate(const PostTables& T, int lo, int hi, double v, int& k, float& w) {
+  const int guess = lo + (int)((v - T.lnlam[lo]) * T.geo_inv_dln);
+  k = locate(T.lnlam, lo, hi, v, guess);
+  const double u = v - T.lnlam[k], dv = T.lnlam[k + 1] - T.lnlam[k];
+  const float f = (float)(u / dv);
+  const float ww = f * (1.0f + 0.5f * (float)dv * (f - 1.0f));
+  w = (u <= 0.0) ? 0.f : ((u >= dv) ? 1.f : ww);
 }
-
-// interpolation weight from log-space offsets: expm1(u)/expm1(v)
-PAYNE_HD float lerp_weight(double u, double v) {
-  float uf = (float)u, vf = (float)v;
-  return (uf / vf) * (1.0f + 0.5f * (uf - vf));
+// position t on a uniform ln grid -> (k, weight of k+1), k clamped to [lo, hi-2]
+PAYNE_HD void uniform_locate(double t, int lo, int hi, float hs, int& k, float& w) {
+  int kk = (int)t;                                       // t >= 0 on every caller's valid range
+  kk = kk < lo ? lo : (kk > hi - 2 ? hi - 2 : kk);
+  float f = (float)(t - (double)kk);
+  f = f < 0.f ? 0.f : (f > 1.f ? 1.f : f);
+  k = kk;
+  w = f * (1.0f + hs * (f - 1.0f));                      // expm1(f v)/expm1(v), v = 2 hs
 }
-PAYNE_HD float nanf_() { return __builtin_nanf(""); }
-PAYNE_HD float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
-PAYNE_HD int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 // ---------------------------------------------------------------------------
 // Phases.  `spec`/`work` are the two LDS spectra buffers (n1 floats each).  Loops that
 // read one LDS buffer and write the other are written "load U items, then store U
-// items" so that the U gathers are in flight together (the kernel runs 2 waves per
-// SIMD: latency is hidden by ILP, not by occupancy).
+// items" so that the U gathers are in flight together.
 // ---------------------------------------------------------------------------
 constexpr int kU = 4;
 
 // P0: per-candidate scalars from theta.  The independent fp64 chains (log / sqrt / the
-// instrument width) are given to the first thread of different waves so they overlap.
+// instrument width) go to the first thread of different waves so that they overlap.
 // theta columns: 0 Teff 1 logg 2 FeH 3 aFe 4 Vrad 5 Vrot 6 Vmic 7 Inst_R 8.. pc_*
 PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* th, double instr_factor,
                           CandState& S) {
@@ -308,16 +356,18 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
     const double vrot = th[5];
     S.do_rot = (vrot != 0.0);                       // ystpred.py:214 (NaN passes)
     S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);   // smoothing.py:297,614
-    S.i0 = T.npix; S.i1 = -1; S.n2 = 0; S.bad = 0;
   }
   if (tid == 2 * lanes) {
     const double Rs = th[7] * instr_factor;         // genmod.py:82-85
     S.do_smooth = (Rs > 0.0);                       // ystpred.py:238-240 (false for NaN)
-    S.g_a = 0.0;
+    S.g_a = 0.0; S.wl = 0.0; S.wh = 0.0;
     if (Rs > 0.0) {
       const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;   // smoothing.py:107,113
       const double sig = sqrt(sig_out * sig_out - inres * inres);   // :271 (NaN if negative)
       S.g_a = -2.0 * (kPi * kPi) * (sig * sig);
+      const double pad = 20.0 / Rs;                                 // mask_wave, smoothing.py:631-647
+      S.wl = T.obs_min * (1.0 + pad * -1.0);
+      S.wh = T.obs_max * (1.0 + pad * 1.0);
     }
   }
   if (tid == 3 * lanes)
@@ -325,10 +375,9 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
 }
 
 // P1: load the raw ANN spectrum (already shifted by -1) into LDS.
-PAYNE_HD void phase_load(int tid, int nthr, const PostTables& T, const float* __restrict__ raw,
-                         float* __restrict__ spec) {
-  if (((T.npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0)) {
-    const int n4 = T.npix >> 2;
+PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ raw, float* __restrict__ spec) {
+  if (((npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0)) {
+    const int n4 = npix >> 2;
     for (int base = tid; base < n4; base += kU * nthr) {
       float v[kU][4];
 #pragma unroll
@@ -343,12 +392,12 @@ PAYNE_HD void phase_load(int tid, int nthr, const PostTables& T, const float* __
       }
     }
   } else {
-    for (int i = tid; i < T.npix; i += nthr) spec[i] = raw[i];
+    for (int i = tid; i < npix; i += nthr) spec[i] = raw[i];
   }
 }
 
-// vsini a: resample onto the pow-2 log grid (static map) into `work`; an identity map
-// (geometric grid with npix a power of two) degenerates to a NaN-scrubbing copy.
+// vsini a: resample onto the pow-2 log grid (static map) into `work`; identity maps
+// (geometric grid, npix a power of two) degenerate to a NaN-scrubbing copy.
 PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const float* __restrict__ spec,
                                  float* __restrict__ work) {
   for (int base = tid; base < T.n1; base += kU * nthr) {
@@ -395,80 +444,97 @@ PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float
   }
 }
 // vsini d: spec[0]=spec[1]; spec[-1]=spec[-2]  (ystpred.py:223-224)
-PAYNE_HD void phase_rot_edges(int tid, const PostTables& T, float* spec) {
+PAYNE_HD void phase_rot_edges(int tid, int npix, float* spec) {
   if (tid == 0) spec[0] = spec[1];
-  if (tid == 1) spec[T.npix - 1] = spec[T.npix - 2];
+  if (tid == 1) spec[npix - 1] = spec[npix - 2];
 }
 
-// R a: data-dependent mask (smoothing.py:631-647), exact fp64 products as numpy.  The
-// ANN grid is increasing, so the mask is one run of pixels: the thread that sees the run
-// start (end) writes S.i0 (S.i1, inclusive) -- exactly one writer each, no atomics.
-PAYNE_HD void phase_mask_scan(int tid, int nthr, const PostTables& T, const double* th,
-                              double instr_factor, CandState& S) {
-  const double Rs = th[7] * instr_factor;
-  const double pad = 20.0 / Rs;
-  const double wl = T.obs_min * (1.0 + pad * -1.0), wh = T.obs_max * (1.0 + pad * 1.0);
-  const double op = S.one_plus;
+// R a: data-dependent mask (smoothing.py:631-647), exact fp64 products as numpy.  The ANN
+// grid is increasing, so the mask is the run [#(lam' <= wl), #(lam' < wh)): two counts.
+// On the GPU the counts are wave ballots + popcounts (scalar unit, no atomics); each
+// wave leaves one packed partial in cnt[] (host emulation: one per thread).
+PAYNE_HD void phase_mask_count(int tid, int nthr, const PostTables& T, const CandState& S, int* cnt) {
+  const double wl = S.wl, wh = S.wh, op = S.one_plus;
+  int cb = 0, ca = 0;
   for (int base = tid; base < T.npix; base += kU * nthr) {
-    double wc[kU], wp[kU];
+    double wc[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
       const int i = base + q * nthr;
-      if (i < T.npix) { wc[q] = T.lam[i]; wp[q] = T.lam[i > 0 ? i - 1 : 0]; }
+      if (i < T.npix) wc[q] = T.lam[i];
     }
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
       const int i = base + q * nthr;
       if (i < T.npix) {
-        const double c = wc[q] * op, p = wp[q] * op;
-        const bool in_c = (c > wl) && (c < wh);
-        const bool in_p = (i > 0) && (p > wl) && (p < wh);
-        if (in_c && !in_p) S.i0 = i;
-        if (!in_c && in_p) S.i1 = i - 1;
-        if (in_c && i == T.npix - 1) S.i1 = i;
+        const double c = wc[q] * op;
+        const bool below = !(c > wl), notabove = (c < wh);
+#ifdef __HIP_DEVICE_COMPILE__
+        cb += __popcll(__ballot(below));
+        ca += __popcll(__ballot(notabove));
+#else
+        cb += below ? 1 : 0;
+        ca += notabove ? 1 : 0;
+#endif
       }
     }
   }
+  if ((tid & ((1 << kSlotShift) - 1)) == 0) cnt[tid >> kSlotShift] = cb | (ca << 16);
 }
-// R b: window scalars (one thread): resample_wave's grid (smoothing.py:654-661).
-// ln(lam_k (1+rv/c)) is taken as lnlam[k] + dop (differs from log of the rounded product
-// by < 2e-16, i.e. < 1e-10 pixel: the grid and the interpolation depend on it continuously).
-PAYNE_HD void phase_window(int tid, const PostTables& T, CandState& S) {
-  if (tid != 0) return;
-  int n = S.i1 - S.i0 + 1;
-  if (S.i1 < 0) n = 0;
-  S.i1 = S.i0 + n;                     // exclusive from here on
-  if (n < 8) { S.bad = 1; S.n2 = 8; return; }
-  S.n2 = pow2ceil(n);
-  S.lnmin = T.lnlam[S.i0] + S.dop;
-  S.lnmax = T.lnlam[S.i1 - 1] + S.dop;
-  S.step = (S.lnmax - S.lnmin) / (double)(S.n2 - 1);     // np.linspace
-  S.inv_step = 1.0 / S.step;
-  S.g_val = 1.0 / ((double)S.n2 * (kCkms * S.step));     // rfftfreq(n, d=dv), dv = ckms*median(diff(ln w))
+
+// R b: every thread derives the window from the partial counts (no serial section).
+// ln(lam_k (1+rv/c)) is taken as lnlam[k] + dop (differs from log of the rounded product by
+// < 2e-16, i.e. < 1e-10 pixel: grid and interpolation depend on it continuously).
+PAYNE_HD Window make_window(const PostTables& T, const CandState& S, const int* cnt, int nslots) {
+  Window W;
+  int below = 0, notabove = 0;
+  for (int s = 0; s < nslots; ++s) { const int v = cnt[s]; below += v & 0xffff; notabove += v >> 16; }
+  W.i0 = below; W.i1 = notabove;
+  const int n = W.i1 - W.i0;
+  W.bad = (n < 8) ? 1 : 0;
+  if (W.bad) { W.i0 = 0; W.i1 = 8; }                                 // any valid range: results are NaN'd
+  W.n2 = pow2ceil(W.bad ? 8 : n);
+  const double l0 = T.geo ? (T.ln0 + (double)W.i0 * T.dln) : T.lnlam[W.i0];
+  const double l1 = T.geo ? (T.ln0 + (double)(W.i1 - 1) * T.dln) : T.lnlam[W.i1 - 1];
+  W.lnmin = l0 + S.dop;
+  W.lnmax = l1 + S.dop;
+  W.step = (W.lnmax - W.lnmin) / (double)(W.n2 - 1);                 // np.linspace
+  const double inv_step = (double)(W.n2 - 1) / (W.lnmax - W.lnmin);
+  W.rsA = W.step * T.geo_inv_dln;                                    // geo: geo_inv_dln == 1/dln
+  W.rsB = (l0 - T.ln0) * T.geo_inv_dln;
+  W.obA = inv_step;
+  W.obB = -W.lnmin * inv_step;
+  W.hs_ann = (float)(0.5 * T.dln);
+  W.hs_step = (float)(0.5 * W.step);
+  const double g_val = inv_step / ((double)W.n2 * kCkms);            // rfftfreq: 1/(n2 dv), dv = ckms*step
+  W.g_c2 = (float)(S.g_a * (g_val * g_val) * 1.4426950408889634);
+  return W;
 }
+
 // R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
-PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S,
+PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                                const float* __restrict__ spec, float* __restrict__ work) {
-  for (int base = tid; base < S.n2; base += kU * nthr) {
+  for (int base = tid; base < W.n2; base += kU * nthr) {
     float a[kU], b[kU], w[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
       const int j = base + q * nthr;
-      if (j < S.n2) {
-        const double lw = (j == S.n2 - 1) ? S.lnmax : ((double)j * S.step + S.lnmin);
-        const double v = lw - S.dop;                       // position on the unshifted ANN grid
-        int k; double u, dv;
-        grid_locate(T, S.i0, S.i1, v, k, u, dv);
-        a[q] = spec[k]; b[q] = spec[k + 1];
-        w[q] = (u <= 0.0) ? 0.f : ((u >= dv) ? 1.f : lerp_weight(u, dv));   // np.interp clamps (default left/right)
+      if (j < W.n2) {
+        int k; float ww;
+        if (T.geo) uniform_locate((double)j * W.rsA + W.rsB, W.i0, W.i1, W.hs_ann, k, ww);
+        else {
+          const double lw = (j == W.n2 - 1) ? W.lnmax : ((double)j * W.step + W.lnmin);
+          search_locate(T, W.i0, W.i1, lw - S.dop, k, ww);
+        }
+        a[q] = spec[k]; b[q] = spec[k + 1]; w[q] = ww;
       }
     }
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
       const int j = base + q * nthr;
-      if (j < S.n2) {
-        const float aa = nan_to_zero(a[q]), bb = nan_to_zero(b[q]);
-        work[j] = (w[q] == 0.f) ? aa : ((w[q] == 1.f) ? bb : aa + (bb - aa) * w[q]);
+      if (j < W.n2) {
+        const float aa = nan_to_zero(a[q]), bb = nan_to_zero(b[q]);   // nan_to_num, smoothing.py:138
+        work[j] = aa + (bb - aa) * w[q];
       }
     }
   }
@@ -477,10 +543,14 @@ PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const Can
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
-PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S,
+PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                           const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
   double acc = 0.0;
   const bool cheb = T.npoly > 0;
+  const bool smooth = S.do_smooth != 0;
+  // plain-interp branch on a geometric grid: t = (lnobs - dop - ln0)/dln
+  const double piA = T.geo_inv_dln, piB = -(S.dop + T.ln0) * T.geo_inv_dln;
+  const float hs_ann = (float)(0.5 * T.dln);
   for (int base = tid; base < T.nobs; base += kU * nthr) {
     float a[kU], b[kU], w[kU], of1[kU], iv[kU];
     double xc[kU];
@@ -492,31 +562,19 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
         const double lo = T.lnobs[i];
         if (T.obs_f1) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }
         if (cheb) xc[q] = T.xcheb[i];
-        nanv[q] = false; a[q] = 0.f; b[q] = 0.f; w[q] = 0.f;
-        if (S.bad) nanv[q] = true;
-        else if (S.do_smooth) {
-          if (lo < S.lnmin || lo > S.lnmax) nanv[q] = true;   // np.interp(left=nan, right=nan)
-          else {
-            int j = (int)((lo - S.lnmin) * S.inv_step);
-            if (j > S.n2 - 2) j = S.n2 - 2;
-            double u = lo - ((double)j * S.step + S.lnmin);
-            if (u < 0.0 && j > 0) { --j; u += S.step; }
-            else if (u >= S.step && j < S.n2 - 2) { ++j; u -= S.step; }
-            a[q] = conv[j]; b[q] = conv[j + 1];
-            const float ww = lerp_weight(u, S.step);
-            w[q] = ww < 0.f ? 0.f : (ww > 1.f ? 1.f : ww);
-          }
+        int k = 0; float ww = 0.f;
+        if (smooth) {
+          nanv[q] = W.bad || (lo < W.lnmin) || (lo > W.lnmax);        // np.interp(left=nan, right=nan)
+          if (!nanv[q]) uniform_locate(lo * W.obA + W.obB, 0, W.n2, W.hs_step, k, ww);
         } else {
           const double v = lo - S.dop;
-          if (v < T.ln0 || v > T.ln_last) nanv[q] = true;
-          else {
-            int k; double u, dv;
-            grid_locate(T, 0, T.npix, v, k, u, dv);
-            a[q] = conv[k]; b[q] = conv[k + 1];
-            const float ww = lerp_weight(u, dv);
-            w[q] = ww < 0.f ? 0.f : (ww > 1.f ? 1.f : ww);
+          nanv[q] = (v < T.ln0) || (v > T.ln_last);
+          if (!nanv[q]) {
+            if (T.geo) uniform_locate(lo * piA + piB, 0, T.npix, hs_ann, k, ww);
+            else search_locate(T, 0, T.npix, v, k, ww);
           }
         }
+        a[q] = conv[k]; b[q] = conv[k + 1]; w[q] = ww;
       }
     }
 #pragma unroll
@@ -548,6 +606,17 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
     }
   }
   return acc;
+}
+
+// chi^2 partial of the thread -> one partial per slot in red[] (GPU: wave shuffle reduction)
+PAYNE_HD void store_partial(int tid, double acc, double* red) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+#else
+  red[tid] = acc;
+#endif
 }
 
 }  // namespace payne

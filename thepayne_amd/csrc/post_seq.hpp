@@ -1,7 +1,13 @@
 // post_seq.hpp -- the order of the phases of post_core.hpp for one candidate.
-// `Ex` supplies "run this phase on every thread of the workgroup, then barrier"
-// (`par`) and the merge of the mask bounds (`imin`/`imax`): DevExec in payne_hip.hip
-// (threadIdx + __syncthreads + LDS atomics), HostExec in tests/emul/cpu_emul.cpp.
+// `Ex` supplies "run this phase on every thread of the workgroup, then barrier" (`par`)
+// and the thread count (`nthreads`): DevExec in payne_hip.hip (threadIdx + __syncthreads),
+// HostExec in tests/emul/cpu_emul.cpp.
+//
+// LOG2N > 0 selects the compile-time FFT geometry for spectra of exactly 2^LOG2N points
+// processed by NT threads (strides, trip counts and twiddle steps become immediates);
+// LOG2N = 0 is the runtime-geometry path (any size, any thread count).  A candidate whose
+// R-stage window needs a shorter FFT than the vsini stage falls back to the runtime path
+// for that stage only.
 #pragma once
 #include "post_core.hpp"
 
@@ -13,7 +19,10 @@
 
 namespace payne {
 
-// M-point complex FFT by ping-pong between a and b; returns where the result is.
+// scratch layout (doubles): [0, nthr) chi^2 partials | [nthr, nthr + nthr/2) mask counts (ints) | result
+PAYNE_HD int scratch_doubles(int nthr) { return nthr + nthr / 2 + 2; }
+
+// M-point complex FFT by ping-pong between a and b, runtime geometry; returns where the result is.
 template <class Ex>
 PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, bool conj_last) {
   c32 *src = a, *dst = b;
@@ -30,14 +39,47 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
   return src;
 }
 
+// The same with compile-time geometry (M points, NT threads, twiddle table of 2M entries).
+template <int M, int P, bool CONJ_LAST, int NT, class Ex>
+PAYNE_SEQ c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* tw) {
+  if constexpr (P >= M) {
+    return src;
+  } else {
+    constexpr int R = (M / P >= 8) ? 8 : (M / P);
+    constexpr bool last = (P * R >= M);
+    ex.par([&](int t, int) { fft_pass_fixed<R, M, P, CONJ_LAST && last, NT>(t, src, dst, tw); });
+    return fft_fixed<M, P * R, CONJ_LAST, NT>(ex, dst, src, tw);
+  }
+}
+
+// One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
+template <int LOG2N, int NT, bool VSINI, class Ex>
+PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* tw, float* work, float* other, int n,
+                            const TaperArgs& ta) {
+  const int M = n / 2;
+  if constexpr (LOG2N > 0) {
+    constexpr int MF = (1 << LOG2N) / 2;
+    if (M == MF) {
+      c32* z = fft_fixed<MF, 1, false, NT>(ex, (c32*)work, (c32*)other, tw);
+      ex.par([&](int t, int) { rfft_taper_phase<VSINI>(t, NT, z, MF, tw, 1, ta); });
+      c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
+      return (float*)fft_fixed<MF, 1, true, NT>(ex, z, zo, tw);
+    }
+  }
+  c32* z = fft_run(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false);
+  ex.par([&](int t, int nt) { rfft_taper_phase<VSINI>(t, nt, z, M, tw, T.nmax / (2 * M), ta); });
+  c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
+  return (float*)fft_run(ex, z, zo, M, tw, T.nmax, true);
+}
+
 // out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze)
-template <class Ex>
+template <int LOG2N, int NT, class Ex>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* tw, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
                              float* out, int out_stage, double* chi2_out) {
   ex.par([&](int t, int n) {
     phase_setup(t, n, T, th, instr_factor, S);
-    phase_load(t, n, T, raw, bufA);
+    phase_load(t, n, T.npix, raw, bufA);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -45,51 +87,48 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* tw, const d
     ex.par([&](int t, int n) { for (int i = t; i < T.npix; i += n) out[i] = spec[i] + kBase; });
     return;
   }
-  if (S.do_rot) {
+  const bool rot = S.do_rot != 0, smooth = S.do_smooth != 0;
+  if (rot) {
     ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
-    const int M = T.n1 / 2;
-    c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, tw, T.nmax, false);
-    ex.par([&](int t, int n) { rfft_taper_phase<true>(t, n, z, M, tw, T.nmax, S.vs_a, T.vs_val, T.vs_tab); });
-    c32* zo = ((float*)z == bufA) ? (c32*)bufB : (c32*)bufA;
-    c32* y = fft_run(ex, z, zo, M, tw, T.nmax, true);
-    float* conv = (float*)y;
+    TaperArgs ta{};
+    ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
+    ta.vs_c = S.vs_a * T.vs_val;                       // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)
+    ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
+    float* conv = conv_stage<LOG2N, NT, true>(ex, T, tw, work, spec, T.n1, ta);
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }          // conv IS on the ANN grid
     else ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); });
-    ex.par([&](int t, int n) { phase_rot_edges(t, T, dst); });
     spec = dst;
     work = conv;
+    if (out_stage == 1 || !smooth) ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
   }
   if (out_stage == 1) {
     ex.par([&](int t, int n) { for (int i = t; i < T.npix; i += n) out[i] = spec[i] + kBase; });
     return;
   }
   const float* on_grid = spec;
-  if (S.do_smooth) {
-    ex.par([&](int t, int n) { phase_mask_scan(t, n, T, th, instr_factor, S); });
-    ex.par([&](int t, int n) { phase_window(t, T, S); });
-    if (!S.bad) {
-      ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, spec, work); });
-      const int M = S.n2 / 2;
-      c32* z = fft_run(ex, (c32*)work, (c32*)spec, M, tw, T.nmax, false);
-      ex.par([&](int t, int n) { rfft_taper_phase<false>(t, n, z, M, tw, T.nmax, S.g_a, S.g_val, nullptr); });
-      c32* zo = ((float*)z == bufA) ? (c32*)bufB : (c32*)bufA;
-      on_grid = (const float*)fft_run(ex, z, zo, M, tw, T.nmax, true);
+  Window W{};
+  if (smooth) {
+    const int nthr = ex.nthreads();
+    int* cnt = reinterpret_cast<int*>(red + nthr);
+    ex.par([&](int t, int n) {
+      if (rot) phase_rot_edges(t, T.npix, spec);       // the count does not touch the spectrum
+      phase_mask_count(t, n, T, S, cnt);
+    });
+    W = make_window(T, S, cnt, n_slots(nthr));
+    if (!W.bad) {
+      ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, W, spec, work); });
+      TaperArgs ta{};
+      ta.g_c2 = W.g_c2;
+      on_grid = conv_stage<LOG2N, NT, false>(ex, T, tw, work, spec, W.n2, ta);
     }
   }
-  ex.par([&](int t, int n) { red[t] = phase_obs(t, n, T, S, on_grid, out, out_stage); });
-  ex.par([&](int t, int n) {
-    const int chunk = (n + 15) / 16;
-    if (t < 16) {
-      double s = 0.0;
-      for (int i = t * chunk; i < (t + 1) * chunk && i < n; ++i) s += red[i];
-      red[n + t] = s;
-    }
-  });
+  ex.par([&](int t, int n) { store_partial(t, phase_obs(t, n, T, S, W, on_grid, out, out_stage), red); });
   ex.par([&](int t, int n) {
     if (t == 0) {
       double s = 0.0;
-      for (int i = 0; i < 16; ++i) s += red[n + i];
+      const int ns = n_slots(n);
+      for (int i = 0; i < ns; ++i) s += red[i];
       *chi2_out = s;
     }
   });
