@@ -1,0 +1,179 @@
+"""The reference-shaped Python API (FitPayne / likelihood / GenMod / PayneSpecPredict /
+FastPayneSEDPredict) driving the HIP engine, against the oracle.  Reads like a test the
+reference would have for these classes."""
+import numpy as np
+import pytest
+
+import oracle as O
+from thepayne_amd import synth, nnio
+from helpers import SPEC_PARS, yst_problem, lnl_tol
+
+pytestmark = pytest.mark.gpu
+ALL_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R',
+            'log(R)', 'Dist', 'log(A)', 'Av', 'Rv', 'CarbonScale']
+
+
+def _save_yst(tmp_path, raw, name="yst.npz"):
+    path = str(tmp_path / name)
+    nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
+    return path
+
+
+def test_payne_spec_predict_yst(tmp_path):
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    assert np.allclose(PP.anns.wavelength, raw["wavelength"]) and PP.anns.resolution == raw["resolution"]
+    lab = [5300.0, 4.1, -0.3, 0.15]
+    assert np.abs(PP.predictspec(lab) - O.yst_forward(raw, lab)).max() < 1e-6
+    obs = synth.obs_grid(raw["wavelength"], 700, inset=1.5)
+    kw = dict(Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
+    for extra in (dict(rad_vel=12.0, rot_vel=4.0, inst_R=2.355 * 28000.0, outwave=obs),
+                  dict(rad_vel=-20.0, rot_vel=0.0, inst_R=2.355 * 20000.0, outwave=obs),
+                  dict(rad_vel=5.0, rot_vel=2.0, outwave=obs),                      # no inst_R: plain interpolation
+                  dict(rot_vel=3.0),                                               # model grid, rotation only
+                  dict(rad_vel=30.0, rot_vel=3.0)):                                # shifted model grid
+        w, f = PP.getspec(**kw, **extra)
+        wr, fr = O.getspec(raw, **kw, **extra)
+        assert np.allclose(w, wr, rtol=0, atol=1e-9)
+        assert np.array_equal(np.isnan(f), np.isnan(fr)) and np.nanmax(np.abs(f - fr)) < 1e-6
+    # aliases and defaults (ystpred.py:132-165): solar defaults when labels are absent
+    w1, f1 = PP.getspec(**{'logt': np.log10(5300.0), 'log(g)': 4.1, '[Fe/H]': -0.3, '[a/Fe]': 0.15}, rot_vel=3.0)
+    w2, f2 = PP.getspec(**kw, rot_vel=3.0)
+    assert np.abs(f1 - f2).max() < 2e-6
+    _, fs = PP.getspec()
+    assert np.abs(fs - O.yst_forward(raw, [5770.0, 4.44, 0.0, 0.0])).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        PP.getspec(**kw, inst_R=np.full(1024, 0.1), outwave=obs)                   # LSF vector: not built yet
+
+
+def test_payne_spec_predict_linnet(tmp_path):
+    from thepayne_amd.predict.predictspec import PayneSpecPredict
+    raw = synth.make_torch_net("LinNet", npix=512, seed=7)
+    path = str(tmp_path / "lin.npz")
+    d = {("model/" + k if k.startswith("lin") else k): v for k, v in raw.items() if k != "kind"}
+    d["wavelengths"] = d.pop("wavelength")
+    nnio.save_npz(path, d)
+    PP = PayneSpecPredict(nnpath=path, NNtype='LinNet')
+    lab = [6100.0, 3.9, -0.8, 0.2]
+    ref = O.torchnet_forward(raw, lab)
+    got = PP.predictspec(lab)
+    assert got.dtype == np.float32 and np.abs(got - ref).max() < 3e-6
+
+
+def test_sed_predictors():
+    from thepayne_amd.predict.predictsed import FastPayneSEDPredict, PayneSEDPredict
+    phot = synth.make_phot_nets()
+    S = FastPayneSEDPredict(usebands=phot["filters"], nnpath=phot)
+    oph = dict(phot); oph["hiav"] = np.array(S.HiAv.Avlist, dtype=float)
+    for av in (0.3, 4.999, 5.0, 7.5):
+        m = S.sed(logt=np.log10(5800.0), logg=4.3, feh=-0.2, afe=0.1, av=av, rv=3.3, logl=0.1, dist=150.0)
+        assert np.abs(m - O.sed_mags(oph, np.log10(5800.0), 4.3, -0.2, 0.1, av=av, rv=3.3, logl=0.1, dist=150.0)).max() < 1e-9
+        m = S.sed(logt=np.log10(4800.0), logg=2.3, feh=-1.2, afe=0.3, av=av, logA=1.7)
+        assert np.abs(m - O.sed_mags(oph, np.log10(4800.0), 2.3, -1.2, 0.3, av=av, logA=1.7)).max() < 1e-9
+    assert len(S.sed(logt=3.76, logg=4.4, feh=0, afe=0, logA=0.0, band_indices=slice(0, 3))) == 3
+    with pytest.raises(IOError):
+        S.sed(logt=3.76, logg=4.4, feh=0, afe=0)
+    x = [5800.0, 4.3, -0.2, 0.1, 0.4, 3.1]
+    assert np.abs(S.anns.eval(x) - O.fastann_forward(phot, x)).max() < 1e-10
+    P = PayneSEDPredict(usebands=phot["filters"], nnpath=phot)
+    assert np.allclose(P.sed(logt=3.7, logg=4.0, feh=0, afe=0, av=0.2, rv=3.1, logA=1.0),
+                       S.sed(logt=3.7, logg=4.0, feh=0, afe=0, av=0.2, rv=3.1, logA=1.0))
+
+
+def _fit_objects(tmp_path, photscale=True, modpoly=False):
+    from thepayne_amd.fitting.likelihood import likelihood
+    from thepayne_amd.fitting.prior import prior
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    phot = synth.make_phot_nets()
+    obs_phot = {f: [5.0 + 0.1 * i, 0.05] for i, f in enumerate(phot["filters"])}
+    on = SPEC_PARS + (['log(A)', 'Av'] if photscale else ['log(R)', 'Dist', 'Av'])
+    names = list(ALL_PARS) + (['pc_0', 'pc_1', 'pc_2'] if modpoly else [])
+    fitpars = [names, {p: (p in on or p.startswith('pc_')) for p in names}]
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+               'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1', 'fixedpars': {},
+               'photANNpath': phot, 'obs_phot': obs_phot}
+    runbools = [True, True, modpoly, photscale, False]
+    pd = synth.demo_priordict()
+    pd['log(A)'] = {'pv_uniform': [-1.0, 1.0]}
+    pd['Av'] = {'pv_uniform': [0.0, 2.0]}
+    pd['log(R)'] = {'pv_uniform': [-0.5, 0.5]}
+    pd['Dist'] = {'pv_uniform': [10.0, 1000.0]}
+    if modpoly:
+        pd['blaze_coeff'] = [[0.0, 0.05], [0.0, 0.02], [0.0, 0.01]]
+    L = likelihood(fitargs, fitpars, runbools, b_max=64)
+    P = prior(fitargs, pd, fitpars, runbools)
+    OL = O.OracleLikelihood(raw, obs, flux, eflux, L.fitpars_i, phot=dict(phot, hiav=None), obs_phot=obs_phot,
+                            photscale=photscale, modpoly=modpoly)
+    from thepayne_amd.engine import highav_coefficients
+    OL.phot["hiav"] = highav_coefficients(phot["filters"])
+    return L, P, OL
+
+
+@pytest.mark.parametrize("photscale,modpoly", [(True, False), (False, False), (True, True)])
+def test_likelihood_object_scalar_and_batch(tmp_path, photscale, modpoly):
+    from thepayne_amd.fitting.fitstar import lnprobfn, lnprob_batch
+    L, P, OL = _fit_objects(tmp_path, photscale, modpoly)
+    assert L.ndim == len(L.fitpars_i) == P.ndim
+    U = np.random.default_rng(4).uniform(size=(24, L.ndim))
+    theta = P.priortrans_batch(U)
+    ref = np.array([OL.lnlikefn(t) for t in theta])
+    got = L.lnlike_batch(theta)
+    assert np.all(np.abs(got - ref) <= lnl_tol(ref))
+    one = L.lnlikefn(theta[3])
+    assert isinstance(one, float) and abs(one - ref[3]) <= lnl_tol(ref[3])
+    assert list(L.parsdict.keys())[:L.ndim] == L.fitpars_i and L.parsdict['Teff'] == theta[3, 0]
+    assert abs(lnprobfn(theta[5], L, P) - ref[5]) <= lnl_tol(ref[5])
+    assert np.all(np.abs(lnprob_batch(theta, L, P) - ref) <= lnl_tol(ref))
+    # explicit specpars / photpars lists (likelihood.lnlike signature)
+    sp, pp = OL.split([float(x) for x in theta[7]])
+    assert abs(L.lnlike(specpars=sp, photpars=pp) - ref[7]) <= lnl_tol(ref[7])
+    # GenMod pieces
+    w, f = L.GM.genspec(sp, outwave=L.fitargs['obs_wave_fit'], modpoly=modpoly)
+    _, fr = O.genspec(OL.net, sp, outwave=OL.obs_wave, modpoly=modpoly)
+    assert np.nanmax(np.abs(f - fr)) < 2e-6
+    mags = L.GM.genphot_scaled(pp) if photscale else L.GM.genphot(pp)
+    mref = np.atleast_1d(O.genphot_scaled(OL.phot, pp) if photscale else O.genphot(OL.phot, pp))
+    assert list(mags.keys()) == list(L.fitargs['obs_phot'].keys())
+    assert np.abs(np.array(list(mags.values())) - mref).max() < 1e-9
+
+
+def test_fixed_parameters_are_merged(tmp_path):
+    from thepayne_amd.fitting.likelihood import likelihood
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    names = list(ALL_PARS)
+    on = [p for p in SPEC_PARS if p not in ('[a/Fe]', 'Vrot')]
+    fitpars = [names, {p: p in on for p in names}]
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+               'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1', 'fixedpars': {'[a/Fe]': 0.03, 'Vrot': 2.5}}
+    L = likelihood(fitargs, fitpars, [True, False, False, False, False], b_max=8)
+    OL = O.OracleLikelihood(raw, obs, flux, eflux, on, fixedpars=fitargs['fixedpars'])
+    th = np.array([5600.0, 4.3, 0.02, 10.2, 28500.0])
+    assert abs(L.lnlikefn(th) - OL.lnlikefn(th)) <= lnl_tol(OL.lnlikefn(th))
+    assert L.parsdict['Vrot'] == 2.5
+
+
+def test_fitpayne_run_end_to_end(tmp_path):
+    """C1-style plumbing: the reference's inputdict through FitPayne.run with the batched
+    sampler; the posterior must bracket the truth and the output file keep its format."""
+    from thepayne_amd.fitting.fitstar import FitPayne
+    raw, obs, flux, eflux = yst_problem("small", H=64, line_depth=0.3)
+    inputdict = {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1',
+        'sampler': {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': 128,
+                    'walks': 20, 'delta_logz_final': 0.5, 'bootstrap': 0, 'flushnum': 200, 'seed': 3},
+        'priordict': synth.demo_priordict(),
+        'output': str(tmp_path / 'fit.dat'),
+    }
+    sampler = FitPayne().run(inputdict=inputdict, verbose=False)
+    r = sampler.results
+    w = sampler.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+    lines = open(inputdict['output']).read().splitlines()
+    assert lines[0].split()[:2] == ['Iter', 'Teff'] and lines[0].split()[-7:] == ['log(lk)', 'log(vol)', 'log(wt)', 'h', 'nc', 'log(z)', 'delta(log(z))']
+    assert len(lines) == 1 + r.niter and len(lines[1].split()) == 1 + 7 + 7
