@@ -21,7 +21,7 @@ struct HostExec {
 template <int LOG2N>
 static void run_one(HostExec& ex, const PostTables& T, const double* th, double factor, const float* raw, float* a,
                     float* b, CandState& S, double* red, float* out, int stage, double* x2) {
-  run_candidate<LOG2N, 256>(ex, T, T.tw, th, factor, raw, a, b, S, red, out, stage, x2);
+  run_candidate<LOG2N, 256>(ex, T, T.twf, th, factor, raw, a, b, S, red, out, stage, x2);
 }
 
 extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const double* obs_wave,
@@ -37,7 +37,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   std::memset(&T, 0, sizeof(T));
   fill_model_scalars(H, T);
   T.nobs = nobs; T.vs_tab = H.vs_tab32.data();
-  T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data();
+  T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data(); T.twf = H.twf.data();
   T.rs1_idx = H.rs1_idx.data(); T.rs1_frac = H.rs1_frac.data();
   T.bk1_idx = H.bk1_idx.data(); T.bk1_frac = H.bk1_frac.data();
   T.lnobs = H.lnobs.data(); T.xcheb = H.xcheb.data();
@@ -61,7 +61,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
     else if (fixed && H.n1 == 2048) run_one<11>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     else if (fixed && H.n1 == 1024) run_one<10>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     else if (fixed && H.n1 == 8192) run_one<13>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
-    else run_candidate<0, 256>(ex, T, T.tw, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    else run_candidate<0, 256>(ex, T, T.twf, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     if (chi2) chi2[c] = x2;
     if (info) {   // mask first / count / FFT length, recomputed the way the kernel derives them
       info[3 * c] = info[3 * c + 1] = info[3 * c + 2] = -1;

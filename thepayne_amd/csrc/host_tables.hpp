@@ -17,7 +17,7 @@ namespace payne {
 struct HostTables {
   int npix = 0, nobs = 0, n1 = 0, nmax = 0;
   std::vector<double> lnlam, lam, lnobs, xcheb;
-  std::vector<c32> tw;
+  std::vector<c32> tw, twf;
   std::vector<int> rs1_idx, bk1_idx;
   std::vector<float> rs1_frac, bk1_frac, obs_f1, obs_ivar;
   double vs_val = 0, obs_min = 0, obs_max = 0, geo_inv_dln = 0;
@@ -33,6 +33,7 @@ inline void fill_model_scalars(const HostTables& H, PostTables& T) {
   T.npix = H.npix; T.n1 = H.n1; T.nmax = H.nmax; T.vs_val = H.vs_val;
   T.geo_inv_dln = H.geo_inv_dln; T.geo = H.geo; T.ln0 = H.ln0; T.dln = H.dln; T.ln_last = H.ln_last;
   T.vs_tab_n = (int)H.vs_tab32.size();
+  T.twf_n = (int)H.twf.size();
   T.rot_identity = H.rot_identity;
 }
 
@@ -125,6 +126,24 @@ inline int build_model_tables(const double* wave, int npix, HostTables& H) {
   for (int j = 0; j < H.nmax; ++j) {
     const double a = 2.0 * kPi * (double)j / (double)H.nmax;
     H.tw[j] = {(float)std::cos(a), (float)(-std::sin(a))};
+  }
+  // pass-ordered twiddles of the fixed-geometry (n1/2)-point FFT + the real-FFT split factors
+  {
+    const int M = H.n1 / 2;
+    H.twf.clear();
+    for (int P = 1; P < M; P *= plan_radix(M, P)) {
+      const int R = plan_radix(M, P);
+      if (P == 1) continue;
+      for (int r = 1; r < R; ++r)
+        for (int k = 0; k < P; ++k) {
+          const double a = 2.0 * kPi * (double)k * (double)r / ((double)P * (double)R);
+          H.twf.push_back({(float)std::cos(a), (float)(-std::sin(a))});
+        }
+    }
+    for (int k = 0; k < M / 2; ++k) {
+      const double a = 2.0 * kPi * (double)k / (double)(2 * M);
+      H.twf.push_back({(float)std::cos(a), (float)(-std::sin(a))});
+    }
   }
   return 0;
 }

@@ -321,12 +321,13 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   float* bufB = bufA + n1;
   double* red = reinterpret_cast<double*>(bufB + n1);          // scratch_doubles(256)
   CandState* S = reinterpret_cast<CandState*>(red + scratch_doubles(kPostThreads));
-  const c32* tw = T.tw;
-  if (TW_LDS) {   // full twiddle circle into LDS: the FFT passes then never leave the CU
+  const c32* twf = T.twf;
+  if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
     c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
-    const c32* __restrict__ g = T.tw;
-    for (int i = threadIdx.x; i < n1; i += kPostThreads) twl[i] = g[i];
-    tw = twl;                                                  // made visible by the first phase barrier
+    const c32* __restrict__ g = T.twf;
+    const int nt = T.twf_n;
+    for (int i = threadIdx.x; i < nt; i += kPostThreads) twl[i] = g[i];
+    twf = twl;                                                 // made visible by the first phase barrier
   }
   const int b = blockIdx.x;
   DevExec ex;
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   }
 #endif
   double* chi2 = red + scratch_doubles(kPostThreads) - 1;
-  run_candidate<LOG2N, kPostThreads>(ex, T, tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+  run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
                                      a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red,
                                      a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2);
   if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
@@ -654,6 +655,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if ((rc = upload(c, c->H.lnlam, &T.lnlam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lam, &T.lam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.tw, &T.tw, c->owned))) return bail(rc);
+    if ((rc = upload(c, c->H.twf, &T.twf, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.rs1_idx, &T.rs1_idx, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.rs1_frac, &T.rs1_frac, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.bk1_idx, &T.bk1_idx, c->owned))) return bail(rc);
@@ -666,9 +668,10 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
     c->post_lds = (size_t)T.n1 * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
     // twiddles in LDS while two workgroups still fit a CU (160 KiB); larger spectra read them from L2
-    c->post_tw_lds = (c->post_lds + (size_t)T.n1 * 8) <= 80 * 1024;
+    const size_t tw_bytes = c->H.twf.size() * sizeof(c32);         // ~0.75 n1 entries
+    c->post_tw_lds = (c->post_lds + tw_bytes) <= 80 * 1024;
     if (getenv("PAYNE_TW_GLOBAL")) c->post_tw_lds = false;
-    if (c->post_tw_lds) c->post_lds += (size_t)T.n1 * 8;
+    if (c->post_tw_lds) c->post_lds += tw_bytes;
     c->post_fn = pick_post_kernel(getenv("PAYNE_POST_GENERIC") ? 0 : T.n1, c->post_tw_lds);
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));

@@ -69,7 +69,9 @@ struct PostTables {
   int nmax;            // twiddle table length (== n1)
   const double* lnlam;     // [npix]  ln(lambda_ANN)
   const double* lam;       // [npix]  lambda_ANN (exact mask test)
-  const c32* tw;           // [nmax]  exp(-2 pi i j / nmax), full circle
+  const c32* tw;           // [nmax]  exp(-2 pi i j / nmax), full circle (runtime-geometry FFT)
+  const c32* twf;          // [twf_n] pass-ordered twiddles of the n1/2-point FFT + exp(-2 pi i k/n1), k < n1/4
+  int twf_n;
   // vsini stage maps (theta-independent, smoothing.py:649-668 + :311)
   const int* rs1_idx;      // [n1]   source pixel k of resampled point j
   const float* rs1_frac;   // [n1]   weight of pixel k+1
@@ -177,12 +179,26 @@ PAYNE_HD void fft_pass(int tid, int nthr, const c32* __restrict__ src, c32* __re
 }
 PAYNE_HD int pass_radix(int M, int p) { int rem = M / p; return rem >= 8 ? 8 : rem; }
 
-// Compile-time-geometry pass: M points, sub-length P, NT threads, twiddle table of 2M
-// entries.  Strides, trip counts and twiddle steps fold to immediates.
-template <int R, int M, int P, bool CONJ, int NT>
+// Compile-time geometry ("plan") of an M-point FFT: greedy radix-8 passes, then 4 or 2.
+// Its twiddles are stored PASS-ORDERED: for every pass with sub-length P > 1 and radix R,
+// (R-1)*P entries  twf[off(P) + (r-1)*P + k] = exp(-2 pi i k r/(P R))  -- the lanes of a wave
+// read consecutive k, so the LDS reads are conflict-free (a plain full-circle table is read
+// with stride 2M/(P R): 8- to 16-way bank conflicts) -- followed by the M/2 factors
+// exp(-2 pi i k/2M) of the real-FFT split.
+constexpr int plan_radix(int M, int P) { return (M / P >= 8) ? 8 : (M / P); }
+constexpr int plan_offset(int M, int P) {
+  int off = 0, p = 1;
+  while (p < P) { const int r = plan_radix(M, p); if (p > 1) off += (r - 1) * p; p *= r; }
+  return off;
+}
+constexpr int plan_total(int M) { return plan_offset(M, M); }
+constexpr int plan_table_len(int M) { return plan_total(M) + M / 2; }
+
+// One pass: M points, sub-length P, NT threads; `sign` = 0x80000000 conjugates the output.
+template <int R, int M, int P, int NT>
 PAYNE_HD void fft_pass_fixed(int tid, const c32* __restrict__ src, c32* __restrict__ dst,
-                             const c32* __restrict__ tw) {
-  constexpr int NB = M / R, TS = (2 * M) / (P * R);
+                             const c32* __restrict__ twf, unsigned sign) {
+  constexpr int NB = M / R, OFF = plan_offset(M, P);
 #pragma unroll
   for (int i0 = 0; i0 < NB; i0 += NT) {
     const int i = i0 + tid;
@@ -194,14 +210,19 @@ PAYNE_HD void fft_pass_fixed(int tid, const c32* __restrict__ src, c32* __restri
     if (P > 1) {
       c32 w[R];
 #pragma unroll
-      for (int r = 1; r < R; ++r) w[r] = tw[(k * r) * TS];
+      for (int r = 1; r < R; ++r) w[r] = twf[OFF + (r - 1) * P + k];
 #pragma unroll
       for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
     }
     dftR<R>(u);
     const int j = (i - k) * R + k;
 #pragma unroll
-    for (int r = 0; r < R; ++r) dst[j + r * P] = CONJ ? cconj(u[r]) : u[r];
+    for (int r = 0; r < R; ++r) {
+      c32 v = u[r];
+      union { float f; unsigned b; } cv;
+      cv.f = v.y; cv.b ^= sign; v.y = cv.f;
+      dst[j + r * P] = v;
+    }
   }
 }
 
@@ -374,8 +395,11 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
     for (int i = 0; i < T.npoly && i < 12; ++i) S.poly[i] = th[8 + i];
 }
 
-// P1: load the raw ANN spectrum (already shifted by -1) into LDS.
-PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ raw, float* __restrict__ spec) {
+// P1: load the raw ANN spectrum (already shifted by -1) into LDS.  SCRUB applies
+// nan_to_num(nan=1.0) (0 in shifted flux, smoothing.py:138) on the way: used when the row
+// goes straight into the vsini FFT (identity resampling maps).
+PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ raw, float* __restrict__ spec,
+                         bool scrub) {
   if (((npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0)) {
     const int n4 = npix >> 2;
     for (int base = tid; base < n4; base += kU * nthr) {
@@ -388,11 +412,14 @@ PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ 
 #pragma unroll
       for (int q = 0; q < kU; ++q) {
         const int i = base + q * nthr;
-        if (i < n4) { spec[4 * i] = v[q][0]; spec[4 * i + 1] = v[q][1]; spec[4 * i + 2] = v[q][2]; spec[4 * i + 3] = v[q][3]; }
+        if (i < n4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) spec[4 * i + e] = scrub ? nan_to_zero(v[q][e]) : v[q][e];
+        }
       }
     }
   } else {
-    for (int i = tid; i < npix; i += nthr) spec[i] = raw[i];
+    for (int i = tid; i < npix; i += nthr) spec[i] = scrub ? nan_to_zero(raw[i]) : raw[i];
   }
 }
 
@@ -456,15 +483,16 @@ PAYNE_HD void phase_rot_edges(int tid, int npix, float* spec) {
 PAYNE_HD void phase_mask_count(int tid, int nthr, const PostTables& T, const CandState& S, int* cnt) {
   const double wl = S.wl, wh = S.wh, op = S.one_plus;
   int cb = 0, ca = 0;
-  for (int base = tid; base < T.npix; base += kU * nthr) {
-    double wc[kU];
+  constexpr int MU = 8;                                  // global loads: keep 8 in flight per thread
+  for (int base = tid; base < T.npix; base += MU * nthr) {
+    double wc[MU];
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < MU; ++q) {
       const int i = base + q * nthr;
       if (i < T.npix) wc[q] = T.lam[i];
     }
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < MU; ++q) {
       const int i = base + q * nthr;
       if (i < T.npix) {
         const double c = wc[q] * op;
@@ -545,18 +573,19 @@ PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const Can
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
 PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                           const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
-  double acc = 0.0;
-  const bool cheb = T.npoly > 0;
+  float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the
+  const bool cheb = T.npoly > 0;                         // cross-thread reduction is fp64
   const bool smooth = S.do_smooth != 0;
+  constexpr int OU = 8;                                  // global loads: keep 8 pixels in flight per thread
   // plain-interp branch on a geometric grid: t = (lnobs - dop - ln0)/dln
   const double piA = T.geo_inv_dln, piB = -(S.dop + T.ln0) * T.geo_inv_dln;
   const float hs_ann = (float)(0.5 * T.dln);
-  for (int base = tid; base < T.nobs; base += kU * nthr) {
-    float a[kU], b[kU], w[kU], of1[kU], iv[kU];
-    double xc[kU];
-    bool nanv[kU];
+  for (int base = tid; base < T.nobs; base += OU * nthr) {
+    float a[OU], b[OU], w[OU], of1[OU], iv[OU];
+    double xc[OU];
+    bool nanv[OU];
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < OU; ++q) {
       const int i = base + q * nthr;
       if (i < T.nobs) {
         const double lo = T.lnobs[i];
@@ -578,7 +607,7 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
       }
     }
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < OU; ++q) {
       const int i = base + q * nthr;
       if (i < T.nobs) {
         const float m1 = nanv[q] ? nanf_() : a[q] + (b[q] - a[q]) * w[q];
@@ -600,12 +629,12 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
         if (out) out[i] = (out_stage == 3) ? (m1 + kBase) * p : (m1 + kBase);   // genspec / getspec
         if (T.obs_f1) {
           const float d = cheb ? (m1 * p + (pm1 - of1[q])) : (m1 - of1[q]);
-          acc += (double)(d * d * iv[q]);
+          acc = fmaf(d * d, iv[q], acc);
         }
       }
     }
   }
-  return acc;
+  return (double)acc;
 }
 
 // chi^2 partial of the thread -> one partial per slot in red[] (GPU: wave shuffle reduction)

@@ -13,8 +13,10 @@
 
 #ifdef __HIPCC__
 #define PAYNE_SEQ __device__ __forceinline__
+#define PAYNE_SEQ_CALL __device__ __attribute__((noinline))
 #else
 #define PAYNE_SEQ inline
+#define PAYNE_SEQ_CALL inline
 #endif
 
 namespace payne {
@@ -39,33 +41,42 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
   return src;
 }
 
-// The same with compile-time geometry (M points, NT threads, twiddle table of 2M entries).
-template <int M, int P, bool CONJ_LAST, int NT, class Ex>
-PAYNE_SEQ c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* tw) {
+// The same with compile-time geometry (M points, NT threads, pass-ordered twiddles `twf`).
+template <int M, int P, int NT, class Ex>
+PAYNE_SEQ c32* fft_fixed_passes(Ex& ex, c32* src, c32* dst, const c32* twf, unsigned sign_last) {
   if constexpr (P >= M) {
     return src;
   } else {
-    constexpr int R = (M / P >= 8) ? 8 : (M / P);
+    constexpr int R = plan_radix(M, P);
     constexpr bool last = (P * R >= M);
-    ex.par([&](int t, int) { fft_pass_fixed<R, M, P, CONJ_LAST && last, NT>(t, src, dst, tw); });
-    return fft_fixed<M, P * R, CONJ_LAST, NT>(ex, dst, src, tw);
+    const unsigned sign = last ? sign_last : 0u;
+    ex.par([&](int t, int) { fft_pass_fixed<R, M, P, NT>(t, src, dst, twf, sign); });
+    return fft_fixed_passes<M, P * R, NT>(ex, dst, src, twf, sign_last);
   }
+}
+// One body for the four transforms of a candidate (2 stages x forward/inverse): kept out of
+// line so the instruction stream stays small enough for the instruction cache.
+template <int M, int NT, class Ex>
+PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsigned sign_last) {
+  return fft_fixed_passes<M, 1, NT>(ex, src, dst, twf, sign_last);
 }
 
 // One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
+// `twf`: pass-ordered table of the fixed geometry (LDS or global); T.tw: plain full circle.
 template <int LOG2N, int NT, bool VSINI, class Ex>
-PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* tw, float* work, float* other, int n,
+PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
                             const TaperArgs& ta) {
   const int M = n / 2;
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
-      c32* z = fft_fixed<MF, 1, false, NT>(ex, (c32*)work, (c32*)other, tw);
-      ex.par([&](int t, int) { rfft_taper_phase<VSINI>(t, NT, z, MF, tw, 1, ta); });
+      c32* z = fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u);
+      ex.par([&](int t, int) { rfft_taper_phase<VSINI>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
-      return (float*)fft_fixed<MF, 1, true, NT>(ex, z, zo, tw);
+      return (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u);
     }
   }
+  const c32* tw = T.tw;
   c32* z = fft_run(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false);
   ex.par([&](int t, int nt) { rfft_taper_phase<VSINI>(t, nt, z, M, tw, T.nmax / (2 * M), ta); });
   c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
@@ -74,12 +85,14 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* tw, float* w
 
 // out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze)
 template <int LOG2N, int NT, class Ex>
-PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* tw, const double* th, double instr_factor,
+PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
                              float* out, int out_stage, double* chi2_out) {
+  // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer
+  const bool direct = (out_stage != 0) && T.rot_identity && (th[5] != 0.0);
   ex.par([&](int t, int n) {
     phase_setup(t, n, T, th, instr_factor, S);
-    phase_load(t, n, T.npix, raw, bufA);
+    phase_load(t, n, T.npix, raw, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -89,12 +102,12 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* tw, const d
   }
   const bool rot = S.do_rot != 0, smooth = S.do_smooth != 0;
   if (rot) {
-    ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
+    if (!direct) ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
     TaperArgs ta{};
     ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
     ta.vs_c = S.vs_a * T.vs_val;                       // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)
     ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
-    float* conv = conv_stage<LOG2N, NT, true>(ex, T, tw, work, spec, T.n1, ta);
+    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta);
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }          // conv IS on the ANN grid
     else ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); });
@@ -120,7 +133,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* tw, const d
       ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, W, spec, work); });
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
-      on_grid = conv_stage<LOG2N, NT, false>(ex, T, tw, work, spec, W.n2, ta);
+      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta);
     }
   }
   ex.par([&](int t, int n) { store_partial(t, phase_obs(t, n, T, S, W, on_grid, out, out_stage), red); });
