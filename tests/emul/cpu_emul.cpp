@@ -21,7 +21,7 @@ struct HostExec {
 template <int LOG2N>
 static void run_one(HostExec& ex, const PostTables& T, const double* th, double factor, const float* raw, float* a,
                     float* b, CandState& S, double* red, float* out, int stage, double* x2) {
-  run_candidate<LOG2N, 256>(ex, T, T.twf, th, factor, raw, a, b, S, red, out, stage, x2);
+  run_candidate<LOG2N, kPostThreads>(ex, T, T.twf, th, factor, raw, a, b, S, red, out, stage, x2);
 }
 
 extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const double* obs_wave,
@@ -49,7 +49,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   HostExec ex{nthreads};
   std::vector<float> a(H.n1), b(H.n1);
   std::vector<double> red(scratch_doubles(nthreads));
-  const bool fixed = (nthreads == 256) && !force_general;
+  const bool fixed = (nthreads == kPostThreads) && !force_general;
   for (int c = 0; c < B; ++c) {
     CandState S;
     std::memset(&S, 0, sizeof(S));
@@ -61,7 +61,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
     else if (fixed && H.n1 == 2048) run_one<11>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     else if (fixed && H.n1 == 1024) run_one<10>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     else if (fixed && H.n1 == 8192) run_one<13>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
-    else run_candidate<0, 256>(ex, T, T.twf, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    else run_candidate<0, kPostThreads>(ex, T, T.twf, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     if (chi2) chi2[c] = x2;
     if (info) {   // mask first / count / FFT length, recomputed the way the kernel derives them
       info[3 * c] = info[3 * c + 1] = info[3 * c + 2] = -1;

@@ -204,62 +204,70 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
   const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
   const int row = tm * 16 + r, col = tn * 16 + r;
   const bool rowok = row < p.B, colok = col < p.N;
-  float xh[PAYNE_MAX_LABELS];
-  if (FUSE_L0) {
+  float xh[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool fast0 = FUSE_L0 && (p.n_labels == 4);            // 4-label nets: W0 rows are float4
+  if (FUSE_L0 && rowok) {
 #pragma unroll
-    for (int d = 0; d < PAYNE_MAX_LABELS; ++d) {
-      xh[d] = 0.f;
-      if (d < p.n_labels && rowok) {
-        const double x = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)];
-        xh[d] = (float)((x - p.xmin[d]) / p.xden[d] - 0.5);
-      }
-    }
+    for (int d = 0; d < 4; ++d)
+      if (d < p.n_labels) xh[d] = (float)((p.theta[(size_t)row * p.ld_theta + d] - p.xmin[d]) / p.xden[d] - 0.5);
   }
+  float xh4 = 0.f;                                            // 5th label (vmic, theta column 6)
+  if (FUSE_L0 && rowok && p.n_labels == 5)
+    xh4 = (float)((p.theta[(size_t)row * p.ld_theta + 6] - p.xmin[4]) / p.xden[4] - 0.5);
   f32x4_t acc[2];
   acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const float* wrow = p.W + (size_t)(colok ? col : 0) * p.K;
   const float* xrow = FUSE_L0 ? nullptr : p.X + (size_t)(rowok ? row : 0) * p.ldx;
-#pragma unroll 2
-  for (int k0 = 0; k0 < p.K; k0 += 32) {
+  // K is walked 64 at a time: the 4 steps' operand loads (B fragment, and W0/b0 rows or the A
+  // fragment) are all issued before the first MFMA, so one L2 latency is paid per 64 k, not per 16.
+  constexpr int SU = 4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < p.K; k0 += 16 * SU) {
+    float4 b[SU], a[SU], bb[SU], w0[SU][4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = k0 + h * 16 + 4 * g;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (k < p.K) {
-        if (colok) b = *reinterpret_cast<const float4*>(wrow + k);
-        if (FUSE_L0) {
-          float o[4] = {0.f, 0.f, 0.f, 0.f};
-          if (rowok && p.n_labels == 4 && k + 3 < p.K0) {          // common case: 5 wide loads per step
-            const float4 bb = *reinterpret_cast<const float4*>(p.b0 + k);
-            const float4* w0 = reinterpret_cast<const float4*>(p.W0 + (size_t)k * 4);
-            const float4 w0a = w0[0], w0b = w0[1], w0c = w0[2], w0d = w0[3];
-            o[0] = act_apply(fmaf(w0a.w, xh[3], fmaf(w0a.z, xh[2], fmaf(w0a.y, xh[1], fmaf(w0a.x, xh[0], bb.x)))), p.act0);
-            o[1] = act_apply(fmaf(w0b.w, xh[3], fmaf(w0b.z, xh[2], fmaf(w0b.y, xh[1], fmaf(w0b.x, xh[0], bb.y)))), p.act0);
-            o[2] = act_apply(fmaf(w0c.w, xh[3], fmaf(w0c.z, xh[2], fmaf(w0c.y, xh[1], fmaf(w0c.x, xh[0], bb.z)))), p.act0);
-            o[3] = act_apply(fmaf(w0d.w, xh[3], fmaf(w0d.z, xh[2], fmaf(w0d.y, xh[1], fmaf(w0d.x, xh[0], bb.w)))), p.act0);
-          } else if (rowok) {
+    for (int s = 0; s < SU; ++s) {
+      const int k = k0 + s * 16 + 4 * g;
+      b[s] = (colok && k < p.K) ? *reinterpret_cast<const float4*>(wrow + k) : z4;
+      if (FUSE_L0) {
+        if (fast0 && rowok && k + 3 < p.K0) {
+          bb[s] = *reinterpret_cast<const float4*>(p.b0 + k);
+          const float4* wp = reinterpret_cast<const float4*>(p.W0 + (size_t)k * 4);
+          w0[s][0] = wp[0]; w0[s][1] = wp[1]; w0[s][2] = wp[2]; w0[s][3] = wp[3];
+        }
+      } else {
+        a[s] = (rowok && k < p.K) ? *reinterpret_cast<const float4*>(xrow + k) : z4;
+      }
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (k + j < p.K0) {
-                float z = p.b0[k + j];
-                const float* w0 = p.W0 + (size_t)(k + j) * p.n_labels;
+    for (int s = 0; s < SU; ++s) {
+      const int k = k0 + s * 16 + 4 * g;
+      if (FUSE_L0) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (fast0 && rowok && k + 3 < p.K0) {
+          const float bq[4] = {bb[s].x, bb[s].y, bb[s].z, bb[s].w};
 #pragma unroll
-                for (int d = 0; d < PAYNE_MAX_LABELS; ++d)
-                  if (d < p.n_labels) z = fmaf(w0[d], xh[d], z);
-                o[j] = act_apply(z, p.act0);
-              }
+          for (int j = 0; j < 4; ++j)
+            o[j] = act_apply(fmaf(w0[s][j].w, xh[3], fmaf(w0[s][j].z, xh[2], fmaf(w0[s][j].y, xh[1], fmaf(w0[s][j].x, xh[0], bq[j])))), p.act0);
+        } else if (rowok) {                                   // 5-label nets / ragged tail
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (k + j < p.K0) {
+              float z = p.b0[k + j];
+              const float* wq = p.W0 + (size_t)(k + j) * p.n_labels;
+              for (int d = 0; d < p.n_labels && d < 4; ++d) z = fmaf(wq[d], xh[d], z);
+              if (p.n_labels == 5) z = fmaf(wq[4], xh4, z);
+              o[j] = act_apply(z, p.act0);
             }
           }
-          a = make_float4(o[0], o[1], o[2], o[3]);
-        } else if (rowok) {
-          a = *reinterpret_cast<const float4*>(xrow + k);
         }
+        a[s] = make_float4(o[0], o[1], o[2], o[3]);
       }
-      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[h], 0, 0, 0);
-      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[h], 0, 0, 0);
-      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[h], 0, 0, 0);
-      acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[h], 0, 0, 0);
+      f32x4_t& c = acc[s & 1];
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b[s].x, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, b[s].y, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, b[s].z, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, b[s].w, c, 0, 0, 0);
     }
   }
   // C/D map of the 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg
@@ -309,8 +317,6 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
   for (int f = 0; f < F; ++f) { const double d = mags[f] - obs[f]; s += (d * d) / (err[f] * err[f]); }
   return s;
 }
-
-constexpr int kPostThreads = 256;
 
 template <int LOG2N, bool TW_LDS>
 __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables* __restrict__ Tp, PostArgs a) {

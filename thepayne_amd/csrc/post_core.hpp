@@ -45,6 +45,10 @@ constexpr double kPi = 3.141592653589793;
 constexpr float kBase = 1.0f;                // the flux shift
 constexpr double kVsTabStep = 1.0 / 64.0;    // vsini taper table spacing in u
 constexpr double kVsTabMax = 256.0;
+// Threads of the per-candidate workgroup.  512 candidates on 256 CUs leave 2 workgroups per
+// CU: 8 waves each give 4 waves per SIMD, which is what hides LDS latency between barriers
+// (measured: 256-thread groups ran the same instruction stream ~1.8x slower).
+constexpr int kPostThreads = 512;
 
 struct c32 { float x, y; };
 PAYNE_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -179,13 +183,16 @@ PAYNE_HD void fft_pass(int tid, int nthr, const c32* __restrict__ src, c32* __re
 }
 PAYNE_HD int pass_radix(int M, int p) { int rem = M / p; return rem >= 8 ? 8 : rem; }
 
-// Compile-time geometry ("plan") of an M-point FFT: greedy radix-8 passes, then 4 or 2.
+// Compile-time geometry ("plan") of an M-point FFT on kPostThreads threads.
 // Its twiddles are stored PASS-ORDERED: for every pass with sub-length P > 1 and radix R,
 // (R-1)*P entries  twf[off(P) + (r-1)*P + k] = exp(-2 pi i k r/(P R))  -- the lanes of a wave
 // read consecutive k, so the LDS reads are conflict-free (a plain full-circle table is read
 // with stride 2M/(P R): 8- to 16-way bank conflicts) -- followed by the M/2 factors
 // exp(-2 pi i k/2M) of the real-FFT split.
-constexpr int plan_radix(int M, int P) { return (M / P >= 8) ? 8 : (M / P); }
+// radix: 8 while that still gives every thread a butterfly (M/8 >= threads), else 4, else 2
+constexpr int plan_radix(int M, int P) {
+  return (M / P >= 8 && M / 8 >= kPostThreads) ? 8 : ((M / P >= 4) ? 4 : 2);
+}
 constexpr int plan_offset(int M, int P) {
   int off = 0, p = 1;
   while (p < P) { const int r = plan_radix(M, p); if (p > 1) off += (r - 1) * p; p *= r; }
