@@ -28,7 +28,7 @@ def emul():
     def P(a, t):
         return a.ctypes.data_as(t) if a is not None else None
 
-    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=512):
+    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=256):
         theta8 = np.atleast_2d(theta8)
         B, npix = len(theta8), len(net["wavelength"])
         raw = np.array([O.yst_forward(net, t[:4]) - 1.0 for t in theta8]).astype(np.float32)
@@ -136,7 +136,7 @@ int main() {
   for (int b = 0; b < B; ++b) { double* t = &th[b * 8]; t[0]=5770; t[1]=4.4; t[2]=0; t[3]=0; t[4]=10.0*b; t[5]=b; t[6]=NAN; t[7]=25000+2000*b; }
   std::vector<float> out(B * nobs); std::vector<double> chi(B); std::vector<int> info(3 * B);
   int rc = payne_emul_post(w.data(), npix, 32000 * 2.3548, ow.data(), fl.data(), ef.data(), nobs, 0, th.data(), 8, B, 2.355,
-                           raw.data(), 2, out.data(), nobs, chi.data(), info.data(), 512, 0);
+                           raw.data(), 2, out.data(), nobs, chi.data(), info.data(), 256, 0);
   std::printf("rc=%d chi=%g\n", rc, chi[1]);
   return rc;
 }''')

@@ -54,15 +54,20 @@ __device__ __forceinline__ float act_apply(float z, int act) {
   return z;
 }
 
-template <int BM, int BN, bool FUSE_L0>
+template <int BM, int BN, int BK>
+constexpr size_t dense_lds_bytes() { return (size_t)(2 * (BM + BN) * (BK + 4) + BM * PAYNE_MAX_LABELS) * sizeof(float); }
+
+template <int BM, int BN, int BK, bool FUSE_L0>
 __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
-  constexpr int BK = 32, PITCH = BK + 4;            // +4 floats: conflict-free ds_read_b128 fragments
+  constexpr int PITCH = BK + 4;                     // +4 floats: conflict-free ds_read_b128 fragments (BK = 32, 64)
   constexpr int WM = BM / 2, WN = BN / 2;           // 2x2 waves
   constexpr int TM = WM / 32, TN = WN / 32;         // 32x32 MFMA tiles per wave
-  constexpr int A_F4 = BM * (BK / 4) / 256, B_F4 = BN * (BK / 4) / 256;
-  __shared__ __attribute__((aligned(16))) float As[2][BM * PITCH];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * PITCH];
-  __shared__ float Xh[FUSE_L0 ? BM * PAYNE_MAX_LABELS : 4];
+  constexpr int KQ = BK / 4;                        // float4 per tile row
+  constexpr int A_F4 = BM * KQ / 256, B_F4 = BN * KQ / 256;
+  extern __shared__ __attribute__((aligned(16))) float dk_sm[];
+  float (*As)[BM * PITCH] = reinterpret_cast<float (*)[BM * PITCH]>(dk_sm);
+  float (*Bs)[BN * PITCH] = reinterpret_cast<float (*)[BN * PITCH]>(dk_sm + 2 * BM * PITCH);
+  float* Xh = dk_sm + 2 * (BM + BN) * PITCH;
 
   // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
   // XCD a contiguous run of tiles (m fastest): its L2 then holds 1/8 of W and all of X.
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * 256, r = idx >> 3, k = k0 + (idx & 7) * 4, row = m0 + r;
+      const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4, row = m0 + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (FUSE_L0) {
         if (k < p.K0) {
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-      const int idx = tid + i * 256, r = idx >> 3, k = k0 + (idx & 7) * 4, col = n0 + r;
+      const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4, col = n0 + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (col < p.N && k < p.K) v = *reinterpret_cast<const float4*>(p.W + (size_t)col * p.K + k);
       rb[i] = v;
@@ -123,12 +128,12 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int idx = tid + i * 256;
-      *reinterpret_cast<float4*>(&As[buf][(idx >> 3) * PITCH + (idx & 7) * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&As[buf][(idx / KQ) * PITCH + (idx % KQ) * 4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
       const int idx = tid + i * 256;
-      *reinterpret_cast<float4*>(&Bs[buf][(idx >> 3) * PITCH + (idx & 7) * 4]) = rb[i];
+      *reinterpret_cast<float4*>(&Bs[buf][(idx / KQ) * PITCH + (idx % KQ) * 4]) = rb[i];
     }
   };
 
@@ -277,6 +282,122 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
     for (int q = 0; q < 4; ++q) {
       const int orow = tm * 16 + 4 * g + q;
       if (orow < p.B) p.Y[(size_t)orow * p.ldy + col] = act_apply(acc[0][q] + acc[1][q] + bv, p.act);
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------
+// Hidden layers, workgroup form: one 256-thread group per 32x32 output tile, the whole K
+// extent (<= 320 per chunk) of both operands staged in LDS by coalesced float4 loads issued
+// together (one L2 latency), then the four waves split K between them (v_mfma_f32_16x16x4_f32,
+// 2x2 tiles each) and their partial tiles are summed through LDS.  With FUSE_L0 the A tile is
+// produced in place from theta (label encoding + first layer + activation).
+// ----------------------------------------------------------------------------
+constexpr int HK_KC = 320;          // K chunk
+constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
+constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
+
+template <bool FUSE_L0>
+__global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) {
+  extern __shared__ __attribute__((aligned(16))) float hk_sm[];
+  float* As = hk_sm;
+  float* Bs = As + 32 * HK_PITCH;
+  float* Xh = Bs + 32 * HK_PITCH;
+  const int tm = blockIdx.x / p.grid_n, tn = blockIdx.x - tm * p.grid_n;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  if (FUSE_L0) {
+    for (int idx = tid; idx < 32 * PAYNE_MAX_LABELS; idx += 256) {
+      const int rr = idx / PAYNE_MAX_LABELS, d = idx - rr * PAYNE_MAX_LABELS, row = m0 + rr;
+      float v = 0.f;
+      if (row < p.B && d < p.n_labels) {
+        const double x = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)];
+        v = (float)((x - p.xmin[d]) / p.xden[d] - 0.5);
+      }
+      Xh[idx] = v;
+    }
+    __syncthreads();
+  }
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int kc = 0; kc < p.K; kc += HK_KC) {
+    const int kn = (p.K - kc < HK_KC) ? (p.K - kc) : HK_KC;        // multiple of 4
+    const int kn16 = (kn + 15) & ~15;
+    const int nk4 = kn16 >> 2;
+    // ---- stage B (weights) and A (activations or the fused first layer) -------------------
+    for (int r0 = 0; r0 < 32; r0 += 8) {
+      const int rr = r0 + (tid >> 5);
+      for (int k4 = tid & 31; k4 < nk4; k4 += 32) {
+        const int k = kc + 4 * k4;
+        float4 vb = z4, va = z4;
+        if (n0 + rr < p.N && 4 * k4 < kn) vb = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + rr) * p.K + k);
+        if (!FUSE_L0 && m0 + rr < p.B && 4 * k4 < kn) va = *reinterpret_cast<const float4*>(p.X + (size_t)(m0 + rr) * p.ldx + k);
+        *reinterpret_cast<float4*>(&Bs[rr * HK_PITCH + 4 * k4]) = vb;
+        if (!FUSE_L0) *reinterpret_cast<float4*>(&As[rr * HK_PITCH + 4 * k4]) = va;
+      }
+    }
+    if (FUSE_L0) {
+      for (int kk = tid; kk < kn16; kk += 256) {
+        const int k = kc + kk;
+        float w0[PAYNE_MAX_LABELS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float bz = 0.f;
+        const bool live = k < p.K0;
+        if (live) {
+          bz = p.b0[k];
+          for (int d = 0; d < p.n_labels; ++d) w0[d] = p.W0[(size_t)k * p.n_labels + d];
+        }
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+          float z = bz;
+#pragma unroll
+          for (int d = 0; d < PAYNE_MAX_LABELS; ++d) z = fmaf(w0[d], Xh[rr * PAYNE_MAX_LABELS + d], z);
+          As[rr * HK_PITCH + kk] = live ? act_apply(z, p.act0) : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the four waves split the K steps of this chunk -------------------------------------
+    const int steps = kn16 >> 4;
+    for (int s = wave; s < steps; s += 4) {
+      const int k = s * 16 + 4 * g;
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const float4*>(&As[(16 * i + r) * HK_PITCH + k]);
+        b[i] = *reinterpret_cast<const float4*>(&Bs[(16 * i + r) * HK_PITCH + k]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- sum the four partial tiles (C/D map: col = lane&15, row = 4*(lane>>4) + reg) ------------
+  float* Red = As;                                               // [4][32][33]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Red[(wave * 32 + 16 * i + 4 * g + q) * 33 + 16 * j + r] = acc[i][j][q];
+  __syncthreads();
+  for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int rr = idx >> 5, cc = idx & 31, row = m0 + rr, col = n0 + cc;
+    if (row < p.B && col < p.N) {
+      const float v = Red[rr * 33 + cc] + Red[(32 + rr) * 33 + cc] + Red[(64 + rr) * 33 + cc] + Red[(96 + rr) * 33 + cc];
+      p.Y[(size_t)row * p.ldy + col] = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
     }
   }
 }
@@ -739,11 +860,17 @@ extern "C" int payne_ctx_set_obs(payne_ctx* c, const payne_obs_desc* obs) {
 }
 
 // ---- launches --------------------------------------------------------------
-template <int BM, int BN, bool FUSE>
+template <int BM, int BN, int BK, bool FUSE>
 static void launch_dense(DenseParams& p, hipStream_t s) {
   p.grid_m = (p.B + BM - 1) / BM;
   p.grid_n = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((payne_dense_kernel<BM, BN, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
+  constexpr size_t lds = dense_lds_bytes<BM, BN, BK>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_kernel<BM, BN, BK, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
 static int out_tile_choice() {
@@ -752,8 +879,28 @@ static int out_tile_choice() {
   return v;
 }
 
+static int hidden_kernel_choice() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PAYNE_HIDDEN_KERNEL"); v = e ? atoi(e) : 1; }   // 1: workgroup form, 0: wave-per-tile
+  return v;
+}
+
+template <bool FUSE>
+static void launch_hidden(DenseParams& p, hipStream_t s) {
+  p.grid_m = (p.B + 31) / 32;
+  p.grid_n = (p.N + 31) / 32;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((payne_dense_hidden_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), HK_LDS_BYTES, s, p);
+}
+
 template <bool FUSE>
 static void launch_small(DenseParams& p, hipStream_t s) {
+  if (hidden_kernel_choice() == 1) { launch_hidden<FUSE>(p, s); return; }
   p.grid_m = (p.B + 15) / 16;
   p.grid_n = (p.N + 15) / 16;
   hipLaunchKernelGGL((payne_dense_small_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(64), 0, s, p);
@@ -776,15 +923,17 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
       p.theta = theta; p.ld_theta = c->ncols;
       p.W0 = L0.w; p.b0 = L0.b; p.n_labels = c->n_labels; p.act0 = L0.act; p.K0 = L0.n_out;
       for (int d = 0; d < c->n_labels; ++d) { p.xmin[d] = c->xmin[d]; p.xden[d] = c->xden[d]; }
-      if (last) launch_dense<64, 64, true>(p, s);
+      if (last) launch_dense<64, 64, 32, true>(p, s);
       else launch_small<true>(p, s);
     } else {
       p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
       if (!last) launch_small<false>(p, s);
       else switch (out_tile_choice()) {
-        case 1: launch_dense<128, 64, false>(p, s); break;
-        case 2: launch_dense<64, 128, false>(p, s); break;
-        default: launch_dense<64, 64, false>(p, s); break;
+        case 1: launch_dense<128, 64, 32, false>(p, s); break;
+        case 2: launch_dense<64, 128, 32, false>(p, s); break;
+        case 3: launch_dense<64, 64, 64, false>(p, s); break;
+        case 4: launch_dense<128, 64, 64, false>(p, s); break;
+        default: launch_dense<64, 64, 32, false>(p, s); break;
       }
     }
   }

@@ -45,10 +45,11 @@ constexpr double kPi = 3.141592653589793;
 constexpr float kBase = 1.0f;                // the flux shift
 constexpr double kVsTabStep = 1.0 / 64.0;    // vsini taper table spacing in u
 constexpr double kVsTabMax = 256.0;
-// Threads of the per-candidate workgroup.  512 candidates on 256 CUs leave 2 workgroups per
-// CU: 8 waves each give 4 waves per SIMD, which is what hides LDS latency between barriers
-// (measured: 256-thread groups ran the same instruction stream ~1.8x slower).
-constexpr int kPostThreads = 512;
+// Threads of the per-candidate workgroup.  Measured at C2 (512 candidates, 2 groups per CU):
+// 256 threads (radix-8 passes, 4 barriers per FFT) 41 us per batch; 512 threads (radix-4
+// passes, 6 barriers per FFT, 4 waves per SIMD) 46 us: the extra barriers and LDS traffic of
+// the lower radix cost more than the extra occupancy hides.
+constexpr int kPostThreads = 256;
 
 struct c32 { float x, y; };
 PAYNE_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }

@@ -1,0 +1,19 @@
+#!/bin/bash
+# quick GPU check: parity tests + bench variants (env knobs)
+TAG=${1:-q}
+OUT=$PWD/gpurun_out; mkdir -p $OUT
+python -m pytest tests -m gpu -q -x > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_$TAG.log
+b() { name=$1; shift; env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_${TAG}_$name.log 2>&1
+python - <<PY
+import json
+try:
+    d=json.loads(open("$OUT/bench_${TAG}_$name.log").read().strip().splitlines()[-1])
+    print("$name", round(d["value"]), "evals/s", round(d["ms_per_step"]*1e3,1), "us/step", {k: round(v,1) for k,v in d["kernels_us"].items()})
+except Exception as e: print("$name failed", e, open("$OUT/bench_${TAG}_$name.log").read()[-800:])
+PY
+}
+b base A=1
+b hid0 PAYNE_HIDDEN_KERNEL=0
+b tile3 PAYNE_OUT_TILE=3
+b tile4 PAYNE_OUT_TILE=4
+b tile1 PAYNE_OUT_TILE=1
