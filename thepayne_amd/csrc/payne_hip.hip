@@ -331,33 +331,57 @@ __global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) 
     const int kn16 = (kn + 15) & ~15;
     const int nk4 = kn16 >> 2;
     // ---- stage B (weights) and A (activations or the fused first layer) -------------------
-    for (int r0 = 0; r0 < 32; r0 += 8) {
-      const int rr = r0 + (tid >> 5);
-      for (int k4 = tid & 31; k4 < nk4; k4 += 32) {
-        const int k = kc + 4 * k4;
-        float4 vb = z4, va = z4;
-        if (n0 + rr < p.N && 4 * k4 < kn) vb = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + rr) * p.K + k);
-        if (!FUSE_L0 && m0 + rr < p.B && 4 * k4 < kn) va = *reinterpret_cast<const float4*>(p.X + (size_t)(m0 + rr) * p.ldx + k);
-        *reinterpret_cast<float4*>(&Bs[rr * HK_PITCH + 4 * k4]) = vb;
-        if (!FUSE_L0) *reinterpret_cast<float4*>(&As[rr * HK_PITCH + 4 * k4]) = va;
+    // every global load of the chunk is issued before the first LDS store (a load->store loop
+    // would pay one L2 latency per iteration)
+    constexpr int NKI = (HK_KC / 4 + 31) / 32;                   // k4 slots per thread: 3
+    float4 vb[4 * NKI], va[FUSE_L0 ? 1 : 4 * NKI];
+#pragma unroll
+    for (int it = 0; it < 4 * NKI; ++it) {
+      const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI), k = kc + 4 * k4;
+      vb[it] = z4;
+      if (!FUSE_L0) va[it] = z4;
+      if (4 * k4 < kn) {
+        if (n0 + rr < p.N) vb[it] = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + rr) * p.K + k);
+        if (!FUSE_L0 && m0 + rr < p.B) va[it] = *reinterpret_cast<const float4*>(p.X + (size_t)(m0 + rr) * p.ldx + k);
+      }
+    }
+    float w0[2][PAYNE_MAX_LABELS], bz[2];
+    if (FUSE_L0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = kc + tid + 256 * h;
+        bz[h] = 0.f;
+#pragma unroll
+        for (int d = 0; d < PAYNE_MAX_LABELS; ++d) w0[h][d] = 0.f;
+        if (tid + 256 * h < kn16 && k < p.K0) {
+          bz[h] = p.b0[k];
+#pragma unroll
+          for (int d = 0; d < PAYNE_MAX_LABELS; ++d)
+            if (d < p.n_labels) w0[h][d] = p.W0[(size_t)k * p.n_labels + d];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4 * NKI; ++it) {
+      const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
+      if (k4 < nk4) {
+        *reinterpret_cast<float4*>(&Bs[rr * HK_PITCH + 4 * k4]) = vb[it];
+        if (!FUSE_L0) *reinterpret_cast<float4*>(&As[rr * HK_PITCH + 4 * k4]) = va[it];
       }
     }
     if (FUSE_L0) {
-      for (int kk = tid; kk < kn16; kk += 256) {
-        const int k = kc + kk;
-        float w0[PAYNE_MAX_LABELS] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        float bz = 0.f;
-        const bool live = k < p.K0;
-        if (live) {
-          bz = p.b0[k];
-          for (int d = 0; d < p.n_labels; ++d) w0[d] = p.W0[(size_t)k * p.n_labels + d];
-        }
-#pragma unroll 4
-        for (int rr = 0; rr < 32; ++rr) {
-          float z = bz;
 #pragma unroll
-          for (int d = 0; d < PAYNE_MAX_LABELS; ++d) z = fmaf(w0[d], Xh[rr * PAYNE_MAX_LABELS + d], z);
-          As[rr * HK_PITCH + kk] = live ? act_apply(z, p.act0) : 0.f;
+      for (int h = 0; h < 2; ++h) {
+        const int kk = tid + 256 * h;
+        if (kk < kn16) {
+          const bool live = (kc + kk) < p.K0;
+#pragma unroll 8
+          for (int rr = 0; rr < 32; ++rr) {
+            float z = bz[h];
+#pragma unroll
+            for (int d = 0; d < PAYNE_MAX_LABELS; ++d) z = fmaf(w0[h][d], Xh[rr * PAYNE_MAX_LABELS + d], z);
+            As[rr * HK_PITCH + kk] = live ? act_apply(z, p.act0) : 0.f;
+          }
         }
       }
     }
@@ -399,6 +423,115 @@ __global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) 
       const float v = Red[rr * 33 + cc] + Red[(32 + rr) * 33 + cc] + Red[(64 + rr) * 33 + cc] + Red[(96 + rr) * 33 + cc];
       p.Y[(size_t)row * p.ldy + col] = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
     }
+  }
+}
+
+
+// ----------------------------------------------------------------------------
+// Output layer, K-resident form (K <= 312, i.e. hidden width <= 312): a workgroup keeps its
+// 64-candidate activation tile (whole K) in LDS and walks a run of 32-pixel weight tiles
+// through a register-staged double buffer, so the only exposed global latency is the first
+// tile's; every later tile's loads fly under the previous tile's MFMAs (the streaming-K kernel
+// above re-pays the load latency every 32 k and sits at ~40 % MFMA utilisation for K = 300).
+// Wave w owns rows 16w..16w+15 of the tile and both 16-column halves (v_mfma_f32_16x16x4_f32,
+// two accumulators).  LDS: 64 x 312 + 2 x 32 x 312 floats = 156 KiB -> one workgroup per CU,
+// grid = (#64-row tiles) x (runs of pixel tiles) ~ one workgroup per CU.
+// ----------------------------------------------------------------------------
+constexpr int OK_PITCH = 312;                                   // 8*odd floats (conflict-free fragment reads)
+constexpr int OK_KMAX = 304;                                    // padded K handled (19 steps of 16)
+constexpr size_t OK_LDS_BYTES = (size_t)(64 + 2 * 32) * OK_PITCH * sizeof(float);
+
+__global__ void __launch_bounds__(256) payne_dense_out_kernel(DenseParams p, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float ok_sm[];
+  float* As = ok_sm;                                            // [64][OK_PITCH]
+  float* Bs = ok_sm + 64 * OK_PITCH;                            // [2][32][OK_PITCH]
+  const int ngroups = p.grid_n, total = p.grid_m * ngroups;
+  int t = blockIdx.x;
+  if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);  // XCD-contiguous runs (m fastest)
+  const int m0 = (t % p.grid_m) * 64;
+  const int ntiles = (p.N + 31) >> 5;
+  const int tile0 = (t / p.grid_m) * tiles_per_wg;
+  const int tile1 = (tile0 + tiles_per_wg < ntiles) ? tile0 + tiles_per_wg : ntiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int K = p.K, K16 = (K + 15) & ~15, nk4 = K16 >> 2;     // K % 4 == 0
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int BI = (32 * (OK_KMAX / 4) + 255) / 256;          // float4 per thread per B tile: 10
+
+  // ---- A tile: 64 rows x K, all loads first ---------------------------------------------------
+  {
+    constexpr int AI = (64 * (OK_KMAX / 4) + 255) / 256;        // 19
+    float4 va[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
+      va[i] = z4;
+      if (rr < 64 && m0 + rr < p.B && 4 * k4 < K) va[i] = *reinterpret_cast<const float4*>(p.X + (size_t)(m0 + rr) * p.ldx + 4 * k4);
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
+      if (rr < 64 && k4 < nk4) *reinterpret_cast<float4*>(&As[rr * OK_PITCH + 4 * k4]) = va[i];
+    }
+  }
+  float4 vb[BI];
+  auto load_b = [&](int tile) {
+    const int n0 = tile << 5;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
+      vb[i] = z4;
+      if (rr < 32 && n0 + rr < p.N && 4 * k4 < K) vb[i] = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + rr) * K + 4 * k4);
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* B = Bs + buf * 32 * OK_PITCH;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
+      if (rr < 32 && k4 < nk4) *reinterpret_cast<float4*>(&B[rr * OK_PITCH + 4 * k4]) = vb[i];
+    }
+  };
+  if (tile0 < tile1) { load_b(tile0); store_b(0); }
+  __syncthreads();
+
+  const int steps = K16 >> 4;
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int buf = (tile - tile0) & 1;
+    if (tile + 1 < tile1) load_b(tile + 1);                     // flies under this tile's MFMAs
+    const float* B = Bs + buf * 32 * OK_PITCH;
+    f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 2
+    for (int s = 0; s < steps; ++s) {
+      const int k = s * 16 + 4 * g;
+      const float4 a = *reinterpret_cast<const float4*>(&As[(16 * wave + r) * OK_PITCH + k]);
+      const float4 b0 = *reinterpret_cast<const float4*>(&B[r * OK_PITCH + k]);
+      const float4 b1 = *reinterpret_cast<const float4*>(&B[(16 + r) * OK_PITCH + k]);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+    }
+    // C/D map: col = lane&15, row = 4*(lane>>4) + reg
+    const int n0 = tile << 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + 16 * j + r;
+      if (col < p.N) {
+        const float bv = p.bias[col] - p.bias_shift;
+        const f32x4_t& a4 = j ? acc1 : acc0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + 16 * wave + 4 * g + q;
+          if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(a4[q] + bv, p.act);
+        }
+      }
+    }
+    if (tile + 1 < tile1) store_b(buf ^ 1);
+    __syncthreads();
   }
 }
 
@@ -875,8 +1008,24 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
 
 static int out_tile_choice() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }   // 0: K-resident kernel when K fits
   return v;
+}
+
+static void launch_out_resident(DenseParams& p, hipStream_t s) {
+  p.grid_m = (p.B + 63) / 64;
+  const int ntiles = (p.N + 31) / 32;
+  int groups = 256 / (p.grid_m > 0 ? p.grid_m : 1);             // ~ one workgroup per CU
+  if (groups < 1) groups = 1;
+  if (groups > ntiles) groups = ntiles;
+  const int tiles_per_wg = (ntiles + groups - 1) / groups;
+  p.grid_n = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)OK_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
 }
 
 static int hidden_kernel_choice() {
@@ -928,12 +1077,13 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
     } else {
       p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
       if (!last) launch_small<false>(p, s);
+      else if (out_tile_choice() == 0 && p.K <= OK_KMAX) launch_out_resident(p, s);
       else switch (out_tile_choice()) {
         case 1: launch_dense<128, 64, 32, false>(p, s); break;
         case 2: launch_dense<64, 128, 32, false>(p, s); break;
         case 3: launch_dense<64, 64, 64, false>(p, s); break;
         case 4: launch_dense<128, 64, 64, false>(p, s); break;
-        default: launch_dense<64, 64, 32, false>(p, s); break;
+        default: launch_dense<64, 64, 32, false>(p, s); break;    // 5 (or K too large for the resident form)
       }
     }
   }

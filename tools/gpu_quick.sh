@@ -14,6 +14,5 @@ PY
 }
 b base A=1
 b hid0 PAYNE_HIDDEN_KERNEL=0
+b tile5 PAYNE_OUT_TILE=5
 b tile3 PAYNE_OUT_TILE=3
-b tile4 PAYNE_OUT_TILE=4
-b tile1 PAYNE_OUT_TILE=1
