@@ -31,6 +31,7 @@ using namespace payne;
 // dense layer on the matrix cores
 // ============================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));   // register-resident 16-byte value (HIP's f32x4_t struct arrays end up in scratch)
 
 struct DenseParams {
   const float* X; int ldx;     // [B][ldx] activations (ignored with FUSE_L0)
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
   constexpr int PITCH = BK + 4;                     // +4 floats: conflict-free ds_read_b128 fragments (BK = 32, 64)
   constexpr int WM = BM / 2, WN = BN / 2;           // 2x2 waves
   constexpr int TM = WM / 32, TN = WN / 32;         // 32x32 MFMA tiles per wave
-  constexpr int KQ = BK / 4;                        // float4 per tile row
+  constexpr int KQ = BK / 4;                        // f32x4_t per tile row
   constexpr int A_F4 = BM * KQ / 256, B_F4 = BN * KQ / 256;
   extern __shared__ __attribute__((aligned(16))) float dk_sm[];
   float (*As)[BM * PITCH] = reinterpret_cast<float (*)[BM * PITCH]>(dk_sm);
@@ -91,49 +92,50 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
     __syncthreads();
   }
 
-  float4 ra[A_F4], rb[B_F4];
+  // Guarded loads (`if (ok) v = *p`) compile to a branch plus a wait per load and serialise
+  // the tile fetch; load unconditionally from a clamped (always valid) address and apply the
+  // mask when the value is written to LDS.
+  f32x4_t ra[A_F4], rb[B_F4];
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4, row = m0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (FUSE_L0) {
-        if (k < p.K0) {
-          float o[4];
+        float o[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            o[j] = 0.f;
-            if (k + j < p.K0) {
-              float z = p.b0[k + j];
-              for (int d = 0; d < p.n_labels; ++d) z = fmaf(p.W0[(k + j) * p.n_labels + d], Xh[r * PAYNE_MAX_LABELS + d], z);
-              o[j] = act_apply(z, p.act0);
-            }
-          }
-          v = make_float4(o[0], o[1], o[2], o[3]);
+        for (int j = 0; j < 4; ++j) {
+          const int kj = (k + j < p.K0) ? k + j : p.K0 - 1;
+          float z = p.b0[kj];
+          for (int d = 0; d < p.n_labels; ++d) z = fmaf(p.W0[kj * p.n_labels + d], Xh[r * PAYNE_MAX_LABELS + d], z);
+          o[j] = (k + j < p.K0) ? act_apply(z, p.act0) : 0.f;
         }
-      } else if (row < p.B && k < p.K) {
-        v = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + k);
+        ra[i] = (f32x4_t){o[0], o[1], o[2], o[3]};
+      } else {
+        const int rc = row < p.B ? row : p.B - 1, kc = k < p.K ? k : p.K - 4;
+        ra[i] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)rc * p.ldx + kc);
       }
-      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
       const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4, col = n0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (col < p.N && k < p.K) v = *reinterpret_cast<const float4*>(p.W + (size_t)col * p.K + k);
-      rb[i] = v;
+      const int cc = col < p.N ? col : p.N - 1, kc = k < p.K ? k : p.K - 4;
+      rb[i] = *reinterpret_cast<const f32x4_t*>(p.W + (size_t)cc * p.K + kc);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int k0) {
+    const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * 256;
-      *reinterpret_cast<float4*>(&As[buf][(idx / KQ) * PITCH + (idx % KQ) * 4]) = ra[i];
+      const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4;
+      const bool ok = FUSE_L0 || ((m0 + r) < p.B && k < p.K);
+      *reinterpret_cast<f32x4_t*>(&As[buf][r * PITCH + (idx % KQ) * 4]) = ok ? ra[i] : z4;
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-      const int idx = tid + i * 256;
-      *reinterpret_cast<float4*>(&Bs[buf][(idx / KQ) * PITCH + (idx % KQ) * 4]) = rb[i];
+      const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4;
+      const bool ok = (n0 + r) < p.N && k < p.K;
+      *reinterpret_cast<f32x4_t*>(&Bs[buf][r * PITCH + (idx % KQ) * 4]) = ok ? rb[i] : z4;
     }
   };
 
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 
   const int nk = (p.K + BK - 1) / BK;
   load_tiles(0);
-  store_tiles(0);
+  store_tiles(0, 0);
   __syncthreads();
   for (int it = 0; it < nk; ++it) {
     const int buf = it & 1;
@@ -156,13 +158,13 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
     // contracts k = {8kk + s, 8kk + 4 + s} -- the same k set on both operands.
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 a[TM], b[TN];
+      f32x4_t a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const float4*>(&As[buf][(wm0 + i * 32 + (lane & 31)) * PITCH + kk * 8 + 4 * (lane >> 5)]);
+        a[i] = *reinterpret_cast<const f32x4_t*>(&As[buf][(wm0 + i * 32 + (lane & 31)) * PITCH + kk * 8 + 4 * (lane >> 5)]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const float4*>(&Bs[buf][(wn0 + j * 32 + (lane & 31)) * PITCH + kk * 8 + 4 * (lane >> 5)]);
+        b[j] = *reinterpret_cast<const f32x4_t*>(&Bs[buf][(wn0 + j * 32 + (lane & 31)) * PITCH + kk * 8 + 4 * (lane >> 5)]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (it + 1 < nk) store_tiles(buf ^ 1);
+    if (it + 1 < nk) store_tiles(buf ^ 1, (it + 1) * BK);
     __syncthreads();
   }
 
@@ -197,11 +199,10 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 // ----------------------------------------------------------------------------
 // Hidden layers are tiny GEMMs ([B x H] x [H x H], ~0.1 GFLOP): one wave per 16x16 output
 // tile (hundreds of independent waves) with v_mfma_f32_16x16x4_f32, fragments read straight
-// from L2 as float4 (lane (r, g) holds 4 consecutive k of row r at offset 4g; MFMA step t
+// from L2 as f32x4_t (lane (r, g) holds 4 consecutive k of row r at offset 4g; MFMA step t
 // contracts k = {4g + t}, identically on both operands), two accumulators to cover the
 // 40-cycle dependent-issue latency.  No LDS, no barriers: latency ~ K/4 MFMAs.
 // ----------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <bool FUSE_L0>
 __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
@@ -210,7 +211,7 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
   const int row = tm * 16 + r, col = tn * 16 + r;
   const bool rowok = row < p.B, colok = col < p.N;
   float xh[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool fast0 = FUSE_L0 && (p.n_labels == 4);            // 4-label nets: W0 rows are float4
+  const bool fast0 = FUSE_L0 && (p.n_labels == 4);            // 4-label nets: W0 rows are f32x4_t
   if (FUSE_L0 && rowok) {
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -227,21 +228,21 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
   // K is walked 64 at a time: the 4 steps' operand loads (B fragment, and W0/b0 rows or the A
   // fragment) are all issued before the first MFMA, so one L2 latency is paid per 64 k, not per 16.
   constexpr int SU = 4;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < p.K; k0 += 16 * SU) {
-    float4 b[SU], a[SU], bb[SU], w0[SU][4];
+    f32x4_t b[SU], a[SU], bb[SU], w0[SU][4];
 #pragma unroll
     for (int s = 0; s < SU; ++s) {
       const int k = k0 + s * 16 + 4 * g;
-      b[s] = (colok && k < p.K) ? *reinterpret_cast<const float4*>(wrow + k) : z4;
+      b[s] = (colok && k < p.K) ? *reinterpret_cast<const f32x4_t*>(wrow + k) : z4;
       if (FUSE_L0) {
         if (fast0 && rowok && k + 3 < p.K0) {
-          bb[s] = *reinterpret_cast<const float4*>(p.b0 + k);
-          const float4* wp = reinterpret_cast<const float4*>(p.W0 + (size_t)k * 4);
+          bb[s] = *reinterpret_cast<const f32x4_t*>(p.b0 + k);
+          const f32x4_t* wp = reinterpret_cast<const f32x4_t*>(p.W0 + (size_t)k * 4);
           w0[s][0] = wp[0]; w0[s][1] = wp[1]; w0[s][2] = wp[2]; w0[s][3] = wp[3];
         }
       } else {
-        a[s] = (rowok && k < p.K) ? *reinterpret_cast<const float4*>(xrow + k) : z4;
+        a[s] = (rowok && k < p.K) ? *reinterpret_cast<const f32x4_t*>(xrow + k) : z4;
       }
     }
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
             }
           }
         }
-        a[s] = make_float4(o[0], o[1], o[2], o[3]);
+        a[s] = (f32x4_t){o[0], o[1], o[2], o[3]};
       }
       f32x4_t& c = acc[s & 1];
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b[s].x, c, 0, 0, 0);
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
 
 // ----------------------------------------------------------------------------
 // Hidden layers, workgroup form: one 256-thread group per 32x32 output tile, the whole K
-// extent (<= 320 per chunk) of both operands staged in LDS by coalesced float4 loads issued
+// extent (<= 320 per chunk) of both operands staged in LDS by coalesced f32x4_t loads issued
 // together (one L2 latency), then the four waves split K between them (v_mfma_f32_16x16x4_f32,
 // 2x2 tiles each) and their partial tiles are summed through LDS.  With FUSE_L0 the A tile is
 // produced in place from theta (label encoding + first layer + activation).
@@ -299,7 +300,7 @@ constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
 
 template <bool FUSE_L0>
-__global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) {
+__global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p) {
   extern __shared__ __attribute__((aligned(16))) float hk_sm[];
   float* As = hk_sm;
   float* Bs = As + 32 * HK_PITCH;
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   for (int kc = 0; kc < p.K; kc += HK_KC) {
     const int kn = (p.K - kc < HK_KC) ? (p.K - kc) : HK_KC;        // multiple of 4
@@ -334,15 +335,16 @@ __global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) 
     // every global load of the chunk is issued before the first LDS store (a load->store loop
     // would pay one L2 latency per iteration)
     constexpr int NKI = (HK_KC / 4 + 31) / 32;                   // k4 slots per thread: 3
-    float4 vb[4 * NKI], va[FUSE_L0 ? 1 : 4 * NKI];
+    f32x4_t vb[4 * NKI], va[FUSE_L0 ? 1 : 4 * NKI];
 #pragma unroll
-    for (int it = 0; it < 4 * NKI; ++it) {
-      const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI), k = kc + 4 * k4;
-      vb[it] = z4;
-      if (!FUSE_L0) va[it] = z4;
-      if (4 * k4 < kn) {
-        if (n0 + rr < p.N) vb[it] = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + rr) * p.K + k);
-        if (!FUSE_L0 && m0 + rr < p.B) va[it] = *reinterpret_cast<const float4*>(p.X + (size_t)(m0 + rr) * p.ldx + k);
+    for (int it = 0; it < 4 * NKI; ++it) {   // unconditional loads from clamped addresses (see payne_dense_kernel)
+      const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
+      const int kcl = (4 * k4 < kn) ? kc + 4 * k4 : kc + kn - 4;
+      const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
+      vb[it] = *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * p.K + kcl);
+      if (!FUSE_L0) {
+        const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1;
+        va[it] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kcl);
       }
     }
     float w0[2][PAYNE_MAX_LABELS], bz[2];
@@ -350,23 +352,22 @@ __global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = kc + tid + 256 * h;
-        bz[h] = 0.f;
+        const int kq = k < p.K0 ? k : p.K0 - 1;
+        bz[h] = p.b0[kq];
 #pragma unroll
-        for (int d = 0; d < PAYNE_MAX_LABELS; ++d) w0[h][d] = 0.f;
-        if (tid + 256 * h < kn16 && k < p.K0) {
-          bz[h] = p.b0[k];
+        for (int d = 0; d < PAYNE_MAX_LABELS; ++d) w0[h][d] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
 #pragma unroll
-          for (int d = 0; d < PAYNE_MAX_LABELS; ++d)
-            if (d < p.n_labels) w0[h][d] = p.W0[(size_t)k * p.n_labels + d];
-        }
+        for (int d = 0; d < PAYNE_MAX_LABELS; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);        // keep every load ahead of the first LDS store
 #pragma unroll
     for (int it = 0; it < 4 * NKI; ++it) {
       const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
       if (k4 < nk4) {
-        *reinterpret_cast<float4*>(&Bs[rr * HK_PITCH + 4 * k4]) = vb[it];
-        if (!FUSE_L0) *reinterpret_cast<float4*>(&As[rr * HK_PITCH + 4 * k4]) = va[it];
+        const bool kok = 4 * k4 < kn;
+        *reinterpret_cast<f32x4_t*>(&Bs[rr * HK_PITCH + 4 * k4]) = (kok && n0 + rr < p.N) ? vb[it] : z4;
+        if (!FUSE_L0) *reinterpret_cast<f32x4_t*>(&As[rr * HK_PITCH + 4 * k4]) = (kok && m0 + rr < p.B) ? va[it] : z4;
       }
     }
     if (FUSE_L0) {
@@ -390,11 +391,11 @@ __global__ void __launch_bounds__(256) payne_dense_hidden_kernel(DenseParams p) 
     const int steps = kn16 >> 4;
     for (int s = wave; s < steps; s += 4) {
       const int k = s * 16 + 4 * g;
-      float4 a[2], b[2];
+      f32x4_t a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const float4*>(&As[(16 * i + r) * HK_PITCH + k]);
-        b[i] = *reinterpret_cast<const float4*>(&Bs[(16 * i + r) * HK_PITCH + k]);
+        a[i] = *reinterpret_cast<const f32x4_t*>(&As[(16 * i + r) * HK_PITCH + k]);
+        b[i] = *reinterpret_cast<const f32x4_t*>(&Bs[(16 * i + r) * HK_PITCH + k]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -441,7 +442,7 @@ constexpr int OK_PITCH = 312;                                   // 8*odd floats 
 constexpr int OK_KMAX = 304;                                    // padded K handled (19 steps of 16)
 constexpr size_t OK_LDS_BYTES = (size_t)(64 + 2 * 32) * OK_PITCH * sizeof(float);
 
-__global__ void __launch_bounds__(256) payne_dense_out_kernel(DenseParams p, int tiles_per_wg) {
+__global__ void __launch_bounds__(256, 1) payne_dense_out_kernel(DenseParams p, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float ok_sm[];
   float* As = ok_sm;                                            // [64][OK_PITCH]
   float* Bs = ok_sm + 64 * OK_PITCH;                            // [2][32][OK_PITCH]
@@ -454,44 +455,47 @@ __global__ void __launch_bounds__(256) payne_dense_out_kernel(DenseParams p, int
   const int tile1 = (tile0 + tiles_per_wg < ntiles) ? tile0 + tiles_per_wg : ntiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int K = p.K, K16 = (K + 15) & ~15, nk4 = K16 >> 2;     // K % 4 == 0
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int BI = (32 * (OK_KMAX / 4) + 255) / 256;          // float4 per thread per B tile: 10
+  const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  constexpr int BI = (32 * (OK_KMAX / 4) + 255) / 256;          // f32x4_t per thread per B tile: 10
 
   // ---- A tile: 64 rows x K, all loads first ---------------------------------------------------
   {
     constexpr int AI = (64 * (OK_KMAX / 4) + 255) / 256;        // 19
-    float4 va[AI];
+    f32x4_t va[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      va[i] = z4;
-      if (rr < 64 && m0 + rr < p.B && 4 * k4 < K) va[i] = *reinterpret_cast<const float4*>(p.X + (size_t)(m0 + rr) * p.ldx + 4 * k4);
+      const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1, kq = (4 * k4 < K) ? 4 * k4 : K - 4;   // clamped: no branch
+      va[i] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kq);
     }
+    __builtin_amdgcn_sched_barrier(0);        // keep every load ahead of the first LDS store
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      if (rr < 64 && k4 < nk4) *reinterpret_cast<float4*>(&As[rr * OK_PITCH + 4 * k4]) = va[i];
+      if (k4 < nk4) *reinterpret_cast<f32x4_t*>(&As[rr * OK_PITCH + 4 * k4]) = (m0 + rr < p.B && 4 * k4 < K) ? va[i] : z4;
     }
   }
-  float4 vb[BI];
+  f32x4_t vb[BI];
   auto load_b = [&](int tile) {
     const int n0 = tile << 5;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      vb[i] = z4;
-      if (rr < 32 && n0 + rr < p.N && 4 * k4 < K) vb[i] = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + rr) * K + 4 * k4);
+      const int nr = (rr < 32 && n0 + rr < p.N) ? n0 + rr : p.N - 1, kq = (4 * k4 < K) ? 4 * k4 : K - 4;
+      vb[i] = *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * K + kq);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, int tile) {
     float* B = Bs + buf * 32 * OK_PITCH;
+    const int n0 = tile << 5;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      if (rr < 32 && k4 < nk4) *reinterpret_cast<float4*>(&B[rr * OK_PITCH + 4 * k4]) = vb[i];
+      if (rr < 32 && k4 < nk4) *reinterpret_cast<f32x4_t*>(&B[rr * OK_PITCH + 4 * k4]) = (n0 + rr < p.N && 4 * k4 < K) ? vb[i] : z4;
     }
   };
-  if (tile0 < tile1) { load_b(tile0); store_b(0); }
+  if (tile0 < tile1) { load_b(tile0); store_b(0, tile0); }
   __syncthreads();
 
   const int steps = K16 >> 4;
@@ -503,9 +507,9 @@ __global__ void __launch_bounds__(256) payne_dense_out_kernel(DenseParams p, int
 #pragma unroll 2
     for (int s = 0; s < steps; ++s) {
       const int k = s * 16 + 4 * g;
-      const float4 a = *reinterpret_cast<const float4*>(&As[(16 * wave + r) * OK_PITCH + k]);
-      const float4 b0 = *reinterpret_cast<const float4*>(&B[r * OK_PITCH + k]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&B[(16 + r) * OK_PITCH + k]);
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(&As[(16 * wave + r) * OK_PITCH + k]);
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(&B[r * OK_PITCH + k]);
+      const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(&B[(16 + r) * OK_PITCH + k]);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
@@ -515,6 +519,7 @@ __global__ void __launch_bounds__(256) payne_dense_out_kernel(DenseParams p, int
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
     }
+    if (tile + 1 < tile1) store_b(buf ^ 1, tile + 1);           // before the output stores: vmcnt then only covers the loads
     // C/D map: col = lane&15, row = 4*(lane>>4) + reg
     const int n0 = tile << 5;
 #pragma unroll
@@ -530,7 +535,6 @@ __global__ void __launch_bounds__(256) payne_dense_out_kernel(DenseParams p, int
         }
       }
     }
-    if (tile + 1 < tile1) store_b(buf ^ 1);
     __syncthreads();
   }
 }
