@@ -504,21 +504,44 @@ __global__ void __launch_bounds__(256, 1) payne_dense_out_kernel(DenseParams p, 
     if (tile + 1 < tile1) load_b(tile + 1);                     // flies under this tile's MFMAs
     const float* B = Bs + buf * 32 * OK_PITCH;
     f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll 2
-    for (int s = 0; s < steps; ++s) {
-      const int k = s * 16 + 4 * g;
-      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(&As[(16 * wave + r) * OK_PITCH + k]);
-      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(&B[r * OK_PITCH + k]);
-      const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(&B[(16 + r) * OK_PITCH + k]);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+    // software pipeline: the fragments of step s+1 are read from LDS while the 8 MFMAs of step s
+    // issue (one wave per SIMD: nothing else would cover the ds_read latency)
+    const float* Arow = &As[(16 * wave + r) * OK_PITCH + 4 * g];
+    const float* B0row = &B[r * OK_PITCH + 4 * g];
+    const float* B1row = &B[(16 + r) * OK_PITCH + 4 * g];
+#define OK_READ(A_, B0_, B1_, S_)                                               \
+    A_ = *reinterpret_cast<const f32x4_t*>(Arow + (S_) * 16);                     \
+    B0_ = *reinterpret_cast<const f32x4_t*>(B0row + (S_) * 16);                   \
+    B1_ = *reinterpret_cast<const f32x4_t*>(B1row + (S_) * 16);                   \
+    __builtin_amdgcn_sched_barrier(0)      /* the reads are ISSUED here, ahead of the MFMAs below */
+#define OK_MFMA8(A_, B0_, B1_)                                                    \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.x, B0_.x, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.x, B1_.x, acc1, 0, 0, 0);      \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.y, B0_.y, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.y, B1_.y, acc1, 0, 0, 0);      \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.z, B0_.z, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.z, B1_.z, acc1, 0, 0, 0);      \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.w, B0_.w, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.w, B1_.w, acc1, 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0)
+    f32x4_t a, b0, b1, an, b0n, b1n;
+    OK_READ(a, b0, b1, 0);
+    int s = 0;
+    for (; s + 2 < steps; s += 2) {
+      OK_READ(an, b0n, b1n, s + 1);
+      OK_MFMA8(a, b0, b1);
+      OK_READ(a, b0, b1, s + 2);
+      OK_MFMA8(an, b0n, b1n);
     }
+    if (s + 1 < steps) {                       // two steps left
+      OK_READ(an, b0n, b1n, s + 1);
+      OK_MFMA8(a, b0, b1);
+      OK_MFMA8(an, b0n, b1n);
+    } else {                                   // one step left
+      OK_MFMA8(a, b0, b1);
+    }
+#undef OK_READ
+#undef OK_MFMA8
     if (tile + 1 < tile1) store_b(buf ^ 1, tile + 1);           // before the output stores: vmcnt then only covers the loads
     // C/D map: col = lane&15, row = 4*(lane>>4) + reg
     const int n0 = tile << 5;
@@ -1010,6 +1033,13 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
   hipLaunchKernelGGL((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
+// Timing experiments only (results are invalid): PAYNE_SKIP bit 0 = hidden layers, 1 = output layer, 2 = post kernel.
+static int skip_mask() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PAYNE_SKIP"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 static int out_tile_choice() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }   // 0: K-resident kernel when K fits
@@ -1070,6 +1100,7 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
     p.bias_shift = last ? kBase : 0.f;
     p.Y = last ? c->raw : c->hid[(l - 1) & 1];
     p.ldy = last ? c->T.npix : c->ld_hid;
+    if (skip_mask() & (last ? 2 : 1)) continue;
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
       const payne_layer& L0 = c->layers[0];
@@ -1128,6 +1159,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
+  if (skip_mask() & 4) return PAYNE_OK;
   {
     ProfScope ps(c, s, 1);
     hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, (const PostTables*)c->d_T, a);

@@ -13,6 +13,5 @@ except Exception as e: print("$name failed", e, open("$OUT/bench_${TAG}_$name.lo
 PY
 }
 b base A=1
-b hid0 PAYNE_HIDDEN_KERNEL=0
+b only_out PAYNE_SKIP=5
 b tile5 PAYNE_OUT_TILE=5
-b tile3 PAYNE_OUT_TILE=3
