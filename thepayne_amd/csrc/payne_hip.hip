@@ -433,7 +433,10 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 // 64-candidate activation tile (whole K) in LDS and walks a run of 32-pixel weight tiles
 // through a register-staged double buffer, so the only exposed global latency is the first
 // tile's; every later tile's loads fly under the previous tile's MFMAs (the streaming-K kernel
-// above re-pays the load latency every 32 k and sits at ~40 % MFMA utilisation for K = 300).
+// above re-pays the load latency every 32 k).  Measured at C2: 26.8 us against 22.4 us for the
+// streaming kernel at 2 workgroups per CU -- both are bound by fp32-MFMA issue at the clock the
+// chip holds under matrix load, not by staging -- so this form is kept as an option
+// (PAYNE_OUT_TILE=6), not the default.
 // Wave w owns rows 16w..16w+15 of the tile and both 16-column halves (v_mfma_f32_16x16x4_f32,
 // two accumulators).  LDS: 64 x 312 + 2 x 32 x 312 floats = 156 KiB -> one workgroup per CU,
 // grid = (#64-row tiles) x (runs of pixel tiles) ~ one workgroup per CU.
@@ -1042,7 +1045,7 @@ static int skip_mask() {
 
 static int out_tile_choice() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }   // 0: K-resident kernel when K fits
+  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }   // 0: streaming 64x64x32 (fastest measured); 6: K-resident kernel
   return v;
 }
 
@@ -1112,7 +1115,7 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
     } else {
       p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
       if (!last) launch_small<false>(p, s);
-      else if (out_tile_choice() == 0 && p.K <= OK_KMAX) launch_out_resident(p, s);
+      else if (out_tile_choice() == 6 && p.K <= OK_KMAX) launch_out_resident(p, s);
       else switch (out_tile_choice()) {
         case 1: launch_dense<128, 64, 32, false>(p, s); break;
         case 2: launch_dense<64, 128, 32, false>(p, s); break;

@@ -253,16 +253,21 @@ PAYNE_HD_COLD double vsini_sb_exact(double ub) {
 // smoothing.py:612-620 for bin k: 4-point Lagrange interpolation in the host-built table
 // (fp64-accurate values stored as fp32; the factor multiplies Fourier amplitudes of the
 // SHIFTED spectrum, so 6e-8 on it is ~1e-9 in flux); sb is even in u; sb[0] = 1.
-PAYNE_HD float vsini_taper(const float* __restrict__ tab, int tab_n, double vs_c64, double vs_c, int k) {
-  if (k == 0) return 1.0f;
+// Branch-free (loads from a clamped index): a guarded load costs a branch and a wait and
+// serialises the caller's unrolled evaluations.  `far` reports bins beyond the table (or a
+// NaN argument); the caller re-evaluates those with vsini_sb_exact.
+PAYNE_HD float vsini_taper_fast(const float* __restrict__ tab, int tab_n, double vs_c64, int k, bool& far) {
   const double t = (double)k * vs_c64;                   // u / kVsTabStep
-  if (!(t < (double)(tab_n - 3))) return (float)vsini_sb_exact((double)k * vs_c);   // NaN / far tail
-  const int i = (int)t;
-  const float f = (float)(t - (double)i);
+  const bool in = t < (double)(tab_n - 3);               // false for NaN
+  far = far || !in;
+  int i = in ? (int)t : 0;
+  i = i < 0 ? 0 : i;
+  const float f = in ? (float)(t - (double)i) : 0.f;
   const float ym = tab[i > 0 ? i - 1 : 1], y0 = tab[i], y1 = tab[i + 1], y2 = tab[i + 2];
   const float fm1 = f - 1.0f, fm2 = f - 2.0f, fp1 = f + 1.0f;
-  return (-f * fm1 * fm2 * (1.0f / 6.0f)) * ym + (fp1 * fm1 * fm2 * 0.5f) * y0 + (-fp1 * f * fm2 * 0.5f) * y1 +
-         (fp1 * f * fm1 * (1.0f / 6.0f)) * y2;
+  const float v = (-f * fm1 * fm2 * (1.0f / 6.0f)) * ym + (fp1 * fm1 * fm2 * 0.5f) * y0 + (-fp1 * f * fm2 * 0.5f) * y1 +
+                  (fp1 * f * fm1 * (1.0f / 6.0f)) * y2;
+  return k == 0 ? 1.0f : v;
 }
 // smoothing.py:598-599: exp(-2 pi^2 sigma^2 ss^2), ss = k/(n dv), as exp2(c2 k^2)
 PAYNE_HD float gauss_taper(float g_c2, int k) {
@@ -278,8 +283,13 @@ struct TaperArgs {
   const float* vs_tab; int vs_tab_n; double vs_c64, vs_c;   // vsini
   float g_c2;                                               // gauss
 };
-template <bool VSINI> PAYNE_HD float taper_at(const TaperArgs& a, int k) {
-  return VSINI ? vsini_taper(a.vs_tab, a.vs_tab_n, a.vs_c64, a.vs_c, k) : gauss_taper(a.g_c2, k);
+template <bool VSINI> PAYNE_HD float taper_at(const TaperArgs& a, int k, bool& far) {
+  return VSINI ? vsini_taper_fast(a.vs_tab, a.vs_tab_n, a.vs_c64, k, far) : gauss_taper(a.g_c2, k);
+}
+// exact re-evaluation of a bin the table does not cover (rare: u >= 256 or NaN)
+PAYNE_HD float taper_far(const TaperArgs& a, int k, float fast) {
+  const double t = (double)k * a.vs_c64;
+  return (k != 0 && !(t < (double)(a.vs_tab_n - 3))) ? (float)vsini_sb_exact((double)k * a.vs_c) : fast;
 }
 
 // Middle step of a real convolution done with a half-length complex FFT.
@@ -298,38 +308,51 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
   for (int base = tid; base < npair; base += PU * nthr) {
     c32 zk[PU], zm[PU], w[PU];
     float tk[PU], tm[PU];
+    bool far = false;
 #pragma unroll
-    for (int q = 0; q < PU; ++q) {
-      const int k = 1 + base + q * nthr;
-      if (k <= npair) {
-        zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * tw_step];
-        tk[q] = taper_at<VSINI>(ta, k);
-        tm[q] = taper_at<VSINI>(ta, M - k);
+    for (int q = 0; q < PU; ++q) {                     // loads from clamped indices: no branches here
+      const int k0 = 1 + base + q * nthr, k = k0 <= npair ? k0 : npair;
+      zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * tw_step];
+      tk[q] = taper_at<VSINI>(ta, k, far);
+      tm[q] = taper_at<VSINI>(ta, M - k, far);
+    }
+    if (VSINI && far) {
+#pragma unroll
+      for (int q = 0; q < PU; ++q) {
+        const int k0 = 1 + base + q * nthr, k = k0 <= npair ? k0 : npair;
+        tk[q] = taper_far(ta, k, tk[q]);
+        tm[q] = taper_far(ta, M - k, tm[q]);
       }
     }
 #pragma unroll
     for (int q = 0; q < PU; ++q) {
       const int k = 1 + base + q * nthr;
+      const c32 A = cadd(zk[q], zm[q]);
+      const c32 C = cmul(w[q], cmul_negi(csub(zk[q], zm[q])));
+      const c32 S1 = cscale(cadd(A, C), tk[q] * g), S2 = cscale(csub(A, C), tm[q] * g);
+      const c32 E = cadd(S1, S2);
+      const c32 iO = cmul_posi(cmul(cconj(w[q]), csub(S1, S2)));
       if (k <= npair) {
-        const c32 A = cadd(zk[q], zm[q]);
-        const c32 C = cmul(w[q], cmul_negi(csub(zk[q], zm[q])));
-        const c32 S1 = cscale(cadd(A, C), tk[q] * g), S2 = cscale(csub(A, C), tm[q] * g);
-        const c32 E = cadd(S1, S2);
-        const c32 iO = cmul_posi(cmul(cconj(w[q]), csub(S1, S2)));
         Z[k] = cconj(cadd(E, iO));
         Z[M - k] = csub(E, iO);
       }
     }
   }
   if (tid == nthr - 1) {                               // k = 0 with k = M (real bins X[0], X[M])
-    const float t0 = taper_at<VSINI>(ta, 0), tM = taper_at<VSINI>(ta, M);
+    bool far = false;
+    const float t0 = taper_at<VSINI>(ta, 0, far);
+    float tM = taper_at<VSINI>(ta, M, far);
+    if (VSINI && far) tM = taper_far(ta, M, tM);
     const c32 z0 = Z[0];
     const float x0 = t0 * (z0.x + z0.y), xm = tM * (z0.x - z0.y);
     Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
   }
   if (tid == (nthr > 1 ? nthr - 2 : 0) && M >= 2) {    // k = M/2 (self-conjugate)
     const int k = M / 2;
-    Z[k] = cscale(cconj(Z[k]), taper_at<VSINI>(ta, k) * invM);
+    bool far = false;
+    float th = taper_at<VSINI>(ta, k, far);
+    if (VSINI && far) th = taper_far(ta, k, th);
+    Z[k] = cscale(cconj(Z[k]), th * invM);
   }
 }
 
@@ -413,9 +436,9 @@ PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ 
     for (int base = tid; base < n4; base += kU * nthr) {
       float v[kU][4];
 #pragma unroll
-      for (int q = 0; q < kU; ++q) {
-        const int i = base + q * nthr;
-        if (i < n4) { v[q][0] = raw[4 * i]; v[q][1] = raw[4 * i + 1]; v[q][2] = raw[4 * i + 2]; v[q][3] = raw[4 * i + 3]; }
+      for (int q = 0; q < kU; ++q) {                    // clamped index: unconditional loads
+        const int i0 = base + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
+        v[q][0] = raw[4 * i]; v[q][1] = raw[4 * i + 1]; v[q][2] = raw[4 * i + 2]; v[q][3] = raw[4 * i + 3];
       }
 #pragma unroll
       for (int q = 0; q < kU; ++q) {
@@ -439,11 +462,9 @@ PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const f
     float a[kU], b[kU], f[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
-      const int j = base + q * nthr;
-      if (j < T.n1) {
-        if (T.rot_identity) { a[q] = spec[j]; b[q] = a[q]; f[q] = 0.f; }
-        else { const int k = T.rs1_idx[j]; f[q] = T.rs1_frac[j]; a[q] = spec[k]; b[q] = spec[k + 1]; }
-      }
+      const int j0 = base + q * nthr, j = j0 < T.n1 ? j0 : T.n1 - 1;
+      if (T.rot_identity) { a[q] = spec[j]; b[q] = a[q]; f[q] = 0.f; }
+      else { const int k = T.rs1_idx[j]; f[q] = T.rs1_frac[j]; a[q] = spec[k]; b[q] = spec[k + 1]; }
     }
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
@@ -464,12 +485,10 @@ PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float
     int jj[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
-      const int i = base + q * nthr;
-      if (i < T.npix) {
-        jj[q] = T.bk1_idx[i]; f[q] = T.bk1_frac[i];
-        const int j = jj[q] < 0 ? 0 : jj[q];
-        a[q] = work[j]; b[q] = work[j + 1];
-      }
+      const int i0 = base + q * nthr, i = i0 < T.npix ? i0 : T.npix - 1;
+      jj[q] = T.bk1_idx[i]; f[q] = T.bk1_frac[i];
+      const int j = jj[q] < 0 ? 0 : jj[q];
+      a[q] = work[j]; b[q] = work[j + 1];
     }
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
@@ -496,23 +515,21 @@ PAYNE_HD void phase_mask_count(int tid, int nthr, const PostTables& T, const Can
     double wc[MU];
 #pragma unroll
     for (int q = 0; q < MU; ++q) {
-      const int i = base + q * nthr;
-      if (i < T.npix) wc[q] = T.lam[i];
+      const int i0 = base + q * nthr;
+      wc[q] = T.lam[i0 < T.npix ? i0 : T.npix - 1];
     }
 #pragma unroll
     for (int q = 0; q < MU; ++q) {
-      const int i = base + q * nthr;
-      if (i < T.npix) {
-        const double c = wc[q] * op;
-        const bool below = !(c > wl), notabove = (c < wh);
+      const bool valid = (base + q * nthr) < T.npix;
+      const double c = wc[q] * op;
+      const bool below = valid && !(c > wl), notabove = valid && (c < wh);
 #ifdef __HIP_DEVICE_COMPILE__
-        cb += __popcll(__ballot(below));
-        ca += __popcll(__ballot(notabove));
+      cb += __popcll(__ballot(below));
+      ca += __popcll(__ballot(notabove));
 #else
-        cb += below ? 1 : 0;
-        ca += notabove ? 1 : 0;
+      cb += below ? 1 : 0;
+      ca += notabove ? 1 : 0;
 #endif
-      }
     }
   }
   if ((tid & ((1 << kSlotShift) - 1)) == 0) cnt[tid >> kSlotShift] = cb | (ca << 16);
@@ -554,16 +571,14 @@ PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const Can
     float a[kU], b[kU], w[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
-      const int j = base + q * nthr;
-      if (j < W.n2) {
-        int k; float ww;
-        if (T.geo) uniform_locate((double)j * W.rsA + W.rsB, W.i0, W.i1, W.hs_ann, k, ww);
-        else {
-          const double lw = (j == W.n2 - 1) ? W.lnmax : ((double)j * W.step + W.lnmin);
-          search_locate(T, W.i0, W.i1, lw - S.dop, k, ww);
-        }
-        a[q] = spec[k]; b[q] = spec[k + 1]; w[q] = ww;
+      const int j0 = base + q * nthr, j = j0 < W.n2 ? j0 : W.n2 - 1;
+      int k; float ww;
+      if (T.geo) uniform_locate((double)j * W.rsA + W.rsB, W.i0, W.i1, W.hs_ann, k, ww);
+      else {
+        const double lw = (j == W.n2 - 1) ? W.lnmax : ((double)j * W.step + W.lnmin);
+        search_locate(T, W.i0, W.i1, lw - S.dop, k, ww);
       }
+      a[q] = spec[k]; b[q] = spec[k + 1]; w[q] = ww;
     }
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
@@ -594,10 +609,11 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
     bool nanv[OU];
 #pragma unroll
     for (int q = 0; q < OU; ++q) {
-      const int i = base + q * nthr;
-      if (i < T.nobs) {
+      const int i0 = base + q * nthr, i = i0 < T.nobs ? i0 : T.nobs - 1;     // clamped: unconditional loads
+      {
         const double lo = T.lnobs[i];
-        if (T.obs_f1) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }
+        of1[q] = 0.f; iv[q] = 0.f; xc[q] = 0.0;
+        if (T.obs_f1) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }         // uniform branches
         if (cheb) xc[q] = T.xcheb[i];
         int k = 0; float ww = 0.f;
         if (smooth) {

@@ -13,5 +13,4 @@ except Exception as e: print("$name failed", e, open("$OUT/bench_${TAG}_$name.lo
 PY
 }
 b base A=1
-b only_out PAYNE_SKIP=5
-b tile5 PAYNE_OUT_TILE=5
+python tools/post_stamps.py > $OUT/stamps_$TAG.log 2>&1; tail -26 $OUT/stamps_$TAG.log
