@@ -510,7 +510,7 @@ PAYNE_HD void phase_rot_edges(int tid, int npix, float* spec) {
 PAYNE_HD void phase_mask_count(int tid, int nthr, const PostTables& T, const CandState& S, int* cnt) {
   const double wl = S.wl, wh = S.wh, op = S.one_plus;
   int cb = 0, ca = 0;
-  constexpr int MU = 8;                                  // global loads: keep 8 in flight per thread
+  constexpr int MU = 16;                                 // global loads: keep a whole thread-share in flight
   for (int base = tid; base < T.npix; base += MU * nthr) {
     double wc[MU];
 #pragma unroll
@@ -599,7 +599,7 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
   float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the
   const bool cheb = T.npoly > 0;                         // cross-thread reduction is fp64
   const bool smooth = S.do_smooth != 0;
-  constexpr int OU = 8;                                  // global loads: keep 8 pixels in flight per thread
+  constexpr int OU = 16;                                 // global loads: keep a whole thread-share in flight
   // plain-interp branch on a geometric grid: t = (lnobs - dop - ln0)/dln
   const double piA = T.geo_inv_dln, piB = -(S.dop + T.ln0) * T.geo_inv_dln;
   const float hs_ann = (float)(0.5 * T.dln);
