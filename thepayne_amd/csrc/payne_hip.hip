@@ -603,9 +603,11 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
 }
 
 template <int LOG2N, bool TW_LDS>
-__global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables* __restrict__ Tp, PostArgs a) {
+__global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables T, PostArgs a) {
+  // T by value: its pointer members then live in the kernarg segment and are known to be
+  // global (a struct read through a device pointer yields generic pointers -> flat_load,
+  // which also ties every table load to the LDS wait counter)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const PostTables& T = *Tp;                                   // uniform address: scalar loads
   const int n1 = T.n1;
   float* bufA = reinterpret_cast<float*>(smem);
   float* bufB = bufA + n1;
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
 #endif
 }
 
-typedef void (*post_kernel_fn)(const PostTables*, PostArgs);
+typedef void (*post_kernel_fn)(const PostTables, PostArgs);
 // compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
 static post_kernel_fn pick_post_kernel(int n1, bool tw_lds) {
   if (tw_lds) {
@@ -1165,7 +1167,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   if (skip_mask() & 4) return PAYNE_OK;
   {
     ProfScope ps(c, s, 1);
-    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, (const PostTables*)c->d_T, a);
+    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("post launch: ") + hipGetErrorString(e));
@@ -1258,7 +1260,7 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d;
-  hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, (const PostTables*)c->d_T, a);
+  hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T, a);
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(d); (void)hipFree(lnl);
