@@ -456,14 +456,15 @@ PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ 
 
 // vsini a: resample onto the pow-2 log grid (static map) into `work`; identity maps
 // (geometric grid, npix a power of two) degenerate to a NaN-scrubbing copy.
-PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const float* __restrict__ spec,
-                                 float* __restrict__ work) {
+template <bool IDENT>
+PAYNE_HD void rot_resample_loop(int tid, int nthr, const PostTables& T, const float* __restrict__ spec,
+                                float* __restrict__ work) {
   for (int base = tid; base < T.n1; base += kU * nthr) {
     float a[kU], b[kU], f[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
       const int j0 = base + q * nthr, j = j0 < T.n1 ? j0 : T.n1 - 1;
-      if (T.rot_identity) { a[q] = spec[j]; b[q] = a[q]; f[q] = 0.f; }
+      if (IDENT) { a[q] = spec[j]; b[q] = a[q]; f[q] = 0.f; }
       else { const int k = T.rs1_idx[j]; f[q] = T.rs1_frac[j]; a[q] = spec[k]; b[q] = spec[k + 1]; }
     }
 #pragma unroll
@@ -475,6 +476,14 @@ PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const f
       }
     }
   }
+}
+// (workgroup-uniform conditions are resolved OUTSIDE the unrolled loops everywhere below: a
+// branch inside the body, even a uniform one, stops the compiler from batching the loads of
+// the unrolled iterations, and each iteration then pays its own memory latency)
+PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const float* __restrict__ spec,
+                                 float* __restrict__ work) {
+  if (T.rot_identity) rot_resample_loop<true>(tid, nthr, T, spec, work);
+  else rot_resample_loop<false>(tid, nthr, T, spec, work);
 }
 // vsini c: back onto the ANN grid (left/right = NaN), into `spec` (skipped for identity maps:
 // the convolved buffer then IS the spectrum on the ANN grid).
@@ -565,15 +574,16 @@ PAYNE_HD Window make_window(const PostTables& T, const CandState& S, const int* 
 }
 
 // R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
-PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
-                               const float* __restrict__ spec, float* __restrict__ work) {
+template <bool GEO>
+PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
+                              const float* __restrict__ spec, float* __restrict__ work) {
   for (int base = tid; base < W.n2; base += kU * nthr) {
     float a[kU], b[kU], w[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
       const int j0 = base + q * nthr, j = j0 < W.n2 ? j0 : W.n2 - 1;
       int k; float ww;
-      if (T.geo) uniform_locate((double)j * W.rsA + W.rsB, W.i0, W.i1, W.hs_ann, k, ww);
+      if (GEO) uniform_locate((double)j * W.rsA + W.rsB, W.i0, W.i1, W.hs_ann, k, ww);
       else {
         const double lw = (j == W.n2 - 1) ? W.lnmax : ((double)j * W.step + W.lnmin);
         search_locate(T, W.i0, W.i1, lw - S.dop, k, ww);
@@ -590,74 +600,99 @@ PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const Can
     }
   }
 }
+PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
+                               const float* __restrict__ spec, float* __restrict__ work) {
+  if (T.geo) R_resample_loop<true>(tid, nthr, T, S, W, spec, work);
+  else R_resample_loop<false>(tid, nthr, T, S, W, spec, work);
+}
+
+// Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
+// `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
+// (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
+// MODE: 0 = smoothed spectrum on the candidate's uniform log grid; 1 = plain interpolation on a
+// geometric ANN grid; 2 = plain interpolation with a search (non-geometric grid).
+template <int MODE, bool CHEB, bool HASF, bool OUT>
+PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
+                        const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
+  float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the
+  constexpr int OU = 16;                                 // cross-thread reduction is fp64
+  const double piA = T.geo_inv_dln, piB = -(S.dop + T.ln0) * T.geo_inv_dln;   // MODE 1: t = (lnobs - dop - ln0)/dln
+  const float hs_ann = (float)(0.5 * T.dln);
+  const int nc = T.npoly;
+  for (int base = tid; base < T.nobs; base += OU * nthr) {
+    float a[OU], b[OU], w[OU], of1[OU], iv[OU];
+    double xc[OU];
+    bool nanv[OU];
+#pragma unroll
+    for (int q = 0; q < OU; ++q) {                       // clamped index: every load unconditional
+      const int i0 = base + q * nthr, i = i0 < T.nobs ? i0 : T.nobs - 1;
+      const double lo = T.lnobs[i];
+      if (HASF) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }
+      if (CHEB) xc[q] = T.xcheb[i];
+      int k = 0; float ww = 0.f;
+      if (MODE == 0) {
+        nanv[q] = (lo < W.lnmin) || (lo > W.lnmax);      // np.interp(left=nan, right=nan)
+        uniform_locate(nanv[q] ? 0.0 : lo * W.obA + W.obB, 0, W.n2, W.hs_step, k, ww);
+      } else {
+        const double v = lo - S.dop;
+        nanv[q] = (v < T.ln0) || (v > T.ln_last);
+        if (MODE == 1) uniform_locate(nanv[q] ? 0.0 : lo * piA + piB, 0, T.npix, hs_ann, k, ww);
+        else if (!nanv[q]) search_locate(T, 0, T.npix, v, k, ww);
+      }
+      a[q] = conv[k]; b[q] = conv[k + 1]; w[q] = ww;
+    }
+#pragma unroll
+    for (int q = 0; q < OU; ++q) {
+      const int i = base + q * nthr;
+      const bool valid = i < T.nobs;
+      const float m1 = nanv[q] ? nanf_() : a[q] + (b[q] - a[q]) * w[q];
+      float pm1 = 0.f, p = 1.f;
+      if (CHEB) {   // numpy.polynomial.chebyshev.chebval (Clenshaw), fitutils.py:11-20
+        const double x = xc[q];
+        double c0, c1;
+        if (nc == 1) { c0 = S.poly[0]; c1 = 0.0; }
+        else if (nc == 2) { c0 = S.poly[0]; c1 = S.poly[1]; }
+        else {
+          const double x2 = 2.0 * x;
+          c0 = S.poly[nc - 2]; c1 = S.poly[nc - 1];
+          for (int r = 3; r <= nc; ++r) { double t = c0; c0 = S.poly[nc - r] - c1; c1 = t + c1 * x2; }
+        }
+        const double pv = c0 + c1 * x;
+        p = (float)pv; pm1 = (float)(pv - 1.0);
+      }
+      if (OUT && valid) out[i] = (out_stage == 3) ? (m1 + kBase) * p : (m1 + kBase);   // genspec / getspec
+      if (HASF) {
+        const float d = CHEB ? (m1 * p + (pm1 - of1[q])) : (m1 - of1[q]);
+        acc = valid ? fmaf(d * d, iv[q], acc) : acc;
+      }
+    }
+  }
+  return acc;
+}
 
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
 PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                           const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
-  float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the
-  const bool cheb = T.npoly > 0;                         // cross-thread reduction is fp64
-  const bool smooth = S.do_smooth != 0;
-  constexpr int OU = 16;                                 // global loads: keep a whole thread-share in flight
-  // plain-interp branch on a geometric grid: t = (lnobs - dop - ln0)/dln
-  const double piA = T.geo_inv_dln, piB = -(S.dop + T.ln0) * T.geo_inv_dln;
-  const float hs_ann = (float)(0.5 * T.dln);
-  for (int base = tid; base < T.nobs; base += OU * nthr) {
-    float a[OU], b[OU], w[OU], of1[OU], iv[OU];
-    double xc[OU];
-    bool nanv[OU];
-#pragma unroll
-    for (int q = 0; q < OU; ++q) {
-      const int i0 = base + q * nthr, i = i0 < T.nobs ? i0 : T.nobs - 1;     // clamped: unconditional loads
-      {
-        const double lo = T.lnobs[i];
-        of1[q] = 0.f; iv[q] = 0.f; xc[q] = 0.0;
-        if (T.obs_f1) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }         // uniform branches
-        if (cheb) xc[q] = T.xcheb[i];
-        int k = 0; float ww = 0.f;
-        if (smooth) {
-          nanv[q] = W.bad || (lo < W.lnmin) || (lo > W.lnmax);        // np.interp(left=nan, right=nan)
-          if (!nanv[q]) uniform_locate(lo * W.obA + W.obB, 0, W.n2, W.hs_step, k, ww);
-        } else {
-          const double v = lo - S.dop;
-          nanv[q] = (v < T.ln0) || (v > T.ln_last);
-          if (!nanv[q]) {
-            if (T.geo) uniform_locate(lo * piA + piB, 0, T.npix, hs_ann, k, ww);
-            else search_locate(T, 0, T.npix, v, k, ww);
-          }
-        }
-        a[q] = conv[k]; b[q] = conv[k + 1]; w[q] = ww;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < OU; ++q) {
-      const int i = base + q * nthr;
-      if (i < T.nobs) {
-        const float m1 = nanv[q] ? nanf_() : a[q] + (b[q] - a[q]) * w[q];
-        float pm1 = 0.f, p = 1.f;
-        if (cheb) {   // numpy.polynomial.chebyshev.chebval (Clenshaw), fitutils.py:11-20
-          const double x = xc[q];
-          double c0, c1;
-          const int nc = T.npoly;
-          if (nc == 1) { c0 = S.poly[0]; c1 = 0.0; }
-          else if (nc == 2) { c0 = S.poly[0]; c1 = S.poly[1]; }
-          else {
-            const double x2 = 2.0 * x;
-            c0 = S.poly[nc - 2]; c1 = S.poly[nc - 1];
-            for (int r = 3; r <= nc; ++r) { double t = c0; c0 = S.poly[nc - r] - c1; c1 = t + c1 * x2; }
-          }
-          const double pv = c0 + c1 * x;
-          p = (float)pv; pm1 = (float)(pv - 1.0);
-        }
-        if (out) out[i] = (out_stage == 3) ? (m1 + kBase) * p : (m1 + kBase);   // genspec / getspec
-        if (T.obs_f1) {
-          const float d = cheb ? (m1 * p + (pm1 - of1[q])) : (m1 - of1[q]);
-          acc = fmaf(d * d, iv[q], acc);
-        }
-      }
-    }
+  const bool cheb = T.npoly > 0, hasf = T.obs_f1 != nullptr, smooth = S.do_smooth != 0;
+  if (!out && !hasf) return 0.0;                         // nothing to produce
+  if (smooth && W.bad) {                                 // window too small: every pixel NaN
+    if (out) for (int i = tid; i < T.nobs; i += nthr) out[i] = nanf_();
+    return hasf ? (double)nanf_() : 0.0;
   }
+#define PAYNE_OBS(MODE_)                                                                              \
+  (out ? (cheb ? (hasf ? obs_loop<MODE_, true, true, true>(tid, nthr, T, S, W, conv, out, out_stage)    \
+                       : obs_loop<MODE_, true, false, true>(tid, nthr, T, S, W, conv, out, out_stage))  \
+               : (hasf ? obs_loop<MODE_, false, true, true>(tid, nthr, T, S, W, conv, out, out_stage)   \
+                       : obs_loop<MODE_, false, false, true>(tid, nthr, T, S, W, conv, out, out_stage))) \
+       : (cheb ? obs_loop<MODE_, true, true, false>(tid, nthr, T, S, W, conv, out, out_stage)           \
+               : obs_loop<MODE_, false, true, false>(tid, nthr, T, S, W, conv, out, out_stage)))
+  float acc;
+  if (smooth) acc = PAYNE_OBS(0);
+  else if (T.geo) acc = PAYNE_OBS(1);
+  else acc = PAYNE_OBS(2);
+#undef PAYNE_OBS
   return (double)acc;
 }
 
