@@ -565,6 +565,151 @@ __global__ void __launch_bounds__(256, 1) payne_dense_out_kernel(DenseParams p, 
   }
 }
 
+
+// ----------------------------------------------------------------------------
+// Output layer on the bf16 matrix pipe at fp32 accuracy ("3 x bf16" split).
+// Every fp32 operand is written exactly as x = x1 + x2 + x3 with bf16 parts (8 + 8 + 8
+// mantissa bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the subtractions are
+// exact).  A product a*b is then the six partial products with i + j <= 4,
+//   a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1,
+// each exact in fp32 (8b x 8b), the dropped terms being < 2^-23 |ab|; accumulation is fp32 in
+// the MFMA accumulator exactly as for the f32 MFMA.  v_mfma_f32_32x32x16_bf16 retires 16 k per
+// 32 cycles against 2 k per 64 cycles for v_mfma_f32_32x32x2_f32, so six of them cost 3/8 of the
+// fp32 issue time -- and the f32 MFMA kernel above is bound exactly by that issue time.
+// Weights are split once at context creation ([3][Npad][Kp] bf16, zero padded); activations are
+// split while their tile is staged into LDS.  Tile 64 x 128 x 32, 4 waves as 2 x 2, wave tile
+// 32 x 64; LDS rows padded to 80 B (conflict-free ds_read_b128 for the 32-row x 2-half lane map).
+// ----------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+constexpr int BX_BM = 64, BX_BN = 128, BX_BK = 32, BX_PITCH = 80;            // bytes per LDS row
+constexpr size_t BX_LDS_BYTES = (size_t)2 * 3 * (BX_BM + BX_BN) * BX_PITCH;
+
+__device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 b1 = (__bf16)x;
+  const float r1 = x - (float)b1;
+  const __bf16 b2 = (__bf16)r1;
+  const float r2 = r1 - (float)b2;
+  const __bf16 b3 = (__bf16)r2;
+  h = bf16_bits(b1); m = bf16_bits(b2); l = bf16_bits(b3);
+}
+
+struct Bx3Params {
+  DenseParams d;
+  const unsigned short* Wp;     // [3][Npad][Kp] bf16 planes of W
+  int Kp, Npad;
+};
+
+__global__ void __launch_bounds__(256, 1) payne_dense_bf16x3_kernel(Bx3Params q) {
+  const DenseParams& p = q.d;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bx_sm[];
+  // [buf][plane][A rows 64 | B rows 128][80 B]
+  auto lds_a = [&](int buf, int pl) { return bx_sm + ((size_t)(buf * 3 + pl) * (BX_BM + BX_BN)) * BX_PITCH; };
+  auto lds_b = [&](int buf, int pl) { return lds_a(buf, pl) + (size_t)BX_BM * BX_PITCH; };
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);             // XCD-contiguous tile runs (m fastest)
+  const int m0 = (t % p.grid_m) * BX_BM, n0 = (t / p.grid_m) * BX_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+  const int r = lane & 31, h = lane >> 5;
+
+  // staging registers: A = 2 float4 of fp32 per thread, B = 2 x 16 B per plane per thread
+  f32x4_t ra[2];
+  f32x4_t rb[3][2];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, k = k0 + (idx & 7) * 4;
+      const int mr = (m0 + row < p.B) ? m0 + row : p.B - 1, kc = (k < p.K) ? k : p.K - 4;
+      ra[i] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kc);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 2, c16 = idx & 3;
+        rb[pl][i] = *reinterpret_cast<const f32x4_t*>(q.Wp + ((size_t)pl * q.Npad + n0 + row) * q.Kp + k0 + 8 * c16);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_tiles = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, k4 = idx & 7, k = k0 + k4 * 4;
+      const bool ok = (m0 + row < p.B) && (k < p.K);
+      const float v[4] = {ok ? ra[i].x : 0.f, ok ? ra[i].y : 0.f, ok ? ra[i].z : 0.f, ok ? ra[i].w : 0.f};
+      u16x4_t p1, p2, p3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short a1, a2, a3;
+        split3(v[e], a1, a2, a3);
+        p1[e] = a1; p2[e] = a2; p3[e] = a3;
+      }
+      *reinterpret_cast<u16x4_t*>(lds_a(buf, 0) + row * BX_PITCH + k4 * 8) = p1;
+      *reinterpret_cast<u16x4_t*>(lds_a(buf, 1) + row * BX_PITCH + k4 * 8) = p2;
+      *reinterpret_cast<u16x4_t*>(lds_a(buf, 2) + row * BX_PITCH + k4 * 8) = p3;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 2, c16 = idx & 3;
+        *reinterpret_cast<f32x4_t*>(lds_b(buf, pl) + row * BX_PITCH + c16 * 16) = rb[pl][i];
+      }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  const int nk = (p.K + BX_BK - 1) / BX_BK;
+  load_tiles(0);
+  store_tiles(0, 0);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) load_tiles((it + 1) * BX_BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                    // two 16-deep MFMA steps per 32-deep tile
+      bf16x8_t a[3], b[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[pl] = *reinterpret_cast<const bf16x8_t*>(lds_a(buf, pl) + (wm0 + r) * BX_PITCH + ks * 32 + h * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[j][pl] = *reinterpret_cast<const bf16x8_t*>(lds_b(buf, pl) + (wn0 + 32 * j + r) * BX_PITCH + ks * 32 + h * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                     // smallest partial products first
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
+      }
+    }
+    if (it + 1 < nk) store_tiles(buf ^ 1, (it + 1) * BX_BK);
+    __syncthreads();
+  }
+  // C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn0 + 32 * j + r;
+    if (col >= p.N) continue;
+    const float bv = p.bias[col] - p.bias_shift;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[j][e] + bv, p.act);
+    }
+  }
+}
+
 // ============================================================================
 // per-candidate spectrum pipeline
 // ============================================================================
@@ -764,6 +909,8 @@ struct payne_ctx {
   float* hid[2] = {nullptr, nullptr};
   int ld_hid = 0;
   float* raw = nullptr;
+  unsigned short* w_planes = nullptr;   // bf16 x 3 split of the output layer's weights
+  int wp_Kp = 0, wp_Npad = 0;
   size_t post_lds = 0;
   bool post_tw_lds = false;
   PostTables* d_T = nullptr;          // device copy of T (kernel argument)
@@ -932,6 +1079,37 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       }
       if (l + 1 < model->n_layers) maxh = std::max(maxh, L.n_out);
     }
+    {   // exact 3 x bf16 split of the output layer's weights (payne_dense_bf16x3_kernel)
+      const payne_layer& L = c->layers[model->n_layers - 1];
+      const int K = L.n_in, N = L.n_out;
+      const int Kp = (K + 31) & ~31, Npad = (N + 127) & ~127;
+      std::vector<float> w((size_t)N * K);
+      he = hipMemcpy(w.data(), L.w, w.size() * 4, hipMemcpyDeviceToHost);
+      if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(W out): ") + hipGetErrorString(he)));
+      std::vector<unsigned short> pl((size_t)3 * Npad * Kp, 0);
+      auto to_bf16 = [](float x) -> unsigned short {            // round to nearest even (NaN kept quiet)
+        unsigned u; std::memcpy(&u, &x, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+        return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+      };
+      auto from_bf16 = [](unsigned short b) -> float { unsigned u = (unsigned)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+      for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+          const float x = w[(size_t)n * K + k];
+          const unsigned short b1 = to_bf16(x);
+          const float r1 = x - from_bf16(b1);
+          const unsigned short b2 = to_bf16(r1);
+          const float r2 = r1 - from_bf16(b2);
+          const unsigned short b3 = to_bf16(r2);
+          pl[((size_t)0 * Npad + n) * Kp + k] = b1;
+          pl[((size_t)1 * Npad + n) * Kp + k] = b2;
+          pl[((size_t)2 * Npad + n) * Kp + k] = b3;
+        }
+      const unsigned short* dp = nullptr;
+      if ((rc = upload(c, pl, &dp, c->owned))) return bail(rc);
+      c->w_planes = const_cast<unsigned short*>(dp);
+      c->wp_Kp = Kp; c->wp_Npad = Npad;
+    }
     c->n_layers = model->n_layers;
     c->n_labels = model->n_labels;
     for (int d = 0; d < model->n_labels; ++d) { c->xmin[d] = model->xmin[d]; c->xden[d] = model->xmax[d] - model->xmin[d]; }
@@ -1067,6 +1245,18 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
   hipLaunchKernelGGL(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
 }
 
+static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  p.grid_m = (p.B + BX_BM - 1) / BX_BM;
+  p.grid_n = (p.N + BX_BN - 1) / BX_BN;
+  Bx3Params q{p, c->w_planes, c->wp_Kp, c->wp_Npad};
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BX_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(payne_dense_bf16x3_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BX_LDS_BYTES, s, q);
+}
+
 static int hidden_kernel_choice() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("PAYNE_HIDDEN_KERNEL"); v = e ? atoi(e) : 1; }   // 1: workgroup form, 0: wave-per-tile
@@ -1117,6 +1307,7 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
     } else {
       p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
       if (!last) launch_small<false>(p, s);
+      else if (out_tile_choice() == 7 && c->w_planes) launch_out_bf16x3(c, p, s);
       else if (out_tile_choice() == 6 && p.K <= OK_KMAX) launch_out_resident(p, s);
       else switch (out_tile_choice()) {
         case 1: launch_dense<128, 64, 32, false>(p, s); break;

@@ -13,4 +13,6 @@ except Exception as e: print("$name failed", e, open("$OUT/bench_${TAG}_$name.lo
 PY
 }
 b base A=1
-python tools/post_stamps.py > $OUT/stamps_$TAG.log 2>&1; tail -26 $OUT/stamps_$TAG.log
+PAYNE_OUT_TILE=7 python -m pytest tests -m gpu -q -x > $OUT/pytest_${TAG}_bf.log 2>&1; echo "pytest bf16x3 rc=$?"; tail -5 $OUT/pytest_${TAG}_bf.log
+b bf16x3 PAYNE_OUT_TILE=7
+b bf16x3_only PAYNE_OUT_TILE=7 PAYNE_SKIP=5
