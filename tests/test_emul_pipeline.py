@@ -90,13 +90,13 @@ def test_modpoly_matches_reference_golden(emul, golden):
     assert np.all(np.abs(-0.5 * chi2 - g["lnlike"]) <= lnl_tol(g["lnlike"]))
 
 
-@pytest.mark.parametrize("npix,nobs,nthreads", [(300, 250, 64), (777, 600, 256), (2048, 1800, 128), (5000, 4000, 256)])
+@pytest.mark.parametrize("npix,nobs,nthreads", [(300, 250, 64), (777, 600, 256), (2048, 1800, 128), (5000, 4000, 256), (40000, 30000, 512)])
 def test_ragged_sizes_vs_oracle(emul, npix, nobs, nthreads):
     """npix not a power of two (the vsini grid is then a genuine resampling), few threads."""
     net = synth.make_yst_net(npix=npix, H=24, seed=21, line_depth=0.2)
     span = net["wavelength"][-1] - net["wavelength"][0]
     obs = synth.obs_grid(net["wavelength"], nobs, inset=0.06 * span)
-    th7 = synth.draw_candidates(6, seed=npix)
+    th7 = synth.draw_candidates(6 if npix < 20000 else 2, seed=npix)
     ref = np.array([O.genspec(net, list(_th8(t)[0]), outwave=obs)[1] for t in th7])
     out, _, _ = emul(net, obs, None, None, _th8(th7), 2, nthreads=nthreads)
     assert np.array_equal(np.isnan(out), np.isnan(ref))

@@ -181,8 +181,31 @@ def test_abi_error_paths(Engine):
     assert rc == -4 and b"b_max" in eng.lib.payne_last_error(eng._ctx)          # PAYNE_E_BATCH
     rc = eng.lib.payne_lnlike_batch(eng._ctx, th.data_ptr(), 4, out.data_ptr(), None)
     assert rc == -1                                                             # no flux bound
-    with pytest.raises(RuntimeError):
-        Engine(_net(synth.make_yst_net(npix=40000, H=8)), b_max=1)             # beyond the LDS pipeline (for now)
+
+
+def test_spectra_larger_than_lds_vs_oracle(Engine):
+    """n1 > 16384 takes the global-workspace kernel (persistent workgroups): a 40 000-pixel net and the
+    65 536-pixel C5 grid (R ~ 100k), a few candidates each (the oracle needs ~0.1 s per evaluation)."""
+    for npix, nobs, lam0, R, B in ((40000, 30000, 5150.0, 32000.0, 3), (65536, 60000, 4000.0, 100000.0, 5)):
+        raw = synth.make_yst_net(npix=npix, lam0=lam0, R_fwhm=R, H=16, seed=31, line_depth=0.1)
+        obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.0005, relative=True)
+        th7 = synth.draw_candidates(B, seed=npix)
+        th7[:, 6] = np.linspace(0.6, 0.85, B) * R                  # instrument R below the ANN's own
+        rows = [list(theta_full(t)[0, :8]) for t in th7]
+        ref_flux = np.array([O.genspec(raw, r, outwave=obs)[1] for r in rows])
+        flux = ref_flux[0] + np.random.default_rng(1).normal(0, 0.01, nobs)
+        eflux = np.full(nobs, 0.01)
+        eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=2)   # b_max < B: chunked, grid < batch
+        got = eng.predict_batch(theta_full(th7), stage=2, fwhm_R=True).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref_flux))
+        assert np.nanmax(np.abs(got - ref_flux)) <= FLUX_TOL, npix
+        L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
+        ref = np.array([L.lnlikefn(t) for t in th7])
+        lnl = eng.lnlike_batch(theta_full(th7)).cpu().numpy()
+        assert np.all(np.abs(lnl - ref) <= lnl_tol(ref)), (npix, np.abs(lnl - ref).max())
+        s1 = eng.predict_batch(theta_full(th7[:1]), stage=1).cpu().numpy()[0]
+        r1 = O.getspec(raw, Teff=th7[0, 0], logg=th7[0, 1], feh=th7[0, 2], afe=th7[0, 3], rot_vel=th7[0, 5])[1]
+        assert np.abs(s1 - r1).max() <= FLUX_TOL
 
 
 def test_full_size_properties(Engine):

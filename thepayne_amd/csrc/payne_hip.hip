@@ -599,6 +599,7 @@ struct Bx3Params {
   DenseParams d;
   const unsigned short* Wp;     // [3][Npad][Kp] bf16 planes of W
   int Kp, Npad;
+  int dbg;                      // timing experiments (PAYNE_BX_DBG): 1 = no output stores, 2 = no MFMAs, 4 = no staging
 };
 
 __global__ void __launch_bounds__(256, 1) payne_dense_bf16x3_kernel(Bx3Params q) {
@@ -672,7 +673,8 @@ __global__ void __launch_bounds__(256, 1) payne_dense_bf16x3_kernel(Bx3Params q)
   __syncthreads();
   for (int it = 0; it < nk; ++it) {
     const int buf = it & 1;
-    if (it + 1 < nk) load_tiles((it + 1) * BX_BK);
+    if (it + 1 < nk && !(q.dbg & 4)) load_tiles((it + 1) * BX_BK);
+    if (!(q.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                    // two 16-deep MFMA steps per 32-deep tile
       bf16x8_t a[3], b[2][3];
@@ -693,8 +695,17 @@ __global__ void __launch_bounds__(256, 1) payne_dense_bf16x3_kernel(Bx3Params q)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
       }
     }
-    if (it + 1 < nk) store_tiles(buf ^ 1, (it + 1) * BX_BK);
+    if (it + 1 < nk && !(q.dbg & 4)) store_tiles(buf ^ 1, (it + 1) * BX_BK);
     __syncthreads();
+  }
+  if (q.dbg & 1) {   // keep the accumulators alive, store one value per wave
+    float sacc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc += acc[j][e];
+    if (sacc == 12345.678f) p.Y[0] = sacc;
+    return;
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
@@ -787,6 +798,34 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
 #ifdef PAYNE_STAMPS
   if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
 #endif
+}
+
+
+// Spectra that do not fit LDS (n1 > 16384, e.g. the 65k-pixel R~100k grid): the same phase code
+// with the two spectrum buffers in a per-workgroup global workspace (L2 / Infinity-Cache resident
+// while it is being worked on) and the runtime-geometry FFT.  Workgroups are persistent and walk
+// the batch with stride gridDim.x, so the workspace is sized by the grid, not by the batch.  All
+// waves of a workgroup share one CU's L1, so __syncthreads() orders the global accesses between
+// phases exactly as it orders LDS.  This is the HBM/L2-bandwidth-bound regime of SURVEY.md 8(d).
+constexpr int kBigThreads = 512;
+__global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B) {
+  __shared__ double red[kBigThreads + kBigThreads / 2 + 2];
+  __shared__ CandState S;
+  float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
+  float* bufB = bufA + T.n1;
+  DevExec ex;
+  double* chi2 = red + scratch_doubles(kBigThreads) - 1;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    run_candidate<0, kBigThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+                                  a.raw + (size_t)b * a.ld_raw, bufA, bufB, S, red,
+                                  a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2);
+    if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
+      double x2 = *chi2;
+      if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+      a.lnl[b] = -0.5 * x2;
+    }
+    __syncthreads();
+  }
 }
 
 typedef void (*post_kernel_fn)(const PostTables, PostArgs);
@@ -913,8 +952,10 @@ struct payne_ctx {
   int wp_Kp = 0, wp_Npad = 0;
   size_t post_lds = 0;
   bool post_tw_lds = false;
-  PostTables* d_T = nullptr;          // device copy of T (kernel argument)
+  PostTables* d_T = nullptr;          // device copy of T
   post_kernel_fn post_fn = nullptr;
+  float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
+  int big_grid = 0;
   bool obs_bound = false;
   // photometry
   bool has_phot = false, has_obs_phot = false;
@@ -1116,7 +1157,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     rc = build_model_tables(model->wavelength, model->npix, c->H);
     if (rc == -1) return bail(fail(c, PAYNE_E_INVALID, "model.npix must be >= 16"));
     if (rc == -2) return bail(fail(c, PAYNE_E_INVALID, "model.wavelength must be strictly increasing"));
-    if (c->H.n1 > 16384) return bail(fail(c, PAYNE_E_UNSUPPORTED, "npix > 16384: spectrum does not fit the LDS-resident pipeline"));
+    if (c->H.n1 > (1 << 20)) return bail(fail(c, PAYNE_E_UNSUPPORTED, "npix > 2^20"));
     PostTables& T = c->T;
     fill_model_scalars(c->H, T);
     T.r_ann = model->resolution; T.npoly = opts->npoly;
@@ -1136,7 +1177,11 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
-    c->post_lds = (size_t)T.n1 * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
+    if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
+      c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
+      if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
+    }
+    c->post_lds = (size_t)(T.n1 > 16384 ? 64 : T.n1) * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
     // twiddles in LDS while two workgroups still fit a CU (160 KiB); larger spectra read them from L2
     const size_t tw_bytes = c->H.twf.size() * sizeof(c32);         // ~0.75 n1 entries
     c->post_tw_lds = (c->post_lds + tw_bytes) <= 80 * 1024;
@@ -1248,7 +1293,9 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
 static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
   p.grid_m = (p.B + BX_BM - 1) / BX_BM;
   p.grid_n = (p.N + BX_BN - 1) / BX_BN;
-  Bx3Params q{p, c->w_planes, c->wp_Kp, c->wp_Npad};
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("PAYNE_BX_DBG"); dbg = e ? atoi(e) : 0; }
+  Bx3Params q{p, c->w_planes, c->wp_Kp, c->wp_Npad, dbg};
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BX_LDS_BYTES);
@@ -1358,7 +1405,12 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   if (skip_mask() & 4) return PAYNE_OK;
   {
     ProfScope ps(c, s, 1);
-    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+    if (c->big_ws) {
+      const int grid = B < c->big_grid ? B : c->big_grid;
+      hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, s, c->T, a, c->big_ws, B);
+    } else {
+      hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("post launch: ") + hipGetErrorString(e));

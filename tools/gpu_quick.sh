@@ -2,7 +2,6 @@
 # quick GPU check: parity tests + bench variants (env knobs)
 TAG=${1:-q}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-python -m pytest tests -m gpu -q -x > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_$TAG.log
 b() { name=$1; shift; env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_${TAG}_$name.log 2>&1
 python - <<PY
 import json
@@ -12,7 +11,5 @@ try:
 except Exception as e: print("$name failed", e, open("$OUT/bench_${TAG}_$name.log").read()[-800:])
 PY
 }
+python -m pytest tests -m gpu -q > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_$TAG.log
 b base A=1
-PAYNE_OUT_TILE=7 python -m pytest tests -m gpu -q -x > $OUT/pytest_${TAG}_bf.log 2>&1; echo "pytest bf16x3 rc=$?"; tail -5 $OUT/pytest_${TAG}_bf.log
-b bf16x3 PAYNE_OUT_TILE=7
-b bf16x3_only PAYNE_OUT_TILE=7 PAYNE_SKIP=5
