@@ -95,6 +95,23 @@ def cpu_baseline(cfg_name, budget_s=10.0, max_procs=32):
                        % (cfg_name, cores, budget_s, sum(r[0] for r in res), wall))
 
 
+def pmc_traffic(kind):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of the same command
+    (profiles/r1_c2_rocprofv3_pmc_hbm.csv; FETCH_SIZE and WRITE_SIZE in separate runs, KB).  FETCH_SIZE
+    is doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads on gfx950."""
+    path = os.path.join(ROOT, "profiles", "r1_c2_rocprofv3_pmc_hbm.csv")
+    key = {"dense_out": "payne_dense_kernel", "post": "payne_post_kernel"}[kind]
+    try:
+        import csv
+        tot = {}
+        for r in csv.DictReader(open(path)):
+            if key in r["kernel"]:
+                tot[r["counter"]] = float(r["mean_value_per_launch_KB_raw"])
+        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 # ----------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -212,7 +229,8 @@ def main():
     D, H, N = net["layers"][0][0].shape[1], net["layers"][0][0].shape[0], cfg["npix"]
     evals = world * B * args.steps
     out = {
-        "metric": "likelihood-evals/sec (4k-pixel ANN, 512 live points)",
+        "metric": "likelihood-evals/sec (4k-pixel ANN, 512 live points)" if args.config == "C2" else
+                  "likelihood-evals/sec (%s)" % args.config,
         "value": evals / dt, "unit": "likelihood-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
@@ -226,13 +244,31 @@ def main():
     }
     if kern is not None:
         per = {k: (1e3 * v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}      # us per launch
-        # dominant kernel decides the roofline line
-        flops = {"dense_out": 2.0 * B * H * N, "post": B * (2 * 2 * 2.5 * N * np.log2(N) + 60.0 * N)}
+        n1 = 1 << int(np.ceil(np.log2(N)))
         dom = max(("dense_out", "post"), key=lambda k: per[k])
-        ach = flops[dom] / (max(per[dom], 1e-9) * 1e-6) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "payne_dense_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
-                           "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                           "traffic": None, "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
+        if n1 > 16384 and dom == "post":
+            # spectra larger than LDS stream through a global workspace: HBM/L2-bound.
+            # Algorithmic bytes per candidate: raw row in, 2 conv stages x (2 FFTs x log8(N/2) passes + taper)
+            # x (read + write) of 4N, mask scan 8N, resample 8N, observed arrays 16 Nobs.
+            npass = int(np.ceil(np.log2(n1 / 2) / 3.0))
+            bytes_eval = 4.0 * n1 * (1 + 2 * (2 * npass + 1) * 2 + 2) + 8.0 * N + 16.0 * cfg["nobs"]
+            ach = bytes_eval * B / (max(per[dom], 1e-9) * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                               "alg_bytes_per_launch": bytes_eval * B, "avg_us_per_launch": per[dom]}
+        else:
+            # dominant kernel decides the roofline line; both are FLOP-bound at C2 (AI ~ 300 FLOP/B)
+            flops = {"dense_out": 2.0 * B * H * N, "post": B * (2 * 2 * 2.5 * N * np.log2(N) + 60.0 * N)}
+            ach = flops[dom] / (max(per[dom], 1e-9) * 1e-6) / 1e12
+            out["roofline"] = {"bound": "mfma",
+                               "kernel": "payne_dense_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
+                               "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                               "traffic": pmc_traffic(dom) if args.config == "C2" else None,
+                               "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
+            out["mfma_kernel"] = {"kernel": "payne_dense_kernel (output layer)", "alg_flops_per_launch": flops["dense_out"],
+                                  "avg_us_per_launch": per["dense_out"],
+                                  "achieved_tflops": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12,
+                                  "frac_of_fp32_peak": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12 / PEAK_FP32_TFLOPS}
         out["kernels_us"] = per
         out["alg_flops_per_eval"] = alg_flops_per_eval(D, H, N)
         out["whole_path_tflops"] = alg_flops_per_eval(D, H, N) * B / (max(sum(per.values()), 1e-9) * 1e-6) / 1e12

@@ -11,5 +11,5 @@ try:
 except Exception as e: print("$name failed", e, open("$OUT/bench_${TAG}_$name.log").read()[-800:])
 PY
 }
-python -m pytest tests -m gpu -q > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_$TAG.log
-b base A=1
+python bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_${TAG}_C5.log 2>&1; tail -1 $OUT/bench_${TAG}_C5.log | cut -c1-1500
+python bench.py --config C5 --batch 512 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_${TAG}_C5b512.log 2>&1; tail -1 $OUT/bench_${TAG}_C5b512.log | cut -c1-400
