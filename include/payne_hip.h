@@ -158,6 +158,60 @@ int payne_sed_batch(payne_ctx* ctx, const double* pars, int B, double* mags, voi
  * av, rv; bc: device fp64 [B][F]. */
 int payne_bc_batch(payne_ctx* ctx, const double* x, int B, double* bc, void* stream);
 
+/* ---- device-side sampler step ------------------------------------
+ * The reference evaluates prior.priortrans(u) and lnprobfn(v) one vector at a time on the host
+ * (Payne/fitting/prior.py:126-272, Payne/fitting/fitstar.py:647-659; 334 us per priortrans call).
+ * A batched sampler would be host-bound by that, so the unit-cube -> parameter transform, the
+ * additive ln-priors, the assembly of theta rows and the random-walk proposal loop run on the
+ * GPU; the host only launches and reads back the survivors. */
+#define PAYNE_MAX_DIM 24
+#define PAYNE_MAX_FIXED 16
+#define PAYNE_PRIOR_UNIFORM 0    /* p = lo, hi                 (max-min)*u+min          prior.py:153-157 */
+#define PAYNE_PRIOR_GAUSSIAN 1   /* p = mu, sigma              norm.ppf                 prior.py:158-159 */
+#define PAYNE_PRIOR_TGAUSSIAN 2  /* p = lo, hi, mu, sigma      truncnorm.ppf, inf -> hi prior.py:161-166 */
+#define PAYNE_PRIOR_EXP 3        /* p = loc, scale             expon.ppf                prior.py:167-168 */
+#define PAYNE_PRIOR_TEXP 4       /* p = lo, hi, scale          truncexpon.ppf, inf -> hi prior.py:169-174 */
+#define PAYNE_PRIOR_LOGUNIFORM 5 /* p = lo, hi */
+
+typedef struct payne_prior_dim {
+  int kind;      /* PAYNE_PRIOR_* */
+  int theta_col; /* column of the theta row this sampled dimension fills (payne_theta_cols layout) */
+  double p[4];
+  int has_gauss; /* additive ln-prior -0.5((v-mu)/sigma)^2      prior.py:388-390 */
+  int has_box;   /* -inf outside [box_lo, box_hi]               prior.py:391-394 */
+  double g_mu, g_sigma, box_lo, box_hi;
+} payne_prior_dim;
+
+typedef struct payne_sampler_desc {
+  int ndim; /* <= PAYNE_MAX_DIM */
+  payne_prior_dim dims[PAYNE_MAX_DIM];
+  int n_fixed; /* 'fixed' parameters merged into every theta row (likelihood.py:47-48) */
+  int fixed_col[PAYNE_MAX_FIXED];
+  double fixed_val[PAYNE_MAX_FIXED];
+} payne_sampler_desc;
+
+typedef struct payne_sampler payne_sampler;
+
+int payne_sampler_create(payne_ctx* ctx, const payne_sampler_desc* desc, int k_max, payne_sampler** out);
+void payne_sampler_destroy(payne_sampler* s);
+
+/* v = priortrans(u) for K unit-cube vectors.  u, v: device fp64 [K][ndim]. */
+int payne_prior_transform_batch(payne_sampler* s, const double* u, int K, double* v, void* stream);
+
+/* v = priortrans(u); lnprob = lnprior(v) + lnlike(v)  (lnprobfn over a batch).
+ * u, v: device fp64 [K][ndim]; lnprob: device fp64 [K]. */
+int payne_lnprob_u_batch(payne_sampler* s, const double* u, int K, double* v, double* lnprob, void* stream);
+
+/* `walks` Metropolis steps for K lock-step chains under the constraint lnprob > loglstar
+ * (the 'rwalk' proposal of the nested sampler): u' = u + scale * (axes . z), z uniform in the
+ * unit ball; a step is accepted iff u' is inside the unit cube and lnprob(u') > loglstar.
+ * u, v: device fp64 [K][ndim] in/out (chain positions); lnprob: device fp64 [K] in/out;
+ * axes: HOST fp64 [ndim][ndim] row-major; nacc, ncall: device int32 [K] (accepted steps,
+ * likelihood calls) overwritten.  One small kernel + one payne_lnlike_batch per step. */
+int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
+                      double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
+                      void* stream);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

@@ -1,0 +1,202 @@
+"""Device-side sampler step (payne_sampler_* in include/payne_hip.h): prior transform, ln-prior
+and random-walk proposals on the GPU, against the golden vectors frozen from the reference's
+``prior`` class (tests/golden/g6_prior.npz), the oracle likelihood and the host sampler path."""
+
+import numpy as np
+import pytest
+
+import oracle as O
+from thepayne_amd import synth
+from helpers import SPEC_PARS, lnl_tol
+from test_api_gpu import _fit_objects, _save_yst, ALL_PARS
+from test_host_logic import KINDS
+
+pytestmark = pytest.mark.gpu
+
+
+def _proposer(L, P, k_max=64):
+    from thepayne_amd.sampler.device import DeviceProposer
+    return DeviceProposer(L, P, k_max=k_max)
+
+
+@pytest.mark.parametrize("photscale", [True, False])
+def test_device_prior_transform_every_kind(tmp_path, golden, photscale):
+    """Every pv_* kind of Payne/fitting/prior.py:151-178 / :236-270 on the device, one fit per kind with
+    that kind applied to every parameter the golden file holds for it."""
+    g = golden("g6_prior")
+    u = g["u"]
+    L, P0, _ = _fit_objects(tmp_path, photscale=photscale)
+    names = L.fitpars_i
+    checked = 0
+    for kname, spec in KINDS.items():
+        cols = {}
+        pd = {}
+        for j, par in enumerate(names):
+            which = "phot" if par in ('log(A)', 'log(R)', 'Av', 'Dist', 'Rv') else "spec"
+            key = "%s_%s_%s" % (which, par, kname)
+            if key in g.files:
+                cols[j] = key
+                if spec is not None:
+                    pd[par] = dict(spec)
+        if not cols:
+            continue
+        Pk = _clone_prior(P0, pd)
+        prop = _proposer(L, Pk)
+        U = np.repeat(u[:, None], len(names), axis=1)
+        inner = (u > 0) & (u < 1)
+        with np.errstate(all="ignore"):
+            V = prop.prior_transform(U)
+            host = Pk.priortrans_batch(U)
+        for j, key in cols.items():
+            np.testing.assert_allclose(V[inner, j], g[key][inner], rtol=1e-9, atol=1e-9, err_msg=key)
+            checked += 1
+        # every column agrees with the host transform, golden or not
+        np.testing.assert_allclose(V[inner], host[inner], rtol=1e-9, atol=1e-9)
+        prop.close()
+    assert checked >= 25
+
+
+def _clone_prior(P0, pd):
+    """A prior object for the same fit as P0 with priordict `pd`."""
+    from thepayne_amd.fitting.prior import prior
+    names = list(ALL_PARS) + [p for p in P0.fitpars_i if p.startswith('pc_')]
+    return prior({'fixedpars': dict(P0.fixedpars)}, pd, [names, {p: p in P0.fitpars_i for p in names}],
+                 [P0.spec_bool, P0.phot_bool, P0.modpoly_bool, P0.photscale_bool, False])
+
+
+def test_device_blaze_and_additional_priors(tmp_path):
+    """Blaze-coefficient boxes (prior.py:180-191) and the additive gaussian/uniform ln-priors
+    (prior.py:379-465): device vs the host prior class, which test_host_logic pins to the golden file."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    L, P0, OL = _fit_objects(tmp_path, photscale=True, modpoly=True)
+    pd = synth.demo_priordict()
+    pd['log(A)'] = {'pv_uniform': [-1.0, 1.0]}
+    pd['Av'] = {'pv_uniform': [0.0, 2.0], 'gaussian': [0.4, 0.3], 'uniform': [0.05, 1.7]}
+    # (no additive prior on a spectroscopic label here: the reference raises KeyError for one in a joint fit,
+    #  see gen_golden.g6_prior)
+    pd['blaze_coeff'] = [[0.0, 0.05], [0.0, 0.02], [0.0, 0.01]]
+    P = _clone_prior(P0, pd)
+    prop = _proposer(L, P)
+    U = np.random.default_rng(8).uniform(size=(48, L.ndim))
+    V, lp = prop.lnprob_u(U)
+    theta = P.priortrans_batch(U)
+    np.testing.assert_allclose(V, theta, rtol=1e-11, atol=1e-11)
+    lnp = P.lnprior_batch(theta)
+    assert np.isinf(lnp).any() and np.isfinite(lnp).any()
+    ref = np.array([OL.lnlikefn(t) for t in theta]) + lnp
+    assert np.array_equal(np.isinf(lp), np.isinf(ref))
+    ok = np.isfinite(ref)
+    assert np.all(np.abs(lp[ok] - ref[ok]) <= lnl_tol(ref[ok]))
+    host = lnprob_batch(theta, L, P)
+    assert np.all(np.abs(lp[ok] - host[ok]) <= 1e-9 * np.abs(host[ok]) + 1e-9)     # same kernels, same rows
+    prop.close()
+
+
+def test_device_fixed_parameters(tmp_path):
+    from thepayne_amd.fitting.likelihood import likelihood
+    from thepayne_amd.fitting.prior import prior
+    from helpers import yst_problem
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    on = [p for p in SPEC_PARS if p not in ('[a/Fe]', 'Vrot')]
+    fitpars = [list(ALL_PARS), {p: p in on for p in ALL_PARS}]
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+               'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1', 'fixedpars': {'[a/Fe]': 0.03, 'Vrot': 2.5}}
+    rb = [True, False, False, False, False]
+    L = likelihood(fitargs, fitpars, rb, b_max=16)
+    P = prior(fitargs, synth.demo_priordict(), fitpars, rb)
+    OL = O.OracleLikelihood(raw, obs, flux, eflux, on, fixedpars=fitargs['fixedpars'])
+    prop = _proposer(L, P, k_max=16)
+    U = np.random.default_rng(2).uniform(size=(40, L.ndim))     # > k_max: chunked
+    V, lp = prop.lnprob_u(U)
+    np.testing.assert_allclose(V, P.priortrans_batch(U), rtol=1e-11)
+    ref = np.array([OL.lnlikefn(t) for t in V])
+    assert np.all(np.abs(lp - ref) <= lnl_tol(ref))
+    prop.close()
+
+
+def test_device_rwalk_invariants(tmp_path):
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    L, P, OL = _fit_objects(tmp_path, photscale=True)
+    prop = _proposer(L, P)
+    rng = np.random.default_rng(5)
+    K, nd = 64, L.ndim
+    U0 = rng.uniform(0.3, 0.7, size=(K, nd))
+    V0, lp0 = prop.lnprob_u(U0)
+    lp0 = np.where(np.isnan(lp0), -np.inf, lp0)
+    lstar = float(np.median(lp0[np.isfinite(lp0)]))
+    axes = 0.05 * np.eye(nd)
+    walks = 12
+    U, V, lp, nacc, ncall = prop.rwalk(U0, V0, lp0, axes, 1.0, lstar, walks, seed=1234)
+    assert np.all((U > 0) & (U < 1))
+    assert np.all(ncall <= walks) and np.all(nacc <= ncall) and ncall.sum() > 0 and nacc.sum() > 0
+    moved = nacc > 0
+    assert np.all(lp[moved] > lstar)                                   # accepted points beat the threshold
+    assert np.array_equal(U[~moved], U0[~moved]) and np.array_equal(lp[~moved], lp0[~moved])
+    assert np.all(np.abs(U - U0).max(axis=1) <= walks * 0.05 + 1e-12)  # each step stays inside the scaled ball
+    np.testing.assert_allclose(V, P.priortrans_batch(U), rtol=1e-11, atol=1e-11)
+    host = lnprob_batch(V, L, P)
+    assert np.all(np.abs(lp[moved] - host[moved]) <= 1e-9 * np.abs(host[moved]) + 1e-9)
+    ref = np.array([OL.lnlikefn(t) for t in V[moved][:16]]) + P.lnprior_batch(V[moved][:16])
+    assert np.all(np.abs(lp[moved][:16] - ref) <= lnl_tol(ref))
+    # same seed -> same chains; another seed -> other chains
+    again = prop.rwalk(U0, V0, lp0, axes, 1.0, lstar, walks, seed=1234)
+    assert np.array_equal(again[0], U) and np.array_equal(again[2], lp)
+    other = prop.rwalk(U0, V0, lp0, axes, 1.0, lstar, walks, seed=99)
+    assert not np.array_equal(other[0], U)
+    # proposals are uniform in the ball: with an impossible threshold nothing moves, every in-cube proposal counts
+    still = prop.rwalk(U0, V0, lp0, axes, 1.0, np.inf, walks, seed=7)
+    assert np.array_equal(still[0], U0) and still[3].sum() == 0 and np.all(still[4] == walks)
+    prop.close()
+
+
+def test_device_rwalk_step_distribution(tmp_path):
+    """One step with threshold -inf accepts every in-cube proposal: the displacement must be uniform in the
+    ellipsoid axes @ unit ball (mean 0, covariance axes axes^T / (n+2), |z| <= 1)."""
+    L, P, _ = _fit_objects(tmp_path, photscale=True)
+    prop = _proposer(L, P, k_max=64)
+    nd = L.ndim
+    rng = np.random.default_rng(11)
+    A = np.tril(rng.normal(size=(nd, nd))) * 0.01 + 0.02 * np.eye(nd)
+    D = []
+    for rep in range(40):
+        U0 = np.full((64, nd), 0.5)
+        V0, lp0 = prop.lnprob_u(U0) if rep == 0 else (V0, lp0)
+        U, V, lp, nacc, ncall = prop.rwalk(U0, V0, lp0, A, 1.0, -np.inf, 1, seed=1000 + rep)
+        fin = np.isfinite(lp) & (nacc == 1)
+        D.append((U - U0)[fin])
+    D = np.concatenate(D)
+    assert len(D) > 1500
+    Z = np.linalg.solve(A, D.T).T
+    r = np.linalg.norm(Z, axis=1)
+    assert r.max() <= 1.0 + 1e-9
+    assert np.abs(Z.mean(axis=0)).max() < 4.0 / np.sqrt(len(Z) * (nd + 2))
+    cov = Z.T @ Z / len(Z)
+    assert np.abs(cov - np.eye(nd) / (nd + 2)).max() < 0.02
+    assert abs((r ** nd).mean() - 0.5) < 0.04                              # r^n uniform on (0, 1)
+    prop.close()
+
+
+@pytest.mark.parametrize("device_proposals", [True, False])
+def test_fitpayne_with_and_without_device_proposals(tmp_path, device_proposals):
+    from thepayne_amd.fitting.fitstar import FitPayne
+    from helpers import yst_problem
+    raw, obs, flux, eflux = yst_problem("small", H=64, line_depth=0.3)
+    inputdict = {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1',
+        'sampler': {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': 128,
+                    'walks': 20, 'delta_logz_final': 0.5, 'bootstrap': 0, 'flushnum': 200, 'seed': 3,
+                    'device_proposals': device_proposals},
+        'priordict': synth.demo_priordict(),
+        'output': str(tmp_path / 'fit.dat'),
+    }
+    F = FitPayne()
+    sampler = F.run(inputdict=inputdict, verbose=False)
+    assert (F.proposer is not None) == device_proposals
+    r = sampler.results
+    w = sampler.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)

@@ -16,7 +16,12 @@ ABI_VERSION = 1
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_destroy", "payne_last_error",
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
-           "payne_profile", "payne_profile_read"]
+           "payne_profile", "payne_profile_read",
+           "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
+           "payne_rwalk_batch"]
+
+PAYNE_MAX_DIM, PAYNE_MAX_FIXED = 24, 16
+PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_TGAUSSIAN, PRIOR_EXP, PRIOR_TEXP, PRIOR_LOGUNIFORM = range(6)
 
 _dp = C.POINTER(C.c_double)
 
@@ -43,6 +48,17 @@ class PhotDesc(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("b_max", C.c_int), ("npoly", C.c_int), ("photscale", C.c_int)]
+
+
+class PriorDim(C.Structure):
+    _fields_ = [("kind", C.c_int), ("theta_col", C.c_int), ("p", C.c_double * 4),
+                ("has_gauss", C.c_int), ("has_box", C.c_int),
+                ("g_mu", C.c_double), ("g_sigma", C.c_double), ("box_lo", C.c_double), ("box_hi", C.c_double)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [("ndim", C.c_int), ("dims", PriorDim * 24), ("n_fixed", C.c_int),
+                ("fixed_col", C.c_int * 16), ("fixed_val", C.c_double * 16)]
 
 
 class PayneLibraryError(RuntimeError):
@@ -97,6 +113,17 @@ def load(path=None):
     lib.payne_profile.restype = C.c_int
     lib.payne_profile_read.argtypes = [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     lib.payne_profile_read.restype = C.c_int
+    lib.payne_sampler_create.argtypes = [ctxp, C.POINTER(SamplerDesc), C.c_int, C.POINTER(ctxp)]
+    lib.payne_sampler_create.restype = C.c_int
+    lib.payne_sampler_destroy.argtypes = [ctxp]
+    lib.payne_sampler_destroy.restype = None
+    lib.payne_prior_transform_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.payne_prior_transform_batch.restype = C.c_int
+    lib.payne_lnprob_u_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.payne_lnprob_u_batch.restype = C.c_int
+    lib.payne_rwalk_batch.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double,
+                                      C.c_double, C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.payne_rwalk_batch.restype = C.c_int
     lib.payne_kernel_name.argtypes = [C.c_int]
     lib.payne_kernel_name.restype = C.c_char_p
     if lib.payne_version() != ABI_VERSION:

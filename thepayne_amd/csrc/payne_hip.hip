@@ -1454,6 +1454,268 @@ extern "C" int payne_sed_batch(payne_ctx* c, const double* pars, int B, double* 
   return run_sed(c, pars, 9, 0, B, mags, reinterpret_cast<hipStream_t>(stream));
 }
 
+
+// ============================================================================
+// device-side sampler step: prior transform, ln-prior, theta rows, random-walk proposals
+// ============================================================================
+struct SamplerDev {
+  int ndim, ncols, nfixed;
+  payne_prior_dim dims[PAYNE_MAX_DIM];
+  int fixed_col[PAYNE_MAX_FIXED];
+  double fixed_val[PAYNE_MAX_FIXED];
+};
+
+// unit cube -> parameter (Payne/fitting/prior.py:151-178, scipy.stats ppf's restated)
+__device__ double prior_ppf(const payne_prior_dim& d, double u) {
+  switch (d.kind) {
+    case PAYNE_PRIOR_UNIFORM: {
+      const double lo = fmin(d.p[0], d.p[1]), hi = fmax(d.p[0], d.p[1]);
+      return (hi - lo) * u + lo;
+    }
+    case PAYNE_PRIOR_GAUSSIAN: return d.p[0] + d.p[1] * normcdfinv(u);
+    case PAYNE_PRIOR_TGAUSSIAN: {
+      const double a = (d.p[0] - d.p[2]) / d.p[3], b = (d.p[1] - d.p[2]) / d.p[3];
+      double x;
+      if (a > 0.0) {                    // both limits in the upper tail: work with survival functions
+        const double sa = normcdf(-a), sb = normcdf(-b);
+        x = -normcdfinv(sa - u * (sa - sb));
+      } else {
+        const double ca = normcdf(a), cb = normcdf(b);
+        x = normcdfinv(ca + u * (cb - ca));
+      }
+      double v = d.p[2] + d.p[3] * x;
+      if (!(v <= d.p[1])) v = (v != v) ? v : d.p[1];           // +inf (u = 1) -> hi, prior.py:165-166
+      return v;
+    }
+    case PAYNE_PRIOR_EXP: return d.p[0] - d.p[1] * log1p(-u);
+    case PAYNE_PRIOR_TEXP: {
+      const double b = (d.p[1] - d.p[0]) / d.p[2];
+      double v = d.p[0] - d.p[2] * log1p(u * expm1(-b));        // truncexpon.ppf
+      if (!(v <= d.p[1])) v = (v != v) ? v : d.p[1];
+      return v;
+    }
+    case PAYNE_PRIOR_LOGUNIFORM: return exp(log(d.p[0]) + u * (log(d.p[1]) - log(d.p[0])));
+    default: return u;
+  }
+}
+__device__ double prior_ln(const payne_prior_dim& d, double v) {
+  double lp = 0.0;
+  if (d.has_gauss) { const double z = v - d.g_mu; lp += -0.5 * ((z * z) / (d.g_sigma * d.g_sigma)); }
+  if (d.has_box && ((v < d.box_lo) || (v > d.box_hi))) lp = -INFINITY;
+  return lp;
+}
+// one theta row: NaN = absent, fixed values, then the sampled dimensions
+__device__ void write_theta_row(const SamplerDev& sd, const double* v, double* row) {
+  for (int c = 0; c < sd.ncols; ++c) row[c] = __builtin_nan("");
+  for (int i = 0; i < sd.nfixed; ++i) row[sd.fixed_col[i]] = sd.fixed_val[i];
+  for (int d = 0; d < sd.ndim; ++d) if (sd.dims[d].theta_col >= 0) row[sd.dims[d].theta_col] = v[d];
+}
+
+// counter-based generator: splitmix64 of (seed, chain, step, draw)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ double u01(unsigned long long seed, unsigned chain, unsigned step, unsigned draw) {
+  const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)chain << 32 | step)) + draw);
+  return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);      // (0,1)
+}
+
+// transform only (mode 0) or transform + ln-prior + theta row (mode 1)
+__global__ void payne_prior_kernel(SamplerDev sd, const double* u, int K, double* v, double* lnprior, double* rows, int mode) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K) return;
+  double vv[PAYNE_MAX_DIM];
+  double lp = 0.0;
+  for (int d = 0; d < sd.ndim; ++d) {
+    vv[d] = prior_ppf(sd.dims[d], u[(size_t)c * sd.ndim + d]);
+    v[(size_t)c * sd.ndim + d] = vv[d];
+    lp += prior_ln(sd.dims[d], vv[d]);
+  }
+  if (mode) { lnprior[c] = lp; write_theta_row(sd, vv, rows + (size_t)c * sd.ncols); }
+}
+// lnprob = lnprior + lnlike (-inf prior wins; NaN likelihood stays NaN)
+__global__ void payne_lnprob_kernel(const double* lnprior, const double* lnl, int K, double* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < K) out[c] = (lnprior[c] == -INFINITY) ? -INFINITY : lnprior[c] + lnl[c];
+}
+
+// One random-walk step for every chain: first settle the previous proposal (accept iff inside the
+// cube and lnprob > loglstar), then draw the next one.  `propose` = 0 on the closing call.
+__global__ void payne_rwalk_kernel(SamplerDev sd, int K, double* u, double* v, double* lnprob, int* nacc, int* ncall,
+                                   double* u_prop, double* v_prop, double* lnprior_prop, int* inside,
+                                   const double* lnl_prop, double* rows, const double* axes, double scale,
+                                   double loglstar, unsigned long long seed, int step, int settle, int propose) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K) return;
+  const int nd = sd.ndim;
+  double uc[PAYNE_MAX_DIM];
+  for (int d = 0; d < nd; ++d) uc[d] = u[(size_t)c * nd + d];
+  if (settle) {
+    if (inside[c]) {
+      ncall[c] += 1;
+      const double lp = (lnprior_prop[c] == -INFINITY) ? -INFINITY : lnprior_prop[c] + lnl_prop[c];
+      if (lp > loglstar) {                                    // false for NaN
+        for (int d = 0; d < nd; ++d) {
+          uc[d] = u_prop[(size_t)c * nd + d];
+          u[(size_t)c * nd + d] = uc[d];
+          v[(size_t)c * nd + d] = v_prop[(size_t)c * nd + d];
+        }
+        lnprob[c] = lp;
+        nacc[c] += 1;
+      }
+    }
+  }
+  if (!propose) return;
+  // z uniform in the unit ball: normal direction (Box-Muller), radius U^(1/n)
+  double z[PAYNE_MAX_DIM];
+  double n2 = 0.0;
+  for (int d = 0; d < nd; d += 2) {
+    const double a = u01(seed, c, step, d), b = u01(seed, c, step, d + 1);
+    const double rr = sqrt(-2.0 * log(a));
+    double sn, cs;
+    sincos(6.283185307179586 * b, &sn, &cs);
+    z[d] = rr * cs; n2 += z[d] * z[d];
+    if (d + 1 < nd) { z[d + 1] = rr * sn; n2 += z[d + 1] * z[d + 1]; }
+  }
+  const double rad = pow(u01(seed, c, step, 64), 1.0 / (double)nd) / sqrt(n2);
+  bool in = true;
+  double up[PAYNE_MAX_DIM], vp[PAYNE_MAX_DIM];
+  double lp = 0.0;
+  for (int d = 0; d < nd; ++d) {
+    double s = 0.0;
+    for (int e = 0; e < nd; ++e) s += axes[d * nd + e] * z[e];
+    up[d] = uc[d] + scale * rad * s;
+    in = in && (up[d] > 0.0) && (up[d] < 1.0);
+  }
+  for (int d = 0; d < nd; ++d) {
+    vp[d] = in ? prior_ppf(sd.dims[d], up[d]) : v[(size_t)c * nd + d];   // outside: a harmless valid row
+    lp += prior_ln(sd.dims[d], vp[d]);
+    u_prop[(size_t)c * nd + d] = up[d];
+    v_prop[(size_t)c * nd + d] = vp[d];
+  }
+  inside[c] = in ? 1 : 0;
+  lnprior_prop[c] = lp;
+  write_theta_row(sd, vp, rows + (size_t)c * sd.ncols);
+}
+
+struct payne_sampler {
+  payne_ctx* ctx = nullptr;
+  SamplerDev sd{};
+  int k_max = 0;
+  double *u_prop = nullptr, *v_prop = nullptr, *lnprior = nullptr, *lnl = nullptr, *rows = nullptr, *axes = nullptr;
+  int* inside = nullptr;
+  std::vector<void*> owned;
+};
+
+extern "C" void payne_sampler_destroy(payne_sampler* s) {
+  if (!s) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(s->ctx->device);
+  for (void* p : s->owned) (void)hipFree(p);
+  (void)hipSetDevice(prev);
+  delete s;
+}
+
+extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, int k_max, payne_sampler** out) {
+  if (!c || !out) return PAYNE_E_INVALID;
+  *out = nullptr;
+  if (!d || d->ndim <= 0 || d->ndim > PAYNE_MAX_DIM) return fail(c, PAYNE_E_INVALID, "sampler.ndim out of range");
+  if (d->n_fixed < 0 || d->n_fixed > PAYNE_MAX_FIXED) return fail(c, PAYNE_E_INVALID, "sampler.n_fixed out of range");
+  if (k_max <= 0 || k_max > c->opts.b_max) return fail(c, PAYNE_E_INVALID, "sampler.k_max must be in 1..opts.b_max");
+  for (int i = 0; i < d->ndim; ++i)
+    if (d->dims[i].theta_col >= c->ncols || d->dims[i].kind < 0 || d->dims[i].kind > PAYNE_PRIOR_LOGUNIFORM)
+      return fail(c, PAYNE_E_INVALID, "sampler dimension with bad theta_col / kind");
+  for (int i = 0; i < d->n_fixed; ++i)
+    if (d->fixed_col[i] < 0 || d->fixed_col[i] >= c->ncols) return fail(c, PAYNE_E_INVALID, "fixed parameter with bad column");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != c->device) (void)hipSetDevice(c->device);
+  payne_sampler* s = new payne_sampler();
+  s->ctx = c; s->k_max = k_max;
+  s->sd.ndim = d->ndim; s->sd.ncols = c->ncols; s->sd.nfixed = d->n_fixed;
+  for (int i = 0; i < d->ndim; ++i) s->sd.dims[i] = d->dims[i];
+  for (int i = 0; i < d->n_fixed; ++i) { s->sd.fixed_col[i] = d->fixed_col[i]; s->sd.fixed_val[i] = d->fixed_val[i]; }
+  auto alloc = [&](size_t bytes, void** p) -> int {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("hipMalloc(sampler): ") + hipGetErrorString(e));
+    s->owned.push_back(*p);
+    return PAYNE_OK;
+  };
+  const size_t K = (size_t)k_max, nd = (size_t)d->ndim;
+  int rc;
+  if ((rc = alloc(K * nd * 8, (void**)&s->u_prop)) || (rc = alloc(K * nd * 8, (void**)&s->v_prop)) ||
+      (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
+      (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc(nd * nd * 8, (void**)&s->axes)) ||
+      (rc = alloc(K * 4, (void**)&s->inside))) {
+    payne_sampler_destroy(s);
+    return rc;
+  }
+  (void)hipMemset(s->inside, 0, K * 4);
+  *out = s;
+  return PAYNE_OK;
+}
+
+static int sampler_check(payne_sampler* s, const void* a, int K, const void* b) {
+  if (!s) return PAYNE_E_INVALID;
+  payne_ctx* c = s->ctx;
+  if (!a || !b) return fail(c, PAYNE_E_INVALID, "NULL input/output pointer");
+  if (K <= 0 || K > s->k_max) return fail(c, PAYNE_E_BATCH, "K exceeds the sampler's k_max");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != c->device) (void)hipSetDevice(c->device);
+  return PAYNE_OK;
+}
+
+extern "C" int payne_prior_transform_batch(payne_sampler* s, const double* u, int K, double* v, void* stream) {
+  int rc = sampler_check(s, u, K, v);
+  if (rc) return rc;
+  hipLaunchKernelGGL(payne_prior_kernel, dim3((K + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), s->sd, u, K,
+                     v, (double*)nullptr, (double*)nullptr, 0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s->ctx, PAYNE_E_HIP, std::string("prior launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+extern "C" int payne_lnprob_u_batch(payne_sampler* s, const double* u, int K, double* v, double* lnprob, void* stream) {
+  int rc = sampler_check(s, u, K, v);
+  if (rc) return rc;
+  if (!lnprob) return fail(s->ctx, PAYNE_E_INVALID, "lnprob is NULL");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(payne_prior_kernel, dim3((K + 127) / 128), dim3(128), 0, st, s->sd, u, K, v, s->lnprior, s->rows, 1);
+  if ((rc = payne_lnlike_batch(s->ctx, s->rows, K, s->lnl, stream))) return rc;
+  hipLaunchKernelGGL(payne_lnprob_kernel, dim3((K + 127) / 128), dim3(128), 0, st, s->lnprior, s->lnl, K, lnprob);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s->ctx, PAYNE_E_HIP, std::string("lnprob launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+extern "C" int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
+                                 double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
+                                 void* stream) {
+  int rc = sampler_check(s, u, K, v);
+  if (rc) return rc;
+  if (!lnprob || !axes || !nacc || !ncall || walks <= 0) return fail(s->ctx, PAYNE_E_INVALID, "bad rwalk arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nd = s->sd.ndim;
+  HIPCHK(s->ctx, hipMemcpyAsync(s->axes, axes, (size_t)nd * nd * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(s->ctx, hipMemsetAsync(nacc, 0, (size_t)K * 4, st));
+  HIPCHK(s->ctx, hipMemsetAsync(ncall, 0, (size_t)K * 4, st));
+  const dim3 grid((K + 63) / 64), block(64);
+  for (int w = 0; w <= walks; ++w) {
+    hipLaunchKernelGGL(payne_rwalk_kernel, grid, block, 0, st, s->sd, K, u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop,
+                       s->lnprior, s->inside, s->lnl, s->rows, s->axes, scale, loglstar, seed, w, w > 0 ? 1 : 0,
+                       w < walks ? 1 : 0);
+    if (w < walks && (rc = payne_lnlike_batch(s->ctx, s->rows, K, s->lnl, stream))) return rc;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(s->ctx, PAYNE_E_HIP, std::string("rwalk launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
 extern "C" int payne_bc_batch(payne_ctx* c, const double* x, int B, double* bc, void* stream) {
   int rc = check_call(c, x, B, bc);
   if (rc) return rc;

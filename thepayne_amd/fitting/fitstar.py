@@ -192,8 +192,19 @@ class FitPayne(object):
                       samplemethod, numwalks, npoints, self.ndim, delta_logz_final, starttime))
             print('Max Iter: {0} / Max Call: {1}'.format(maxiter, maxcall))
         sys.stdout.flush()
+        # prior transform, ln-prior and the random-walk proposals run on the GPU when the fit's priors
+        # can be expressed there (everything but derived-quantity priors); host path otherwise
+        proposer = None
+        if samplerdict.get('device_proposals', True):
+            try:
+                from ..sampler.device import DeviceProposer
+                proposer = DeviceProposer(self.likeobj, self.priorobj,
+                                          k_max=max(npoints, int(samplerdict.get('queue_size', npoints))))
+            except NotImplementedError:
+                proposer = None
+        self.proposer = proposer
         sampler = NestedSampler(
-            lnprob_batch, self.priorobj.priortrans_batch, self.ndim,
+            lnprob_batch, self.priorobj.priortrans_batch, self.ndim, proposer=proposer,
             logl_args=[self.likeobj, self.priorobj], nlive=npoints, bound=bound, sample=samplemethod,
             bootstrap=samplerdict.get('bootstrap', 0), walks=numwalks, slices=samplerdict.get('slices', 5),
             batched=True, queue_size=samplerdict.get('queue_size', npoints),

@@ -1,0 +1,162 @@
+"""Device-side sampler step: the prior transform, ln-priors and random-walk proposals of a fit
+evaluated on the GPU (payne_sampler_* in include/payne_hip.h), so that a batched nested
+sampler is not bound by 0.4 ms of scipy ppf calls and a host round trip per chain step.
+
+``DeviceProposer(likeobj, priorobj)`` translates the reference-shaped ``prior`` object
+(thepayne_amd.fitting.prior) into the C descriptor: the same per-name priority of prior kinds as
+``priortrans_spec`` / ``priortrans_phot`` (Payne/fitting/prior.py:151-178, :236-270), the blaze
+coefficient boxes (:180-191) and the additive 'gaussian' / 'uniform' priors (:379-465).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+
+_SPEC = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R', 'CarbonScale']
+_ATM = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]']
+_ISO = ['log(A)', 'log(R)', 'Av', 'Rv', 'Dist']
+_KIND = {'uniform': _lib.PRIOR_UNIFORM, 'gaussian': _lib.PRIOR_GAUSSIAN, 'tgaussian': _lib.PRIOR_TGAUSSIAN,
+         'exp': _lib.PRIOR_EXP, 'texp': _lib.PRIOR_TEXP, 'loguniform': _lib.PRIOR_LOGUNIFORM}
+
+
+class DeviceProposer(object):
+    def __init__(self, likeobj, priorobj, k_max=None):
+        self.like = likeobj
+        self.prior = priorobj
+        self.eng = likeobj.GM.engine
+        self.torch = self.eng.torch
+        self.lib = self.eng.lib
+        self.ndim = priorobj.ndim
+        self.k_max = int(k_max or self.eng.b_max)
+        if self.ndim > _lib.PAYNE_MAX_DIM:
+            raise ValueError("more than %d sampled dimensions" % _lib.PAYNE_MAX_DIM)
+        ncols, idx, fixed = likeobj._columns()
+        col_of = {likeobj.fitpars_i[j]: c for c, j in idx}
+        d = _lib.SamplerDesc()
+        d.ndim = self.ndim
+        for j, name in enumerate(priorobj.fitpars_i):
+            kind, p = self._kind(name)
+            dim = d.dims[j]
+            dim.kind = kind
+            dim.theta_col = col_of.get(name, -1)
+            for q, val in enumerate(p):
+                dim.p[q] = float(val)
+            add = self._additional(name)
+            if 'gaussian' in add:
+                dim.has_gauss, dim.g_mu, dim.g_sigma = 1, float(add['gaussian'][0]), float(add['gaussian'][1])
+            if 'uniform' in add:
+                dim.has_box, dim.box_lo, dim.box_hi = 1, float(add['uniform'][0]), float(add['uniform'][1])
+        if 'Parallax' in priorobj.additionalpriors:
+            raise NotImplementedError("a 'Parallax' prior is a derived quantity; use the host sampler path")
+        if len(fixed) > _lib.PAYNE_MAX_FIXED:
+            raise ValueError("too many fixed parameters")
+        d.n_fixed = len(fixed)
+        for q, (c, val) in enumerate(fixed):
+            d.fixed_col[q] = c
+            d.fixed_val[q] = val
+        self._handle = C.c_void_p()
+        rc = self.lib.payne_sampler_create(self.eng._ctx, C.byref(d), self.k_max, C.byref(self._handle))
+        if rc != 0:
+            self.eng._err(rc, "payne_sampler_create")
+        dev = self.eng.device
+        f64, i32 = self.torch.float64, self.torch.int32
+        self._u = self.torch.empty((self.k_max, self.ndim), dtype=f64, device=dev)
+        self._v = self.torch.empty((self.k_max, self.ndim), dtype=f64, device=dev)
+        self._lp = self.torch.empty(self.k_max, dtype=f64, device=dev)
+        self._nacc = self.torch.empty(self.k_max, dtype=i32, device=dev)
+        self._ncall = self.torch.empty(self.k_max, dtype=i32, device=dev)
+
+    # -- prior description -----------------------------------------------------------
+    def _kind(self, name):
+        P = self.prior
+        if 'pc' in name:                                            # prior.py:180-191
+            if name == 'pc_0':
+                return _lib.PRIOR_UNIFORM, (0.75, 1.25)
+            mu, sig = P.polycoefarr[int(name.split('_')[-1])][:2]
+            return _lib.PRIOR_UNIFORM, (mu - 5.0 * sig, mu + 5.0 * sig)
+        if name in _ISO and P.phot_bool and not (P.spec_bool and name in _SPEC):
+            order = ('uniform', 'gaussian', 'exp', 'tgaussian', 'texp', 'loguniform')
+        else:
+            order = ('uniform', 'gaussian', 'tgaussian', 'exp', 'texp')
+        for kind in order:
+            if name in P.priordict[kind]:
+                return _KIND[kind], tuple(P.priordict[kind][name])
+        lo, hi = P.defaultpars[name]
+        return _lib.PRIOR_UNIFORM, (lo, hi)
+
+    def _additional(self, name):
+        P = self.prior
+        add = P.additionalpriors.get(name, {})
+        add = {k: v for k, v in add.items() if k in ('gaussian', 'uniform')}
+        if not add:
+            return {}
+        in_spec = P.spec_bool and name in _SPEC
+        in_phot = P.phot_bool and (name in ('log(R)', 'Dist', 'log(A)', 'Av') or (not P.spec_bool and name in _ATM))
+        return add if (in_spec or in_phot) else {}
+
+    # -- calls -------------------------------------------------------------------------
+    def _stream(self):
+        return self.eng._stream()
+
+    def _up(self, a, dst):
+        t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64))
+        dst[:len(a)].copy_(t.reshape(dst[:len(a)].shape))
+        return len(a)
+
+    def prior_transform(self, U):
+        """U[K, ndim] -> V[K, ndim] (numpy)."""
+        out = []
+        U = np.atleast_2d(U)
+        for s in range(0, len(U), self.k_max):
+            K = self._up(U[s:s + self.k_max], self._u)
+            rc = self.lib.payne_prior_transform_batch(self._handle, self._u.data_ptr(), K, self._v.data_ptr(), self._stream())
+            if rc != 0:
+                self.eng._err(rc, "payne_prior_transform_batch")
+            out.append(self._v[:K].cpu().numpy())
+        return np.concatenate(out)
+
+    def lnprob_u(self, U):
+        """U[K, ndim] -> (V[K, ndim], lnprob[K]) with lnprob = lnprior + lnlike."""
+        Vs, Ls = [], []
+        U = np.atleast_2d(U)
+        for s in range(0, len(U), self.k_max):
+            K = self._up(U[s:s + self.k_max], self._u)
+            rc = self.lib.payne_lnprob_u_batch(self._handle, self._u.data_ptr(), K, self._v.data_ptr(), self._lp.data_ptr(),
+                                               self._stream())
+            if rc != 0:
+                self.eng._err(rc, "payne_lnprob_u_batch")
+            Vs.append(self._v[:K].cpu().numpy())
+            Ls.append(self._lp[:K].cpu().numpy())
+        return np.concatenate(Vs), np.concatenate(Ls)
+
+    def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed):
+        """K lock-step random-walk chains of `walks` steps under lnprob > loglstar.
+        Returns (U, V, lnprob, nacc, ncall) as numpy arrays."""
+        K = len(U)
+        if K > self.k_max:
+            raise ValueError("K > k_max")
+        self._up(U, self._u)
+        self._up(V, self._v)
+        self._lp[:K].copy_(self.torch.as_tensor(np.ascontiguousarray(lnprob, dtype=np.float64)))
+        ax = np.ascontiguousarray(axes, dtype=np.float64)
+        rc = self.lib.payne_rwalk_batch(self._handle, self._u.data_ptr(), self._v.data_ptr(), self._lp.data_ptr(), K,
+                                        ax.ctypes.data_as(C.POINTER(C.c_double)), float(scale), float(loglstar), int(walks),
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, self._nacc.data_ptr(), self._ncall.data_ptr(),
+                                        self._stream())
+        if rc != 0:
+            self.eng._err(rc, "payne_rwalk_batch")
+        return (self._u[:K].cpu().numpy(), self._v[:K].cpu().numpy(), self._lp[:K].cpu().numpy(),
+                self._nacc[:K].cpu().numpy(), self._ncall[:K].cpu().numpy())
+
+    def close(self):
+        if self._handle.value:
+            self.torch.cuda.synchronize(self.eng.device)
+            self.lib.payne_sampler_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -43,7 +43,7 @@ def _unit_ball(rng, n, ndim):
 class NestedSampler(object):
     def __init__(self, loglikelihood, prior_transform, ndim, nlive=500, bound='multi', sample='unif',
                  logl_args=None, bootstrap=0, walks=25, slices=5, enlarge=None, rstate=None,
-                 batched=False, queue_size=None, update_interval=None, first_update=None, **ignored):
+                 batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None, **ignored):
         if sample not in ('unif', 'rwalk'):
             raise NotImplementedError("sample=%r: this driver provides 'unif' and 'rwalk'" % (sample,))
         if bound not in ('none', 'single', 'multi'):
@@ -57,6 +57,8 @@ class NestedSampler(object):
         self.rng = rstate if rstate is not None else np.random.default_rng()
         self.queue_size = int(queue_size) if queue_size else self.nlive
         args = list(logl_args or [])
+        # device-side prior transform / lnprob / random walks (thepayne_amd.sampler.device.DeviceProposer)
+        self.proposer = proposer
         if batched:
             self._logl = lambda V: np.asarray(loglikelihood(V, *args), dtype=np.float64)
             self._ptform = lambda U: np.asarray(prior_transform(U), dtype=np.float64)
@@ -65,8 +67,12 @@ class NestedSampler(object):
             self._ptform = lambda U: np.array([prior_transform(u) for u in U], dtype=np.float64)
         # live points
         self.live_u = self.rng.uniform(size=(self.nlive, self.ndim))
-        self.live_v = self._ptform(self.live_u)
-        self.live_logl = self._eval(self.live_v)
+        if self.proposer is not None:
+            self.live_v, ll = self.proposer.lnprob_u(self.live_u)
+            self.live_logl = np.where(np.isnan(ll), -np.inf, ll)
+        else:
+            self.live_v = self._ptform(self.live_u)
+            self.live_logl = self._eval(self.live_v)
         self.live_it = np.zeros(self.nlive, dtype=int)
         self.ncall = self.nlive
         self.it = 1
@@ -125,8 +131,12 @@ class NestedSampler(object):
             V = np.empty((K, nd))
             ll = np.full(K, -np.inf)
             if inside.any():
-                V[inside] = self._ptform(U[inside])
-                ll[inside] = self._eval(V[inside])
+                if self.proposer is not None:
+                    V[inside], lli = self.proposer.lnprob_u(U[inside])
+                    ll[inside] = np.where(np.isnan(lli), -np.inf, lli)
+                else:
+                    V[inside] = self._ptform(U[inside])
+                    ll[inside] = self._eval(V[inside])
             nin = int(inside.sum())
             self.ncall += nin
             for i in np.nonzero(inside)[0]:
@@ -139,7 +149,11 @@ class NestedSampler(object):
         U, V, ll = self.live_u[start].copy(), self.live_v[start].copy(), self.live_logl[start].copy()
         nacc = np.zeros(K, dtype=int)
         ncalls = np.zeros(K, dtype=int)
-        for _ in range(self.walks):
+        if self.proposer is not None:      # all `walks` steps of all K chains in one device call
+            U, V, ll, nacc, ncalls = self.proposer.rwalk(U, V, ll, self._axes_unit, self.scale, lstar, self.walks,
+                                                        int(rng.integers(0, 2 ** 62)))
+            ll = np.where(np.isnan(ll), -np.inf, ll)
+        for _ in range(self.walks if self.proposer is None else 0):
             prop = U + self.scale * (_unit_ball(rng, K, nd) @ self._axes_unit.T)
             inside = np.all((prop > 0.0) & (prop < 1.0), axis=1)
             if not inside.any():

@@ -1,0 +1,76 @@
+"""End-to-end throughput of the batched nested sampler on the C2 problem (GPU box):
+likelihood calls per second as the sampler sees them, host proposals vs device proposals.
+
+  python tools/sampler_bench.py [--maxcall 400000] [--nlive 512] [--walks 25]
+
+The synthetic spectrum is produced with the engine itself (no oracle: this is a timing tool).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from thepayne_amd import synth, nnio                                  # noqa: E402
+from thepayne_amd.fitting.likelihood import likelihood               # noqa: E402
+from thepayne_amd.fitting.prior import prior                         # noqa: E402
+from thepayne_amd.fitting.fitstar import lnprob_batch                # noqa: E402
+from thepayne_amd.sampler import NestedSampler                       # noqa: E402
+
+SPEC = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
+ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', 'log(R)', 'Dist', 'log(A)', 'Av', 'Rv',
+       'CarbonScale']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--maxcall", type=int, default=400000)
+    ap.add_argument("--nlive", type=int, default=512)
+    ap.add_argument("--walks", type=int, default=25)
+    ap.add_argument("--modes", default="host,device")
+    a = ap.parse_args()
+    cfg = synth.CONFIGS[a.config]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0, line_depth=0.3)
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "yst.npz")
+    nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
+    fitpars = [list(ALL), {p: p in SPEC for p in ALL}]
+    rb = [True, False, False, False, False]
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': np.ones(len(obs)), 'obs_eflux_fit': np.full(len(obs), 0.01),
+               'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {}}
+    L = likelihood(fitargs, fitpars, rb, b_max=a.nlive, verbose=False)
+    T = synth.TRUTH
+    truth = np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]]])
+    clean = L.GM.engine.predict_batch(L.theta_rows(truth), stage=3, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+    fitargs['obs_flux_fit'] = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
+    L = likelihood(fitargs, fitpars, rb, b_max=a.nlive, verbose=False)
+    P = prior(fitargs, synth.demo_priordict(), fitpars, rb)
+    out = {}
+    for mode in a.modes.split(","):
+        proposer = None
+        if mode == "device":
+            from thepayne_amd.sampler.device import DeviceProposer
+            proposer = DeviceProposer(L, P, k_max=a.nlive)
+        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=a.nlive, bound='multi',
+                          sample='rwalk', walks=a.walks, batched=True, queue_size=a.nlive,
+                          rstate=np.random.default_rng(1), proposer=proposer)
+        t0 = time.perf_counter()
+        c0 = S.ncall
+        for _ in S.sample(maxcall=a.maxcall, dlogz=0.01):
+            pass
+        dt = time.perf_counter() - t0
+        out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 3),
+                     "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale)}
+        print(mode, json.dumps(out[mode]), flush=True)
+    print(json.dumps({"sampler_bench": out, "config": a.config, "nlive": a.nlive, "walks": a.walks}))
+
+
+if __name__ == "__main__":
+    main()
