@@ -15,6 +15,8 @@ struct HostExec {
   int nthr;
   template <class F> void par(F&& f) { for (int t = 0; t < nthr; ++t) f(t, nthr); }
   int nthreads() const { return nthr; }
+  static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
+  static const c32* twid(const c32* p) { return p; }
 };
 
 // the same instantiation choice the GPU launcher makes (compile-time FFT geometry needs 256 threads)

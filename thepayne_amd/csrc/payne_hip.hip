@@ -735,7 +735,20 @@ struct PostArgs {
   unsigned long long* stamps;        // diagnostic build: [B][64] cycle stamps (slot 0 = count)
 };
 
-struct DevExec {
+// BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
+template <bool BUF_LDS, bool TW_LDS>
+struct DevExecT {
+#ifdef __HIP_DEVICE_COMPILE__
+  static __device__ __forceinline__ auto buf(c32* p) {
+    if constexpr (BUF_LDS) return (PAYNE_AS_LDS f2v*)p; else return (PAYNE_AS_GLOBAL f2v*)p;
+  }
+  static __device__ __forceinline__ auto twid(const c32* p) {
+    if constexpr (TW_LDS) return (const PAYNE_AS_LDS f2v*)p; else return (const PAYNE_AS_GLOBAL f2v*)p;
+  }
+#else
+  static c32* buf(c32* p) { return p; }
+  static const c32* twid(const c32* p) { return p; }
+#endif
 #ifdef PAYNE_STAMPS
   // diagnostic build only (libpayne_hip_diag.so): cycle stamp after every phase barrier
   unsigned long long* stamps = nullptr;
@@ -778,7 +791,7 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
     twf = twl;                                                 // made visible by the first phase barrier
   }
   const int b = blockIdx.x;
-  DevExec ex;
+  DevExecT<true, TW_LDS> ex;
 #ifdef PAYNE_STAMPS
   if (a.stamps) {
     ex.stamps = a.stamps + (size_t)b * 64;
@@ -813,7 +826,7 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   __shared__ CandState S;
   float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
   float* bufB = bufA + T.n1;
-  DevExec ex;
+  DevExecT<false, false> ex;
   double* chi2 = red + scratch_doubles(kBigThreads) - 1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     run_candidate<0, kBigThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,

@@ -202,10 +202,24 @@ constexpr int plan_offset(int M, int P) {
 constexpr int plan_total(int M) { return plan_offset(M, M); }
 constexpr int plan_table_len(int M) { return plan_total(M) + M / 2; }
 
+// Complex loads/stores through a pointer whose address space is part of its type: the
+// out-of-line FFT body is handed LDS (or global) pointers explicitly, otherwise its
+// accesses compile to flat_load/flat_store (slower, and counted on both wait counters).
+#ifdef __HIP_DEVICE_COMPILE__
+typedef float f2v __attribute__((ext_vector_type(2)));
+#define PAYNE_AS_LDS __attribute__((address_space(3)))
+#define PAYNE_AS_GLOBAL __attribute__((address_space(1)))
+template <class Ptr> __device__ __forceinline__ c32 ldc(Ptr p, int i) { const f2v v = p[i]; return {v.x, v.y}; }
+template <class Ptr> __device__ __forceinline__ void stc(Ptr p, int i, c32 v) { f2v t; t.x = v.x; t.y = v.y; p[i] = t; }
+#else
+inline c32 ldc(const c32* p, int i) { return p[i]; }
+inline void stc(c32* p, int i, c32 v) { p[i] = v; }
+#endif
+
 // One pass: M points, sub-length P, NT threads; `sign` = 0x80000000 conjugates the output.
-template <int R, int M, int P, int NT>
-PAYNE_HD void fft_pass_fixed(int tid, const c32* __restrict__ src, c32* __restrict__ dst,
-                             const c32* __restrict__ twf, unsigned sign) {
+// SP/DP/TP: pointer types as produced by Ex::buf / Ex::twid.
+template <int R, int M, int P, int NT, class SP, class DP, class TP>
+PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign) {
   constexpr int NB = M / R, OFF = plan_offset(M, P);
 #pragma unroll
   for (int i0 = 0; i0 < NB; i0 += NT) {
@@ -214,11 +228,11 @@ PAYNE_HD void fft_pass_fixed(int tid, const c32* __restrict__ src, c32* __restri
     const int k = i & (P - 1);
     c32 u[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) u[r] = src[i + r * NB];
+    for (int r = 0; r < R; ++r) u[r] = ldc(src, i + r * NB);
     if (P > 1) {
       c32 w[R];
 #pragma unroll
-      for (int r = 1; r < R; ++r) w[r] = twf[OFF + (r - 1) * P + k];
+      for (int r = 1; r < R; ++r) w[r] = ldc(twf, OFF + (r - 1) * P + k);
 #pragma unroll
       for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
     }
@@ -229,7 +243,7 @@ PAYNE_HD void fft_pass_fixed(int tid, const c32* __restrict__ src, c32* __restri
       c32 v = u[r];
       union { float f; unsigned b; } cv;
       cv.f = v.y; cv.b ^= sign; v.y = cv.f;
-      dst[j + r * P] = v;
+      stc(dst, j + r * P, v);
     }
   }
 }

@@ -42,8 +42,8 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
 }
 
 // The same with compile-time geometry (M points, NT threads, pass-ordered twiddles `twf`).
-template <int M, int P, int NT, class Ex>
-PAYNE_SEQ c32* fft_fixed_passes(Ex& ex, c32* src, c32* dst, const c32* twf, unsigned sign_last) {
+template <int M, int P, int NT, class Ex, class BP, class TP>
+PAYNE_SEQ BP fft_fixed_passes(Ex& ex, BP src, BP dst, TP twf, unsigned sign_last) {
   if constexpr (P >= M) {
     return src;
   } else {
@@ -55,10 +55,13 @@ PAYNE_SEQ c32* fft_fixed_passes(Ex& ex, c32* src, c32* dst, const c32* twf, unsi
   }
 }
 // One body for the four transforms of a candidate (2 stages x forward/inverse): kept out of
-// line so the instruction stream stays small enough for the instruction cache.
+// line so the instruction stream stays small enough for the instruction cache.  Ex::buf /
+// Ex::twid put the address space of the buffers and of the twiddle table into the pointer types.
 template <int M, int NT, class Ex>
 PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsigned sign_last) {
-  return fft_fixed_passes<M, 1, NT>(ex, src, dst, twf, sign_last);
+  auto s = Ex::buf(src);
+  auto d = Ex::buf(dst);
+  return fft_fixed_passes<M, 1, NT>(ex, s, d, Ex::twid(twf), sign_last) == s ? src : dst;
 }
 
 // One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
