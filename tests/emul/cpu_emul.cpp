@@ -11,10 +11,14 @@
 
 using namespace payne;
 
+static int g_fast_windows = 0;   // candidates whose R-stage window came from the setup-time probe
+extern "C" int payne_emul_fast_windows() { return g_fast_windows; }
+
 struct HostExec {
   int nthr;
   template <class F> void par(F&& f) { for (int t = 0; t < nthr; ++t) f(t, nthr); }
   int nthreads() const { return nthr; }
+  void mark(int) {}
   static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
   static const c32* twid(const c32* p) { return p; }
 };
@@ -49,7 +53,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.npoly = npoly;
   if (force_general) { T.geo = 0; T.rot_identity = 0; }
   HostExec ex{nthreads};
-  std::vector<float> a(H.n1), b(H.n1);
+  std::vector<float> a(fft_buf_floats(H.n1)), b(fft_buf_floats(H.n1));
   std::vector<double> red(scratch_doubles(nthreads));
   const bool fixed = (nthreads == kPostThreads) && !force_general;
   for (int c = 0; c < B; ++c) {
@@ -65,14 +69,21 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
     else if (fixed && H.n1 == 8192) run_one<13>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     else run_candidate<0, kPostThreads>(ex, T, T.twf, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
     if (chi2) chi2[c] = x2;
-    if (info) {   // mask first / count / FFT length, recomputed the way the kernel derives them
+    // the setup-time probe must agree with the full mask count (phase_mask_count over every thread)
+    int full_below = -1, full_notabove = -1;
+    if (S.do_smooth && out_stage != 0 && out_stage != 1) {
+      std::vector<int> cnt(nthreads);
+      for (int t = 0; t < nthreads; ++t) phase_mask_count(t, nthreads, T, S, cnt.data());
+      full_below = full_notabove = 0;
+      for (int s = 0; s < n_slots(nthreads); ++s) { full_below += cnt[s] & 0xffff; full_notabove += cnt[s] >> 16; }
+      if (S.win_ready) ++g_fast_windows;
+      if (S.win_ready && (S.win_below != full_below || S.win_notabove != full_notabove)) return -77;
+    }
+    if (info) {   // mask first / count / FFT length / whether the probe path was taken
       info[3 * c] = info[3 * c + 1] = info[3 * c + 2] = -1;
-      if (S.do_smooth && out_stage != 0 && out_stage != 1) {
-        int* cnt = reinterpret_cast<int*>(red.data() + nthreads);
-        Window W = make_window(T, S, cnt, n_slots(nthreads));
-        int below = 0, notabove = 0;
-        for (int s = 0; s < n_slots(nthreads); ++s) { below += cnt[s] & 0xffff; notabove += cnt[s] >> 16; }
-        info[3 * c] = below; info[3 * c + 1] = notabove - below; info[3 * c + 2] = W.n2;
+      if (full_below >= 0) {
+        const Window W = window_from_counts(T, S.dop, S.g_a, full_below, full_notabove);
+        info[3 * c] = full_below; info[3 * c + 1] = full_notabove - full_below; info[3 * c + 2] = W.n2;
       }
     }
   }

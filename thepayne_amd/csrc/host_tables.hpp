@@ -35,6 +35,8 @@ inline void fill_model_scalars(const HostTables& H, PostTables& T) {
   T.vs_tab_n = (int)H.vs_tab32.size();
   T.twf_n = (int)H.twf.size();
   T.rot_identity = H.rot_identity;
+  T.inv_lam0 = H.lam.empty() ? 0.f : (float)(1.0 / H.lam[0]);
+  T.inv_dln32 = (float)H.geo_inv_dln;
 }
 
 // numpy.linspace(start, stop, n)

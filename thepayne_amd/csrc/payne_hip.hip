@@ -299,7 +299,8 @@ constexpr int HK_KC = 320;          // K chunk
 constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
 
-template <bool FUSE_L0>
+// NL: label slots the fused first layer loops over (4 for the usual Teff/logg/FeH/aFe nets, else PAYNE_MAX_LABELS)
+template <bool FUSE_L0, int NL>
 __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p) {
   extern __shared__ __attribute__((aligned(16))) float hk_sm[];
   float* As = hk_sm;
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         va[it] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kcl);
       }
     }
-    float w0[2][PAYNE_MAX_LABELS], bz[2];
+    float w0[2][NL], bz[2];
     if (FUSE_L0) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -355,9 +356,9 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         const int kq = k < p.K0 ? k : p.K0 - 1;
         bz[h] = p.b0[kq];
 #pragma unroll
-        for (int d = 0; d < PAYNE_MAX_LABELS; ++d) w0[h][d] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
+        for (int d = 0; d < NL; ++d) w0[h][d] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
 #pragma unroll
-        for (int d = 0; d < PAYNE_MAX_LABELS; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
+        for (int d = 0; d < NL; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
       }
     }
     __builtin_amdgcn_sched_barrier(0);        // keep every load ahead of the first LDS store
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
           for (int rr = 0; rr < 32; ++rr) {
             float z = bz[h];
 #pragma unroll
-            for (int d = 0; d < PAYNE_MAX_LABELS; ++d) z = fmaf(w0[h][d], Xh[rr * PAYNE_MAX_LABELS + d], z);
+            for (int d = 0; d < NL; ++d) z = fmaf(w0[h][d], Xh[rr * PAYNE_MAX_LABELS + d], z);
             As[rr * HK_PITCH + kk] = live ? act_apply(z, p.act0) : 0.f;
           }
         }
@@ -758,8 +759,14 @@ struct DevExecT {
   __device__ __forceinline__ void par(F&& f) {
     f((int)threadIdx.x, (int)blockDim.x);
     __syncthreads();
+    mark(0);
+  }
+  // diagnostic build: an extra cycle stamp inside a phase, written by thread `who`
+  __device__ __forceinline__ void mark(int who) {
 #ifdef PAYNE_STAMPS
-    if (stamps && threadIdx.x == 0 && nst < 63) stamps[++nst] = __builtin_amdgcn_s_memtime();
+    if (stamps && nst < 62) { ++nst; if ((int)threadIdx.x == who) stamps[nst] = __builtin_amdgcn_s_memtime(); }
+#else
+    (void)who;
 #endif
   }
   __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
@@ -779,8 +786,8 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n1 = T.n1;
   float* bufA = reinterpret_cast<float*>(smem);
-  float* bufB = bufA + n1;
-  double* red = reinterpret_cast<double*>(bufB + n1);          // scratch_doubles(256)
+  float* bufB = bufA + fft_buf_floats(n1);                     // room for the padded FFT intermediates
+  double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(n1));          // scratch_doubles(256)
   CandState* S = reinterpret_cast<CandState*>(red + scratch_doubles(kPostThreads));
   const c32* twf = T.twf;
   if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
@@ -1194,7 +1201,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
       if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
     }
-    c->post_lds = (size_t)(T.n1 > 16384 ? 64 : T.n1) * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
+    c->post_lds = (size_t)(T.n1 > 16384 ? 64 : fft_buf_floats(T.n1)) * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
     // twiddles in LDS while two workgroups still fit a CU (160 KiB); larger spectra read them from L2
     const size_t tw_bytes = c->H.twf.size() * sizeof(c32);         // ~0.75 n1 entries
     c->post_tw_lds = (c->post_lds + tw_bytes) <= 80 * 1024;
@@ -1329,11 +1336,15 @@ static void launch_hidden(DenseParams& p, hipStream_t s) {
   p.grid_n = (p.N + 31) / 32;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((payne_dense_hidden_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), HK_LDS_BYTES, s, p);
+  const dim3 grid(p.grid_m * p.grid_n), block(256);
+  if (!FUSE) hipLaunchKernelGGL((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p);
+  else if (p.n_labels <= 4) hipLaunchKernelGGL((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p);
+  else hipLaunchKernelGGL((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p);
 }
 
 template <bool FUSE>

@@ -99,19 +99,10 @@ struct PostTables {
   const float* vs_tab;        // vsini taper sb(i*kVsTabStep), fp32 copy of the fp64 host table
   int vs_tab_n;
   int rot_identity;    // the vsini resampling maps are the identity (to fp32): skip them
+  float inv_lam0, inv_dln32;  // 1/lam[0], 1/dln in fp32: the +-31-pixel position guess of the mask probe
 };
 
 // Per-candidate scalars from theta, shared by the workgroup (lives in LDS).
-struct CandState {
-  double one_plus;   // 1 + rv/c
-  double dop;        // ln(one_plus)
-  double vs_a;       // 2 pi sigma        (vsini)
-  double g_a;        // -2 pi^2 sigma^2   (gauss)
-  double wl, wh;     // mask limits (smoothing.py:631-647)
-  double poly[12];
-  int do_rot, do_smooth;
-};
-
 // The R-stage window of one candidate, derived (redundantly, by every thread) from the
 // mask bounds: resample_wave's grid (smoothing.py:654-661) and the two position maps.
 struct Window {
@@ -124,6 +115,18 @@ struct Window {
   int i0, i1;            // masked pixels [i0, i1)
   int n2;                // FFT length of the R stage
   int bad;               // window too small for an FFT -> NaN result
+};
+
+struct CandState {
+  double one_plus;   // 1 + rv/c
+  double dop;        // ln(one_plus)
+  double vs_a;       // 2 pi sigma        (vsini)
+  double g_a;        // -2 pi^2 sigma^2   (gauss)
+  double wl, wh;     // mask limits (smoothing.py:631-647)
+  double poly[12];
+  int do_rot, do_smooth;
+  int win_ready;     // the two mask counts below come from phase_setup's probe (geometric grids)
+  int win_below, win_notabove;
 };
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -216,19 +219,54 @@ inline c32 ldc(const c32* p, int i) { return p[i]; }
 inline void stc(c32* p, int i, c32 v) { p[i] = v; }
 #endif
 
+// Layout of the buffer BETWEEN two passes.  A pass with sub-length P and radix R writes, per
+// lane i (k = i mod P, g = i div P), the R elements j + r P with j = g P R + k: for P < 32 the
+// lanes of a half-wave land in a few banks (P = 1: lane stride R complex = 64 B -> 4 distinct
+// 8-byte slots; P = 8: 64-byte runs 512 B apart -> 4-way conflicts).  Padding the intermediate
+// buffer makes those writes conflict-free while the next pass still reads consecutive lanes
+// from consecutive (or once-shifted) addresses:
+//   P R < 32 : phys(j) = j + (j >> 5)               one complex per 32 (the R-runs of 4 lanes rotate by 8 B)
+//   P < 32   : phys(j) = j + P (j div P R)          group stride P R + P  ==  P (mod 32 complex = 256 B)
+//   P >= 32  : phys(j) = j
+// The first pass reads and the last pass writes the plain layout.  Both padded forms are additive
+// over multiples of their period, so the per-element offsets stay compile-time constants.
+template <int PW, int RW>
+PAYNE_HD int fft_lay(int j) {
+  if constexpr (PW == 0 || PW >= 32) return j;
+  else if constexpr (PW * RW < 32) return j + (j >> 5);
+  else return j + PW * (j / (PW * RW));
+}
+// sub-length of the pass that precedes the pass with sub-length P (P > 1)
+constexpr int plan_prev_p(int M, int P) {
+  int p = 1;
+  while (p * plan_radix(M, p) < P) p *= plan_radix(M, p);
+  return p;
+}
+// floats each of the two ping-pong buffers needs for n-point spectra (M = n/2 complex + padding <= M/R)
+PAYNE_HD constexpr int fft_buf_floats(int n) { return n + ((n / 2) / 8 >= kPostThreads ? n / 8 : n / 4); }
+
 // One pass: M points, sub-length P, NT threads; `sign` = 0x80000000 conjugates the output.
 // SP/DP/TP: pointer types as produced by Ex::buf / Ex::twid.
+// `edge` (last pass only): the result is a real spectrum packed as (even, odd) pairs; apply
+// spec[0] = spec[1], spec[-1] = spec[-2] (ystpred.py:223-224) on the way out.
 template <int R, int M, int P, int NT, class SP, class DP, class TP>
-PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign) {
+PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign, bool edge = false) {
   constexpr int NB = M / R, OFF = plan_offset(M, P);
+  constexpr int PI = (P > 1) ? plan_prev_p(M, P) : 0;              // layout we read: written by pass (PI, RI)
+  constexpr int RI = (P > 1) ? plan_radix(M, PI) : 0;
+  constexpr bool last = (P * R >= M);
+  constexpr int PO = last ? 0 : P;                                 // layout we write
+  static_assert(!last || P >= 32 || M < 64, "the last pass must write the plain layout");
+  static_assert(NB % 32 == 0 || PI == 0 || PI >= 32, "padded reads need NB to be a multiple of the pad period");
 #pragma unroll
   for (int i0 = 0; i0 < NB; i0 += NT) {
     const int i = i0 + tid;
     if ((NB % NT) != 0 && i >= NB) break;
     const int k = i & (P - 1);
+    const int ib = fft_lay<PI, RI>(i);
     c32 u[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) u[r] = ldc(src, i + r * NB);
+    for (int r = 0; r < R; ++r) u[r] = ldc(src, ib + fft_lay<PI, RI>(r * NB));
     if (P > 1) {
       c32 w[R];
 #pragma unroll
@@ -237,12 +275,16 @@ PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign) {
       for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
     }
     dftR<R>(u);
-    const int j = (i - k) * R + k;
+    const int j = fft_lay<PO, R>((i - k) * R + k);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       c32 v = u[r];
       union { float f; unsigned b; } cv;
       cv.f = v.y; cv.b ^= sign; v.y = cv.f;
+      if constexpr (last) {
+        if (r == 0 && edge && i == 0) v.x = v.y;                    // element 0     = (spec[0], spec[1])
+        if (r == R - 1 && edge && i == NB - 1) v.y = v.x;           // element M - 1 = (spec[n-2], spec[n-1])
+      }
       stc(dst, j + r * P, v);
     }
   }
@@ -319,23 +361,31 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
   constexpr int PU = 4;
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const int npair = M / 2 - 1;                        // k = 1 .. M/2-1
+  // The two self-conjugate bins (0 with M, and M/2) need taper(M) and taper(M/2): they ride in the
+  // one slot of the loop that falls on k0 == M/2 (past the last pair), so their table loads are in
+  // flight with everybody else's instead of forming a second, serial round trip at the end.
+  bool special_done = false;
   for (int base = tid; base < npair; base += PU * nthr) {
     c32 zk[PU], zm[PU], w[PU];
     float tk[PU], tm[PU];
     bool far = false;
 #pragma unroll
     for (int q = 0; q < PU; ++q) {                     // loads from clamped indices: no branches here
-      const int k0 = 1 + base + q * nthr, k = k0 <= npair ? k0 : npair;
+      const int k0 = 1 + base + q * nthr;
+      const bool pair = k0 <= npair;
+      const int k = pair ? k0 : npair;
       zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * tw_step];
-      tk[q] = taper_at<VSINI>(ta, k, far);
-      tm[q] = taper_at<VSINI>(ta, M - k, far);
+      tk[q] = taper_at<VSINI>(ta, pair ? k : M / 2, far);
+      tm[q] = taper_at<VSINI>(ta, pair ? M - k : M, far);
     }
     if (VSINI && far) {
 #pragma unroll
       for (int q = 0; q < PU; ++q) {
-        const int k0 = 1 + base + q * nthr, k = k0 <= npair ? k0 : npair;
-        tk[q] = taper_far(ta, k, tk[q]);
-        tm[q] = taper_far(ta, M - k, tm[q]);
+        const int k0 = 1 + base + q * nthr;
+        const bool pair = k0 <= npair;
+        const int k = pair ? k0 : npair;
+        tk[q] = taper_far(ta, pair ? k : M / 2, tk[q]);
+        tm[q] = taper_far(ta, pair ? M - k : M, tm[q]);
       }
     }
 #pragma unroll
@@ -349,24 +399,40 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
       if (k <= npair) {
         Z[k] = cconj(cadd(E, iO));
         Z[M - k] = csub(E, iO);
+      } else if (k == M / 2) {                         // tk = taper(M/2), tm = taper(M); taper(0) = 1
+        const c32 z0 = Z[0], zh = Z[M / 2];
+        const float x0 = z0.x + z0.y, xm = tm[q] * (z0.x - z0.y);
+        Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+        Z[M / 2] = cscale(cconj(zh), tk[q] * invM);
+        special_done = true;
       }
     }
   }
-  if (tid == nthr - 1) {                               // k = 0 with k = M (real bins X[0], X[M])
-    bool far = false;
-    const float t0 = taper_at<VSINI>(ta, 0, far);
-    float tM = taper_at<VSINI>(ta, M, far);
-    if (VSINI && far) tM = taper_far(ta, M, tM);
-    const c32 z0 = Z[0];
-    const float x0 = t0 * (z0.x + z0.y), xm = tM * (z0.x - z0.y);
-    Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+  // does some thread's loop contain the slot k0 == M/2 ?  (uniform arithmetic; true for every
+  // power-of-two M >= 2 PU nthr, e.g. the kernel's 2048 points on 256 threads)
+  bool covered = false;
+  for (int q = 1; q < PU; ++q) {
+    const int b = npair - q * nthr;
+    covered = covered || (b >= 0 && (b % (PU * nthr)) < nthr);
   }
-  if (tid == (nthr > 1 ? nthr - 2 : 0) && M >= 2) {    // k = M/2 (self-conjugate)
-    const int k = M / 2;
-    bool far = false;
-    float th = taper_at<VSINI>(ta, k, far);
-    if (VSINI && far) th = taper_far(ta, k, th);
-    Z[k] = cscale(cconj(Z[k]), th * invM);
+  (void)special_done;
+  if (!covered) {
+    if (tid == nthr - 1) {                               // k = 0 with k = M (real bins X[0], X[M])
+      bool far = false;
+      const float t0 = taper_at<VSINI>(ta, 0, far);
+      float tM = taper_at<VSINI>(ta, M, far);
+      if (VSINI && far) tM = taper_far(ta, M, tM);
+      const c32 z0 = Z[0];
+      const float x0 = t0 * (z0.x + z0.y), xm = tM * (z0.x - z0.y);
+      Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+    }
+    if (tid == (nthr > 1 ? nthr - 2 : 0) && M >= 2) {    // k = M/2 (self-conjugate)
+      const int k = M / 2;
+      bool far = false;
+      float th = taper_at<VSINI>(ta, k, far);
+      if (VSINI && far) th = taper_far(ta, k, th);
+      Z[k] = cscale(cconj(Z[k]), th * invM);
+    }
   }
 }
 
@@ -399,6 +465,26 @@ PAYNE_HD void uniform_locate(double t, int lo, int hi, float hs, int& k, float& 
   k = kk;
   w = f * (1.0f + hs * (f - 1.0f));                      // expm1(f v)/expm1(v), v = 2 hs
 }
+// The same split without fp64 conversions (v_cvt_*_f64 run at a fraction of the fma rate and
+// there were four per pixel): the caller folds kPosMagic = 1.5 * 2^20 into the constant term of its
+// position fma, so that tm = t + kPosMagic (0 <= t < 2^19) has ulp 2^-32: the low dword of tm IS
+// the fraction in units of 2^-32, bits 0..18 of the high dword the integer part, and the
+// exponent field is the constant 0x413.  Position resolution 2.3e-10 pixel (single rounding).
+// Anything else in the exponent field (NaN, negative, huge) gives a NaN weight.
+constexpr double kPosMagic = 1572864.0;
+PAYNE_HD void magic_locate(double tm, int lo, int hi, float hs, int& k, float& w) {
+  union { double d; unsigned long long u; } cv;
+  cv.d = tm;
+  const unsigned lo_dw = (unsigned)cv.u, hi_dw = (unsigned)(cv.u >> 32);
+  int kk = (int)(hi_dw & 0x7FFFFu);
+  float f = (float)lo_dw * 2.3283064365386963e-10f;      // 2^-32
+  const bool below = kk < lo, above = kk > hi - 2;
+  kk = below ? lo : (above ? hi - 2 : kk);
+  f = below ? 0.f : (above ? 1.f : f);
+  f = ((hi_dw >> 20) == 0x413u) ? f : nanf_();
+  k = kk;
+  w = f * (1.0f + hs * (f - 1.0f));
+}
 
 // ---------------------------------------------------------------------------
 // Phases.  `spec`/`work` are the two LDS spectra buffers (n1 floats each).  Loops that
@@ -406,6 +492,95 @@ PAYNE_HD void uniform_locate(double t, int lo, int hi, float hs, int& k, float& 
 // items" so that the U gathers are in flight together.
 // ---------------------------------------------------------------------------
 constexpr int kU = 4;
+
+// The R-stage window from the two mask counts (see phase_mask_count / make_window below).
+PAYNE_HD int pow2ceil_fast(int n) {                    // n >= 2
+#ifdef __HIP_DEVICE_COMPILE__
+  return 1 << (32 - __clz(n - 1));
+#else
+  return pow2ceil(n);
+#endif
+}
+// Every thread evaluates this between two phases, so it is kept short: one fp64 division (the
+// np.linspace step), the rest multiplications by reciprocals that are exact or constant.
+PAYNE_HD Window window_from_counts(const PostTables& T, double dop, double g_a, int below, int notabove) {
+  Window W;
+  W.i0 = below; W.i1 = notabove;
+  const int n = W.i1 - W.i0;
+  W.bad = (n < 8) ? 1 : 0;
+  if (W.bad) { W.i0 = 0; W.i1 = 8; }                                 // any valid range: results are NaN'd
+  W.n2 = pow2ceil_fast(W.bad ? 8 : n);
+  const double l0 = T.geo ? (T.ln0 + (double)W.i0 * T.dln) : T.lnlam[W.i0];
+  const double l1 = T.geo ? (T.ln0 + (double)(W.i1 - 1) * T.dln) : T.lnlam[W.i1 - 1];
+  W.lnmin = l0 + dop;
+  W.lnmax = l1 + dop;
+  const double span = W.lnmax - W.lnmin, nm1 = (double)(W.n2 - 1);
+  W.step = span / nm1;                                               // np.linspace
+  // 1/step: |step * (nm1/span) - 1| < 2^-52, positions move by < 1e-12 pixel
+  const double inv_step = nm1 * (1.0 / span);
+  W.rsA = W.step * T.geo_inv_dln;                                    // geo: geo_inv_dln == 1/dln
+  W.rsB = (l0 - T.ln0) * T.geo_inv_dln;
+  W.obA = inv_step;
+  W.obB = -W.lnmin * inv_step;
+  W.hs_ann = (float)(0.5 * T.dln);
+  W.hs_step = (float)(0.5 * W.step);
+  const double g_val = inv_step * ((1.0 / kCkms) / (double)W.n2);    // rfftfreq: 1/(n2 dv), dv = ckms*step; 1/n2 exact
+  W.g_c2 = (float)(g_a * (g_val * g_val) * 1.4426950408889634);
+  return W;
+}
+PAYNE_HD int probe_start(const PostTables& T, float op32, double lim) {
+  const float ratio = ((float)lim * T.inv_lam0) / op32;
+#ifdef __HIP_DEVICE_COMPILE__
+  const float pos = (__builtin_amdgcn_logf(ratio) * 0.6931471805599453f) * T.inv_dln32;   // v_log_f32 is log2
+#else
+  const float pos = logf(ratio) * T.inv_dln32;
+#endif
+  if (!(pos > -1e9f && pos < 1e9f)) return INT32_MIN;
+  return (int)floorf(pos) - 31;
+}
+template <bool UPPER>
+PAYNE_HD int probe_count(const PostTables& T, double op, double lim, int s, int lane, int nl) {
+  if (s == INT32_MIN) return -1;
+  int cnt = 0, nvalid = 0;
+#ifdef __HIP_DEVICE_COMPILE__
+  if (nl != 64) return -1;                                              // needs a whole wave
+  const int idx = s + lane;
+  const bool valid = idx >= 0 && idx < T.npix;
+  const double c = T.lam[valid ? idx : 0] * op;
+  const bool pr = valid && (UPPER ? (c < lim) : !(c > lim));
+  cnt = __popcll(__ballot(pr));
+  nvalid = __popcll(__ballot(valid));
+#else
+  (void)lane; (void)nl;
+  for (int l = 0; l < 64; ++l) {
+    const int idx = s + l;
+    const bool valid = idx >= 0 && idx < T.npix;
+    if (!valid) continue;
+    const double c = T.lam[idx] * op;
+    ++nvalid;
+    if (UPPER ? (c < lim) : !(c > lim)) ++cnt;
+  }
+#endif
+  if (s > 0 && cnt == 0) return -1;                                     // boundary is left of the probe
+  if (s + 63 < T.npix - 1 && cnt == nvalid) return -1;                  // ... or right of it (also NaN products)
+  if (nvalid == 0) return s < 0 ? 0 : T.npix;
+  return (s > 0 ? s : 0) + cnt;
+}
+// Setup-time mask counts (one wave): fills S.win_below / S.win_notabove / S.win_ready.
+PAYNE_HD void setup_window(const PostTables& T, const double* th, double wl, double wh, bool smooth,
+                           CandState& S, int lane, int nl) {
+  int ready = 0, below = 0, notabove = 0;
+  if (smooth && T.geo) {
+    const double rv = th[4];
+    const double op = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;    // as phase_setup's thread 0
+    const float op32 = (float)op;
+    const int s_lo = probe_start(T, op32, wl), s_hi = probe_start(T, op32, wh);
+    below = probe_count<false>(T, op, wl, s_lo, lane, nl);
+    notabove = probe_count<true>(T, op, wh, s_hi, lane, nl);
+    ready = (below >= 0 && notabove >= 0) ? 1 : 0;
+  }
+  if (lane == 0) { S.win_below = below; S.win_notabove = notabove; S.win_ready = ready; }
+}
 
 // P0: per-candidate scalars from theta.  The independent fp64 chains (log / sqrt / the
 // instrument width) go to the first thread of different waves so that they overlap.
@@ -423,18 +598,26 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
     S.do_rot = (vrot != 0.0);                       // ystpred.py:214 (NaN passes)
     S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);   // smoothing.py:297,614
   }
-  if (tid == 2 * lanes) {
+  // the instrument chain runs on a whole wave: its first lane publishes the scalars, and all 64
+  // lanes probe the mask limits (geometric grids) while the spectrum row is still on its way from
+  // memory; otherwise phase_mask_count runs later
+  if (lanes ? ((tid >> 6) == 2) : (tid == 0)) {
+    const int lane = lanes ? (tid & 63) : 0;
     const double Rs = th[7] * instr_factor;         // genmod.py:82-85
-    S.do_smooth = (Rs > 0.0);                       // ystpred.py:238-240 (false for NaN)
-    S.g_a = 0.0; S.wl = 0.0; S.wh = 0.0;
+    double g_a = 0.0, wl = 0.0, wh = 0.0;
     if (Rs > 0.0) {
       const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;   // smoothing.py:107,113
       const double sig = sqrt(sig_out * sig_out - inres * inres);   // :271 (NaN if negative)
-      S.g_a = -2.0 * (kPi * kPi) * (sig * sig);
+      g_a = -2.0 * (kPi * kPi) * (sig * sig);
       const double pad = 20.0 / Rs;                                 // mask_wave, smoothing.py:631-647
-      S.wl = T.obs_min * (1.0 + pad * -1.0);
-      S.wh = T.obs_max * (1.0 + pad * 1.0);
+      wl = T.obs_min * (1.0 + pad * -1.0);
+      wh = T.obs_max * (1.0 + pad * 1.0);
     }
+    if (lane == 0) {
+      S.do_smooth = (Rs > 0.0);                     // ystpred.py:238-240 (false for NaN)
+      S.g_a = g_a; S.wl = wl; S.wh = wh;
+    }
+    setup_window(T, th, wl, wh, Rs > 0.0, S, lane, lanes ? 64 : 1);
   }
   if (tid == 3 * lanes)
     for (int i = 0; i < T.npoly && i < 12; ++i) S.poly[i] = th[8 + i];
@@ -443,14 +626,35 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
 // P1: load the raw ANN spectrum (already shifted by -1) into LDS.  SCRUB applies
 // nan_to_num(nan=1.0) (0 in shifted flux, smoothing.py:138) on the way: used when the row
 // goes straight into the vsini FFT (identity resampling maps).
-PAYNE_HD void phase_load(int tid, int nthr, int npix, const float* __restrict__ raw, float* __restrict__ spec,
-                         bool scrub) {
-  if (((npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0)) {
+// Split in two so that the global loads of the first kU*nthr float4 (the whole row at 4096
+// pixels) are in flight WHILE phase_setup's fp64 chains run: issue -> setup -> commit.
+struct RowRegs { float v[kU][4]; };
+PAYNE_HD bool row_vectorised(int npix, const float* raw) { return ((npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0); }
+PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restrict__ raw, RowRegs& R) {
+  if (!row_vectorised(npix, raw)) return;
+  const int n4 = npix >> 2;
+#pragma unroll
+  for (int q = 0; q < kU; ++q) {                      // clamped index: unconditional loads
+    const int i0 = tid + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
+    R.v[q][0] = raw[4 * i]; R.v[q][1] = raw[4 * i + 1]; R.v[q][2] = raw[4 * i + 2]; R.v[q][3] = raw[4 * i + 3];
+  }
+}
+PAYNE_HD void phase_load_commit(int tid, int nthr, int npix, const float* __restrict__ raw, const RowRegs& R,
+                                float* __restrict__ spec, bool scrub) {
+  if (row_vectorised(npix, raw)) {
     const int n4 = npix >> 2;
-    for (int base = tid; base < n4; base += kU * nthr) {
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int i = tid + q * nthr;
+      if (i < n4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) spec[4 * i + e] = scrub ? nan_to_zero(R.v[q][e]) : R.v[q][e];
+      }
+    }
+    for (int base = tid + kU * nthr; base < n4; base += kU * nthr) {      // rows longer than kU*nthr float4
       float v[kU][4];
 #pragma unroll
-      for (int q = 0; q < kU; ++q) {                    // clamped index: unconditional loads
+      for (int q = 0; q < kU; ++q) {
         const int i0 = base + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
         v[q][0] = raw[4 * i]; v[q][1] = raw[4 * i + 1]; v[q][2] = raw[4 * i + 2]; v[q][3] = raw[4 * i + 3];
       }
@@ -562,42 +766,25 @@ PAYNE_HD void phase_mask_count(int tid, int nthr, const PostTables& T, const Can
 // ln(lam_k (1+rv/c)) is taken as lnlam[k] + dop (differs from log of the rounded product by
 // < 2e-16, i.e. < 1e-10 pixel: grid and interpolation depend on it continuously).
 PAYNE_HD Window make_window(const PostTables& T, const CandState& S, const int* cnt, int nslots) {
-  Window W;
   int below = 0, notabove = 0;
   for (int s = 0; s < nslots; ++s) { const int v = cnt[s]; below += v & 0xffff; notabove += v >> 16; }
-  W.i0 = below; W.i1 = notabove;
-  const int n = W.i1 - W.i0;
-  W.bad = (n < 8) ? 1 : 0;
-  if (W.bad) { W.i0 = 0; W.i1 = 8; }                                 // any valid range: results are NaN'd
-  W.n2 = pow2ceil(W.bad ? 8 : n);
-  const double l0 = T.geo ? (T.ln0 + (double)W.i0 * T.dln) : T.lnlam[W.i0];
-  const double l1 = T.geo ? (T.ln0 + (double)(W.i1 - 1) * T.dln) : T.lnlam[W.i1 - 1];
-  W.lnmin = l0 + S.dop;
-  W.lnmax = l1 + S.dop;
-  W.step = (W.lnmax - W.lnmin) / (double)(W.n2 - 1);                 // np.linspace
-  const double inv_step = (double)(W.n2 - 1) / (W.lnmax - W.lnmin);
-  W.rsA = W.step * T.geo_inv_dln;                                    // geo: geo_inv_dln == 1/dln
-  W.rsB = (l0 - T.ln0) * T.geo_inv_dln;
-  W.obA = inv_step;
-  W.obB = -W.lnmin * inv_step;
-  W.hs_ann = (float)(0.5 * T.dln);
-  W.hs_step = (float)(0.5 * W.step);
-  const double g_val = inv_step / ((double)W.n2 * kCkms);            // rfftfreq: 1/(n2 dv), dv = ckms*step
-  W.g_c2 = (float)(S.g_a * (g_val * g_val) * 1.4426950408889634);
-  return W;
+  return window_from_counts(T, S.dop, S.g_a, below, notabove);
 }
 
 // R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
 template <bool GEO>
 PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                               const float* __restrict__ spec, float* __restrict__ work) {
-  for (int base = tid; base < W.n2; base += kU * nthr) {
-    float a[kU], b[kU], w[kU];
+  constexpr int RU = 16;                                 // a whole 4096-point thread-share of gathers in flight
+  const double rsBm = W.rsB + kPosMagic, rsD = (double)nthr * W.rsA;
+  for (int base = tid; base < W.n2; base += RU * nthr) {
+    float a[RU], b[RU], w[RU];
+    const double tm0 = fma((double)base, W.rsA, rsBm);   // point base + q nthr sits at tm0 + q rsD
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < RU; ++q) {
       const int j0 = base + q * nthr, j = j0 < W.n2 ? j0 : W.n2 - 1;
       int k; float ww;
-      if (GEO) uniform_locate((double)j * W.rsA + W.rsB, W.i0, W.i1, W.hs_ann, k, ww);
+      if (GEO) magic_locate(fma((double)q, rsD, tm0), W.i0, W.i1, W.hs_ann, k, ww);   // (k is clamped: j0 >= n2 is harmless)
       else {
         const double lw = (j == W.n2 - 1) ? W.lnmax : ((double)j * W.step + W.lnmin);
         search_locate(T, W.i0, W.i1, lw - S.dop, k, ww);
@@ -605,7 +792,7 @@ PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const Cand
       a[q] = spec[k]; b[q] = spec[k + 1]; w[q] = ww;
     }
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < RU; ++q) {
       const int j = base + q * nthr;
       if (j < W.n2) {
         const float aa = nan_to_zero(a[q]), bb = nan_to_zero(b[q]);   // nan_to_num, smoothing.py:138
@@ -630,7 +817,8 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
                         const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
   float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the
   constexpr int OU = 16;                                 // cross-thread reduction is fp64
-  const double piA = T.geo_inv_dln, piB = -(S.dop + T.ln0) * T.geo_inv_dln;   // MODE 1: t = (lnobs - dop - ln0)/dln
+  const double piA = T.geo_inv_dln, piBm = -(S.dop + T.ln0) * T.geo_inv_dln + kPosMagic;   // MODE 1: t = (lnobs - dop - ln0)/dln
+  const double obBm = W.obB + kPosMagic;
   const float hs_ann = (float)(0.5 * T.dln);
   const int nc = T.npoly;
   for (int base = tid; base < T.nobs; base += OU * nthr) {
@@ -646,11 +834,11 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
       int k = 0; float ww = 0.f;
       if (MODE == 0) {
         nanv[q] = (lo < W.lnmin) || (lo > W.lnmax);      // np.interp(left=nan, right=nan)
-        uniform_locate(nanv[q] ? 0.0 : lo * W.obA + W.obB, 0, W.n2, W.hs_step, k, ww);
+        magic_locate(nanv[q] ? kPosMagic : fma(lo, W.obA, obBm), 0, W.n2, W.hs_step, k, ww);
       } else {
         const double v = lo - S.dop;
         nanv[q] = (v < T.ln0) || (v > T.ln_last);
-        if (MODE == 1) uniform_locate(nanv[q] ? 0.0 : lo * piA + piB, 0, T.npix, hs_ann, k, ww);
+        if (MODE == 1) magic_locate(nanv[q] ? kPosMagic : fma(lo, piA, piBm), 0, T.npix, hs_ann, k, ww);
         else if (!nanv[q]) search_locate(T, 0, T.npix, v, k, ww);
       }
       a[q] = conv[k]; b[q] = conv[k + 1]; w[q] = ww;

@@ -43,40 +43,44 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
 
 // The same with compile-time geometry (M points, NT threads, pass-ordered twiddles `twf`).
 template <int M, int P, int NT, class Ex, class BP, class TP>
-PAYNE_SEQ BP fft_fixed_passes(Ex& ex, BP src, BP dst, TP twf, unsigned sign_last) {
+PAYNE_SEQ BP fft_fixed_passes(Ex& ex, BP src, BP dst, TP twf, unsigned sign_last, bool edge) {
   if constexpr (P >= M) {
     return src;
   } else {
     constexpr int R = plan_radix(M, P);
     constexpr bool last = (P * R >= M);
     const unsigned sign = last ? sign_last : 0u;
-    ex.par([&](int t, int) { fft_pass_fixed<R, M, P, NT>(t, src, dst, twf, sign); });
-    return fft_fixed_passes<M, P * R, NT>(ex, dst, src, twf, sign_last);
+    ex.par([&](int t, int) { fft_pass_fixed<R, M, P, NT>(t, src, dst, twf, sign, last && edge); });
+    return fft_fixed_passes<M, P * R, NT>(ex, dst, src, twf, sign_last, edge);
   }
 }
 // One body for the four transforms of a candidate (2 stages x forward/inverse): kept out of
 // line so the instruction stream stays small enough for the instruction cache.  Ex::buf /
 // Ex::twid put the address space of the buffers and of the twiddle table into the pointer types.
 template <int M, int NT, class Ex>
-PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsigned sign_last) {
+PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsigned sign_last, bool edge) {
   auto s = Ex::buf(src);
   auto d = Ex::buf(dst);
-  return fft_fixed_passes<M, 1, NT>(ex, s, d, Ex::twid(twf), sign_last) == s ? src : dst;
+  return fft_fixed_passes<M, 1, NT>(ex, s, d, Ex::twid(twf), sign_last, edge) == s ? src : dst;
 }
 
 // One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
 // `twf`: pass-ordered table of the fixed geometry (LDS or global); T.tw: plain full circle.
+// `edge` in: the caller wants spec[0]=spec[1], spec[-1]=spec[-2] applied to the result;
+// out: whether that is still to be done (the fixed-geometry transform does it in its last pass).
 template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
-                            const TaperArgs& ta) {
+                            const TaperArgs& ta, bool& edge) {
   const int M = n / 2;
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
-      c32* z = fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u);
+      c32* z = fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
       ex.par([&](int t, int) { rfft_taper_phase<VSINI>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
-      return (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u);
+      float* res = (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
+      edge = false;
+      return res;
     }
   }
   const c32* tw = T.tw;
@@ -94,8 +98,11 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer
   const bool direct = (out_stage != 0) && T.rot_identity && (th[5] != 0.0);
   ex.par([&](int t, int n) {
+    RowRegs row;
+    phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     phase_setup(t, n, T, th, instr_factor, S);
-    phase_load(t, n, T.npix, raw, direct ? bufB : bufA, direct);
+    ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
+    phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -104,19 +111,27 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     return;
   }
   const bool rot = S.do_rot != 0, smooth = S.do_smooth != 0;
+  bool edges_pending = false;
   if (rot) {
     if (!direct) ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
     TaperArgs ta{};
     ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
     ta.vs_c = S.vs_a * T.vs_val;                       // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)
     ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
-    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta);
+    // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
+    // transform's last pass can apply the edge rule itself
+    bool edge = T.rot_identity != 0;
+    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge);
     float* dst = (conv == bufA) ? bufB : bufA;
-    if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }          // conv IS on the ANN grid
-    else ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); });
+    if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
+    else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = true; }
     spec = dst;
     work = conv;
-    if (out_stage == 1 || !smooth) ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
+    edges_pending = edge;
+    if (edges_pending && (out_stage == 1 || !smooth)) {
+      ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
+      edges_pending = false;
+    }
   }
   if (out_stage == 1) {
     ex.par([&](int t, int n) { for (int i = t; i < T.npix; i += n) out[i] = spec[i] + kBase; });
@@ -125,18 +140,25 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   const float* on_grid = spec;
   Window W{};
   if (smooth) {
-    const int nthr = ex.nthreads();
-    int* cnt = reinterpret_cast<int*>(red + nthr);
-    ex.par([&](int t, int n) {
-      if (rot) phase_rot_edges(t, T.npix, spec);       // the count does not touch the spectrum
-      phase_mask_count(t, n, T, S, cnt);
-    });
-    W = make_window(T, S, cnt, n_slots(nthr));
+    if (S.win_ready) {                                 // window derived during setup
+      if (edges_pending) ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
+      W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);   // by every thread
+      ex.mark(0);
+    } else {
+      const int nthr = ex.nthreads();
+      int* cnt = reinterpret_cast<int*>(red + nthr);
+      ex.par([&](int t, int n) {
+        if (edges_pending) phase_rot_edges(t, T.npix, spec);   // the count does not touch the spectrum
+        phase_mask_count(t, n, T, S, cnt);
+      });
+      W = make_window(T, S, cnt, n_slots(nthr));
+    }
     if (!W.bad) {
       ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, W, spec, work); });
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
-      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta);
+      bool no_edge = false;
+      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta, no_edge);
     }
   }
   ex.par([&](int t, int n) { store_partial(t, phase_obs(t, n, T, S, W, on_grid, out, out_stage), red); });
