@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the short nested-sampling run behind `end_to_end`")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("PAYNE_BENCH_STREAMS", "1")),
                     help="independent batches in flight (one engine + HIP stream each); a batched sampler with "
                          "two chain populations keeps two batches in flight")
@@ -274,6 +275,17 @@ def main():
         out["whole_path_tflops"] = alg_flops_per_eval(D, H, N) * B / (max(sum(per.values()), 1e-9) * 1e-6) / 1e12
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if world == 1 and not args.no_e2e and B <= 4096 and cfg["npix"] <= 16384:
+        # the same likelihood as the batched nested sampler sees it -- prior transform,
+        # random-walk proposals (device), transfers and the dead-point bookkeeping included
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import sampler_bench
+        eng.close()
+        e2e = sampler_bench.run(args.config, maxcall=250000, nlive=B, walks=25, modes=("device_chunks",))["device_chunks"]
+        out["end_to_end"] = {"value": e2e["evals_per_s"], "unit": "likelihood-evals/s", "calls": e2e["calls"],
+                             "iterations": e2e["iterations"], "seconds": e2e["seconds"],
+                             "what": "static nested sampler, %d live points, rwalk x25 on the device, multi-ellipsoid "
+                                     "bound, dead points consumed in bulk" % B}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

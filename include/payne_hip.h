@@ -212,6 +212,41 @@ int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double* lnprob, in
                       double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
                       void* stream);
 
+/* ---- host-side nested-sampling bookkeeping (no GPU work) ---------------------------------
+ * Replaces the per-iteration body of dynesty's sampling loop as the reference drives it
+ * (Payne/fitting/fitstar.py:332-338: one 15-tuple per dead point) for a QUEUE of proposals
+ * evaluated in one GPU batch: worst live point, trapezoid evidence update, replacement by the
+ * next queued proposal with lnprob > threshold.  All arrays are the caller's. */
+typedef struct payne_ns_state {
+  int nlive, ndim;
+  long long it;            /* iteration number of the next dead point (starts at 1) */
+  long long pending_nc;    /* likelihood calls spent since the last accepted replacement */
+  double logz, logzvar, h, logvol, loglstar;   /* start: -1e300, 0, 0, 0, -1e300 */
+} payne_ns_state;
+
+typedef struct payne_ns_dead {          /* one row per dead point, capacity `cap` rows */
+  int* worst;       double* u;          /* [cap], [cap][ndim] */
+  double* v;        double* logl;       /* [cap][ndim], [cap] */
+  double* logvol;   double* logwt;
+  double* logz;     double* logzvar;
+  double* h;        int* nc;
+  int* worst_it;    double* delta_logz;
+} payne_ns_dead;
+
+#define PAYNE_NS_QUEUE_EMPTY 0   /* every queued proposal was used or rejected */
+#define PAYNE_NS_CONVERGED   1   /* ln(1 + L_max X / Z) < dlogz */
+#define PAYNE_NS_LIMIT       2   /* max_emit or the record capacity reached */
+#define PAYNE_NS_LOGL_MAX    3   /* worst live lnprob >= logl_max */
+
+/* live_*: [nlive][ndim] / [nlive], updated in place.  q*: the proposal queue in order
+ * ([nq][ndim], [nq]; qnc = likelihood calls behind each proposal).  Returns the number of dead
+ * points written to `out` (>= 0) or a negative error code; *consumed = queue entries used up,
+ * *stop = one of PAYNE_NS_*. */
+int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_v, double* live_logl, int* live_it,
+                     const double* qu, const double* qv, const double* ql, const int* qnc, int nq,
+                     double dlogz, long long max_emit, double logl_max, payne_ns_dead* out, int cap,
+                     int* consumed, int* stop);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

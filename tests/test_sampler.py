@@ -76,3 +76,57 @@ def test_nan_likelihood_is_never_accepted_and_limits_hold():
     assert np.all(s.live_v[np.isfinite(s.live_logl), 0] <= 0.6)
     with pytest.raises(NotImplementedError):
         NestedSampler(ll, ptform_batch, NDIM, sample="slice")
+
+
+def test_native_bookkeeping_matches_python_loop():
+    """payne_ns_consume (C++) against the same loop in Python: identical dead points, evidence and live set."""
+    from thepayne_amd.build import build_lib
+    build_lib()
+    nd = 4
+
+    def ll(V):
+        return -0.5 * np.sum(((V - 0.5) / 0.05) ** 2, axis=1)
+
+    runs = []
+    for native in (True, False):
+        S = NestedSampler(ll, lambda U: U, nd, nlive=64, bound='single', sample='rwalk', walks=10, batched=True,
+                          queue_size=64, rstate=np.random.default_rng(5), native=native)
+        tuples = list(S.sample(dlogz=0.05, maxiter=700))
+        tuples += list(S.add_live_points())
+        runs.append((S, tuples))
+    (Sn, tn), (Sp, tp) = runs
+    assert len(tn) == len(tp) > 500
+    for a, b in zip(tn, tp):
+        assert a[0] == b[0] and a[9] == b[9] and a[10] == b[10]                 # worst, nc, worst_it
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])       # ustar, vstar
+        np.testing.assert_allclose([a[i] for i in (3, 4, 5, 6, 7, 8, 13, 14)], [b[i] for i in (3, 4, 5, 6, 7, 8, 13, 14)],
+                                   rtol=1e-12, atol=1e-12)
+    assert np.array_equal(Sn.live_u, Sp.live_u) and Sn.ncall == Sp.ncall and Sn.it == Sp.it
+    rn, rp = Sn.results, Sp.results
+    assert rn.niter == len(tn) and np.allclose(rn.logz, rp.logz, rtol=1e-12)
+    # analytic evidence of the Gaussian in the unit cube: ln((2 pi)^(nd/2) sigma^nd)
+    assert abs(rn.logz[-1] - (0.5 * nd * np.log(2 * np.pi) + nd * np.log(0.05))) < 5 * rn.logzerr[-1] + 0.3
+
+
+def test_fitpayne_bulk_rows_equal_single_rows(tmp_path):
+    import io
+    from thepayne_amd.fitting.fitstar import FitPayne
+
+    class _L:
+        fitpars_i = ['Teff', 'log(g)', 'Vrad']
+    F = FitPayne()
+    F.likeobj, F.fitargs_fixed = _L(), {'[Fe/H]': -0.25, 'Vrad': 3.0}
+    F.parnames = ['Teff', 'log(g)', 'Vrad', '[Fe/H]']
+    rng = np.random.default_rng(0)
+    m = 7
+    rec = {"v": rng.normal(size=(m, 3)) * 1e3, "logl": rng.normal(size=m), "logvol": -rng.uniform(size=m),
+           "logwt": rng.normal(size=m), "h": rng.uniform(size=m), "nc": rng.integers(1, 40, m).astype(np.int32),
+           "logz": rng.normal(size=m), "delta_logz": rng.uniform(size=m) * 10}
+    F.outff = io.StringIO()
+    F._rows(11, rec)
+    bulk = F.outff.getvalue()
+    F.outff = io.StringIO()
+    for i in range(m):
+        F._row(11 + i, rec["v"][i], (rec["logl"][i], rec["logvol"][i], rec["logwt"][i], rec["h"][i], rec["nc"][i],
+                                     rec["logz"][i], rec["delta_logz"][i]))
+    assert bulk == F.outff.getvalue() and bulk.count('\n') == m

@@ -18,7 +18,7 @@ SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
-           "payne_rwalk_batch"]
+           "payne_rwalk_batch", "payne_ns_consume"]
 
 PAYNE_MAX_DIM, PAYNE_MAX_FIXED = 24, 16
 PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_TGAUSSIAN, PRIOR_EXP, PRIOR_TEXP, PRIOR_LOGUNIFORM = range(6)
@@ -59,6 +59,21 @@ class PriorDim(C.Structure):
 class SamplerDesc(C.Structure):
     _fields_ = [("ndim", C.c_int), ("dims", PriorDim * 24), ("n_fixed", C.c_int),
                 ("fixed_col", C.c_int * 16), ("fixed_val", C.c_double * 16)]
+
+
+class NsState(C.Structure):
+    _fields_ = [("nlive", C.c_int), ("ndim", C.c_int), ("it", C.c_longlong), ("pending_nc", C.c_longlong),
+                ("logz", C.c_double), ("logzvar", C.c_double), ("h", C.c_double), ("logvol", C.c_double),
+                ("loglstar", C.c_double)]
+
+
+class NsDead(C.Structure):
+    # (plain addresses: ndarray.ctypes.data_as costs tens of microseconds per array)
+    _fields_ = [(k, C.c_void_p) for k in ("worst", "u", "v", "logl", "logvol", "logwt", "logz", "logzvar", "h", "nc",
+                                          "worst_it", "delta_logz")]
+
+
+NS_QUEUE_EMPTY, NS_CONVERGED, NS_LIMIT, NS_LOGL_MAX = range(4)
 
 
 class PayneLibraryError(RuntimeError):
@@ -126,6 +141,10 @@ def load(path=None):
     lib.payne_rwalk_batch.restype = C.c_int
     lib.payne_kernel_name.argtypes = [C.c_int]
     lib.payne_kernel_name.restype = C.c_char_p
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    lib.payne_ns_consume.argtypes = [C.POINTER(NsState), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_double,
+                                     C.c_longlong, C.c_double, C.POINTER(NsDead), C.c_int, ip, ip]
+    lib.payne_ns_consume.restype = C.c_int
     if lib.payne_version() != ABI_VERSION:
         raise PayneLibraryError("ABI version %d != %d" % (lib.payne_version(), ABI_VERSION))
     _lib = lib

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpayne_hip.so")
 SOURCES = ["payne_hip.hip"]
-HEADERS = ["post_core.hpp", "post_seq.hpp", "host_tables.hpp"]
+HEADERS = ["post_core.hpp", "post_seq.hpp", "host_tables.hpp", "ns_core.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc",
                "-DNDEBUG", "-Wall", "-Wno-unused-function"]
 

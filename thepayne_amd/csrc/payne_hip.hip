@@ -24,6 +24,7 @@
 #include "../../include/payne_hip.h"
 #include "host_tables.hpp"
 #include "post_seq.hpp"
+#include "ns_core.hpp"
 
 using namespace payne;
 

@@ -175,6 +175,20 @@ class FitPayne(object):
         self.outff.write(' {0} {1} {2} {3} {4} {5} {6} '.format(loglstar, logvol, logwt, h, nc, logz, delta_logz))
         self.outff.write('\n')
 
+    def _rows(self, it0, rec):
+        """The rows of one chunk of dead points, same text as ``_row`` one by one."""
+        names, fixed = self.likeobj.fitpars_i, self.fitargs_fixed
+        col = {pp: j for j, pp in enumerate(names)}
+        V = rec["v"].tolist()
+        tail = zip(rec["logl"].tolist(), rec["logvol"].tolist(), rec["logwt"].tolist(), rec["h"].tolist(),
+                   rec["nc"].tolist(), rec["logz"].tolist(), rec["delta_logz"].tolist())
+        fixed_s = {q: str(fixed[q]) for q in self.parnames if q in fixed}   # a fixed entry overrides (pars.update)
+        lines = []
+        for i, (v, t) in enumerate(zip(V, tail)):
+            pars = ' '.join([fixed_s[q] if q in fixed_s else str(v[col[q]]) for q in self.parnames])
+            lines.append('{0} {1} {2} {3} {4} {5} {6} {7} {8} \n'.format(it0 + i, pars, *t))
+        self.outff.write(''.join(lines))
+
     def _runsampler(self, samplerdict):
         npoints = samplerdict.get('npoints', 200)
         bound = samplerdict.get('samplerbounds', 'multi')
@@ -212,31 +226,31 @@ class FitPayne(object):
         self.parnames = list(self.likeobj.fitpars_i) + list(self.fitargs['fixedpars'].keys())
         self.fitargs_fixed = dict(self.fitargs['fixedpars'])
         self._initoutput(self.parnames)
-        ncall, nit = 0, 0
+        ncall, nit = 0, -1
         t_iter = datetime.now()
-        dts = []
         print('Start Sampling @ {}'.format(t_iter))
-        for it, results in enumerate(sampler.sample(dlogz=delta_logz_final, maxiter=maxiter, maxcall=maxcall)):
-            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
-             h, nc, worst_it, propidx, propiter, eff, delta_logz) = results
-            self._row(it, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
-            ncall += nc
-            nit = it
-            dts.append((datetime.now() - t_iter).total_seconds() / float(nc))
-            t_iter = datetime.now()
-            if ((it % flushnum) == 0) or (it == maxiter):
+        # dead points arrive a consumed queue at a time (arrays); rows keep the reference's text format
+        for rec in sampler.sample_chunks(dlogz=delta_logz_final, maxiter=maxiter, maxcall=maxcall):
+            m = len(rec["logl"])
+            self._rows(nit + 1, rec)
+            nc_chunk = int(rec["nc"].sum())
+            ncall += nc_chunk
+            first, nit = nit + 1, nit + m
+            if (first // flushnum) != ((nit + 1) // flushnum) or first == 0 or nit >= maxiter:
                 self.outff.flush()
                 if self.verbose:
+                    now = datetime.now()
+                    logzvar = float(rec["logzvar"][-1])
                     logzerr = np.sqrt(logzvar) if logzvar > 0. else np.nan
                     sys.stdout.write("\riter: {0:d} | nc: {1:d} | ncall: {2:d} | eff(%): {3:6.3f} | "
                                      "logz: {4:6.3f} +/- {5:6.3f} | loglk: {6:6.3f} | dlogz: {7:6.3f} > {8:6.3f}   | "
                                      "mean(time):  {9:7.5f} | time: {10} \n".format(
-                                         nit, nc, ncall, eff, logz, logzerr, loglstar, delta_logz, delta_logz_final,
-                                         np.mean(dts), datetime.now()))
+                                         nit, int(rec["nc"][-1]), ncall, float(rec["eff"][-1]), float(rec["logz"][-1]),
+                                         logzerr, float(rec["logl"][-1]), float(rec["delta_logz"][-1]), delta_logz_final,
+                                         (now - t_iter).total_seconds() / max(1, nc_chunk), now))
                     sys.stdout.flush()
-                    dts = []
-            if it == maxiter:
-                break
+            t_iter = datetime.now()
+        nit = max(nit, 0)
         for it2, results in enumerate(sampler.add_live_points()):
             (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
              h, nc, worst_it, boundidx, bounditer, eff, delta_logz) = results

@@ -66,6 +66,7 @@ class DeviceProposer(object):
         self._lp = self.torch.empty(self.k_max, dtype=f64, device=dev)
         self._nacc = self.torch.empty(self.k_max, dtype=i32, device=dev)
         self._ncall = self.torch.empty(self.k_max, dtype=i32, device=dev)
+        self._pack_h = None                  # pinned staging for rwalk, made on first use
 
     # -- prior description -----------------------------------------------------------
     def _kind(self, name):
@@ -132,22 +133,38 @@ class DeviceProposer(object):
 
     def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed):
         """K lock-step random-walk chains of `walks` steps under lnprob > loglstar.
-        Returns (U, V, lnprob, nacc, ncall) as numpy arrays."""
-        K = len(U)
+        Returns (U, V, lnprob, nacc, ncall) as numpy arrays.  One packed pinned transfer each way."""
+        K, nd = len(U), self.ndim
         if K > self.k_max:
             raise ValueError("K > k_max")
-        self._up(U, self._u)
-        self._up(V, self._v)
-        self._lp[:K].copy_(self.torch.as_tensor(np.ascontiguousarray(lnprob, dtype=np.float64)))
+        if self._pack_h is None:
+            t = self.torch
+            n = self.k_max * (2 * nd + 1)
+            self._pack_h = t.empty(n, dtype=t.float64).pin_memory()
+            self._pack_d = t.empty(n, dtype=t.float64, device=self.eng.device)
+            self._ipack_h = t.empty(2 * self.k_max, dtype=t.int32).pin_memory()
+            self._ipack_d = t.empty(2 * self.k_max, dtype=t.int32, device=self.eng.device)
+        n = K * (2 * nd + 1)
+        h = self._pack_h.numpy()
+        h[:K * nd] = np.asarray(U, dtype=np.float64).reshape(-1)
+        h[K * nd:2 * K * nd] = np.asarray(V, dtype=np.float64).reshape(-1)
+        h[2 * K * nd:n] = lnprob
+        d = self._pack_d
+        d[:n].copy_(self._pack_h[:n], non_blocking=True)
+        pu, pv, pl = d.data_ptr(), d.data_ptr() + 8 * K * nd, d.data_ptr() + 16 * K * nd
         ax = np.ascontiguousarray(axes, dtype=np.float64)
-        rc = self.lib.payne_rwalk_batch(self._handle, self._u.data_ptr(), self._v.data_ptr(), self._lp.data_ptr(), K,
-                                        ax.ctypes.data_as(C.POINTER(C.c_double)), float(scale), float(loglstar), int(walks),
-                                        int(seed) & 0xFFFFFFFFFFFFFFFF, self._nacc.data_ptr(), self._ncall.data_ptr(),
-                                        self._stream())
+        rc = self.lib.payne_rwalk_batch(self._handle, pu, pv, pl, K, C.cast(ax.ctypes.data, C.POINTER(C.c_double)),
+                                        float(scale), float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                        self._ipack_d.data_ptr(), self._ipack_d.data_ptr() + 4 * K, self._stream())
         if rc != 0:
             self.eng._err(rc, "payne_rwalk_batch")
-        return (self._u[:K].cpu().numpy(), self._v[:K].cpu().numpy(), self._lp[:K].cpu().numpy(),
-                self._nacc[:K].cpu().numpy(), self._ncall[:K].cpu().numpy())
+        self._pack_h[:n].copy_(d[:n], non_blocking=True)
+        self._ipack_h[:2 * K].copy_(self._ipack_d[:2 * K], non_blocking=True)
+        self.torch.cuda.current_stream(self.eng.device).synchronize()
+        h = self._pack_h.numpy()
+        ih = self._ipack_h.numpy()
+        return (h[:K * nd].reshape(K, nd).copy(), h[K * nd:2 * K * nd].reshape(K, nd).copy(), h[2 * K * nd:n].copy(),
+                ih[:K].astype(np.int64), ih[K:2 * K].astype(np.int64))
 
     def close(self):
         if self._handle.value:

@@ -9,7 +9,10 @@ the subset of that contract the reference uses, re-designed around BATCHED likel
 calls: proposals are generated ``queue_size`` at a time as lock-step chains, so every
 chain step is one GPU batch (the same "queue" parallelisation dynesty applies with a
 pool: a proposal made under an older likelihood threshold is kept iff it still beats the
-current one).
+current one).  The per-iteration bookkeeping (worst point, evidence update, replacement from
+the queue) runs in C++ (``payne_ns_consume`` in include/payne_hip.h) a queue at a time;
+``sample()`` replays the resulting records as dynesty's 15-tuples, ``sample_chunks()`` hands
+them over as arrays for consumers that can work in bulk (FitPayne's output writer).
 
 Algorithm (Skilling 2004/2006 static nested sampling; trapezoid evidence weights):
   * nlive points drawn from the unit cube; at iteration i the worst live point
@@ -22,8 +25,8 @@ Algorithm (Skilling 2004/2006 static nested sampling; trapezoid evidence weights
     factor (target acceptance 0.5);
   * stop when ln(1 + L_max X / Z) < dlogz, then ``add_live_points`` closes the integral.
 """
+import ctypes as C
 import math
-from collections import deque
 
 import numpy as np
 
@@ -43,7 +46,8 @@ def _unit_ball(rng, n, ndim):
 class NestedSampler(object):
     def __init__(self, loglikelihood, prior_transform, ndim, nlive=500, bound='multi', sample='unif',
                  logl_args=None, bootstrap=0, walks=25, slices=5, enlarge=None, rstate=None,
-                 batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None, **ignored):
+                 batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None,
+                 native=True, **ignored):
         if sample not in ('unif', 'rwalk'):
             raise NotImplementedError("sample=%r: this driver provides 'unif' and 'rwalk'" % (sample,))
         if bound not in ('none', 'single', 'multi'):
@@ -73,19 +77,27 @@ class NestedSampler(object):
         else:
             self.live_v = self._ptform(self.live_u)
             self.live_logl = self._eval(self.live_v)
-        self.live_it = np.zeros(self.nlive, dtype=int)
+        self.live_u = np.ascontiguousarray(self.live_u, dtype=np.float64)
+        self.live_v = np.ascontiguousarray(self.live_v, dtype=np.float64)
+        self.live_logl = np.ascontiguousarray(self.live_logl, dtype=np.float64)
+        self.live_it = np.zeros(self.nlive, dtype=np.int32)
         self.ncall = self.nlive
         self.it = 1
         self.scale = 1.0
-        self._queue = deque()
-        self._queue_logl_min = -np.inf
+        self._pending_nc = 0
+        self._clear_queue()
         self._since_update = 0
+        # native bookkeeping (C++); native=False keeps the same loop in Python (cross-check / no library)
+        self._lib = None
+        if native:
+            from .. import _lib
+            self._lib = _lib.load()
+            self._L = _lib
         self._axes = None
         self.nbound = 1
         self.update_interval = int(update_interval) if update_interval and update_interval >= 1 else max(1, int(0.6 * self.nlive))
         # saved run
-        self.saved = {k: [] for k in ("id", "u", "v", "logl", "logvol", "logwt", "logz", "logzvar", "h", "nc", "it",
-                                      "boundidx", "bounditer", "scale")}
+        self._chunks = []                      # dead-point records, one dict of arrays per consumed queue
         self.logz, self.logzvar, self.h, self.logvol, self.loglstar = -1e300, 0.0, 0.0, 0.0, -1e300
         self.eff = 100.0
         self.added_live = False
@@ -117,6 +129,19 @@ class NestedSampler(object):
         self._since_update = 0
 
     # ---- proposal generation: fills the queue with batched evaluations -------------------
+    def _clear_queue(self):
+        nd = self.ndim
+        self._qU, self._qV = np.empty((0, nd)), np.empty((0, nd))
+        self._ql, self._qnc = np.empty(0), np.empty(0, dtype=np.int32)
+        self._qpos = 0
+
+    def _set_queue(self, U, V, ll, nc):
+        self._qU = np.ascontiguousarray(U, dtype=np.float64)
+        self._qV = np.ascontiguousarray(V, dtype=np.float64)
+        self._ql = np.ascontiguousarray(ll, dtype=np.float64)
+        self._qnc = np.ascontiguousarray(nc, dtype=np.int32)
+        self._qpos = 0
+
     def _fill_queue(self):
         K, nd, rng = self.queue_size, self.ndim, self.rng
         lstar = self.loglstar
@@ -128,112 +153,174 @@ class NestedSampler(object):
             else:
                 U = self._ctr + _unit_ball(rng, K, nd) @ self._axes.T
             inside = np.all((U > 0.0) & (U < 1.0), axis=1)
-            V = np.empty((K, nd))
-            ll = np.full(K, -np.inf)
-            if inside.any():
+            U = U[inside]
+            nin = len(U)
+            if nin:
                 if self.proposer is not None:
-                    V[inside], lli = self.proposer.lnprob_u(U[inside])
-                    ll[inside] = np.where(np.isnan(lli), -np.inf, lli)
+                    V, ll = self.proposer.lnprob_u(U)
+                    ll = np.where(np.isnan(ll), -np.inf, ll)
                 else:
-                    V[inside] = self._ptform(U[inside])
-                    ll[inside] = self._eval(V[inside])
-            nin = int(inside.sum())
-            self.ncall += nin
-            for i in np.nonzero(inside)[0]:
-                self._queue.append((U[i].copy(), V[i].copy(), ll[i], 1))
-            if nin == 0:
+                    V = self._ptform(U)
+                    ll = self._eval(V)
+                self._set_queue(U, V, ll, np.ones(nin, dtype=np.int32))
+            else:
+                self._clear_queue()
                 self._update_bound()
+            self.ncall += nin
             return
         # rwalk: K lock-step chains
         start = rng.integers(0, self.nlive, size=K)
         U, V, ll = self.live_u[start].copy(), self.live_v[start].copy(), self.live_logl[start].copy()
-        nacc = np.zeros(K, dtype=int)
-        ncalls = np.zeros(K, dtype=int)
         if self.proposer is not None:      # all `walks` steps of all K chains in one device call
             U, V, ll, nacc, ncalls = self.proposer.rwalk(U, V, ll, self._axes_unit, self.scale, lstar, self.walks,
                                                         int(rng.integers(0, 2 ** 62)))
             ll = np.where(np.isnan(ll), -np.inf, ll)
-        for _ in range(self.walks if self.proposer is None else 0):
-            prop = U + self.scale * (_unit_ball(rng, K, nd) @ self._axes_unit.T)
-            inside = np.all((prop > 0.0) & (prop < 1.0), axis=1)
-            if not inside.any():
-                continue
-            pv = self._ptform(prop[inside])
-            pl = self._eval(pv)
-            ncalls[inside] += 1
-            ok = pl > lstar
-            idx = np.nonzero(inside)[0][ok]
-            U[idx], V[idx], ll[idx] = prop[idx], pv[ok], pl[ok]
-            nacc[idx] += 1
+        else:
+            nacc = np.zeros(K, dtype=np.int64)
+            ncalls = np.zeros(K, dtype=np.int64)
+            for _ in range(self.walks):
+                prop = U + self.scale * (_unit_ball(rng, K, nd) @ self._axes_unit.T)
+                inside = np.all((prop > 0.0) & (prop < 1.0), axis=1)
+                if not inside.any():
+                    continue
+                pv = self._ptform(prop[inside])
+                pl = self._eval(pv)
+                ncalls[inside] += 1
+                ok = pl > lstar
+                idx = np.nonzero(inside)[0][ok]
+                U[idx], V[idx], ll[idx] = prop[idx], pv[ok], pl[ok]
+                nacc[idx] += 1
         self.ncall += int(ncalls.sum())
         frac = nacc.sum() / max(1, ncalls.sum())
         # dynesty-like scale adaptation towards 50 % acceptance
-        self.scale *= math.exp((frac - 0.5) / nd / (0.5 if frac > 0.5 else 0.5))
+        self.scale *= math.exp((frac - 0.5) / nd / 0.5)
         self.scale = min(max(self.scale, 1e-4), 4.0)
-        for i in range(K):
-            if nacc[i] > 0:                                   # a chain that never moved is a copy of a live point
-                self._queue.append((U[i], V[i], ll[i], max(1, int(ncalls[i]))))
-            else:
-                self._pending_nc = getattr(self, "_pending_nc", 0) + int(ncalls[i])
+        moved = nacc > 0                                      # a chain that never moved is a copy of a live point
+        self._pending_nc += int(ncalls[~moved].sum())
+        self._set_queue(U[moved], V[moved], ll[moved], np.maximum(1, ncalls[moved]))
 
-    def _new_point(self):
-        nc = getattr(self, "_pending_nc", 0)
-        self._pending_nc = 0
-        while True:
-            if not self._queue:
-                self._fill_queue()
-                nc += getattr(self, "_pending_nc", 0)
-                self._pending_nc = 0
-                continue
-            u, v, ll, c = self._queue.popleft()
-            nc += c
-            if ll > self.loglstar:
-                return u, v, ll, nc
+    # ---- the bookkeeping loop over one queue --------------------------------------------------
+    def _records(self, m):
+        nd = self.ndim
+        return {"worst": np.empty(m, np.int32), "u": np.empty((m, nd)), "v": np.empty((m, nd)), "logl": np.empty(m),
+                "logvol": np.empty(m), "logwt": np.empty(m), "logz": np.empty(m), "logzvar": np.empty(m),
+                "h": np.empty(m), "nc": np.empty(m, np.int32), "worst_it": np.empty(m, np.int32),
+                "delta_logz": np.empty(m)}
 
-    # ---- dynesty-contract generators ----------------------------------------------------
-    def sample(self, maxiter=None, maxcall=None, dlogz=0.01, logl_max=np.inf, **ignored):
-        maxiter = np.inf if maxiter is None else maxiter
-        maxcall = np.inf if maxcall is None else maxcall
-        dlv = math.log((self.nlive + 1.0) / self.nlive)
-        niter_here = 0
+    def _consume(self, dlogz, max_emit, logl_max):
+        """Walk the queue: returns (records, stop) with stop in {'queue', 'converged', 'limit', 'logl_max'}."""
+        nq = len(self._ql) - self._qpos
+        cap = int(min(max_emit, max(nq, 0)))
+        rec = self._records(cap)
+        if self._lib is not None:
+            L = self._L
+            st = L.NsState(self.nlive, self.ndim, int(self.it), int(self._pending_nc), self.logz, self.logzvar, self.h,
+                           self.logvol, self.loglstar)
+            A = lambda a: a.ctypes.data                                              # noqa: E731
+            dead = L.NsDead(*[A(rec[k]) for k in ("worst", "u", "v", "logl", "logvol", "logwt", "logz", "logzvar", "h",
+                                                  "nc", "worst_it", "delta_logz")])
+            q0, nd = self._qpos, self.ndim
+            consumed, stop = C.c_int(0), C.c_int(0)
+            m = self._lib.payne_ns_consume(C.byref(st), A(self.live_u), A(self.live_v), A(self.live_logl),
+                                           A(self.live_it), A(self._qU) + q0 * nd * 8, A(self._qV) + q0 * nd * 8,
+                                           A(self._ql) + q0 * 8, A(self._qnc) + q0 * 4, nq, float(dlogz),
+                                           int(min(max_emit, 2 ** 62)), float(logl_max), C.byref(dead), cap,
+                                           C.byref(consumed), C.byref(stop))
+            if m < 0:
+                raise RuntimeError("payne_ns_consume failed (%d)" % m)
+            self._qpos += consumed.value
+            self.it, self._pending_nc = int(st.it), int(st.pending_nc)
+            self.logz, self.logzvar, self.h, self.logvol, self.loglstar = st.logz, st.logzvar, st.h, st.logvol, st.loglstar
+            stop = ('queue', 'converged', 'limit', 'logl_max')[stop.value]
+        else:
+            m, stop = self._consume_py(rec, dlogz, max_emit, logl_max, cap)
+        if m < cap:
+            rec = {k: v[:m] for k, v in rec.items()}
+        return rec, stop
+
+    def _consume_py(self, rec, dlogz, max_emit, logl_max, cap):
+        """The loop of payne_ns_consume in Python (thepayne_amd/csrc/ns_core.hpp), statement for statement."""
+        n = self.nlive
+        dlv = math.log((n + 1.0) / n)
+        logdfac = math.log(0.5 * math.expm1(dlv))
+        lae = _logaddexp
+        ql, qnc, nq = self._ql, self._qnc, len(self._ql)
+        m, stop = 0, 'queue'
         while True:
-            logz_remain = self.live_logl.max() + self.logvol
-            delta_logz = np.logaddexp(self.logz, logz_remain) - self.logz if self.logz > -1e299 else np.inf
-            if niter_here >= maxiter or self.ncall >= maxcall or delta_logz < dlogz:
-                break
             worst = int(np.argmin(self.live_logl))
-            ustar, vstar = self.live_u[worst].copy(), self.live_v[worst].copy()
-            loglstar_new = self.live_logl[worst]
-            worst_it = self.live_it[worst]
-            if loglstar_new >= logl_max:
-                break
-            # evidence update (trapezoid rule on ln X)
+            lmin, lmax = float(self.live_logl[worst]), float(self.live_logl.max())
+            delta = lae(self.logz, lmax + self.logvol) - self.logz if self.logz > -1e299 else np.inf
+            if delta < dlogz:
+                stop = 'converged'; break
+            if m >= max_emit or m >= cap:
+                stop = 'limit'; break
+            if lmin >= logl_max:
+                stop = 'logl_max'; break
+            nc = self._pending_nc
+            while self._qpos < nq and not (ql[self._qpos] > lmin):
+                nc += int(qnc[self._qpos]); self._qpos += 1
+            if self._qpos >= nq:
+                self._pending_nc = nc; stop = 'queue'; break
+            q = self._qpos
+            nc += int(qnc[q])
+            self._pending_nc = 0
             logvol = self.logvol - dlv
-            logdvol = math.log(0.5 * math.expm1(dlv)) + logvol          # 0.5 (X_{i-1} - X_i)
-            logwt = np.logaddexp(loglstar_new, self.loglstar) + logdvol
-            logz_new = np.logaddexp(self.logz, logwt)
-            lzterm = (math.exp(self.loglstar - logz_new + logdvol) * self.loglstar if self.loglstar > -1e299 else 0.0) + \
-                     (math.exp(loglstar_new - logz_new + logdvol) * loglstar_new if np.isfinite(loglstar_new) else 0.0)
-            h_new = lzterm + (math.exp(self.logz - logz_new) * (self.h + self.logz) if self.logz > -1e299 else 0.0) - logz_new
+            logdvol = logdfac + logvol
+            logwt = lae(lmin, self.loglstar) + logdvol
+            logz_new = lae(self.logz, logwt)
+            lz = (math.exp(self.loglstar - logz_new + logdvol) * self.loglstar if self.loglstar > -1e299 else 0.0) + \
+                 (math.exp(lmin - logz_new + logdvol) * lmin if math.isfinite(lmin) else 0.0)
+            h_new = lz + (math.exp(self.logz - logz_new) * (self.h + self.logz) if self.logz > -1e299 else 0.0) - logz_new
             dh = h_new - self.h
             self.h, self.logz = h_new, logz_new
             self.logzvar += dh * dlv
-            self.logvol = logvol
-            self.loglstar = loglstar_new
-            if self._since_update >= self.update_interval or (self._axes is None and self.bound != 'none'):
-                self._update_bound()
-                self._queue.clear()
-            u, v, ll, nc = self._new_point()
-            self._since_update += 1
-            self.live_u[worst], self.live_v[worst], self.live_logl[worst], self.live_it[worst] = u, v, ll, self.it
-            self.eff = 100.0 * self.it / self.ncall
-            logz_remain = self.live_logl.max() + self.logvol
-            delta_logz = np.logaddexp(self.logz, logz_remain) - self.logz
-            self._save(worst, ustar, vstar, loglstar_new, logvol, logwt, nc, worst_it)
-            yield (worst, ustar, vstar, loglstar_new, logvol, logwt, self.logz, self.logzvar, self.h, nc,
-                   worst_it, 0, self.nbound, self.eff, delta_logz)
+            self.logvol, self.loglstar = logvol, lmin
+            rec["worst"][m] = worst; rec["u"][m] = self.live_u[worst]; rec["v"][m] = self.live_v[worst]
+            rec["logl"][m] = lmin; rec["logvol"][m] = logvol; rec["logwt"][m] = logwt; rec["logz"][m] = self.logz
+            rec["logzvar"][m] = self.logzvar; rec["h"][m] = self.h; rec["nc"][m] = nc; rec["worst_it"][m] = self.live_it[worst]
+            self.live_u[worst], self.live_v[worst] = self._qU[q], self._qV[q]
+            self.live_logl[worst], self.live_it[worst] = ql[q], self.it
+            self._qpos += 1
+            rec["delta_logz"][m] = lae(self.logz, float(self.live_logl.max()) + self.logvol) - self.logz
             self.it += 1
-            niter_here += 1
+            m += 1
+        return m, stop
+
+    # ---- dynesty-contract generators ----------------------------------------------------
+    def sample_chunks(self, maxiter=None, maxcall=None, dlogz=0.01, logl_max=np.inf, **ignored):
+        """The sampling loop, one dict of record ARRAYS per consumed queue (keys: worst, u, v, logl, logvol,
+        logwt, logz, logzvar, h, nc, worst_it, delta_logz, plus it0 / bounditer / eff)."""
+        maxiter = np.inf if maxiter is None else maxiter
+        maxcall = np.inf if maxcall is None else maxcall
+        niter_here = 0
+        while niter_here < maxiter and self.ncall < maxcall:
+            if self._since_update >= self.update_interval or (self._axes is None and self.bound != 'none'):
+                self._update_bound()      # (queued proposals stay: each is still tested against the current threshold)
+            if self._qpos >= len(self._ql):
+                self._fill_queue()
+            room = min(maxiter - niter_here, self.update_interval - self._since_update)
+            it0 = self.it
+            rec, stop = self._consume(dlogz, max(1, room), logl_max)
+            m = len(rec["logl"])
+            if m:
+                its = np.arange(it0, it0 + m)
+                rec["it0"] = it0
+                rec["bounditer"] = np.full(m, self.nbound, dtype=np.int64)
+                rec["eff"] = 100.0 * its / self.ncall
+                rec["scale"] = np.full(m, self.scale)
+                self.eff = float(rec["eff"][-1])
+                self._since_update += m
+                niter_here += m
+                self._chunks.append(rec)
+                yield rec
+            if stop in ('converged', 'logl_max'):
+                break
+
+    def sample(self, maxiter=None, maxcall=None, dlogz=0.01, logl_max=np.inf, **ignored):
+        """dynesty's generator contract: one 15-tuple per dead point (fitstar.py:337-338)."""
+        for rec in self.sample_chunks(maxiter=maxiter, maxcall=maxcall, dlogz=dlogz, logl_max=logl_max):
+            for t in _tuples(rec):
+                yield t
 
     def add_live_points(self):
         """Append the remaining live points (dynesty's add_live_points contract)."""
@@ -259,9 +346,17 @@ class NestedSampler(object):
             self.loglstar = ll
             self.logvol = logvol
             delta_logz = 0.0 if rank == n - 1 else np.logaddexp(self.logz, self.live_logl.max() + logvol) - self.logz
-            self._save(int(i), self.live_u[i].copy(), self.live_v[i].copy(), ll, logvol, logwt, 1, self.live_it[i])
-            yield (int(i), self.live_u[i].copy(), self.live_v[i].copy(), ll, logvol, logwt, self.logz, self.logzvar,
-                   self.h, 1, self.live_it[i], 0, self.nbound, self.eff, delta_logz)
+            rec = self._records(1)
+            rec["worst"][0] = i; rec["u"][0] = self.live_u[i]; rec["v"][0] = self.live_v[i]; rec["logl"][0] = ll
+            rec["logvol"][0] = logvol; rec["logwt"][0] = logwt; rec["logz"][0] = self.logz
+            rec["logzvar"][0] = self.logzvar; rec["h"][0] = self.h; rec["nc"][0] = 1; rec["worst_it"][0] = self.live_it[i]
+            rec["delta_logz"][0] = delta_logz
+            rec["it0"] = self.it
+            rec["bounditer"] = np.full(1, self.nbound, dtype=np.int64)
+            rec["eff"] = np.full(1, self.eff)
+            rec["scale"] = np.full(1, self.scale)
+            self._chunks.append(rec)
+            yield next(_tuples(rec))
 
     def run_nested(self, dlogz=0.01, maxiter=None, maxcall=None, add_live=True, **kw):
         for _ in self.sample(dlogz=dlogz, maxiter=maxiter, maxcall=maxcall):
@@ -270,23 +365,18 @@ class NestedSampler(object):
             for _ in self.add_live_points():
                 pass
 
-    def _save(self, idx, u, v, logl, logvol, logwt, nc, it):
-        s = self.saved
-        s["id"].append(idx); s["u"].append(u); s["v"].append(v); s["logl"].append(logl)
-        s["logvol"].append(logvol); s["logwt"].append(logwt); s["logz"].append(self.logz)
-        s["logzvar"].append(self.logzvar); s["h"].append(self.h); s["nc"].append(nc); s["it"].append(it)
-        s["boundidx"].append(0); s["bounditer"].append(self.nbound); s["scale"].append(self.scale)
-
     @property
     def results(self):
-        s = self.saved
-        logwt = np.array(s["logwt"])
-        logz = np.array(s["logz"])
-        return Results(nlive=self.nlive, niter=len(s["logl"]), ncall=np.array(s["nc"]), eff=self.eff,
-                       samples=np.array(s["v"]), samples_u=np.array(s["u"]), samples_id=np.array(s["id"]),
-                       samples_it=np.array(s["it"]), logl=np.array(s["logl"]), logvol=np.array(s["logvol"]),
-                       logwt=logwt, logz=logz, logzerr=np.sqrt(np.maximum(np.array(s["logzvar"]), 0.0)),
-                       information=np.array(s["h"]), scale=np.array(s["scale"]))
+        ch = self._chunks
+        cat = (lambda k: np.concatenate([c[k] for c in ch])) if ch else (lambda k: np.empty(0))
+        logz = cat("logz")
+        samples = cat("v") if ch else np.empty((0, self.ndim))
+        samples_u = cat("u") if ch else np.empty((0, self.ndim))
+        return Results(nlive=self.nlive, niter=len(logz), ncall=cat("nc"), eff=self.eff,
+                       samples=samples, samples_u=samples_u, samples_id=cat("worst"),
+                       samples_it=cat("worst_it"), logl=cat("logl"), logvol=cat("logvol"),
+                       logwt=cat("logwt"), logz=logz, logzerr=np.sqrt(np.maximum(cat("logzvar"), 0.0)),
+                       information=cat("h"), scale=cat("scale"))
 
     def posterior_weights(self):
         r = self.results
@@ -308,3 +398,20 @@ class NestedSampler(object):
             q = [float(x[o][min(len(x) - 1, np.searchsorted(cw, p))]) for p in (0.16, 0.5, 0.84)]
             out += [mean, std] + q
         return np.array(out, dtype=np.float64)
+
+
+def _logaddexp(a, b):
+    if a == b:
+        return a + 0.6931471805599453
+    m, d = (a, b - a) if a > b else (b, a - b)
+    return m + math.log1p(math.exp(d)) if d == d else a + b
+
+
+def _tuples(rec):
+    """Record arrays -> dynesty's 15-tuples (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar, h, nc,
+    worst_it, boundidx, bounditer, eff, delta_logz)."""
+    for i in range(len(rec["logl"])):
+        yield (int(rec["worst"][i]), rec["u"][i], rec["v"][i], float(rec["logl"][i]), float(rec["logvol"][i]),
+               float(rec["logwt"][i]), float(rec["logz"][i]), float(rec["logzvar"][i]), float(rec["h"][i]),
+               int(rec["nc"][i]), int(rec["worst_it"][i]), 0, int(rec["bounditer"][i]), float(rec["eff"][i]),
+               float(rec["delta_logz"][i]))

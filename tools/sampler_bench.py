@@ -27,15 +27,10 @@ ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', '
        'CarbonScale']
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="C2")
-    ap.add_argument("--maxcall", type=int, default=400000)
-    ap.add_argument("--nlive", type=int, default=512)
-    ap.add_argument("--walks", type=int, default=25)
-    ap.add_argument("--modes", default="host,device")
-    a = ap.parse_args()
-    cfg = synth.CONFIGS[a.config]
+def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks"), verbose=False):
+    """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
+    bookkeeping included).  Returns {mode: {...}}."""
+    cfg = synth.CONFIGS[config]
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0, line_depth=0.3)
     obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
     tmp = tempfile.mkdtemp()
@@ -45,30 +40,51 @@ def main():
     rb = [True, False, False, False, False]
     fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': np.ones(len(obs)), 'obs_eflux_fit': np.full(len(obs), 0.01),
                'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {}}
-    L = likelihood(fitargs, fitpars, rb, b_max=a.nlive, verbose=False)
+    L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False)
     T = synth.TRUTH
     truth = np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]]])
     clean = L.GM.engine.predict_batch(L.theta_rows(truth), stage=3, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+    L.GM.engine.close()
     fitargs['obs_flux_fit'] = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
-    L = likelihood(fitargs, fitpars, rb, b_max=a.nlive, verbose=False)
+    L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False)
     P = prior(fitargs, synth.demo_priordict(), fitpars, rb)
     out = {}
-    for mode in a.modes.split(","):
+    for mode in modes:
         proposer = None
-        if mode == "device":
+        if mode.startswith("device"):
             from thepayne_amd.sampler.device import DeviceProposer
-            proposer = DeviceProposer(L, P, k_max=a.nlive)
-        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=a.nlive, bound='multi',
-                          sample='rwalk', walks=a.walks, batched=True, queue_size=a.nlive,
+            proposer = DeviceProposer(L, P, k_max=nlive)
+        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound='multi',
+                          sample='rwalk', walks=walks, batched=True, queue_size=nlive,
                           rstate=np.random.default_rng(1), proposer=proposer)
         t0 = time.perf_counter()
         c0 = S.ncall
-        for _ in S.sample(maxcall=a.maxcall, dlogz=0.01):
-            pass
+        if mode.endswith("chunks"):
+            for _ in S.sample_chunks(maxcall=maxcall, dlogz=0.01):
+                pass
+        else:
+            for _ in S.sample(maxcall=maxcall, dlogz=0.01):
+                pass
         dt = time.perf_counter() - t0
-        out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 3),
+        out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 4),
                      "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale)}
-        print(mode, json.dumps(out[mode]), flush=True)
+        if verbose:
+            print(mode, json.dumps(out[mode]), flush=True)
+        if proposer is not None:
+            proposer.close()
+    L.GM.engine.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--maxcall", type=int, default=400000)
+    ap.add_argument("--nlive", type=int, default=512)
+    ap.add_argument("--walks", type=int, default=25)
+    ap.add_argument("--modes", default="host,device,device_chunks")
+    a = ap.parse_args()
+    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True)
     print(json.dumps({"sampler_bench": out, "config": a.config, "nlive": a.nlive, "walks": a.walks}))
 
 
