@@ -26,15 +26,15 @@ struct HostExec {
 // the same instantiation choice the GPU launcher makes (compile-time FFT geometry needs 256 threads)
 template <int LOG2N>
 static void run_one(HostExec& ex, const PostTables& T, const double* th, double factor, const float* raw, float* a,
-                    float* b, CandState& S, double* red, float* out, int stage, double* x2) {
-  run_candidate<LOG2N, kPostThreads>(ex, T, T.twf, th, factor, raw, a, b, S, red, out, stage, x2);
+                    float* b, CandState& S, double* red, float* out, int stage, double* x2, const CandState* prep) {
+  run_candidate<LOG2N, kPostThreads>(ex, T, T.twf, th, factor, raw, a, b, S, red, out, stage, x2, prep);
 }
 
 extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const double* obs_wave,
                                const double* obs_flux, const double* obs_eflux, int nobs, int npoly,
                                const double* theta, int ncols, int B, double instr_factor,
                                const float* raw_m1, int out_stage, float* out, int ld_out,
-                               double* chi2, int* info, int nthreads, int force_general) {
+                               double* chi2, int* info, int nthreads, int force_general, int use_prep) {
   HostTables H;
   int rc = build_model_tables(wave, npix, H);
   if (rc) return rc;
@@ -63,11 +63,15 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
     const double* th = theta + (size_t)c * ncols;
     const float* rw = raw_m1 + (size_t)c * npix;
     float* o = out ? out + (size_t)c * ld_out : nullptr;
-    if (fixed && H.n1 == 4096) run_one<12>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
-    else if (fixed && H.n1 == 2048) run_one<11>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
-    else if (fixed && H.n1 == 1024) run_one<10>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
-    else if (fixed && H.n1 == 8192) run_one<13>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
-    else run_candidate<0, kPostThreads>(ex, T, T.twf, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2);
+    // the record the first dense launch would have written (prep_candidate), when asked for
+    CandState P;
+    const CandState* prep = nullptr;
+    if (use_prep) { prep_candidate(T, th, instr_factor, P); prep = &P; }
+    if (fixed && H.n1 == 4096) run_one<12>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2, prep);
+    else if (fixed && H.n1 == 2048) run_one<11>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2, prep);
+    else if (fixed && H.n1 == 1024) run_one<10>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2, prep);
+    else if (fixed && H.n1 == 8192) run_one<13>(ex, T, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2, prep);
+    else run_candidate<0, kPostThreads>(ex, T, T.twf, th, instr_factor, rw, a.data(), b.data(), S, red.data(), o, out_stage, &x2, prep);
     if (chi2) chi2[c] = x2;
     // the setup-time probe must agree with the full mask count (phase_mask_count over every thread)
     int full_below = -1, full_notabove = -1;

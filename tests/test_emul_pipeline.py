@@ -28,7 +28,7 @@ def emul():
     def P(a, t):
         return a.ctypes.data_as(t) if a is not None else None
 
-    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=256):
+    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=256, prep=1):
         theta8 = np.atleast_2d(theta8)
         B, npix = len(theta8), len(net["wavelength"])
         raw = np.array([O.yst_forward(net, t[:4]) - 1.0 for t in theta8]).astype(np.float32)
@@ -39,7 +39,7 @@ def emul():
         rc = lib.payne_emul_post(P(net["wavelength"], dp), npix, ctypes.c_double(net["resolution"]), P(obs, dp),
                                  P(flux, dp), P(eflux, dp), len(obs), npoly, P(th, dp), th.shape[1], B,
                                  ctypes.c_double(factor), P(raw, fp), stage, P(out, fp), nout, P(chi2, dp), P(info, ip),
-                                 nthreads, general)
+                                 nthreads, general, prep)
         assert rc == 0, rc        # -77/-78: the setup-time mask probe disagrees with the full mask count
         return out, chi2, info
     run.fast_windows = lib.payne_emul_fast_windows
@@ -51,15 +51,17 @@ def _th8(th7):
     return np.column_stack([th7[:, :6], np.full(len(th7), np.nan), th7[:, 6]])
 
 
-@pytest.mark.parametrize("general", [0, 1])
-def test_c2_lnlike_matches_reference_golden(emul, golden, general):
+@pytest.mark.parametrize("general,prep", [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_c2_lnlike_matches_reference_golden(emul, golden, general, prep):
     g = golden("g4_lnlike_c2")
     cfg = synth.CONFIGS["C2"]
     net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
     idx = np.arange(0, 512, 16)
     before = emul.fast_windows()
-    _, chi2, info = emul(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], _th8(g["theta"][idx]), -1, general=general)
-    assert emul.fast_windows() - before == (0 if general else len(idx))   # geometric grid: windows from the setup probe
+    _, chi2, info = emul(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], _th8(g["theta"][idx]), -1, general=general,
+                         prep=prep)
+    # mask counts without the full scan: always with the ahead-of-kernel record, else on geometric grids (setup probe)
+    assert emul.fast_windows() - before == (len(idx) if (prep or not general) else 0)
     ref = g["lnlike"][idx]
     assert np.all(np.abs(-0.5 * chi2 - ref) <= lnl_tol(ref))
     assert np.abs(-0.5 * chi2 - ref).max() < 1e-3        # in practice ~1e-4

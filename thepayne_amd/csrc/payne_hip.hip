@@ -48,13 +48,33 @@ struct DenseParams {
   const float* W0; const float* b0; int n_labels; int act0;
   int K0;                      // real width of the first layer (W0 has K0 rows)
   double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
+#ifdef PAYNE_STAMPS
+  unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
+#endif
 };
+#ifdef PAYNE_STAMPS
+#define HK_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+static unsigned long long* g_hidden_stamps = nullptr;
+static unsigned long long* g_dense_stamps = nullptr;
+#else
+#define HK_STAMP(k) do {} while (0)
+#endif
 
+// Activations without per-lane branches: a `z > 0 ? .. : ..` chain compiles to exec-mask branches, and
+// an unrolled epilogue then serialises on them (the fused first layer spent 11 500 of 22 500 cycles
+// that way).  leaky ReLU(0.01) = max(z, 0.01 z) for every finite z, 0 and NaN (ystpred.py:57-58).
+__device__ __forceinline__ float lrelu01(float z) { return fmaxf(z, 0.01f * z); }
 __device__ __forceinline__ float act_apply(float z, int act) {
-  if (act == PAYNE_ACT_LRELU) return z > 0.f ? z : (z < 0.f ? 0.01f * z : z * 0.f);  // NaN stays NaN, 0 -> 0
-  if (act == PAYNE_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));
-  return z;
+  if (act == PAYNE_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));          // (uniform: a scalar branch)
+  const float l = lrelu01(z);
+  return act == PAYNE_ACT_LRELU ? l : z;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier and the fence
+// waits for EVERY outstanding memory operation (vmcnt(0)), so a global load issued two k-steps ahead
+// would be waited for at the very next barrier; here only the LDS counter is drained and the loads
+// stay in flight (the compiler still waits on vmcnt before the first use of their registers).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BM, int BN, int BK>
 constexpr size_t dense_lds_bytes() { return (size_t)(2 * (BM + BN) * (BK + 4) + BM * PAYNE_MAX_LABELS) * sizeof(float); }
@@ -96,8 +116,11 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
   // Guarded loads (`if (ok) v = *p`) compile to a branch plus a wait per load and serialise
   // the tile fetch; load unconditionally from a clamped (always valid) address and apply the
   // mask when the value is written to LDS.
-  f32x4_t ra[A_F4], rb[B_F4];
-  auto load_tiles = [&](int k0) {
+  // two register stages: a tile is requested TWO k-steps before it is needed (one step is ~2000
+  // MFMA cycles, about one L2/Infinity-Cache round trip: with a one-step lead every step waited
+  // for its loads -- measured 2900 cycles per step against 2048 of matrix work)
+  f32x4_t ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];
+  auto load_tiles = [&](f32x4_t (&ra)[A_F4], f32x4_t (&rb)[B_F4], int k0) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int idx = tid + i * 256, r = idx / KQ, k = k0 + (idx % KQ) * 4, row = m0 + r;
@@ -124,7 +147,7 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_tiles = [&](int buf, int k0) {
+  auto store_tiles = [&](const f32x4_t (&ra)[A_F4], const f32x4_t (&rb)[B_F4], int buf, int k0) {
     const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
@@ -149,12 +172,8 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (p.K + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0, 0);
-  __syncthreads();
-  for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk) load_tiles((it + 1) * BK);
+  HK_STAMP(0);
+  auto compute = [&](int buf) {
     // A lane (row = lane&31, half = lane>>5) reads 4 consecutive k; MFMA step s then
     // contracts k = {8kk + s, 8kk + 4 + s} -- the same k set on both operands.
 #pragma unroll
@@ -176,8 +195,25 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (it + 1 < nk) store_tiles(buf ^ 1, (it + 1) * BK);
-    __syncthreads();
+  };
+  load_tiles(ra0, rb0, 0);
+  store_tiles(ra0, rb0, 0, 0);
+  load_tiles(ra0, rb0, BK);                       // tile 1 (addresses are clamped: over-asking is harmless)
+  load_tiles(ra1, rb1, 2 * BK);                   // tile 2
+  lds_barrier();
+  HK_STAMP(1);
+  for (int it = 0; it < nk; it += 2) {
+    compute(0);                                   // tile it
+    if (it + 1 < nk) store_tiles(ra0, rb0, 1, (it + 1) * BK);
+    if (it + 3 < nk) load_tiles(ra0, rb0, (it + 3) * BK);
+    lds_barrier();
+    if (it < 12) HK_STAMP(2 + it);
+    if (it + 1 >= nk) break;
+    compute(1);                                   // tile it + 1
+    if (it + 2 < nk) store_tiles(ra1, rb1, 0, (it + 2) * BK);
+    if (it + 4 < nk) load_tiles(ra1, rb1, (it + 4) * BK);
+    lds_barrier();
+    if (it + 1 < 12) HK_STAMP(3 + it);
   }
 
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -194,8 +230,104 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
         if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[i][j][r] + bv, p.act);
       }
   }
+  HK_STAMP(15);
 }
 
+
+// ----------------------------------------------------------------------------
+// Output layer, LDS-DMA form: the same 64x64x32 tiling and MFMA schedule as payne_dense_kernel, but
+// the operand tiles go from global memory straight into a 3-stage LDS ring with
+// global_load_lds_dwordx4 (no VGPR staging, no address-clamp/select VALU work, no LDS store
+// instructions), requested TWO k-steps ahead and waited for with explicit vmcnt counts.  The
+// register-staged kernel cannot keep loads in flight across its barriers (measured: a k-step
+// that issues loads takes 2750 cycles, one that does not 1550).
+//   * A lane's 16 bytes land at (wave-uniform base) + 16*lane, so padding rows is impossible; bank
+//     conflicts of the fragment reads are avoided by an XOR swizzle instead: 16-byte chunk c of
+//     tile row r sits at chunk c ^ ((r >> 1) & 7) -- the lane simply FETCHES the chunk that belongs
+//     in its slot.
+//   * nothing can be masked on the way, so both operands must be zero-padded in k to a multiple
+//     of 32 in memory (X: the hidden buffers' pitch; W: ctx->w_out_pad) and rows are clamped.
+// ----------------------------------------------------------------------------
+constexpr int DM_NS = 3;                                   // ring stages
+constexpr int DM_STAGE = (64 + 64) * 32;                   // floats per stage (A tile, then B tile)
+constexpr size_t DM_LDS_BYTES = (size_t)DM_NS * DM_STAGE * sizeof(float);
+
+__global__ void __launch_bounds__(256) payne_dense_dma_kernel(DenseParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dm_sm[];
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+
+  // the four 1-KiB pieces this wave moves per stage: rows 8*blk .. 8*blk+7 of A (j = 0,1) and B (j = 2,3)
+  const float* src[4];
+  int dst[4];                                              // float offset inside a stage (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int blk = wave * 2 + (j & 1), row = 8 * blk + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);           // which chunk of the row belongs in this lane's slot
+    if (j < 2) {
+      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
+      src[j] = p.X + (size_t)r * p.ldx + 4 * c;
+    } else {
+      const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
+      src[j] = p.W + (size_t)r * p.K + 4 * c;              // p.K: padded pitch of the weight copy
+    }
+    dst[j] = (j < 2 ? 0 : 64 * 32) + blk * 256;
+  }
+  auto issue = [&](int stage, int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                       (__attribute__((address_space(3))) void*)(dm_sm + stage * DM_STAGE + dst[j]), 16, 0, 0);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // fragment addresses (floats inside a stage): row R, chunk 2kk + half, swizzled
+  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), half = lane >> 5;
+  const int sa = (Ra >> 1) & 7, sb = (Rb >> 1) & 7;
+
+  const int nk = p.K / 32;                                 // padded: exact
+  HK_STAMP(0);
+  issue(0, 0);
+  if (nk > 1) issue(1, 32);
+  for (int it = 0; it < nk; ++it) {
+    // my pieces of stage `it` have landed once at most the 4 younger loads (stage it+1) are outstanding
+    if (it + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                // everybody's pieces landed; everybody finished step it-1
+    if (it < 13) HK_STAMP(1 + it);
+    if (it + 2 < nk) issue((it + 2) % DM_NS, (it + 2) * 32);    // into the buffer step it-1 just released
+    const float* Asb = dm_sm + (it % DM_NS) * DM_STAGE;
+    const float* Bsb = Asb + 64 * 32;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = 2 * kk + half;
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(Asb + Ra * 32 + 4 * (c ^ sa));
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * 32 + 4 * (c ^ sb));
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = n0 + wn0 + (lane & 31);
+  if (col < p.N) {
+    const float bv = p.bias[col] - p.bias_shift;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[r] + bv, p.act);
+    }
+  }
+  HK_STAMP(15);
+}
 
 // ----------------------------------------------------------------------------
 // Hidden layers are tiny GEMMs ([B x H] x [H x H], ~0.1 GFLOP): one wave per 16x16 output
@@ -300,9 +432,27 @@ constexpr int HK_KC = 320;          // K chunk
 constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
 
+// Workgroups past the GEMM tiles (first-layer launch only) compute the per-candidate records of
+// the post kernel (prep_candidate: Doppler / rotation / instrument scalars, mask counts, R-stage
+// window), one thread per candidate, on compute units the 160 GEMM tiles leave idle.
+struct PrepArgs {
+  PostTables T;
+  CandState* out;            // [B] (null: no records from this launch)
+  double instr_factor;
+  int n_gemm;                // workgroups that are GEMM tiles
+};
+
 // NL: label slots the fused first layer loops over (4 for the usual Teff/logg/FeH/aFe nets, else PAYNE_MAX_LABELS)
 template <bool FUSE_L0, int NL>
-__global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p) {
+__global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p, const PrepArgs pa) {
+  if ((int)blockIdx.x >= pa.n_gemm) {
+    if (FUSE_L0 && pa.out) {
+      const int cand = ((int)blockIdx.x - pa.n_gemm) * 256 + (int)threadIdx.x;
+      if (cand < p.B) prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+    }
+    return;
+  }
+  HK_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float hk_sm[];
   float* As = hk_sm;
   float* Bs = As + 32 * HK_PITCH;
@@ -310,18 +460,6 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
   const int tm = blockIdx.x / p.grid_n, tn = blockIdx.x - tm * p.grid_n;
   const int m0 = tm * 32, n0 = tn * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-  if (FUSE_L0) {
-    for (int idx = tid; idx < 32 * PAYNE_MAX_LABELS; idx += 256) {
-      const int rr = idx / PAYNE_MAX_LABELS, d = idx - rr * PAYNE_MAX_LABELS, row = m0 + rr;
-      float v = 0.f;
-      if (row < p.B && d < p.n_labels) {
-        const double x = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)];
-        v = (float)((x - p.xmin[d]) / p.xden[d] - 0.5);
-      }
-      Xh[idx] = v;
-    }
-    __syncthreads();
-  }
   f32x4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -362,7 +500,22 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         for (int d = 0; d < NL; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
       }
     }
+    // the encoded labels of the tile's rows (first chunk only): theta is fetched while the weight
+    // loads above are still in flight -- one memory round trip for both
+    double xlab = 0.0;
+    const int xrr = tid / PAYNE_MAX_LABELS, xd = tid - xrr * PAYNE_MAX_LABELS;
+    const bool xlive = FUSE_L0 && kc == 0 && (xrr < 32) && (m0 + xrr < p.B) && (xd < p.n_labels);
+    if (FUSE_L0 && kc == 0) {
+      static_assert(32 * PAYNE_MAX_LABELS <= 256, "one (row, label) pair per thread");
+      const int row = (m0 + xrr < p.B) ? m0 + xrr : p.B - 1;
+      xlab = p.theta[(size_t)row * p.ld_theta + (xd < 4 ? xd : 6)];
+    }
+    HK_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);        // keep every load ahead of the first LDS store
+    if (FUSE_L0 && kc == 0) {
+      const int dd = xd < p.n_labels ? xd : 0;
+      if (tid < 32 * PAYNE_MAX_LABELS) Xh[tid] = xlive ? (float)((xlab - p.xmin[dd]) / p.xden[dd] - 0.5) : 0.f;
+    }
 #pragma unroll
     for (int it = 0; it < 4 * NKI; ++it) {
       const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
@@ -372,23 +525,45 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         if (!FUSE_L0) *reinterpret_cast<f32x4_t*>(&As[rr * HK_PITCH + 4 * k4]) = (kok && m0 + rr < p.B) ? va[it] : z4;
       }
     }
+    if (FUSE_L0 && kc == 0) __syncthreads();  // Xh complete
+    HK_STAMP(2);
     if (FUSE_L0) {
+      // the 32 x NL encoded labels into registers first: As and Xh are the same LDS array to the
+      // compiler, so a read of Xh cannot move above a store to As, and a loop that alternates them
+      // pays one LDS round trip per row (measured: 14 600 of the kernel's 25 000 cycles)
+      float xr[32][NL];
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr)
+#pragma unroll
+        for (int d = 0; d < NL; ++d) xr[rr][d] = Xh[rr * PAYNE_MAX_LABELS + d];
+      const bool lre = p.act0 == PAYNE_ACT_LRELU, plain = !lre && p.act0 != PAYNE_ACT_SIGMOID;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kk = tid + 256 * h;
         if (kk < kn16) {
           const bool live = (kc + kk) < p.K0;
-#pragma unroll 8
+          float zz[32];
+#pragma unroll
           for (int rr = 0; rr < 32; ++rr) {
             float z = bz[h];
 #pragma unroll
-            for (int d = 0; d < NL; ++d) z = fmaf(w0[h][d], Xh[rr * PAYNE_MAX_LABELS + d], z);
-            As[rr * HK_PITCH + kk] = live ? act_apply(z, p.act0) : 0.f;
+            for (int d = 0; d < NL; ++d) z = fmaf(w0[h][d], xr[rr][d], z);
+            zz[rr] = z;
           }
+          if (lre) {
+#pragma unroll
+            for (int rr = 0; rr < 32; ++rr) zz[rr] = lrelu01(zz[rr]);
+          } else if (!plain) {
+#pragma unroll
+            for (int rr = 0; rr < 32; ++rr) zz[rr] = 1.0f / (1.0f + expf(-zz[rr]));
+          }
+#pragma unroll
+          for (int rr = 0; rr < 32; ++rr) As[rr * HK_PITCH + kk] = live ? zz[rr] : 0.f;
         }
       }
     }
     __syncthreads();
+    HK_STAMP(3);
     // ---- the four waves split the K steps of this chunk -------------------------------------
     const int steps = kn16 >> 4;
     for (int s = wave; s < steps; s += 4) {
@@ -411,6 +586,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     }
     __syncthreads();
   }
+  HK_STAMP(4);
   // ---- sum the four partial tiles (C/D map: col = lane&15, row = 4*(lane>>4) + reg) ------------
   float* Red = As;                                               // [4][32][33]
 #pragma unroll
@@ -427,6 +603,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       p.Y[(size_t)row * p.ldy + col] = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
     }
   }
+  HK_STAMP(5);
 }
 
 
@@ -735,6 +912,7 @@ struct PostArgs {
   const double* mags; int n_filters; // SED magnitudes of this batch (null: no photometry)
   const double* obs_mag; const double* obs_err;
   unsigned long long* stamps;        // diagnostic build: [B][64] cycle stamps (slot 0 = count)
+  const CandState* prep;             // [B] per-candidate records made by the first dense launch (null: none)
 };
 
 // BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
@@ -793,9 +971,28 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   const c32* twf = T.twf;
   if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
     c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
-    const c32* __restrict__ g = T.twf;
-    const int nt = T.twf_n;
-    for (int i = threadIdx.x; i < nt; i += kPostThreads) twl[i] = g[i];
+    typedef float f2g __attribute__((ext_vector_type(2)));
+    const f2g* __restrict__ g = reinterpret_cast<const f2g*>(T.twf);
+    f2g* tl = reinterpret_cast<f2g*>(twl);
+    if constexpr (LOG2N > 0) {
+      // every load of the table in flight at once (a load -> store loop pays one L2 round trip per
+      // iteration: twelve of them at 4096 points, ~3.5 us before the first phase could start)
+      constexpr int NTW = plan_table_len((1 << LOG2N) / 2), PER = (NTW + kPostThreads - 1) / kPostThreads;
+      f2g tmp[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i0 = (int)threadIdx.x + q * kPostThreads;
+        tmp[q] = g[i0 < NTW ? i0 : NTW - 1];
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i0 = (int)threadIdx.x + q * kPostThreads;
+        if (i0 < NTW) tl[i0] = tmp[q];
+      }
+    } else {
+      const int nt = T.twf_n;
+      for (int i = threadIdx.x; i < nt; i += kPostThreads) tl[i] = g[i];
+    }
     twf = twl;                                                 // made visible by the first phase barrier
   }
   const int b = blockIdx.x;
@@ -810,7 +1007,8 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   double* chi2 = red + scratch_doubles(kPostThreads) - 1;
   run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
                                      a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red,
-                                     a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2);
+                                     a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
+                                     a.prep ? a.prep + b : nullptr);
   if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
     double x2 = *chi2;
     if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
@@ -970,6 +1168,9 @@ struct payne_ctx {
   int ld_hid = 0;
   float* raw = nullptr;
   unsigned short* w_planes = nullptr;   // bf16 x 3 split of the output layer's weights
+  const float* w_out_pad = nullptr;     // output layer's weights [N][w_out_kp], k zero-padded to a multiple of 32 (LDS-DMA kernel)
+  int w_out_kp = 0;
+  bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
   int wp_Kp = 0, wp_Npad = 0;
   size_t post_lds = 0;
   bool post_tw_lds = false;
@@ -978,6 +1179,8 @@ struct payne_ctx {
   float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
   int big_grid = 0;
   bool obs_bound = false;
+  CandState* prep = nullptr;      // [b_max] per-candidate records of the post kernel (written by the first dense launch)
+  bool prep_valid = false;        // ... as of the last run_ann
   // photometry
   bool has_phot = false, has_obs_phot = false;
   PhotTables P{};
@@ -1141,6 +1344,19 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       }
       if (l + 1 < model->n_layers) maxh = std::max(maxh, L.n_out);
     }
+    {   // k-padded copy of the output layer's weights for the LDS-DMA kernel (operands cannot be masked on the way)
+      const payne_layer& L = c->layers[model->n_layers - 1];
+      const int Kp = (L.n_in + 31) & ~31;
+      float* wp = nullptr;
+      if ((rc = dev_alloc(c, (size_t)L.n_out * Kp, &wp, c->owned))) return bail(rc);
+      he = hipMemcpy2D(wp, (size_t)Kp * 4, L.w, (size_t)L.n_in * 4, (size_t)L.n_in * 4, L.n_out, hipMemcpyDeviceToDevice);
+      if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(he)));
+      c->w_out_pad = wp; c->w_out_kp = Kp;
+      // the activations' pad columns are zero only if no wider layer ever wrote them: all hidden widths equal
+      bool same = model->n_layers >= 3;
+      for (int l = 1; l + 1 < model->n_layers; ++l) same = same && model->layers[l].n_out == model->layers[0].n_out;
+      c->dma_ok = same;
+    }
     {   // exact 3 x bf16 split of the output layer's weights (payne_dense_bf16x3_kernel)
       const payne_layer& L = c->layers[model->n_layers - 1];
       const int K = L.n_in, N = L.n_out;
@@ -1198,6 +1414,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
       if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
@@ -1279,6 +1496,9 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_kernel<BM, BN, BK, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+#ifdef PAYNE_STAMPS
+  p.stamps = FUSE ? nullptr : g_dense_stamps;
+#endif
   hipLaunchKernelGGL((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
@@ -1291,7 +1511,7 @@ static int skip_mask() {
 
 static int out_tile_choice() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 0; }   // 0: streaming 64x64x32 (fastest measured); 6: K-resident kernel
+  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 8; }   // 8: LDS-DMA 64x64x32 (default; needs zero-padded operands, else 0); 0: register-staged streaming; 6: K-resident; 7: bf16x3
   return v;
 }
 
@@ -1309,6 +1529,21 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
+}
+
+static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  p.W = c->w_out_pad; p.K = c->w_out_kp;                   // padded pitch; X's pitch (ld_hid) is a multiple of 32 too
+  p.grid_m = (p.B + 63) / 64;
+  p.grid_n = (p.N + 63) / 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DM_LDS_BYTES);
+    attr_set = true;
+  }
+#ifdef PAYNE_STAMPS
+  p.stamps = g_dense_stamps;
+#endif
+  hipLaunchKernelGGL(payne_dense_dma_kernel, dim3(p.grid_m * p.grid_n), dim3(256), DM_LDS_BYTES, s, p);
 }
 
 static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
@@ -1332,7 +1567,7 @@ static int hidden_kernel_choice() {
 }
 
 template <bool FUSE>
-static void launch_hidden(DenseParams& p, hipStream_t s) {
+static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   p.grid_m = (p.B + 31) / 32;
   p.grid_n = (p.N + 31) / 32;
   static bool attr_set = false;
@@ -1342,23 +1577,38 @@ static void launch_hidden(DenseParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
     attr_set = true;
   }
-  const dim3 grid(p.grid_m * p.grid_n), block(256);
-  if (!FUSE) hipLaunchKernelGGL((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p);
-  else if (p.n_labels <= 4) hipLaunchKernelGGL((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p);
-  else hipLaunchKernelGGL((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p);
+  pa.n_gemm = p.grid_m * p.grid_n;
+  if (!FUSE) pa.out = nullptr;
+#ifdef PAYNE_STAMPS
+  p.stamps = FUSE ? g_hidden_stamps : nullptr;
+#endif
+  const dim3 grid(pa.n_gemm + (pa.out ? (p.B + 255) / 256 : 0)), block(256);
+  if (!FUSE) hipLaunchKernelGGL((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
+  else if (p.n_labels <= 4) hipLaunchKernelGGL((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
+  else hipLaunchKernelGGL((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
 }
 
 template <bool FUSE>
-static void launch_small(DenseParams& p, hipStream_t s) {
-  if (hidden_kernel_choice() == 1) { launch_hidden<FUSE>(p, s); return; }
+static void launch_small(DenseParams& p, PrepArgs& pa, hipStream_t s) {
+  if (hidden_kernel_choice() == 1) { launch_hidden<FUSE>(p, pa, s); return; }
+  pa.out = nullptr;
   p.grid_m = (p.B + 15) / 16;
   p.grid_n = (p.N + 15) / 16;
   hipLaunchKernelGGL((payne_dense_small_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(64), 0, s, p);
 }
 
 // ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
-static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
+static bool prep_enabled() {
+  static int v = -1;
+  if (v < 0) v = getenv("PAYNE_NO_PREP") ? 0 : 1;
+  return v == 1;
+}
+
+// `instr_factor`: what Inst_R is multiplied by (2.355 in the likelihood / genspec, 1 in getspec): the
+// first-layer launch also writes the post kernel's per-candidate records (c->prep) for that factor.
+static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s) {
   const int n = c->n_layers;
+  c->prep_valid = false;
   for (int l = 1; l < n; ++l) {
     DenseParams p{};
     const payne_layer& L = c->layers[l];
@@ -1374,11 +1624,16 @@ static int run_ann(payne_ctx* c, const double* theta, int B, hipStream_t s) {
       p.theta = theta; p.ld_theta = c->ncols;
       p.W0 = L0.w; p.b0 = L0.b; p.n_labels = c->n_labels; p.act0 = L0.act; p.K0 = L0.n_out;
       for (int d = 0; d < c->n_labels; ++d) { p.xmin[d] = c->xmin[d]; p.xden[d] = c->xden[d]; }
+      PrepArgs pa{};
+      pa.T = c->T; pa.instr_factor = instr_factor;
+      pa.out = (c->prep && c->obs_bound && prep_enabled()) ? c->prep : nullptr;
       if (last) launch_dense<64, 64, 32, true>(p, s);
-      else launch_small<true>(p, s);
+      else { launch_small<true>(p, pa, s); c->prep_valid = pa.out != nullptr; }
     } else {
       p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
-      if (!last) launch_small<false>(p, s);
+      PrepArgs pa{};
+      if (!last) launch_small<false>(p, pa, s);
+      else if (out_tile_choice() == 8 && c->dma_ok && c->ld_hid >= c->w_out_kp) launch_out_dma(c, p, s);
       else if (out_tile_choice() == 7 && c->w_planes) launch_out_bf16x3(c, p, s);
       else if (out_tile_choice() == 6 && p.K <= OK_KMAX) launch_out_resident(p, s);
       else switch (out_tile_choice()) {
@@ -1427,6 +1682,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
+  a.prep = c->prep_valid ? c->prep : nullptr;
   if (skip_mask() & 4) return PAYNE_OK;
   {
     ProfScope ps(c, s, 1);
@@ -1449,7 +1705,7 @@ extern "C" int payne_lnlike_batch(payne_ctx* c, const double* theta, int B, doub
   if (c->has_phot && !c->has_obs_phot) return fail(c, PAYNE_E_INVALID, "photometric model without observed magnitudes");
   if (c->has_model) {
     if (!c->obs_bound || !c->T.obs_f1) return fail(c, PAYNE_E_INVALID, "no observed spectrum (flux, eflux) bound");
-    if ((rc = run_ann(c, theta, B, s))) return rc;
+    if ((rc = run_ann(c, theta, B, 2.355, s))) return rc;
   }
   if (c->has_phot && (rc = run_sed(c, theta, c->ncols, 1, B, c->mags_ws, s))) return rc;
   if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s);
@@ -1468,7 +1724,7 @@ extern "C" int payne_predict_batch(payne_ctx* c, const double* theta, int B, int
   if (stage >= 2 && !c->obs_bound) return fail(c, PAYNE_E_INVALID, "no observed grid bound");
   if (ld_out < (stage >= 2 ? c->T.nobs : c->T.npix)) return fail(c, PAYNE_E_INVALID, "ld_out too small");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if ((rc = run_ann(c, theta, B, s))) return rc;
+  if ((rc = run_ann(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, s))) return rc;
   return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage, out, ld_out, nullptr, false, s);
 }
 
@@ -1776,6 +2032,22 @@ extern "C" int payne_profile_read(payne_ctx* c, int kind, double* total_ms, long
 }
 
 #ifdef PAYNE_STAMPS
+// Diagnostic build only: cycle stamps of the first hidden-layer launch ([grid][16], slot 15 = grid size).
+extern "C" int payne_diag_hidden_stamps(payne_ctx* c, const double* theta, int B, unsigned long long* host, int max_blocks) {
+  int rc = check_call(c, theta, B, host);
+  if (rc) return rc;
+  unsigned long long* d = nullptr;
+  const size_t nb_ = (size_t)(max_blocks < 0 ? -max_blocks : max_blocks);
+  HIPCHK(c, hipMalloc(&d, nb_ * 16 * 8));
+  HIPCHK(c, hipMemset(d, 0, nb_ * 16 * 8));
+  if (max_blocks < 0) { max_blocks = -max_blocks; g_dense_stamps = d; } else g_hidden_stamps = d;   // negative: the output layer
+  rc = run_ann(c, theta, B, 2.355, nullptr);
+  g_hidden_stamps = nullptr; g_dense_stamps = nullptr;
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(host, d, (size_t)max_blocks * 16 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return rc;
+}
 // Diagnostic build only: one lnlike batch with per-phase cycle stamps of the post kernel.
 // stamps: host [B][64] (slot 0 = number of stamps, slots 1.. = s_memtime after each barrier).
 extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, unsigned long long* stamps_host) {
@@ -1786,10 +2058,10 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   HIPCHK(c, hipMalloc(&d, (size_t)B * 64 * 8));
   HIPCHK(c, hipMalloc(&lnl, (size_t)B * 8));
   HIPCHK(c, hipMemset(d, 0, (size_t)B * 64 * 8));
-  if ((rc = run_ann(c, theta, B, nullptr))) return rc;
+  if ((rc = run_ann(c, theta, B, 2.355, nullptr))) return rc;
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
-  a.out_stage = -1; a.lnl = lnl; a.stamps = d;
+  a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
   hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T, a);
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));

@@ -127,6 +127,8 @@ struct CandState {
   int do_rot, do_smooth;
   int win_ready;     // the two mask counts below come from phase_setup's probe (geometric grids)
   int win_below, win_notabove;
+  int w_ready;       // W below is valid (filled by prep_candidate, ahead of the kernel)
+  Window W;
 };
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -579,7 +581,69 @@ PAYNE_HD void setup_window(const PostTables& T, const double* th, double wl, dou
     notabove = probe_count<true>(T, op, wh, s_hi, lane, nl);
     ready = (below >= 0 && notabove >= 0) ? 1 : 0;
   }
-  if (lane == 0) { S.win_below = below; S.win_notabove = notabove; S.win_ready = ready; }
+  if (lane == 0) { S.win_below = below; S.win_notabove = notabove; S.win_ready = ready; S.w_ready = 0; }
+}
+
+// ---------------------------------------------------------------------------
+// Everything phase_setup + the window derivation produce, by ONE thread, ahead of the post
+// kernel (extra workgroups of the first dense-layer launch run it while the matrix cores
+// work): the kernel then starts from a 256-byte record instead of ~7000 cycles of dependent
+// fp64 arithmetic and two dependent memory round trips.
+// ---------------------------------------------------------------------------
+// #pixels whose Doppler-shifted wavelength passes the (monotone) limit test: the index of the
+// first failing pixel.  A guess that is right costs two loads; otherwise a bisection.
+template <bool UPPER>
+PAYNE_HD int count_search(const PostTables& T, double op, double lim, int guess) {
+  const double* __restrict__ lam = T.lam;
+  auto pred = [&](int i) { const double c = lam[i] * op; return UPPER ? (c < lim) : !(c > lim); };
+  const int n = T.npix;
+  int g = guess < 0 ? 0 : (guess > n ? n : guess);
+  for (int tries = 0; tries < 3; ++tries) {                         // the guess, then its neighbours
+    const bool left_ok = (g == 0) || pred(g - 1), right_ok = (g == n) || !pred(g);
+    if (left_ok && right_ok) return g;
+    if (!left_ok) { if (g == 0) break; --g; } else { if (g == n) break; ++g; }
+  }
+  int lo = 0, hi = n;                                               // pred true on [0, lo), false on [hi, n)
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (pred(mid)) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr_factor, CandState& S) {
+  const double rv = th[4];
+  S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;       // ystpred.py:228-232
+  S.dop = log(S.one_plus);
+  const double vrot = th[5];
+  S.do_rot = (vrot != 0.0);                                         // ystpred.py:214 (NaN passes)
+  S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);                     // smoothing.py:297,614
+  const double Rs = th[7] * instr_factor;                           // genmod.py:82-85
+  S.do_smooth = (Rs > 0.0);                                         // ystpred.py:238-240 (false for NaN)
+  S.g_a = 0.0; S.wl = 0.0; S.wh = 0.0;
+  S.win_ready = 0; S.win_below = 0; S.win_notabove = 0; S.w_ready = 0;
+  for (int i = 0; i < 12; ++i) S.poly[i] = (i < T.npoly) ? th[8 + i] : 0.0;
+  Window W{};
+  if (Rs > 0.0 && T.nobs > 0) {
+    const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;     // smoothing.py:107,113
+    const double sig = sqrt(sig_out * sig_out - inres * inres);     // :271 (NaN if negative)
+    S.g_a = -2.0 * (kPi * kPi) * (sig * sig);
+    const double pad = 20.0 / Rs;                                   // mask_wave, smoothing.py:631-647
+    S.wl = T.obs_min * (1.0 + pad * -1.0);
+    S.wh = T.obs_max * (1.0 + pad * 1.0);
+    const float op32 = (float)S.one_plus;
+    const int g_lo = probe_start(T, op32, S.wl), g_hi = probe_start(T, op32, S.wh);
+    S.win_below = count_search<false>(T, S.one_plus, S.wl, g_lo == INT32_MIN ? 0 : g_lo + 32);
+    S.win_notabove = count_search<true>(T, S.one_plus, S.wh, g_hi == INT32_MIN ? 0 : g_hi + 32);
+    S.win_ready = 1;
+    W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);
+    S.w_ready = 1;
+  }
+  S.W = W;
+}
+// Phase 0 of the kernel when the record exists: a dword copy into the workgroup's state.
+PAYNE_HD void phase_take_prep(int tid, const CandState* __restrict__ prep, CandState& S) {
+  constexpr int ND = (int)(sizeof(CandState) / 4);
+  static_assert(sizeof(CandState) % 4 == 0, "dword copy");
+  const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(prep);
+  unsigned* dst = reinterpret_cast<unsigned*>(&S);
+  if (tid < 64) for (int i = tid; i < ND; i += 64) dst[i] = src[i];
 }
 
 // P0: per-candidate scalars from theta.  The independent fp64 chains (log / sqrt / the

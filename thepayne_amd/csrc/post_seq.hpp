@@ -94,13 +94,14 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
 template <int LOG2N, int NT, class Ex>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
-                             float* out, int out_stage, double* chi2_out) {
+                             float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr) {
   // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer
   const bool direct = (out_stage != 0) && T.rot_identity && (th[5] != 0.0);
   ex.par([&](int t, int n) {
     RowRegs row;
     phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
-    phase_setup(t, n, T, th, instr_factor, S);
+    if (prep) phase_take_prep(t, prep, S);             // per-candidate scalars were computed ahead of the kernel
+    else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
     phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
@@ -140,9 +141,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   const float* on_grid = spec;
   Window W{};
   if (smooth) {
-    if (S.win_ready) {                                 // window derived during setup
+    if (S.win_ready) {                                 // mask counts known since setup
       if (edges_pending) ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
-      W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);   // by every thread
+      if (S.w_ready) W = S.W;                          // ... and so is the window (prep_candidate)
+      else W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);   // by every thread
       ex.mark(0);
     } else {
       const int nthr = ex.nthreads();

@@ -45,3 +45,54 @@ npass = 4 if cfgname == "C2" else None
 print("stamps per block:", n, " total median cycles:", int(np.median(st[:, n].astype(np.int64) - st[:, 1].astype(np.int64))))
 for i, m in enumerate(med):
     print("phase %2d  median %8d cycles  (p10 %8d  p90 %8d)" % (i, m, np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+
+# ---- hidden-layer kernel: stamps 0 entry | 1 loads issued | 2 B tile + labels in LDS | 3 A tile (fused layer 0) |
+#      4 MFMA done | 5 end
+try:
+    fh = eng.lib.payne_diag_hidden_stamps
+    fh.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    fh.restype = C.c_int
+    NB = 256
+    hs = np.zeros((NB, 16), dtype=np.uint64)
+    for rep in range(3):
+        assert fh(eng._ctx, th.data_ptr(), B, hs.ctypes.data, NB) == 0
+    used = hs[:, 5] > 0
+    h = hs[used].astype(np.int64)
+    print("hidden kernel: %d workgroups stamped" % used.sum())
+    t0 = h[:, 0].min()
+    print("  entry spread (first..last workgroup start): %d cycles" % (h[:, 0].max() - t0))
+    for k, name in enumerate(["loads issued", "B tile + labels in LDS", "A tile (layer 0) in LDS", "MFMA done", "end"]):
+        dlt = h[:, k + 1] - h[:, k]
+        print("  %-26s median %6d  p90 %6d" % (name, np.median(dlt), np.percentile(dlt, 90)))
+    print("  whole workgroup median %d ; first start -> last end %d cycles" % (np.median(h[:, 5] - h[:, 0]), h[:, 5].max() - t0))
+except AttributeError:
+    pass
+
+# ---- output-layer kernel (streaming 64x64x32): 0 entry | 1 first tiles in LDS | 2.. end of k-step | 15 end
+try:
+    NB = 512
+    ds = np.zeros((NB, 16), dtype=np.uint64)
+    for rep in range(3):
+        assert fh(eng._ctx, th.data_ptr(), B, ds.ctypes.data, -NB) == 0
+    used = ds[:, 15] > 0
+    h = ds[used].astype(np.int64)
+    print("output-layer kernel: %d workgroups stamped" % used.sum())
+    nk = int((h[0, 2:15] > 0).sum())
+    print("  prologue (first tiles)    median %6d" % np.median(h[:, 1] - h[:, 0]))
+    for k in range(nk):
+        print("  k-step %2d                 median %6d  p90 %6d" % (k, np.median(h[:, 2 + k] - h[:, 1 + k]), np.percentile(h[:, 2 + k] - h[:, 1 + k], 90)))
+    print("  epilogue                  median %6d" % np.median(h[:, 15] - h[:, 1 + nk]))
+    print("  whole workgroup median %d" % np.median(h[:, 15] - h[:, 0]))
+except Exception as e:
+    print("dense stamps failed:", e)
+try:
+    whole = h[:, 15] - h[:, 0]
+    print("  whole workgroup p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(whole, [10, 50, 90, 100])))
+    idx = np.nonzero(used)[0]
+    for x in range(8):                      # blocks b, b+8, ... share an XCD (and its clock counter)
+        sel = (idx % 8) == x
+        t0 = h[sel, 0].min()
+        print("  XCD %d: %3d workgroups, starts spread over %6d cycles, last end at %6d" %
+              (x, sel.sum(), h[sel, 0].max() - t0, h[sel, 15].max() - t0))
+except Exception as e:
+    print("dense stamps (2) failed:", e)
