@@ -100,7 +100,7 @@ def pmc_traffic(kind):
     (profiles/r1_c2_rocprofv3_pmc_hbm.csv; FETCH_SIZE and WRITE_SIZE in separate runs, KB).  FETCH_SIZE
     is doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads on gfx950."""
     path = os.path.join(ROOT, "profiles", "r1_c2_rocprofv3_pmc_hbm.csv")
-    key = {"dense_out": "payne_dense_kernel", "post": "payne_post_kernel"}[kind]
+    key = {"dense_out": "payne_dense_dma_kernel", "post": "payne_post_kernel"}[kind]
     try:
         import csv
         tot = {}
@@ -262,11 +262,11 @@ def main():
             flops = {"dense_out": 2.0 * B * H * N, "post": B * (2 * 2 * 2.5 * N * np.log2(N) + 60.0 * N)}
             ach = flops[dom] / (max(per[dom], 1e-9) * 1e-6) / 1e12
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "payne_dense_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
+                               "kernel": "payne_dense_dma_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
                                "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                                "traffic": pmc_traffic(dom) if args.config == "C2" else None,
                                "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
-            out["mfma_kernel"] = {"kernel": "payne_dense_kernel (output layer)", "alg_flops_per_launch": flops["dense_out"],
+            out["mfma_kernel"] = {"kernel": "payne_dense_dma_kernel (output layer)", "alg_flops_per_launch": flops["dense_out"],
                                   "avg_us_per_launch": per["dense_out"],
                                   "achieved_tflops": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12,
                                   "frac_of_fp32_peak": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12 / PEAK_FP32_TFLOPS}
