@@ -19,6 +19,7 @@ struct HostExec {
   template <class F> void par(F&& f) { for (int t = 0; t < nthr; ++t) f(t, nthr); }
   int nthreads() const { return nthr; }
   void mark(int) {}
+  template <class F> void single(F&& f) { f(nthr); }
   static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
   static const c32* twid(const c32* p) { return p; }
 };
@@ -46,7 +47,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data(); T.twf = H.twf.data();
   T.rs1_idx = H.rs1_idx.data(); T.rs1_frac = H.rs1_frac.data();
   T.bk1_idx = H.bk1_idx.data(); T.bk1_frac = H.bk1_frac.data();
-  T.lnobs = H.lnobs.data(); T.xcheb = H.xcheb.data();
+  T.lnobs = H.lnobs.data(); T.xcheb = H.xcheb.data(); T.obs_rec = H.obs_rec.data();
   T.obs_f1 = H.has_flux ? H.obs_f1.data() : nullptr;
   T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;

@@ -940,6 +940,8 @@ struct DevExecT {
     __syncthreads();
     mark(0);
   }
+  template <class F>
+  __device__ __forceinline__ void single(F&& f) { if (threadIdx.x == 0) f((int)blockDim.x); }
   // diagnostic build: an extra cycle stamp inside a phase, written by thread `who`
   __device__ __forceinline__ void mark(int who) {
 #ifdef PAYNE_STAMPS
@@ -1259,13 +1261,14 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   for (void* p : c->obs_owned) (void)hipFree(p);
   c->obs_owned.clear();
   c->obs_bound = false;
-  c->T.nobs = 0; c->T.lnobs = nullptr; c->T.xcheb = nullptr; c->T.obs_f1 = nullptr; c->T.obs_ivar = nullptr;
+  c->T.nobs = 0; c->T.lnobs = nullptr; c->T.obs_rec = nullptr; c->T.xcheb = nullptr; c->T.obs_f1 = nullptr; c->T.obs_ivar = nullptr;
   if (!obs || obs->nobs <= 0) return sync_tables(c);
   if (!obs->wave) return fail(c, PAYNE_E_INVALID, "obs.wave is NULL");
   if ((obs->flux == nullptr) != (obs->eflux == nullptr)) return fail(c, PAYNE_E_INVALID, "obs.flux and obs.eflux must both be given or both NULL");
   build_obs_tables(obs->wave, obs->flux, obs->eflux, obs->nobs, c->H);
   int rc;
   if ((rc = upload(c, c->H.lnobs, &c->T.lnobs, c->obs_owned))) return rc;
+  if ((rc = upload(c, c->H.obs_rec, &c->T.obs_rec, c->obs_owned))) return rc;
   if ((rc = upload(c, c->H.xcheb, &c->T.xcheb, c->obs_owned))) return rc;
   if (c->H.has_flux) {
     if ((rc = upload(c, c->H.obs_f1, &c->T.obs_f1, c->obs_owned))) return rc;

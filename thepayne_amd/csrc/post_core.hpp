@@ -67,6 +67,9 @@ PAYNE_HD int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 // Static (per-context) tables, all device-resident; built once on the host
 // (host_tables.hpp).
 // ---------------------------------------------------------------------------
+// observed pixel as the chi^2 loop reads it (f1 = ivar = 0 when no flux is bound)
+struct alignas(16) ObsRec { double lnw; float f1, ivar; };
+
 struct PostTables {
   int npix;            // ANN pixels
   int nobs;            // observed pixels (0: no obs grid bound)
@@ -85,6 +88,7 @@ struct PostTables {
   double vs_val;           // 1/(n1*dv1): rfftfreq spacing of the vsini grid
   // observed grid
   const double* lnobs;     // [nobs] ln(obs wave)
+  const struct ObsRec* obs_rec;   // [nobs] {ln(obs wave), flux - 1, 1/eflux^2} in one 16-byte record (one load per pixel)
   const double* xcheb;     // [nobs] polycalc abscissa in [-1,1]
   const float* obs_f1;     // [nobs] obs flux - 1
   const float* obs_ivar;   // [nobs] 1/eflux^2
@@ -892,8 +896,9 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
 #pragma unroll
     for (int q = 0; q < OU; ++q) {                       // clamped index: every load unconditional
       const int i0 = base + q * nthr, i = i0 < T.nobs ? i0 : T.nobs - 1;
-      const double lo = T.lnobs[i];
-      if (HASF) { of1[q] = T.obs_f1[i]; iv[q] = T.obs_ivar[i]; }
+      const ObsRec rec = T.obs_rec[i];                   // one 16-byte load
+      const double lo = rec.lnw;
+      if (HASF) { of1[q] = rec.f1; iv[q] = rec.ivar; }
       if (CHEB) xc[q] = T.xcheb[i];
       int k = 0; float ww = 0.f;
       if (MODE == 0) {

@@ -1,6 +1,6 @@
 // post_seq.hpp -- the order of the phases of post_core.hpp for one candidate.
 // `Ex` supplies "run this phase on every thread of the workgroup, then barrier" (`par`)
-// and the thread count (`nthreads`): DevExec in payne_hip.hip (threadIdx + __syncthreads),
+// (`single`: on thread 0 only, no barrier) and the thread count (`nthreads`): DevExec in payne_hip.hip (threadIdx + __syncthreads),
 // HostExec in tests/emul/cpu_emul.cpp.
 //
 // LOG2N > 0 selects the compile-time FFT geometry for spectra of exactly 2^LOG2N points
@@ -164,13 +164,12 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     }
   }
   ex.par([&](int t, int n) { store_partial(t, phase_obs(t, n, T, S, W, on_grid, out, out_stage), red); });
-  ex.par([&](int t, int n) {
-    if (t == 0) {
-      double s = 0.0;
-      const int ns = n_slots(n);
-      for (int i = 0; i < ns; ++i) s += red[i];
-      *chi2_out = s;
-    }
+  // the sum of the per-wave partials: thread 0 alone, no closing barrier (it is also the only reader)
+  ex.single([&](int n) {
+    double s = 0.0;
+    const int ns = n_slots(n);
+    for (int i = 0; i < ns; ++i) s += red[i];
+    *chi2_out = s;
   });
 }
 
