@@ -467,7 +467,9 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  for (int kc = 0; kc < p.K; kc += HK_KC) {
+  // one K chunk; the usual single-chunk case (K <= 320) is called outside any loop: around a loop the
+  // compiler's wait-count bookkeeping turns conservative (a vmcnt(0) right after the first load)
+  auto chunk = [&](const int kc) {
     const int kn = (p.K - kc < HK_KC) ? (p.K - kc) : HK_KC;        // multiple of 4
     const int kn16 = (kn + 15) & ~15;
     const int nk4 = kn16 >> 2;
@@ -476,6 +478,36 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     // would pay one L2 latency per iteration)
     constexpr int NKI = (HK_KC / 4 + 31) / 32;                   // k4 slots per thread: 3
     f32x4_t vb[4 * NKI], va[FUSE_L0 ? 1 : 4 * NKI];
+    // Order of issue = order of arrival (vmcnt counts in order): the few small loads the fused first layer
+    // needs (theta, W0, b0) go first, the 12 weight-tile loads after them, so that the first layer is
+    // computed WHILE the weight tile is still on its way (it used to wait ~2000 cycles for it first).
+    // Columns of the first layer: thread t owns column t (all 32 rows); the columns past 256 (48 of them at
+    // H = 300) are spread over all threads -- column 256 + t % nE, rows t / nE, + G, + 2G, .. -- instead of
+    // giving 48 threads of wave 0 a second full column each (that wave was the critical path).
+    double xlab = 0.0;
+    const int xrr = tid / PAYNE_MAX_LABELS, xd = tid - xrr * PAYNE_MAX_LABELS;
+    const bool xlive = FUSE_L0 && kc == 0 && (xrr < 32) && (m0 + xrr < p.B) && (xd < p.n_labels);
+    if (FUSE_L0 && kc == 0) {
+      static_assert(32 * PAYNE_MAX_LABELS <= 256, "one (row, label) pair per thread");
+      const int row = (m0 + xrr < p.B) ? m0 + xrr : p.B - 1;
+      xlab = p.theta[(size_t)row * p.ld_theta + (xd < 4 ? xd : 6)];
+    }
+    const int nE = kn16 > 256 ? kn16 - 256 : 0;                  // extra columns
+    const int G = nE ? 256 / nE : 1, eg = nE ? tid / nE : 0, ec = nE ? 256 + (tid - eg * nE) : 0;
+    const bool eact = nE && eg < G;
+    float w0[2][NL], bz[2];
+    if (FUSE_L0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = kc + (h ? ec : tid);
+        const int kq = k < p.K0 ? k : p.K0 - 1;
+        bz[h] = p.b0[kq];
+#pragma unroll
+        for (int d = 0; d < NL; ++d) w0[h][d] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
+#pragma unroll
+        for (int d = 0; d < NL; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
+      }
+    }
 #pragma unroll
     for (int it = 0; it < 4 * NKI; ++it) {   // unconditional loads from clamped addresses (see payne_dense_kernel)
       const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
@@ -487,34 +519,74 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         va[it] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kcl);
       }
     }
-    float w0[2][NL], bz[2];
-    if (FUSE_L0) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = kc + tid + 256 * h;
-        const int kq = k < p.K0 ? k : p.K0 - 1;
-        bz[h] = p.b0[kq];
-#pragma unroll
-        for (int d = 0; d < NL; ++d) w0[h][d] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
-#pragma unroll
-        for (int d = 0; d < NL; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
-      }
-    }
-    // the encoded labels of the tile's rows (first chunk only): theta is fetched while the weight
-    // loads above are still in flight -- one memory round trip for both
-    double xlab = 0.0;
-    const int xrr = tid / PAYNE_MAX_LABELS, xd = tid - xrr * PAYNE_MAX_LABELS;
-    const bool xlive = FUSE_L0 && kc == 0 && (xrr < 32) && (m0 + xrr < p.B) && (xd < p.n_labels);
-    if (FUSE_L0 && kc == 0) {
-      static_assert(32 * PAYNE_MAX_LABELS <= 256, "one (row, label) pair per thread");
-      const int row = (m0 + xrr < p.B) ? m0 + xrr : p.B - 1;
-      xlab = p.theta[(size_t)row * p.ld_theta + (xd < 4 ? xd : 6)];
-    }
     HK_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);        // keep every load ahead of the first LDS store
-    if (FUSE_L0 && kc == 0) {
-      const int dd = xd < p.n_labels ? xd : 0;
-      if (tid < 32 * PAYNE_MAX_LABELS) Xh[tid] = xlive ? (float)((xlab - p.xmin[dd]) / p.xden[dd] - 0.5) : 0.f;
+    if (FUSE_L0) {
+      if (kc == 0) {
+        // (static indices + selects: p.xmin[dd] with a per-lane dd is a vector load from the kernarg
+        //  segment, queued BEHIND the weight-tile loads -- waiting for it would wait for them)
+        double xm = p.xmin[0], xdn = p.xden[0];
+#pragma unroll
+        for (int d = 1; d < PAYNE_MAX_LABELS; ++d) { xm = (xd == d) ? p.xmin[d] : xm; xdn = (xd == d) ? p.xden[d] : xdn; }
+        if (tid < 32 * PAYNE_MAX_LABELS) Xh[tid] = xlive ? (float)((xlab - xm) / xdn - 0.5) : 0.f;
+        lds_barrier();                        // LDS only: the weight-tile loads stay in flight
+      }
+      HK_STAMP(2);
+      // the encoded labels into registers first: As and Xh are the same LDS array to the compiler, so a read
+      // of Xh cannot move above a store to As, and a loop that alternates them pays one LDS round trip per
+      // row (measured: 14 600 of the kernel's 25 000 cycles)
+      float xr[32][NL], xe[8][NL];
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr)
+#pragma unroll
+        for (int d = 0; d < NL; ++d) xr[rr][d] = Xh[rr * PAYNE_MAX_LABELS + d];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rr = eg + G * j, rc = rr < 32 ? rr : 31;
+#pragma unroll
+        for (int d = 0; d < NL; ++d) xe[j][d] = Xh[rc * PAYNE_MAX_LABELS + d];
+      }
+      const bool lre = p.act0 == PAYNE_ACT_LRELU, plain = !lre && p.act0 != PAYNE_ACT_SIGMOID;
+      {
+        const bool live = (kc + tid) < p.K0;
+        float zz[32];
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr) {
+          float z = bz[0];
+#pragma unroll
+          for (int d = 0; d < NL; ++d) z = fmaf(w0[0][d], xr[rr][d], z);
+          zz[rr] = z;
+        }
+        if (lre) {
+#pragma unroll
+          for (int rr = 0; rr < 32; ++rr) zz[rr] = lrelu01(zz[rr]);
+        } else if (!plain) {
+#pragma unroll
+          for (int rr = 0; rr < 32; ++rr) zz[rr] = 1.0f / (1.0f + expf(-zz[rr]));
+        }
+        if (tid < kn16) {
+#pragma unroll
+          for (int rr = 0; rr < 32; ++rr) As[rr * HK_PITCH + tid] = live ? zz[rr] : 0.f;
+        }
+      }
+      if (nE) {                               // (G * 8 >= 32 for every nE <= 64)
+        const bool live = (kc + ec) < p.K0;
+        float ze[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = bz[1];
+#pragma unroll
+          for (int d = 0; d < NL; ++d) z = fmaf(w0[1][d], xe[j][d], z);
+          ze[j] = lre ? lrelu01(z) : (plain ? z : 1.0f / (1.0f + expf(-z)));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int rr = eg + G * j;
+          if (eact && rr < 32) As[rr * HK_PITCH + ec] = live ? ze[j] : 0.f;
+        }
+      }
+    } else {
+      HK_STAMP(2);
     }
 #pragma unroll
     for (int it = 0; it < 4 * NKI; ++it) {
@@ -523,43 +595,6 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         const bool kok = 4 * k4 < kn;
         *reinterpret_cast<f32x4_t*>(&Bs[rr * HK_PITCH + 4 * k4]) = (kok && n0 + rr < p.N) ? vb[it] : z4;
         if (!FUSE_L0) *reinterpret_cast<f32x4_t*>(&As[rr * HK_PITCH + 4 * k4]) = (kok && m0 + rr < p.B) ? va[it] : z4;
-      }
-    }
-    if (FUSE_L0 && kc == 0) __syncthreads();  // Xh complete
-    HK_STAMP(2);
-    if (FUSE_L0) {
-      // the 32 x NL encoded labels into registers first: As and Xh are the same LDS array to the
-      // compiler, so a read of Xh cannot move above a store to As, and a loop that alternates them
-      // pays one LDS round trip per row (measured: 14 600 of the kernel's 25 000 cycles)
-      float xr[32][NL];
-#pragma unroll
-      for (int rr = 0; rr < 32; ++rr)
-#pragma unroll
-        for (int d = 0; d < NL; ++d) xr[rr][d] = Xh[rr * PAYNE_MAX_LABELS + d];
-      const bool lre = p.act0 == PAYNE_ACT_LRELU, plain = !lre && p.act0 != PAYNE_ACT_SIGMOID;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int kk = tid + 256 * h;
-        if (kk < kn16) {
-          const bool live = (kc + kk) < p.K0;
-          float zz[32];
-#pragma unroll
-          for (int rr = 0; rr < 32; ++rr) {
-            float z = bz[h];
-#pragma unroll
-            for (int d = 0; d < NL; ++d) z = fmaf(w0[h][d], xr[rr][d], z);
-            zz[rr] = z;
-          }
-          if (lre) {
-#pragma unroll
-            for (int rr = 0; rr < 32; ++rr) zz[rr] = lrelu01(zz[rr]);
-          } else if (!plain) {
-#pragma unroll
-            for (int rr = 0; rr < 32; ++rr) zz[rr] = 1.0f / (1.0f + expf(-zz[rr]));
-          }
-#pragma unroll
-          for (int rr = 0; rr < 32; ++rr) As[rr * HK_PITCH + kk] = live ? zz[rr] : 0.f;
-        }
       }
     }
     __syncthreads();
@@ -585,7 +620,9 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         }
     }
     __syncthreads();
-  }
+  };
+  if (p.K <= HK_KC) chunk(0);
+  else for (int kc = 0; kc < p.K; kc += HK_KC) chunk(kc);
   HK_STAMP(4);
   // ---- sum the four partial tiles (C/D map: col = lane&15, row = 4*(lane>>4) + reg) ------------
   float* Red = As;                                               // [4][32][33]
