@@ -996,7 +996,10 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
   return s;
 }
 
-template <int LOG2N, bool TW_LDS>
+// LEAN: the likelihood-only instantiation (out_stage == -1, no spectrum output, per-candidate records present):
+// the output variants of the observed-grid loop, the stage branches and the in-kernel setup are compiled out
+// (most of the 270 KB of the full kernel).
+template <int LOG2N, bool TW_LDS, bool LEAN = false>
 __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables T, PostArgs a) {
   // T by value: its pointer members then live in the kernarg segment and are known to be
   // global (a struct read through a device pointer yields generic pointers -> flat_load,
@@ -1044,11 +1047,13 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   }
 #endif
   double* chi2 = red + scratch_doubles(kPostThreads) - 1;
+  const int ostage = LEAN ? -1 : a.out_stage;
+  float* outp = LEAN ? nullptr : (a.out ? a.out + (size_t)b * a.ld_out : nullptr);
+  const CandState* prep = a.prep ? a.prep + b : nullptr;
+  if (LEAN) { prep = a.prep + b; __builtin_assume(prep != nullptr); }     // LEAN is launched only with records
   run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
-                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red,
-                                     a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
-                                     a.prep ? a.prep + b : nullptr);
-  if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
+                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep);
+  if (threadIdx.x == 0 && a.lnl && ostage < 0) {
     double x2 = *chi2;
     if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
     a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
@@ -1088,7 +1093,12 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
 
 typedef void (*post_kernel_fn)(const PostTables, PostArgs);
 // compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
-static post_kernel_fn pick_post_kernel(int n1, bool tw_lds) {
+static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
+  if (lean) {                                   // likelihood-only builds of the two LDS-twiddle sizes that matter
+    if (tw_lds && n1 == 4096) return payne_post_kernel<12, true, true>;
+    if (tw_lds && n1 == 2048) return payne_post_kernel<11, true, true>;
+    if (!tw_lds && n1 == 8192) return payne_post_kernel<13, false, true>;
+  }
   if (tw_lds) {
     switch (n1) {
       case 1024: return payne_post_kernel<10, true>;
@@ -1212,6 +1222,7 @@ struct payne_ctx {
   bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
   int wp_Kp = 0, wp_Npad = 0;
   size_t post_lds = 0;
+  void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
   PostTables* d_T = nullptr;          // device copy of T
   post_kernel_fn post_fn = nullptr;
@@ -1466,6 +1477,9 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if (getenv("PAYNE_TW_GLOBAL")) c->post_tw_lds = false;
     if (c->post_tw_lds) c->post_lds += tw_bytes;
     c->post_fn = pick_post_kernel(getenv("PAYNE_POST_GENERIC") ? 0 : T.n1, c->post_tw_lds);
+    c->post_fn_lean = getenv("PAYNE_POST_FULL") ? c->post_fn : pick_post_kernel(getenv("PAYNE_POST_GENERIC") ? 0 : T.n1, c->post_tw_lds, true);
+    he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn_lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
+    if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     c->has_model = true;
@@ -1730,7 +1744,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
       const int grid = B < c->big_grid ? B : c->big_grid;
       hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, s, c->T, a, c->big_ws, B);
     } else {
-      hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+      hipLaunchKernelGGL((stage < 0 && !out && a.prep) ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
     }
   }
   hipError_t e = hipGetLastError();
