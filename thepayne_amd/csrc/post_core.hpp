@@ -462,17 +462,10 @@ PAYNE_HD void search_locate(const PostTables& T, int lo, int hi, double v, int& 
   const float ww = f * (1.0f + 0.5f * (float)dv * (f - 1.0f));
   w = (u <= 0.0) ? 0.f : ((u >= dv) ? 1.f : ww);
 }
-// position t on a uniform ln grid -> (k, weight of k+1), k clamped to [lo, hi-2]
-PAYNE_HD void uniform_locate(double t, int lo, int hi, float hs, int& k, float& w) {
-  int kk = (int)t;                                       // t >= 0 on every caller's valid range
-  kk = kk < lo ? lo : (kk > hi - 2 ? hi - 2 : kk);
-  float f = (float)(t - (double)kk);
-  f = f < 0.f ? 0.f : (f > 1.f ? 1.f : f);
-  k = kk;
-  w = f * (1.0f + hs * (f - 1.0f));                      // expm1(f v)/expm1(v), v = 2 hs
-}
-// The same split without fp64 conversions (v_cvt_*_f64 run at a fraction of the fma rate and
-// there were four per pixel): the caller folds kPosMagic = 1.5 * 2^20 into the constant term of its
+// position t on a uniform ln grid -> (k, weight of k+1), k clamped to [lo, hi-2]:  k = floor(t), f = t - k,
+// weight = f (1 + hs (f - 1))  [= expm1(f v)/expm1(v), v = 2 hs].
+// Done without fp64 conversions (v_cvt_*_f64 run at a fraction of the fma rate and a floor/convert
+// formulation needs four per pixel): the caller folds kPosMagic = 1.5 * 2^20 into the constant term of its
 // position fma, so that tm = t + kPosMagic (0 <= t < 2^19) has ulp 2^-32: the low dword of tm IS
 // the fraction in units of 2^-32, bits 0..18 of the high dword the integer part, and the
 // exponent field is the constant 0x413.  Position resolution 2.3e-10 pixel (single rounding).
