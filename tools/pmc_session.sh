@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o c -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timing > $OUT/pmc_${TAG}_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o c -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e > $OUT/pmc_${TAG}_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SMEM
