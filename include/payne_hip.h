@@ -116,6 +116,13 @@ int payne_ctx_create(const payne_model_desc* model, const payne_obs_desc* obs,
 /* Re-bind the observed grid (the `outwave` of getspec / a new spectrum). */
 int payne_ctx_set_obs(payne_ctx* ctx, const payne_obs_desc* obs);
 
+/* Bind (or, with NULL, remove) the continuum network of ystpred.PayneSpecPredict(Cnnpath=...)
+ * (Payne/predict/ystpred.py:81-85): every spectrum the context produces from then on is the spectral
+ * ANN's output times the continuum network's, converted F_nu -> F_lambda, normalised by its
+ * NaN-ignoring median and interpolated onto the spectral ANN grid (NaN outside; ystpred.py:191-209).
+ * Same descriptor as the spectral model (`resolution` unused); n_labels must match; npix <= 8192. */
+int payne_ctx_set_continuum(payne_ctx* ctx, const payne_model_desc* cont);
+
 void payne_ctx_destroy(payne_ctx* ctx);
 
 /* Message for the last failure on ctx (ctx == NULL: last create failure). */
@@ -140,10 +147,14 @@ int payne_lnlike_batch(payne_ctx* ctx, const double* theta, int B, double* lnl, 
  *   stage 1: after rotational broadening, ANN grid   (ystpred.py:211-224)
  *   stage 2: getspec on the bound observed grid      (ystpred.py:226-277)
  *   stage 3: genspec = stage 2 x Chebyshev blaze     (genmod.py:103-106)
+ *   stage 4: the continuum network's own output      (predictcont, ystpred.py:101-117); ld_out >= its npix
+ * With a continuum network bound (payne_ctx_set_continuum) stages 1-3 and the likelihood include the
+ * normalised continuum (ystpred.py:191-209); stage 0 stays the spectral network's own output.
  * flags bit 0 (PAYNE_F_FWHM_R): theta[7] is FWHM-based (genspec semantics, x2.355);
  * otherwise it is the sigma-based R handed to getspec.
  * out: device fp32 [B][ld_out]; ld_out >= npix (stages 0,1) or nobs (stages 2,3). */
 #define PAYNE_F_FWHM_R 1u
+#define PAYNE_STAGE_CONT 4
 int payne_predict_batch(payne_ctx* ctx, const double* theta, int B, int stage, unsigned flags,
                         float* out, int ld_out, void* stream);
 

@@ -308,7 +308,35 @@ def g7_misc():
          air=air, vac=airtovacuum(air))
 
 
+# ------------------------------------------------------------------ G8
+def g8_continuum():
+    """PayneSpecPredict with a continuum network (Cnnpath, ystpred.py:81-85, 191-209): predictcont and
+    getspec for two continuum grids -- one covering the spectral ANN, one that leaves its red end NaN."""
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    rs.register_yst('/g8/yst.h5', net)
+    obs = synth.obs_grid(net["wavelength"], 700, inset=1.5)
+    labs = np.array([[5300.0, 4.1, -0.3, 0.15], [6400.0, 3.2, -1.4, 0.4], [4300.0, 4.9, 0.3, -0.1]])
+    rows = np.array([(0.0, 0.0, 25000.0), (12.0, 4.0, 28000.0), (-35.0, 9.0, 18000.0), (5.0, 2.0, np.nan)])
+    out = dict(obs=obs, labels=labs, rows=rows)
+    for tag, (lo, hi, npc) in {"full": (5140.0, 5190.0, 600), "short": (5140.0, 5170.0, 333)}.items():
+        cnet = synth.make_cont_net(npix=npc, lam_lo=lo, lam_hi=hi)
+        rs.register_yst('/g8/cont_%s.h5' % tag, cnet)
+        PP = ystpred.PayneSpecPredict(nnpath='/g8/yst.h5', Cnnpath='/g8/cont_%s.h5' % tag, NNtype='YST1')
+        out["cont_" + tag] = np.array([PP.predictcont(list(l)) for l in labs])
+        fin, native = [], []
+        for l in labs:
+            kw = dict(Teff=l[0], logg=l[1], feh=l[2], afe=l[3])
+            with np.errstate(all="ignore"):
+                native.append(PP.getspec(**kw)[1])
+                for vrad, vrot, R in rows:
+                    fin.append(PP.getspec(rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=2.355 * R, outwave=obs, **kw)[1])
+        out["native_" + tag] = np.array(native)
+        out["final_" + tag] = np.array(fin).reshape(len(labs), len(rows), len(obs))
+    save("g8_continuum", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8"]
     for k in which:
-        {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc}[k]()
+        {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
+         "g8": g8_continuum}[k]()

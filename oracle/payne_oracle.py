@@ -163,10 +163,11 @@ def smooth_R(wave, spec, Rsigma, outwave, R_ann, return_parts=False):
 
 
 def getspec(net, Teff=5770.0, logg=4.44, feh=0.0, afe=0.0, rad_vel=None, rot_vel=None,
-            vmic=None, inst_R=None, outwave=None, return_stages=False):
+            vmic=None, inst_R=None, outwave=None, return_stages=False, cnet=None):
     """``PayneSpecPredict.getspec`` (Payne/predict/ystpred.py:119-277 ==
     Payne/predict/predictspec.py:136-294), scalar ``inst_R`` branch.
 
+    ``cnet``: the optional continuum network (``Cnnpath``).
     ``inst_R`` is the sigma-based R handed straight to smoothspec (the 2.355
     factor belongs to genspec).  ``None`` for rad_vel/rot_vel/inst_R means
     "kwarg absent".  Stages: raw ANN, after vsini, on the output grid.
@@ -177,6 +178,12 @@ def getspec(net, Teff=5770.0, logg=4.44, feh=0.0, afe=0.0, rad_vel=None, rot_vel
     modspec = ann_forward(net, labels)
     raw = modspec
     modwave = net["wavelength"]
+    if cnet is not None:                             # continuum network, ystpred.py:191-209
+        modcont = ann_forward(cnet, labels)
+        modcontwave = cnet["wavelength"]
+        modcont = modcont * (C_KMS_DOPPLER / ((modcontwave * 1E-8) ** 2.0))      # F_nu -> F_lambda
+        modcont = modcont / np.nanmedian(modcont)
+        modspec = modspec * np.interp(modwave, modcontwave, modcont, right=np.nan, left=np.nan)
 
     if rot_vel is not None and rot_vel != 0.0:       # ystpred.py:211-224
         modspec = smooth_vsini(modwave, modspec, rot_vel)
@@ -213,14 +220,15 @@ def polycalc(coef, inwave):
     return np.polynomial.chebyshev.chebval(x, coef)
 
 
-def genspec(net, pars, outwave=None, modpoly=False):
-    """``GenMod.genspec`` (Payne/fitting/genmod.py:58-108), carbon off."""
+def genspec(net, pars, outwave=None, modpoly=False, cnet=None):
+    """``GenMod.genspec`` (Payne/fitting/genmod.py:58-108), carbon off; ``cnet``: the continuum
+    network GenMod._initspecnn(Cnnpath=...) hands to PayneSpecPredict (genmod.py:28-32)."""
     Teff, logg, FeH, aFe, radvel, rotvel, vmic, inst_R = pars[:8]
     polycoef = pars[8:] if modpoly else pars[8:-1]
     if isinstance(inst_R, float):                    # genmod.py:82-85
         inst_R = 2.355 * inst_R
     wave, flux = getspec(net, Teff=Teff, logg=logg, feh=FeH, afe=aFe, rad_vel=radvel,
-                         rot_vel=rotvel, vmic=vmic, inst_R=inst_R, outwave=outwave)
+                         rot_vel=rotvel, vmic=vmic, inst_R=inst_R, outwave=outwave, cnet=cnet)
     if modpoly:                                      # genmod.py:103-106
         flux = flux * polycalc(polycoef, wave)
     return wave, flux

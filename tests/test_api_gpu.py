@@ -177,3 +177,53 @@ def test_fitpayne_run_end_to_end(tmp_path):
     lines = open(inputdict['output']).read().splitlines()
     assert lines[0].split()[:2] == ['Iter', 'Teff'] and lines[0].split()[-7:] == ['log(lk)', 'log(vol)', 'log(wt)', 'h', 'nc', 'log(z)', 'delta(log(z))']
     assert len(lines) == 1 + r.niter and len(lines[1].split()) == 1 + 7 + 7
+
+
+def test_continuum_network(tmp_path, golden):
+    """PayneSpecPredict(Cnnpath=...): predictcont and getspec with the continuum product
+    (ystpred.py:81-85, 101-117, 191-209) against vectors frozen from the reference, two continuum grids."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    g = golden("g8_continuum")
+    raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    spath = _save_yst(tmp_path, raw)
+    for tag, (lo, hi, npc) in {"full": (5140.0, 5190.0, 600), "short": (5140.0, 5170.0, 333)}.items():
+        cnet = synth.make_cont_net(npix=npc, lam_lo=lo, lam_hi=hi)
+        PP = PayneSpecPredict(nnpath=spath, Cnnpath=_save_yst(tmp_path, cnet, "cont_%s.npz" % tag), NNtype='YST1')
+        assert np.allclose(PP.Canns.wavelength, cnet["wavelength"])
+        for i, l in enumerate(g["labels"]):
+            pc = PP.predictcont(list(l))
+            assert np.abs(pc / g["cont_" + tag][i] - 1.0).max() < 2e-6            # fp32 network, values ~4e-5
+            assert np.abs(PP.predictspec(list(l)) - O.yst_forward(raw, list(l))).max() < 1e-6   # no continuum in predictspec
+            kw = dict(Teff=l[0], logg=l[1], feh=l[2], afe=l[3])
+            w, nat = PP.getspec(**kw)
+            ref = g["native_" + tag][i]
+            assert np.array_equal(np.isnan(nat), np.isnan(ref)) and np.isnan(ref).any() == (tag == "short")
+            assert np.nanmax(np.abs(nat - ref)) < 2e-6
+            for j, (vrad, vrot, R) in enumerate(g["rows"]):
+                _, f = PP.getspec(rad_vel=vrad, rot_vel=vrot, inst_R=2.355 * R, outwave=g["obs"], **kw)
+                ref = g["final_" + tag][i, j]
+                assert np.array_equal(np.isnan(f), np.isnan(ref)), (tag, i, j)
+                assert np.nanmax(np.abs(f - ref)) < 2e-6, (tag, i, j)
+
+
+def test_genmod_with_continuum_network(tmp_path):
+    """GenMod._initspecnn(Cnnpath=...) (genmod.py:28-32): genspec and the batched chi^2 carry the continuum."""
+    from thepayne_amd.fitting.genmod import GenMod
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    cnet = synth.make_cont_net(npix=500, lam_lo=raw["wavelength"][0] - 2.0, lam_hi=raw["wavelength"][-1] + 2.0, H=24)
+    GM = GenMod(b_max=16)
+    GM._initspecnn(nnpath=_save_yst(tmp_path, raw), NNtype='YST1', Cnnpath=_save_yst(tmp_path, cnet, "cont.npz"))
+    GM.configure(obs=(obs, flux, eflux))
+    rng = np.random.default_rng(3)
+    th7 = synth.draw_candidates(8, seed=9)
+    for t in th7[:3]:
+        pars = [float(x) for x in t[:6]] + [np.nan, float(t[6])]
+        w, f = GM.genspec(pars, outwave=obs)
+        _, fr = O.genspec(raw, pars + [np.nan], outwave=obs, cnet=cnet)
+        assert np.array_equal(np.isnan(f), np.isnan(fr)) and np.nanmax(np.abs(f - fr)) < 2e-6
+    from helpers import theta_full
+    got = GM.engine.lnlike_batch(theta_full(th7)).cpu().numpy()
+    ref = np.array([-0.5 * O.chi2_spec(O.genspec(raw, [float(x) for x in t[:6]] + [np.nan, float(t[6]), np.nan], outwave=obs,
+                                                 cnet=cnet)[1], flux, eflux) for t in th7])
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), ok) and np.all(np.abs(got[ok] - ref[ok]) <= lnl_tol(ref[ok]))

@@ -112,3 +112,25 @@ def test_g7_polycalc(golden):
     g = golden("g7_misc")
     for c, ref in zip(g["coefs"], g["poly"]):
         np.testing.assert_allclose(O.polycalc(c, g["wave"]), ref, atol=1e-14)
+
+
+def test_g8_continuum(golden):
+    """Continuum network branch of getspec (ystpred.py:191-209) and predictcont, two continuum grids."""
+    g = golden("g8_continuum")
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    for tag, (lo, hi, npc) in {"full": (5140.0, 5190.0, 600), "short": (5140.0, 5170.0, 333)}.items():
+        cnet = synth.make_cont_net(npix=npc, lam_lo=lo, lam_hi=hi)
+        for i, l in enumerate(g["labels"]):
+            np.testing.assert_allclose(O.ann_forward(cnet, list(l)), g["cont_" + tag][i], rtol=1e-12)
+            kw = dict(Teff=l[0], logg=l[1], feh=l[2], afe=l[3], cnet=cnet)
+            with np.errstate(all="ignore"):
+                nat = O.getspec(net, **kw)[1]
+            assert np.array_equal(np.isnan(nat), np.isnan(g["native_" + tag][i]))
+            assert np.isnan(nat).any() == (tag == "short")
+            np.testing.assert_allclose(nat, g["native_" + tag][i], rtol=1e-12, equal_nan=True)
+            for j, (vrad, vrot, R) in enumerate(g["rows"]):
+                with np.errstate(all="ignore"):
+                    f = O.getspec(net, rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=2.355 * R, outwave=g["obs"], **kw)[1]
+                ref = g["final_" + tag][i, j]
+                assert np.array_equal(np.isnan(f), np.isnan(ref))
+                np.testing.assert_allclose(f, ref, rtol=1e-10, atol=1e-12, equal_nan=True)

@@ -1228,6 +1228,17 @@ struct payne_ctx {
   post_kernel_fn post_fn = nullptr;
   float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
   int big_grid = 0;
+  // optional continuum network (payne_ctx_set_continuum; ystpred.py:81-85, 191-209)
+  bool has_cont = false;
+  int cn_layers = 0, cn_npix = 0, cn_ld_hid = 0;
+  payne_layer clayers[PAYNE_MAX_LAYERS];
+  double cxmin[PAYNE_MAX_LABELS], cxden[PAYNE_MAX_LABELS];
+  float* chid[2] = {nullptr, nullptr};
+  float* cont_raw = nullptr;            // [b_max][cn_npix] continuum ANN output (F_nu)
+  const double* cont_scale = nullptr;   // [cn_npix] (lam_ref / lam_c)^2 : F_nu -> F_lambda up to a constant the median removes
+  const int* cont_idx = nullptr;        // [npix] np.interp(modwave, modcontwave, .) map: left pixel (-1: outside -> NaN)
+  const double* cont_frac = nullptr;    // [npix] weight of the right pixel
+  std::vector<void*> cont_owned;
   bool obs_bound = false;
   CandState* prep = nullptr;      // [b_max] per-candidate records of the post kernel (written by the first dense launch)
   bool prep_valid = false;        // ... as of the last run_ann
@@ -1351,6 +1362,7 @@ extern "C" void payne_ctx_destroy(payne_ctx* c) {
   (void)hipSetDevice(c->device);
   for (void* p : c->owned) (void)hipFree(p);
   for (void* p : c->obs_owned) (void)hipFree(p);
+  for (void* p : c->cont_owned) (void)hipFree(p);
   for (auto& r : c->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   (void)hipSetDevice(prev);
   delete c;
@@ -1539,6 +1551,71 @@ extern "C" int payne_ctx_set_obs(payne_ctx* c, const payne_obs_desc* obs) {
   return rc;
 }
 
+// Continuum network (ystpred.PayneSpecPredict(Cnnpath=...)): weights as for the spectral model; the label
+// set must be the spectral model's.  cont == NULL removes it.
+extern "C" int payne_ctx_set_continuum(payne_ctx* c, const payne_model_desc* cont) {
+  if (!c) return PAYNE_E_INVALID;
+  if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (prev != c->device) (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : c->cont_owned) (void)hipFree(p);
+  c->cont_owned.clear();
+  c->has_cont = false;
+  auto done = [&](int rc) { if (prev != c->device) (void)hipSetDevice(prev); return rc; };
+  if (!cont) return done(PAYNE_OK);
+  if (cont->n_layers < 3 || cont->n_layers > PAYNE_MAX_LAYERS) return done(fail(c, PAYNE_E_INVALID, "continuum.n_layers must be 3..8"));
+  if (cont->n_labels != c->n_labels) return done(fail(c, PAYNE_E_INVALID, "continuum.n_labels != model.n_labels"));
+  if (!cont->xmin || !cont->xmax || !cont->wavelength || cont->npix < 2 || cont->npix > 8192)
+    return done(fail(c, PAYNE_E_INVALID, "continuum.xmin/xmax/wavelength missing or npix outside 2..8192"));
+  if (cont->layers[0].n_in != cont->n_labels || cont->layers[cont->n_layers - 1].n_out != cont->npix)
+    return done(fail(c, PAYNE_E_INVALID, "continuum layer shapes do not match n_labels / npix"));
+  int rc = PAYNE_OK, maxh = 0;
+  for (int l = 0; l < cont->n_layers; ++l) {
+    const payne_layer& L = cont->layers[l];
+    if (!L.w || !L.b || L.n_in <= 0 || L.n_out <= 0) return done(fail(c, PAYNE_E_INVALID, "continuum layer with null weights or bad shape"));
+    if (l > 0 && L.n_in != cont->layers[l - 1].n_out) return done(fail(c, PAYNE_E_INVALID, "continuum layer shapes do not chain"));
+    c->clayers[l] = L;
+    if (l > 0 && (L.n_in & 3)) {            // float4 tile loads need K % 4 == 0: zero-padded copy
+      const int Kp = (L.n_in + 3) & ~3;
+      float* wp = nullptr;
+      if ((rc = dev_alloc(c, (size_t)L.n_out * Kp, &wp, c->cont_owned))) return done(rc);
+      hipError_t he = hipMemcpy2D(wp, (size_t)Kp * 4, L.w, (size_t)L.n_in * 4, (size_t)L.n_in * 4, L.n_out, hipMemcpyDeviceToDevice);
+      if (he != hipSuccess) return done(fail(c, PAYNE_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(he)));
+      c->clayers[l].w = wp; c->clayers[l].n_in = Kp;
+    }
+    if (l + 1 < cont->n_layers) maxh = std::max(maxh, L.n_out);
+  }
+  c->cn_layers = cont->n_layers; c->cn_npix = cont->npix; c->cn_ld_hid = (maxh + 31) & ~31;
+  for (int d = 0; d < cont->n_labels; ++d) { c->cxmin[d] = cont->xmin[d]; c->cxden[d] = cont->xmax[d] - cont->xmin[d]; }
+  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * c->cn_ld_hid, &c->chid[0], c->cont_owned))) return done(rc);
+  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * c->cn_ld_hid, &c->chid[1], c->cont_owned))) return done(rc);
+  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * cont->npix, &c->cont_raw, c->cont_owned, false))) return done(rc);
+  // host tables: F_nu -> F_lambda factor (constants cancel in the median normalisation) and the np.interp map
+  const int npc = cont->npix, npix = c->T.npix;
+  std::vector<double> scale(npc), frac(npix);
+  std::vector<int> idx(npix);
+  const double* wc = cont->wavelength;
+  for (int i = 1; i < npc; ++i)
+    if (!(wc[i] > wc[i - 1])) return done(fail(c, PAYNE_E_INVALID, "continuum.wavelength must be strictly increasing"));
+  const double lref = wc[npc / 2];
+  for (int i = 0; i < npc; ++i) { const double r = lref / wc[i]; scale[i] = r * r; }
+  for (int i = 0; i < npix; ++i) {
+    const double x = c->H.lam[i];
+    if (x < wc[0] || x > wc[npc - 1]) { idx[i] = -1; frac[i] = 0.0; continue; }   // left = right = NaN
+    int k = (int)(std::upper_bound(wc, wc + npc, x) - wc) - 1;
+    if (k > npc - 2) k = npc - 2;
+    idx[i] = k;
+    frac[i] = (x - wc[k]) / (wc[k + 1] - wc[k]);
+  }
+  if ((rc = upload(c, scale, &c->cont_scale, c->cont_owned))) return done(rc);
+  if ((rc = upload(c, idx, &c->cont_idx, c->cont_owned))) return done(rc);
+  if ((rc = upload(c, frac, &c->cont_frac, c->cont_owned))) return done(rc);
+  c->has_cont = true;
+  return done(PAYNE_OK);
+}
+
 // ---- launches --------------------------------------------------------------
 template <int BM, int BN, int BK, bool FUSE>
 static void launch_dense(DenseParams& p, hipStream_t s) {
@@ -1658,35 +1735,39 @@ static bool prep_enabled() {
   return v == 1;
 }
 
-// `instr_factor`: what Inst_R is multiplied by (2.355 in the likelihood / genspec, 1 in getspec): the
-// first-layer launch also writes the post kernel's per-candidate records (c->prep) for that factor.
-static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s) {
-  const int n = c->n_layers;
-  c->prep_valid = false;
+// One network of the context: the spectral emulator or the continuum network.
+struct NetRef {
+  const payne_layer* layers; int n_layers; int n_labels; const double* xmin; const double* xden;
+  float* const* hid; int ld_hid; float* out; int ld_out; float out_shift;
+  bool spectral;                      // the spectral net owns the DMA / bf16x3 operand copies and the prep records
+};
+static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, double instr_factor, hipStream_t s) {
+  const int n = N.n_layers;
   for (int l = 1; l < n; ++l) {
     DenseParams p{};
-    const payne_layer& L = c->layers[l];
+    const payne_layer& L = N.layers[l];
     const bool last = (l == n - 1);
     p.W = L.w; p.K = L.n_in; p.bias = L.b; p.N = L.n_out; p.B = B; p.act = L.act;
-    p.bias_shift = last ? kBase : 0.f;
-    p.Y = last ? c->raw : c->hid[(l - 1) & 1];
-    p.ldy = last ? c->T.npix : c->ld_hid;
-    if (skip_mask() & (last ? 2 : 1)) continue;
+    p.bias_shift = last ? N.out_shift : 0.f;
+    p.Y = last ? N.out : N.hid[(l - 1) & 1];
+    p.ldy = last ? N.ld_out : N.ld_hid;
+    if (N.spectral && (skip_mask() & (last ? 2 : 1))) continue;
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
-      const payne_layer& L0 = c->layers[0];
+      const payne_layer& L0 = N.layers[0];
       p.theta = theta; p.ld_theta = c->ncols;
-      p.W0 = L0.w; p.b0 = L0.b; p.n_labels = c->n_labels; p.act0 = L0.act; p.K0 = L0.n_out;
-      for (int d = 0; d < c->n_labels; ++d) { p.xmin[d] = c->xmin[d]; p.xden[d] = c->xden[d]; }
+      p.W0 = L0.w; p.b0 = L0.b; p.n_labels = N.n_labels; p.act0 = L0.act; p.K0 = L0.n_out;
+      for (int d = 0; d < N.n_labels; ++d) { p.xmin[d] = N.xmin[d]; p.xden[d] = N.xden[d]; }
       PrepArgs pa{};
       pa.T = c->T; pa.instr_factor = instr_factor;
-      pa.out = (c->prep && c->obs_bound && prep_enabled()) ? c->prep : nullptr;
+      pa.out = (N.spectral && c->prep && c->obs_bound && prep_enabled()) ? c->prep : nullptr;
       if (last) launch_dense<64, 64, 32, true>(p, s);
-      else { launch_small<true>(p, pa, s); c->prep_valid = pa.out != nullptr; }
+      else { launch_small<true>(p, pa, s); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
-      p.X = c->hid[(l - 2) & 1]; p.ldx = c->ld_hid;
+      p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last) launch_small<false>(p, pa, s);
+      else if (!N.spectral) launch_dense<64, 64, 32, false>(p, s);
       else if (out_tile_choice() == 8 && c->dma_ok && c->ld_hid >= c->w_out_kp) launch_out_dma(c, p, s);
       else if (out_tile_choice() == 7 && c->w_planes) launch_out_bf16x3(c, p, s);
       else if (out_tile_choice() == 6 && p.K <= OK_KMAX) launch_out_resident(p, s);
@@ -1701,6 +1782,79 @@ static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("dense launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+// ---- continuum network ------------------------------------------------------------------
+// ystpred.py:191-209 for one candidate per workgroup: F_nu -> F_lambda, normalise by the NaN-ignoring
+// median, interpolate onto the spectral ANN grid (NaN outside), multiply into the spectrum.
+// The median is the middle of a bitonic sort in LDS (fp64 keys, NaN -> +inf); the spectrum row is stored
+// shifted by -1, so (m C) - 1 = (m - 1) C + (C - 1).
+__global__ void __launch_bounds__(256) payne_cont_kernel(const float* __restrict__ cont, int npc, int npc2,
+                                                          const double* __restrict__ scale, const int* __restrict__ idx,
+                                                          const double* __restrict__ frac, float* raw, int npix) {
+  extern __shared__ __attribute__((aligned(16))) double cs[];       // [npc2] sort buffer
+  __shared__ double med_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* row = cont + (size_t)b * npc;
+  int nv = 0;
+  for (int i = tid; i < npc2; i += 256) {
+    double q = INFINITY;
+    if (i < npc) { q = (double)row[i] * scale[i]; if (q != q) q = INFINITY; else ++nv; }
+    cs[i] = q;
+  }
+  // number of non-NaN values: wave ballot sums through LDS would do; npc is small, use an LDS atomic
+  __shared__ int nvalid;
+  if (tid == 0) nvalid = 0;
+  __syncthreads();
+  atomicAdd(&nvalid, nv);
+  for (int k = 2; k <= npc2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < npc2; i += 256) {
+        const int p = i ^ j;
+        if (p > i) {
+          const double a = cs[i], c2 = cs[p];
+          const bool up = (i & k) == 0;
+          if ((a > c2) == up) { cs[i] = c2; cs[p] = a; }
+        }
+      }
+    }
+  __syncthreads();
+  if (tid == 0) {
+    const int n = nvalid;                                            // np.nanmedian: mean of the two middle values
+    med_s = n == 0 ? __builtin_nan("") : ((n & 1) ? cs[n >> 1] : 0.5 * (cs[(n >> 1) - 1] + cs[n >> 1]));
+  }
+  __syncthreads();
+  const double med = med_s;
+  float* r = raw + (size_t)b * npix;
+  for (int i = tid; i < npix; i += 256) {
+    const int k = idx[i];
+    double C = __builtin_nan("");
+    if (k >= 0) {
+      const double q0 = (double)row[k] * scale[k], q1 = (double)row[k + 1] * scale[k + 1];
+      C = (q0 + frac[i] * (q1 - q0)) / med;
+    }
+    const float m1 = r[i];
+    r[i] = (float)((double)m1 * C + (C - 1.0));
+  }
+}
+
+// `instr_factor`: what Inst_R is multiplied by (2.355 in the likelihood / genspec, 1 in getspec): the
+// first-layer launch also writes the post kernel's per-candidate records (c->prep) for that factor.
+static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s, bool with_cont = true) {
+  c->prep_valid = false;
+  NetRef N{c->layers, c->n_layers, c->n_labels, c->xmin, c->xden, c->hid, c->ld_hid, c->raw, c->T.npix, kBase, true};
+  int rc = run_net(c, N, theta, B, instr_factor, s);
+  if (rc || !c->has_cont || !with_cont) return rc;
+  NetRef C{c->clayers, c->cn_layers, c->n_labels, c->cxmin, c->cxden, c->chid, c->cn_ld_hid, c->cont_raw, c->cn_npix, 0.f, false};
+  if ((rc = run_net(c, C, theta, B, instr_factor, s))) return rc;
+  int npc2 = 1;
+  while (npc2 < c->cn_npix) npc2 <<= 1;
+  hipLaunchKernelGGL(payne_cont_kernel, dim3(B), dim3(256), (size_t)npc2 * 8, s, c->cont_raw, c->cn_npix, npc2, c->cont_scale,
+                     c->cont_idx, c->cont_frac, c->raw, c->T.npix);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("continuum launch: ") + hipGetErrorString(e));
   return PAYNE_OK;
 }
 
@@ -1774,11 +1928,21 @@ extern "C" int payne_predict_batch(payne_ctx* c, const double* theta, int B, int
   int rc = check_call(c, theta, B, out);
   if (rc) return rc;
   if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
-  if (stage < 0 || stage > 3) return fail(c, PAYNE_E_INVALID, "stage must be 0..3");
+  if (stage < 0 || stage > 4) return fail(c, PAYNE_E_INVALID, "stage must be 0..4");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stage == PAYNE_STAGE_CONT) {                       // predictcont: the continuum network's own output
+    if (!c->has_cont) return fail(c, PAYNE_E_INVALID, "no continuum network bound");
+    if (ld_out < c->cn_npix) return fail(c, PAYNE_E_INVALID, "ld_out too small");
+    NetRef C{c->clayers, c->cn_layers, c->n_labels, c->cxmin, c->cxden, c->chid, c->cn_ld_hid, c->cont_raw, c->cn_npix, 0.f, false};
+    if ((rc = run_net(c, C, theta, B, 1.0, s))) return rc;
+    hipError_t he = hipMemcpy2DAsync(out, (size_t)ld_out * 4, c->cont_raw, (size_t)c->cn_npix * 4, (size_t)c->cn_npix * 4, B,
+                                     hipMemcpyDeviceToDevice, s);
+    if (he != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(he));
+    return PAYNE_OK;
+  }
   if (stage >= 2 && !c->obs_bound) return fail(c, PAYNE_E_INVALID, "no observed grid bound");
   if (ld_out < (stage >= 2 ? c->T.nobs : c->T.npix)) return fail(c, PAYNE_E_INVALID, "ld_out too small");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if ((rc = run_ann(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, s))) return rc;
+  if ((rc = run_ann(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, s, stage != 0))) return rc;   // stage 0 = predictspec: no continuum
   return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage, out, ld_out, nullptr, false, s);
 }
 

@@ -63,6 +63,7 @@ class PayneEngine(object):
         self.phot = phot
         self.npix = 0
         self.nobs = 0
+        self.npix_cont = 0
         mdesc = odesc = pdesc = None
         if spec_net is not None:
             mdesc = self._model_desc(spec_net)
@@ -178,6 +179,22 @@ class PayneEngine(object):
         if rc != 0:
             self._err(rc, "payne_ctx_set_obs")
 
+    def set_continuum(self, net):
+        """Bind a continuum network (normalised like the spectral net by nnio) or, with None, remove it
+        (payne_ctx_set_continuum)."""
+        if net is None:
+            rc = self.lib.payne_ctx_set_continuum(self._ctx, None)
+            self.npix_cont = 0
+        else:
+            npix, nlab, wave = self.npix, self.n_labels, self.wavelength
+            d = self._model_desc(net)                      # (overwrites the three attributes above)
+            self.npix_cont = d.npix
+            self.npix, self.n_labels, self.wavelength = npix, nlab, wave
+            rc = self.lib.payne_ctx_set_continuum(self._ctx, C.byref(d))
+        self._release_host()
+        if rc != 0:
+            self._err(rc, "payne_ctx_set_continuum")
+
     def make_theta(self, B):
         """A NaN-filled [B, ncols] device tensor (NaN = parameter absent)."""
         return self.torch.full((B, self.ncols), float("nan"), dtype=self.torch.float64, device=self.device)
@@ -200,7 +217,7 @@ class PayneEngine(object):
         """Model spectra [B, npix|nobs] fp32 device tensor (payne_predict_batch)."""
         t = self._theta(theta, self.ncols)
         B = t.shape[0]
-        n_out = self.npix if stage < 2 else self.nobs
+        n_out = self.npix if stage < 2 else (self.npix_cont if stage == 4 else self.nobs)
         out = self.torch.empty((B, n_out), dtype=self.torch.float32, device=self.device)
         for s in range(0, B, self.b_max):
             n = min(self.b_max, B - s)

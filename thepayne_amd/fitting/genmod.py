@@ -28,9 +28,9 @@ class GenMod(object):
     def _initspecnn(self, nnpath=None, **kwargs):
         """genmod.py:15-32: NNtype 'YST1' -> ystpred layout, anything else -> predictspec."""
         self.NNtype = kwargs.get('NNtype', 'YST1')
-        if kwargs.get('Cnnpath', None) is not None:
-            raise NotImplementedError("continuum ANN (Cnnpath) is not built")
         self._spec_net = nnio.load_spec_net(nnpath, self.NNtype)
+        Cnnpath = kwargs.get('Cnnpath', None)              # genmod.py:28-32 (the reference's likelihood never passes it)
+        self._cont_net = nnio.load_spec_net(Cnnpath, self.NNtype) if Cnnpath is not None else None
         self._engine = None
 
     def _initphotnn(self, filterarray, nnpath=None):
@@ -51,6 +51,8 @@ class GenMod(object):
             self._engine = PayneEngine(self._spec_net, obs=self._obs, phot=self._phot, obs_phot=self._obs_phot,
                                        npoly=self._npoly, photscale=self._photscale, b_max=self.b_max,
                                        device=self.device)
+            if getattr(self, "_cont_net", None) is not None:
+                self._engine.set_continuum(self._cont_net)
         return self._engine
 
     # -- reference API (one parameter list) --------------------------------------

@@ -47,6 +47,26 @@ class SpecANN(object):
         return out[0] if x.ndim == 1 else out
 
 
+class ContANN(object):
+    """``.Canns``: the continuum network (``Net(Cnnpath)``, ystpred.py:81-85).  It lives in the spectral
+    network's context: from here on every spectrum that context produces past the raw ANN stage is multiplied
+    by the normalised continuum (ystpred.py:191-209)."""
+
+    def __init__(self, nnpath, NNtype, spec_ann):
+        self.nnpath = nnpath
+        self.net = nnio.load_spec_net(nnpath, NNtype)
+        self.xmin, self.xmax = self.net["xmin"], self.net["xmax"]
+        self.wavelength = self.net["wavelength"]
+        self.resolution = self.net["resolution"]
+        self._spec = spec_ann
+        spec_ann.engine.set_continuum(self.net)
+
+    def eval(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        out = self._spec.engine.predict_batch(self._spec._theta(x), stage=4).cpu().numpy().astype(np.float64)
+        return out[0] if x.ndim == 1 else out
+
+
 class PayneSpecPredict(object):
     """Predict spectra from a Payne-learned ANN (drop-in for the reference class)."""
 
@@ -61,10 +81,9 @@ class PayneSpecPredict(object):
         self.NNtype = kwargs.get('NNtype', self.default_NNtype)
         self.anns = SpecANN(self.nnpath, self.NNtype, b_max=kwargs.get('b_max', 256), device=kwargs.get('device'))
         self.Cnnpath = kwargs.get('Cnnpath', None)
-        if self.Cnnpath is not None:
-            raise NotImplementedError("continuum ANN (Cnnpath, ystpred.py:191-209) is not wired into FitPayne "
-                                      "in the reference and is not built here yet")
         self.Canns = None
+        if self.Cnnpath is not None:                    # ystpred.py:81-85
+            self.Canns = ContANN(self.Cnnpath, self.NNtype, self.anns)
         self._bound = None
 
     # -- reference API -----------------------------------------------------------
@@ -73,7 +92,10 @@ class PayneSpecPredict(object):
         return self.anns.eval(labels)
 
     def predictcont(self, labels):
-        raise NotImplementedError("continuum ANN not built (see __init__)")
+        """Continuum network output for the same labels (ystpred.py:101-117)."""
+        if self.Canns is None:
+            raise AttributeError("no continuum network (pass Cnnpath=)")
+        return self.Canns.eval(labels)
 
     @staticmethod
     def _labels_from_kwargs(kwargs):

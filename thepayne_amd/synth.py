@@ -46,6 +46,29 @@ def make_yst_net(npix=4096, lam0=5150.0, R_fwhm=32000.0, H=300, seed=0, D=4, lin
     return net
 
 
+def make_cont_net(npix=600, lam_lo=5145.0, lam_hi=5250.0, H=32, seed=11, D=4):
+    """Random continuum network in the same YST1 container (``Cnnpath`` of ystpred.PayneSpecPredict,
+    Payne/predict/ystpred.py:81-85): a smooth positive F_nu continuum on its own, coarser, linear grid."""
+    rng = np.random.default_rng(seed)
+    wave = np.linspace(lam_lo, lam_hi, npix)
+    x = (wave - wave.mean()) / (wave.max() - wave.min())
+    net = {
+        "kind": "YST1",
+        "w_array_0": rng.normal(0, 0.5, (H, D)).astype(np.float32),
+        "b_array_0": rng.normal(0, 0.1, H).astype(np.float32),
+        "w_array_1": rng.normal(0, np.sqrt(1.0 / H), (H, H)).astype(np.float32),
+        "b_array_1": rng.normal(0, 0.1, H).astype(np.float32),
+        "w_array_2": (0.05 / np.sqrt(H) * np.outer(1.0 + 0.5 * x, rng.normal(0, 1, H))).astype(np.float32),
+        "b_array_2": (3.0e-5 * (1.0 + 0.3 * x + 0.2 * x * x)).astype(np.float32) + np.float32(1.0e-5),
+        "x_min": SPEC_LABEL_MIN[:D].copy() if D <= 4 else np.append(SPEC_LABEL_MIN, 0.5),
+        "x_max": SPEC_LABEL_MAX[:D].copy() if D <= 4 else np.append(SPEC_LABEL_MAX, 2.5),
+        "wavelength": wave,
+        "resolution": 1000.0,
+    }
+    net["w_array_2"] *= np.float32(1.0e-5)          # output ~ 4e-5 +- 1e-6: positive, F_nu-like magnitudes
+    return net
+
+
 def make_torch_net(kind, npix=1024, lam0=5150.0, R_fwhm=32000.0, H=(64, 48, 32), seed=0, D=4):
     """Random LinNet / SMLP state dict with the reference's key names
     (Payne/train/NNmodels.py:58-63, 92-168)."""
