@@ -123,6 +123,14 @@ int payne_ctx_set_obs(payne_ctx* ctx, const payne_obs_desc* obs);
  * Same descriptor as the spectral model (`resolution` unused); n_labels must match; npix <= 8192. */
 int payne_ctx_set_continuum(payne_ctx* ctx, const payne_model_desc* cont);
 
+/* LSF-vector instrumental broadening: getspec(inst_R=<array>, outwave=...) (Payne/predict/ystpred.py:248-269
+ * -> smoothspec(smoothtype='lsf') -> smooth_lsf_fft, Payne/utils/smoothing.py:125-151, 482-586).
+ * lsf: HOST fp64 [n], the Gaussian dispersion (same units as the wavelengths) at every pixel of the bound
+ * observed grid (n must equal its length).  While a vector is set, theta's Inst_R column is ignored by
+ * payne_lnlike_batch and stages 2/3 of payne_predict_batch; results are never NaN inside the model's range
+ * (np.interp clamps).  NULL removes it; payne_ctx_set_obs removes it too.  Spectra up to 8192 pixels. */
+int payne_ctx_set_lsf(payne_ctx* ctx, const double* lsf, int n);
+
 void payne_ctx_destroy(payne_ctx* ctx);
 
 /* Message for the last failure on ctx (ctx == NULL: last create failure). */

@@ -335,8 +335,35 @@ def g8_continuum():
     save("g8_continuum", **out)
 
 
+# ------------------------------------------------------------------ G9
+def g9_lsf():
+    """getspec with an LSF vector for inst_R (ystpred.py:248-269 -> smoothspec 'lsf' -> smooth_lsf_fft):
+    dispersion in AA per observed pixel, three shapes; also genspec / lnlike through GenMod with the array."""
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    rs.register_yst('/g9/yst.h5', net)
+    PP = ystpred.PayneSpecPredict(nnpath='/g9/yst.h5', NNtype='YST1')
+    obs = synth.obs_grid(net["wavelength"], 700, inset=1.5)
+    xo = (obs - obs.mean()) / (obs.max() - obs.min())
+    lsfs = np.array([np.full(len(obs), 0.08), 0.07 * (1.0 + 0.5 * xo), 0.10 + 0.04 * xo ** 2 + 0.02 * xo])
+    labs = np.array([[5300.0, 4.1, -0.3, 0.15], [6400.0, 3.2, -1.4, 0.4]])
+    rows = np.array([(0.0, 0.0), (12.0, 4.0), (-35.0, 9.0), (250.0, 1.5)])
+    fin = np.zeros((len(labs), len(lsfs), len(rows), len(obs)))
+    for a, l in enumerate(labs):
+        kw = dict(Teff=l[0], logg=l[1], feh=l[2], afe=l[3])
+        for b, lsf in enumerate(lsfs):
+            for c, (vrad, vrot) in enumerate(rows):
+                with np.errstate(all="ignore"):
+                    fin[a, b, c] = PP.getspec(rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=lsf, outwave=obs, **kw)[1]
+    # on the model grid itself (outwave=None): the vector must have the model's length
+    lsf_native = 0.09 * (1.0 + 0.3 * (net["wavelength"] - net["wavelength"].mean()) / 20.0)
+    with np.errstate(all="ignore"):
+        native = PP.getspec(rad_vel=8.0, rot_vel=3.0, inst_R=lsf_native, Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
+    save("g9_lsf", obs=obs, lsfs=lsfs, labels=labs, rows=rows, final=fin, lsf_native=lsf_native,
+         native_wave=native[0], native=native[1])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum}[k]()
+         "g8": g8_continuum, "g9": g9_lsf}[k]()

@@ -10,7 +10,7 @@ __all__ = [
     "CKMS", "SIGMA_TO_FWHM", "C_KMS_DOPPLER",
     "leaky_relu", "yst_encode", "yst_forward", "torchnet_forward", "ann_forward",
     "mask_range", "resample_pow2", "taper_vsini", "taper_gauss", "fft_convolve",
-    "smooth_vsini", "smooth_R", "getspec", "polycalc", "genspec",
+    "smooth_vsini", "smooth_R", "smooth_lsf", "getspec", "polycalc", "genspec",
     "chi2_spec", "fastann_forward", "highav_offset", "sed_mags",
     "genphot", "genphot_scaled", "OracleLikelihood", "lnprobfn",
 ]
@@ -162,6 +162,30 @@ def smooth_R(wave, spec, Rsigma, outwave, R_ann, return_parts=False):
     return out
 
 
+def smooth_lsf(wave, spec, disparr, outwave, pix_per_sigma=2):
+    """smoothspec(..., smoothtype='lsf', fftsmooth=True) -> smooth_lsf_fft
+    (Payne/utils/smoothing.py:125-128, 131-151, 482-586): wavelength-dependent Gaussian LSF of dispersion
+    ``disparr`` (same units as ``wave``, one value per input pixel) by warping to the coordinate in which the
+    LSF has constant width.  Returns the smoothed spectrum on ``outwave`` (np.interp: clamped, no NaN)."""
+    wlim = np.array([outwave.min(), outwave.max()]) + 20.0 * 100 * np.array([-1, 1])      # mask_wave, linear, width=100
+    mask = (wave > wlim[0]) & (wave < wlim[1])
+    w, s, sigma = wave[mask], np.nan_to_num(spec[mask], nan=1.0), disparr[mask]
+    dw = np.gradient(w)
+    cdf = np.cumsum(dw / sigma)
+    cdf /= cdf.max()
+    sigma_per_pixel = dw / sigma
+    x_per_pixel = np.gradient(cdf)
+    x_per_sigma = np.nanmedian(x_per_pixel / sigma_per_pixel)
+    N = pix_per_sigma / x_per_sigma
+    nx = int(2 ** np.ceil(np.log2(N)))
+    x = np.linspace(0, 1, nx)
+    dx = 1.0 / nx
+    lam = np.interp(x, cdf, w)
+    newspec = np.interp(lam, w, s)
+    conv = fft_convolve(newspec, taper_gauss(nx, dx, x_per_sigma))          # smooth_fft(dx, newspec, x_per_sigma)
+    return np.interp(outwave, lam, conv)
+
+
 def getspec(net, Teff=5770.0, logg=4.44, feh=0.0, afe=0.0, rad_vel=None, rot_vel=None,
             vmic=None, inst_R=None, outwave=None, return_stages=False, cnet=None):
     """``PayneSpecPredict.getspec`` (Payne/predict/ystpred.py:119-277 ==
@@ -202,8 +226,12 @@ def getspec(net, Teff=5770.0, logg=4.44, feh=0.0, afe=0.0, rad_vel=None, rot_vel
             if inst_R > 0.0:
                 smoothed = True
                 modspec = smooth_R(modwave, modspec, inst_R, outwave, net["resolution"])
-        else:
-            raise NotImplementedError("LSF-vector inst_R (ystpred.py:248-269) is outside the oracle")
+        else:                                        # LSF: dispersion (AA) per output pixel, ystpred.py:248-269
+            smoothed = True
+            inst_R = np.asarray(inst_R, dtype=np.float64)
+            disparr = np.interp(modwave, outwave, inst_R) if outwave is not None else inst_R
+            assert len(disparr) == len(modwave), "Length of LSF vector not equal to input wavelength"
+            modspec = smooth_lsf(modwave, modspec, disparr, outwave if outwave is not None else modwave)
     if (not smoothed) and (outwave is not None):     # ystpred.py:271-272
         modspec = np.interp(outwave, modwave, modspec, right=np.nan, left=np.nan)
     if outwave is not None:

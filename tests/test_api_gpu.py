@@ -43,8 +43,8 @@ def test_payne_spec_predict_yst(tmp_path):
     assert np.abs(f1 - f2).max() < 2e-6
     _, fs = PP.getspec()
     assert np.abs(fs - O.yst_forward(raw, [5770.0, 4.44, 0.0, 0.0])).max() < 1e-6
-    with pytest.raises(NotImplementedError):
-        PP.getspec(**kw, inst_R=np.full(1024, 0.1), outwave=obs)                   # LSF vector: not built yet
+    with pytest.raises(ValueError):
+        PP.getspec(**kw, inst_R=np.full(1024, 0.1), outwave=obs)                   # LSF vector of the wrong length (np.interp raises)
 
 
 def test_payne_spec_predict_linnet(tmp_path):
@@ -227,3 +227,48 @@ def test_genmod_with_continuum_network(tmp_path):
                                                  cnet=cnet)[1], flux, eflux) for t in th7])
     ok = np.isfinite(ref)
     assert np.array_equal(np.isfinite(got), ok) and np.all(np.abs(got[ok] - ref[ok]) <= lnl_tol(ref[ok]))
+
+
+def test_lsf_vector_inst_R(tmp_path, golden):
+    """getspec(inst_R=<dispersion per output pixel>) (ystpred.py:248-269 -> smooth_lsf_fft) against vectors
+    frozen from the reference: three LSF shapes x Doppler / rotation, plus the model-grid (outwave=None) form."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    g = golden("g9_lsf")
+    raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    worst = 0.0
+    for a, l in enumerate(g["labels"]):
+        kw = dict(Teff=l[0], logg=l[1], feh=l[2], afe=l[3])
+        for b, lsf in enumerate(g["lsfs"]):
+            for c, (vrad, vrot) in enumerate(g["rows"]):
+                w, f = PP.getspec(rad_vel=vrad, rot_vel=vrot, inst_R=lsf, outwave=g["obs"], **kw)
+                assert np.array_equal(w, g["obs"]) and not np.isnan(f).any()
+                worst = max(worst, np.abs(f - g["final"][a, b, c]).max())
+    assert worst < 2e-6, worst
+    w, f = PP.getspec(rad_vel=8.0, rot_vel=3.0, inst_R=g["lsf_native"], Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
+    assert np.allclose(w, g["native_wave"], rtol=1e-14) and np.abs(f - g["native"]).max() < 2e-6
+    # a scalar call afterwards is unaffected (the vector is bound for the call only)
+    _, fs = PP.getspec(rad_vel=12.0, rot_vel=4.0, inst_R=2.355 * 28000.0, outwave=g["obs"], Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
+    _, fr = O.getspec(raw, Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15, rad_vel=12.0, rot_vel=4.0, inst_R=2.355 * 28000.0, outwave=g["obs"])
+    assert np.nanmax(np.abs(fs - fr)) < 1e-6
+    with pytest.raises(RuntimeError):
+        PP.anns.engine.set_lsf(np.full(len(g["obs"]) - 1, 0.1))
+
+
+def test_fixed_lsf_vector_in_the_likelihood(tmp_path):
+    """A fixed array-valued Inst_R (fixedpars) reaches getspec as an LSF vector (genmod.py:82-85)."""
+    from thepayne_amd.fitting.likelihood import likelihood
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    lsf = 0.075 * (1.0 + 0.3 * (obs - obs.mean()) / (obs.max() - obs.min()))
+    on = [p for p in SPEC_PARS if p != 'Inst_R']
+    fitpars = [list(ALL_PARS), {p: p in on for p in ALL_PARS}]
+    fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+               'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1', 'fixedpars': {'Inst_R': lsf}}
+    L = likelihood(fitargs, fitpars, [True, False, False, False, False], b_max=8)
+    th = synth.draw_candidates(6, seed=4)[:, :6]
+    got = L.lnlike_batch(th)
+    ref = np.array([-0.5 * O.chi2_spec(O.genspec(raw, [float(x) for x in t] + [np.nan, lsf, np.nan], outwave=obs)[1], flux, eflux)
+                    for t in th])
+    assert np.all(np.isfinite(got)) and np.all(np.abs(got - ref) <= lnl_tol(ref))
+    w, f = L.GM.genspec([float(x) for x in th[0]] + [np.nan, lsf], outwave=obs)
+    assert np.abs(f - O.genspec(raw, [float(x) for x in th[0]] + [np.nan, lsf, np.nan], outwave=obs)[1]).max() < 2e-6

@@ -134,3 +134,21 @@ def test_g8_continuum(golden):
                 ref = g["final_" + tag][i, j]
                 assert np.array_equal(np.isnan(f), np.isnan(ref))
                 np.testing.assert_allclose(f, ref, rtol=1e-10, atol=1e-12, equal_nan=True)
+
+
+def test_g9_lsf(golden):
+    """LSF-vector inst_R (ystpred.py:248-269, smoothing.py:125-151, 482-586)."""
+    g = golden("g9_lsf")
+    net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    for a, l in enumerate(g["labels"]):
+        kw = dict(Teff=l[0], logg=l[1], feh=l[2], afe=l[3])
+        for b, lsf in enumerate(g["lsfs"]):
+            for c, (vrad, vrot) in enumerate(g["rows"]):
+                with np.errstate(all="ignore"):
+                    f = O.getspec(net, rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=lsf, outwave=g["obs"], **kw)[1]
+                assert not np.isnan(f).any()
+                np.testing.assert_allclose(f, g["final"][a, b, c], rtol=1e-10, atol=1e-12)
+    with np.errstate(all="ignore"):
+        w, f = O.getspec(net, rad_vel=8.0, rot_vel=3.0, inst_R=g["lsf_native"], Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
+    np.testing.assert_allclose(w, g["native_wave"], rtol=1e-15)
+    np.testing.assert_allclose(f, g["native"], rtol=1e-10, atol=1e-12)

@@ -14,7 +14,7 @@ ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
 F_FWHM_R = 1
 ABI_VERSION = 1
 
-SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_destroy", "payne_last_error",
+SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_destroy", "payne_last_error",
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
@@ -112,6 +112,8 @@ def load(path=None):
     lib.payne_ctx_set_obs.restype = C.c_int
     lib.payne_ctx_set_continuum.argtypes = [ctxp, C.POINTER(ModelDesc)]
     lib.payne_ctx_set_continuum.restype = C.c_int
+    lib.payne_ctx_set_lsf.argtypes = [ctxp, C.POINTER(C.c_double), C.c_int]
+    lib.payne_ctx_set_lsf.restype = C.c_int
     lib.payne_ctx_destroy.argtypes = [ctxp]
     lib.payne_ctx_destroy.restype = None
     lib.payne_last_error.argtypes = [ctxp]

@@ -21,6 +21,7 @@ struct HostTables {
   std::vector<int> rs1_idx, bk1_idx;
   std::vector<float> rs1_frac, bk1_frac, obs_f1, obs_ivar;
   std::vector<ObsRec> obs_rec;
+  std::vector<double> obs_wave;     // the observed grid itself (LSF path: np.interp in wavelength)
   double vs_val = 0, obs_min = 0, obs_max = 0, geo_inv_dln = 0;
   bool has_flux = false;
   int geo = 0, rot_identity = 0;
@@ -172,6 +173,7 @@ inline int build_obs_tables(const double* wave, const double* flux, const double
       H.obs_ivar[i] = (float)(1.0 / (eflux[i] * eflux[i]));
     }
   }
+  H.obs_wave.assign(wave, wave + nobs);
   H.obs_rec.resize(nobs);
   for (int i = 0; i < nobs; ++i)
     H.obs_rec[i] = ObsRec{H.lnobs[i], H.has_flux ? H.obs_f1[i] : 0.f, H.has_flux ? H.obs_ivar[i] : 0.f};

@@ -1091,6 +1091,224 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   }
 }
 
+// ============================================================================
+// LSF-vector instrumental broadening (inst_R = dispersion in AA per observed pixel):
+// ystpred.py:248-269 -> smoothspec(smoothtype='lsf') -> smooth_lsf_fft (smoothing.py:125-151, 482-586).
+// Not on the sampler's usual path (Inst_R is a sampled scalar there); one workgroup per candidate,
+// fp64 position arithmetic through a global workspace, written for clarity rather than speed:
+//   mask (linear, +-2000 AA) -> sigma_i = interp(lambda_i (1+rv/c), obs, lsf) -> r = gradient(w)/sigma ->
+//   cdf = cumsum(r)/max -> x_per_sigma = nanmedian(gradient(cdf)/r) -> nx = 2^ceil(log2(2/x_per_sigma)) ->
+//   lam = interp(linspace(0,1,nx), cdf, w); s' = interp(lam, w, s) -> Gaussian FFT smoothing of width
+//   x_per_sigma (dx = 1/nx) -> np.interp(obs, lam, .) (clamped: no NaN) -> blaze -> chi^2.
+// Input: the spectrum after rotational broadening on the ANN grid (post kernel, stage 5), shifted by -1.
+// ============================================================================
+struct LsfArgs {
+  const double* theta; int ld_theta;
+  const float* spec; int ld_spec;        // [B][npix] after vsini, shifted
+  const double* obs_wave; const double* lsf; // [nobs]
+  double* ws; size_t ws_stride;          // per candidate: a[npix] | cdf[npix] | lam[n1]
+  float* out; int ld_out; int out_stage; // 2 / 3 / -1
+  double* lnl;
+  const double* mags; int n_filters; const double* obs_mag; const double* obs_err;
+};
+// np.interp(x, xp, fp) (arr_interp): clamped outside, slope form inside
+__device__ double interp_np(double x, const double* xp, const double* fp, int n) {
+  if (x > xp[n - 1]) return fp[n - 1];
+  if (x < xp[0]) return fp[0];
+  int lo = 0, hi = n;                                   // last j with xp[j] <= x
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
+  const int j = lo;
+  if (j == n - 1 || xp[j] == x) return fp[j];
+  const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  return slope * (x - xp[j]) + fp[j];
+}
+__global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  double* sortb = reinterpret_cast<double*>(lsm);                      // [n1] median sort buffer
+  float* bufA = reinterpret_cast<float*>(sortb + T.n1);
+  float* bufB = bufA + fft_buf_floats(T.n1);
+  double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(T.n1));    // [256 + 8]
+  __shared__ int cnt_s[2], nvalid_s, nx_s;
+  __shared__ double scal_s[4];                                         // 0 max(cdf), 1 x_per_sigma
+  const int b = blockIdx.x, tid = threadIdx.x, npix = T.npix, nobs = T.nobs;
+  const double* th = a.theta + (size_t)b * a.ld_theta;
+  const float* sp = a.spec + (size_t)b * a.ld_spec;
+  double* wsA = a.ws + (size_t)b * a.ws_stride;
+  double* wsC = wsA + npix;
+  double* wsL = wsC + npix;
+  const double rv = th[4];
+  const double op = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;      // ystpred.py:228-232
+  // ---- mask_wave(linear=True, width=100): strict limits obs.min - 2000, obs.max + 2000
+  const double wl = T.obs_min + 20.0 * 100.0 * -1.0, wh = T.obs_max + 20.0 * 100.0 * 1.0;
+  if (tid < 2) cnt_s[tid] = 0;
+  __syncthreads();
+  {
+    int cb = 0, ca = 0;
+    for (int i = tid; i < npix; i += 256) { const double c = T.lam[i] * op; cb += !(c > wl); ca += (c < wh); }
+    atomicAdd(&cnt_s[0], cb); atomicAdd(&cnt_s[1], ca);
+  }
+  __syncthreads();
+  const int i0 = cnt_s[0], n = cnt_s[1] - cnt_s[0];
+  bool bad = n < 8;
+  auto W = [&](int i) { return T.lam[i0 + i] * op; };
+  if (!bad) {
+    // ---- sigma_i (disparr = np.interp(modwave, outwave, inst_R)), r_i = gradient(w)_i / sigma_i
+    for (int i = tid; i < n; i += 256) {
+      const double sig = interp_np(W(i), a.obs_wave, a.lsf, nobs);
+      const double dw = (i == 0) ? (W(1) - W(0)) : ((i == n - 1) ? (W(n - 1) - W(n - 2)) : (W(i + 1) - W(i - 1)) / 2.0);
+      wsA[i] = dw / sig;
+    }
+    __syncthreads();
+    // ---- cdf = cumsum(r): per-thread chunks, then a scan of the 256 chunk sums
+    const int chunk = (n + 255) / 256, c0 = tid * chunk, c1 = (c0 + chunk < n) ? c0 + chunk : n;
+    double acc = 0.0;
+    for (int i = c0; i < c1; ++i) { acc += wsA[i]; wsC[i] = acc; }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid == 0) { double run = 0.0; for (int t = 0; t < 256; ++t) { const double v = red[t]; red[t] = run; run += v; } }
+    __syncthreads();
+    const double offs = red[tid];
+    double mx = -INFINITY; bool anynan = false;
+    for (int i = c0; i < c1; ++i) { const double v = wsC[i] + offs; wsC[i] = v; if (v != v) anynan = true; mx = v > mx ? v : mx; }
+    __syncthreads();
+    red[tid] = anynan ? __builtin_nan("") : mx;
+    __syncthreads();
+    if (tid == 0) {
+      double m = -INFINITY; bool nn = false;
+      for (int t = 0; t < 256; ++t) { const double v = red[t]; if (v != v) nn = true; else m = v > m ? v : m; }
+      scal_s[0] = nn ? __builtin_nan("") : m;                           // ndarray.max() propagates NaN
+      nvalid_s = 0;
+    }
+    __syncthreads();
+    const double cmax = scal_s[0];
+    for (int i = tid; i < n; i += 256) wsC[i] = wsC[i] / cmax;           // cdf /= cdf.max()
+    __syncthreads();
+    // ---- x_per_sigma = nanmedian(gradient(cdf) / r): bitonic sort of the ratios in LDS
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    int nv = 0;
+    for (int i = tid; i < n2; i += 256) {
+      double q = INFINITY;
+      if (i < n) {
+        const double g = (i == 0) ? (wsC[1] - wsC[0]) : ((i == n - 1) ? (wsC[n - 1] - wsC[n - 2]) : (wsC[i + 1] - wsC[i - 1]) / 2.0);
+        q = g / wsA[i];
+        if (q != q) q = INFINITY; else ++nv;
+      }
+      sortb[i] = q;
+    }
+    atomicAdd(&nvalid_s, nv);
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        __syncthreads();
+        for (int i = tid; i < n2; i += 256) {
+          const int p = i ^ j;
+          if (p > i) {
+            const double x0 = sortb[i], x1 = sortb[p];
+            const bool up = (i & k) == 0;
+            if ((x0 > x1) == up) { sortb[i] = x1; sortb[p] = x0; }
+          }
+        }
+      }
+    __syncthreads();
+    if (tid == 0) {
+      const int m = nvalid_s;
+      const double xps = m == 0 ? __builtin_nan("") : ((m & 1) ? sortb[m >> 1] : 0.5 * (sortb[(m >> 1) - 1] + sortb[m >> 1]));
+      scal_s[1] = xps;
+      const double N = 2.0 / xps;                                       // pix_per_sigma = 2
+      int nx = 0;
+      if (N == N && N > 0.0 && N <= (double)T.n1) { nx = 1; while ((double)nx < N) nx <<= 1; }
+      nx_s = nx;
+    }
+    __syncthreads();
+  }
+  const int nx = bad ? 0 : nx_s;
+  bad = bad || nx < 8 || nx > T.n1;        // x_per_sigma NaN / a grid finer than the context's FFT tables: NaN result
+  const float* conv = bufA;
+  if (!bad) {
+    // ---- lam = np.interp(linspace(0, 1, nx), cdf, w);  newspec = np.interp(lam, w, s)
+    const double step = 1.0 / (double)(nx - 1);
+    for (int j = tid; j < nx; j += 256) {
+      const double x = (j == nx - 1) ? 1.0 : (double)j * step;
+      double lamj; int k;
+      if (x > wsC[n - 1]) { lamj = W(n - 1); k = n - 2; }
+      else if (x < wsC[0]) { lamj = W(0); k = 0; }
+      else {
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wsC[mid] <= x) lo = mid; else hi = mid; }
+        k = lo;
+        if (k == n - 1 || wsC[k] == x) lamj = W(k);
+        else { const double slope = (W(k + 1) - W(k)) / (wsC[k + 1] - wsC[k]); lamj = slope * (x - wsC[k]) + W(k); }
+        if (k > n - 2) k = n - 2;
+      }
+      wsL[j] = lamj;
+      // np.interp(lamj, w, s): w[k2] <= lamj < w[k2+1]; k is right up to rounding at the pixel edges
+      int k2 = k;
+      while (k2 > 0 && lamj < W(k2)) --k2;
+      while (k2 < n - 2 && lamj >= W(k2 + 1)) ++k2;
+      const double s0 = (double)nan_to_zero(sp[i0 + k2]), s1 = (double)nan_to_zero(sp[i0 + k2 + 1]);   // nan_to_num(nan=1.0), shifted
+      double v;
+      if (lamj >= W(n - 1)) v = (double)nan_to_zero(sp[i0 + n - 1]);
+      else if (lamj <= W(0)) v = (double)nan_to_zero(sp[i0]);
+      else v = (s1 - s0) / (W(k2 + 1) - W(k2)) * (lamj - W(k2)) + s0;
+      bufB[j] = (float)v;
+    }
+    __syncthreads();
+    // ---- smooth_fft(dx = 1/nx, newspec, x_per_sigma): taper exp(-2 pi^2 sigma^2 k^2)
+    DevExecT<true, false> ex;
+    TaperArgs ta{};
+    const double xps = scal_s[1];
+    ta.g_c2 = (float)(-2.0 * (kPi * kPi) * (xps * xps) * 1.4426950408889634);
+    bool no_edge = false;
+    conv = conv_stage<0, 256, false>(ex, T, T.tw, bufB, bufA, nx, ta, no_edge);
+  }
+  // ---- np.interp(outwave, lam, conv) (clamped), blaze, chi^2
+  const bool cheb = T.npoly > 0 && a.out_stage != 2, hasf = T.obs_f1 != nullptr;
+  double accx = 0.0;
+  for (int i = tid; i < nobs; i += 256) {
+    float m1 = nanf_();
+    if (!bad) {
+      const double x = a.obs_wave[i];
+      if (x > wsL[nx - 1]) m1 = conv[nx - 1];
+      else if (x < wsL[0]) m1 = conv[0];
+      else {
+        int lo = 0, hi = nx;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wsL[mid] <= x) lo = mid; else hi = mid; }
+        const int j = lo;
+        if (j == nx - 1 || wsL[j] == x) m1 = conv[j];
+        else m1 = (float)(((double)conv[j + 1] - (double)conv[j]) / (wsL[j + 1] - wsL[j]) * (x - wsL[j]) + (double)conv[j]);
+      }
+    }
+    double pv = 1.0;
+    if (cheb) {                                           // chebval, fitutils.py:11-20
+      const double xc = T.xcheb[i];
+      const int nc = T.npoly;
+      double c0, c1;
+      if (nc == 1) { c0 = th[8]; c1 = 0.0; }
+      else if (nc == 2) { c0 = th[8]; c1 = th[9]; }
+      else {
+        const double x2 = 2.0 * xc;
+        c0 = th[8 + nc - 2]; c1 = th[8 + nc - 1];
+        for (int r = 3; r <= nc; ++r) { const double t = c0; c0 = th[8 + nc - r] - c1; c1 = t + c1 * x2; }
+      }
+      pv = c0 + c1 * xc;
+    }
+    const double model1 = (double)m1 * pv + (pv - 1.0);   // (m - 1) p + (p - 1) = m p - 1
+    if (a.out) a.out[(size_t)b * a.ld_out + i] = (float)(model1 + 1.0);
+    if (hasf && a.lnl) { const double d = model1 - (double)T.obs_f1[i]; accx += (d * d) * (double)T.obs_ivar[i]; }
+  }
+  if (a.lnl) {
+    __syncthreads();
+    red[tid] = accx;
+    __syncthreads();
+    if (tid == 0) {
+      double x2 = 0.0;
+      for (int t = 0; t < 256; ++t) x2 += red[t];
+      if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+      a.lnl[b] = -0.5 * x2;
+    }
+  }
+}
+
 typedef void (*post_kernel_fn)(const PostTables, PostArgs);
 // compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
 static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
@@ -1239,6 +1457,13 @@ struct payne_ctx {
   const int* cont_idx = nullptr;        // [npix] np.interp(modwave, modcontwave, .) map: left pixel (-1: outside -> NaN)
   const double* cont_frac = nullptr;    // [npix] weight of the right pixel
   std::vector<void*> cont_owned;
+  // optional LSF vector (payne_ctx_set_lsf): dispersion in AA per bound observed pixel; replaces Inst_R
+  bool has_lsf = false;
+  const double* d_obs_wave = nullptr;   // [nobs] (obs_owned)
+  const double* lsf = nullptr;          // [nobs]
+  float* lsf_spec = nullptr;            // [b_max][npix] spectra after vsini, shifted
+  double* lsf_ws = nullptr;             // [b_max][2 npix + n1]
+  std::vector<void*> lsf_owned;
   bool obs_bound = false;
   CandState* prep = nullptr;      // [b_max] per-candidate records of the post kernel (written by the first dense launch)
   bool prep_valid = false;        // ... as of the last run_ann
@@ -1320,6 +1545,8 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   for (void* p : c->obs_owned) (void)hipFree(p);
   c->obs_owned.clear();
   c->obs_bound = false;
+  for (void* p : c->lsf_owned) (void)hipFree(p);      // an LSF vector belongs to the grid it was given on
+  c->lsf_owned.clear(); c->has_lsf = false; c->d_obs_wave = nullptr;
   c->T.nobs = 0; c->T.lnobs = nullptr; c->T.obs_rec = nullptr; c->T.xcheb = nullptr; c->T.obs_f1 = nullptr; c->T.obs_ivar = nullptr;
   if (!obs || obs->nobs <= 0) return sync_tables(c);
   if (!obs->wave) return fail(c, PAYNE_E_INVALID, "obs.wave is NULL");
@@ -1328,6 +1555,7 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   int rc;
   if ((rc = upload(c, c->H.lnobs, &c->T.lnobs, c->obs_owned))) return rc;
   if ((rc = upload(c, c->H.obs_rec, &c->T.obs_rec, c->obs_owned))) return rc;
+  if ((rc = upload(c, c->H.obs_wave, &c->d_obs_wave, c->obs_owned))) return rc;
   if ((rc = upload(c, c->H.xcheb, &c->T.xcheb, c->obs_owned))) return rc;
   if (c->H.has_flux) {
     if ((rc = upload(c, c->H.obs_f1, &c->T.obs_f1, c->obs_owned))) return rc;
@@ -1363,6 +1591,7 @@ extern "C" void payne_ctx_destroy(payne_ctx* c) {
   for (void* p : c->owned) (void)hipFree(p);
   for (void* p : c->obs_owned) (void)hipFree(p);
   for (void* p : c->cont_owned) (void)hipFree(p);
+  for (void* p : c->lsf_owned) (void)hipFree(p);
   for (auto& r : c->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   (void)hipSetDevice(prev);
   delete c;
@@ -1613,6 +1842,38 @@ extern "C" int payne_ctx_set_continuum(payne_ctx* c, const payne_model_desc* con
   if ((rc = upload(c, idx, &c->cont_idx, c->cont_owned))) return done(rc);
   if ((rc = upload(c, frac, &c->cont_frac, c->cont_owned))) return done(rc);
   c->has_cont = true;
+  return done(PAYNE_OK);
+}
+
+// LSF vector for the instrumental broadening: `lsf[n]` = Gaussian dispersion (AA) at each pixel of the bound
+// observed grid (getspec(inst_R=array, outwave=...), ystpred.py:248-269).  While set, theta's Inst_R column
+// is ignored.  NULL removes it; re-binding the observed grid removes it too.
+extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) {
+  if (!c) return PAYNE_E_INVALID;
+  if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (prev != c->device) (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : c->lsf_owned) (void)hipFree(p);
+  c->lsf_owned.clear();
+  c->has_lsf = false;
+  auto done = [&](int rc) { if (prev != c->device) (void)hipSetDevice(prev); return rc; };
+  if (!lsf) return done(PAYNE_OK);
+  if (!c->obs_bound) return done(fail(c, PAYNE_E_INVALID, "bind the observed grid before its LSF vector"));
+  if (n != c->T.nobs) return done(fail(c, PAYNE_E_INVALID, "the LSF vector must have one entry per observed pixel"));
+  if (c->T.n1 > 8192) return done(fail(c, PAYNE_E_UNSUPPORTED, "LSF broadening is built for spectra up to 8192 pixels"));
+  for (int i = 0; i < n; ++i)
+    if (!(lsf[i] > 0.0)) return done(fail(c, PAYNE_E_INVALID, "LSF dispersions must be positive"));
+  std::vector<double> v(lsf, lsf + n);
+  int rc;
+  if ((rc = upload(c, v, &c->lsf, c->lsf_owned))) return done(rc);
+  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * c->T.npix, &c->lsf_spec, c->lsf_owned, false))) return done(rc);
+  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * (2 * (size_t)c->T.npix + c->T.n1), &c->lsf_ws, c->lsf_owned, false))) return done(rc);
+  const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
+  hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_lsf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (he != hipSuccess) return done(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
+  c->has_lsf = true;
   return done(PAYNE_OK);
 }
 
@@ -1883,8 +2144,12 @@ static int run_sed(payne_ctx* c, const double* in, int ld, int mode, int B, doub
   return PAYNE_OK;
 }
 
+static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, float* out, int ld_out, double* lnl,
+                        bool with_phot, hipStream_t s);
+
 static int run_post(payne_ctx* c, const double* theta, int B, double instr_factor, int stage, float* out, int ld_out,
                     double* lnl, bool with_phot, hipStream_t s) {
+  if (c->has_lsf && (stage < 0 || stage == 2 || stage == 3)) return run_post_lsf(c, theta, B, stage, out, ld_out, lnl, with_phot, s);
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = instr_factor;
   a.raw = c->raw; a.ld_raw = c->T.npix;
@@ -1903,6 +2168,31 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("post launch: ") + hipGetErrorString(e));
+  return PAYNE_OK;
+}
+
+// LSF path: spectra after rotational broadening (post kernel, stage 5) -> payne_lsf_kernel
+static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, float* out, int ld_out, double* lnl,
+                        bool with_phot, hipStream_t s) {
+  if (c->big_ws) return fail(c, PAYNE_E_UNSUPPORTED, "LSF broadening is built for spectra up to 8192 pixels");
+  const bool had = c->has_lsf;
+  c->has_lsf = false;                                      // (the stage-5 pass below goes through run_post)
+  int rc = run_post(c, theta, B, 1.0, 5, c->lsf_spec, c->T.npix, nullptr, false, s);
+  c->has_lsf = had;
+  if (rc) return rc;
+  LsfArgs a{};
+  a.theta = theta; a.ld_theta = c->ncols; a.spec = c->lsf_spec; a.ld_spec = c->T.npix;
+  a.obs_wave = c->d_obs_wave; a.lsf = c->lsf;
+  a.ws = c->lsf_ws; a.ws_stride = 2 * (size_t)c->T.npix + c->T.n1;
+  a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
+  if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
+  const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
+  {
+    ProfScope ps(c, s, 1);
+    hipLaunchKernelGGL(payne_lsf_kernel, dim3(B), dim3(256), lds, s, c->T, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("lsf launch: ") + hipGetErrorString(e));
   return PAYNE_OK;
 }
 

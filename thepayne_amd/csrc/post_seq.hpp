@@ -90,7 +90,7 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
   return (float*)fft_run(ex, z, zo, M, tw, T.nmax, true);
 }
 
-// out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze)
+// out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze) | 5 after vsini, shifted
 template <int LOG2N, int NT, class Ex>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
@@ -129,13 +129,14 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     spec = dst;
     work = conv;
     edges_pending = edge;
-    if (edges_pending && (out_stage == 1 || !smooth)) {
+    if (edges_pending && (out_stage == 1 || out_stage == 5 || !smooth)) {
       ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
       edges_pending = false;
     }
   }
-  if (out_stage == 1) {
-    ex.par([&](int t, int n) { for (int i = t; i < T.npix; i += n) out[i] = spec[i] + kBase; });
+  if (out_stage == 1 || out_stage == 5) {               // 5: the same, still shifted by -1 (input of the LSF kernel)
+    const float base = out_stage == 1 ? kBase : 0.f;
+    ex.par([&](int t, int n) { for (int i = t; i < T.npix; i += n) out[i] = spec[i] + base; });
     return;
   }
   const float* on_grid = spec;

@@ -179,6 +179,17 @@ class PayneEngine(object):
         if rc != 0:
             self._err(rc, "payne_ctx_set_obs")
 
+    def set_lsf(self, lsf):
+        """Bind an LSF vector (dispersion per pixel of the bound observed grid) or, with None, remove it
+        (payne_ctx_set_lsf).  While set, theta's Inst_R column is ignored."""
+        if lsf is None:
+            rc = self.lib.payne_ctx_set_lsf(self._ctx, None, 0)
+        else:
+            a = np.ascontiguousarray(lsf, dtype=np.float64)
+            rc = self.lib.payne_ctx_set_lsf(self._ctx, a.ctypes.data_as(C.POINTER(C.c_double)), len(a))
+        if rc != 0:
+            self._err(rc, "payne_ctx_set_lsf")
+
     def set_continuum(self, net):
         """Bind a continuum network (normalised like the spectral net by nnio) or, with None, remove it
         (payne_ctx_set_continuum)."""

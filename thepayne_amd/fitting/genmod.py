@@ -60,9 +60,11 @@ class GenMod(object):
         """(wave, flux) for pars = [Teff, logg, FeH, aFe, Vrad, Vrot, Vmic, Inst_R, pc...]
         (genmod.py:58-108).  Inst_R is FWHM-based; the 2.355 factor is applied on the GPU."""
         pars = list(pars)
-        if not isinstance(pars[7], float):
-            raise NotImplementedError("LSF-vector Inst_R is not built yet")
         eng = self.engine
+        lsf = None
+        if not isinstance(pars[7], float):                 # LSF vector: handed to getspec as is (genmod.py:82-85)
+            lsf = np.atleast_1d(np.asarray(pars[7], dtype=np.float64))
+            pars[7] = np.nan
         polycoef = pars[8:] if modpoly else []
         if modpoly and len(polycoef) != eng.npoly:
             raise ValueError("engine configured for %d blaze coefficients, got %d" % (eng.npoly, len(polycoef)))
@@ -75,7 +77,13 @@ class GenMod(object):
             if self._obs is None or outwave is not self._obs[0]:
                 if eng.nobs != len(outwave) or not np.array_equal(eng.obs_wave, outwave):
                     raise ValueError("genspec(outwave=...) must be the grid bound with configure(obs=...)")
-            flux = eng.predict_batch(th, stage=3 if modpoly else 2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+            if lsf is not None:
+                eng.set_lsf(lsf)
+            try:
+                flux = eng.predict_batch(th, stage=3 if modpoly else 2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+            finally:
+                if lsf is not None:
+                    eng.set_lsf(None)
             return outwave, flux
         raise NotImplementedError("genspec without outwave: use PayneSpecPredict.getspec")
 

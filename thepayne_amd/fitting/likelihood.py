@@ -56,7 +56,11 @@ class likelihood(object):
             if name in col_of:
                 idx.append((col_of[name], j))
         for name, val in self.fixedpars.items():
-            if name in col_of:
+            if name == 'Inst_R' and np.ndim(val) > 0:
+                # a fixed LSF vector (dispersion per observed pixel): genspec hands it to getspec as is
+                # (genmod.py:82-85 -> ystpred.py:248-269); it lives in the engine, not in theta
+                eng.set_lsf(np.asarray(val, dtype=np.float64))
+            elif name in col_of:
                 fixed.append((col_of[name], float(val)))
         self._colmap = (eng.ncols, idx, fixed)
         return self._colmap

@@ -134,10 +134,28 @@ class PayneSpecPredict(object):
         rad_vel = kwargs.get('rad_vel', 0.0)
         has_R = 'inst_R' in kwargs
         inst_R = kwargs.get('inst_R', np.nan)
-        if has_R and not isinstance(inst_R, float):
-            raise NotImplementedError("LSF-vector inst_R (ystpred.py:248-269) is not built yet; pass a float "
-                                      "(np.float64 counts, np.float32/int do not -- as in the reference)")
         eng = self.anns.engine
+        if has_R and not isinstance(inst_R, float):
+            # LSF case: inst_R is the dispersion (AA) at each output pixel (ystpred.py:248-269); anything that
+            # is not a Python float lands here in the reference too (np.float64 is one, np.float32 / int are not)
+            lsf = np.atleast_1d(np.asarray(inst_R, dtype=np.float64))
+            modwave = self.anns.wavelength
+            if rad_vel != 0.0:
+                modwave = modwave * (1.0 + (rad_vel / speedoflight))
+            grid = np.ascontiguousarray(outwave, dtype=np.float64) if outwave is not None else np.ascontiguousarray(modwave)
+            if outwave is None:
+                assert len(lsf) == len(modwave), 'Length of LSF vector not equal to input wavelength'
+            elif len(lsf) != len(grid):
+                raise ValueError("fp and xp are not of the same length.")      # np.interp(modwave, outwave, inst_R)
+            self._bind(grid)
+            th = np.full((1, eng.ncols), np.nan)
+            th[0, :8] = [teff, logg, feh, afe, rad_vel, rot_vel, vmic, np.nan]
+            eng.set_lsf(lsf)
+            try:
+                flux = eng.predict_batch(th, stage=2).cpu().numpy()[0].astype(np.float64)
+            finally:
+                eng.set_lsf(None)
+            return grid, flux
         th = np.full((1, eng.ncols), np.nan)
         th[0, :8] = [teff, logg, feh, afe, rad_vel, rot_vel, vmic, inst_R if has_R else np.nan]
         modwave = self.anns.wavelength
