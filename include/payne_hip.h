@@ -166,6 +166,13 @@ int payne_lnlike_batch(payne_ctx* ctx, const double* theta, int B, double* lnl, 
 int payne_predict_batch(payne_ctx* ctx, const double* theta, int B, int stage, unsigned flags,
                         float* out, int ld_out, void* stream);
 
+/* The broadening stages on caller-supplied spectra: PayneSpecPredict.smoothspec (Payne/predict/ystpred.py:279-281 ->
+ * Payne/utils/smoothing.py:19-169, the 'vsini' / 'vel' / 'R' / 'lsf' FFT branches).  spectra: device fp32
+ * [B][ld_spec], full flux on the context's model wavelength grid; theta, stage (1..3), flags and out as for
+ * payne_predict_batch -- the ANN forward pass is simply replaced by `spectra`. */
+int payne_smooth_batch(payne_ctx* ctx, const float* spectra, int ld_spec, const double* theta, int B, int stage,
+                       unsigned flags, float* out, int ld_out, void* stream);
+
 /* Magnitudes for B parameter vectors: FastPayneSEDPredict.sed
  * (Payne/predict/predictsed.py:75-103).  pars: device fp64 [B][9] =
  * logt, logg, feh, afe, av, rv, logl, dist, logA  (NaN = kwarg absent; the

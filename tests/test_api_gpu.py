@@ -272,3 +272,31 @@ def test_fixed_lsf_vector_in_the_likelihood(tmp_path):
     assert np.all(np.isfinite(got)) and np.all(np.abs(got - ref) <= lnl_tol(ref))
     w, f = L.GM.genspec([float(x) for x in th[0]] + [np.nan, lsf], outwave=obs)
     assert np.abs(f - O.genspec(raw, [float(x) for x in th[0]] + [np.nan, lsf, np.nan], outwave=obs)[1]).max() < 2e-6
+
+
+def test_smoothspec_on_arbitrary_spectra(tmp_path):
+    """PayneSpecPredict.smoothspec(wave, spec, sigma, ...) (ystpred.py:279-281 -> smoothing.smoothspec) on a
+    caller-supplied, linearly sampled spectrum: the 'vsini', 'R' (with and without inres), 'vel' and 'lsf' branches."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    raw = synth.make_yst_net(npix=256, H=16, seed=2)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    rng = np.random.default_rng(12)
+    wave = np.linspace(6500.0, 6620.0, 3000)                       # linear grid: the non-geometric code path
+    spec = np.ones_like(wave)
+    for c, d, s in zip(rng.uniform(6505, 6615, 60), rng.uniform(0.05, 0.6, 60), rng.uniform(0.06, 0.15, 60)):
+        spec -= d * np.exp(-0.5 * ((wave - c) / s) ** 2)
+    out = wave[200:-200:2].copy()
+    got = PP.smoothspec(wave, spec, 12.0, outwave=None, smoothtype='vsini', fftsmooth=True, inres=0.0)
+    ref = O.smooth_vsini(wave, spec, 12.0)                                                 # (NaN where the log grid ends short)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) < 1e-6
+    got = PP.smoothspec(wave, spec, 20000.0, outwave=out, smoothtype='R', fftsmooth=True, inres=60000.0)
+    assert np.abs(got - O.smooth_R(wave, spec, 20000.0, out, 60000.0)).max() < 1e-6
+    got = PP.smoothspec(wave, spec, 25000.0, outwave=out, smoothtype='R')                  # no inres: nothing subtracted
+    assert np.abs(got - O.smooth_R(wave, spec, 25000.0, out, np.inf)).max() < 1e-6
+    got = PP.smoothspec(wave, spec, 14.0, outwave=out)                                     # default 'vel': sigma in km/s
+    assert np.abs(got - O.smooth_R(wave, spec, 2.998e5 / 14.0, out, np.inf)).max() < 1e-6
+    lsf = 0.25 * (1.0 + 0.4 * (wave - wave.mean()) / 120.0)
+    got = PP.smoothspec(wave, spec, lsf, outwave=wave, smoothtype='lsf')
+    assert np.abs(got - O.smooth_lsf(wave, spec, lsf, wave)).max() < 2e-6
+    with pytest.raises(NotImplementedError):
+        PP.smoothspec(wave, spec, 0.5, outwave=out, smoothtype='lambda')

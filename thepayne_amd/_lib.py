@@ -15,7 +15,7 @@ F_FWHM_R = 1
 ABI_VERSION = 1
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_destroy", "payne_last_error",
-           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
+           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
            "payne_rwalk_batch", "payne_ns_consume"]
@@ -114,6 +114,9 @@ def load(path=None):
     lib.payne_ctx_set_continuum.restype = C.c_int
     lib.payne_ctx_set_lsf.argtypes = [ctxp, C.POINTER(C.c_double), C.c_int]
     lib.payne_ctx_set_lsf.restype = C.c_int
+    lib.payne_smooth_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int,
+                                       C.c_void_p]
+    lib.payne_smooth_batch.restype = C.c_int
     lib.payne_ctx_destroy.argtypes = [ctxp]
     lib.payne_ctx_destroy.restype = None
     lib.payne_last_error.argtypes = [ctxp]

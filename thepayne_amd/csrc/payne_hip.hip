@@ -2236,6 +2236,32 @@ extern "C" int payne_predict_batch(payne_ctx* c, const double* theta, int B, int
   return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage, out, ld_out, nullptr, false, s);
 }
 
+// smoothspec on caller-supplied spectra (PayneSpecPredict.smoothspec, ystpred.py:279-281 -> utils.smoothing.smoothspec):
+// the same stages as payne_predict_batch with the ANN forward pass replaced by `spectra` (full flux on the context's
+// model grid).  stage 1: rotational broadening on the model grid; stage 2/3: ... and instrumental broadening onto
+// the bound observed grid.
+__global__ void payne_shift_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int npix, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)B * npix) { const size_t b = i / npix, p = i - b * npix; out[i] = in[b * ld_in + p] - kBase; }
+}
+extern "C" int payne_smooth_batch(payne_ctx* c, const float* spectra, int ld_spec, const double* theta, int B, int stage,
+                                  unsigned flags, float* out, int ld_out, void* stream) {
+  int rc = check_call(c, theta, B, out);
+  if (rc) return rc;
+  if (!spectra) return fail(c, PAYNE_E_INVALID, "spectra is NULL");
+  if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
+  if (stage < 1 || stage > 3) return fail(c, PAYNE_E_INVALID, "stage must be 1..3");
+  if (ld_spec < c->T.npix) return fail(c, PAYNE_E_INVALID, "ld_spec too small");
+  if (stage >= 2 && !c->obs_bound) return fail(c, PAYNE_E_INVALID, "no observed grid bound");
+  if (ld_out < (stage >= 2 ? c->T.nobs : c->T.npix)) return fail(c, PAYNE_E_INVALID, "ld_out too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = (size_t)B * c->T.npix;
+  hipLaunchKernelGGL(payne_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spectra, ld_spec, c->raw, c->T.npix, B);
+  c->prep_valid = false;                                   // no dense launch wrote records for these rows
+  // stage 1 here is smoothspec('vsini') itself: getspec's edge rule (ystpred.py:223-224) is not part of it
+  return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage == 1 ? 6 : stage, out, ld_out, nullptr, false, s);
+}
+
 extern "C" int payne_sed_batch(payne_ctx* c, const double* pars, int B, double* mags, void* stream) {
   int rc = check_call(c, pars, B, mags);
   if (rc) return rc;

@@ -90,7 +90,7 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
   return (float*)fft_run(ex, z, zo, M, tw, T.nmax, true);
 }
 
-// out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze) | 5 after vsini, shifted
+// out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze) | 5 after vsini, shifted | 6 after vsini, without the spec[0]=spec[1] edge rule
 template <int LOG2N, int NT, class Ex>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
@@ -121,11 +121,11 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
     // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
     // transform's last pass can apply the edge rule itself
-    bool edge = T.rot_identity != 0;
+    bool edge = T.rot_identity != 0 && out_stage != 6;   // 6 = smoothspec('vsini') itself: no edge rule
     float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge);
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
-    else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = true; }
+    else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = out_stage != 6; }
     spec = dst;
     work = conv;
     edges_pending = edge;
@@ -134,8 +134,8 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       edges_pending = false;
     }
   }
-  if (out_stage == 1 || out_stage == 5) {               // 5: the same, still shifted by -1 (input of the LSF kernel)
-    const float base = out_stage == 1 ? kBase : 0.f;
+  if (out_stage == 1 || out_stage == 5 || out_stage == 6) {   // 5: still shifted by -1 (input of the LSF kernel); 6: no edge rule
+    const float base = out_stage == 5 ? 0.f : kBase;
     ex.par([&](int t, int n) { for (int i = t; i < T.npix; i += n) out[i] = spec[i] + base; });
     return;
   }

@@ -179,6 +179,22 @@ class PayneEngine(object):
         if rc != 0:
             self._err(rc, "payne_ctx_set_obs")
 
+    def smooth_batch(self, spectra, theta, stage=2, fwhm_R=False):
+        """The broadening stages on caller-supplied spectra [B, npix] (full flux on the model grid):
+        payne_smooth_batch.  Returns a fp32 device tensor [B, npix | nobs]."""
+        t = self._theta(theta, self.ncols)
+        B = t.shape[0]
+        sp = self.torch.as_tensor(np.ascontiguousarray(spectra, dtype=np.float32)).to(self.device).reshape(B, self.npix)
+        n_out = self.npix if stage < 2 else self.nobs
+        out = self.torch.empty((B, n_out), dtype=self.torch.float32, device=self.device)
+        for s in range(0, B, self.b_max):
+            n = min(self.b_max, B - s)
+            rc = self.lib.payne_smooth_batch(self._ctx, sp[s:s + n].data_ptr(), self.npix, t[s:s + n].data_ptr(), n, int(stage),
+                                             _lib.F_FWHM_R if fwhm_R else 0, out[s:s + n].data_ptr(), n_out, self._stream())
+            if rc != 0:
+                self._err(rc, "payne_smooth_batch")
+        return out
+
     def set_lsf(self, lsf):
         """Bind an LSF vector (dispersion per pixel of the bound observed grid) or, with None, remove it
         (payne_ctx_set_lsf).  While set, theta's Inst_R column is ignored."""

@@ -172,8 +172,64 @@ class PayneSpecPredict(object):
         return outwave, eng.predict_batch(th, stage=2).cpu().numpy()[0].astype(np.float64)
 
     def smoothspec(self, wave, spec, sigma, outwave=None, **kwargs):
-        raise NotImplementedError("free-standing smoothspec on arbitrary spectra is not part of the batched path; "
-                                  "use getspec(rot_vel=..., inst_R=...)")
+        """``smoothspec(wave, spec, resolution=sigma, outwave=outwave, **kwargs)`` (ystpred.py:279-281 ->
+        Payne/utils/smoothing.py:19-169) on the GPU, for the FFT branches this build has kernels for:
+        smoothtype 'vsini' (outwave=None), 'vel' and 'R' (optional ``inres``), 'lsf' (dispersion vector on
+        ``wave``; outwave None or ``wave`` itself).  Anything else raises NotImplementedError."""
+        smoothtype = kwargs.get('smoothtype', 'vel')
+        if not kwargs.get('fftsmooth', True):
+            raise NotImplementedError("fftsmooth=False (direct-sum smoothing) is not built")
+        if kwargs.get('min_wave_smooth', 0) != 0 or kwargs.get('max_wave_smooth', np.inf) != np.inf:
+            raise NotImplementedError("min_wave_smooth / max_wave_smooth are not built")
+        wave = np.ascontiguousarray(wave, dtype=np.float64)
+        spec = np.asarray(spec, dtype=np.float64)
+        ckms = 2.998e5                                                       # smoothing.py:16
+        inres = kwargs.get('inres', None)
+        r_in = np.inf
+        if smoothtype == 'vsini':
+            if outwave is not None or (inres not in (None, 0, 0.0)):
+                raise NotImplementedError("smoothtype='vsini' is built for outwave=None, inres=0 (as getspec calls it)")
+            th_R, th_rot, stage = np.nan, float(sigma), 1
+        elif smoothtype in ('vel', 'R'):
+            if smoothtype == 'vel':                                          # sigma in km/s -> R_sigma; inres in km/s
+                th_R = ckms / float(sigma)
+                r_in = (ckms / inres) if inres else np.inf
+            else:                                                            # smoothing.py:103-115
+                th_R = float(sigma)
+                r_in = float(inres) if inres is not None else np.inf
+            th_rot, stage = 0.0, 2
+        elif smoothtype == 'lsf':
+            if outwave is not None and not np.array_equal(np.asarray(outwave, dtype=np.float64), wave):
+                raise NotImplementedError("smoothtype='lsf' is built for outwave=None or outwave=wave")
+            th_R, th_rot, stage = np.nan, 0.0, 2
+        else:
+            raise NotImplementedError("smoothtype=%r is not built (have 'vsini', 'vel', 'R', 'lsf')" % (smoothtype,))
+        eng = self._smooth_engine(wave, r_in)
+        if stage == 2:
+            grid = wave if outwave is None else np.ascontiguousarray(outwave, dtype=np.float64)
+            eng.set_obs(grid)
+        th = np.full((1, eng.ncols), np.nan)
+        th[0, :8] = [5000.0, 4.0, 0.0, 0.0, 0.0, th_rot, np.nan, th_R]
+        if smoothtype == 'lsf':
+            eng.set_lsf(np.atleast_1d(np.asarray(sigma, dtype=np.float64)))
+        out = eng.smooth_batch(spec[None, :], th, stage=stage).cpu().numpy()[0].astype(np.float64)
+        if stage == 1:
+            return out
+        return out
+
+    def _smooth_engine(self, wave, r_in):
+        """A context whose model grid is ``wave`` (a two-layer dummy network: only the broadening stages run)."""
+        key = (len(wave), float(wave[0]), float(wave[-1]), hash(wave.tobytes()), float(r_in))
+        cache = self.__dict__.setdefault('_smooth_cache', {})
+        if key not in cache:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache))).close()
+            n = len(wave)
+            net = {"layers": [(np.zeros((4, 1), np.float32), np.zeros(4, np.float32), 0),
+                              (np.zeros((n, 4), np.float32), np.ones(n, np.float32), 0)],
+                   "xmin": np.array([0.0]), "xmax": np.array([1.0]), "wavelength": wave, "resolution": float(r_in)}
+            cache[key] = PayneEngine(net, b_max=8, device=self.anns.engine.device.index)
+        return cache[key]
 
     # -- new: batch API ------------------------------------------------------------
     def getspec_batch(self, theta8, outwave, stage=2):
