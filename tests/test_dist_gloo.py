@@ -64,3 +64,45 @@ def test_shard_is_a_partition():
         for w in (1, 2, 8):
             got = sorted(i for r in range(w) for i in shard(n, r, w))
             assert got == list(range(n))
+
+
+WORKER2 = textwrap.dedent('''
+    import sys, numpy as np
+    sys.path.insert(0, %r)
+    from thepayne_amd import dist as pdist
+    rank, world, _ = pdist.init_from_env("gloo")
+    rng = np.random.default_rng(7)                      # same candidates on every rank
+    out = {}
+    for B in (1, 2, 5, 64, 67):
+        theta = rng.normal(size=(B, 3))
+        calls = []
+        def fn(block):
+            calls.append(len(block))
+            return (block ** 2).sum(axis=1) + 0.5
+        out["B%%d" %% B] = pdist.sharded_lnlike(fn, theta, rank, world)
+        out["ref%%d" %% B] = (theta ** 2).sum(axis=1) + 0.5
+        out["n%%d" %% B] = np.array(calls)
+    np.savez(sys.argv[1] + "/sharded_%%d.npz" %% rank, **out)
+    pdist.finalize()
+''') % ROOT
+
+
+def test_two_ranks_split_one_batch_and_gather_lnl(tmp_path):
+    """Within-star sharding (SURVEY 8(e)-2): contiguous blocks of the batch per rank, one all_gather."""
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-3000:]
+    r0, r1 = np.load(tmp_path / "sharded_0.npz"), np.load(tmp_path / "sharded_1.npz")
+    for B in (1, 2, 5, 64, 67):
+        assert np.array_equal(r0["B%d" % B], r0["ref%d" % B]) and np.array_equal(r1["B%d" % B], r0["ref%d" % B])
+        per = (B + 1) // 2
+        assert r0["n%d" % B].sum() == per and r1["n%d" % B].sum() == B - per      # each rank evaluated only its block

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-__all__ = ["init_from_env", "shard", "gather_summaries", "fit_stars", "finalize"]
+__all__ = ["init_from_env", "shard", "gather_summaries", "fit_stars", "sharded_lnlike", "finalize"]
 
 
 def init_from_env(backend=None):
@@ -74,6 +74,34 @@ def fit_stars(stars, fit_fn, summary_length, backend=None):
     rank, world, _ = init_from_env(backend)
     local = {i: np.asarray(fit_fn(stars[i], i), dtype=np.float64) for i in shard(len(stars), rank, world)}
     return gather_summaries(local, len(stars), rank, world, summary_length)
+
+
+def sharded_lnlike(lnlike_fn, theta, rank, world):
+    """One star, one batch, G GPUs (pays only when a batch takes much longer than the ~20 us
+    of the exchange, i.e. for 65k-pixel spectra): rank r evaluates the contiguous block r of the B candidate
+    vectors with ``lnlike_fn(block) -> lnL[block]`` (numpy or a torch tensor on the rank's device) and one
+    ``all_gather`` of <= ceil(B/G) doubles per rank rebuilds lnL[B] on every rank.  The candidates themselves
+    are replicated (same proposals on every rank: shared RNG seed), so nothing else travels."""
+    import torch
+    import torch.distributed as dist
+    theta = np.asarray(theta) if not hasattr(theta, "shape") else theta
+    B = theta.shape[0]
+    if world == 1:
+        out = lnlike_fn(theta)
+        return out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out, dtype=np.float64)
+    per = (B + world - 1) // world
+    lo, hi = min(B, rank * per), min(B, (rank + 1) * per)
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    mine = torch.full((per,), float("nan"), dtype=torch.float64, device=dev)
+    if hi > lo:
+        part = lnlike_fn(theta[lo:hi])
+        part = part if isinstance(part, torch.Tensor) else torch.as_tensor(np.asarray(part, dtype=np.float64))
+        mine[:hi - lo] = part.to(device=dev, dtype=torch.float64)
+    full = torch.empty(per * world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(full, mine)
+    full = full.cpu().numpy().reshape(world, per)
+    return np.concatenate([full[r, :max(0, min(B, (r + 1) * per) - min(B, r * per))] for r in range(world)])
 
 
 def finalize():
