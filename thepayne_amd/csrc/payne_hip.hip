@@ -48,6 +48,9 @@ struct DenseParams {
   const float* W0; const float* b0; int n_labels; int act0;
   int K0;                      // real width of the first layer (W0 has K0 rows)
   double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
+  // optional second output of the hidden-layer kernel: the activations as three bf16 planes (x = x1 + x2 + x3
+  // exactly), operand of payne_dense_bx3dma_kernel
+  unsigned short* Yp; int ldyp; size_t yp_plane;   // [3][yp_plane] elements, row pitch ldyp
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
@@ -249,40 +252,52 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 //     of 32 in memory (X: the hidden buffers' pitch; W: ctx->w_out_pad) and rows are clamped.
 // ----------------------------------------------------------------------------
 constexpr int DM_NS = 3;                                   // ring stages
-constexpr int DM_STAGE = (64 + 64) * 32;                   // floats per stage (A tile, then B tile)
-constexpr size_t DM_LDS_BYTES = (size_t)DM_NS * DM_STAGE * sizeof(float);
+// WN = wave columns: tile = 64 x (32 WN), 2 WN waves.  WN = 2 is the 64 x 64 / 256-thread form (two workgroups
+// per CU); WN = 4 the 64 x 128 / 512-thread form (one per CU, same waves per SIMD): the activation tile is then
+// fetched once per 128 columns, 24 KB instead of 2 x 16 KB per k-step and CU -- the kernel is bound by the CU's
+// miss throughput, not by the matrix pipes.
+template <int WN> constexpr int dm_stage_floats() { return (64 + 32 * WN) * 32; }
+template <int WN> constexpr size_t dm_lds_bytes() { return (size_t)DM_NS * dm_stage_floats<WN>() * sizeof(float); }
 
-__global__ void __launch_bounds__(256) payne_dense_dma_kernel(DenseParams p) {
+template <int WN>
+__global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p) {
+  constexpr int BN = 32 * WN, NW = 2 * WN;                 // tile columns, waves
+  constexpr int STAGE = dm_stage_floats<WN>();
+  constexpr int NBLK = (64 + BN) / 8;                      // 1-KiB pieces per stage: 8 rows each
+  constexpr int PER = NBLK / NW;                           // pieces per wave: 4 (WN = 2) or 3 (WN = 4)
+  static_assert(NBLK % NW == 0, "pieces divide over the waves");
   extern __shared__ __attribute__((aligned(16))) float dm_sm[];
   const int ntiles = p.grid_m * p.grid_n;
   int t = blockIdx.x;
   if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
-  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 64;
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;
 
-  // the four 1-KiB pieces this wave moves per stage: rows 8*blk .. 8*blk+7 of A (j = 0,1) and B (j = 2,3)
-  const float* src[4];
-  int dst[4];                                              // float offset inside a stage (wave-uniform)
+  // the 1-KiB pieces this wave moves per stage: piece q covers rows 8q .. 8q+7 of A (q < 8) or of B (q >= 8)
+  const float* src[PER];
+  int dst[PER];                                            // float offset inside a stage (wave-uniform)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int blk = wave * 2 + (j & 1), row = 8 * blk + (lane >> 3);
+  for (int j = 0; j < PER; ++j) {
+    const int q = wave * PER + j;
+    const bool isA = q < 8;
+    const int blk = isA ? q : q - 8, row = 8 * blk + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);           // which chunk of the row belongs in this lane's slot
-    if (j < 2) {
+    if (isA) {
       const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
       src[j] = p.X + (size_t)r * p.ldx + 4 * c;
     } else {
       const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
       src[j] = p.W + (size_t)r * p.K + 4 * c;              // p.K: padded pitch of the weight copy
     }
-    dst[j] = (j < 2 ? 0 : 64 * 32) + blk * 256;
+    dst[j] = (isA ? 0 : 64 * 32) + blk * 256;
   }
   auto issue = [&](int stage, int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PER; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                       (__attribute__((address_space(3))) void*)(dm_sm + stage * DM_STAGE + dst[j]), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dm_sm + stage * STAGE + dst[j]), 16, 0, 0);
   };
 
   f32x16 acc;
@@ -297,23 +312,28 @@ __global__ void __launch_bounds__(256) payne_dense_dma_kernel(DenseParams p) {
   issue(0, 0);
   if (nk > 1) issue(1, 32);
   for (int it = 0; it < nk; ++it) {
-    // my pieces of stage `it` have landed once at most the 4 younger loads (stage it+1) are outstanding
-    if (it + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // my pieces of stage `it` have landed once at most the PER younger loads (stage it+1) are outstanding
+    if (it + 1 < nk) { if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");                // everybody's pieces landed; everybody finished step it-1
     if (it < 13) HK_STAMP(1 + it);
     if (it + 2 < nk) issue((it + 2) % DM_NS, (it + 2) * 32);    // into the buffer step it-1 just released
-    const float* Asb = dm_sm + (it % DM_NS) * DM_STAGE;
+    const float* Asb = dm_sm + (it % DM_NS) * STAGE;
     const float* Bsb = Asb + 64 * 32;
+    f32x4_t a[4], b[4];                                     // all eight fragments first (one LDS round trip per step)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = 2 * kk + half;
-      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(Asb + Ra * 32 + 4 * (c ^ sa));
-      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * 32 + 4 * (c ^ sb));
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      a[kk] = *reinterpret_cast<const f32x4_t*>(Asb + Ra * 32 + 4 * (c ^ sa));
+      b[kk] = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * 32 + 4 * (c ^ sb));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].w, b[kk].w, acc, 0, 0, 0);
     }
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -637,7 +657,18 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     const int rr = idx >> 5, cc = idx & 31, row = m0 + rr, col = n0 + cc;
     if (row < p.B && col < p.N) {
       const float v = Red[rr * 33 + cc] + Red[(32 + rr) * 33 + cc] + Red[(64 + rr) * 33 + cc] + Red[(96 + rr) * 33 + cc];
-      p.Y[(size_t)row * p.ldy + col] = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
+      const float y = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
+      p.Y[(size_t)row * p.ldy + col] = y;
+      if (p.Yp) {                                           // the same value as three bf16 planes
+        const __bf16 b1 = (__bf16)y;
+        const float r1 = y - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const __bf16 b3 = (__bf16)(r1 - (float)b2);
+        const size_t o = (size_t)row * p.ldyp + col;
+        p.Yp[o] = __builtin_bit_cast(unsigned short, b1);
+        p.Yp[p.yp_plane + o] = __builtin_bit_cast(unsigned short, b2);
+        p.Yp[2 * p.yp_plane + o] = __builtin_bit_cast(unsigned short, b3);
+      }
     }
   }
   HK_STAMP(5);
@@ -933,6 +964,115 @@ __global__ void __launch_bounds__(256, 1) payne_dense_bf16x3_kernel(Bx3Params q)
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
       if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[j][e] + bv, p.act);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Output layer, 3 x bf16 split on the LDS-DMA ring: the arithmetic of payne_dense_bf16x3_kernel (six bf16
+// partial products per term, fp32-accurate) with the operand delivery of payne_dense_dma_kernel.  BOTH
+// operands arrive pre-split -- the weights at context creation, the activations from the hidden-layer kernel's
+// epilogue (DenseParams::Yp) -- so the kernel issues nothing but DMA requests, fragment reads and MFMAs:
+// per 32-deep k-step and wave 12 x v_mfma_f32_32x32x16_bf16 = 384 matrix cycles against 1024 for fp32.
+// (The register-staged bf16x3 kernel was only ~10 % faster than fp32 because its barriers drained the loads;
+// with the ring the steady state is matrix-bound again, at 3/8 of the fp32 time.)
+// Stage = 3 planes x (64 A rows + 64 B rows) x 64 B = 24 KB; a 1-KiB DMA piece = 16 rows of one plane;
+// 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3) (conflict-free 16-lane fragment reads).
+// ----------------------------------------------------------------------------
+constexpr int BD_STAGE = 3 * (64 + 64) * 64;               // bytes per stage
+constexpr size_t BD_LDS_BYTES = (size_t)DM_NS * BD_STAGE;
+struct Bd3Params {
+  DenseParams d;
+  const unsigned short* Ap; int lda; size_t a_plane;       // activation planes [3][a_plane], row pitch lda (elements)
+  const unsigned short* Wp; int Kp; int Npad;              // weight planes [3][Npad][Kp]
+  int dbg;                                                 // timing experiments (PAYNE_BD_DBG): 1 no MFMAs, 2 no DMA after the prologue, 4 no fragment reads, 8 no output stores
+};
+__global__ void __launch_bounds__(256) payne_dense_bx3dma_kernel(Bd3Params q) {
+  const DenseParams& p = q.d;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_sm[];
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  // 24 pieces per stage: piece q = (operand, plane, 16-row block); 6 per wave
+  const unsigned char* src[6];
+  int dst[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int qq = wave * 6 + j, isB = qq / 12, pl = (qq % 12) / 4, blk = qq % 4;
+    const int row = 16 * blk + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);           // which 16-byte chunk of the row belongs in this lane's slot
+    if (!isB) {
+      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(q.Ap + (size_t)pl * q.a_plane + (size_t)r * q.lda) + 16 * c;
+    } else {
+      src[j] = reinterpret_cast<const unsigned char*>(q.Wp + ((size_t)pl * q.Npad + n0 + row) * q.Kp) + 16 * c;
+    }
+    dst[j] = (isB ? 3 * 64 * 64 : 0) + pl * 64 * 64 + blk * 1024;
+  }
+  auto issue = [&](int stage, int k0) {                    // k0 in elements: 2 bytes each
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
+                                       (__attribute__((address_space(3))) void*)(bd_sm + stage * BD_STAGE + dst[j]), 16, 0, 0);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
+  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
+  const int nk = q.Kp / 32;
+  issue(0, 0);
+  if (nk > 1) issue(1, 32);
+  for (int it = 0; it < nk; ++it) {
+    if (q.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (it + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (it + 2 < nk && !(q.dbg & 2)) issue((it + 2) % DM_NS, (it + 2) * 32);
+    const unsigned char* As = bd_sm + (it % DM_NS) * BD_STAGE;
+    const unsigned char* Bs = As + 3 * 64 * 64;
+    // all twelve fragments of the stage first, then the twelve MFMAs back to back: read -> wait -> MFMA per
+    // fragment pair exposes one LDS round trip per pair (the compiler places reads next to their use)
+    bf16x8_t a[2][3], b[2][3];
+    if (q.dbg & 4) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { a[ks][pl] = (bf16x8_t)(__bf16)(float)it; b[ks][pl] = (bf16x8_t)(__bf16)1.0f; }
+    } else
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                       // two 16-deep MFMA steps per 32-deep stage
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[ks][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
+        b[ks][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * 4096 + Rb * 64 + 16 * (c ^ sb));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (q.dbg & 1) { acc[0] += (float)a[0][0][0] + (float)b[1][2][3]; continue; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][2], b[ks][0], acc, 0, 0, 0);   // smallest partial products first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], b[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[ks][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], b[ks][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[ks][0], acc, 0, 0, 0);
+    }
+  }
+  if (q.dbg & 8) { float sacc = 0.f; for (int r = 0; r < 16; ++r) sacc += acc[r]; if (sacc == 12345.678f) p.Y[0] = sacc; return; }
+  const int col = n0 + wn0 + (lane & 31);
+  if (col < p.N) {
+    const float bv = p.bias[col] - p.bias_shift;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[r] + bv, p.act);
     }
   }
 }
@@ -1438,6 +1578,7 @@ struct payne_ctx {
   const float* w_out_pad = nullptr;     // output layer's weights [N][w_out_kp], k zero-padded to a multiple of 32 (LDS-DMA kernel)
   int w_out_kp = 0;
   bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
+  unsigned short* a_planes = nullptr;   // [3][b_max][ld_hid] bf16 planes of the last hidden layer's activations (bx3dma kernel)
   int wp_Kp = 0, wp_Npad = 0;
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
@@ -1706,6 +1847,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
+    if (c->dma_ok && (rc = dev_alloc(c, (size_t)3 * opts->b_max * c->ld_hid, &c->a_planes, c->owned))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
@@ -1903,7 +2045,7 @@ static int skip_mask() {
 
 static int out_tile_choice() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 8; }   // 8: LDS-DMA 64x64x32 (default; needs zero-padded operands, else 0); 0: register-staged streaming; 6: K-resident; 7: bf16x3
+  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 8; }   // 8: fp32 LDS-DMA (default); 9: 3 x bf16 split on the LDS-DMA ring (both need zero-padded operands, else 0); 0: register-staged streaming; 6: K-resident; 7: register-staged bf16x3
   return v;
 }
 
@@ -1923,19 +2065,39 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
   hipLaunchKernelGGL(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
 }
 
-static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
+template <int WN>
+static void launch_out_dma_t(payne_ctx* c, DenseParams& p, hipStream_t s) {
   p.W = c->w_out_pad; p.K = c->w_out_kp;                   // padded pitch; X's pitch (ld_hid) is a multiple of 32 too
   p.grid_m = (p.B + 63) / 64;
-  p.grid_n = (p.N + 63) / 64;
+  p.grid_n = (p.N + 32 * WN - 1) / (32 * WN);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DM_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dm_lds_bytes<WN>());
     attr_set = true;
   }
 #ifdef PAYNE_STAMPS
   p.stamps = g_dense_stamps;
 #endif
-  hipLaunchKernelGGL(payne_dense_dma_kernel, dim3(p.grid_m * p.grid_n), dim3(256), DM_LDS_BYTES, s, p);
+  hipLaunchKernelGGL(payne_dense_dma_kernel<WN>, dim3(p.grid_m * p.grid_n), dim3(128 * WN), dm_lds_bytes<WN>(), s, p);
+}
+static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  static int wide = -1;                                    // PAYNE_DMA_WIDE=0: 64 x 64 tiles; default: 64 x 128
+  if (wide < 0) { const char* e = getenv("PAYNE_DMA_WIDE"); wide = e ? atoi(e) : 1; }
+  if (wide) launch_out_dma_t<4>(c, p, s); else launch_out_dma_t<2>(c, p, s);
+}
+
+static void launch_out_bx3dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  p.grid_m = (p.B + 63) / 64;
+  p.grid_n = (p.N + 63) / 64;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("PAYNE_BD_DBG"); dbg = e ? atoi(e) : 0; }
+  Bd3Params q{p, c->a_planes, c->ld_hid, (size_t)c->opts.b_max * c->ld_hid, c->w_planes, c->wp_Kp, c->wp_Npad, dbg};
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bx3dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(payne_dense_bx3dma_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BD_LDS_BYTES, s, q);
 }
 
 static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
@@ -2012,6 +2174,9 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     p.bias_shift = last ? N.out_shift : 0.f;
     p.Y = last ? N.out : N.hid[(l - 1) & 1];
     p.ldy = last ? N.ld_out : N.ld_hid;
+    if (N.spectral && l == n - 2 && c->a_planes && out_tile_choice() == 9) {   // feeds the output layer: also as bf16 planes
+      p.Yp = c->a_planes; p.ldyp = c->ld_hid; p.yp_plane = (size_t)c->opts.b_max * c->ld_hid;
+    }
     if (N.spectral && (skip_mask() & (last ? 2 : 1))) continue;
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
@@ -2029,7 +2194,8 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       PrepArgs pa{};
       if (!last) launch_small<false>(p, pa, s);
       else if (!N.spectral) launch_dense<64, 64, 32, false>(p, s);
-      else if (out_tile_choice() == 8 && c->dma_ok && c->ld_hid >= c->w_out_kp) launch_out_dma(c, p, s);
+      else if (out_tile_choice() == 9 && c->dma_ok && c->a_planes && c->w_planes && c->ld_hid >= c->wp_Kp) launch_out_bx3dma(c, p, s);
+      else if ((out_tile_choice() == 8 || out_tile_choice() == 9) && c->dma_ok && c->ld_hid >= c->w_out_kp) launch_out_dma(c, p, s);
       else if (out_tile_choice() == 7 && c->w_planes) launch_out_bf16x3(c, p, s);
       else if (out_tile_choice() == 6 && p.K <= OK_KMAX) launch_out_resident(p, s);
       else switch (out_tile_choice()) {
