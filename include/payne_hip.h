@@ -273,6 +273,15 @@ int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_v, double* 
                      double dlogz, long long max_emit, double logl_max, payne_ns_dead* out, int cap,
                      int* consumed, int* stop);
 
+/* payne_rwalk_batch in two parts: `begin` takes the same arguments and enqueues the set-up, `step(s, w)` for
+ * w = 0 .. walks enqueues one step (settle proposal w-1, draw and evaluate proposal w; the last only settles).
+ * A caller driving several samplers (one context and one stream each) interleaves their steps from one host
+ * thread to keep two independent batches in flight. */
+int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
+                      double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
+                      void* stream);
+int payne_rwalk_step(payne_sampler* s, int w);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

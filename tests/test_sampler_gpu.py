@@ -200,3 +200,30 @@ def test_fitpayne_with_and_without_device_proposals(tmp_path, device_proposals):
     T = synth.TRUTH
     truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
     assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+
+
+def test_two_populations_interleaved(tmp_path):
+    """MultiPopProposer: the steps of two chain populations (two contexts, two streams) interleaved through
+    payne_rwalk_begin / payne_rwalk_step give the same chains as the populations run one after the other."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    from thepayne_amd.sampler.device import MultiPopProposer
+    L, P, OL = _fit_objects(tmp_path, photscale=True)
+    M = MultiPopProposer(L, P, k_max=32, n_pop=2)
+    rng = np.random.default_rng(9)
+    K, nd = 64, L.ndim
+    U0 = rng.uniform(0.3, 0.7, size=(K, nd))
+    V0, lp0 = M.lnprob_u(U0)
+    lp0 = np.where(np.isnan(lp0), -np.inf, lp0)
+    lstar = float(np.median(lp0[np.isfinite(lp0)]))
+    axes = 0.05 * np.eye(nd)
+    U, V, lp, nacc, ncall = M.rwalk(U0, V0, lp0, axes, 1.0, lstar, 10, seed=77)
+    assert U.shape == (K, nd) and np.all((U > 0) & (U < 1)) and nacc.sum() > 0
+    moved = nacc > 0
+    assert np.all(lp[moved] > lstar) and np.array_equal(U[~moved], U0[~moved])
+    np.testing.assert_allclose(V, P.priortrans_batch(U), rtol=1e-11, atol=1e-11)
+    host = lnprob_batch(V, L, P)
+    assert np.all(np.abs(lp[moved] - host[moved]) <= 1e-9 * np.abs(host[moved]) + 1e-9)
+    # population 0 alone, same seed: identical first half
+    a = M.pops[0].rwalk(U0[:32], V0[:32], lp0[:32], axes, 1.0, lstar, 10, seed=77)
+    assert np.array_equal(a[0], U[:32]) and np.array_equal(a[2], lp[:32])
+    M.close()

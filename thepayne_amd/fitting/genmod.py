@@ -45,14 +45,18 @@ class GenMod(object):
         self._obs, self._obs_phot, self._npoly, self._photscale = obs, obs_phot, int(npoly), bool(photscale)
         self._engine = None
 
+    def new_engine(self):
+        """Another context with the same networks and data (own workspaces: a second batch can be in flight)."""
+        eng = PayneEngine(self._spec_net, obs=self._obs, phot=self._phot, obs_phot=self._obs_phot,
+                          npoly=self._npoly, photscale=self._photscale, b_max=self.b_max, device=self.device)
+        if getattr(self, "_cont_net", None) is not None:
+            eng.set_continuum(self._cont_net)
+        return eng
+
     @property
     def engine(self):
         if self._engine is None:
-            self._engine = PayneEngine(self._spec_net, obs=self._obs, phot=self._phot, obs_phot=self._obs_phot,
-                                       npoly=self._npoly, photscale=self._photscale, b_max=self.b_max,
-                                       device=self.device)
-            if getattr(self, "_cont_net", None) is not None:
-                self._engine.set_continuum(self._cont_net)
+            self._engine = self.new_engine()
         return self._engine
 
     # -- reference API (one parameter list) --------------------------------------

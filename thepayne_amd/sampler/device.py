@@ -21,10 +21,10 @@ _KIND = {'uniform': _lib.PRIOR_UNIFORM, 'gaussian': _lib.PRIOR_GAUSSIAN, 'tgauss
 
 
 class DeviceProposer(object):
-    def __init__(self, likeobj, priorobj, k_max=None):
+    def __init__(self, likeobj, priorobj, k_max=None, engine=None):
         self.like = likeobj
         self.prior = priorobj
-        self.eng = likeobj.GM.engine
+        self.eng = engine if engine is not None else likeobj.GM.engine
         self.torch = self.eng.torch
         self.lib = self.eng.lib
         self.ndim = priorobj.ndim
@@ -134,33 +134,54 @@ class DeviceProposer(object):
     def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed):
         """K lock-step random-walk chains of `walks` steps under lnprob > loglstar.
         Returns (U, V, lnprob, nacc, ncall) as numpy arrays.  One packed pinned transfer each way."""
+        self.rwalk_begin(U, V, lnprob, axes, scale, loglstar, walks, seed)
+        for w in range(int(walks) + 1):
+            self.rwalk_step(w)
+        return self.rwalk_finish()
+
+    # the same in three parts (MultiPopProposer interleaves the steps of several populations)
+    def rwalk_begin(self, U, V, lnprob, axes, scale, loglstar, walks, seed, stream=None):
         K, nd = len(U), self.ndim
         if K > self.k_max:
             raise ValueError("K > k_max")
+        t = self.torch
         if self._pack_h is None:
-            t = self.torch
             n = self.k_max * (2 * nd + 1)
             self._pack_h = t.empty(n, dtype=t.float64).pin_memory()
             self._pack_d = t.empty(n, dtype=t.float64, device=self.eng.device)
             self._ipack_h = t.empty(2 * self.k_max, dtype=t.int32).pin_memory()
             self._ipack_d = t.empty(2 * self.k_max, dtype=t.int32, device=self.eng.device)
+        self._run_stream = stream if stream is not None else t.cuda.current_stream(self.eng.device)
         n = K * (2 * nd + 1)
         h = self._pack_h.numpy()
         h[:K * nd] = np.asarray(U, dtype=np.float64).reshape(-1)
         h[K * nd:2 * K * nd] = np.asarray(V, dtype=np.float64).reshape(-1)
         h[2 * K * nd:n] = lnprob
         d = self._pack_d
-        d[:n].copy_(self._pack_h[:n], non_blocking=True)
+        with t.cuda.stream(self._run_stream):
+            d[:n].copy_(self._pack_h[:n], non_blocking=True)
         pu, pv, pl = d.data_ptr(), d.data_ptr() + 8 * K * nd, d.data_ptr() + 16 * K * nd
         ax = np.ascontiguousarray(axes, dtype=np.float64)
-        rc = self.lib.payne_rwalk_batch(self._handle, pu, pv, pl, K, C.cast(ax.ctypes.data, C.POINTER(C.c_double)),
+        rc = self.lib.payne_rwalk_begin(self._handle, pu, pv, pl, K, C.cast(ax.ctypes.data, C.POINTER(C.c_double)),
                                         float(scale), float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                        self._ipack_d.data_ptr(), self._ipack_d.data_ptr() + 4 * K, self._stream())
+                                        self._ipack_d.data_ptr(), self._ipack_d.data_ptr() + 4 * K,
+                                        C.c_void_p(self._run_stream.cuda_stream))
         if rc != 0:
-            self.eng._err(rc, "payne_rwalk_batch")
-        self._pack_h[:n].copy_(d[:n], non_blocking=True)
-        self._ipack_h[:2 * K].copy_(self._ipack_d[:2 * K], non_blocking=True)
-        self.torch.cuda.current_stream(self.eng.device).synchronize()
+            self.eng._err(rc, "payne_rwalk_begin")
+        self._run_K = K
+
+    def rwalk_step(self, w):
+        rc = self.lib.payne_rwalk_step(self._handle, int(w))
+        if rc != 0:
+            self.eng._err(rc, "payne_rwalk_step")
+
+    def rwalk_finish(self):
+        K, nd, t = self._run_K, self.ndim, self.torch
+        n = K * (2 * nd + 1)
+        with t.cuda.stream(self._run_stream):
+            self._pack_h[:n].copy_(self._pack_d[:n], non_blocking=True)
+            self._ipack_h[:2 * K].copy_(self._ipack_d[:2 * K], non_blocking=True)
+        self._run_stream.synchronize()
         h = self._pack_h.numpy()
         ih = self._ipack_h.numpy()
         return (h[:K * nd].reshape(K, nd).copy(), h[K * nd:2 * K * nd].reshape(K, nd).copy(), h[2 * K * nd:n].copy(),
@@ -177,3 +198,52 @@ class DeviceProposer(object):
             self.close()
         except Exception:
             pass
+
+
+class MultiPopProposer(object):
+    """Several chain populations in flight: ``n_pop`` DeviceProposers, each on its own context and HIP stream,
+    their walk steps interleaved from this one host thread (payne_rwalk_begin / payne_rwalk_step).  One
+    likelihood batch is three dependent launches with a fixed cost each; a second, independent batch fills the
+    idle time (13.6 M against 10.6 M evaluations/s at the 4096-pixel / 512-candidate size).  ``rwalk`` takes up to
+    ``n_pop * k_max`` chains and splits them into contiguous blocks; everything else goes to population 0."""
+
+    def __init__(self, likeobj, priorobj, k_max=None, n_pop=2):
+        if likeobj.fixedpars and any(np.ndim(v) > 0 for v in likeobj.fixedpars.values()):
+            raise NotImplementedError("an LSF vector lives in one context; use a single population")
+        first = DeviceProposer(likeobj, priorobj, k_max=k_max)
+        self.pops = [first] + [DeviceProposer(likeobj, priorobj, k_max=k_max, engine=likeobj.GM.new_engine())
+                               for _ in range(1, int(n_pop))]
+        self.k_max = first.k_max * len(self.pops)
+        self.ndim = first.ndim
+        t = first.torch
+        self._streams = [t.cuda.Stream(device=p.eng.device) for p in self.pops]
+
+    def prior_transform(self, U):
+        return self.pops[0].prior_transform(U)
+
+    def lnprob_u(self, U):
+        return self.pops[0].lnprob_u(U)
+
+    def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed):
+        K, n = len(U), len(self.pops)
+        if K > self.k_max:
+            raise ValueError("K > n_pop * k_max")
+        per = (K + n - 1) // n
+        live = []
+        for i, p in enumerate(self.pops):
+            lo, hi = i * per, min(K, (i + 1) * per)
+            if hi > lo:
+                p.rwalk_begin(U[lo:hi], V[lo:hi], lnprob[lo:hi], axes, scale, loglstar, walks,
+                              (int(seed) + 0x9E3779B9 * i) & 0xFFFFFFFFFFFFFFFF, stream=self._streams[i])
+                live.append(p)
+        for w in range(int(walks) + 1):                 # one step of every population, round robin
+            for p in live:
+                p.rwalk_step(w)
+        parts = [p.rwalk_finish() for p in live]
+        return tuple(np.concatenate([q[j] for q in parts]) for j in range(5))
+
+    def close(self):
+        for p in self.pops[1:]:
+            p.close()
+            p.eng.close()
+        self.pops[0].close()

@@ -27,7 +27,8 @@ ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', '
        'CarbonScale']
 
 
-def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks"), verbose=False):
+def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
+        verbose=False):
     """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
     bookkeeping included).  Returns {mode: {...}}."""
     cfg = synth.CONFIGS[config]
@@ -51,11 +52,16 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
     out = {}
     for mode in modes:
         proposer = None
-        if mode.startswith("device"):
+        queue = nlive
+        if mode.startswith("device2"):                      # two chain populations in flight
+            from thepayne_amd.sampler.device import MultiPopProposer
+            proposer = MultiPopProposer(L, P, k_max=nlive, n_pop=2)
+            queue = 2 * nlive
+        elif mode.startswith("device"):
             from thepayne_amd.sampler.device import DeviceProposer
             proposer = DeviceProposer(L, P, k_max=nlive)
         S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound='multi',
-                          sample='rwalk', walks=walks, batched=True, queue_size=nlive,
+                          sample='rwalk', walks=walks, batched=True, queue_size=queue,
                           rstate=np.random.default_rng(1), proposer=proposer)
         t0 = time.perf_counter()
         c0 = S.ncall
@@ -82,7 +88,7 @@ def main():
     ap.add_argument("--maxcall", type=int, default=400000)
     ap.add_argument("--nlive", type=int, default=512)
     ap.add_argument("--walks", type=int, default=25)
-    ap.add_argument("--modes", default="host,device,device_chunks")
+    ap.add_argument("--modes", default="host,device,device_chunks,device2_chunks")
     a = ap.parse_args()
     out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True)
     print(json.dumps({"sampler_bench": out, "config": a.config, "nlive": a.nlive, "walks": a.walks}))
