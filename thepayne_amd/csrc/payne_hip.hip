@@ -1624,10 +1624,16 @@ struct payne_ctx {
   long long prof_n[4] = {0, 0, 0, 0};
 };
 
-// RAII bracket: records an event pair around one launch on the launch stream.
+// RAII bracket of one timed launch.  The event pair is handed to the launch itself (hipExtLaunchKernelGGL:
+// start/stop are the kernel's own dispatch timestamps -- what rocprofv3 reports); events recorded AROUND a
+// launch on the stream read ~2 us more (their own packets).  A scope that sees no PAYNE_LAUNCH gives its
+// record back; a scope with several launches times the first.
+struct ProfScope;
+static thread_local ProfScope* g_prof_scope = nullptr;
 struct ProfScope {
-  payne_ctx* c; hipStream_t s; payne_ctx::ProfRec* r = nullptr;
+  payne_ctx* c; hipStream_t s; payne_ctx::ProfRec* r = nullptr; bool used = false; ProfScope* outer = nullptr;
   ProfScope(payne_ctx* c_, hipStream_t s_, int kind) : c(c_), s(s_) {
+    outer = g_prof_scope; g_prof_scope = this;
     if (!c->prof) return;
     if (c->prof_used == c->prof_pool.size()) {
       payne_ctx::ProfRec n{};
@@ -1636,10 +1642,23 @@ struct ProfScope {
     }
     r = &c->prof_pool[c->prof_used++];
     r->kind = kind;
-    (void)hipEventRecord(r->e0, s);
   }
-  ~ProfScope() { if (r) (void)hipEventRecord(r->e1, s); }
+  ~ProfScope() {
+    g_prof_scope = outer;
+    if (r && !used) --c->prof_used;                      // nothing was launched under this scope
+  }
 };
+#include <hip/hip_ext.h>
+#define PAYNE_LAUNCH(kernel, grid, block, lds, stream, ...)                                               \
+  do {                                                                                                    \
+    ProfScope* ps_ = g_prof_scope;                                                                        \
+    if (ps_ && ps_->r && !ps_->used) {                                                                    \
+      ps_->used = true;                                                                                   \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, ps_->r->e0, ps_->r->e1, 0, __VA_ARGS__); \
+    } else {                                                                                              \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                  \
+    }                                                                                                     \
+  } while (0)
 
 #define HIPCHK(ctx, call)                                                                 \
   do {                                                                                    \
@@ -2033,7 +2052,7 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
 #ifdef PAYNE_STAMPS
   p.stamps = FUSE ? nullptr : g_dense_stamps;
 #endif
-  hipLaunchKernelGGL((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
+  PAYNE_LAUNCH((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
 // Timing experiments only (results are invalid): PAYNE_SKIP bit 0 = hidden layers, 1 = output layer, 2 = post kernel.
@@ -2062,7 +2081,7 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)OK_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
+  PAYNE_LAUNCH(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
 }
 
 template <int WN>
@@ -2078,7 +2097,7 @@ static void launch_out_dma_t(payne_ctx* c, DenseParams& p, hipStream_t s) {
 #ifdef PAYNE_STAMPS
   p.stamps = g_dense_stamps;
 #endif
-  hipLaunchKernelGGL(payne_dense_dma_kernel<WN>, dim3(p.grid_m * p.grid_n), dim3(128 * WN), dm_lds_bytes<WN>(), s, p);
+  PAYNE_LAUNCH(payne_dense_dma_kernel<WN>, dim3(p.grid_m * p.grid_n), dim3(128 * WN), dm_lds_bytes<WN>(), s, p);
 }
 static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
   static int wide = -1;                                    // PAYNE_DMA_WIDE=0: 64 x 64 tiles; default: 64 x 128
@@ -2097,7 +2116,7 @@ static void launch_out_bx3dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bx3dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(payne_dense_bx3dma_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BD_LDS_BYTES, s, q);
+  PAYNE_LAUNCH(payne_dense_bx3dma_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BD_LDS_BYTES, s, q);
 }
 
 static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
@@ -2111,7 +2130,7 @@ static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BX_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(payne_dense_bf16x3_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BX_LDS_BYTES, s, q);
+  PAYNE_LAUNCH(payne_dense_bf16x3_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BX_LDS_BYTES, s, q);
 }
 
 static int hidden_kernel_choice() {
@@ -2137,9 +2156,9 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   p.stamps = FUSE ? g_hidden_stamps : nullptr;
 #endif
   const dim3 grid(pa.n_gemm + (pa.out ? (p.B + 255) / 256 : 0)), block(256);
-  if (!FUSE) hipLaunchKernelGGL((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
-  else if (p.n_labels <= 4) hipLaunchKernelGGL((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
-  else hipLaunchKernelGGL((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
+  if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
+  else if (p.n_labels <= 4) PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
+  else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
 }
 
 template <bool FUSE>
@@ -2148,7 +2167,7 @@ static void launch_small(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   pa.out = nullptr;
   p.grid_m = (p.B + 15) / 16;
   p.grid_n = (p.N + 15) / 16;
-  hipLaunchKernelGGL((payne_dense_small_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(64), 0, s, p);
+  PAYNE_LAUNCH((payne_dense_small_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(64), 0, s, p);
 }
 
 // ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
@@ -2278,7 +2297,7 @@ static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor
   if ((rc = run_net(c, C, theta, B, instr_factor, s))) return rc;
   int npc2 = 1;
   while (npc2 < c->cn_npix) npc2 <<= 1;
-  hipLaunchKernelGGL(payne_cont_kernel, dim3(B), dim3(256), (size_t)npc2 * 8, s, c->cont_raw, c->cn_npix, npc2, c->cont_scale,
+  PAYNE_LAUNCH(payne_cont_kernel, dim3(B), dim3(256), (size_t)npc2 * 8, s, c->cont_raw, c->cn_npix, npc2, c->cont_scale,
                      c->cont_idx, c->cont_frac, c->raw, c->T.npix);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("continuum launch: ") + hipGetErrorString(e));
@@ -2302,7 +2321,7 @@ static int check_call(payne_ctx* c, const void* in, int B, const void* out) {
 static int run_sed(payne_ctx* c, const double* in, int ld, int mode, int B, double* mags, hipStream_t s) {
   {
     ProfScope ps(c, s, 2);
-    hipLaunchKernelGGL(payne_sed_kernel, dim3(c->P.F, B), dim3(64), (size_t)c->P.H * 16, s, c->P, in, ld, mode,
+    PAYNE_LAUNCH(payne_sed_kernel, dim3(c->P.F, B), dim3(64), (size_t)c->P.H * 16, s, c->P, in, ld, mode,
                        8 + c->opts.npoly, c->opts.photscale, mags);
   }
   hipError_t e = hipGetLastError();
@@ -2327,9 +2346,9 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
     ProfScope ps(c, s, 1);
     if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
-      hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, s, c->T, a, c->big_ws, B);
+      PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, s, c->T, a, c->big_ws, B);
     } else {
-      hipLaunchKernelGGL((stage < 0 && !out && a.prep) ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+      PAYNE_LAUNCH((stage < 0 && !out && a.prep) ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
     }
   }
   hipError_t e = hipGetLastError();
@@ -2355,7 +2374,7 @@ static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, flo
   const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
   {
     ProfScope ps(c, s, 1);
-    hipLaunchKernelGGL(payne_lsf_kernel, dim3(B), dim3(256), lds, s, c->T, a);
+    PAYNE_LAUNCH(payne_lsf_kernel, dim3(B), dim3(256), lds, s, c->T, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("lsf launch: ") + hipGetErrorString(e));
