@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[r] + bv, p.act);
+      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
     }
   }
   HK_STAMP(15);
