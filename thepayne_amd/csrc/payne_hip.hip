@@ -608,6 +608,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     } else {
       HK_STAMP(2);
     }
+    HK_STAMP(6);                                          // (first layer done; the weight tile is stored next)
 #pragma unroll
     for (int it = 0; it < 4 * NKI; ++it) {
       const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);

@@ -61,8 +61,10 @@ try:
     print("hidden kernel: %d workgroups stamped" % used.sum())
     t0 = h[:, 0].min()
     print("  entry spread (first..last workgroup start): %d cycles" % (h[:, 0].max() - t0))
-    for k, name in enumerate(["loads issued", "B tile + labels in LDS", "A tile (layer 0) in LDS", "MFMA done", "end"]):
-        dlt = h[:, k + 1] - h[:, k]
+    order = [0, 1, 2, 6, 3, 4, 5]          # slot 6 = first layer done (added later, between 2 and 3)
+    for (a_, b_), name in zip(zip(order[:-1], order[1:]), ["loads issued", "labels in LDS", "first layer computed",
+                                                           "weight tile stored", "MFMA done", "end"]):
+        dlt = h[:, b_] - h[:, a_]
         print("  %-26s median %6d  p90 %6d" % (name, np.median(dlt), np.percentile(dlt, 90)))
     print("  whole workgroup median %d ; first start -> last end %d cycles" % (np.median(h[:, 5] - h[:, 0]), h[:, 5].max() - t0))
 except AttributeError:
