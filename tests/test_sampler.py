@@ -130,3 +130,63 @@ def test_fitpayne_bulk_rows_equal_single_rows(tmp_path):
         F._row(11 + i, rec["v"][i], (rec["logl"][i], rec["logvol"][i], rec["logwt"][i], rec["h"][i], rec["nc"][i],
                                      rec["logz"][i], rec["delta_logz"][i]))
     assert bulk == F.outff.getvalue() and bulk.count('\n') == m
+
+
+def test_ns_consume_stop_conditions():
+    """payne_ns_consume: empty queue, emission limit, likelihood ceiling, exhausted queue with carried call counts."""
+    import ctypes as C
+    from thepayne_amd.build import build_lib
+    from thepayne_amd import _lib
+    build_lib()
+    lib = _lib.load()
+    L = _lib
+    n, nd = 8, 2
+    rng = np.random.default_rng(0)
+
+    def fresh():
+        lu = np.ascontiguousarray(rng.uniform(size=(n, nd)))
+        return lu, lu.copy(), np.ascontiguousarray(np.arange(n, dtype=np.float64)), np.zeros(n, dtype=np.int32)
+
+    def call(st, live, q, dlogz=1e-9, max_emit=100, logl_max=np.inf, cap=16):
+        lu, lv, ll, lit = live
+        qu, qv, ql, qnc = q
+        rec = {k: np.empty(cap) for k in ("logl", "logvol", "logwt", "logz", "logzvar", "h", "delta_logz")}
+        rec.update(worst=np.empty(cap, np.int32), nc=np.empty(cap, np.int32), worst_it=np.empty(cap, np.int32),
+                   u=np.empty((cap, nd)), v=np.empty((cap, nd)))
+        A = lambda a: a.ctypes.data                                              # noqa: E731
+        dead = L.NsDead(*[A(rec[k]) for k in ("worst", "u", "v", "logl", "logvol", "logwt", "logz", "logzvar", "h", "nc",
+                                              "worst_it", "delta_logz")])
+        consumed, stop = C.c_int(0), C.c_int(0)
+        m = lib.payne_ns_consume(C.byref(st), A(lu), A(lv), A(ll), A(lit), A(qu), A(qv), A(ql), A(qnc), len(ql), dlogz,
+                                       max_emit, logl_max, C.byref(dead), cap, C.byref(consumed), C.byref(stop))
+        return m, consumed.value, stop.value, rec
+
+    def queue(vals, nc=3):
+        k = len(vals)
+        return (np.ascontiguousarray(rng.uniform(size=(k, nd))), np.ascontiguousarray(rng.uniform(size=(k, nd))),
+                np.ascontiguousarray(np.asarray(vals, dtype=np.float64)), np.full(k, nc, dtype=np.int32))
+
+    new_state = lambda: L.NsState(n, nd, 1, 0, -1e300, 0.0, 0.0, 0.0, -1e300)    # noqa: E731
+    # empty queue: nothing emitted, nothing consumed
+    st, live = new_state(), fresh()
+    m, used, stop, _ = call(st, live, queue([]))
+    assert (m, used, stop) == (0, 0, L.NS_QUEUE_EMPTY) and st.it == 1
+    # proposals below the threshold are skipped and their calls carried over; the good ones replace the worst points
+    m, used, stop, rec = call(st, live, queue([-1.0, 50.0, 0.5, 60.0]))
+    assert (m, used, stop) == (2, 4, L.NS_QUEUE_EMPTY)
+    assert list(rec["logl"][:2]) == [0.0, 1.0] and list(rec["nc"][:2]) == [6, 6] and list(rec["worst"][:2]) == [0, 1]
+    assert st.it == 3 and st.pending_nc == 0 and live[2][0] == 50.0 and live[2][1] == 60.0
+    m, used, stop, rec = call(st, live, queue([1.5]))                       # does not beat the current worst (2.0)
+    assert (m, used, stop) == (0, 1, L.NS_QUEUE_EMPTY) and st.pending_nc == 3
+    m, used, stop, rec = call(st, live, queue([70.0]))
+    assert m == 1 and rec["nc"][0] == 6                                       # 3 carried + 3
+    # emission limit and likelihood ceiling
+    m, used, stop, _ = call(st, live, queue([80.0, 81.0, 82.0]), max_emit=2)
+    assert (m, used, stop) == (2, 2, L.NS_LIMIT)
+    m, used, stop, _ = call(st, live, queue([90.0]), logl_max=4.0)           # worst live point is 5.0 by now
+    assert (m, stop) == (0, L.NS_LOGL_MAX)
+    # convergence: a huge dlogz stops at once
+    m, used, stop, _ = call(st, live, queue([95.0]), dlogz=1e9)
+    assert (m, stop) == (0, L.NS_CONVERGED)
+    # volumes shrink by ln((n+1)/n) per dead point
+    assert abs(st.logvol + (st.it - 1) * np.log((n + 1.0) / n)) < 1e-12
