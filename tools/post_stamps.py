@@ -13,7 +13,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from thepayne_amd import build, _lib  # noqa: E402
 
@@ -21,10 +20,33 @@ path = build.build_diag()
 os.environ["PAYNE_HIP_LIB"] = path
 from thepayne_amd import synth, nnio  # noqa: E402
 from thepayne_amd.engine import PayneEngine  # noqa: E402
-from helpers import theta_full, yst_problem  # noqa: E402
+
+
+def theta_full(theta7):
+    """[B,7] sampled spectroscopic vectors -> [B, 12] ABI rows (NaN = absent)."""
+    theta7 = np.atleast_2d(theta7)
+    out = np.full((len(theta7), 12), np.nan)
+    out[:, 0:6] = theta7[:, 0:6]
+    out[:, 7] = theta7[:, 6]
+    return out
+
+
+def problem(cfg_name):
+    """Synthetic net + observed spectrum made with the engine itself (a timing tool: no oracle here)."""
+    cfg = synth.CONFIGS[cfg_name]
+    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    obs = synth.obs_grid(net["wavelength"], cfg["nobs"])
+    e0 = PayneEngine(nnio.normalize_spec_net(net), obs=(obs,), b_max=1)
+    T = synth.TRUTH
+    truth = theta_full(np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]]]))
+    clean = e0.predict_batch(truth, stage=2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+    e0.close()
+    flux = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
+    return net, obs, flux, np.full(len(obs), 0.01)
+
 
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C2"
-raw, obs, flux, eflux = yst_problem(cfgname)
+raw, obs, flux, eflux = problem(cfgname)
 B = synth.CONFIGS[cfgname]["batch"]
 eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=B)
 th = eng._theta(theta_full(synth.draw_candidates(B, seed=1)), eng.ncols)
