@@ -239,7 +239,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels, batch of %d "
                                "candidate vectors per step (dynesty live points)" % (args.config, N, H, cfg["nobs"], B),
-                   "batch": B, "npix": N, "nobs": cfg["nobs"], "hidden": H, "stars": world,
+                   "batch": B, "npix": N, "nobs": cfg["nobs"], "stars": world,
                    "batches_in_flight": S,
                    "parallelism": "1 star per GPU, no data-path collective"},
     }
