@@ -626,8 +626,17 @@ PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr
     S.wh = T.obs_max * (1.0 + pad * 1.0);
     const float op32 = (float)S.one_plus;
     const int g_lo = probe_start(T, op32, S.wl), g_hi = probe_start(T, op32, S.wh);
-    S.win_below = count_search<false>(T, S.one_plus, S.wl, g_lo == INT32_MIN ? 0 : g_lo + 32);
-    S.win_notabove = count_search<true>(T, S.one_plus, S.wh, g_hi == INT32_MIN ? 0 : g_hi + 32);
+    // both guesses checked with ONE round trip (four independent loads); a guess that does not bracket its limit
+    // (or sits at an end of the grid) goes through count_search
+    const int n = T.npix;
+    const int ga = g_lo == INT32_MIN ? 0 : g_lo + 32, gb = g_hi == INT32_MIN ? 0 : g_hi + 32;
+    const bool ina = ga >= 1 && ga < n, inb = gb >= 1 && gb < n;
+    const double a0 = T.lam[ina ? ga - 1 : 0] * S.one_plus, a1 = T.lam[ina ? ga : 0] * S.one_plus;
+    const double b0 = T.lam[inb ? gb - 1 : 0] * S.one_plus, b1 = T.lam[inb ? gb : 0] * S.one_plus;
+    const bool oka = ina && !(a0 > S.wl) && (a1 > S.wl);          // pred true at ga-1, false at ga
+    const bool okb = inb && (b0 < S.wh) && !(b1 < S.wh);
+    S.win_below = oka ? ga : count_search<false>(T, S.one_plus, S.wl, ga);
+    S.win_notabove = okb ? gb : count_search<true>(T, S.one_plus, S.wh, gb);
     S.win_ready = 1;
     W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);
     S.w_ready = 1;
