@@ -256,16 +256,19 @@ constexpr int DM_NS = 3;                                   // ring stages
 // per CU); WN = 4 the 64 x 128 / 512-thread form (one per CU, same waves per SIMD): the activation tile is then
 // fetched once per 128 columns, 24 KB instead of 2 x 16 KB per k-step and CU -- the kernel is bound by the CU's
 // miss throughput, not by the matrix pipes.
-template <int WN> constexpr int dm_stage_floats() { return (64 + 32 * WN) * 32; }
-template <int WN> constexpr size_t dm_lds_bytes() { return (size_t)DM_NS * dm_stage_floats<WN>() * sizeof(float); }
+// BK = k-depth of a stage: 32 (rows of 128 B, 8 chunks, swizzle by (r >> 1) & 7) or 64 (rows of 256 B = one full
+// bank cycle, 16 chunks, swizzle by r & 15): half as many barrier steps for the same bytes.
+template <int WN, int BK> constexpr int dm_stage_floats() { return (64 + 32 * WN) * BK; }
+template <int WN, int BK> constexpr size_t dm_lds_bytes() { return (size_t)DM_NS * dm_stage_floats<WN, BK>() * sizeof(float); }
 
-template <int WN>
+template <int WN, int BK>
 __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p) {
   constexpr int BN = 32 * WN, NW = 2 * WN;                 // tile columns, waves
-  constexpr int STAGE = dm_stage_floats<WN>();
-  constexpr int NBLK = (64 + BN) / 8;                      // 1-KiB pieces per stage: 8 rows each
-  constexpr int PER = NBLK / NW;                           // pieces per wave: 4 (WN = 2) or 3 (WN = 4)
-  static_assert(NBLK % NW == 0, "pieces divide over the waves");
+  constexpr int STAGE = dm_stage_floats<WN, BK>();
+  constexpr int CH = BK / 4, RP = 256 / BK;                // 16-byte chunks per row, rows per 1-KiB piece
+  constexpr int NBLK = (64 + BN) / RP, NA = 64 / RP;       // pieces per stage, of which A
+  constexpr int PER = NBLK / NW;                           // pieces per wave
+  static_assert(NBLK % NW == 0 && (BK == 32 || BK == 64), "pieces divide over the waves");
   extern __shared__ __attribute__((aligned(16))) float dm_sm[];
   const int ntiles = p.grid_m * p.grid_n;
   int t = blockIdx.x;
@@ -274,16 +277,17 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;
+  auto swz = [](int row) { return BK == 32 ? ((row >> 1) & 7) : (row & 15); };
 
-  // the 1-KiB pieces this wave moves per stage: piece q covers rows 8q .. 8q+7 of A (q < 8) or of B (q >= 8)
+  // the 1-KiB pieces this wave moves per stage: piece q covers RP rows of A (q < NA) or of B
   const float* src[PER];
   int dst[PER];                                            // float offset inside a stage (wave-uniform)
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int q = wave * PER + j;
-    const bool isA = q < 8;
-    const int blk = isA ? q : q - 8, row = 8 * blk + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);           // which chunk of the row belongs in this lane's slot
+    const bool isA = q < NA;
+    const int blk = isA ? q : q - NA, row = RP * blk + lane / CH;
+    const int c = (lane % CH) ^ swz(row);                  // which chunk of the row belongs in this lane's slot
     if (isA) {
       const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
       src[j] = p.X + (size_t)r * p.ldx + 4 * c;
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
       const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
       src[j] = p.W + (size_t)r * p.K + 4 * c;              // p.K: padded pitch of the weight copy
     }
-    dst[j] = (isA ? 0 : 64 * 32) + blk * 256;
+    dst[j] = (isA ? 0 : 64 * BK) + blk * 256;
   }
   auto issue = [&](int stage, int k0) {
 #pragma unroll
@@ -305,31 +309,36 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   // fragment addresses (floats inside a stage): row R, chunk 2kk + half, swizzled
   const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), half = lane >> 5;
-  const int sa = (Ra >> 1) & 7, sb = (Rb >> 1) & 7;
+  const int sa = swz(Ra), sb = swz(Rb);
 
-  const int nk = p.K / 32;                                 // padded: exact
+  const int nk = p.K / BK;                                 // padded: exact
   HK_STAMP(0);
   issue(0, 0);
-  if (nk > 1) issue(1, 32);
+  if (nk > 1) issue(1, BK);
   for (int it = 0; it < nk; ++it) {
     // my pieces of stage `it` have landed once at most the PER younger loads (stage it+1) are outstanding
-    if (it + 1 < nk) { if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it + 1 < nk) {
+      if (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(PER == 3 || PER == 4 || PER == 6 || PER == 8, "vmcnt literal");
     asm volatile("s_barrier" ::: "memory");                // everybody's pieces landed; everybody finished step it-1
     if (it < 13) HK_STAMP(1 + it);
-    if (it + 2 < nk) issue((it + 2) % DM_NS, (it + 2) * 32);    // into the buffer step it-1 just released
+    if (it + 2 < nk) issue((it + 2) % DM_NS, (it + 2) * BK);    // into the buffer step it-1 just released
     const float* Asb = dm_sm + (it % DM_NS) * STAGE;
-    const float* Bsb = Asb + 64 * 32;
-    f32x4_t a[4], b[4];                                     // all eight fragments first (one LDS round trip per step)
+    const float* Bsb = Asb + 64 * BK;
+    f32x4_t a[BK / 8], b[BK / 8];                           // all fragments first (one LDS round trip per step)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       const int c = 2 * kk + half;
-      a[kk] = *reinterpret_cast<const f32x4_t*>(Asb + Ra * 32 + 4 * (c ^ sa));
-      b[kk] = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * 32 + 4 * (c ^ sb));
+      a[kk] = *reinterpret_cast<const f32x4_t*>(Asb + Ra * BK + 4 * (c ^ sa));
+      b[kk] = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * BK + 4 * (c ^ sb));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
@@ -2085,25 +2094,29 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
   PAYNE_LAUNCH(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
 }
 
-template <int WN>
+template <int WN, int BK>
 static void launch_out_dma_t(payne_ctx* c, DenseParams& p, hipStream_t s) {
   p.W = c->w_out_pad; p.K = c->w_out_kp;                   // padded pitch; X's pitch (ld_hid) is a multiple of 32 too
   p.grid_m = (p.B + 63) / 64;
   p.grid_n = (p.N + 32 * WN - 1) / (32 * WN);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dm_lds_bytes<WN>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dm_lds_bytes<WN, BK>());
     attr_set = true;
   }
 #ifdef PAYNE_STAMPS
   p.stamps = g_dense_stamps;
 #endif
-  PAYNE_LAUNCH(payne_dense_dma_kernel<WN>, dim3(p.grid_m * p.grid_n), dim3(128 * WN), dm_lds_bytes<WN>(), s, p);
+  constexpr size_t lds = dm_lds_bytes<WN, BK>();
+  PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
 }
 static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
-  static int wide = -1;                                    // PAYNE_DMA_WIDE=0: 64 x 64 tiles; default: 64 x 128
+  static int wide = -1, deep = -1;                         // PAYNE_DMA_WIDE=0: 64 x 64 tiles (default 64 x 128); PAYNE_DMA_BK=64: 64-deep stages
   if (wide < 0) { const char* e = getenv("PAYNE_DMA_WIDE"); wide = e ? atoi(e) : 1; }
-  if (wide) launch_out_dma_t<4>(c, p, s); else launch_out_dma_t<2>(c, p, s);
+  if (deep < 0) { const char* e = getenv("PAYNE_DMA_BK"); deep = e ? atoi(e) : 32; }
+  if (wide && deep == 64 && (c->w_out_kp % 64) == 0) launch_out_dma_t<4, 64>(c, p, s);
+  else if (wide) launch_out_dma_t<4, 32>(c, p, s);
+  else launch_out_dma_t<2, 32>(c, p, s);
 }
 
 static void launch_out_bx3dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
