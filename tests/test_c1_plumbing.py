@@ -1,0 +1,106 @@
+"""C1 of SURVEY 8(d): plumbing without a GPU.
+
+A ``runPayne.py``-shaped ``inputdict`` (demo/runPayne.py:60-150) goes through the
+build's ``FitPayne.run`` -- argument parsing, prior object, batched static sampler,
+text output -- with the CPU restatement (``oracle``) standing in for the likelihood
+object, so everything around the HIP path is exercised here on CPU.  Pass criterion:
+the sampler terminates and the posterior brackets the truth.  The GPU twin of this
+test (the real likelihood) is tests/test_api_gpu.py::test_fitpayne_run_end_to_end.
+"""
+import numpy as np
+
+import oracle as O
+from thepayne_amd import synth, nnio
+from thepayne_amd.fitting.fitstar import FitPayne
+from helpers import yst_problem
+
+
+class OracleBackedLikelihood(object):
+    """Same constructor and attributes as fitting/likelihood.py's ``likelihood``
+    (Payne/fitting/likelihood.py:5-40), evaluated by the oracle one row at a time."""
+    calls = 0
+
+    def __init__(self, fitargs, fitpars, runbools, **kwargs):
+        self.fitargs = fitargs
+        self.spec_bool, self.phot_bool, self.modpoly_bool, self.photscale_bool = runbools[:4]
+        self.fixedpars = fitargs['fixedpars']
+        self.fitpars_i = [pp for pp in fitpars[0] if fitpars[1][pp]]
+        self.ndim = len(self.fitpars_i)
+        with np.load(fitargs['specANNpath']) as z:
+            net = {k: z[k] for k in z.files}
+        net['kind'] = 'YST1'
+        net['resolution'] = float(np.ravel(net['resolution'])[0])
+        self.inner = O.OracleLikelihood(net, fitargs['obs_wave_fit'], fitargs['obs_flux_fit'],
+                                        fitargs['obs_eflux_fit'], self.fitpars_i, fixedpars=self.fixedpars,
+                                        modpoly=self.modpoly_bool)
+        self.parsdict = {}
+
+    def lnlikefn(self, pars):
+        out = self.inner.lnlikefn(pars)
+        self.parsdict = self.inner.parsdict
+        type(self).calls += 1
+        return out
+
+    def lnlike_batch(self, theta):
+        return np.array([self.lnlikefn(row) for row in np.atleast_2d(theta)])
+
+
+def _inputdict(tmp_path, **sampler_kw):
+    raw, obs, flux, eflux = yst_problem("tiny", H=16, line_depth=0.3)
+    path = str(tmp_path / "yst.npz")
+    nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
+    sampler = {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': 64,
+               'walks': 10, 'delta_logz_final': 0.5, 'bootstrap': 0, 'flushnum': 100, 'seed': 11,
+               'device_proposals': False}
+    sampler.update(sampler_kw)
+    return {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': path, 'NNtype': 'YST1', 'sampler': sampler,
+        'priordict': synth.demo_priordict(), 'output': str(tmp_path / 'fit.dat'),
+    }
+
+
+def test_c1_fitpayne_run_with_cpu_restatement(tmp_path):
+    F = FitPayne()
+    F.likelihood = OracleBackedLikelihood
+    OracleBackedLikelihood.calls = 0
+    inputdict = _inputdict(tmp_path)
+    sampler = F.run(inputdict=inputdict, verbose=False)
+    r = sampler.results
+    assert r.niter > 64 and np.isfinite(r.logz[-1])
+    assert OracleBackedLikelihood.calls >= int(np.sum(r.ncall)) - 64     # every call went through the stand-in
+    w = sampler.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+    # output: header + one row per dead point + the final live points (fitstar.py:318-340, :395-420)
+    lines = open(inputdict['output']).read().splitlines()
+    head = lines[0].split()
+    assert head[0] == 'Iter' and head[1:8] == F.likeobj.fitpars_i
+    assert head[-7:] == ['log(lk)', 'log(vol)', 'log(wt)', 'h', 'nc', 'log(z)', 'delta(log(z))']
+    assert len(lines) == 1 + r.niter
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[1:]])
+    assert np.all(np.diff(rows[:, 8]) >= 0)                     # log(lk) never decreases
+    # the run ended on the dlogz rule (fitstar.py:356-372), not on a cap
+    ndead = r.niter - 64
+    assert rows[ndead - 1, -1] <= 0.5 < rows[ndead - 2, -1]
+    assert np.allclose(rows[:, 1:8], r.samples, rtol=1e-6, atol=1e-6)
+
+
+def test_c1_fixed_parameter_and_maxcall(tmp_path):
+    """A 'fixed' prior entry drops the parameter from the sampled vector and appends it to
+    every output row (fitstar.py:226-231, :330-334); maxcall stops the run early."""
+    F = FitPayne()
+    F.likelihood = OracleBackedLikelihood
+    inputdict = _inputdict(tmp_path, maxcall=3000)
+    inputdict['priordict']['Vrot'] = {'fixed': 3.0}
+    sampler = F.run(inputdict=inputdict, verbose=False)
+    assert F.ndim == 6 and 'Vrot' not in F.likeobj.fitpars_i
+    assert int(np.sum(sampler.results.ncall)) < 3000 + 2 * 64
+    lines = open(inputdict['output']).read().splitlines()
+    head = lines[0].split()
+    assert head[1:7] == F.likeobj.fitpars_i and head[7] == 'Vrot'
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[1:]])
+    assert np.all(rows[:, 7] == 3.0)
