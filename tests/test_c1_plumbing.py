@@ -104,3 +104,26 @@ def test_c1_fixed_parameter_and_maxcall(tmp_path):
     assert head[1:7] == F.likeobj.fitpars_i and head[7] == 'Vrot'
     rows = np.array([[float(x) for x in ln.split()] for ln in lines[1:]])
     assert np.all(rows[:, 7] == 3.0)
+
+
+def test_c1_dynamic_sampler_driver(tmp_path):
+    """samplertype 'Dynamic' (fitstar.py:466-645): baseline run, then batches of 2 x npoints placed by the
+    weight function; the rows of the batches follow the baseline's in the same file."""
+    F = FitPayne()
+    F.likelihood = OracleBackedLikelihood
+    inputdict = _inputdict(tmp_path, samplertype='Dynamic', npoints=50, delta_logz_final=1.0, maxbatch=2)
+    dy = F.run(inputdict=inputdict, verbose=False)
+    r = dy.results
+    assert dy.batch == 2 and list(r.batch_nlive) == [50, 100, 100]
+    lines = open(inputdict['output']).read().splitlines()
+    assert len(lines) == 1 + r.niter
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[1:]])
+    assert np.array_equal(rows[:, 0], np.arange(r.niter))
+    # every row of the file is a sample of the merged run
+    assert np.allclose(np.sort(rows[:, 8]), r.logl, rtol=1e-12, atol=1e-9)
+    w = dy.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)

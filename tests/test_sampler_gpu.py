@@ -227,3 +227,33 @@ def test_two_populations_interleaved(tmp_path):
     a = M.pops[0].rwalk(U0[:32], V0[:32], lp0[:32], axes, 1.0, lstar, 10, seed=77)
     assert np.array_equal(a[0], U[:32]) and np.array_equal(a[2], lp[:32])
     M.close()
+
+
+def test_fitpayne_dynamic_sampler_on_the_device(tmp_path):
+    """samplertype 'Dynamic' (fitstar.py:466-645) with the likelihood, the prior transform and the
+    random-walk proposals of the baseline run and of every batch on the GPU."""
+    from thepayne_amd.fitting.fitstar import FitPayne
+    from helpers import yst_problem
+    raw, obs, flux, eflux = yst_problem("small", H=64, line_depth=0.3)
+    inputdict = {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1',
+        'sampler': {'samplertype': 'Dynamic', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': 64,
+                    'walks': 20, 'delta_logz_final': 0.5, 'bootstrap': 0, 'flushnum': 200, 'seed': 5, 'maxbatch': 3},
+        'priordict': synth.demo_priordict(),
+        'output': str(tmp_path / 'fit.dat'),
+    }
+    F = FitPayne()
+    dy = F.run(inputdict=inputdict, verbose=False)
+    assert F.proposer is not None and 1 <= dy.batch <= 3
+    r = dy.results
+    assert list(r.batch_nlive[1:]) == [128] * dy.batch and np.all(np.diff(r.logl) >= 0)
+    assert r.samples_n.max() > 128
+    w = dy.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+    lines = open(inputdict['output']).read().splitlines()
+    assert len(lines) == 1 + r.niter

@@ -151,9 +151,20 @@ class FitPayne(object):
         if kind == 'Static':
             return self._runsampler(samplerdict)
         if kind == 'Dynamic':
-            raise NotImplementedError("samplertype 'Dynamic' (fitstar.py:466-645) is not built yet; use 'Static'")
+            return self._rundysampler(samplerdict)
         print('Did not understand sampler type, return nothing')
         return None
+
+    def _proposer(self, samplerdict, k_max):
+        """Prior transform, ln-prior and random-walk proposals on the GPU when the fit's priors can be
+        expressed there (everything but derived-quantity priors); None = host path."""
+        if not samplerdict.get('device_proposals', True):
+            return None
+        try:
+            from ..sampler.device import DeviceProposer
+            return DeviceProposer(self.likeobj, self.priorobj, k_max=k_max)
+        except NotImplementedError:
+            return None
 
     def _initoutput(self, parnames):
         self.outff = open(self.output, 'w')
@@ -208,15 +219,7 @@ class FitPayne(object):
         sys.stdout.flush()
         # prior transform, ln-prior and the random-walk proposals run on the GPU when the fit's priors
         # can be expressed there (everything but derived-quantity priors); host path otherwise
-        proposer = None
-        if samplerdict.get('device_proposals', True):
-            try:
-                from ..sampler.device import DeviceProposer
-                proposer = DeviceProposer(self.likeobj, self.priorobj,
-                                          k_max=max(npoints, int(samplerdict.get('queue_size', npoints))))
-            except NotImplementedError:
-                proposer = None
-        self.proposer = proposer
+        self.proposer = proposer = self._proposer(samplerdict, max(npoints, int(samplerdict.get('queue_size', npoints))))
         sampler = NestedSampler(
             lnprob_batch, self.priorobj.priortrans_batch, self.ndim, proposer=proposer,
             logl_args=[self.likeobj, self.priorobj], nlive=npoints, bound=bound, sample=samplemethod,
@@ -261,3 +264,92 @@ class FitPayne(object):
             sys.stdout.write('\n')
             print('RUN TIME: {0}'.format(datetime.now() - starttime))
         return sampler
+
+    def _progress(self, nit, nc, ncall, eff, logz, logzvar, delta_logz, delta_logz_final, mean_time):
+        logzerr = np.sqrt(logzvar) if logzvar >= 0. else np.nan
+        sys.stdout.write("\riter: {0:d} | nc: {1:d} | ncall: {2:d} | eff(%): {3:6.3f} | "
+                         "logz: {4:6.3f} +/- {5:6.3f} | dlogz: {6:6.3f} > {7:6.3f}   | mean(time):  {8:7.5f} | time: {9} \n"
+                         .format(nit, nc, ncall, eff, logz, logzerr, delta_logz, delta_logz_final, mean_time,
+                                 datetime.now()))
+        sys.stdout.flush()
+
+    def _rundysampler(self, samplerdict):
+        """The reference's dynamic-sampling driver (fitstar.py:466-645): a baseline static run, then
+        batches of 2 x npoints particles placed by the weight function until the stopping function
+        fires, each merged into the saved run.  Output rows keep the reference's text: during the
+        batches the evidence columns repeat the baseline run's last values (fitstar.py:601-603)."""
+        from ..sampler.dynamic import DynamicNestedSampler
+        npoints = samplerdict.get('npoints', 200)
+        delta_logz_final = samplerdict.get('delta_logz_final', 0.01)
+        flushnum = samplerdict.get('flushnum', 10)
+        maxiter = samplerdict.get('maxiter', sys.maxsize)
+        maxbatch = samplerdict.get('maxbatch', sys.maxsize)
+        samplemethod = samplerdict.get('samplemethod', 'unif')
+        seed = samplerdict.get('seed', None)
+        starttime = datetime.now()
+        if self.verbose:
+            print('Start Dynamic batched nested sampler w/ {0} sampler, {1} number of samples, Ndim = {2}, '
+                  'and w/ stopping criteria of dlog(z) = {3}: {4}'.format(
+                      samplemethod, npoints, self.ndim, delta_logz_final, starttime))
+        sys.stdout.flush()
+        queue = max(2 * npoints, int(samplerdict.get('queue_size', 2 * npoints)))
+        self.proposer = proposer = self._proposer(samplerdict, queue)
+        dy_sampler = DynamicNestedSampler(
+            lnprob_batch, self.priorobj.priortrans_batch, self.ndim, logl_args=[self.likeobj, self.priorobj],
+            bound=samplerdict.get('samplerbounds', 'multi'), sample=samplemethod,
+            update_interval=samplerdict.get('update_interval', 0.6), bootstrap=samplerdict.get('bootstrap', 0),
+            walks=samplerdict.get('walks', 25), slices=samplerdict.get('slices', 5), batched=True,
+            queue_size=queue, proposer=proposer,
+            rstate=np.random.default_rng(seed))
+        self.parnames = list(self.likeobj.fitpars_i) + list(self.fitargs['fixedpars'].keys())
+        self.fitargs_fixed = dict(self.fitargs['fixedpars'])
+        self._initoutput(self.parnames)
+        ncall = nit = 0
+        t_iter, dt = datetime.now(), []
+        logvol = logwt = h = logz = logzvar = delta_logz = eff = 0.0
+        for it, results in enumerate(dy_sampler.sample_initial(nlive=npoints, dlogz=delta_logz_final, maxiter=maxiter)):
+            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
+             h, nc, worst_it, propidx, propiter, eff, delta_logz) = results
+            ncall += nc
+            nit = it
+            self._row(it, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
+            now = datetime.now()
+            dt.append((now - t_iter).total_seconds() / float(max(1, nc)))
+            t_iter = now
+            if (it % flushnum) == 0 or it == maxiter:
+                self.outff.flush()
+                if self.verbose:
+                    self._progress(nit, nc, ncall, eff, logz, logzvar, delta_logz, delta_logz_final, np.mean(dt))
+                dt = []
+            if it == maxiter:
+                break
+        sys.stdout.write('\n Finished Initial Static Run {0}\n'.format(datetime.now() - starttime))
+        sys.stdout.flush()
+        nit += 1
+        for n in range(dy_sampler.batch, min(maxiter, maxbatch)):
+            res = dy_sampler.results
+            res['prop'] = None
+            stop, stop_vals = dy_sampler.stopping_function(res, return_vals=True)
+            if stop:
+                break
+            logl_bounds = dy_sampler.weight_function(res)
+            it2 = -1
+            for it2, results2 in enumerate(dy_sampler.sample_batch(nlive_new=npoints * 2, logl_bounds=logl_bounds,
+                                                                   maxiter=maxiter, save_bounds=True)):
+                (worst, ustar, vstar, loglstar, nc, worst_it, propidx, propiter, eff) = results2
+                ncall += nc
+                self._row(nit + it2, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
+                now = datetime.now()
+                dt.append((now - t_iter).total_seconds() / float(max(1, nc)))
+                t_iter = now
+                if (it2 % flushnum) == 0:
+                    self.outff.flush()
+                    if self.verbose:
+                        self._progress(nit + it2, nc, ncall, eff, logz, logzvar, delta_logz, delta_logz_final, np.mean(dt))
+                    dt = []
+            nit += it2 + 1
+            dy_sampler.combine_runs()
+        self.outff.close()
+        sys.stdout.write('\n Finished Full Dynamic Run {0}\n'.format(datetime.now() - starttime))
+        sys.stdout.flush()
+        return dy_sampler

@@ -1,1 +1,2 @@
 from .nested import NestedSampler, Results  # noqa: F401
+from .dynamic import DynamicNestedSampler  # noqa: F401

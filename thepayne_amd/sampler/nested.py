@@ -47,7 +47,7 @@ class NestedSampler(object):
     def __init__(self, loglikelihood, prior_transform, ndim, nlive=500, bound='multi', sample='unif',
                  logl_args=None, bootstrap=0, walks=25, slices=5, enlarge=None, rstate=None,
                  batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None,
-                 native=True, **ignored):
+                 native=True, live_points=None, loglstar=None, **ignored):
         if sample not in ('unif', 'rwalk'):
             raise NotImplementedError("sample=%r: this driver provides 'unif' and 'rwalk'" % (sample,))
         if bound not in ('none', 'single', 'multi'):
@@ -69,9 +69,17 @@ class NestedSampler(object):
         else:
             self._logl = lambda V: np.array([loglikelihood(v, *args) for v in V], dtype=np.float64)
             self._ptform = lambda U: np.array([prior_transform(u) for u in U], dtype=np.float64)
-        # live points
-        self.live_u = self.rng.uniform(size=(self.nlive, self.ndim))
-        if self.proposer is not None:
+        # live points (dynesty's `live_points=[u, v, logl]` hands over an existing set; the dynamic sampler's
+        # batches start that way, above the threshold `loglstar`)
+        if live_points is not None:
+            self.live_u, self.live_v, self.live_logl = [np.array(a, dtype=np.float64) for a in live_points]
+            if self.live_u.shape != (self.nlive, self.ndim) or self.live_logl.shape != (self.nlive,):
+                raise ValueError("live_points must be (u[nlive, ndim], v[nlive, ndim], logl[nlive])")
+        else:
+            self.live_u = self.rng.uniform(size=(self.nlive, self.ndim))
+        if live_points is not None:
+            pass
+        elif self.proposer is not None:
             self.live_v, ll = self.proposer.lnprob_u(self.live_u)
             self.live_logl = np.where(np.isnan(ll), -np.inf, ll)
         else:
@@ -81,7 +89,7 @@ class NestedSampler(object):
         self.live_v = np.ascontiguousarray(self.live_v, dtype=np.float64)
         self.live_logl = np.ascontiguousarray(self.live_logl, dtype=np.float64)
         self.live_it = np.zeros(self.nlive, dtype=np.int32)
-        self.ncall = self.nlive
+        self.ncall = self.nlive if live_points is None else 0
         self.it = 1
         self.scale = 1.0
         self._pending_nc = 0
@@ -99,6 +107,8 @@ class NestedSampler(object):
         # saved run
         self._chunks = []                      # dead-point records, one dict of arrays per consumed queue
         self.logz, self.logzvar, self.h, self.logvol, self.loglstar = -1e300, 0.0, 0.0, 0.0, -1e300
+        if loglstar is not None:
+            self.loglstar = float(loglstar)
         self.eff = 100.0
         self.added_live = False
 
