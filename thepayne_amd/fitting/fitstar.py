@@ -145,9 +145,10 @@ class FitPayne(object):
         self.ndim = sum(1 for pp in fitpars[0] if fitpars[1][pp])
         self.priorobj = self.prior(fitargs, indicts['priordict'], fitpars, runbools)
         nlive = samplerdict.get('npoints', 200)
-        self.likeobj = self.likelihood(fitargs, fitpars, runbools, device=self.device,
-                                       b_max=max(64, int(samplerdict.get('queue_size', nlive))))
         kind = samplerdict.get('samplertype', 'Static')
+        widest = 2 * nlive if kind == 'Dynamic' else nlive        # the dynamic sampler's batches carry 2 x npoints
+        self.likeobj = self.likelihood(fitargs, fitpars, runbools, device=self.device,
+                                       b_max=max(64, widest, int(samplerdict.get('queue_size', widest))))
         if kind == 'Static':
             return self._runsampler(samplerdict)
         if kind == 'Dynamic':
