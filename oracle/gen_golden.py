@@ -362,8 +362,57 @@ def g9_lsf():
          native_wave=native[0], native=native[1])
 
 
+# ------------------------------------------------------------------ G10
+def g10_advanced_priors():
+    """The priordict keys IMF / VROT / GAL / VTOT / AngDia as prior.py applies them: IMF and VROT through
+    lnpriorfn (prior.py:286-336), GAL through the transform of Dist (prior.py:231-234); VTOT and AngDia
+    leave everything unchanged in the reference (flag never set / function never called)."""
+    fitargs = {'fixedpars': {}}
+    rng = np.random.default_rng(10)
+    out = {}
+    # joint fit with log(R) + Dist: IMF and VROT need log(g), log(R)
+    names = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R', 'log(R)', 'Dist', 'Av']
+    fitpars = fitpars_for(names)
+    n = 48
+    theta = np.column_stack([rng.uniform(4000, 7000, n), rng.uniform(0.5, 5.2, n), rng.uniform(-2, 0.4, n),
+                             rng.uniform(-0.1, 0.5, n), rng.uniform(-50, 50, n), rng.uniform(0, 40, n),
+                             rng.uniform(20000, 35000, n), rng.uniform(-1.3, 1.6, n), rng.uniform(50, 5000, n),
+                             rng.uniform(0, 1, n)])
+    out["theta"] = theta
+    runb = [True, True, False, False, False]
+    base = {'Dist': {'pv_uniform': [10.0, 20000.0]}}
+    cases = {
+        "imf": dict(base, IMF={'IMF_type': 'Kroupa'}),
+        "vrot": dict(base, VROT={}),
+        "imf_vrot_gauss": dict(base, IMF={'IMF_type': 'Kroupa'}, VROT={}, Vrad={'gaussian': [5.0, 30.0]}),
+        "vtot_angdia": dict(base, VTOT={'pmra': 30.0, 'pmdec': -12.0}, AngDia={'gaussian': [0.5, 0.05]}),
+    }
+    for tag, pd in cases.items():
+        P = prior(fitargs, pd, fitpars, runb)
+        out["lnp_" + tag] = np.array([P.lnpriorfn(list(t)) for t in theta], dtype=float)
+    # photscale fit (log(A)): VROT takes mass 1, eep 350
+    names_a = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R', 'log(A)', 'Av']
+    P = prior(fitargs, {'VROT': {}}, fitpars_for(names_a), [True, True, False, True, False])
+    theta_a = np.delete(theta, 8, axis=1)
+    out["theta_a"] = theta_a
+    out["lnp_vrot_logA"] = np.array([P.lnpriorfn(list(t)) for t in theta_a], dtype=float)
+    # GAL: Dist = 1000 * gal_ppf(u) for two sight lines and two distance ranges
+    u = np.concatenate([[0.0, 1e-6, 1e-3], np.linspace(0.01, 0.99, 29), [1 - 1e-6, 1.0]])
+    out["u"] = u
+    gal = {"disk": ([90.0, 2.0], [10.0, 20000.0]), "pole": ([10.0, 80.0], [100.0, 100000.0]), "nodist": ([200.0, -35.0], None)}
+    fp = fitpars_for(['Dist'])
+    for tag, (lb, rng_d) in gal.items():
+        pd = {'GAL': {'lb_coords': lb}}
+        if rng_d is not None:
+            pd['Dist'] = {'pv_uniform': rng_d}
+        P = prior(fitargs, pd, fp, [False, True, False, False, False])
+        out["gal_" + tag] = np.array([P.priortrans([ui])[0] for ui in u], dtype=float)
+        out["gal_lb_" + tag] = np.array(lb)
+    save("g10_advpriors", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum, "g9": g9_lsf}[k]()
+         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors}[k]()

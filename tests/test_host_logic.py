@@ -86,9 +86,42 @@ def test_lnprior_additional(golden):
     assert P.lnpriorfn([5770.0, 4.4, 0, 0, 10, 3, 28000.0]) == 0.0
 
 
-def test_advanced_priors_are_refused():
-    with pytest.raises(NotImplementedError):
-        prior({'fixedpars': {}}, {'IMF': {'IMF_type': 'Kroupa'}}, fitpars_for(SPEC_PARS), [True, False, False, False, False])
+def test_advanced_priors(golden):
+    """IMF / VROT in lnpriorfn, GAL in the transform of Dist, VTOT / AngDia without effect --
+    against values frozen from the reference (oracle/gen_golden.py g10)."""
+    g = golden("g10_advpriors")
+    fitargs = {'fixedpars': {}}
+    names = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R', 'log(R)', 'Dist', 'Av']
+    base = {'Dist': {'pv_uniform': [10.0, 20000.0]}}
+    cases = {
+        "imf": dict(base, IMF={'IMF_type': 'Kroupa'}),
+        "vrot": dict(base, VROT={}),
+        "imf_vrot_gauss": dict(base, IMF={'IMF_type': 'Kroupa'}, VROT={}, Vrad={'gaussian': [5.0, 30.0]}),
+        "vtot_angdia": dict(base, VTOT={'pmra': 30.0, 'pmdec': -12.0}, AngDia={'gaussian': [0.5, 0.05]}),
+    }
+    for tag, pd in cases.items():
+        P = prior(fitargs, pd, fitpars_for(names), [True, True, False, False, False])
+        ref = g["lnp_" + tag]
+        for got in (np.array([P.lnpriorfn(list(t)) for t in g["theta"]]), P.lnprior_batch(g["theta"])):
+            assert np.array_equal(np.isinf(got), np.isinf(ref)), tag
+            ok = np.isfinite(ref)
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12, atol=1e-300, err_msg=tag)
+    assert np.isinf(g["lnp_imf"]).any() and (g["lnp_vrot"] < -9).any()       # both tails are exercised
+    names_a = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R', 'log(A)', 'Av']
+    P = prior(fitargs, {'VROT': {}}, fitpars_for(names_a), [True, True, False, True, False])
+    np.testing.assert_allclose(P.lnprior_batch(g["theta_a"]), g["lnp_vrot_logA"], rtol=1e-12, atol=1e-300)
+    for tag, rng_d in (("disk", [10.0, 20000.0]), ("pole", [100.0, 100000.0]), ("nodist", None)):
+        pd = {'GAL': {'lb_coords': list(g["gal_lb_" + tag])}}
+        if rng_d is not None:
+            pd['Dist'] = {'pv_uniform': rng_d}
+        P = prior(fitargs, pd, fitpars_for(['Dist']), [False, True, False, False, False])
+        one = np.array([P.priortrans([ui])[0] for ui in g["u"]])
+        np.testing.assert_allclose(one, g["gal_" + tag], rtol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(P.priortrans_batch(g["u"][:, None])[:, 0], g["gal_" + tag], rtol=1e-12)
+    # a spectrum-only fit has no log(R): the mass cannot be formed (KeyError in the reference too)
+    P = prior(fitargs, {'IMF': {'IMF_type': 'Kroupa'}}, fitpars_for(SPEC_PARS), [True, False, False, False, False])
+    with pytest.raises(KeyError):
+        P.lnpriorfn([5770.0, 4.4, 0, 0, 10, 3, 28000.0])
 
 
 def test_fitutils(golden):

@@ -6,12 +6,17 @@ parameters in ``fitpars_i`` order, ``lnpriorfn(pars)`` adds the optional
 'gaussian'/'uniform' priors.  New here: ``priortrans_batch`` / ``lnprior_batch``
 over a [B, ndim] array, which is what the batched sampler calls once per step.
 
-Out of scope: the brutus-derived AdvancedPriors (IMF, GAL,
-VROT, VTOT, AngDia) -- requesting one raises NotImplementedError instead of being
-silently ignored.
+The physically motivated priors (priordict keys IMF, GAL, VROT, VTOT, AngDia;
+fitting/advancedpriors.py) act exactly where the reference lets them: IMF and VROT add
+to ``lnpriorfn`` (prior.py:288-336), GAL replaces the transform of ``Dist``
+(prior.py:231-234).  VTOT sets ``pm_bool`` rather than ``vtot_bool`` in the reference
+(prior.py:66-69), so its branch of ``lnpriorfn`` never runs, and ``AngDia`` is stored but
+never evaluated (prior.py:119-120); both are accepted here with the same (absent) effect.
 """
 import numpy as np
 from scipy.stats import norm, truncnorm, expon, truncexpon
+
+from .advancedpriors import AdvancedPriors
 
 __all__ = ["prior"]
 
@@ -37,24 +42,42 @@ class prior(object):
         self.ndim = len(self.fitpars_i)
         self.spec_bool, self.phot_bool, self.modpoly_bool, self.photscale_bool = runbools[:4]
         self.imf_bool = self.gal_bool = self.vrot_bool = self.vtot_bool = False
+        self.angdia_bool = 'AngDia' in inpriordict
         self.defaultpars = {k: list(v) for k, v in DEFAULT_RANGES.items()}
         self.priordict = {k: {} for k in _KINDS}
         self.additionalpriors = {}
         for name, spec in inpriordict.items():
             if name == 'blaze_coeff':
                 self.polycoefarr = spec
-            elif name in ('IMF', 'GAL', 'VROT', 'VTOT', 'AngDia'):
-                raise NotImplementedError(
-                    "the %r advanced prior (Payne/fitting/advancedpriors.py) is outside this build's "
-                    "hot-path scope" % name)
+            elif name == 'IMF':
+                self.imf = spec['IMF_type']
+                self.imf_bool = True
+            elif name == 'GAL':
+                self.gal_bool = True
+                self.lb_coords = spec['lb_coords']
+                if 'Dist' in inpriordict:
+                    self.mindist, self.maxdist = inpriordict['Dist']['pv_uniform'][:2]
+                else:
+                    self.mindist, self.maxdist = 1.0, 200000.0
+            elif name == 'VROT':
+                self.vrot_bool = True
+            elif name == 'VTOT':
+                self.pmra, self.pmdec = spec['pmra'], spec['pmdec']
+                self.pm_bool = True                                    # (not vtot_bool: prior.py:66-69)
             else:
                 for kind, val in spec.items():
                     if kind.startswith('pv_') and kind[3:] in _KINDS:
                         self.priordict[kind[3:]][name] = val
-                    elif kind == 'fixed':
-                        self.additionalpriors.setdefault(name, {})[kind] = val
                     else:
                         self.additionalpriors.setdefault(name, {})[kind] = val
+        apargs = {}
+        if self.gal_bool:
+            apargs.update(l=self.lb_coords[0], b=self.lb_coords[1], mindist=self.mindist / 1000.0,
+                          maxdist=self.maxdist / 1000.0)
+        if self.angdia_bool:
+            apargs['AngDia'] = inpriordict['AngDia']['gaussian']
+        self.AP = AdvancedPriors(**apargs)
+        self.advanced = self.imf_bool or self.gal_bool or self.vrot_bool
         # like the reference, a 'fixed' entry lands in additionalpriors (prior.py:84-88), which
         # switches off the early return of lnpriorfn; keep that behaviour.
 
@@ -108,7 +131,11 @@ class prior(object):
             for name in _ATM_NAMES:
                 if name in upars:
                     out[name] = self._transform(name, upars[name], ('uniform', 'gaussian', 'tgaussian', 'exp', 'texp'))
-        for name in _ISO_NAMES:
+        iso = list(_ISO_NAMES)
+        if self.gal_bool and 'Dist' in upars:                          # prior.py:231-234
+            out['Dist'] = 1000.0 * self.AP.gal_ppf(upars['Dist'])
+            iso.remove('Dist')
+        for name in iso:
             if name in upars:
                 # NB 'texp' for these parameters indexes a 4-vector with 3 shape arguments in the
                 # reference (prior.py:259-261) and cannot run there; the 3-vector form is used.
@@ -137,22 +164,49 @@ class prior(object):
 
     # ---- additive ln-priors -----------------------------------------------------
     def lnpriorfn(self, pars):
-        """prior.py:274-377 (advanced priors excluded): 0.0 unless 'gaussian' /
-        'uniform' entries were given; -inf outside a 'uniform' box."""
+        """prior.py:274-377: the IMF / VROT terms, plus 'gaussian' / 'uniform' entries if any
+        were given (-inf outside a 'uniform' box)."""
         if isinstance(pars, list):
             parsdict = {pp: vv for pp, vv in zip(self.fitpars_i, pars)}
         else:
             parsdict = pars
         for kk in self.fixedpars.keys():
             parsdict[kk] = self.fixedpars[kk]
+        total = self._advanced(parsdict) if (self.imf_bool or self.vrot_bool) else 0.0
         if len(self.additionalpriors) == 0:
-            return 0.0
-        total = 0.0
+            return total
         if self.spec_bool:
             total = total + self.lnprior_spec(parsdict)
         if self.phot_bool:
             total = total + self.lnprior_phot(parsdict)
         return total
+
+    def _advanced(self, parsdict):
+        """prior.py:286-336.  Masses come from log(g) and log(R) when the fit carries no
+        'initial_Mass'; the two branches use different zero points, as the reference does."""
+        adv = 0.0
+        if self.imf_bool:
+            if 'initial_Mass' not in parsdict:
+                # (a fit without log(R) raises KeyError here, as the reference does)
+                if np.isfinite(parsdict['log(g)']) and np.isfinite(parsdict['log(R)']):
+                    mass = 10.0 ** (parsdict['log(g)'] + 2.0 * parsdict['log(R)'] - 4.437)
+                else:
+                    raise NameError("IMF prior: no mass can be formed from non-finite log(g) / log(R)")
+            else:
+                mass = parsdict['initial_Mass']
+            adv += float(self.AP.imf_lnprior(mass)[0])
+        if self.vrot_bool:
+            mass, eep = parsdict.get('initial_Mass'), parsdict.get('EEP')
+            if mass is None:
+                if 'log(A)' in parsdict:
+                    mass = 1.0
+                elif np.isfinite(parsdict['log(g)']) and np.isfinite(parsdict['log(R)']):
+                    mass = 10.0 ** (parsdict['log(g)'] + 2.0 * parsdict['log(R)'])
+                else:
+                    mass = 1.0
+                eep = 350
+            adv += float(self.AP.vrot_lnprior(vrot=parsdict['Vrot'], mass=mass, eep=eep, logg=parsdict['log(g)']))
+        return adv
 
     def _apply_additional(self, names, values):
         lnp = 0.0
@@ -193,6 +247,6 @@ class prior(object):
     def lnprior_batch(self, theta):
         """theta[B, ndim] -> lnprior[B] (fp64)."""
         theta = np.asarray(theta, dtype=np.float64)
-        if len(self.additionalpriors) == 0:
+        if len(self.additionalpriors) == 0 and not (self.imf_bool or self.vrot_bool):
             return np.zeros(theta.shape[0])
         return np.array([self.lnpriorfn(list(t)) for t in theta], dtype=np.float64)

@@ -47,6 +47,8 @@ class DeviceProposer(object):
                 dim.has_gauss, dim.g_mu, dim.g_sigma = 1, float(add['gaussian'][0]), float(add['gaussian'][1])
             if 'uniform' in add:
                 dim.has_box, dim.box_lo, dim.box_hi = 1, float(add['uniform'][0]), float(add['uniform'][1])
+        if getattr(priorobj, 'advanced', False):
+            raise NotImplementedError("IMF / VROT / GAL priors are evaluated on the host; use the host sampler path")
         if 'Parallax' in priorobj.additionalpriors:
             raise NotImplementedError("a 'Parallax' prior is a derived quantity; use the host sampler path")
         if len(fixed) > _lib.PAYNE_MAX_FIXED:
