@@ -257,3 +257,43 @@ def test_fitpayne_dynamic_sampler_on_the_device(tmp_path):
     assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
     lines = open(inputdict['output']).read().splitlines()
     assert len(lines) == 1 + r.niter
+
+
+def test_evidence_agrees_between_scalar_cpu_and_batched_gpu_likelihoods(tmp_path):
+    """the same fit sampled twice -- the CPU restatement called one
+    theta at a time (the reference's way of driving dynesty) and the batched GPU likelihood
+    with device proposals -- must agree in ln Z and in the posterior means."""
+    from thepayne_amd.fitting.fitstar import FitPayne
+    from thepayne_amd.sampler import NestedSampler
+    from helpers import yst_problem
+    raw, obs, flux, eflux = yst_problem("tiny", H=16, line_depth=0.3)
+    inputdict = {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1',
+        'sampler': {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': 200,
+                    'walks': 20, 'delta_logz_final': 0.1, 'bootstrap': 0, 'flushnum': 500, 'seed': 21},
+        'priordict': synth.demo_priordict(),
+        'output': str(tmp_path / 'gpu.dat'),
+    }
+    F = FitPayne()
+    gpu = F.run(inputdict=inputdict, verbose=False)
+    assert F.proposer is not None
+    rg = gpu.results
+    # the scalar CPU twin: oracle likelihood, host prior object, scalar callables as dynesty would call them
+    OL = O.OracleLikelihood(raw, obs, flux, eflux, F.likeobj.fitpars_i)
+    P = F.priorobj
+    cpu = NestedSampler(lambda v: O.lnprobfn(v, OL, P.lnpriorfn), P.priortrans, F.ndim, nlive=200, bound='multi',
+                        sample='rwalk', walks=20, rstate=np.random.default_rng(22), native=True)
+    cpu.run_nested(dlogz=0.1)
+    rc = cpu.results
+    err = np.hypot(rg.logzerr[-1], rc.logzerr[-1])
+    assert abs(rg.logz[-1] - rc.logz[-1]) < 4 * err + 0.1, (rg.logz[-1], rc.logz[-1], err)
+
+    def moments(s, r):
+        w = s.posterior_weights()
+        m = (w[:, None] * r.samples).sum(0)
+        return m, np.sqrt((w[:, None] * (r.samples - m) ** 2).sum(0))
+    mg, sg = moments(gpu, rg)
+    mc, sc = moments(cpu, rc)
+    assert np.all(np.abs(mg - mc) < 0.5 * np.maximum(sg, sc)), (mg, mc, sg, sc)
+    assert np.all(np.abs(sg / sc - 1.0) < 0.35), (sg, sc)
