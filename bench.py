@@ -284,8 +284,8 @@ def main():
         e2e = sampler_bench.run(args.config, maxcall=250000, nlive=B, walks=25, modes=("device_chunks",))["device_chunks"]
         out["end_to_end"] = {"value": e2e["evals_per_s"], "unit": "likelihood-evals/s", "calls": e2e["calls"],
                              "iterations": e2e["iterations"], "seconds": e2e["seconds"],
-                             "what": "static nested sampler, %d live points, rwalk x25 on the device, multi-ellipsoid "
-                                     "bound, dead points consumed in bulk" % B}
+                             "what": "static nested sampler, %d live points, rwalk x25 on the device, bound='multi' "
+                                     "(one enlarged ellipsoid in this driver), dead points consumed in bulk" % B}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
