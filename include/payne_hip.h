@@ -282,6 +282,14 @@ int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, in
                       void* stream);
 int payne_rwalk_step(payne_sampler* s, int w);
 
+/* `begin` for a multi-ellipsoid bound (dynesty bound='multi' as fitstar.py:314 passes it): axes is HOST fp64
+ * [n_ell][ndim][ndim], ell is HOST int32 [K] naming the ellipsoid whose axes shape chain k's steps (NULL with
+ * n_ell == 1 is payne_rwalk_begin). */
+#define PAYNE_MAX_ELL 32
+int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
+                          int n_ell, const int* ell, double scale, double loglstar, int walks,
+                          unsigned long long seed, int* nacc, int* ncall, void* stream);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

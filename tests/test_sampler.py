@@ -190,3 +190,52 @@ def test_ns_consume_stop_conditions():
     assert (m, stop) == (0, L.NS_CONVERGED)
     # volumes shrink by ln((n+1)/n) per dead point
     assert abs(st.logvol + (st.it - 1) * np.log((n + 1.0) / n)) < 1e-12
+
+
+# ---- bound='multi': two well-separated modes -----------------------------------------------------
+C_A, C_B = np.array([0.25, 0.3, 0.5]), np.array([0.75, 0.7, 0.5])
+LOGZ_TWO = LOGZ_TRUE + np.log(2.0)
+
+
+def loglike_two_modes(V):
+    a = -0.5 * np.sum(((V - C_A) / SIG) ** 2, axis=1)
+    b = -0.5 * np.sum(((V - C_B) / SIG) ** 2, axis=1)
+    return np.logaddexp(a, b)
+
+
+@pytest.mark.parametrize("method", ["unif", "rwalk"])
+def test_multi_ellipsoid_bound_on_two_modes(method):
+    runs = {}
+    for bound in ("single", "multi"):
+        s = NestedSampler(loglike_two_modes, ptform_batch, NDIM, nlive=400, bound=bound, sample=method, walks=20,
+                          batched=True, rstate=np.random.default_rng(12), queue_size=400)
+        nell = []
+        for _ in s.sample(dlogz=0.05):
+            nell.append(len(s._ells))
+        for _ in s.add_live_points():
+            pass
+        runs[bound] = (s, max(nell))
+    s, nmax = runs["multi"]
+    assert nmax >= 2 and runs["single"][1] == 1
+    r = s.results
+    assert abs(r.logz[-1] - LOGZ_TWO) < max(0.15, 4 * r.logzerr[-1]), (r.logz[-1], LOGZ_TWO, r.logzerr[-1])
+    w = s.posterior_weights()
+    in_a = np.linalg.norm(r.samples - C_A, axis=1) < np.linalg.norm(r.samples - C_B, axis=1)
+    assert abs(w[in_a].sum() - 0.5) < 0.1                               # both modes carry half the mass
+    if method == "unif":                                                # the union wastes far fewer draws
+        assert runs["multi"][0].ncall < 0.6 * runs["single"][0].ncall
+
+
+def test_ellipsoid_decomposition_is_a_cover():
+    from thepayne_amd.sampler.nested import _Ell, _split_ellipsoids
+    rng = np.random.default_rng(3)
+    u = np.concatenate([C_A + 0.02 * rng.standard_normal((150, 3)), C_B + 0.03 * rng.standard_normal((250, 3))])
+    whole = _Ell(u, 1.25)
+    ells = _split_ellipsoids(u, whole, 1.25, [32])
+    assert len(ells) == 2
+    covered = np.any([e.dist2(u) <= 1.0 for e in ells], axis=0)
+    assert covered.all()
+    assert np.logaddexp(ells[0].logvol, ells[1].logvol) < whole.logvol + np.log(0.5)
+    # one compact cloud is left alone
+    one = _Ell(u[:150], 1.25)
+    assert len(_split_ellipsoids(u[:150], one, 1.25, [32])) == 1

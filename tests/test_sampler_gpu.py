@@ -297,3 +297,63 @@ def test_evidence_agrees_between_scalar_cpu_and_batched_gpu_likelihoods(tmp_path
     mc, sc = moments(cpu, rc)
     assert np.all(np.abs(mg - mc) < 0.5 * np.maximum(sg, sc)), (mg, mc, sg, sc)
     assert np.all(np.abs(sg / sc - 1.0) < 0.35), (sg, sc)
+
+
+def test_device_rwalk_with_one_ellipsoid_per_chain(tmp_path):
+    """payne_rwalk_begin_ell (bound='multi'): every chain steps in the metric of its own ellipsoid; with a
+    single ellipsoid the call is payne_rwalk_begin."""
+    L, P, _ = _fit_objects(tmp_path, photscale=True)
+    prop = _proposer(L, P, k_max=64)
+    nd = L.ndim
+    rng = np.random.default_rng(13)
+    A = np.stack([np.tril(rng.normal(size=(nd, nd))) * 0.01 + 0.02 * np.eye(nd), 0.002 * np.eye(nd),
+                  np.diag(np.linspace(0.001, 0.03, nd))])
+    ell = rng.integers(0, 3, size=64).astype(np.int32)
+    U0 = np.full((64, nd), 0.5)
+    V0, lp0 = prop.lnprob_u(U0)
+    Z = [[], [], []]
+    for rep in range(30):
+        U, V, lp, nacc, ncall = prop.rwalk(U0, V0, lp0, A, 1.0, -np.inf, 1, seed=500 + rep, ell=ell)
+        fin = np.isfinite(lp) & (nacc == 1)
+        for e in range(3):
+            sel = fin & (ell == e)
+            Z[e].append(np.linalg.solve(A[e], (U - U0)[sel].T).T)
+    for e in range(3):
+        z = np.concatenate(Z[e])
+        r = np.linalg.norm(z, axis=1)
+        assert len(z) > 300 and r.max() <= 1.0 + 1e-9
+        assert abs((r ** nd).mean() - 0.5) < 0.06, e                        # uniform in its OWN ellipsoid
+    # a stack of one matrix, or a plain matrix, is the single-ellipsoid walk
+    a = prop.rwalk(U0, V0, lp0, A[:1], 1.0, -np.inf, 3, seed=77)
+    b = prop.rwalk(U0, V0, lp0, A[0], 1.0, -np.inf, 3, seed=77)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    with pytest.raises(RuntimeError):
+        prop.rwalk(U0, V0, lp0, A, 1.0, -np.inf, 1, seed=1, ell=np.full(64, 3, dtype=np.int32))
+    prop.close()
+
+
+def test_multi_ellipsoid_fit_on_the_device(tmp_path):
+    """A fit whose live points split into two clouds early on (two priors boxes are not needed: Vrad wide
+    enough for the cross-correlation's side lobes) still converges to the truth with bound='multi'."""
+    from thepayne_amd.fitting.fitstar import FitPayne
+    from helpers import yst_problem
+    raw, obs, flux, eflux = yst_problem("small", H=64, line_depth=0.3)
+    pd = synth.demo_priordict()
+    pd['Vrad'] = {'pv_uniform': [-60.0, 80.0]}
+    inputdict = {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1',
+        'sampler': {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': 256,
+                    'walks': 20, 'delta_logz_final': 0.5, 'bootstrap': 0, 'flushnum': 500, 'seed': 4},
+        'priordict': pd, 'output': str(tmp_path / 'fit.dat'),
+    }
+    F = FitPayne()
+    sampler = F.run(inputdict=inputdict, verbose=False)
+    assert F.proposer is not None
+    r = sampler.results
+    w = sampler.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)

@@ -2569,7 +2569,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, int K, double* u, double* v, double* lnprob, int* nacc, int* ncall,
                                    double* u_prop, double* v_prop, double* lnprior_prop, int* inside,
-                                   const double* lnl_prop, double* rows, const double* axes, double scale,
+                                   const double* lnl_prop, double* rows, const double* axes, const int* ell, double scale,
                                    double loglstar, unsigned long long seed, int step, int settle, int propose) {
   const int lane = threadIdx.x & 63;
   const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -2598,10 +2598,11 @@ __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, int K, 
   }
   const double n2 = wave_sum(z * z);
   const double rad = pow(u01(seed, c, step, 128), 1.0 / (double)nd) / sqrt(n2);
+  const double* ax = axes + (ell ? (size_t)ell[c] * nd * nd : 0);   // this chain's ellipsoid (bound='multi')
   double sdot = 0.0;
   for (int e = 0; e < nd; ++e) {
     const double ze = __shfl(z, e);
-    sdot = fma(axes[dl * nd + e], ze, sdot);
+    sdot = fma(ax[dl * nd + e], ze, sdot);
   }
   const double up = uc + scale * rad * sdot;
   const bool in = __ballot(act && !((up > 0.0) && (up < 1.0))) == 0ull;
@@ -2626,9 +2627,10 @@ struct payne_sampler {
   int k_max = 0;
   double *u_prop = nullptr, *v_prop = nullptr, *lnprior = nullptr, *lnl = nullptr, *rows = nullptr, *axes = nullptr;
   int* inside = nullptr;
+  int* ell = nullptr;                     // per-chain ellipsoid index of the walk in progress
   std::vector<void*> owned;
   // a walk in progress (payne_rwalk_begin / payne_rwalk_step)
-  struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; } run{};
+  struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; bool multi; } run{};
 };
 
 extern "C" void payne_sampler_destroy(payne_sampler* s) {
@@ -2670,8 +2672,8 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
   int rc;
   if ((rc = alloc(K * nd * 8, (void**)&s->u_prop)) || (rc = alloc(K * nd * 8, (void**)&s->v_prop)) ||
       (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
-      (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc(nd * nd * 8, (void**)&s->axes)) ||
-      (rc = alloc(K * 4, (void**)&s->inside))) {
+      (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
+      (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell))) {
     payne_sampler_destroy(s);
     return rc;
   }
@@ -2717,19 +2719,29 @@ extern "C" int payne_lnprob_u_batch(payne_sampler* s, const double* u, int K, do
 // The walk in two parts, so that a caller can interleave the steps of several samplers (one context and
 // one HIP stream each) from one host thread: two independent batches in flight fill the idle time a single
 // chain of dependent launches leaves (13.6 M against 10.6 M evaluations/s at 512 x 4096 pixels).
-extern "C" int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
-                                 double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
-                                 void* stream) {
+extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
+                                     int n_ell, const int* ell, double scale, double loglstar, int walks,
+                                     unsigned long long seed, int* nacc, int* ncall, void* stream) {
   int rc = sampler_check(s, u, K, v);
   if (rc) return rc;
   if (!lnprob || !axes || !nacc || !ncall || walks <= 0) return fail(s->ctx, PAYNE_E_INVALID, "bad rwalk arguments");
+  if (n_ell < 1 || n_ell > PAYNE_MAX_ELL || (n_ell > 1 && !ell)) return fail(s->ctx, PAYNE_E_INVALID, "bad ellipsoid list");
+  if (ell)
+    for (int i = 0; i < K; ++i)
+      if (ell[i] < 0 || ell[i] >= n_ell) return fail(s->ctx, PAYNE_E_INVALID, "ellipsoid index out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nd = s->sd.ndim;
-  HIPCHK(s->ctx, hipMemcpyAsync(s->axes, axes, (size_t)nd * nd * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(s->ctx, hipMemcpyAsync(s->axes, axes, (size_t)n_ell * nd * nd * 8, hipMemcpyHostToDevice, st));
+  if (ell) HIPCHK(s->ctx, hipMemcpyAsync(s->ell, ell, (size_t)K * 4, hipMemcpyHostToDevice, st));
   HIPCHK(s->ctx, hipMemsetAsync(nacc, 0, (size_t)K * 4, st));
   HIPCHK(s->ctx, hipMemsetAsync(ncall, 0, (size_t)K * 4, st));
-  s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true};
+  s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr};
   return PAYNE_OK;
+}
+extern "C" int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
+                                 double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
+                                 void* stream) {
+  return payne_rwalk_begin_ell(s, u, v, lnprob, K, axes, 1, nullptr, scale, loglstar, walks, seed, nacc, ncall, stream);
 }
 // step w = 0 .. walks: settle proposal w-1, draw proposal w and evaluate it (the last step only settles)
 extern "C" int payne_rwalk_step(payne_sampler* s, int w) {
@@ -2739,7 +2751,8 @@ extern "C" int payne_rwalk_step(payne_sampler* s, int w) {
   hipStream_t st = reinterpret_cast<hipStream_t>(r.stream);
   const dim3 grid((r.K + 3) / 4), block(256);                  // one wave per chain
   hipLaunchKernelGGL(payne_rwalk_kernel, grid, block, 0, st, s->sd, r.K, r.u, r.v, r.lnprob, r.nacc, r.ncall, s->u_prop,
-                     s->v_prop, s->lnprior, s->inside, s->lnl, s->rows, s->axes, r.scale, r.loglstar, r.seed, w,
+                     s->v_prop, s->lnprior, s->inside, s->lnl, s->rows, s->axes, r.multi ? s->ell : (const int*)nullptr, r.scale,
+                     r.loglstar, r.seed, w,
                      w > 0 ? 1 : 0, w < r.walks ? 1 : 0);
   int rc = PAYNE_OK;
   if (w < r.walks) rc = payne_lnlike_batch(s->ctx, s->rows, r.K, s->lnl, r.stream);

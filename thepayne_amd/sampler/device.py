@@ -133,16 +133,17 @@ class DeviceProposer(object):
             Ls.append(self._lp[:K].cpu().numpy())
         return np.concatenate(Vs), np.concatenate(Ls)
 
-    def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed):
-        """K lock-step random-walk chains of `walks` steps under lnprob > loglstar.
+    def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed, ell=None):
+        """K lock-step random-walk chains of `walks` steps under lnprob > loglstar.  `axes` is one
+        [ndim, ndim] matrix, or [n_ell, ndim, ndim] with `ell[K]` naming each chain's ellipsoid.
         Returns (U, V, lnprob, nacc, ncall) as numpy arrays.  One packed pinned transfer each way."""
-        self.rwalk_begin(U, V, lnprob, axes, scale, loglstar, walks, seed)
+        self.rwalk_begin(U, V, lnprob, axes, scale, loglstar, walks, seed, ell=ell)
         for w in range(int(walks) + 1):
             self.rwalk_step(w)
         return self.rwalk_finish()
 
     # the same in three parts (MultiPopProposer interleaves the steps of several populations)
-    def rwalk_begin(self, U, V, lnprob, axes, scale, loglstar, walks, seed, stream=None):
+    def rwalk_begin(self, U, V, lnprob, axes, scale, loglstar, walks, seed, stream=None, ell=None):
         K, nd = len(U), self.ndim
         if K > self.k_max:
             raise ValueError("K > k_max")
@@ -164,12 +165,20 @@ class DeviceProposer(object):
             d[:n].copy_(self._pack_h[:n], non_blocking=True)
         pu, pv, pl = d.data_ptr(), d.data_ptr() + 8 * K * nd, d.data_ptr() + 16 * K * nd
         ax = np.ascontiguousarray(axes, dtype=np.float64)
-        rc = self.lib.payne_rwalk_begin(self._handle, pu, pv, pl, K, C.cast(ax.ctypes.data, C.POINTER(C.c_double)),
-                                        float(scale), float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                        self._ipack_d.data_ptr(), self._ipack_d.data_ptr() + 4 * K,
-                                        C.c_void_p(self._run_stream.cuda_stream))
+        n_ell, ell_p = 1, None
+        if ax.ndim == 3:
+            n_ell = ax.shape[0]
+            if n_ell > 1:
+                self._ell_h = np.ascontiguousarray(ell, dtype=np.int32)
+                if self._ell_h.shape != (K,):
+                    raise ValueError("ell must name one ellipsoid per chain")
+                ell_p = self._ell_h.ctypes.data
+        rc = self.lib.payne_rwalk_begin_ell(self._handle, pu, pv, pl, K, ax.ctypes.data, n_ell, ell_p,
+                                            float(scale), float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                            self._ipack_d.data_ptr(), self._ipack_d.data_ptr() + 4 * K,
+                                            C.c_void_p(self._run_stream.cuda_stream))
         if rc != 0:
-            self.eng._err(rc, "payne_rwalk_begin")
+            self.eng._err(rc, "payne_rwalk_begin_ell")
         self._run_K = K
 
     def rwalk_step(self, w):
@@ -226,7 +235,7 @@ class MultiPopProposer(object):
     def lnprob_u(self, U):
         return self.pops[0].lnprob_u(U)
 
-    def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed):
+    def rwalk(self, U, V, lnprob, axes, scale, loglstar, walks, seed, ell=None):
         K, n = len(U), len(self.pops)
         if K > self.k_max:
             raise ValueError("K > n_pop * k_max")
@@ -236,7 +245,8 @@ class MultiPopProposer(object):
             lo, hi = i * per, min(K, (i + 1) * per)
             if hi > lo:
                 p.rwalk_begin(U[lo:hi], V[lo:hi], lnprob[lo:hi], axes, scale, loglstar, walks,
-                              (int(seed) + 0x9E3779B9 * i) & 0xFFFFFFFFFFFFFFFF, stream=self._streams[i])
+                              (int(seed) + 0x9E3779B9 * i) & 0xFFFFFFFFFFFFFFFF, stream=self._streams[i],
+                              ell=None if ell is None else ell[lo:hi])
                 live.append(p)
         for w in range(int(walks) + 1):                 # one step of every population, round robin
             for p in live:

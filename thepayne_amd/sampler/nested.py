@@ -18,11 +18,13 @@ Algorithm (Skilling 2004/2006 static nested sampling; trapezoid evidence weights
   * nlive points drawn from the unit cube; at iteration i the worst live point
     (loglstar) dies with ln X_i = -i ln((nlive+1)/nlive) and is replaced by a point
     drawn from the prior restricted to logl > loglstar;
-  * replacement proposals: 'unif' = uniform in the (enlarged) bounding ellipsoid of the
-    live points in the unit cube ('single'/'multi': one ellipsoid; 'none': the cube);
+  * replacement proposals: 'unif' = uniform in the (enlarged) bounding ellipsoid(s) of the
+    live points in the unit cube ('single': one ellipsoid; 'multi': the live points are split
+    recursively by 2-means while the children's ellipsoids hold less than half the parent's
+    volume, proposals are uniform in the union; 'none': the cube);
     'rwalk' = `walks` Metropolis steps started from random live points, steps drawn
-    uniformly from an ellipsoid with the live points' covariance scaled by an adaptive
-    factor (target acceptance 0.5);
+    uniformly from an ellipsoid with the covariance of the start point's cluster scaled by
+    an adaptive factor (target acceptance 0.5);
   * stop when ln(1 + L_max X / Z) < dlogz, then ``add_live_points`` closes the integral.
 """
 import ctypes as C
@@ -41,6 +43,69 @@ def _unit_ball(rng, n, ndim):
     z = rng.standard_normal((n, ndim))
     z /= np.linalg.norm(z, axis=1)[:, None]
     return z * rng.uniform(size=(n, 1)) ** (1.0 / ndim)
+
+
+class _Ell(object):
+    """Bounding ellipsoid of a set of unit-cube points: {ctr + axes z, |z| <= 1}."""
+    __slots__ = ("ctr", "axes", "axes_unit", "ainv", "logvol", "_cov")
+
+    def __init__(self, u, enlarge):
+        n, nd = u.shape
+        self.ctr = u.mean(axis=0)
+        dev = u - self.ctr
+        cov = (dev.T @ dev) / max(1, n - 1)
+        cov += 1e-14 * np.eye(nd) * max(1e-300, np.trace(cov) / nd)
+        try:
+            L = np.linalg.cholesky(cov)
+            logdet = float(np.log(np.diagonal(L)).sum())
+        except np.linalg.LinAlgError:
+            w, Q = np.linalg.eigh(cov)
+            L = Q * np.sqrt(np.clip(w, 1e-30, None))
+            logdet = float(np.linalg.slogdet(L)[1])
+        linv = np.linalg.inv(L)
+        r2max = ((dev @ linv.T) ** 2).sum(axis=1).max()      # smallest scaled ellipsoid holding every point
+        f = math.sqrt(r2max) * enlarge ** (1.0 / nd)
+        self.axes = L * f
+        self.axes_unit = L * math.sqrt(nd + 2.0)              # 1-sigma-ish metric for rwalk steps
+        self.ainv = linv / f
+        self.logvol = logdet + nd * math.log(f)               # up to the unit ball's volume
+        self._cov = cov
+
+    def dist2(self, U):
+        """Squared radius of the points in this ellipsoid's coordinates (<= 1 inside)."""
+        return (((U - self.ctr) @ self.ainv.T) ** 2).sum(axis=1)
+
+
+def _split_ellipsoids(u, ell, enlarge, budget, vol_dec=0.5):
+    """Recursive 2-means decomposition (the rule dynesty's MultiEllipsoid applies, vol_dec = 0.5):
+    keep a split while the children hold less than vol_dec of the parent's volume."""
+    n, nd = u.shape
+    if n < 4 * nd + 2 or budget[0] <= 1:
+        return [ell]
+    # 2-means on the points themselves (unit-cube coordinates), started from the two halves along the
+    # direction of largest spread; the assignment step is one matrix-vector product
+    w = u - ell.ctr
+    _, vec = np.linalg.eigh(ell._cov)
+    lab = (w @ vec[:, -1]) > 0
+    for _ in range(8):
+        if lab.all() or not lab.any():
+            return [ell]
+        c0, c1 = w[~lab].mean(axis=0), w[lab].mean(axis=0)
+        new = (w @ (c1 - c0)) > 0.5 * (c1 @ c1 - c0 @ c0)
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    n1 = int(lab.sum())
+    if min(n1, n - n1) < 2 * nd + 1:
+        return [ell]
+    e0, e1 = _Ell(u[~lab], enlarge), _Ell(u[lab], enlarge)
+    if np.logaddexp(e0.logvol, e1.logvol) >= ell.logvol + math.log(vol_dec):
+        return [ell]
+    budget[0] -= 1
+    return _split_ellipsoids(u[~lab], e0, enlarge, budget, vol_dec) + _split_ellipsoids(u[lab], e1, enlarge, budget, vol_dec)
+
+
+MAX_ELL = 32                                                    # PAYNE_MAX_ELL of include/payne_hip.h
 
 
 class NestedSampler(object):
@@ -102,6 +167,8 @@ class NestedSampler(object):
             self._lib = _lib.load()
             self._L = _lib
         self._axes = None
+        self._ells = []
+        self._split_wait = 0
         self.nbound = 1
         self.update_interval = int(update_interval) if update_interval and update_interval >= 1 else max(1, int(0.6 * self.nlive))
         # saved run
@@ -123,18 +190,16 @@ class NestedSampler(object):
             self._axes = None
             return
         u = self.live_u
-        self._ctr = u.mean(axis=0)
-        cov = np.cov(u, rowvar=False).reshape(self.ndim, self.ndim)
-        cov += 1e-14 * np.eye(self.ndim) * max(1e-300, np.trace(cov) / self.ndim)
-        try:
-            L = np.linalg.cholesky(cov)
-        except np.linalg.LinAlgError:
-            w, Q = np.linalg.eigh(cov)
-            L = Q * np.sqrt(np.clip(w, 1e-30, None))
-        d = np.linalg.solve(L, (u - self._ctr).T)
-        r2max = (d ** 2).sum(axis=0).max()                   # smallest scaled ellipsoid holding every live point
-        self._axes = L * math.sqrt(r2max) * self.enlarge ** (1.0 / self.ndim)
-        self._axes_unit = L * math.sqrt(self.ndim + 2.0)      # 1-sigma-ish metric for rwalk steps
+        whole = _Ell(u, self.enlarge)
+        self._ctr, self._axes, self._axes_unit = whole.ctr, whole.axes, whole.axes_unit
+        self._ells = [whole]
+        if self.bound == 'multi':
+            # the decomposition is tried at every update while it finds several ellipsoids, at every
+            # fourth one while the live points keep forming a single cloud
+            self._split_wait -= 1
+            if self._split_wait <= 0:
+                self._ells = _split_ellipsoids(u, whole, self.enlarge, [MAX_ELL])
+                self._split_wait = 1 if len(self._ells) > 1 else 4
         self.nbound += 1
         self._since_update = 0
 
@@ -160,8 +225,16 @@ class NestedSampler(object):
         if self.method == 'unif':
             if self.bound == 'none':
                 U = rng.uniform(size=(K, nd))
-            else:
+            elif len(self._ells) == 1:
                 U = self._ctr + _unit_ball(rng, K, nd) @ self._axes.T
+            else:                          # uniform in the union: volume-weighted choice, 1/q thinning of overlaps
+                E = self._ells
+                lv = np.array([e.logvol for e in E])
+                pick = rng.choice(len(E), size=K, p=np.exp(lv - lv.max()) / np.exp(lv - lv.max()).sum())
+                ball = _unit_ball(rng, K, nd)
+                U = np.stack([e.ctr for e in E])[pick] + np.einsum('kij,kj->ki', np.stack([e.axes for e in E])[pick], ball)
+                q = np.sum([e.dist2(U) <= 1.0 for e in E], axis=0)
+                U = U[rng.uniform(size=K) * np.maximum(q, 1) < 1.0]
             inside = np.all((U > 0.0) & (U < 1.0), axis=1)
             U = U[inside]
             nin = len(U)
@@ -181,15 +254,25 @@ class NestedSampler(object):
         # rwalk: K lock-step chains
         start = rng.integers(0, self.nlive, size=K)
         U, V, ll = self.live_u[start].copy(), self.live_v[start].copy(), self.live_logl[start].copy()
+        ell, axes = None, self._axes_unit
+        if len(self._ells) > 1:            # each chain steps in the metric of an ellipsoid holding its start point
+            d2 = np.stack([e.dist2(U) for e in self._ells])                     # [n_ell, K]
+            jitter = rng.uniform(size=d2.shape)
+            ell = np.where((d2 <= 1.0).any(axis=0), np.argmax((d2 <= 1.0) * (1.0 + jitter), axis=0), np.argmin(d2, axis=0))
+            axes = np.stack([e.axes_unit for e in self._ells])
         if self.proposer is not None:      # all `walks` steps of all K chains in one device call
-            U, V, ll, nacc, ncalls = self.proposer.rwalk(U, V, ll, self._axes_unit, self.scale, lstar, self.walks,
-                                                        int(rng.integers(0, 2 ** 62)))
+            kw = {} if ell is None else {"ell": ell}
+            U, V, ll, nacc, ncalls = self.proposer.rwalk(U, V, ll, axes, self.scale, lstar, self.walks,
+                                                        int(rng.integers(0, 2 ** 62)), **kw)
             ll = np.where(np.isnan(ll), -np.inf, ll)
         else:
             nacc = np.zeros(K, dtype=np.int64)
             ncalls = np.zeros(K, dtype=np.int64)
             for _ in range(self.walks):
-                prop = U + self.scale * (_unit_ball(rng, K, nd) @ self._axes_unit.T)
+                if ell is None:
+                    prop = U + self.scale * (_unit_ball(rng, K, nd) @ axes.T)
+                else:
+                    prop = U + self.scale * np.einsum('kij,kj->ki', axes[ell], _unit_ball(rng, K, nd))
                 inside = np.all((prop > 0.0) & (prop < 1.0), axis=1)
                 if not inside.any():
                     continue
