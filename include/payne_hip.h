@@ -273,6 +273,14 @@ int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_v, double* 
                      double dlogz, long long max_emit, double logl_max, payne_ns_dead* out, int cap,
                      int* consumed, int* stop);
 
+/* Bounding ellipsoid(s) of n live points u[n][ndim] (unit cube): dynesty's bound='single' (multi = 0) or
+ * 'multi' (recursive 2-means split while the children hold less than half the parent's volume, at most
+ * max_ell <= PAYNE_MAX_ELL pieces).  Outputs, one entry per ellipsoid {ctr + axes z, |z| <= 1}: ctr [.][ndim],
+ * axes / axes_unit (the cluster's Cholesky factor scaled to hold its points, resp. by sqrt(ndim+2)) / ainv
+ * (inverse of axes) [.][ndim][ndim] row-major, logvol [.] (up to the unit ball's volume); *n_ell = count. */
+int payne_ns_bound(const double* u, int n, int ndim, double enlarge, int multi, int max_ell, double* ctr,
+                   double* axes, double* axes_unit, double* ainv, double* logvol, int* n_ell);
+
 /* payne_rwalk_batch in two parts: `begin` takes the same arguments and enqueues the set-up, `step(s, w)` for
  * w = 0 .. walks enqueues one step (settle proposal w-1, draw and evaluate proposal w; the last only settles).
  * A caller driving several samplers (one context and one stream each) interleaves their steps from one host

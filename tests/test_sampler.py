@@ -91,6 +91,7 @@ def test_native_bookkeeping_matches_python_loop():
     for native in (True, False):
         S = NestedSampler(ll, lambda U: U, nd, nlive=64, bound='single', sample='rwalk', walks=10, batched=True,
                           queue_size=64, rstate=np.random.default_rng(5), native=native)
+        S._native_bound = False            # same ellipsoids to the last bit, so that the chains are the same
         tuples = list(S.sample(dlogz=0.05, maxiter=700))
         tuples += list(S.add_live_points())
         runs.append((S, tuples))
@@ -239,3 +240,37 @@ def test_ellipsoid_decomposition_is_a_cover():
     # one compact cloud is left alone
     one = _Ell(u[:150], 1.25)
     assert len(_split_ellipsoids(u[:150], one, 1.25, [32])) == 1
+
+
+def test_native_bound_matches_python_bound():
+    """payne_ns_bound (C++) against _Ell / _split_ellipsoids: same ellipsoids for one cloud and for two."""
+    import ctypes as C
+    from thepayne_amd import _lib
+    from thepayne_amd.sampler.nested import _Ell, _split_ellipsoids
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    one = 0.5 + 0.02 * rng.standard_normal((300, 5)) @ np.diag([1, 3, 0.5, 2, 1.0])
+    two = np.concatenate([C_A + 0.02 * rng.standard_normal((150, 3)), C_B + 0.03 * rng.standard_normal((250, 3))])
+    for u, multi, expect in ((one, 0, 1), (one, 1, 1), (two, 1, 2), (two, 0, 1)):
+        u = np.ascontiguousarray(u)
+        n, nd = u.shape
+        ctr, lv = np.empty((32, nd)), np.empty(32)
+        ax, au, ai = np.empty((32, nd, nd)), np.empty((32, nd, nd)), np.empty((32, nd, nd))
+        ne = C.c_int(0)
+        rc = lib.payne_ns_bound(u.ctypes.data, n, nd, 1.25, multi, 32, ctr.ctypes.data, ax.ctypes.data, au.ctypes.data,
+                                ai.ctypes.data, lv.ctypes.data, C.byref(ne))
+        assert rc == 0 and ne.value == expect
+        whole = _Ell(u, 1.25)
+        ref = _split_ellipsoids(u, whole, 1.25, [32]) if multi else [whole]
+        assert len(ref) == expect
+        order = np.argsort([e.ctr[0] for e in ref])
+        mine = np.argsort(ctr[:expect, 0])
+        for i, j in zip(order, mine):
+            e = ref[i]
+            np.testing.assert_allclose(ctr[j], e.ctr, rtol=1e-12)
+            np.testing.assert_allclose(ax[j], e.axes, rtol=1e-9, atol=1e-15)
+            np.testing.assert_allclose(au[j], e.axes_unit, rtol=1e-9, atol=1e-15)
+            np.testing.assert_allclose(ai[j], e.ainv, rtol=1e-8, atol=1e-9)
+            assert abs(lv[j] - e.logvol) < 1e-9
+            assert np.all((((u - ctr[j]) @ ai[j].T) ** 2).sum(axis=1)[e.dist2(u) <= 1.0] <= 1.0 + 1e-9)
+    assert lib.payne_ns_bound(None, 10, 3, 1.25, 0, 1, None, None, None, None, None, None) < 0

@@ -15,6 +15,8 @@
 #pragma once
 #include <math.h>
 
+#include <vector>
+
 #include "../../include/payne_hip.h"
 
 namespace payne_ns {
@@ -93,4 +95,175 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
   }
   *consumed = qpos;
   return emitted;
+}
+
+// ---- bounding ellipsoids of the live points ------------------------------------------------
+// dynesty's bound='single' / 'multi' as the reference requests them (fitstar.py:314): the smallest
+// scaled covariance ellipsoid holding every live point (unit-cube coordinates), enlarged in volume;
+// for 'multi' the cloud is split recursively by 2-means while the children's ellipsoids hold less than
+// half the parent's volume.  Same arithmetic as thepayne_amd/sampler/nested.py (_Ell, _split_ellipsoids);
+// here because one fit costs ~0.1 ms in numpy and a decomposition needs a dozen of them per update.
+namespace payne_ns {
+
+struct Ell {
+  std::vector<double> ctr, L, Linv, cov;   // L lower-triangular Cholesky factor of cov, row-major [nd][nd]
+  double f = 1.0, logvol = 0.0;
+};
+
+inline bool cholesky(const std::vector<double>& a, int nd, std::vector<double>& L) {
+  L.assign((size_t)nd * nd, 0.0);
+  for (int i = 0; i < nd; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double sum = a[(size_t)i * nd + j];
+      for (int k = 0; k < j; ++k) sum -= L[(size_t)i * nd + k] * L[(size_t)j * nd + k];
+      if (i == j) {
+        if (!(sum > 0.0)) return false;
+        L[(size_t)i * nd + i] = sqrt(sum);
+      } else {
+        L[(size_t)i * nd + j] = sum / L[(size_t)j * nd + j];
+      }
+    }
+  return true;
+}
+
+inline bool fit_ell(const double* u, const int* idx, int n, int nd, double enlarge, Ell& e) {
+  e.ctr.assign(nd, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int d = 0; d < nd; ++d) e.ctr[d] += u[(size_t)idx[i] * nd + d];
+  for (int d = 0; d < nd; ++d) e.ctr[d] /= n;
+  e.cov.assign((size_t)nd * nd, 0.0);
+  std::vector<double> dev(nd);
+  for (int i = 0; i < n; ++i) {
+    for (int d = 0; d < nd; ++d) dev[d] = u[(size_t)idx[i] * nd + d] - e.ctr[d];
+    for (int a = 0; a < nd; ++a)
+      for (int b = 0; b <= a; ++b) e.cov[(size_t)a * nd + b] += dev[a] * dev[b];
+  }
+  double trace = 0.0;
+  for (int a = 0; a < nd; ++a) {
+    for (int b = 0; b <= a; ++b) { e.cov[(size_t)a * nd + b] /= (n > 1 ? n - 1 : 1); e.cov[(size_t)b * nd + a] = e.cov[(size_t)a * nd + b]; }
+    trace += e.cov[(size_t)a * nd + a];
+  }
+  double ridge = 1e-14 * fmax(1e-300, trace / nd);
+  bool ok = false;
+  for (int attempt = 0; attempt < 6 && !ok; ++attempt, ridge *= 1e3) {   // a degenerate cloud gets a larger ridge
+    std::vector<double> c = e.cov;
+    for (int a = 0; a < nd; ++a) c[(size_t)a * nd + a] += ridge;
+    ok = cholesky(c, nd, e.L);
+    if (ok) e.cov = c;
+  }
+  if (!ok) return false;
+  // inverse of the triangular factor by forward substitution
+  e.Linv.assign((size_t)nd * nd, 0.0);
+  for (int c = 0; c < nd; ++c)
+    for (int r = c; r < nd; ++r) {
+      double sum = (r == c) ? 1.0 : 0.0;
+      for (int k = c; k < r; ++k) sum -= e.L[(size_t)r * nd + k] * e.Linv[(size_t)k * nd + c];
+      e.Linv[(size_t)r * nd + c] = sum / e.L[(size_t)r * nd + r];
+    }
+  double r2max = 0.0, logdet = 0.0;
+  for (int i = 0; i < n; ++i) {
+    for (int d = 0; d < nd; ++d) dev[d] = u[(size_t)idx[i] * nd + d] - e.ctr[d];
+    double r2 = 0.0;
+    for (int r = 0; r < nd; ++r) {
+      double z = 0.0;
+      for (int k = 0; k <= r; ++k) z += e.Linv[(size_t)r * nd + k] * dev[k];
+      r2 += z * z;
+    }
+    r2max = r2 > r2max ? r2 : r2max;
+  }
+  for (int d = 0; d < nd; ++d) logdet += log(e.L[(size_t)d * nd + d]);
+  e.f = sqrt(r2max) * pow(enlarge, 1.0 / nd);
+  e.logvol = logdet + nd * log(e.f);
+  return true;
+}
+
+inline void split_ell(const double* u, const std::vector<int>& idx, int nd, double enlarge, const Ell& ell, int& budget,
+                      double vol_dec, std::vector<Ell>& out) {
+  const int n = (int)idx.size();
+  if (n < 4 * nd + 2 || budget <= 1) { out.push_back(ell); return; }
+  // direction of largest spread: power iteration on the covariance
+  std::vector<double> dir(nd), tmp(nd);
+  for (int d = 0; d < nd; ++d) dir[d] = 1.0 + 0.01 * d;
+  for (int it = 0; it < 64; ++it) {
+    double nrm = 0.0;
+    for (int a = 0; a < nd; ++a) {
+      double v = 0.0;
+      for (int b = 0; b < nd; ++b) v += ell.cov[(size_t)a * nd + b] * dir[b];
+      tmp[a] = v; nrm += v * v;
+    }
+    nrm = sqrt(nrm);
+    if (!(nrm > 0.0)) { out.push_back(ell); return; }
+    for (int a = 0; a < nd; ++a) dir[a] = tmp[a] / nrm;
+  }
+  std::vector<char> lab(n), nlab(n);
+  std::vector<double> c0(nd), c1(nd), w(nd);
+  auto proj = [&](int i, const std::vector<double>& v) {
+    double p = 0.0;
+    for (int d = 0; d < nd; ++d) p += (u[(size_t)idx[i] * nd + d] - ell.ctr[d]) * v[d];
+    return p;
+  };
+  int n1 = 0;
+  for (int i = 0; i < n; ++i) { lab[i] = proj(i, dir) > 0.0; n1 += lab[i]; }
+  for (int it = 0; it < 8; ++it) {
+    if (n1 == 0 || n1 == n) { out.push_back(ell); return; }
+    std::fill(c0.begin(), c0.end(), 0.0); std::fill(c1.begin(), c1.end(), 0.0);
+    for (int i = 0; i < n; ++i) {
+      std::vector<double>& c = lab[i] ? c1 : c0;
+      for (int d = 0; d < nd; ++d) c[d] += u[(size_t)idx[i] * nd + d] - ell.ctr[d];
+    }
+    double q0 = 0.0, q1 = 0.0;
+    for (int d = 0; d < nd; ++d) { c0[d] /= (n - n1); c1[d] /= n1; q0 += c0[d] * c0[d]; q1 += c1[d] * c1[d]; w[d] = c1[d] - c0[d]; }
+    const double thr = 0.5 * (q1 - q0);
+    int m1 = 0; bool same = true;
+    for (int i = 0; i < n; ++i) { nlab[i] = proj(i, w) > thr; m1 += nlab[i]; same = same && (nlab[i] == lab[i]); }
+    lab.swap(nlab); n1 = m1;
+    if (same) break;
+  }
+  if (n1 < 2 * nd + 1 || n - n1 < 2 * nd + 1) { out.push_back(ell); return; }
+  std::vector<int> i0, i1;
+  i0.reserve(n - n1); i1.reserve(n1);
+  for (int i = 0; i < n; ++i) (lab[i] ? i1 : i0).push_back(idx[i]);
+  Ell e0, e1;
+  if (!fit_ell(u, i0.data(), (int)i0.size(), nd, enlarge, e0) || !fit_ell(u, i1.data(), (int)i1.size(), nd, enlarge, e1)) {
+    out.push_back(ell); return;
+  }
+  if (logaddexp(e0.logvol, e1.logvol) >= ell.logvol + log(vol_dec)) { out.push_back(ell); return; }
+  budget -= 1;
+  split_ell(u, i0, nd, enlarge, e0, budget, vol_dec, out);
+  split_ell(u, i1, nd, enlarge, e1, budget, vol_dec, out);
+}
+
+}  // namespace payne_ns
+
+extern "C" int payne_ns_bound(const double* u, int n, int ndim, double enlarge, int multi, int max_ell, double* ctr,
+                              double* axes, double* axes_unit, double* ainv, double* logvol, int* n_ell) {
+  using namespace payne_ns;
+  if (!u || !ctr || !axes || !axes_unit || !ainv || !logvol || !n_ell || n < 2 || ndim < 1 || max_ell < 1 || !(enlarge > 0.0))
+    return PAYNE_E_INVALID;
+  const int nd = ndim;
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  Ell whole;
+  if (!fit_ell(u, idx.data(), n, nd, enlarge, whole)) return PAYNE_E_INVALID;
+  std::vector<Ell> ells;
+  if (multi && max_ell > 1) {
+    int budget = max_ell;
+    split_ell(u, idx, nd, enlarge, whole, budget, 0.5, ells);
+  } else {
+    ells.push_back(whole);
+  }
+  const int E = (int)ells.size() > max_ell ? max_ell : (int)ells.size();
+  const double su = sqrt(nd + 2.0);
+  for (int e = 0; e < E; ++e) {
+    const Ell& el = ells[e];
+    for (int d = 0; d < nd; ++d) ctr[(size_t)e * nd + d] = el.ctr[d];
+    for (int i = 0; i < nd * nd; ++i) {
+      axes[(size_t)e * nd * nd + i] = el.L[i] * el.f;
+      axes_unit[(size_t)e * nd * nd + i] = el.L[i] * su;
+      ainv[(size_t)e * nd * nd + i] = el.Linv[i] / el.f;
+    }
+    logvol[e] = el.logvol;
+  }
+  *n_ell = E;
+  return PAYNE_OK;
 }

@@ -71,6 +71,12 @@ class _Ell(object):
         self.logvol = logdet + nd * math.log(f)               # up to the unit ball's volume
         self._cov = cov
 
+    @classmethod
+    def from_arrays(cls, ctr, axes, axes_unit, ainv, logvol):
+        e = cls.__new__(cls)
+        e.ctr, e.axes, e.axes_unit, e.ainv, e.logvol, e._cov = ctr, axes, axes_unit, ainv, float(logvol), None
+        return e
+
     def dist2(self, U):
         """Squared radius of the points in this ellipsoid's coordinates (<= 1 inside)."""
         return (((U - self.ctr) @ self.ainv.T) ** 2).sum(axis=1)
@@ -166,6 +172,7 @@ class NestedSampler(object):
             from .. import _lib
             self._lib = _lib.load()
             self._L = _lib
+        self._native_bound = self._lib is not None
         self._axes = None
         self._ells = []
         self._split_wait = 0
@@ -190,16 +197,30 @@ class NestedSampler(object):
             self._axes = None
             return
         u = self.live_u
-        whole = _Ell(u, self.enlarge)
-        self._ctr, self._axes, self._axes_unit = whole.ctr, whole.axes, whole.axes_unit
-        self._ells = [whole]
+        # the decomposition is tried at every update while it finds several ellipsoids, at every fourth one
+        # while the live points keep forming a single cloud
+        split = False
         if self.bound == 'multi':
-            # the decomposition is tried at every update while it finds several ellipsoids, at every
-            # fourth one while the live points keep forming a single cloud
             self._split_wait -= 1
-            if self._split_wait <= 0:
-                self._ells = _split_ellipsoids(u, whole, self.enlarge, [MAX_ELL])
-                self._split_wait = 1 if len(self._ells) > 1 else 4
+            split = self._split_wait <= 0
+        if self._native_bound:             # C++ (payne_ns_bound): same arithmetic as _Ell / _split_ellipsoids
+            nd, E = self.ndim, MAX_ELL if split else 1
+            ctr, lv = np.empty((E, nd)), np.empty(E)
+            ax, au, ai = np.empty((E, nd, nd)), np.empty((E, nd, nd)), np.empty((E, nd, nd))
+            ne = C.c_int(0)
+            rc = self._lib.payne_ns_bound(u.ctypes.data, len(u), nd, float(self.enlarge), int(split), E, ctr.ctypes.data,
+                                          ax.ctypes.data, au.ctypes.data, ai.ctypes.data, lv.ctypes.data, C.byref(ne))
+            if rc != 0:
+                raise RuntimeError("payne_ns_bound failed (%d)" % rc)
+            ells = [_Ell.from_arrays(ctr[e], ax[e], au[e], ai[e], lv[e]) for e in range(ne.value)]
+        else:
+            whole = _Ell(u, self.enlarge)
+            ells = _split_ellipsoids(u, whole, self.enlarge, [MAX_ELL]) if split else [whole]
+        if split:
+            self._split_wait = 1 if len(ells) > 1 else 4
+        self._ells = ells                  # (an update without a split attempt always follows a single-cloud result)
+        e0 = self._ells[0]
+        self._ctr, self._axes, self._axes_unit = e0.ctr, e0.axes, e0.axes_unit
         self.nbound += 1
         self._since_update = 0
 

@@ -28,7 +28,7 @@ ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', '
 
 
 def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
-        verbose=False):
+        verbose=False, bound='multi'):
     """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
     bookkeeping included).  Returns {mode: {...}}."""
     cfg = synth.CONFIGS[config]
@@ -60,20 +60,21 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
         elif mode.startswith("device"):
             from thepayne_amd.sampler.device import DeviceProposer
             proposer = DeviceProposer(L, P, k_max=nlive)
-        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound='multi',
+        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound=bound,
                           sample='rwalk', walks=walks, batched=True, queue_size=queue,
                           rstate=np.random.default_rng(1), proposer=proposer)
         t0 = time.perf_counter()
         c0 = S.ncall
+        nell = 1
         if mode.endswith("chunks"):
             for _ in S.sample_chunks(maxcall=maxcall, dlogz=0.01):
-                pass
+                nell = max(nell, len(S._ells))
         else:
             for _ in S.sample(maxcall=maxcall, dlogz=0.01):
                 pass
         dt = time.perf_counter() - t0
         out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 4),
-                     "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale)}
+                     "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale), "max_ellipsoids": nell}
         if verbose:
             print(mode, json.dumps(out[mode]), flush=True)
         if proposer is not None:
@@ -89,8 +90,9 @@ def main():
     ap.add_argument("--nlive", type=int, default=512)
     ap.add_argument("--walks", type=int, default=25)
     ap.add_argument("--modes", default="host,device,device_chunks,device2_chunks")
+    ap.add_argument("--bound", default="multi")
     a = ap.parse_args()
-    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True)
+    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True, bound=a.bound)
     print(json.dumps({"sampler_bench": out, "config": a.config, "nlive": a.nlive, "walks": a.walks}))
 
 
