@@ -15,7 +15,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpayne_hip.so")
 SOURCES = ["payne_hip.hip"]
-HEADERS = ["post_core.hpp", "post_seq.hpp", "host_tables.hpp", "ns_core.hpp"]
+HEADERS = ["post_core.hpp", "post_seq.hpp", "host_tables.hpp", "ns_core.hpp", "dense_kernels.hpp", "post_kernels.hpp",
+           "sed_kernel.hpp", "sampler_kernels.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc",
                "-DNDEBUG", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,405 @@
+// post_kernels.hpp -- kernels around the per-candidate spectrum pipeline whose phase code lives in
+// post_core.hpp / post_seq.hpp (device code only; included once by payne_hip.hip): the LDS-resident
+// payne_post_kernel, the global-workspace payne_post_big_kernel for spectra larger than LDS, and
+// payne_lsf_kernel (LSF-vector broadening, Payne/utils/smoothing.py:482-586).
+#pragma once
+
+// ============================================================================
+// per-candidate spectrum pipeline
+// ============================================================================
+struct PostArgs {
+  const double* theta; int ld_theta;
+  double instr_factor;
+  const float* raw; int ld_raw;
+  float* out; int ld_out; int out_stage;
+  double* lnl;                       // [B] or null
+  const double* mags; int n_filters; // SED magnitudes of this batch (null: no photometry)
+  const double* obs_mag; const double* obs_err;
+  unsigned long long* stamps;        // diagnostic build: [B][64] cycle stamps (slot 0 = count)
+  const CandState* prep;             // [B] per-candidate records made by the first dense launch (null: none)
+};
+
+// BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
+template <bool BUF_LDS, bool TW_LDS>
+struct DevExecT {
+#ifdef __HIP_DEVICE_COMPILE__
+  static __device__ __forceinline__ auto buf(c32* p) {
+    if constexpr (BUF_LDS) return (PAYNE_AS_LDS f2v*)p; else return (PAYNE_AS_GLOBAL f2v*)p;
+  }
+  static __device__ __forceinline__ auto twid(const c32* p) {
+    if constexpr (TW_LDS) return (const PAYNE_AS_LDS f2v*)p; else return (const PAYNE_AS_GLOBAL f2v*)p;
+  }
+#else
+  static c32* buf(c32* p) { return p; }
+  static const c32* twid(const c32* p) { return p; }
+#endif
+#ifdef PAYNE_STAMPS
+  // diagnostic build only (libpayne_hip_diag.so): cycle stamp after every phase barrier
+  unsigned long long* stamps = nullptr;
+  int nst = 0;
+#endif
+  template <class F>
+  __device__ __forceinline__ void par(F&& f) {
+    f((int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
+    mark(0);
+  }
+  template <class F>
+  __device__ __forceinline__ void single(F&& f) { if (threadIdx.x == 0) f((int)blockDim.x); }
+  // diagnostic build: an extra cycle stamp inside a phase, written by thread `who`
+  __device__ __forceinline__ void mark(int who) {
+#ifdef PAYNE_STAMPS
+    if (stamps && nst < 62) { ++nst; if ((int)threadIdx.x == who) stamps[nst] = __builtin_amdgcn_s_memtime(); }
+#else
+    (void)who;
+#endif
+  }
+  __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+};
+
+__device__ __forceinline__ double sed_chi2(const double* mags, const double* obs, const double* err, int F) {
+  double s = 0.0;   // likelihood.py:109-112
+  for (int f = 0; f < F; ++f) { const double d = mags[f] - obs[f]; s += (d * d) / (err[f] * err[f]); }
+  return s;
+}
+
+// LEAN: the likelihood-only instantiation (out_stage == -1, no spectrum output, per-candidate records present):
+// the output variants of the observed-grid loop, the stage branches and the in-kernel setup are compiled out
+// (most of the 270 KB of the full kernel).
+template <int LOG2N, bool TW_LDS, bool LEAN = false>
+__global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables T, PostArgs a) {
+  // T by value: its pointer members then live in the kernarg segment and are known to be
+  // global (a struct read through a device pointer yields generic pointers -> flat_load,
+  // which also ties every table load to the LDS wait counter)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n1 = T.n1;
+  float* bufA = reinterpret_cast<float*>(smem);
+  float* bufB = bufA + fft_buf_floats(n1);                     // room for the padded FFT intermediates
+  double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(n1));          // scratch_doubles(256)
+  CandState* S = reinterpret_cast<CandState*>(red + scratch_doubles(kPostThreads));
+  const c32* twf = T.twf;
+  if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
+    c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
+    typedef float f2g __attribute__((ext_vector_type(2)));
+    const f2g* __restrict__ g = reinterpret_cast<const f2g*>(T.twf);
+    f2g* tl = reinterpret_cast<f2g*>(twl);
+    if constexpr (LOG2N > 0) {
+      // every load of the table in flight at once (a load -> store loop pays one L2 round trip per
+      // iteration: twelve of them at 4096 points, ~3.5 us before the first phase could start)
+      constexpr int NTW = plan_table_len((1 << LOG2N) / 2), PER = (NTW + kPostThreads - 1) / kPostThreads;
+      f2g tmp[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i0 = (int)threadIdx.x + q * kPostThreads;
+        tmp[q] = g[i0 < NTW ? i0 : NTW - 1];
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i0 = (int)threadIdx.x + q * kPostThreads;
+        if (i0 < NTW) tl[i0] = tmp[q];
+      }
+    } else {
+      const int nt = T.twf_n;
+      for (int i = threadIdx.x; i < nt; i += kPostThreads) tl[i] = g[i];
+    }
+    twf = twl;                                                 // made visible by the first phase barrier
+  }
+  const int b = blockIdx.x;
+  DevExecT<true, TW_LDS> ex;
+#ifdef PAYNE_STAMPS
+  if (a.stamps) {
+    ex.stamps = a.stamps + (size_t)b * 64;
+    if (threadIdx.x == 0) { ex.stamps[1] = __builtin_amdgcn_s_memtime(); }
+    ex.nst = 1;
+  }
+#endif
+  double* chi2 = red + scratch_doubles(kPostThreads) - 1;
+  const int ostage = LEAN ? -1 : a.out_stage;
+  float* outp = LEAN ? nullptr : (a.out ? a.out + (size_t)b * a.ld_out : nullptr);
+  const CandState* prep = a.prep ? a.prep + b : nullptr;
+  if (LEAN) { prep = a.prep + b; __builtin_assume(prep != nullptr); }     // LEAN is launched only with records
+  run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep);
+  if (threadIdx.x == 0 && a.lnl && ostage < 0) {
+    double x2 = *chi2;
+    if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+    a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
+  }
+#ifdef PAYNE_STAMPS
+  if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
+#endif
+}
+
+
+// Spectra that do not fit LDS (n1 > 16384, e.g. the 65k-pixel R~100k grid): the same phase code
+// with the two spectrum buffers in a per-workgroup global workspace (L2 / Infinity-Cache resident
+// while it is being worked on) and the runtime-geometry FFT.  Workgroups are persistent and walk
+// the batch with stride gridDim.x, so the workspace is sized by the grid, not by the batch.  All
+// waves of a workgroup share one CU's L1, so __syncthreads() orders the global accesses between
+// phases exactly as it orders LDS.  This is the HBM/L2-bandwidth-bound regime of SURVEY.md 8(d).
+constexpr int kBigThreads = 512;
+__global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B) {
+  __shared__ double red[kBigThreads + kBigThreads / 2 + 2];
+  __shared__ CandState S;
+  float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
+  float* bufB = bufA + T.n1;
+  DevExecT<false, false> ex;
+  double* chi2 = red + scratch_doubles(kBigThreads) - 1;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    run_candidate<0, kBigThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+                                  a.raw + (size_t)b * a.ld_raw, bufA, bufB, S, red,
+                                  a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2);
+    if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
+      double x2 = *chi2;
+      if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+      a.lnl[b] = -0.5 * x2;
+    }
+    __syncthreads();
+  }
+}
+
+// ============================================================================
+// LSF-vector instrumental broadening (inst_R = dispersion in AA per observed pixel):
+// ystpred.py:248-269 -> smoothspec(smoothtype='lsf') -> smooth_lsf_fft (smoothing.py:125-151, 482-586).
+// Not on the sampler's usual path (Inst_R is a sampled scalar there); one workgroup per candidate,
+// fp64 position arithmetic through a global workspace, written for clarity rather than speed:
+//   mask (linear, +-2000 AA) -> sigma_i = interp(lambda_i (1+rv/c), obs, lsf) -> r = gradient(w)/sigma ->
+//   cdf = cumsum(r)/max -> x_per_sigma = nanmedian(gradient(cdf)/r) -> nx = 2^ceil(log2(2/x_per_sigma)) ->
+//   lam = interp(linspace(0,1,nx), cdf, w); s' = interp(lam, w, s) -> Gaussian FFT smoothing of width
+//   x_per_sigma (dx = 1/nx) -> np.interp(obs, lam, .) (clamped: no NaN) -> blaze -> chi^2.
+// Input: the spectrum after rotational broadening on the ANN grid (post kernel, stage 5), shifted by -1.
+// ============================================================================
+struct LsfArgs {
+  const double* theta; int ld_theta;
+  const float* spec; int ld_spec;        // [B][npix] after vsini, shifted
+  const double* obs_wave; const double* lsf; // [nobs]
+  double* ws; size_t ws_stride;          // per candidate: a[npix] | cdf[npix] | lam[n1]
+  float* out; int ld_out; int out_stage; // 2 / 3 / -1
+  double* lnl;
+  const double* mags; int n_filters; const double* obs_mag; const double* obs_err;
+};
+// np.interp(x, xp, fp) (arr_interp): clamped outside, slope form inside
+__device__ double interp_np(double x, const double* xp, const double* fp, int n) {
+  if (x > xp[n - 1]) return fp[n - 1];
+  if (x < xp[0]) return fp[0];
+  int lo = 0, hi = n;                                   // last j with xp[j] <= x
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
+  const int j = lo;
+  if (j == n - 1 || xp[j] == x) return fp[j];
+  const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  return slope * (x - xp[j]) + fp[j];
+}
+__global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  double* sortb = reinterpret_cast<double*>(lsm);                      // [n1] median sort buffer
+  float* bufA = reinterpret_cast<float*>(sortb + T.n1);
+  float* bufB = bufA + fft_buf_floats(T.n1);
+  double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(T.n1));    // [256 + 8]
+  __shared__ int cnt_s[2], nvalid_s, nx_s;
+  __shared__ double scal_s[4];                                         // 0 max(cdf), 1 x_per_sigma
+  const int b = blockIdx.x, tid = threadIdx.x, npix = T.npix, nobs = T.nobs;
+  const double* th = a.theta + (size_t)b * a.ld_theta;
+  const float* sp = a.spec + (size_t)b * a.ld_spec;
+  double* wsA = a.ws + (size_t)b * a.ws_stride;
+  double* wsC = wsA + npix;
+  double* wsL = wsC + npix;
+  const double rv = th[4];
+  const double op = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;      // ystpred.py:228-232
+  // ---- mask_wave(linear=True, width=100): strict limits obs.min - 2000, obs.max + 2000
+  const double wl = T.obs_min + 20.0 * 100.0 * -1.0, wh = T.obs_max + 20.0 * 100.0 * 1.0;
+  if (tid < 2) cnt_s[tid] = 0;
+  __syncthreads();
+  {
+    int cb = 0, ca = 0;
+    for (int i = tid; i < npix; i += 256) { const double c = T.lam[i] * op; cb += !(c > wl); ca += (c < wh); }
+    atomicAdd(&cnt_s[0], cb); atomicAdd(&cnt_s[1], ca);
+  }
+  __syncthreads();
+  const int i0 = cnt_s[0], n = cnt_s[1] - cnt_s[0];
+  bool bad = n < 8;
+  auto W = [&](int i) { return T.lam[i0 + i] * op; };
+  if (!bad) {
+    // ---- sigma_i (disparr = np.interp(modwave, outwave, inst_R)), r_i = gradient(w)_i / sigma_i
+    for (int i = tid; i < n; i += 256) {
+      const double sig = interp_np(W(i), a.obs_wave, a.lsf, nobs);
+      const double dw = (i == 0) ? (W(1) - W(0)) : ((i == n - 1) ? (W(n - 1) - W(n - 2)) : (W(i + 1) - W(i - 1)) / 2.0);
+      wsA[i] = dw / sig;
+    }
+    __syncthreads();
+    // ---- cdf = cumsum(r): per-thread chunks, then a scan of the 256 chunk sums
+    const int chunk = (n + 255) / 256, c0 = tid * chunk, c1 = (c0 + chunk < n) ? c0 + chunk : n;
+    double acc = 0.0;
+    for (int i = c0; i < c1; ++i) { acc += wsA[i]; wsC[i] = acc; }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid == 0) { double run = 0.0; for (int t = 0; t < 256; ++t) { const double v = red[t]; red[t] = run; run += v; } }
+    __syncthreads();
+    const double offs = red[tid];
+    double mx = -INFINITY; bool anynan = false;
+    for (int i = c0; i < c1; ++i) { const double v = wsC[i] + offs; wsC[i] = v; if (v != v) anynan = true; mx = v > mx ? v : mx; }
+    __syncthreads();
+    red[tid] = anynan ? __builtin_nan("") : mx;
+    __syncthreads();
+    if (tid == 0) {
+      double m = -INFINITY; bool nn = false;
+      for (int t = 0; t < 256; ++t) { const double v = red[t]; if (v != v) nn = true; else m = v > m ? v : m; }
+      scal_s[0] = nn ? __builtin_nan("") : m;                           // ndarray.max() propagates NaN
+      nvalid_s = 0;
+    }
+    __syncthreads();
+    const double cmax = scal_s[0];
+    for (int i = tid; i < n; i += 256) wsC[i] = wsC[i] / cmax;           // cdf /= cdf.max()
+    __syncthreads();
+    // ---- x_per_sigma = nanmedian(gradient(cdf) / r): bitonic sort of the ratios in LDS
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    int nv = 0;
+    for (int i = tid; i < n2; i += 256) {
+      double q = INFINITY;
+      if (i < n) {
+        const double g = (i == 0) ? (wsC[1] - wsC[0]) : ((i == n - 1) ? (wsC[n - 1] - wsC[n - 2]) : (wsC[i + 1] - wsC[i - 1]) / 2.0);
+        q = g / wsA[i];
+        if (q != q) q = INFINITY; else ++nv;
+      }
+      sortb[i] = q;
+    }
+    atomicAdd(&nvalid_s, nv);
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        __syncthreads();
+        for (int i = tid; i < n2; i += 256) {
+          const int p = i ^ j;
+          if (p > i) {
+            const double x0 = sortb[i], x1 = sortb[p];
+            const bool up = (i & k) == 0;
+            if ((x0 > x1) == up) { sortb[i] = x1; sortb[p] = x0; }
+          }
+        }
+      }
+    __syncthreads();
+    if (tid == 0) {
+      const int m = nvalid_s;
+      const double xps = m == 0 ? __builtin_nan("") : ((m & 1) ? sortb[m >> 1] : 0.5 * (sortb[(m >> 1) - 1] + sortb[m >> 1]));
+      scal_s[1] = xps;
+      const double N = 2.0 / xps;                                       // pix_per_sigma = 2
+      int nx = 0;
+      if (N == N && N > 0.0 && N <= (double)T.n1) { nx = 1; while ((double)nx < N) nx <<= 1; }
+      nx_s = nx;
+    }
+    __syncthreads();
+  }
+  const int nx = bad ? 0 : nx_s;
+  bad = bad || nx < 8 || nx > T.n1;        // x_per_sigma NaN / a grid finer than the context's FFT tables: NaN result
+  const float* conv = bufA;
+  if (!bad) {
+    // ---- lam = np.interp(linspace(0, 1, nx), cdf, w);  newspec = np.interp(lam, w, s)
+    const double step = 1.0 / (double)(nx - 1);
+    for (int j = tid; j < nx; j += 256) {
+      const double x = (j == nx - 1) ? 1.0 : (double)j * step;
+      double lamj; int k;
+      if (x > wsC[n - 1]) { lamj = W(n - 1); k = n - 2; }
+      else if (x < wsC[0]) { lamj = W(0); k = 0; }
+      else {
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wsC[mid] <= x) lo = mid; else hi = mid; }
+        k = lo;
+        if (k == n - 1 || wsC[k] == x) lamj = W(k);
+        else { const double slope = (W(k + 1) - W(k)) / (wsC[k + 1] - wsC[k]); lamj = slope * (x - wsC[k]) + W(k); }
+        if (k > n - 2) k = n - 2;
+      }
+      wsL[j] = lamj;
+      // np.interp(lamj, w, s): w[k2] <= lamj < w[k2+1]; k is right up to rounding at the pixel edges
+      int k2 = k;
+      while (k2 > 0 && lamj < W(k2)) --k2;
+      while (k2 < n - 2 && lamj >= W(k2 + 1)) ++k2;
+      const double s0 = (double)nan_to_zero(sp[i0 + k2]), s1 = (double)nan_to_zero(sp[i0 + k2 + 1]);   // nan_to_num(nan=1.0), shifted
+      double v;
+      if (lamj >= W(n - 1)) v = (double)nan_to_zero(sp[i0 + n - 1]);
+      else if (lamj <= W(0)) v = (double)nan_to_zero(sp[i0]);
+      else v = (s1 - s0) / (W(k2 + 1) - W(k2)) * (lamj - W(k2)) + s0;
+      bufB[j] = (float)v;
+    }
+    __syncthreads();
+    // ---- smooth_fft(dx = 1/nx, newspec, x_per_sigma): taper exp(-2 pi^2 sigma^2 k^2)
+    DevExecT<true, false> ex;
+    TaperArgs ta{};
+    const double xps = scal_s[1];
+    ta.g_c2 = (float)(-2.0 * (kPi * kPi) * (xps * xps) * 1.4426950408889634);
+    bool no_edge = false;
+    conv = conv_stage<0, 256, false>(ex, T, T.tw, bufB, bufA, nx, ta, no_edge);
+  }
+  // ---- np.interp(outwave, lam, conv) (clamped), blaze, chi^2
+  const bool cheb = T.npoly > 0 && a.out_stage != 2, hasf = T.obs_f1 != nullptr;
+  double accx = 0.0;
+  for (int i = tid; i < nobs; i += 256) {
+    float m1 = nanf_();
+    if (!bad) {
+      const double x = a.obs_wave[i];
+      if (x > wsL[nx - 1]) m1 = conv[nx - 1];
+      else if (x < wsL[0]) m1 = conv[0];
+      else {
+        int lo = 0, hi = nx;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wsL[mid] <= x) lo = mid; else hi = mid; }
+        const int j = lo;
+        if (j == nx - 1 || wsL[j] == x) m1 = conv[j];
+        else m1 = (float)(((double)conv[j + 1] - (double)conv[j]) / (wsL[j + 1] - wsL[j]) * (x - wsL[j]) + (double)conv[j]);
+      }
+    }
+    double pv = 1.0;
+    if (cheb) {                                           // chebval, fitutils.py:11-20
+      const double xc = T.xcheb[i];
+      const int nc = T.npoly;
+      double c0, c1;
+      if (nc == 1) { c0 = th[8]; c1 = 0.0; }
+      else if (nc == 2) { c0 = th[8]; c1 = th[9]; }
+      else {
+        const double x2 = 2.0 * xc;
+        c0 = th[8 + nc - 2]; c1 = th[8 + nc - 1];
+        for (int r = 3; r <= nc; ++r) { const double t = c0; c0 = th[8 + nc - r] - c1; c1 = t + c1 * x2; }
+      }
+      pv = c0 + c1 * xc;
+    }
+    const double model1 = (double)m1 * pv + (pv - 1.0);   // (m - 1) p + (p - 1) = m p - 1
+    if (a.out) a.out[(size_t)b * a.ld_out + i] = (float)(model1 + 1.0);
+    if (hasf && a.lnl) { const double d = model1 - (double)T.obs_f1[i]; accx += (d * d) * (double)T.obs_ivar[i]; }
+  }
+  if (a.lnl) {
+    __syncthreads();
+    red[tid] = accx;
+    __syncthreads();
+    if (tid == 0) {
+      double x2 = 0.0;
+      for (int t = 0; t < 256; ++t) x2 += red[t];
+      if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+      a.lnl[b] = -0.5 * x2;
+    }
+  }
+}
+
+typedef void (*post_kernel_fn)(const PostTables, PostArgs);
+// compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
+static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
+  if (lean) {                                   // likelihood-only builds of the two LDS-twiddle sizes that matter
+    if (tw_lds && n1 == 4096) return payne_post_kernel<12, true, true>;
+    if (tw_lds && n1 == 2048) return payne_post_kernel<11, true, true>;
+    if (!tw_lds && n1 == 8192) return payne_post_kernel<13, false, true>;
+  }
+  if (tw_lds) {
+    switch (n1) {
+      case 1024: return payne_post_kernel<10, true>;
+      case 2048: return payne_post_kernel<11, true>;
+      case 4096: return payne_post_kernel<12, true>;
+      default: return payne_post_kernel<0, true>;
+    }
+  }
+  switch (n1) {
+    case 8192: return payne_post_kernel<13, false>;
+    default: return payne_post_kernel<0, false>;
+  }
+}
+
+// photometry-only fits: lnL = -0.5 chi2_sed
+__global__ void payne_photonly_kernel(const double* mags, const double* obs, const double* err, int F, int B, double* lnl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) lnl[b] = -0.5 * sed_chi2(mags + (size_t)b * F, obs, err, F);
+}
