@@ -274,3 +274,17 @@ def test_native_bound_matches_python_bound():
             assert abs(lv[j] - e.logvol) < 1e-9
             assert np.all((((u - ctr[j]) @ ai[j].T) ** 2).sum(axis=1)[e.dist2(u) <= 1.0] <= 1.0 + 1e-9)
     assert lib.payne_ns_bound(None, 10, 3, 1.25, 0, 1, None, None, None, None, None, None) < 0
+
+
+@pytest.mark.parametrize("method", ["slice", "rslice"])
+def test_slice_sampling_on_a_gaussian(method):
+    s = NestedSampler(loglike_batch, ptform_batch, NDIM, nlive=300, bound='single', sample=method, slices=3,
+                      batched=True, rstate=np.random.default_rng(17), queue_size=300)
+    s.run_nested(dlogz=0.05)
+    r = s.results
+    assert abs(r.logz[-1] - LOGZ_TRUE) < max(0.15, 4 * r.logzerr[-1]), (r.logz[-1], LOGZ_TRUE, r.logzerr[-1])
+    w = s.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    assert np.all(np.abs(mean - 0.5) < 0.012) and np.all(np.abs(std - SIG) < 0.012), (mean, std)
+    assert np.all(np.diff(r.logl[:-300]) >= 0) and 1e-4 < s.scale < 8.0

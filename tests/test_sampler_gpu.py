@@ -357,3 +357,28 @@ def test_multi_ellipsoid_fit_on_the_device(tmp_path):
     T = synth.TRUTH
     truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
     assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+
+
+def test_fitpayne_slice_sampling_on_the_device(tmp_path):
+    """samplemethod 'slice' (fitstar.py:292-295, slices=): every lock-step round of the chains is one
+    payne_lnprob_u_batch call."""
+    from thepayne_amd.fitting.fitstar import FitPayne
+    from helpers import yst_problem
+    raw, obs, flux, eflux = yst_problem("small", H=64, line_depth=0.3)
+    inputdict = {
+        'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': eflux, 'convertair': False},
+        'specANNpath': _save_yst(tmp_path, raw), 'NNtype': 'YST1',
+        'sampler': {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'slice', 'slices': 2,
+                    'npoints': 100, 'delta_logz_final': 0.5, 'bootstrap': 0, 'flushnum': 500, 'seed': 6},
+        'priordict': synth.demo_priordict(), 'output': str(tmp_path / 'fit.dat'),
+    }
+    F = FitPayne()
+    sampler = F.run(inputdict=inputdict, verbose=False)
+    assert F.proposer is not None and sampler.method == 'slice'
+    r = sampler.results
+    w = sampler.posterior_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    std = np.sqrt((w[:, None] * (r.samples - mean) ** 2).sum(0))
+    T = synth.TRUTH
+    truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
+    assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)

@@ -119,8 +119,8 @@ class NestedSampler(object):
                  logl_args=None, bootstrap=0, walks=25, slices=5, enlarge=None, rstate=None,
                  batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None,
                  native=True, live_points=None, loglstar=None, **ignored):
-        if sample not in ('unif', 'rwalk'):
-            raise NotImplementedError("sample=%r: this driver provides 'unif' and 'rwalk'" % (sample,))
+        if sample not in ('unif', 'rwalk', 'slice', 'rslice'):
+            raise NotImplementedError("sample=%r: this driver provides 'unif', 'rwalk', 'slice' and 'rslice'" % (sample,))
         if bound not in ('none', 'single', 'multi'):
             raise NotImplementedError("bound=%r: this driver provides 'none', 'single', 'multi'" % (bound,))
         self.ndim = int(ndim)
@@ -128,6 +128,7 @@ class NestedSampler(object):
         self.bound = bound
         self.method = sample
         self.walks = int(walks)
+        self.slices = int(slices)
         self.enlarge = 1.25 if enlarge is None else float(enlarge)
         self.rng = rstate if rstate is not None else np.random.default_rng()
         self.queue_size = int(queue_size) if queue_size else self.nlive
@@ -272,9 +273,12 @@ class NestedSampler(object):
                 self._update_bound()
             self.ncall += nin
             return
-        # rwalk: K lock-step chains
+        # rwalk / slice: K lock-step chains
         start = rng.integers(0, self.nlive, size=K)
         U, V, ll = self.live_u[start].copy(), self.live_v[start].copy(), self.live_logl[start].copy()
+        if self.method in ('slice', 'rslice'):
+            self._fill_queue_slice(U, V, ll)
+            return
         ell, axes = None, self._axes_unit
         if len(self._ells) > 1:            # each chain steps in the metric of an ellipsoid holding its start point
             d2 = np.stack([e.dist2(U) for e in self._ells])                     # [n_ell, K]
@@ -312,6 +316,95 @@ class NestedSampler(object):
         moved = nacc > 0                                      # a chain that never moved is a copy of a live point
         self._pending_nc += int(ncalls[~moved].sum())
         self._set_queue(U[moved], V[moved], ll[moved], np.maximum(1, ncalls[moved]))
+
+    def _eval_u(self, U):
+        """Unit-cube points -> (V, lnprob), one batch."""
+        if self.proposer is not None:
+            V, ll = self.proposer.lnprob_u(U)
+            return V, np.where(np.isnan(ll), -np.inf, ll)
+        V = self._ptform(U)
+        return V, self._eval(V)
+
+    def _fill_queue_slice(self, U, V, ll):
+        """Slice sampling (Neal 2003) as dynesty's 'slice' / 'rslice' apply it: `slices` sweeps, each over the
+        ndim principal axes of the bounding ellipsoid in random order ('rslice': `slices` random directions);
+        per axis a window of one axis length is placed at random around the point, stepped out while its
+        ends are above the threshold, then sampled and shrunk until a point above the threshold is found.
+        The K chains run in lock step: every round each unfinished chain asks for exactly one likelihood
+        value, so a round is one batch."""
+        K, nd, rng, lstar = len(U), self.ndim, self.rng, self.loglstar
+        if len(self._ells) > 1:
+            d2 = np.stack([e.dist2(U) for e in self._ells])
+            ell = np.where((d2 <= 1.0).any(axis=0), np.argmax(d2 <= 1.0, axis=0), np.argmin(d2, axis=0))
+            A = np.stack([e.axes for e in self._ells])[ell]                       # [K, nd, nd], columns = axes
+        else:
+            A = np.broadcast_to(self._axes, (K, nd, nd))
+        ncalls = np.zeros(K, dtype=np.int64)
+        nexpand = ncontract = 0
+        n_dir = self.slices * nd if self.method == 'slice' else self.slices
+        order = np.stack([np.concatenate([rng.permutation(nd) for _ in range(self.slices)]) for _ in range(K)]) \
+            if self.method == 'slice' else None
+        rows = np.arange(K)
+        for step in range(n_dir):
+            if self.method == 'slice':
+                axis = self.scale * A[rows, :, order[:, step]]                    # [K, nd]
+            else:
+                z = rng.standard_normal((K, nd))
+                z /= np.linalg.norm(z, axis=1)[:, None]
+                axis = self.scale * np.einsum('kij,kj->ki', A, z)
+            r = rng.uniform(size=(K, 1))
+            left, right = U - r * axis, U + (1.0 - r) * axis
+
+            def value(P, need):
+                """lnprob of the rows of P selected by `need` (-inf outside the cube, without a call)."""
+                out = np.full(K, -np.inf)
+                ask = need & np.all((P > 0.0) & (P < 1.0), axis=1)
+                ncalls[need] += 1
+                if ask.any():
+                    out[ask] = self._eval_u(P[ask])[1]
+                return out
+            # stepping out, both ends in lock step
+            grow_l = np.ones(K, dtype=bool)
+            grow_r = np.ones(K, dtype=bool)
+            while grow_l.any() or grow_r.any():
+                if grow_l.any():
+                    nexpand += int(grow_l.sum())
+                    still = value(left, grow_l) > lstar
+                    left = np.where((grow_l & still)[:, None], left - axis, left)
+                    grow_l &= still
+                if grow_r.any():
+                    nexpand += int(grow_r.sum())
+                    still = value(right, grow_r) > lstar
+                    right = np.where((grow_r & still)[:, None], right + axis, right)
+                    grow_r &= still
+            # shrinkage
+            todo = np.ones(K, dtype=bool)
+            for _ in range(200):
+                span = right - left
+                prop = left + rng.uniform(size=(K, 1)) * span
+                ask = todo & np.all((prop > 0.0) & (prop < 1.0), axis=1)
+                ncalls[todo] += 1
+                ncontract += int(todo.sum())
+                pl = np.full(K, -np.inf)
+                pv = None
+                if ask.any():
+                    pv, got = self._eval_u(prop[ask])
+                    pl[ask] = got
+                ok = todo & (pl > lstar)
+                if ok.any():
+                    sel = ok[ask]
+                    U[ok], V[ok], ll[ok] = prop[ok], pv[sel], pl[ok]
+                side = np.einsum('kj,kj->k', prop - U, span)
+                shrink = todo & ~ok
+                left = np.where((shrink & (side < 0))[:, None], prop, left)
+                right = np.where((shrink & (side >= 0))[:, None], prop, right)
+                todo = shrink
+                if not todo.any():
+                    break
+        self.ncall += int(ncalls.sum())
+        # dynesty's rule: keep expansions ~ twice the contractions
+        self.scale = min(max(self.scale * nexpand / max(1.0, 2.0 * ncontract), 1e-4), 8.0)
+        self._set_queue(U, V, ll, np.maximum(1, ncalls))
 
     # ---- the bookkeeping loop over one queue --------------------------------------------------
     def _records(self, m):
