@@ -75,7 +75,7 @@ def test_nan_likelihood_is_never_accepted_and_limits_hold():
     assert n == 300
     assert np.all(s.live_v[np.isfinite(s.live_logl), 0] <= 0.6)
     with pytest.raises(NotImplementedError):
-        NestedSampler(ll, ptform_batch, NDIM, sample="slice")
+        NestedSampler(ll, ptform_batch, NDIM, sample="hslice", batched=True)
 
 
 def test_native_bookkeeping_matches_python_loop():
