@@ -103,10 +103,11 @@ def pmc_traffic(kind):
     key = {"dense_out": "payne_dense_dma_kernel", "post": "payne_post_kernel"}[kind]
     try:
         import csv
-        tot = {}
+        tot, seen = {}, {}
         for r in csv.DictReader(open(path)):
-            if key in r["kernel"]:
+            if key in r["kernel"] and int(r["launches"]) >= seen.get(r["counter"], 0):     # the steady-state variant
                 tot[r["counter"]] = float(r["mean_value_per_launch_KB_raw"])
+                seen[r["counter"]] = int(r["launches"])
         return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
@@ -285,7 +286,7 @@ def main():
         out["end_to_end"] = {"value": e2e["evals_per_s"], "unit": "likelihood-evals/s", "calls": e2e["calls"],
                              "iterations": e2e["iterations"], "seconds": e2e["seconds"],
                              "what": "static nested sampler, %d live points, rwalk x25 on the device, bound='multi' "
-                                     "(one enlarged ellipsoid in this driver), dead points consumed in bulk" % B}
+                                     "(ellipsoid decomposition by recursive 2-means), dead points consumed in bulk" % B}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
