@@ -95,12 +95,18 @@ def cpu_baseline(cfg_name, budget_s=10.0, max_procs=32):
                        % (cfg_name, cores, budget_s, sum(r[0] for r in res), wall))
 
 
+def pmc_step_bytes():
+    """HBM bytes one likelihood batch moves, all three kernels (same PMC file and corrections as pmc_traffic)."""
+    parts = [pmc_traffic(k) for k in ("dense_hidden", "dense_out", "post")]
+    return None if any(p is None for p in parts) else float(sum(parts))
+
+
 def pmc_traffic(kind):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of the same command
     (profiles/r1_c2_rocprofv3_pmc_hbm.csv; FETCH_SIZE and WRITE_SIZE in separate runs, KB).  FETCH_SIZE
     is doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads on gfx950."""
     path = os.path.join(ROOT, "profiles", "r1_c2_rocprofv3_pmc_hbm.csv")
-    key = {"dense_out": "payne_dense_dma_kernel", "post": "payne_post_kernel"}[kind]
+    key = {"dense_out": "payne_dense_dma_kernel", "post": "payne_post_kernel", "dense_hidden": "payne_dense_hidden_kernel"}[kind]
     try:
         import csv
         tot, seen = {}, {}
@@ -272,6 +278,17 @@ def main():
                                   "achieved_tflops": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12,
                                   "frac_of_fp32_peak": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12 / PEAK_FP32_TFLOPS}
         out["kernels_us"] = per
+        if args.config == "C2" and B == 512:
+            # whole-step HBM rate: the north star asks for the achieved HBM-bandwidth fraction; this path is
+            # FLOP/latency-bound at C2 (AI ~ 300 FLOP/B), so the fraction is small by construction
+            step_bytes = pmc_step_bytes()
+            alg = 4.0 * (D * H + H + H * H + H + H * N + N) + 8.0 * N + 16.0 * cfg["nobs"] + B * (8.0 * 12 + 8) \
+                + 2.0 * 4.0 * B * N                     # + the spectra written by the output layer and read back once
+            if step_bytes is not None:
+                gbs = step_bytes / (1e-3 * out["ms_per_step"]) / 1e9
+                out["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                              "pmc_bytes_per_step": step_bytes, "alg_bytes_per_step": alg,
+                              "source": "profiles/r1_c2_rocprofv3_pmc_hbm.csv (2 x FETCH_SIZE + WRITE_SIZE, three kernels)"}
         out["alg_flops_per_eval"] = alg_flops_per_eval(D, H, N)
         out["whole_path_tflops"] = alg_flops_per_eval(D, H, N) * B / (max(sum(per.values()), 1e-9) * 1e-6) / 1e12
     if cpu is not None:
