@@ -273,6 +273,10 @@ def main():
                                "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                                "traffic": pmc_traffic(dom) if args.config == "C2" else None,
                                "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
+            if dom == "post":
+                out["roofline"]["note"] = ("FFT / interpolation pipeline in LDS: no MFMA instructions; priced against the "
+                                           "fp32 peak (vector = MFMA f32 = 157.3 TFLOP/s). The MFMA kernel of the step is "
+                                           "under `mfma_kernel`.")
             out["mfma_kernel"] = {"kernel": "payne_dense_dma_kernel (output layer)", "alg_flops_per_launch": flops["dense_out"],
                                   "avg_us_per_launch": per["dense_out"],
                                   "achieved_tflops": flops["dense_out"] / (max(per["dense_out"], 1e-9) * 1e-6) / 1e12,
