@@ -300,3 +300,33 @@ def test_smoothspec_on_arbitrary_spectra(tmp_path):
     assert np.abs(got - O.smooth_lsf(wave, spec, lsf, wave)).max() < 2e-6
     with pytest.raises(NotImplementedError):
         PP.smoothspec(wave, spec, 0.5, outwave=out, smoothtype='lambda')
+
+
+def test_genspec_on_any_grid_like_the_reference(tmp_path):
+    """GenMod.genspec(pars, outwave=...) for grids other than the fit's, outwave=None with and without an
+    instrumental stage, and the blaze polynomial on each (genmod.py:58-108)."""
+    from thepayne_amd.fitting.genmod import GenMod
+    raw, obs, flux, eflux = yst_problem("small", H=64, line_depth=0.3)
+    GM = GenMod()
+    GM._initspecnn(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    GM.configure(obs=(obs, flux, eflux), npoly=3)
+    base = [5600.0, 4.3, -0.2, 0.1, 12.0, 4.0, np.nan]
+    coef = [1.02, 0.03, -0.01]
+    other = np.linspace(obs[40], obs[-60], 333)
+    cases = [(28000.0, obs, False), (28000.0, other, False), (28000.0, other, True), (31000.0, other[::2].copy(), True),
+             (28000.0, None, False), (28000.0, None, True), (np.nan, None, False), (np.nan, None, True)]
+    for R, grid, poly in cases:
+        pars = base + [R] + (coef if poly else [])
+        w, f = GM.genspec(pars, outwave=grid, modpoly=poly)
+        wo, fo = O.genspec(raw, pars, outwave=grid, modpoly=poly)
+        np.testing.assert_allclose(w, wo, rtol=1e-15)
+        assert np.array_equal(np.isnan(f), np.isnan(fo))
+        ok = ~np.isnan(fo)
+        assert np.abs(f[ok] - fo[ok]).max() <= 2e-6, (R, None if grid is None else len(grid), poly)
+    # the fit's own context still has its observed spectrum bound
+    th = np.full((1, GM.engine.ncols), np.nan)
+    th[0, :8] = base + [28000.0]
+    th[0, 8:11] = coef
+    lnl = GM.engine.lnlike_batch(th).cpu().numpy()[0]
+    ref = -0.5 * O.chi2_spec(O.genspec(raw, base + [28000.0] + coef, outwave=obs, modpoly=True)[1], flux, eflux)
+    assert abs(lnl - ref) <= lnl_tol(ref)

@@ -8,6 +8,9 @@ import numpy as np
 
 from .. import nnio
 from ..engine import PayneEngine
+from .fitutils import polycalc
+
+speedoflight = 299792.458        # km/s, the Doppler constant of getspec (ystpred.py:232)
 
 
 class GenMod(object):
@@ -44,6 +47,7 @@ class GenMod(object):
         """Bind the data side of the fit (observed spectrum / magnitudes, blaze order)."""
         self._obs, self._obs_phot, self._npoly, self._photscale = obs, obs_phot, int(npoly), bool(photscale)
         self._engine = None
+        self._pred = None
 
     def new_engine(self):
         """Another context with the same networks and data (own workspaces: a second batch can be in flight)."""
@@ -72,24 +76,51 @@ class GenMod(object):
         polycoef = pars[8:] if modpoly else []
         if modpoly and len(polycoef) != eng.npoly:
             raise ValueError("engine configured for %d blaze coefficients, got %d" % (eng.npoly, len(polycoef)))
-        th = np.full((1, eng.ncols), np.nan)
-        th[0, :8] = pars[:8]
-        if modpoly:
-            th[0, 8:8 + eng.npoly] = polycoef
+
+        def row(e):
+            th = np.full((1, e.ncols), np.nan)
+            th[0, :8] = pars[:8]
+            if modpoly:
+                th[0, 8:8 + e.npoly] = polycoef
+            return th
+        # the grid the spectrum comes out on: outwave, or the Doppler-shifted model grid (getspec, ystpred.py:232-272)
         if outwave is not None:
-            outwave = np.ascontiguousarray(outwave, dtype=np.float64)
-            if self._obs is None or outwave is not self._obs[0]:
-                if eng.nobs != len(outwave) or not np.array_equal(eng.obs_wave, outwave):
-                    raise ValueError("genspec(outwave=...) must be the grid bound with configure(obs=...)")
+            grid = np.ascontiguousarray(outwave, dtype=np.float64)
+        else:
+            rv = pars[4]
+            grid = eng.wavelength * (1.0 + rv / speedoflight) if rv != 0.0 else eng.wavelength
+            grid = np.ascontiguousarray(grid, dtype=np.float64)
+            smoothed = lsf is not None or (isinstance(pars[7], float) and pars[7] > 0.0)
+            if not smoothed:                               # no instrumental stage: the broadened ANN spectrum as is
+                flux = eng.predict_batch(row(eng), stage=1, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+                if modpoly:
+                    flux = flux * polycalc(polycoef, grid)
+                return grid, flux
+        use = eng
+        if eng.nobs != len(grid) or not np.array_equal(getattr(eng, "obs_wave", None), grid):
+            use = self._prediction_engine(grid)            # another grid than the fit's: its own context
+        if lsf is not None:
+            use.set_lsf(lsf)
+        try:
+            flux = use.predict_batch(row(use), stage=3 if modpoly else 2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+        finally:
             if lsf is not None:
-                eng.set_lsf(lsf)
-            try:
-                flux = eng.predict_batch(th, stage=3 if modpoly else 2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
-            finally:
-                if lsf is not None:
-                    eng.set_lsf(None)
-            return outwave, flux
-        raise NotImplementedError("genspec without outwave: use PayneSpecPredict.getspec")
+                use.set_lsf(None)
+        return grid, flux
+
+    def _prediction_engine(self, grid):
+        """A context of its own for genspec on grids other than the fit's observed grid (the fit's
+        context keeps its observed flux bound); re-bound when the grid changes."""
+        key = (len(grid), float(grid[0]), float(grid[-1]), hash(grid.tobytes()))
+        if getattr(self, "_pred", None) is None:
+            self._pred = PayneEngine(self._spec_net, obs=(grid,), npoly=self._npoly, b_max=1, device=self.device)
+            if getattr(self, "_cont_net", None) is not None:
+                self._pred.set_continuum(self._cont_net)
+            self._pred_key = key
+        elif self._pred_key != key:
+            self._pred.set_obs(grid)
+            self._pred_key = key
+        return self._pred
 
     def _phot_theta(self, pars, scaled):
         eng = self.engine
