@@ -411,8 +411,32 @@ def g10_advanced_priors():
     save("g10_advpriors", **out)
 
 
+# ------------------------------------------------------------------ G11
+def g11_native_grid():
+    """getspec / genspec without an output grid (outwave=None): the spectrum comes back on the Doppler-shifted
+    model grid, with the instrumental stage (smoothspec puts outwave = wave, smoothing.py:140-141; the end pixels
+    fall outside the resampled grid -> NaN) and without it; genspec also with the blaze polynomial."""
+    from Payne.fitting.genmod import GenMod
+    net = synth.make_yst_net(npix=1024, H=64, seed=0, line_depth=0.3)
+    rs.register_yst('/g11/yst.h5', net)
+    GM = GenMod()
+    GM._initspecnn(nnpath='/g11/yst.h5', NNtype='YST1')
+    base = [5600.0, 4.3, -0.2, 0.1]
+    rows = np.array([(12.0, 4.0, 28000.0), (0.0, 0.0, 25000.0), (-40.0, 7.5, 30000.0), (12.0, 4.0, np.nan), (0.0, 3.0, 0.0)])
+    coef = [1.02, 0.03, -0.01]
+    waves, plain, poly = [], [], []
+    for vrad, vrot, R in rows:
+        with np.errstate(all="ignore"):
+            w, f = GM.genspec(base + [vrad, vrot, np.nan, float(R)], outwave=None)
+            w2, f2 = GM.genspec(base + [vrad, vrot, np.nan, float(R)] + coef, outwave=None, modpoly=True)
+        assert np.array_equal(w, w2)
+        waves.append(w); plain.append(f); poly.append(f2)
+    save("g11_native", base=np.array(base), rows=rows, coef=np.array(coef), wave=np.array(waves),
+         plain=np.array(plain), poly=np.array(poly))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors}[k]()
+         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid}[k]()

@@ -151,6 +151,8 @@ def smooth_R(wave, spec, Rsigma, outwave, R_ann, return_parts=False):
     inres = CKMS / R_ann
     mask = mask_range(wave, Rsigma, outwave)
     w, s = wave[mask], np.nan_to_num(spec[mask], nan=1.0)
+    if outwave is None:                              # smoothing.py:140-141: back onto the input grid
+        outwave = wave
     with np.errstate(invalid="ignore"):
         sigma = np.sqrt(sigma_out ** 2 - inres ** 2)
     wr, sr = resample_pow2(w, s)

@@ -152,3 +152,20 @@ def test_g9_lsf(golden):
         w, f = O.getspec(net, rad_vel=8.0, rot_vel=3.0, inst_R=g["lsf_native"], Teff=5300.0, logg=4.1, feh=-0.3, afe=0.15)
     np.testing.assert_allclose(w, g["native_wave"], rtol=1e-15)
     np.testing.assert_allclose(f, g["native"], rtol=1e-10, atol=1e-12)
+
+
+def test_g11_native_grid(golden):
+    """outwave=None: spectrum on the Doppler-shifted model grid, with and without the instrumental stage."""
+    g = golden("g11_native")
+    net = synth.make_yst_net(npix=1024, H=64, seed=0, line_depth=0.3)
+    base, coef = list(g["base"]), list(g["coef"])
+    for i, (vrad, vrot, R) in enumerate(g["rows"]):
+        with np.errstate(all="ignore"):
+            w, f = O.genspec(net, base + [vrad, vrot, np.nan, float(R)], outwave=None)
+            w2, f2 = O.genspec(net, base + [vrad, vrot, np.nan, float(R)] + coef, outwave=None, modpoly=True)
+        np.testing.assert_allclose(w, g["wave"][i], rtol=1e-15)
+        for got, ref in ((f, g["plain"][i]), (f2, g["poly"][i])):
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=0, atol=1e-12)
+    assert np.isnan(g["plain"][0]).sum() == 2          # the end pixels fall outside the resampled grid
