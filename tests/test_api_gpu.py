@@ -291,6 +291,9 @@ def test_smoothspec_on_arbitrary_spectra(tmp_path):
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) < 1e-6
     got = PP.smoothspec(wave, spec, 20000.0, outwave=out, smoothtype='R', fftsmooth=True, inres=60000.0)
     assert np.abs(got - O.smooth_R(wave, spec, 20000.0, out, 60000.0)).max() < 1e-6
+    got = PP.smoothspec(wave, spec, 20000.0, outwave=None, smoothtype='R', inres=60000.0)   # back onto `wave` itself
+    ref = O.smooth_R(wave, spec, 20000.0, None, 60000.0)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) < 1e-6
     got = PP.smoothspec(wave, spec, 25000.0, outwave=out, smoothtype='R')                  # no inres: nothing subtracted
     assert np.abs(got - O.smooth_R(wave, spec, 25000.0, out, np.inf)).max() < 1e-6
     got = PP.smoothspec(wave, spec, 14.0, outwave=out)                                     # default 'vel': sigma in km/s

@@ -106,6 +106,9 @@ class GenMod(object):
         finally:
             if lsf is not None:
                 use.set_lsf(None)
+        if outwave is None and lsf is None:
+            from ..predict._spec import native_grid_edges
+            flux = native_grid_edges(grid, flux)
         return grid, flux
 
     def _prediction_engine(self, grid):

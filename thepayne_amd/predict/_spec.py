@@ -13,6 +13,16 @@ from ..engine import PayneEngine
 speedoflight = 299792.458            # scipy.constants.c / 1000 (ystpred.py:11-12)
 
 
+def native_grid_edges(grid, flux):
+    """smoothspec(outwave=None) interpolates the convolved spectrum from the resampled grid
+    exp(linspace(ln wmin, ln wmax, n)) back onto the input grid itself with left = right = NaN
+    (smoothing.py:140-141, 283-288): an end pixel is NaN whenever exp(log(w)) rounds to the inside of w.
+    The kernel works in ln(lambda) and cannot see that rounding; the same numpy expressions decide here."""
+    lo, hi = np.exp(np.log(grid.min())), np.exp(np.log(grid.max()))
+    flux[(grid < lo) | (grid > hi)] = np.nan
+    return flux
+
+
 class SpecANN(object):
     """The emulator object the reference exposes as ``.anns``: ``Net``
     (ystpred.py:18-58) / ``ANN`` (predictspec.py:29-74).  ``eval(labels)`` returns
@@ -165,7 +175,7 @@ class PayneSpecPredict(object):
             if has_R and inst_R > 0.0:
                 # smoothspec(outwave=None) -> output on the (shifted) model grid itself
                 self._bind(np.ascontiguousarray(modwave))
-                return modwave, eng.predict_batch(th, stage=2).cpu().numpy()[0].astype(np.float64)
+                return modwave, native_grid_edges(modwave, eng.predict_batch(th, stage=2).cpu().numpy()[0].astype(np.float64))
             return modwave, eng.predict_batch(th, stage=1).cpu().numpy()[0].astype(np.float64)
         outwave = np.ascontiguousarray(outwave, dtype=np.float64)
         self._bind(outwave)
@@ -213,8 +223,8 @@ class PayneSpecPredict(object):
         if smoothtype == 'lsf':
             eng.set_lsf(np.atleast_1d(np.asarray(sigma, dtype=np.float64)))
         out = eng.smooth_batch(spec[None, :], th, stage=stage).cpu().numpy()[0].astype(np.float64)
-        if stage == 1:
-            return out
+        if outwave is None and smoothtype in ('vel', 'R'):
+            out = native_grid_edges(wave, out)
         return out
 
     def _smooth_engine(self, wave, r_in):
