@@ -1,0 +1,126 @@
+"""Random API calls through the HIP path against the oracle: the generator of
+oracle/fuzz_vs_reference.py (which checks the oracle against the reference itself) pointed at
+PayneSpecPredict.getspec / GenMod.genspec / likelihood.lnlikefn.  Tolerances of SURVEY 8(d):
+|dflux| <= 1e-6 (2e-6 where the blaze multiplies), NaN patterns identical, |dlnL| <= 2e-6 |lnL| + 5e-3."""
+import numpy as np
+import pytest
+
+import oracle as O
+from thepayne_amd import synth, nnio
+from helpers import lnl_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _save(tmp_path, raw, name):
+    path = str(tmp_path / name)
+    nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
+    return path
+
+
+@pytest.mark.parametrize("D,seed", [(4, 0), (4, 1), (5, 2)])
+def test_random_getspec_calls(tmp_path, D, seed):
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    rng = np.random.default_rng(100 + seed)
+    net = synth.make_yst_net(npix=[512, 700, 1024][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
+    PP = PayneSpecPredict(nnpath=_save(tmp_path, net, "n.npz"), NNtype='YST1')
+    wave = net["wavelength"]
+    alias = {"Teff": ["Teff", "logt"], "logg": ["logg", "log(g)"], "feh": ["feh", "[Fe/H]"],
+             "afe": ["afe", "aFe", "[a/Fe]", "[alpha/Fe]"]}
+    worst = 0.0
+    for it in range(70):
+        kw, canon = {}, {}
+        lab = dict(Teff=rng.uniform(4000, 7500), logg=rng.uniform(0.5, 5.2), feh=rng.uniform(-2, 0.4), afe=rng.uniform(-0.1, 0.5))
+        for k, v in lab.items():
+            if rng.uniform() < 0.15:
+                continue
+            name = alias[k][rng.integers(len(alias[k]))]
+            kw[name] = np.log10(v) if name == "logt" else v
+            canon[k] = 10.0 ** kw[name] if name == "logt" else v
+        if D == 5 or rng.uniform() < 0.2:
+            kw['vmic'] = rng.uniform(0.5, 2.5) if D == 5 else np.nan
+        if rng.uniform() < 0.75:
+            kw['rot_vel'] = [0.0, 1e-3, rng.uniform(0.2, 60.0)][rng.integers(3)]
+        if rng.uniform() < 0.75:
+            kw['rad_vel'] = [0.0, rng.uniform(-300, 300)][rng.integers(2)]
+        nobs = int(rng.integers(50, 400))
+        lo, hi = np.sort(rng.uniform(wave[0] - 2.0, wave[-1] + 2.0, 2))
+        outwave = np.linspace(lo, max(hi, lo + 1.0), nobs) if rng.uniform() < 0.7 else None
+        if outwave is not None:
+            kw['outwave'] = outwave
+        mode = rng.integers(7)
+        if mode in (1, 3):
+            kw['inst_R'] = float(rng.uniform(8000, 60000))
+        elif mode == 2:
+            kw['inst_R'] = [np.nan, 0.0, -5.0, float(net["resolution"]) * 1.2][rng.integers(4)]
+        elif mode == 4 and outwave is not None:
+            x = np.linspace(-0.5, 0.5, nobs)
+            kw['inst_R'] = 0.08 * (1.0 + rng.uniform(-0.5, 0.5) * x + rng.uniform(0, 0.5) * x ** 2)
+        canon.update({k: v for k, v in kw.items() if k in ('vmic', 'rot_vel', 'rad_vel', 'inst_R', 'outwave')})
+        with np.errstate(all="ignore"):
+            w_o, f_o = O.getspec(net, **canon)
+        w, f = PP.getspec(**kw)
+        np.testing.assert_allclose(w, w_o, rtol=1e-15)
+        assert np.array_equal(np.isnan(f), np.isnan(f_o)), (it, {k: v for k, v in kw.items() if np.ndim(v) == 0})
+        ok = ~np.isnan(f_o)
+        if ok.any():
+            err = np.abs(f[ok] - f_o[ok]).max()
+            worst = max(worst, err)
+            tol = 2e-6 if isinstance(kw.get('inst_R'), np.ndarray) else 1e-6
+            assert err <= tol, (it, err, {k: v for k, v in kw.items() if np.ndim(v) == 0})
+    assert worst > 0.0
+
+
+def test_random_likelihood_setups(tmp_path):
+    from thepayne_amd.fitting.likelihood import likelihood
+    rng = np.random.default_rng(77)
+    net = synth.make_yst_net(npix=512, H=32, seed=24, line_depth=0.3)
+    path = _save(tmp_path, net, "like.npz")
+    phot = synth.make_phot_nets()
+    obs = synth.obs_grid(net["wavelength"], 300, inset=1.0)
+    _, clean = O.getspec(net, Teff=5770.0, logg=4.44, feh=0.0, afe=0.0, rad_vel=10.0, rot_vel=3.0, inst_R=2.355 * 28800.0, outwave=obs)
+    flux = clean + rng.normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    obs_phot = {f: [5.0 + 0.1 * i, 0.05] for i, f in enumerate(phot["filters"])}
+    ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', 'log(R)', 'Dist', 'log(A)', 'Av', 'Rv', 'CarbonScale']
+    R = {'Teff': (4500, 7000), 'log(g)': (1.0, 5.0), '[Fe/H]': (-1.5, 0.4), '[a/Fe]': (-0.1, 0.5), 'Vrad': (-50, 50),
+         'Vrot': (0, 30), 'Inst_R': (20000, 40000), 'log(R)': (-0.5, 1.0), 'Dist': (10, 3000), 'log(A)': (-2, 3),
+         'Av': (0, 4.5), 'Rv': (2.2, 4.8)}
+    ncmp = 0
+    for it in range(24):
+        spec = rng.uniform() < 0.8
+        has_phot = (not spec) or rng.uniform() < 0.5
+        photscale = bool(rng.uniform() < 0.5)
+        modpoly = bool(spec and rng.uniform() < 0.4)
+        on = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]']
+        if spec:
+            on += ['Vrad', 'Vrot', 'Inst_R']
+        if has_phot:
+            on += (['log(A)'] if photscale else ['log(R)', 'Dist']) + ['Av']
+            if rng.uniform() < 0.4:
+                on.append('Rv')
+        names = list(ALL) + (['pc_0', 'pc_1', 'pc_2'] if modpoly else [])
+        fixed = {}
+        for name in rng.permutation(on)[:int(rng.integers(0, 3))]:
+            if name != 'Av':
+                fixed[str(name)] = float(rng.uniform(*R[str(name)]))
+        fitpars = [names, {p: ((p in on and p not in fixed) or p.startswith('pc_')) for p in names}]
+        fitargs = {'fixedpars': dict(fixed)}
+        if spec:
+            fitargs.update(obs_wave_fit=obs, obs_flux_fit=flux, obs_eflux_fit=eflux, specANNpath=path, NNtype='YST1')
+        if has_phot:
+            fitargs.update(photANNpath=phot, obs_phot=obs_phot)
+        L = likelihood(fitargs, fitpars, [spec, has_phot, modpoly, photscale, False], b_max=64, verbose=False)
+        OL = O.OracleLikelihood(net if spec else None, obs if spec else None, flux, eflux, L.fitpars_i, fixedpars=fixed,
+                                modpoly=modpoly, phot=dict(phot, hiav=None) if has_phot else None,
+                                obs_phot=obs_phot if has_phot else None, photscale=photscale, spec=spec)
+        theta = np.array([[rng.uniform(0.95, 1.05) if p == 'pc_0' else rng.normal(0, 0.02) if p.startswith('pc_')
+                           else rng.uniform(*R[p]) for p in L.fitpars_i] for _ in range(6)])
+        ref = np.array([OL.lnlikefn(list(t)) for t in theta])
+        got = L.lnlike_batch(theta)
+        one = L.lnlikefn(list(theta[0]))
+        assert np.all(np.abs(got - ref) <= lnl_tol(ref)), (it, L.fitpars_i, fixed, got, ref)
+        assert abs(one - ref[0]) <= lnl_tol(ref[0]) and L.parsdict == {**dict(zip(L.fitpars_i, theta[0])), **fixed}
+        ncmp += len(ref)
+        L.GM.engine.close()
+    assert ncmp == 24 * 6
