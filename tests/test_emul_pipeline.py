@@ -151,3 +151,25 @@ int main() {
     res = subprocess.run([str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "rc=0" in res.stdout
+
+
+@pytest.mark.parametrize("general", [0, 1])
+def test_output_on_the_model_grid_itself(emul, general):
+    """getspec(outwave=None, inst_R=...): the output grid IS the Doppler-shifted model grid, so its end pixels
+    coincide with the ends of the resampled grid.  The reference keeps or drops them by one rounding of
+    exp(log(.)) (the host applies that verdict, predict/_spec.py native_grid_edges); the kernel must treat them
+    as inside and interpolate at position 0 / n-1 -- not wrap to the other end of the convolved buffer."""
+    net = synth.make_yst_net(npix=700, H=32, seed=21, line_depth=0.3)
+    wave = net["wavelength"]
+    for rv, vrot, R in ((-159.20149211002166, 0.0, 33704.72291801852), (0.0, 3.0, 28000.0), (12.0, 4.0, 30000.0),
+                        (250.0, 0.0, 41000.0), (-33.3, 8.0, 22000.0)):
+        grid = np.ascontiguousarray(wave * (1.0 + rv / 299792.458) if rv != 0.0 else wave)
+        th8 = np.array([[5600.0, 4.3, -0.2, 0.1, rv, vrot, np.nan, R]])
+        out, _, _ = emul(net, grid, None, None, th8, 2, factor=1.0, general=general)
+        with np.errstate(all="ignore"):
+            _, ref = O.getspec(net, Teff=5600.0, logg=4.3, feh=-0.2, afe=0.1, rad_vel=rv, rot_vel=vrot, inst_R=R, outwave=None)
+        assert not np.isnan(out[0]).any()
+        ok = ~np.isnan(ref)
+        assert ok.sum() >= len(ref) - 2 and np.abs(out[0][ok] - ref[ok]).max() <= 1e-6
+        # the end pixels are the convolved buffer's own ends, not the wrapped-around other end
+        assert abs(out[0][0] - out[0][1]) < 5e-3 and abs(out[0][-1] - out[0][-2]) < 5e-3

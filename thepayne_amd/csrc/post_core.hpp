@@ -60,6 +60,7 @@ PAYNE_HD c32 cscale(c32 a, float s) { return {a.x * s, a.y * s}; }
 PAYNE_HD c32 cmul_negi(c32 a) { return {a.y, -a.x}; }   // a * (-i)
 PAYNE_HD c32 cmul_posi(c32 a) { return {-a.y, a.x}; }   // a * (+i)
 PAYNE_HD float nanf_() { return __builtin_nanf(""); }
+constexpr double kEdgeTol = 1e-12;   // ln(lambda): a pixel this close to an end of the model grid counts as on it
 PAYNE_HD float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
 PAYNE_HD int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
@@ -909,13 +910,18 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
       if (HASF) { of1[q] = rec.f1; iv[q] = rec.ivar; }
       if (CHEB) xc[q] = T.xcheb[i];
       int k = 0; float ww = 0.f;
+      // np.interp(left=nan, right=nan).  A pixel that coincides with an end of the model grid (output on
+      // the model grid itself) is inside or outside by one rounding of exp(log(.)) in the reference; here it
+      // is always inside (kEdgeTol in ln lambda, ~1e-7 pixel), the host applies numpy's verdict for that case.
       if (MODE == 0) {
-        nanv[q] = (lo < W.lnmin) || (lo > W.lnmax);      // np.interp(left=nan, right=nan)
-        magic_locate(nanv[q] ? kPosMagic : fma(lo, W.obA, obBm), 0, W.n2, W.hs_step, k, ww);
+        nanv[q] = (lo < W.lnmin - kEdgeTol) || (lo > W.lnmax + kEdgeTol);
+        const double lc = fmin(fmax(lo, W.lnmin), W.lnmax);
+        magic_locate(nanv[q] ? kPosMagic : fmax(fma(lc, W.obA, obBm), kPosMagic), 0, W.n2, W.hs_step, k, ww);
       } else {
-        const double v = lo - S.dop;
-        nanv[q] = (v < T.ln0) || (v > T.ln_last);
-        if (MODE == 1) magic_locate(nanv[q] ? kPosMagic : fma(lo, piA, piBm), 0, T.npix, hs_ann, k, ww);
+        const double v0 = lo - S.dop;
+        nanv[q] = (v0 < T.ln0 - kEdgeTol) || (v0 > T.ln_last + kEdgeTol);
+        const double v = fmin(fmax(v0, T.ln0), T.ln_last);
+        if (MODE == 1) magic_locate(nanv[q] ? kPosMagic : fmax(fma(v + S.dop, piA, piBm), kPosMagic), 0, T.npix, hs_ann, k, ww);
         else if (!nanv[q]) search_locate(T, 0, T.npix, v, k, ww);
       }
       a[q] = conv[k]; b[q] = conv[k + 1]; w[q] = ww;
