@@ -28,7 +28,7 @@ def test_random_getspec_calls(tmp_path, D, seed):
     alias = {"Teff": ["Teff", "logt"], "logg": ["logg", "log(g)"], "feh": ["feh", "[Fe/H]"],
              "afe": ["afe", "aFe", "[a/Fe]", "[alpha/Fe]"]}
     worst = 0.0
-    for it in range(70):
+    for it in range(120):
         kw, canon = {}, {}
         lab = dict(Teff=rng.uniform(4000, 7500), logg=rng.uniform(0.5, 5.2), feh=rng.uniform(-2, 0.4), afe=rng.uniform(-0.1, 0.5))
         for k, v in lab.items():
