@@ -18,12 +18,18 @@ def _save(tmp_path, raw, name):
     return path
 
 
-@pytest.mark.parametrize("D,seed", [(4, 0), (4, 1), (5, 2)])
-def test_random_getspec_calls(tmp_path, D, seed):
+@pytest.mark.parametrize("D,seed,cont", [(4, 0, False), (4, 1, False), (5, 2, False), (4, 3, True)])
+def test_random_getspec_calls(tmp_path, D, seed, cont):
     from thepayne_amd.predict.ystpred import PayneSpecPredict
     rng = np.random.default_rng(100 + seed)
-    net = synth.make_yst_net(npix=[512, 700, 1024][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
-    PP = PayneSpecPredict(nnpath=_save(tmp_path, net, "n.npz"), NNtype='YST1')
+    net = synth.make_yst_net(npix=[512, 700, 1024, 600][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
+    cnet = None
+    if cont:                                           # continuum network on its own, coarser grid (Cnnpath)
+        w = net["wavelength"]
+        cnet = synth.make_cont_net(npix=311, lam_lo=w[0] - 1.0, lam_hi=w[-1] + 1.0)
+        PP = PayneSpecPredict(nnpath=_save(tmp_path, net, "n.npz"), Cnnpath=_save(tmp_path, cnet, "c.npz"), NNtype='YST1')
+    else:
+        PP = PayneSpecPredict(nnpath=_save(tmp_path, net, "n.npz"), NNtype='YST1')
     wave = net["wavelength"]
     alias = {"Teff": ["Teff", "logt"], "logg": ["logg", "log(g)"], "feh": ["feh", "[Fe/H]"],
              "afe": ["afe", "aFe", "[a/Fe]", "[alpha/Fe]"]}
@@ -58,7 +64,7 @@ def test_random_getspec_calls(tmp_path, D, seed):
             kw['inst_R'] = 0.08 * (1.0 + rng.uniform(-0.5, 0.5) * x + rng.uniform(0, 0.5) * x ** 2)
         canon.update({k: v for k, v in kw.items() if k in ('vmic', 'rot_vel', 'rad_vel', 'inst_R', 'outwave')})
         with np.errstate(all="ignore"):
-            w_o, f_o = O.getspec(net, **canon)
+            w_o, f_o = O.getspec(net, cnet=cnet, **canon)
         w, f = PP.getspec(**kw)
         np.testing.assert_allclose(w, w_o, rtol=1e-15)
         assert np.array_equal(np.isnan(f), np.isnan(f_o)), (it, {k: v for k, v in kw.items() if np.ndim(v) == 0})
