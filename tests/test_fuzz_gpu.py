@@ -63,8 +63,14 @@ def test_random_getspec_calls(tmp_path, D, seed, cont):
             x = np.linspace(-0.5, 0.5, nobs)
             kw['inst_R'] = 0.08 * (1.0 + rng.uniform(-0.5, 0.5) * x + rng.uniform(0, 0.5) * x ** 2)
         canon.update({k: v for k, v in kw.items() if k in ('vmic', 'rot_vel', 'rad_vel', 'inst_R', 'outwave')})
-        with np.errstate(all="ignore"):
-            w_o, f_o = O.getspec(net, cnet=cnet, **canon)
+        try:
+            with np.errstate(all="ignore"):
+                w_o, f_o = O.getspec(net, cnet=cnet, **canon)
+        except ValueError:
+            # an output grid that misses the shifted model entirely: numpy reduces an empty mask and raises
+            # (the reference does); the documented deviation of the build is an all-NaN spectrum
+            assert np.isnan(PP.getspec(**kw)[1]).all()
+            continue
         w, f = PP.getspec(**kw)
         np.testing.assert_allclose(w, w_o, rtol=1e-15)
         assert np.array_equal(np.isnan(f), np.isnan(f_o)), (it, {k: v for k, v in kw.items() if np.ndim(v) == 0})
