@@ -146,3 +146,40 @@ def test_random_likelihood_setups(tmp_path):
         ncmp += len(ref)
         L.GM.engine.close()
     assert ncmp >= 18 * 6
+
+
+def test_random_sed_calls():
+    """FastPayneSEDPredict.sed / GenMod.genphot(_scaled) on random arguments (both sides of av = 5, both
+    magnitude formulae) against the oracle."""
+    from thepayne_amd.predict.predictsed import FastPayneSEDPredict
+    from thepayne_amd.fitting.genmod import GenMod
+    rng = np.random.default_rng(55)
+    phot = synth.make_phot_nets()
+    S = FastPayneSEDPredict(usebands=phot["filters"], nnpath=phot)
+    oph = dict(phot)
+    oph["hiav"] = np.array(S.HiAv.Avlist, dtype=float)
+    GM = GenMod()
+    GM._initphotnn(phot["filters"], nnpath=phot)
+    for it in range(80):
+        logt, logg = np.log10(rng.uniform(3500, 9000)), rng.uniform(0, 5)
+        feh, afe = rng.uniform(-2, 0.5), rng.uniform(-0.2, 0.6)
+        av = [rng.uniform(0, 4.99), 5.0, rng.uniform(5.0, 9.0)][rng.integers(3)]
+        kw = dict(logt=logt, logg=logg, feh=feh, afe=afe, av=av)
+        if rng.uniform() < 0.6:
+            kw['rv'] = rng.uniform(2.2, 4.8)
+        if rng.uniform() < 0.5:
+            kw.update(logl=rng.uniform(-1, 2), dist=rng.uniform(5, 5000))
+        else:
+            kw['logA'] = rng.uniform(-2, 3)
+        ref = O.sed_mags(oph, logt, logg, feh, afe, **{k: v for k, v in kw.items() if k in ('av', 'rv', 'logl', 'dist', 'logA')})
+        got = S.sed(**kw)
+        assert np.abs(np.asarray(got) - ref).max() < 1e-9, (it, kw)
+        if av < 5.0:
+            p = [10.0 ** logt, logg, feh, afe, rng.uniform(-0.5, 1.0), rng.uniform(10, 3000), av]
+            ref = O.genphot(oph, p)
+            got = GM.genphot(p)
+            assert np.abs(np.array([got[f] for f in phot["filters"]]) - ref).max() < 1e-9
+            p = [10.0 ** logt, logg, feh, afe, rng.uniform(-2, 3), av]
+            ref = O.genphot_scaled(oph, p)
+            got = GM.genphot_scaled(p)
+            assert np.abs(np.array([got[f] for f in phot["filters"]]) - ref).max() < 1e-9
