@@ -183,3 +183,64 @@ def test_random_sed_calls():
             ref = O.genphot_scaled(oph, p)
             got = GM.genphot_scaled(p)
             assert np.abs(np.array([got[f] for f in phot["filters"]]) - ref).max() < 1e-9
+
+
+def test_random_prior_dictionaries_on_the_device(tmp_path):
+    """Random priordicts (a random pv_* kind with random parameters per sampled dimension, random additional
+    'gaussian' / 'uniform' terms): the device transform and ln-prior against the host prior object, which is
+    pinned to the reference by tests/golden/g6_prior.npz."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    from thepayne_amd.sampler.device import DeviceProposer
+    from test_api_gpu import _fit_objects
+    from test_sampler_gpu import _clone_prior
+    rng = np.random.default_rng(808)
+    centre = {'Teff': 5800.0, 'log(g)': 4.3, '[Fe/H]': -0.1, '[a/Fe]': 0.1, 'Vrad': 10.0, 'Vrot': 4.0, 'Inst_R': 29000.0,
+              'log(A)': 0.2, 'log(R)': 0.1, 'Dist': 300.0, 'Av': 0.6}
+    width = {'Teff': 400.0, 'log(g)': 0.3, '[Fe/H]': 0.2, '[a/Fe]': 0.1, 'Vrad': 3.0, 'Vrot': 2.0, 'Inst_R': 2000.0,
+             'log(A)': 0.3, 'log(R)': 0.2, 'Dist': 100.0, 'Av': 0.3}
+    for photscale in (True, False):
+        L, P0, _ = _fit_objects(tmp_path, photscale=photscale)
+        for trial in range(6):
+            pd = {}
+            for par in L.fitpars_i:
+                c, w = centre[par], width[par]
+                kinds = ['uniform', 'gaussian', 'tgaussian', 'default']
+                if par in ('Vrot', 'Av', 'Dist'):
+                    kinds += ['exp', 'texp']
+                kind = kinds[rng.integers(len(kinds))]
+                spec = {}
+                if kind == 'uniform':
+                    spec['pv_uniform'] = [c - 2 * w, c + 2 * w]
+                elif kind == 'gaussian':
+                    spec['pv_gaussian'] = [c + rng.normal(0, 0.2) * w, w * rng.uniform(0.3, 1.5)]
+                elif kind == 'tgaussian':
+                    spec['pv_tgaussian'] = [c - rng.uniform(0.5, 3) * w, c + rng.uniform(0.5, 3) * w, c, w * rng.uniform(0.3, 2)]
+                elif kind == 'exp':
+                    spec['pv_exp'] = [max(0.0, c - 2 * w), w]
+                elif kind == 'texp':
+                    spec['pv_texp'] = [max(0.0, c - 2 * w), c + 3 * w, w]
+                if rng.uniform() < 0.3:
+                    spec['gaussian'] = [c, w * rng.uniform(0.5, 2)]
+                if rng.uniform() < 0.2:
+                    spec['uniform'] = [c - 1.5 * w, c + 1.5 * w]
+                if spec:
+                    pd[par] = spec
+            P = _clone_prior(P0, pd)
+            prop = DeviceProposer(L, P, k_max=64)
+            U = rng.uniform(size=(64, L.ndim))
+            U[:4] = np.clip(U[:4], 1e-9, 1 - 1e-9)
+            U[0, :] = 1e-7
+            U[1, :] = 1 - 1e-7
+            with np.errstate(all="ignore"):
+                host_v = P.priortrans_batch(U)
+                V = prop.prior_transform(U)
+            np.testing.assert_allclose(V, host_v, rtol=2e-9, atol=1e-9, err_msg=str(pd))
+            V2, lp = prop.lnprob_u(U)
+            np.testing.assert_allclose(V2, host_v, rtol=2e-9, atol=1e-9)
+            with np.errstate(all="ignore"):
+                ref = lnprob_batch(V2, L, P)
+            assert np.array_equal(np.isneginf(lp), np.isneginf(ref)) and np.array_equal(np.isnan(lp), np.isnan(ref))
+            ok = np.isfinite(ref)
+            assert np.all(np.abs(lp[ok] - ref[ok]) <= 1e-9 * np.abs(ref[ok]) + 1e-6), (pd, np.abs(lp[ok] - ref[ok]).max())
+            prop.close()
+        L.GM.engine.close()
