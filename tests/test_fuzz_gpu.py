@@ -10,6 +10,7 @@ from thepayne_amd import synth, nnio
 from helpers import lnl_tol
 
 pytestmark = pytest.mark.gpu
+SEED0 = int(__import__("os").environ.get("PAYNE_FUZZ_SEED", "0"))      # another stream of random calls: PAYNE_FUZZ_SEED=n
 
 
 def _save(tmp_path, raw, name):
@@ -21,7 +22,7 @@ def _save(tmp_path, raw, name):
 @pytest.mark.parametrize("D,seed,cont", [(4, 0, False), (4, 1, False), (5, 2, False), (4, 3, True)])
 def test_random_getspec_calls(tmp_path, D, seed, cont):
     from thepayne_amd.predict.ystpred import PayneSpecPredict
-    rng = np.random.default_rng(100 + seed)
+    rng = np.random.default_rng(100 + seed + 1000 * SEED0)
     net = synth.make_yst_net(npix=[512, 700, 1024, 600][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
     cnet = None
     if cont:                                           # continuum network on its own, coarser grid (Cnnpath)
@@ -85,7 +86,7 @@ def test_random_getspec_calls(tmp_path, D, seed, cont):
 
 def test_random_likelihood_setups(tmp_path):
     from thepayne_amd.fitting.likelihood import likelihood
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + 1000 * SEED0)
     net = synth.make_yst_net(npix=512, H=32, seed=24, line_depth=0.3)
     path = _save(tmp_path, net, "like.npz")
     phot = synth.make_phot_nets()
@@ -153,7 +154,7 @@ def test_random_sed_calls():
     magnitude formulae) against the oracle."""
     from thepayne_amd.predict.predictsed import FastPayneSEDPredict
     from thepayne_amd.fitting.genmod import GenMod
-    rng = np.random.default_rng(55)
+    rng = np.random.default_rng(55 + 1000 * SEED0)
     phot = synth.make_phot_nets()
     S = FastPayneSEDPredict(usebands=phot["filters"], nnpath=phot)
     oph = dict(phot)
@@ -193,7 +194,7 @@ def test_random_prior_dictionaries_on_the_device(tmp_path):
     from thepayne_amd.sampler.device import DeviceProposer
     from test_api_gpu import _fit_objects
     from test_sampler_gpu import _clone_prior
-    rng = np.random.default_rng(808)
+    rng = np.random.default_rng(808 + 1000 * SEED0)
     centre = {'Teff': 5800.0, 'log(g)': 4.3, '[Fe/H]': -0.1, '[a/Fe]': 0.1, 'Vrad': 10.0, 'Vrot': 4.0, 'Inst_R': 29000.0,
               'log(A)': 0.2, 'log(R)': 0.1, 'Dist': 300.0, 'Av': 0.6}
     width = {'Teff': 400.0, 'log(g)': 0.3, '[Fe/H]': 0.2, '[a/Fe]': 0.1, 'Vrad': 3.0, 'Vrot': 2.0, 'Inst_R': 2000.0,
