@@ -8,7 +8,7 @@ announces for its mock run, runPayne.py:17-19; obs_eflux = flux / 25, runPayne.p
 FitPayne the same `inputdict` the reference script assembles (runPayne.py:38-150): every
 likelihood call of the nested sampler is then a batch on the GPU.
 
-    python demo/runPayne.py [--phot] [--dynamic] [--npix 4096] [--npoints 125] [--out demo_sun.dat]
+    python demo/run_mock_sun.py [--phot] [--dynamic] [--npix 4096] [--npoints 125] [--out demo_sun.dat]
 """
 import argparse
 import os
@@ -33,11 +33,8 @@ def main():
     ap.add_argument("--out", default="demo_sun.dat")
     a = ap.parse_args()
 
-    print('-------- RUNNING MOCK SOLAR DEMO ---------')
-    print('----- Teff = 5770.0, log(g) = 4.44 -------')
-    print('-----  [Fe/H] = 0.0, log(A) = 0.0  -------')
-    print('  ---- Running Spec: True')
-    print('  ---- Running Phot: {}'.format(a.phot))
+    print('mock solar fit on synthetic networks: Teff 5770, log g 4.44, [Fe/H] 0, Vrad 10, Vrot 3, R 28800')
+    print('spectrum: yes   photometry: {0}   sampler: {1}'.format('yes' if a.phot else 'no', 'Dynamic' if a.dynamic else 'Static'))
 
     # the networks: files in the reference's key layout (npz instead of HDF5: no h5py here)
     tmp = tempfile.mkdtemp()
@@ -83,11 +80,9 @@ def main():
     inputdict['output'] = a.out
 
     FS = fitstar.FitPayne()
-    print('---------------')
-    print('    PRIORS     ')
+    print('priors:')
     for kk, vv in inputdict['priordict'].items():
-        print('       {0}: {1}'.format(kk, vv))
-    print('--------------')
+        print('   {0:>8s}  {1}'.format(kk, vv))
     sys.stdout.flush()
     result = FS.run(inputdict=inputdict)
     summ = result.summary()
