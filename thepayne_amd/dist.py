@@ -25,14 +25,20 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if ndev > 0 else "gloo"
+            if ndev > 0 and local_world > ndev:
+                # more ranks than GPUs (two stars per GPU keep two independent batches in flight: 13.6 M against
+                # 10.6 M evaluations/s per MI355X): RCCL refuses two ranks on one device ("Duplicate GPU detected"),
+                # and the only collective is a < 1 KiB gather -- it goes over gloo, the GPUs stay compute-only
+                backend = "gloo"
         kw = {}
-        if backend == "nccl":
-            # more ranks than GPUs is fine and useful: two stars per GPU keep two independent batches in flight
-            # (13.6 M against 10.6 M evaluations/s per MI355X at the 4096-pixel / 512-candidate size)
-            local_rank = local_rank % max(1, torch.cuda.device_count())
+        if ndev > 0:
+            local_rank = local_rank % ndev
             torch.cuda.set_device(local_rank)
+        if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
