@@ -281,6 +281,12 @@ int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_v, double* 
 int payne_ns_bound(const double* u, int n, int ndim, double enlarge, int multi, int max_ell, double* ctr,
                    double* axes, double* axes_unit, double* ainv, double* logvol, int* n_ell);
 
+/* Text rows of the output table (fitstar.py:345-371: "Iter <pars> log(lk) log(vol) log(wt) h nc log(z)
+ * delta(log(z))", every value as Python's str() writes it): vals host fp64 [m][ncol], is_int[c] marks integer
+ * columns; each value is followed by a blank, each row by a newline.  Returns bytes written (< 0: error; 48
+ * bytes per value always suffice). */
+long long payne_format_rows(const double* vals, int m, int ncol, const int* is_int, char* out, long long cap);
+
 /* payne_rwalk_batch in two parts: `begin` takes the same arguments and enqueues the set-up, `step(s, w)` for
  * w = 0 .. walks enqueues one step (settle proposal w-1, draw and evaluate proposal w; the last only settles).
  * A caller driving several samplers (one context and one stream each) interleaves their steps from one host

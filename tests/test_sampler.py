@@ -131,6 +131,22 @@ def test_fitpayne_bulk_rows_equal_single_rows(tmp_path):
         F._row(11 + i, rec["v"][i], (rec["logl"][i], rec["logvol"][i], rec["logwt"][i], rec["h"][i], rec["nc"][i],
                                      rec["logz"][i], rec["delta_logz"][i]))
     assert bulk == F.outff.getvalue() and bulk.count('\n') == m
+    assert F._row_formatter() is not None                        # ... and the bulk text came from payne_format_rows
+    # values str() writes in every notation, an integer-valued fixed parameter, and the Python fall-back (a vector)
+    rec["v"][:, 0] = [0.0, -0.0, 1e-5, 1e-4, 1e15, 1e16, 123456789012345680.0]
+    rec["logl"][:] = [np.nan, np.inf, -np.inf, 5e-324, 1.7976931348623157e308, -2.5e-300, 1 / 3]
+    for fixed in ({'[Fe/H]': 2, 'Vrad': 3.0}, {'[Fe/H]': np.float64(0.1), 'Vrad': np.array([0.5, 0.25])}):
+        F.fitargs_fixed = fixed
+        F.parnames = list(F.parnames)                            # a new fit: the formatter is chosen again
+        F.outff = io.StringIO()
+        F._rows(0, rec)
+        bulk = F.outff.getvalue()
+        F.outff = io.StringIO()
+        for i in range(m):
+            F._row(i, rec["v"][i], (rec["logl"][i], rec["logvol"][i], rec["logwt"][i], rec["h"][i], rec["nc"][i],
+                                    rec["logz"][i], rec["delta_logz"][i]))
+        assert bulk == F.outff.getvalue()
+        assert (F._row_formatter() is None) == isinstance(fixed['Vrad'], np.ndarray)
 
 
 def test_ns_consume_stop_conditions():

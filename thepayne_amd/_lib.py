@@ -18,7 +18,7 @@ SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
-           "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_ns_consume", "payne_ns_bound"]
+           "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_ns_consume", "payne_ns_bound", "payne_format_rows"]
 
 PAYNE_MAX_DIM, PAYNE_MAX_FIXED = 24, 16
 PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_TGAUSSIAN, PRIOR_EXP, PRIOR_TEXP, PRIOR_LOGUNIFORM = range(6)
@@ -158,6 +158,8 @@ def load(path=None):
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     lib.payne_ns_bound.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, ip]
     lib.payne_ns_bound.restype = C.c_int
+    lib.payne_format_rows.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_longlong]
+    lib.payne_format_rows.restype = C.c_longlong
     lib.payne_ns_consume.argtypes = [C.POINTER(NsState), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_double,
                                      C.c_longlong, C.c_double, C.POINTER(NsDead), C.c_int, ip, ip]
     lib.payne_ns_consume.restype = C.c_int

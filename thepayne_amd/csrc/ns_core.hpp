@@ -15,6 +15,8 @@
 #pragma once
 #include <math.h>
 
+#include <charconv>
+#include <cstring>
 #include <vector>
 
 #include "../../include/payne_hip.h"
@@ -266,4 +268,84 @@ extern "C" int payne_ns_bound(const double* u, int n, int ndim, double enlarge, 
   }
   *n_ell = E;
   return PAYNE_OK;
+}
+
+// ---- text rows of the output table -----------------------------------------------------------
+// The reference writes one row per dead point with Python's str() of every value
+// (Payne/fitting/fitstar.py:345-371): shortest round-trip digits, fixed notation with a trailing ".0" for
+// integers while -4 < decimal-point position <= 16, otherwise d.ddde+XX.  Formatting ~140 k values per fit in
+// Python costs as much as the sampling itself on the GPU; this is the same text from std::to_chars.
+namespace payne_ns {
+
+inline size_t py_float_repr(double x, char* out) {      // out: >= 32 bytes
+  if (x != x) { memcpy(out, "nan", 3); return 3; }
+  size_t n = 0;
+  if (signbit(x)) { out[n++] = '-'; x = -x; }
+  if (isinf(x)) { memcpy(out + n, "inf", 3); return n + 3; }
+  char buf[40];
+  const auto r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest
+  char digits[24];
+  int nd = 0, e10 = 0;
+  const char* p = buf;
+  for (; p < r.ptr && *p != 'e'; ++p)
+    if (*p != '.') digits[nd++] = *p;
+  if (p < r.ptr) {
+    ++p;
+    const bool neg = (*p == '-');
+    if (*p == '+' || *p == '-') ++p;
+    for (; p < r.ptr; ++p) e10 = 10 * e10 + (*p - '0');
+    if (neg) e10 = -e10;
+  }
+  while (nd > 1 && digits[nd - 1] == '0') --nd;          // (to_chars never pads, but keep the invariant)
+  const int decpt = e10 + 1;
+  if (decpt > -4 && decpt <= 16) {
+    if (decpt <= 0) {
+      out[n++] = '0'; out[n++] = '.';
+      for (int i = 0; i < -decpt; ++i) out[n++] = '0';
+      memcpy(out + n, digits, nd); n += nd;
+    } else if (decpt >= nd) {
+      memcpy(out + n, digits, nd); n += nd;
+      for (int i = nd; i < decpt; ++i) out[n++] = '0';
+      out[n++] = '.'; out[n++] = '0';
+    } else {
+      memcpy(out + n, digits, decpt); n += decpt;
+      out[n++] = '.';
+      memcpy(out + n, digits + decpt, nd - decpt); n += nd - decpt;
+    }
+    return n;
+  }
+  out[n++] = digits[0];
+  if (nd > 1) { out[n++] = '.'; memcpy(out + n, digits + 1, nd - 1); n += nd - 1; }
+  out[n++] = 'e';
+  out[n++] = e10 < 0 ? '-' : '+';
+  const int ae = e10 < 0 ? -e10 : e10;
+  if (ae >= 100) out[n++] = (char)('0' + ae / 100);
+  out[n++] = (char)('0' + (ae / 10) % 10);
+  out[n++] = (char)('0' + ae % 10);
+  return n;
+}
+
+}  // namespace payne_ns
+
+// vals [m][ncol] row-major; is_int[c] != 0: the column is written as an integer.  Every value is followed by
+// one blank, every row by a newline (the reference's row text).  Returns the number of bytes written, or
+// PAYNE_E_INVALID if `cap` is too small (48 bytes per value are always enough).
+extern "C" long long payne_format_rows(const double* vals, int m, int ncol, const int* is_int, char* out, long long cap) {
+  if (!vals || !is_int || !out || m < 0 || ncol <= 0) return PAYNE_E_INVALID;
+  long long n = 0;
+  for (int i = 0; i < m; ++i) {
+    for (int c = 0; c < ncol; ++c) {
+      if (cap - n < 48) return PAYNE_E_INVALID;
+      const double v = vals[(size_t)i * ncol + c];
+      if (is_int[c]) {
+        const auto r = std::to_chars(out + n, out + n + 32, (long long)v);
+        n = r.ptr - out;
+      } else {
+        n += (long long)payne_ns::py_float_repr(v, out + n);
+      }
+      out[n++] = ' ';
+    }
+    out[n++] = '\n';
+  }
+  return n;
 }

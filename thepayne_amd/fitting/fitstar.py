@@ -11,6 +11,8 @@ point, header ``Iter <pars> log(lk) log(vol) log(wt) h nc log(z) delta(log(z))``
 import sys
 from datetime import datetime
 
+import ctypes as C
+
 import numpy as np
 
 from .fitutils import airtovacuum
@@ -188,9 +190,28 @@ class FitPayne(object):
         self.outff.write('\n')
 
     def _rows(self, it0, rec):
-        """The rows of one chunk of dead points, same text as ``_row`` one by one."""
+        """The rows of one chunk of dead points, same text as ``_row`` one by one.  Formatted by the library
+        (payne_format_rows: Python's str() of every value, from std::to_chars) when every fixed parameter is a
+        plain number; in Python otherwise."""
         names, fixed = self.likeobj.fitpars_i, self.fitargs_fixed
         col = {pp: j for j, pp in enumerate(names)}
+        m = len(rec["logl"])
+        fmt = self._row_formatter()
+        if fmt is not None and m:
+            lib, is_int, src = fmt
+            M = np.empty((m, len(is_int)))
+            M[:, 0] = np.arange(it0, it0 + m)
+            for j, (kind, val) in enumerate(src):
+                M[:, 1 + j] = rec["v"][:, val] if kind == 'v' else val
+            k = 1 + len(src)
+            for j, key in enumerate(("logl", "logvol", "logwt", "h", "nc", "logz", "delta_logz")):
+                M[:, k + j] = rec[key]
+            if len(self._row_buf) < 48 * M.size + 16:
+                self._row_buf = C.create_string_buffer(48 * M.size + 16)
+            n = lib.payne_format_rows(M.ctypes.data, m, M.shape[1], is_int.ctypes.data, self._row_buf, len(self._row_buf))
+            if n >= 0:
+                self.outff.write(self._row_buf.raw[:n].decode('ascii'))
+                return
         V = rec["v"].tolist()
         tail = zip(rec["logl"].tolist(), rec["logvol"].tolist(), rec["logwt"].tolist(), rec["h"].tolist(),
                    rec["nc"].tolist(), rec["logz"].tolist(), rec["delta_logz"].tolist())
@@ -200,6 +221,33 @@ class FitPayne(object):
             pars = ' '.join([fixed_s[q] if q in fixed_s else str(v[col[q]]) for q in self.parnames])
             lines.append('{0} {1} {2} {3} {4} {5} {6} {7} {8} \n'.format(it0 + i, pars, *t))
         self.outff.write(''.join(lines))
+
+    def _row_formatter(self):
+        """(library, integer-column flags, source of every parameter column) or None (Python formatting)."""
+        if getattr(self, "_row_fmt_for", None) is self.parnames:
+            return self._row_fmt
+        self._row_fmt_for, self._row_fmt, self._row_buf = self.parnames, None, b""
+        try:
+            from .. import _lib
+            lib = _lib.load()
+        except Exception:
+            return None
+        names, fixed = self.likeobj.fitpars_i, self.fitargs_fixed
+        col = {pp: j for j, pp in enumerate(names)}
+        src, ints = [], [1]
+        for q in self.parnames:
+            if q in fixed:
+                v = fixed[q]
+                if isinstance(v, bool) or not isinstance(v, (int, float, np.integer, np.floating)):
+                    return None                              # an LSF vector, a string, ...: str() of it in Python
+                src.append(('c', float(v)))
+                ints.append(1 if isinstance(v, (int, np.integer)) else 0)
+            else:
+                src.append(('v', col[q]))
+                ints.append(0)
+        ints += [0, 0, 0, 0, 1, 0, 0]
+        self._row_fmt = (lib, np.array(ints, dtype=np.int32), src)
+        return self._row_fmt
 
     def _runsampler(self, samplerdict):
         npoints = samplerdict.get('npoints', 200)
