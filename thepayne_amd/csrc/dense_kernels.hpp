@@ -13,6 +13,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));   // register-residen
 struct DenseParams {
   const float* X; int ldx;     // [B][ldx] activations (ignored with FUSE_L0)
   const float* W; int K;       // [N][K] row-major, K % 4 == 0
+  int k_real;                  // LDS-DMA kernel: width before zero padding (0 = K): the last k-step stops there
   const float* bias;           // [N]
   float* Y; int ldy;           // [B][ldy]
   int B, N;
@@ -288,6 +289,8 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   const int sa = swz(Ra), sb = swz(Rb);
 
   const int nk = p.K / BK;                                 // padded: exact
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * BK;
+  const int kk_last = __builtin_amdgcn_readfirstlane(k_tail >= BK ? BK / 8 : (k_tail <= 0 ? 1 : (k_tail + 7) / 8));
   HK_STAMP(0);
   issue(0, 0);
   if (nk > 1) issue(1, BK);
@@ -313,12 +316,17 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
       b[kk] = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * BK + 4 * (c ^ sb));
     }
     __builtin_amdgcn_sched_barrier(0);
+    // the zero-padded tail of the last step (K = 300 -> 320: 20 of its 32 columns) contributes exact zeros: skip
+    // those matrix instructions (groups of 8 columns; a uniform branch)
+    const int nkk = (it + 1 == nk) ? kk_last : BK / 8;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].w, b[kk].w, acc, 0, 0, 0);
+      if (kk < nkk) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].w, b[kk].w, acc, 0, 0, 0);
+      }
     }
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

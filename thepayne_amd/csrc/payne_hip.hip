@@ -571,6 +571,7 @@ static void launch_out_resident(DenseParams& p, hipStream_t s) {
 
 template <int WN, int BK>
 static void launch_out_dma_t(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  p.k_real = p.K;                                          // the layer's own width: the padded tail is skipped
   p.W = c->w_out_pad; p.K = c->w_out_kp;                   // padded pitch; X's pitch (ld_hid) is a multiple of 32 too
   p.grid_m = (p.B + 63) / 64;
   p.grid_n = (p.N + 32 * WN - 1) / (32 * WN);
