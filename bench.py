@@ -210,8 +210,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    for l_ in lnls:
-        assert os.environ.get("PAYNE_SKIP") or bool(torch.equal(l_, lnl)) or S == 1 or True
+    for l_ in lnls[1:]:                  # every in-flight batch evaluated the same candidates: same answers
+        assert os.environ.get("PAYNE_SKIP") or bool(torch.equal(torch.nan_to_num(l_), torch.nan_to_num(lnl)))
     assert os.environ.get("PAYNE_SKIP") or int(torch.isfinite(lnl).sum()) >= B - 4, "non-finite lnL in the benchmark batch"   # Inst_R tail draws are NaN by contract
 
     # ---- per-kernel device time (HIP events on the launch stream), same K steps replayed
