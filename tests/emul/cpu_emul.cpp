@@ -20,6 +20,8 @@ struct HostExec {
   int nthreads() const { return nthr; }
   void mark(int) {}
   template <class F> void single(F&& f) { f(nthr); }
+  c32* tile_ = nullptr;                                    // scratch of the four-step transform (null: plain passes)
+  c32* tile() const { return tile_; }
   static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
   static const c32* twid(const c32* p) { return p; }
 };
@@ -54,6 +56,11 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.npoly = npoly;
   if (force_general) { T.geo = 0; T.rot_identity = 0; }
   HostExec ex{nthreads};
+  std::vector<c32> tilebuf;
+  if (force_general == 2) {                                // + the four-step transform of the global-workspace kernel
+    tilebuf.resize(2 * (size_t)fft_tile_complex());
+    ex.tile_ = tilebuf.data();
+  }
   std::vector<float> a(fft_buf_floats(H.n1)), b(fft_buf_floats(H.n1));
   std::vector<double> red(scratch_doubles(nthreads));
   const bool fixed = (nthreads == kPostThreads) && !force_general;

@@ -173,3 +173,22 @@ def test_output_on_the_model_grid_itself(emul, general):
         assert ok.sum() >= len(ref) - 2 and np.abs(out[0][ok] - ref[ok]).max() <= 1e-6
         # the end pixels are the convolved buffer's own ends, not the wrapped-around other end
         assert abs(out[0][0] - out[0][1]) < 5e-3 and abs(out[0][-1] - out[0][-2]) < 5e-3
+
+
+@pytest.mark.parametrize("npix,nobs", [(20000, 3000), (40000, 5000), (70000, 4000)])
+def test_four_step_transform_of_the_big_kernel(emul, npix, nobs):
+    """Spectra larger than LDS (payne_post_big_kernel): the four-step transform (512-point sub-transforms in an
+    LDS tile, M = 512 x {32, 64, 128}) against the runtime-geometry passes and against the oracle."""
+    net = synth.make_yst_net(npix=npix, lam0=4000.0, R_fwhm=100000.0, H=8, seed=3, line_depth=0.3)
+    obs = synth.obs_grid(net["wavelength"], nobs, inset=0.0005, relative=True)
+    th8 = np.array([[5600.0, 4.3, -0.2, 0.1, 12.0, 6.0, np.nan, 60000.0],
+                    [6200.0, 3.8, -0.8, 0.2, -35.0, 0.0, np.nan, 80000.0]])
+    plain, _, info0 = emul(net, obs, None, None, th8, 2, factor=1.0, general=1, nthreads=512)
+    tiled, _, info1 = emul(net, obs, None, None, th8, 2, factor=1.0, general=2, nthreads=512)
+    assert np.array_equal(info0, info1) and np.array_equal(np.isnan(plain), np.isnan(tiled))
+    assert 0.0 < np.nanmax(np.abs(plain - tiled)) < 5e-7          # same arithmetic up to the order of the twiddles
+    for i, t in enumerate(th8):
+        with np.errstate(all="ignore"):
+            _, ref = O.getspec(net, Teff=t[0], logg=t[1], feh=t[2], afe=t[3], rad_vel=t[4], rot_vel=t[5], inst_R=t[7], outwave=obs)
+        assert np.array_equal(np.isnan(tiled[i]), np.isnan(ref))
+        assert np.nanmax(np.abs(tiled[i] - ref)) <= 1e-6

@@ -836,7 +836,15 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
     ProfScope ps(c, s, 1);
     if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
-      PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, s, c->T, a, c->big_ws, B);
+      static int tiled = -1;                               // PAYNE_BIG_TILED=0: the runtime-geometry passes only
+      if (tiled < 0) {
+        const char* e = getenv("PAYNE_BIG_TILED");
+        tiled = e ? atoi(e) : 1;
+        if (tiled) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_big_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * fft_tile_complex() * sizeof(c32)));
+      }
+      const size_t lds = tiled ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
+      PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
       PAYNE_LAUNCH((stage < 0 && !out && a.prep) ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
     }

@@ -194,6 +194,108 @@ PAYNE_HD void fft_pass(int tid, int nthr, const c32* __restrict__ src, c32* __re
 }
 PAYNE_HD int pass_radix(int M, int p) { int rem = M / p; return rem >= 8 ? 8 : rem; }
 
+// ---------------------------------------------------------------------------
+// Four-step form of the same transform for spectra that live in a GLOBAL workspace (payne_post_big_kernel):
+// M = 512 B.  Step 1: the B columns x[c + B m] get a 512-point transform each, 16 columns at a time in an LDS
+// tile (three radix-8 passes: global -> X -> Y -> global), written as y[512 c + q].  Step 2: for every k the
+// B values y[k + 512 m] are multiplied by W_M^(k m) and get a B-point transform, 64 k at a time (two or three
+// passes through LDS), written to out[k + 512 q].  Two round trips through memory instead of log8(M):
+// the runtime-geometry passes of fft_pass move the whole spectrum once per radix-8 pass.
+// Tile layouts: step 1 X/Y[cc * kTileLd + m] (column-major, +1 pad: conflict-free column-strided access);
+// step 2 X/Y[row * kTileK + kk].
+// ---------------------------------------------------------------------------
+constexpr int kTileA = 512;          // sub-transform length of step 1
+constexpr int kTileC = 16;           // columns per step-1 tile
+constexpr int kTileLd = kTileA + 1;
+constexpr int kTileK = 64;           // k values per step-2 tile
+PAYNE_HD constexpr int fft_tile_complex() { return kTileC * kTileLd; }          // per LDS buffer (>= kTileK * 128)
+PAYNE_HD bool fft_tiled_ok(int M) { const int B = M / kTileA; return M % kTileA == 0 && (B == 32 || B == 64 || B == 128); }
+
+// step 1, first pass of a tile: global (strided columns) -> X
+PAYNE_HD void fft4_s1_load(int tid, int nthr, const c32* __restrict__ src, c32* __restrict__ X, int B, int c0) {
+  for (int idx = tid; idx < kTileC * 64; idx += nthr) {
+    const int cc = idx % kTileC, i = idx / kTileC;
+    c32 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = src[(size_t)(c0 + cc) + (size_t)B * (i + 64 * r)];
+    dft8(u);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[cc * kTileLd + 8 * i + r] = u[r];
+  }
+}
+// step 1, middle pass (sub-length 8): X -> Y
+PAYNE_HD void fft4_s1_mid(int tid, int nthr, const c32* __restrict__ X, c32* __restrict__ Y, const c32* __restrict__ tw, int tw_n) {
+  const int ts = tw_n / 64;
+  for (int idx = tid; idx < kTileC * 64; idx += nthr) {
+    const int i = idx & 63, cc = idx >> 6, k = i & 7;
+    c32 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = X[cc * kTileLd + i + 64 * r];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
+    dft8(u);
+    const int j = (i - k) * 8 + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) Y[cc * kTileLd + j + 8 * r] = u[r];
+  }
+}
+// step 1, last pass (sub-length 64): Y -> global, natural order within the column's 512 outputs
+PAYNE_HD void fft4_s1_store(int tid, int nthr, const c32* __restrict__ Y, c32* __restrict__ dst, const c32* __restrict__ tw,
+                            int tw_n, int c0) {
+  const int ts = tw_n / 512;
+  for (int idx = tid; idx < kTileC * 64; idx += nthr) {
+    const int i = idx & 63, cc = idx >> 6;
+    c32 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = Y[cc * kTileLd + i + 64 * r];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw[(i * r) * ts]);
+    dft8(u);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dst[(size_t)(c0 + cc) * kTileA + i + 64 * r] = u[r];
+  }
+}
+// step 2, first pass of a tile: global (stride 512) x W_M^(k m) -> X, radix 8
+PAYNE_HD void fft4_s2_load(int tid, int nthr, const c32* __restrict__ src, c32* __restrict__ X, int B, int k0,
+                           const c32* __restrict__ tw, int tw_n) {
+  const int nb = B / 8, tsM = tw_n / (kTileA * B);
+  for (int idx = tid; idx < kTileK * nb; idx += nthr) {
+    const int kk = idx % kTileK, i = idx / kTileK, k = k0 + kk;
+    c32 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = i + nb * r;
+      u[r] = cmul(src[(size_t)k + (size_t)kTileA * m], tw[(k * m) * tsM]);
+    }
+    dft8(u);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[(8 * i + r) * kTileK + kk] = u[r];
+  }
+}
+// step 2, a later pass (sub-length p, radix R): X -> Y (LDS) or, as the last pass, -> global (stride 512)
+template <int R>
+PAYNE_HD void fft4_s2_pass(int tid, int nthr, const c32* __restrict__ X, c32* __restrict__ Y, c32* __restrict__ gdst, int B,
+                           int p, int k0, const c32* __restrict__ tw, int tw_n, bool conj_out) {
+  const int nb = B / R, ts = tw_n / (p * R);
+  for (int idx = tid; idx < kTileK * nb; idx += nthr) {
+    const int kk = idx % kTileK, i = idx / kTileK, k = i & (p - 1);
+    c32 u[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = X[(i + nb * r) * kTileK + kk];
+#pragma unroll
+    for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
+    dftR<R>(u);
+    const int j = (i - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int q = j + r * p;
+      if (gdst) gdst[(size_t)(k0 + kk) + (size_t)kTileA * q] = conj_out ? cconj(u[r]) : u[r];
+      else Y[q * kTileK + kk] = u[r];
+    }
+  }
+}
+
+
 // Compile-time geometry ("plan") of an M-point FFT on kPostThreads threads.
 // Its twiddles are stored PASS-ORDERED: for every pass with sub-length P > 1 and radix R,
 // (R-1)*P entries  twf[off(P) + (r-1)*P + k] = exp(-2 pi i k r/(P R))  -- the lanes of a wave

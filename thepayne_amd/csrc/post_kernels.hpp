@@ -55,6 +55,9 @@ struct DevExecT {
 #endif
   }
   __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+  // LDS tile of the four-step transform (2 x fft_tile_complex()); null: runtime-geometry passes
+  c32* tile_ = nullptr;
+  __device__ __forceinline__ c32* tile() const { return tile_; }
 };
 
 __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs, const double* err, int F) {
@@ -137,13 +140,17 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
 // the batch with stride gridDim.x, so the workspace is sized by the grid, not by the batch.  All
 // waves of a workgroup share one CU's L1, so __syncthreads() orders the global accesses between
 // phases exactly as it orders LDS.  This is the HBM/L2-bandwidth-bound regime of SURVEY.md 8(d).
+// With `tile_lds` the launch carries 2 x fft_tile_complex() complex values of dynamic LDS and the transforms
+// take the four-step form (fft_run_tiled): two round trips through the workspace per transform instead of five.
 constexpr int kBigThreads = 512;
-__global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B) {
+__global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B, int tile_lds) {
   __shared__ double red[kBigThreads + kBigThreads / 2 + 2];
   __shared__ CandState S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_sm[];      // the four-step transform's tile (or nothing)
   float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
   float* bufB = bufA + T.n1;
   DevExecT<false, false> ex;
+  if (tile_lds) ex.tile_ = reinterpret_cast<c32*>(big_sm);
   double* chi2 = red + scratch_doubles(kBigThreads) - 1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     run_candidate<0, kBigThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
