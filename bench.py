@@ -259,11 +259,15 @@ def main():
             # Algorithmic bytes per candidate: raw row in, 2 conv stages x (2 FFTs x log8(N/2) passes + taper)
             # x (read + write) of 4N, mask scan 8N, resample 8N, observed arrays 16 Nobs.
             npass = int(np.ceil(np.log2(n1 / 2) / 3.0))
+            if os.environ.get("PAYNE_BIG_TILED", "1") != "0" and (n1 // 2) % 512 == 0 and (n1 // 2) // 512 in (32, 64, 128):
+                npass = 2                                 # four-step transform: two round trips per FFT
             bytes_eval = 4.0 * n1 * (1 + 2 * (2 * npass + 1) * 2 + 2) + 8.0 * N + 16.0 * cfg["nobs"]
+            out_passes = npass
             ach = bytes_eval * B / (max(per[dom], 1e-9) * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                               "alg_bytes_per_launch": bytes_eval * B, "avg_us_per_launch": per[dom]}
+                               "alg_bytes_per_launch": bytes_eval * B, "avg_us_per_launch": per[dom],
+                               "round_trips_per_fft": out_passes}
         else:
             # dominant kernel decides the roofline line; both are FLOP-bound at C2 (AI ~ 300 FLOP/B)
             flops = {"dense_out": 2.0 * B * H * N, "post": B * (2 * 2 * 2.5 * N * np.log2(N) + 60.0 * N)}
