@@ -24,6 +24,7 @@ struct HostExec {
   c32* tile() const { return tile_; }
   static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
   static const c32* twid(const c32* p) { return p; }
+  static c32* lds(c32* p) { return p; }
 };
 
 // the same instantiation choice the GPU launcher makes (compile-time FFT geometry needs 256 threads)

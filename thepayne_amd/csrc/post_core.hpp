@@ -211,91 +211,139 @@ constexpr int kTileK = 64;           // k values per step-2 tile
 PAYNE_HD constexpr int fft_tile_complex() { return kTileC * kTileLd; }          // per LDS buffer (>= kTileK * 128)
 PAYNE_HD bool fft_tiled_ok(int M) { const int B = M / kTileA; return M % kTileA == 0 && (B == 32 || B == 64 || B == 128); }
 
-// step 1, first pass of a tile: global (strided columns) -> X
-PAYNE_HD void fft4_s1_load(int tid, int nthr, const c32* __restrict__ src, c32* __restrict__ X, int B, int c0) {
-  for (int idx = tid; idx < kTileC * 64; idx += nthr) {
-    const int cc = idx % kTileC, i = idx / kTileC;
-    c32 u[8];
+// Accessors: GP / LP / TP are the pointer types Ex::buf / Ex::lds / Ex::twid hand out (address space in the
+// type on the device); pairs of adjacent complex values travel as one 16-byte access where the index is even.
+#ifdef __HIP_DEVICE_COMPILE__
+typedef float f2q __attribute__((ext_vector_type(2)));
+typedef float f4q __attribute__((ext_vector_type(4)));
+#define PAYNE_Q_LDS __attribute__((address_space(3)))
+#define PAYNE_Q_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ c32 q_ld(const PAYNE_Q_GLOBAL f2q* p, size_t i) { const f2q v = p[i]; return {v.x, v.y}; }
+__device__ __forceinline__ c32 q_ld(const PAYNE_Q_LDS f2q* p, size_t i) { const f2q v = p[i]; return {v.x, v.y}; }
+__device__ __forceinline__ c32 q_ld(PAYNE_Q_GLOBAL f2q* p, size_t i) { const f2q v = p[i]; return {v.x, v.y}; }
+__device__ __forceinline__ c32 q_ld(PAYNE_Q_LDS f2q* p, size_t i) { const f2q v = p[i]; return {v.x, v.y}; }
+__device__ __forceinline__ void q_st(PAYNE_Q_GLOBAL f2q* p, size_t i, c32 v) { f2q t; t.x = v.x; t.y = v.y; p[i] = t; }
+__device__ __forceinline__ void q_st(PAYNE_Q_LDS f2q* p, size_t i, c32 v) { f2q t; t.x = v.x; t.y = v.y; p[i] = t; }
+__device__ __forceinline__ void q_ld2(const PAYNE_Q_GLOBAL f2q* p, size_t i, c32& a, c32& b) {
+  const f4q v = *reinterpret_cast<const PAYNE_Q_GLOBAL f4q*>(p + i); a = {v.x, v.y}; b = {v.z, v.w};
+}
+__device__ __forceinline__ void q_ld2(PAYNE_Q_GLOBAL f2q* p, size_t i, c32& a, c32& b) {
+  const f4q v = *reinterpret_cast<const PAYNE_Q_GLOBAL f4q*>(p + i); a = {v.x, v.y}; b = {v.z, v.w};
+}
+__device__ __forceinline__ void q_ld2(PAYNE_Q_LDS f2q* p, size_t i, c32& a, c32& b) {
+  const f4q v = *reinterpret_cast<const PAYNE_Q_LDS f4q*>(p + i); a = {v.x, v.y}; b = {v.z, v.w};
+}
+__device__ __forceinline__ void q_st2(PAYNE_Q_GLOBAL f2q* p, size_t i, c32 a, c32 b) {
+  f4q t; t.x = a.x; t.y = a.y; t.z = b.x; t.w = b.y; *reinterpret_cast<PAYNE_Q_GLOBAL f4q*>(p + i) = t;
+}
+__device__ __forceinline__ void q_st2(PAYNE_Q_LDS f2q* p, size_t i, c32 a, c32 b) {
+  f4q t; t.x = a.x; t.y = a.y; t.z = b.x; t.w = b.y; *reinterpret_cast<PAYNE_Q_LDS f4q*>(p + i) = t;
+}
+#else
+inline c32 q_ld(const c32* p, size_t i) { return p[i]; }
+inline void q_st(c32* p, size_t i, c32 v) { p[i] = v; }
+inline void q_ld2(const c32* p, size_t i, c32& a, c32& b) { a = p[i]; b = p[i + 1]; }
+inline void q_st2(c32* p, size_t i, c32 a, c32 b) { p[i] = a; p[i + 1] = b; }
+#endif
+
+// step 1, first pass of a tile: global (strided columns, two adjacent columns per thread) -> X
+template <class GP, class LP>
+PAYNE_HD void fft4_s1_load(int tid, int nthr, GP src, LP X, int B, int c0) {
+  for (int idx = tid; idx < (kTileC / 2) * 64; idx += nthr) {
+    const int cp = idx % (kTileC / 2), i = idx / (kTileC / 2), cc = 2 * cp;
+    c32 u[8], v[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = src[(size_t)(c0 + cc) + (size_t)B * (i + 64 * r)];
+    for (int r = 0; r < 8; ++r) q_ld2(src, (size_t)(c0 + cc) + (size_t)B * (i + 64 * r), u[r], v[r]);
     dft8(u);
+    dft8(v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) X[cc * kTileLd + 8 * i + r] = u[r];
+    for (int r = 0; r < 8; ++r) {
+      q_st(X, (size_t)cc * kTileLd + 8 * i + r, u[r]);
+      q_st(X, (size_t)(cc + 1) * kTileLd + 8 * i + r, v[r]);
+    }
   }
 }
 // step 1, middle pass (sub-length 8): X -> Y
-PAYNE_HD void fft4_s1_mid(int tid, int nthr, const c32* __restrict__ X, c32* __restrict__ Y, const c32* __restrict__ tw, int tw_n) {
+template <class LP, class TP>
+PAYNE_HD void fft4_s1_mid(int tid, int nthr, LP X, LP Y, TP tw, int tw_n) {
   const int ts = tw_n / 64;
   for (int idx = tid; idx < kTileC * 64; idx += nthr) {
     const int i = idx & 63, cc = idx >> 6, k = i & 7;
     c32 u[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = X[cc * kTileLd + i + 64 * r];
+    for (int r = 0; r < 8; ++r) u[r] = q_ld(X, (size_t)cc * kTileLd + i + 64 * r);
 #pragma unroll
-    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
+    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], q_ld(tw, (size_t)(k * r) * ts));
     dft8(u);
     const int j = (i - k) * 8 + k;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) Y[cc * kTileLd + j + 8 * r] = u[r];
+    for (int r = 0; r < 8; ++r) q_st(Y, (size_t)cc * kTileLd + j + 8 * r, u[r]);
   }
 }
-// step 1, last pass (sub-length 64): Y -> global, natural order within the column's 512 outputs
-PAYNE_HD void fft4_s1_store(int tid, int nthr, const c32* __restrict__ Y, c32* __restrict__ dst, const c32* __restrict__ tw,
-                            int tw_n, int c0) {
+// step 1, last pass (sub-length 64): Y -> global, natural order within the column's 512 outputs; two adjacent
+// outputs per thread
+template <class LP, class GP, class TP>
+PAYNE_HD void fft4_s1_store(int tid, int nthr, LP Y, GP dst, TP tw, int tw_n, int c0) {
   const int ts = tw_n / 512;
-  for (int idx = tid; idx < kTileC * 64; idx += nthr) {
-    const int i = idx & 63, cc = idx >> 6;
-    c32 u[8];
+  for (int idx = tid; idx < kTileC * 32; idx += nthr) {
+    const int i = 2 * (idx & 31), cc = idx >> 5;
+    c32 u[8], v[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = Y[cc * kTileLd + i + 64 * r];
+    for (int r = 0; r < 8; ++r) { u[r] = q_ld(Y, (size_t)cc * kTileLd + i + 64 * r); v[r] = q_ld(Y, (size_t)cc * kTileLd + i + 1 + 64 * r); }
 #pragma unroll
-    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw[(i * r) * ts]);
+    for (int r = 1; r < 8; ++r) { u[r] = cmul(u[r], q_ld(tw, (size_t)(i * r) * ts)); v[r] = cmul(v[r], q_ld(tw, (size_t)((i + 1) * r) * ts)); }
     dft8(u);
+    dft8(v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dst[(size_t)(c0 + cc) * kTileA + i + 64 * r] = u[r];
+    for (int r = 0; r < 8; ++r) q_st2(dst, (size_t)(c0 + cc) * kTileA + i + 64 * r, u[r], v[r]);
   }
 }
-// step 2, first pass of a tile: global (stride 512) x W_M^(k m) -> X, radix 8
-PAYNE_HD void fft4_s2_load(int tid, int nthr, const c32* __restrict__ src, c32* __restrict__ X, int B, int k0,
-                           const c32* __restrict__ tw, int tw_n) {
+// step 2, first pass of a tile: global (stride 512, two adjacent k per thread) x W_M^(k m) -> X, radix 8
+template <class GP, class LP, class TP>
+PAYNE_HD void fft4_s2_load(int tid, int nthr, GP src, LP X, int B, int k0, TP tw, int tw_n) {
   const int nb = B / 8, tsM = tw_n / (kTileA * B);
-  for (int idx = tid; idx < kTileK * nb; idx += nthr) {
-    const int kk = idx % kTileK, i = idx / kTileK, k = k0 + kk;
-    c32 u[8];
+  for (int idx = tid; idx < (kTileK / 2) * nb; idx += nthr) {
+    const int kk = 2 * (idx % (kTileK / 2)), i = idx / (kTileK / 2), k = k0 + kk;
+    c32 u[8], v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int m = i + nb * r;
-      u[r] = cmul(src[(size_t)k + (size_t)kTileA * m], tw[(k * m) * tsM]);
+      q_ld2(src, (size_t)k + (size_t)kTileA * m, u[r], v[r]);
+      u[r] = cmul(u[r], q_ld(tw, (size_t)(k * m) * tsM));
+      v[r] = cmul(v[r], q_ld(tw, (size_t)((k + 1) * m) * tsM));
     }
     dft8(u);
+    dft8(v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) X[(8 * i + r) * kTileK + kk] = u[r];
+    for (int r = 0; r < 8; ++r) q_st2(X, (size_t)(8 * i + r) * kTileK + kk, u[r], v[r]);
   }
 }
 // step 2, a later pass (sub-length p, radix R): X -> Y (LDS) or, as the last pass, -> global (stride 512)
-template <int R>
-PAYNE_HD void fft4_s2_pass(int tid, int nthr, const c32* __restrict__ X, c32* __restrict__ Y, c32* __restrict__ gdst, int B,
-                           int p, int k0, const c32* __restrict__ tw, int tw_n, bool conj_out) {
+template <int R, bool TO_GLOBAL, class LP, class GP, class TP>
+PAYNE_HD void fft4_s2_pass(int tid, int nthr, LP X, LP Y, GP gdst, int B, int p, int k0, TP tw, int tw_n, bool conj_out) {
   const int nb = B / R, ts = tw_n / (p * R);
-  for (int idx = tid; idx < kTileK * nb; idx += nthr) {
-    const int kk = idx % kTileK, i = idx / kTileK, k = i & (p - 1);
-    c32 u[R];
+  for (int idx = tid; idx < (kTileK / 2) * nb; idx += nthr) {
+    const int kk = 2 * (idx % (kTileK / 2)), i = idx / (kTileK / 2), k = i & (p - 1);
+    c32 u[R], v[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) u[r] = X[(i + nb * r) * kTileK + kk];
+    for (int r = 0; r < R; ++r) q_ld2(X, (size_t)(i + nb * r) * kTileK + kk, u[r], v[r]);
 #pragma unroll
-    for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[(k * r) * ts]);
+    for (int r = 1; r < R; ++r) { const c32 w = q_ld(tw, (size_t)(k * r) * ts); u[r] = cmul(u[r], w); v[r] = cmul(v[r], w); }
     dftR<R>(u);
+    dftR<R>(v);
     const int j = (i - k) * R + k;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int q = j + r * p;
-      if (gdst) gdst[(size_t)(k0 + kk) + (size_t)kTileA * q] = conj_out ? cconj(u[r]) : u[r];
-      else Y[q * kTileK + kk] = u[r];
+      if (TO_GLOBAL) {
+        if (conj_out) q_st2(gdst, (size_t)(k0 + kk) + (size_t)kTileA * q, cconj(u[r]), cconj(v[r]));
+        else q_st2(gdst, (size_t)(k0 + kk) + (size_t)kTileA * q, u[r], v[r]);
+      } else {
+        q_st2(Y, (size_t)q * kTileK + kk, u[r], v[r]);
+      }
     }
   }
 }
-
-
 // Compile-time geometry ("plan") of an M-point FFT on kPostThreads threads.
 // Its twiddles are stored PASS-ORDERED: for every pass with sub-length P > 1 and radix R,
 // (R-1)*P entries  twf[off(P) + (r-1)*P + k] = exp(-2 pi i k r/(P R))  -- the lanes of a wave

@@ -29,9 +29,11 @@ struct DevExecT {
   static __device__ __forceinline__ auto twid(const c32* p) {
     if constexpr (TW_LDS) return (const PAYNE_AS_LDS f2v*)p; else return (const PAYNE_AS_GLOBAL f2v*)p;
   }
+  static __device__ __forceinline__ auto lds(c32* p) { return (PAYNE_AS_LDS f2v*)p; }
 #else
   static c32* buf(c32* p) { return p; }
   static const c32* twid(const c32* p) { return p; }
+  static c32* lds(c32* p) { return p; }
 #endif
 #ifdef PAYNE_STAMPS
   // diagnostic build only (libpayne_hip_diag.so): cycle stamp after every phase barrier

@@ -47,8 +47,12 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
 // through the global workspace per transform.  The closing pass of one tile and the opening pass of the next
 // touch different buffers and share a barrier interval.
 template <class Ex>
-PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, bool conj_last, c32* X) {
-  c32* Y = X + fft_tile_complex();
+PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile) {
+  auto a = Ex::buf(a_);
+  auto b = Ex::buf(b_);
+  auto tw = Ex::twid(tw_);
+  auto X = Ex::lds(tile);
+  auto Y = Ex::lds(tile + fft_tile_complex());
   const int B = M / kTileA;
   // step 1: a -> b
   ex.par([&](int t, int n) { fft4_s1_load(t, n, a, X, B, 0); });
@@ -62,26 +66,26 @@ PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a, c32* b, int M, const c32* tw, int t
   }
   // step 2: b -> a.  The tile buffers alternate, so the closing pass of a tile (which reads one buffer) and the
   // opening pass of the next (which fills the other) share a barrier interval as well.
-  c32 *P = X, *Q = Y;
+  auto P = X, Q = Y;
   ex.par([&](int t, int n) { fft4_s2_load(t, n, b, P, B, 0, tw, tw_n); });
   for (int k0 = 0; k0 < kTileA; k0 += kTileK) {
     const bool more = k0 + kTileK < kTileA;
     if (B == 128) {                                       // 8 x 8 x 2: P -> Q -> global, next tile into P
-      ex.par([&](int t, int n) { fft4_s2_pass<8>(t, n, P, Q, (c32*)nullptr, B, 8, k0, tw, tw_n, false); });
+      ex.par([&](int t, int n) { fft4_s2_pass<8, false>(t, n, P, Q, a, B, 8, k0, tw, tw_n, false); });
       ex.par([&](int t, int n) {
-        fft4_s2_pass<2>(t, n, Q, P, a, B, 64, k0, tw, tw_n, conj_last);
+        fft4_s2_pass<2, true>(t, n, Q, P, a, B, 64, k0, tw, tw_n, conj_last);
         if (more) fft4_s2_load(t, n, b, P, B, k0 + kTileK, tw, tw_n);
       });
     } else {                                              // 8 x 4 or 8 x 8: P -> global, next tile into Q
       ex.par([&](int t, int n) {
-        if (B == 32) fft4_s2_pass<4>(t, n, P, Q, a, B, 8, k0, tw, tw_n, conj_last);
-        else fft4_s2_pass<8>(t, n, P, Q, a, B, 8, k0, tw, tw_n, conj_last);
+        if (B == 32) fft4_s2_pass<4, true>(t, n, P, Q, a, B, 8, k0, tw, tw_n, conj_last);
+        else fft4_s2_pass<8, true>(t, n, P, Q, a, B, 8, k0, tw, tw_n, conj_last);
         if (more) fft4_s2_load(t, n, b, Q, B, k0 + kTileK, tw, tw_n);
       });
-      c32* t_ = P; P = Q; Q = t_;
+      auto t_ = P; P = Q; Q = t_;
     }
   }
-  return a;
+  return a_;
 }
 
 // The same with compile-time geometry (M points, NT threads, pass-ordered twiddles `twf`).
