@@ -1168,7 +1168,12 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
-  hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T, a);
+  if (c->big_ws) {                                         // spectra larger than LDS: plain passes (<= 62 phases fit the stamp row)
+    const int grid = B < c->big_grid ? B : c->big_grid;
+    hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, nullptr, c->T, a, c->big_ws, B, 0);
+  } else {
+    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T, a);
+  }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(d); (void)hipFree(lnl);

@@ -155,14 +155,25 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   if (tile_lds) ex.tile_ = reinterpret_cast<c32*>(big_sm);
   double* chi2 = red + scratch_doubles(kBigThreads) - 1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
+#ifdef PAYNE_STAMPS
+    if (a.stamps) {                                        // diagnostic build: cycle stamps of every candidate's phases
+      ex.stamps = a.stamps + (size_t)b * 64;
+      if (threadIdx.x == 0) ex.stamps[1] = __builtin_amdgcn_s_memtime();
+      ex.nst = 1;
+    }
+#endif
     run_candidate<0, kBigThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
                                   a.raw + (size_t)b * a.ld_raw, bufA, bufB, S, red,
-                                  a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2);
+                                  a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
+                                  a.prep ? a.prep + b : nullptr);     // records made ahead of the kernel: no mask scan here
     if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
       double x2 = *chi2;
       if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
       a.lnl[b] = -0.5 * x2;
     }
+#ifdef PAYNE_STAMPS
+    if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
+#endif
     __syncthreads();
   }
 }
