@@ -19,11 +19,11 @@ def _save(tmp_path, raw, name):
     return path
 
 
-@pytest.mark.parametrize("D,seed,cont", [(4, 0, False), (4, 1, False), (5, 2, False), (4, 3, True)])
+@pytest.mark.parametrize("D,seed,cont", [(4, 0, False), (4, 1, False), (5, 2, False), (4, 3, True), (4, 4, False), (4, 5, False)])
 def test_random_getspec_calls(tmp_path, D, seed, cont):
     from thepayne_amd.predict.ystpred import PayneSpecPredict
     rng = np.random.default_rng(100 + seed + 1000 * SEED0)
-    net = synth.make_yst_net(npix=[512, 700, 1024, 600][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
+    net = synth.make_yst_net(npix=[512, 700, 1024, 600, 4096, 3000][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
     cnet = None
     if cont:                                           # continuum network on its own, coarser grid (Cnnpath)
         w = net["wavelength"]
