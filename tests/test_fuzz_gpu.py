@@ -19,11 +19,12 @@ def _save(tmp_path, raw, name):
     return path
 
 
-@pytest.mark.parametrize("D,seed,cont", [(4, 0, False), (4, 1, False), (5, 2, False), (4, 3, True), (4, 4, False), (4, 5, False)])
+@pytest.mark.parametrize("D,seed,cont", [(4, 0, False), (4, 1, False), (5, 2, False), (4, 3, True), (4, 4, False), (4, 5, False),
+                                         (4, 6, False), (4, 7, False)])
 def test_random_getspec_calls(tmp_path, D, seed, cont):
     from thepayne_amd.predict.ystpred import PayneSpecPredict
     rng = np.random.default_rng(100 + seed + 1000 * SEED0)
-    net = synth.make_yst_net(npix=[512, 700, 1024, 600, 4096, 3000][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
+    net = synth.make_yst_net(npix=[512, 700, 1024, 600, 4096, 3000, 20000, 40000][seed], H=32, seed=20 + seed, D=D, line_depth=0.3)
     cnet = None
     if cont:                                           # continuum network on its own, coarser grid (Cnnpath)
         w = net["wavelength"]
@@ -35,7 +36,7 @@ def test_random_getspec_calls(tmp_path, D, seed, cont):
     alias = {"Teff": ["Teff", "logt"], "logg": ["logg", "log(g)"], "feh": ["feh", "[Fe/H]"],
              "afe": ["afe", "aFe", "[a/Fe]", "[alpha/Fe]"]}
     worst = 0.0
-    for it in range(120):
+    for it in range(120 if len(net["wavelength"]) < 10000 else 40):       # (the big sizes: the global-workspace kernel)
         kw, canon = {}, {}
         lab = dict(Teff=rng.uniform(4000, 7500), logg=rng.uniform(0.5, 5.2), feh=rng.uniform(-2, 0.4), afe=rng.uniform(-0.1, 0.5))
         for k, v in lab.items():
