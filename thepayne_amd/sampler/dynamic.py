@@ -313,29 +313,39 @@ class DynamicNestedSampler(object):
         return np.array(out, dtype=np.float64)
 
     # ---- when to stop ---------------------------------------------------------------------------------
-    def _simulate(self, results, rng):
-        """One simulated realisation of the run: strands (particle ids) resampled with replacement --
-        those started from the prior and those added by batches separately -- and the volume
-        shrinkages drawn as Beta(n, 1).  Returns (indices into the run, logwt, logz)."""
-        ids, birth, logl = results['samples_id'], results['samples_birth'], results['logl']
+    @staticmethod
+    def _strands(results):
+        """Particle ids of the run, which samples belong to which, and the two groups that are resampled
+        separately: strands started from the prior and strands added by batches."""
+        ids, birth = results['samples_id'], results['samples_birth']
         uniq, inv = np.unique(ids, return_inverse=True)
         first_birth = np.full(len(uniq), np.inf)
         np.minimum.at(first_birth, inv, birth)
         from_prior = first_birth == -np.inf
-        count = np.zeros(len(uniq), dtype=np.int64)
-        for grp in (np.nonzero(from_prior)[0], np.nonzero(~from_prior)[0]):
+        return inv, len(uniq), (np.nonzero(from_prior)[0], np.nonzero(~from_prior)[0])
+
+    def _simulate(self, results, rng, strands=None):
+        """One simulated realisation of the run: strands (particle ids) resampled with replacement --
+        those started from the prior and those added by batches separately -- and the volume
+        shrinkages drawn as Beta(n, 1).  Returns (indices into the run, logwt, final logz)."""
+        birth, logl = results['samples_birth'], results['logl']
+        inv, nstr, groups = strands if strands is not None else self._strands(results)
+        count = np.zeros(nstr, dtype=np.int64)
+        for grp in groups:
             if len(grp):
-                np.add.at(count, rng.choice(grp, size=len(grp)), 1)
-        rep = count[inv]
-        idx = np.repeat(np.arange(len(logl)), rep)                   # stays sorted by logl
+                count += np.bincount(rng.choice(grp, size=len(grp)), minlength=nstr)
+        idx = np.repeat(np.arange(len(logl)), count[inv])             # stays sorted by logl
         if len(idx) < 2:
             idx = np.arange(len(logl))
         n = live_counts(logl[idx], birth[idx])
-        n = np.maximum(n, 1)
         ln_t = np.log(rng.uniform(size=len(idx))) / n
-        logvol = _volumes(n, ln_t)
-        _, logwt, logz = _weights(logl[idx], logvol)
-        return idx, logwt, logz
+        logvol = np.cumsum(ln_t)
+        prev_vol = np.concatenate([[0.0], logvol[:-1]])
+        logdvol = math.log(0.5) + prev_vol + np.log1p(-np.exp(ln_t))
+        ll = logl[idx]
+        logwt = np.logaddexp(ll, np.concatenate([[_NEG], ll[:-1]])) + logdvol
+        top = logwt.max()
+        return idx, logwt, top + math.log(np.exp(logwt - top).sum())
 
     def stopping_function(self, results, args=None, rstate=None, M=None, return_vals=False):
         """dynesty's default stopping rule on simulated runs; True = stop."""
@@ -348,11 +358,12 @@ class DynamicNestedSampler(object):
         rng = rstate if rstate is not None else self.rng
         logp2_all = results['logwt'] - results['logz'][-1]
         kld, lnz = np.empty(n_mc), np.empty(n_mc)
+        strands = self._strands(results)
         for k in range(n_mc):
-            idx, logwt, logz = self._simulate(results, rng)
-            logp1 = logwt - logz[-1]
+            idx, logwt, logz = self._simulate(results, rng, strands)
+            logp1 = logwt - logz
             kld[k] = np.sum(np.exp(logp1) * (logp1 - logp2_all[idx]))
-            lnz[k] = logz[-1]
+            lnz[k] = logz
         stop_evid = float(np.std(lnz)) / evid_thresh if pfrac < 1.0 else 0.0
         stop_post = float(np.std(kld) / np.mean(kld)) / post_thresh if pfrac > 0.0 else 0.0
         stop_val = pfrac * stop_post + (1.0 - pfrac) * stop_evid
