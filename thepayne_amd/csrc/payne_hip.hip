@@ -1155,27 +1155,33 @@ extern "C" int payne_diag_hidden_stamps(payne_ctx* c, const double* theta, int B
   return rc;
 }
 // Diagnostic build only: one lnlike batch with per-phase cycle stamps of the post kernel.
-// stamps: host [B][64] (slot 0 = number of stamps, slots 1.. = s_memtime after each barrier).
+// stamps: host [B][payne_diag_stamp_row()] (slot 0 = number of stamps, slots 1.. = s_memtime after each barrier).
+extern "C" int payne_diag_stamp_row(void) { return kStampRow; }
 extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, unsigned long long* stamps_host) {
   int rc = check_call(c, theta, B, stamps_host);
   if (rc) return rc;
   unsigned long long* d = nullptr;
   double* lnl = nullptr;
-  HIPCHK(c, hipMalloc(&d, (size_t)B * 64 * 8));
+  HIPCHK(c, hipMalloc(&d, (size_t)B * kStampRow * 8));
   HIPCHK(c, hipMalloc(&lnl, (size_t)B * 8));
-  HIPCHK(c, hipMemset(d, 0, (size_t)B * 64 * 8));
+  HIPCHK(c, hipMemset(d, 0, (size_t)B * kStampRow * 8));
   if ((rc = run_ann(c, theta, B, 2.355, nullptr))) return rc;
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
-  if (c->big_ws) {                                         // spectra larger than LDS: plain passes (<= 62 phases fit the stamp row)
+  if (c->big_ws) {                                         // spectra larger than LDS (PAYNE_BIG_TILED=0: plain passes)
     const int grid = B < c->big_grid ? B : c->big_grid;
-    hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), 0, nullptr, c->T, a, c->big_ws, B, 0);
+    const char* e = getenv("PAYNE_BIG_TILED");
+    const int tiled = e ? atoi(e) : 1;
+    const size_t lds = tiled ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
+    if (tiled) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_big_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, nullptr, c->T, a, c->big_ws, B, tiled);
   } else {
     hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T, a);
   }
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * kStampRow * 8, hipMemcpyDeviceToHost));
   (void)hipFree(d); (void)hipFree(lnl);
   return PAYNE_OK;
 }

@@ -7,6 +7,7 @@
 // ============================================================================
 // per-candidate spectrum pipeline
 // ============================================================================
+constexpr int kStampRow = 192;        // diagnostic build: stamps per candidate (the four-step transform has ~90 phases)
 struct PostArgs {
   const double* theta; int ld_theta;
   double instr_factor;
@@ -15,7 +16,7 @@ struct PostArgs {
   double* lnl;                       // [B] or null
   const double* mags; int n_filters; // SED magnitudes of this batch (null: no photometry)
   const double* obs_mag; const double* obs_err;
-  unsigned long long* stamps;        // diagnostic build: [B][64] cycle stamps (slot 0 = count)
+  unsigned long long* stamps;        // diagnostic build: [B][kStampRow] cycle stamps (slot 0 = count)
   const CandState* prep;             // [B] per-candidate records made by the first dense launch (null: none)
 };
 
@@ -51,7 +52,7 @@ struct DevExecT {
   // diagnostic build: an extra cycle stamp inside a phase, written by thread `who`
   __device__ __forceinline__ void mark(int who) {
 #ifdef PAYNE_STAMPS
-    if (stamps && nst < 62) { ++nst; if ((int)threadIdx.x == who) stamps[nst] = __builtin_amdgcn_s_memtime(); }
+    if (stamps && nst < kStampRow - 2) { ++nst; if ((int)threadIdx.x == who) stamps[nst] = __builtin_amdgcn_s_memtime(); }
 #else
     (void)who;
 #endif
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   DevExecT<true, TW_LDS> ex;
 #ifdef PAYNE_STAMPS
   if (a.stamps) {
-    ex.stamps = a.stamps + (size_t)b * 64;
+    ex.stamps = a.stamps + (size_t)b * kStampRow;
     if (threadIdx.x == 0) { ex.stamps[1] = __builtin_amdgcn_s_memtime(); }
     ex.nst = 1;
   }
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
 #ifdef PAYNE_STAMPS
     if (a.stamps) {                                        // diagnostic build: cycle stamps of every candidate's phases
-      ex.stamps = a.stamps + (size_t)b * 64;
+      ex.stamps = a.stamps + (size_t)b * kStampRow;
       if (threadIdx.x == 0) ex.stamps[1] = __builtin_amdgcn_s_memtime();
       ex.nst = 1;
     }

@@ -52,7 +52,8 @@ eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=B)
 th = eng._theta(theta_full(synth.draw_candidates(B, seed=1)), eng.ncols)
 eng.lnlike_batch(th)
 eng.torch.cuda.synchronize()
-st = np.zeros((B, 64), dtype=np.uint64)
+ROW = int(eng.lib.payne_diag_stamp_row())
+st = np.zeros((B, ROW), dtype=np.uint64)
 fn = eng.lib.payne_diag_post_stamps
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 fn.restype = C.c_int
