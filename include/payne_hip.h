@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PAYNE_ABI_VERSION 1
+#define PAYNE_ABI_VERSION 2
 
 #define PAYNE_OK 0
 #define PAYNE_E_INVALID (-1)     /* bad argument / descriptor */
@@ -99,7 +99,18 @@ typedef struct payne_opts {
   int b_max;     /* largest batch any call will pass (workspaces are sized for it) */
   int npoly;     /* Chebyshev blaze coefficients pc_0.. in theta (0 = modpoly off) */
   int photscale; /* 1: phot block carries log(A) (genphot_scaled); 0: log(R), Dist (genphot) */
+  unsigned variant; /* 0 = the default kernels; PAYNE_V_* bits select the other code paths that ship */
 } payne_opts;
+
+/* Kernel variants (payne_opts.variant).  Every one computes the same results; they exist because the default of
+ * each pair only covers some shapes (the other is what differently shaped nets / spectra run), and the parity
+ * tests run the reference vectors through each of them. */
+#define PAYNE_V_OUT_GENERIC 1u   /* output layer: register-staged GEMM (what nets with unequal hidden widths use) */
+#define PAYNE_V_POST_GENERIC 2u  /* post kernel: runtime FFT geometry (what spectra other than 1k/2k/4k/8k use) */
+#define PAYNE_V_TW_GLOBAL 4u     /* post kernel: twiddles read from L2 instead of LDS (what 8k spectra use) */
+#define PAYNE_V_POST_FULL 8u     /* likelihood through the full post kernel instead of its likelihood-only build */
+#define PAYNE_V_NO_PREP 16u      /* per-candidate records computed inside the post kernel (what 2-layer nets use) */
+#define PAYNE_V_BIG_PLAIN 32u    /* spectra > 16384 px: plain radix-8 passes instead of the four-step transform */
 
 typedef struct payne_ctx payne_ctx;
 

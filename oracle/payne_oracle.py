@@ -11,7 +11,7 @@ __all__ = [
     "leaky_relu", "yst_encode", "yst_forward", "torchnet_forward", "ann_forward",
     "mask_range", "resample_pow2", "taper_vsini", "taper_gauss", "fft_convolve",
     "smooth_vsini", "smooth_R", "smooth_lsf", "getspec", "polycalc", "genspec",
-    "chi2_spec", "fastann_forward", "highav_offset", "sed_mags",
+    "chi2_spec", "chi2_spec_loop", "fastann_forward", "highav_offset", "sed_mags",
     "genphot", "genphot_scaled", "OracleLikelihood", "lnprobfn",
 ]
 
@@ -269,6 +269,12 @@ def chi2_spec(model, obs, err):
     return np.sum(((model - obs) ** 2.0) / (err ** 2.0))
 
 
+def chi2_spec_loop(model, obs, err):
+    """Payne/fitting/likelihood.py:95-97 literally: a Python list built pixel by pixel, then np.sum.
+    Same value as chi2_spec to rounding; this is the form bench.py's cpu_baseline times."""
+    return np.sum([((m - o) ** 2.0) / (s ** 2.0) for m, o, s in zip(model, obs, err)])
+
+
 # --------------------------------------------------------------------------
 # photometry
 # --------------------------------------------------------------------------
@@ -331,8 +337,9 @@ class OracleLikelihood(object):
     """
 
     def __init__(self, net, obs_wave, obs_flux, obs_eflux, fitpars_i, fixedpars=None,
-                 modpoly=False, phot=None, obs_phot=None, photscale=False, spec=True):
+                 modpoly=False, phot=None, obs_phot=None, photscale=False, spec=True, pixel_loop=False):
         self.net = net
+        self.pixel_loop = pixel_loop          # chi^2 by the reference's per-pixel Python loop (timing baseline)
         self.obs_wave = None if obs_wave is None else np.asarray(obs_wave, dtype=np.float64)
         self.obs_flux = obs_flux
         self.obs_eflux = obs_eflux
@@ -371,7 +378,7 @@ class OracleLikelihood(object):
         specchi2 = sedchi2 = 0.0
         if self.spec_bool:
             _, modflux = genspec(self.net, specpars, outwave=self.obs_wave, modpoly=self.modpoly)
-            specchi2 = chi2_spec(modflux, self.obs_flux, self.obs_eflux)
+            specchi2 = (chi2_spec_loop if self.pixel_loop else chi2_spec)(modflux, self.obs_flux, self.obs_eflux)
         if self.phot_bool:
             mags = genphot_scaled(self.phot, photpars) if self.photscale else genphot(self.phot, photpars)
             mags = np.atleast_1d(mags)

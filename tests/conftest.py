@@ -21,3 +21,11 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """libpayne_hip.so is built (or rebuilt, when a source is newer) before any test loads it: a clean checkout
+    can run `pytest -m gpu` without a separate build step.  hipcc cross-compiles, so this also runs without a GPU."""
+    from thepayne_amd.build import build_lib
+    return build_lib()

@@ -127,3 +127,90 @@ def test_c1_dynamic_sampler_driver(tmp_path):
     T = synth.TRUTH
     truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
     assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+
+
+def _fake_dynesty():
+    """A stand-in for the dynesty module with the calls FitPayne._rundynesty makes: NestedSampler(loglike, ptform, ndim,
+    nlive=, pool=, queue_size=, use_pool=, ...), .sample(dlogz=) yielding the 15-tuples, .add_live_points().  Like the
+    real one it reaches the likelihood only through ``pool.map`` (first live points; the queue of evolving points)."""
+    import types
+    mod = types.ModuleType("dynesty")
+
+    class NestedSampler(object):
+        def __init__(self, loglike, ptform, ndim, nlive=50, pool=None, queue_size=1, walks=5, **kw):
+            self.L, self.P, self.ndim, self.nlive, self.pool, self.q, self.walks = loglike, ptform, ndim, nlive, pool, queue_size, walks
+            self.rng = np.random.default_rng(5)
+            self.u = self.rng.random((nlive, ndim))
+            self.v = np.array(pool.map(ptform, list(self.u)))
+            self.logl = np.array(pool.map(loglike, list(self.v)))
+            self.maps = 0
+
+        def _evolve(self, arg):
+            u, lstar, seed = arg
+            r = np.random.default_rng(seed)
+            v, logl, nc = self.P(u), None, 0
+            for _ in range(self.walks):
+                un = u + 0.02 * r.normal(size=self.ndim)
+                if np.any(un <= 0) or np.any(un >= 1):
+                    continue
+                vn = self.P(un)
+                ln = self.L(vn)
+                nc += 1
+                if ln > lstar:
+                    u, v, logl = un, vn, ln
+            return u, v, logl, nc
+
+        def sample(self, dlogz=0.5, maxiter=10 ** 9, maxcall=10 ** 9):
+            logz, logvol, h, it, queue = -1e300, 0.0, 0.0, 0, []
+            while it < maxiter:
+                worst = int(np.argmin(self.logl))
+                lstar = self.logl[worst]
+                logvol -= 1.0 / self.nlive
+                logwt = lstar + logvol - np.log(self.nlive)
+                logz = np.logaddexp(logz, logwt)
+                dz = np.logaddexp(logz, self.logl.max() + logvol) - logz
+                yield (worst, self.u[worst].copy(), self.v[worst].copy(), lstar, logvol, logwt, logz, 0.0, h, 1, it, 0, 0, 10.0, dz)
+                it += 1
+                if dz < dlogz:
+                    return
+                while True:
+                    if not queue:
+                        starts = self.rng.integers(0, self.nlive, size=self.q)
+                        queue = list(self.pool.map(self._evolve, [(self.u[s], lstar, int(self.rng.integers(1 << 30))) for s in starts]))
+                        self.maps += 1
+                    u, v, logl, nc = queue.pop()
+                    if logl is not None and logl > lstar:
+                        self.u[worst], self.v[worst], self.logl[worst] = u, v, logl
+                        break
+
+        def add_live_points(self):
+            for i in np.argsort(self.logl):
+                yield (int(i), self.u[i], self.v[i], self.logl[i], 0.0, 0.0, 0.0, 0.0, 0.0, 1, 0, 0, 0, 10.0, 0.0)
+
+    mod.NestedSampler = NestedSampler
+    return mod
+
+
+def test_c1_real_dynesty_shape_through_the_pool_adapter(tmp_path, monkeypatch):
+    """sampler['use_dynesty']: FitPayne hands dynesty a BatchPool (sampler/pool.py) -- the `pool=` of
+    Payne/fitting/fitstar.py:309-321 -- and the proposals a queue evaluates at the same time reach the likelihood
+    object as batches, not one by one."""
+    import sys
+    monkeypatch.setitem(sys.modules, "dynesty", _fake_dynesty())
+    sizes = []
+
+    class Recording(OracleBackedLikelihood):
+        def lnlike_batch(self, theta):
+            sizes.append(len(np.atleast_2d(theta)))
+            return super().lnlike_batch(theta)
+
+    F = FitPayne()
+    F.likelihood = Recording
+    inputdict = _inputdict(tmp_path, use_dynesty=True, npoints=32, walks=4, delta_logz_final=5.0, queue_size=16, maxiter=60)
+    sampler = F.run(inputdict=inputdict, verbose=False)
+    assert sampler.maps >= 1 and F.pool.ncall_batches == len(sizes)
+    assert sizes[0] == 32                                        # the first live points: one batch
+    assert max(sizes[1:]) > 1 and np.mean(sizes[1:]) > 4         # queued walks share their batches
+    lines = open(inputdict['output']).read().splitlines()
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[1:]])
+    assert lines[0].split()[0] == 'Iter' and np.all(np.diff(rows[:-32, 8]) >= 0)

@@ -25,11 +25,18 @@ def _net(raw, kind="YST1"):
     return nnio.normalize_spec_net(raw, kind)
 
 
-def test_lnlike_c2_against_reference_golden(Engine, golden):
+# every kernel variant that ships (payne_opts.variant, include/payne_hip.h): the defaults, and the code paths that
+# differently shaped nets / spectra take, forced onto the C2 problem
+VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
+            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_lnlike_c2_against_reference_golden(Engine, golden, variant):
     g = golden("g4_lnlike_c2")
     cfg = synth.CONFIGS["C2"]
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
-    eng = Engine(_net(raw), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=512)
+    eng = Engine(_net(raw), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=512, variant=VARIANTS[variant])
     lnl = eng.lnlike_batch(theta_full(g["theta"])).cpu().numpy()
     err = np.abs(lnl - g["lnlike"])
     assert np.all(err <= lnl_tol(g["lnlike"])), (err.max(), np.argmax(err))
@@ -183,7 +190,8 @@ def test_abi_error_paths(Engine):
     assert rc == -1                                                             # no flux bound
 
 
-def test_spectra_larger_than_lds_vs_oracle(Engine):
+@pytest.mark.parametrize("variant", [0, 32], ids=["four_step", "plain_passes"])
+def test_spectra_larger_than_lds_vs_oracle(Engine, variant):
     """n1 > 16384 takes the global-workspace kernel (persistent workgroups): a 40 000-pixel net and the
     65 536-pixel C5 grid (R ~ 100k), a few candidates each (the oracle needs ~0.1 s per evaluation)."""
     for npix, nobs, lam0, R, B in ((40000, 30000, 5150.0, 32000.0, 3), (65536, 60000, 4000.0, 100000.0, 5)):
@@ -195,7 +203,7 @@ def test_spectra_larger_than_lds_vs_oracle(Engine):
         ref_flux = np.array([O.genspec(raw, r, outwave=obs)[1] for r in rows])
         flux = ref_flux[0] + np.random.default_rng(1).normal(0, 0.01, nobs)
         eflux = np.full(nobs, 0.01)
-        eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=2)   # b_max < B: chunked, grid < batch
+        eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=2, variant=variant)   # b_max < B: chunked, grid < batch
         got = eng.predict_batch(theta_full(th7), stage=2, fwhm_R=True).cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(ref_flux))
         assert np.nanmax(np.abs(got - ref_flux)) <= FLUX_TOL, npix

@@ -149,7 +149,7 @@ def test_c_abi_library_loads_and_exports_the_header():
     assert L.payne_version() == _lib.ABI_VERSION
     assert L.payne_kernel_name(1) == b"payne_post_kernel"
     # struct layouts agree with the header's field order (sizes on LP64)
-    assert ctypes.sizeof(_lib.Layer) == 32 and ctypes.sizeof(_lib.Opts) == 12
+    assert ctypes.sizeof(_lib.Layer) == 32 and ctypes.sizeof(_lib.Opts) == 16
     assert ctypes.sizeof(_lib.ModelDesc) == 8 + 8 * 32 + 8 + 8 + 8 + 8 + 8 + 8
 
 

@@ -10,9 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpayne_hip.so")
 
 PAYNE_MAX_LAYERS = 8
+PAYNE_MAX_POLY = 12
 ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
 F_FWHM_R = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+V_OUT_GENERIC, V_POST_GENERIC, V_TW_GLOBAL, V_POST_FULL, V_NO_PREP, V_BIG_PLAIN = 1, 2, 4, 8, 16, 32
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_destroy", "payne_last_error",
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
@@ -47,7 +49,7 @@ class PhotDesc(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("b_max", C.c_int), ("npoly", C.c_int), ("photscale", C.c_int)]
+    _fields_ = [("b_max", C.c_int), ("npoly", C.c_int), ("photscale", C.c_int), ("variant", C.c_uint)]
 
 
 class PriorDim(C.Structure):

@@ -25,9 +25,6 @@ struct DenseParams {
   const float* W0; const float* b0; int n_labels; int act0;
   int K0;                      // real width of the first layer (W0 has K0 rows)
   double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
-  // optional second output of the hidden-layer kernel: the activations as three bf16 planes (x = x1 + x2 + x3
-  // exactly), operand of payne_dense_bx3dma_kernel
-  unsigned short* Yp; int ldyp; size_t yp_plane;   // [3][yp_plane] elements, row pitch ldyp
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
@@ -343,98 +340,6 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
 }
 
 // ----------------------------------------------------------------------------
-// Hidden layers are tiny GEMMs ([B x H] x [H x H], ~0.1 GFLOP): one wave per 16x16 output
-// tile (hundreds of independent waves) with v_mfma_f32_16x16x4_f32, fragments read straight
-// from L2 as f32x4_t (lane (r, g) holds 4 consecutive k of row r at offset 4g; MFMA step t
-// contracts k = {4g + t}, identically on both operands), two accumulators to cover the
-// 40-cycle dependent-issue latency.  No LDS, no barriers: latency ~ K/4 MFMAs.
-// ----------------------------------------------------------------------------
-
-template <bool FUSE_L0>
-__global__ void __launch_bounds__(64) payne_dense_small_kernel(DenseParams p) {
-  const int tm = blockIdx.x / p.grid_n, tn = blockIdx.x - tm * p.grid_n;
-  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-  const int row = tm * 16 + r, col = tn * 16 + r;
-  const bool rowok = row < p.B, colok = col < p.N;
-  float xh[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool fast0 = FUSE_L0 && (p.n_labels == 4);            // 4-label nets: W0 rows are f32x4_t
-  if (FUSE_L0 && rowok) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-      if (d < p.n_labels) xh[d] = (float)((p.theta[(size_t)row * p.ld_theta + d] - p.xmin[d]) / p.xden[d] - 0.5);
-  }
-  float xh4 = 0.f;                                            // 5th label (vmic, theta column 6)
-  if (FUSE_L0 && rowok && p.n_labels == 5)
-    xh4 = (float)((p.theta[(size_t)row * p.ld_theta + 6] - p.xmin[4]) / p.xden[4] - 0.5);
-  f32x4_t acc[2];
-  acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const float* wrow = p.W + (size_t)(colok ? col : 0) * p.K;
-  const float* xrow = FUSE_L0 ? nullptr : p.X + (size_t)(rowok ? row : 0) * p.ldx;
-  // K is walked 64 at a time: the 4 steps' operand loads (B fragment, and W0/b0 rows or the A
-  // fragment) are all issued before the first MFMA, so one L2 latency is paid per 64 k, not per 16.
-  constexpr int SU = 4;
-  const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < p.K; k0 += 16 * SU) {
-    f32x4_t b[SU], a[SU], bb[SU], w0[SU][4];
-#pragma unroll
-    for (int s = 0; s < SU; ++s) {
-      const int k = k0 + s * 16 + 4 * g;
-      b[s] = (colok && k < p.K) ? *reinterpret_cast<const f32x4_t*>(wrow + k) : z4;
-      if (FUSE_L0) {
-        if (fast0 && rowok && k + 3 < p.K0) {
-          bb[s] = *reinterpret_cast<const f32x4_t*>(p.b0 + k);
-          const f32x4_t* wp = reinterpret_cast<const f32x4_t*>(p.W0 + (size_t)k * 4);
-          w0[s][0] = wp[0]; w0[s][1] = wp[1]; w0[s][2] = wp[2]; w0[s][3] = wp[3];
-        }
-      } else {
-        a[s] = (rowok && k < p.K) ? *reinterpret_cast<const f32x4_t*>(xrow + k) : z4;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < SU; ++s) {
-      const int k = k0 + s * 16 + 4 * g;
-      if (FUSE_L0) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        if (fast0 && rowok && k + 3 < p.K0) {
-          const float bq[4] = {bb[s].x, bb[s].y, bb[s].z, bb[s].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = act_apply(fmaf(w0[s][j].w, xh[3], fmaf(w0[s][j].z, xh[2], fmaf(w0[s][j].y, xh[1], fmaf(w0[s][j].x, xh[0], bq[j])))), p.act0);
-        } else if (rowok) {                                   // 5-label nets / ragged tail
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (k + j < p.K0) {
-              float z = p.b0[k + j];
-              const float* wq = p.W0 + (size_t)(k + j) * p.n_labels;
-              for (int d = 0; d < p.n_labels && d < 4; ++d) z = fmaf(wq[d], xh[d], z);
-              if (p.n_labels == 5) z = fmaf(wq[4], xh4, z);
-              o[j] = act_apply(z, p.act0);
-            }
-          }
-        }
-        a[s] = (f32x4_t){o[0], o[1], o[2], o[3]};
-      }
-      f32x4_t& c = acc[s & 1];
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b[s].x, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, b[s].y, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, b[s].z, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, b[s].w, c, 0, 0, 0);
-    }
-  }
-  // C/D map of the 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg
-  if (colok) {
-    const float bv = p.bias[col] - p.bias_shift;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int orow = tm * 16 + 4 * g + q;
-      if (orow < p.B) p.Y[(size_t)orow * p.ldy + col] = act_apply(acc[0][q] + acc[1][q] + bv, p.act);
-    }
-  }
-}
-
-
-// ----------------------------------------------------------------------------
 // Hidden layers, workgroup form: one 256-thread group per 32x32 output tile, the whole K
 // extent (<= 320 per chunk) of both operands staged in LDS by coalesced f32x4_t loads issued
 // together (one L2 latency), then the four waves split K between them (v_mfma_f32_16x16x4_f32,
@@ -653,420 +558,22 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       const float v = Red[rr * 33 + cc] + Red[(32 + rr) * 33 + cc] + Red[(64 + rr) * 33 + cc] + Red[(96 + rr) * 33 + cc];
       const float y = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
       p.Y[(size_t)row * p.ldy + col] = y;
-      if (p.Yp) {                                           // the same value as three bf16 planes
-        const __bf16 b1 = (__bf16)y;
-        const float r1 = y - (float)b1;
-        const __bf16 b2 = (__bf16)r1;
-        const __bf16 b3 = (__bf16)(r1 - (float)b2);
-        const size_t o = (size_t)row * p.ldyp + col;
-        p.Yp[o] = __builtin_bit_cast(unsigned short, b1);
-        p.Yp[p.yp_plane + o] = __builtin_bit_cast(unsigned short, b2);
-        p.Yp[2 * p.yp_plane + o] = __builtin_bit_cast(unsigned short, b3);
-      }
     }
   }
   HK_STAMP(5);
 }
 
 
-// ----------------------------------------------------------------------------
-// Output layer, K-resident form (K <= 312, i.e. hidden width <= 312): a workgroup keeps its
-// 64-candidate activation tile (whole K) in LDS and walks a run of 32-pixel weight tiles
-// through a register-staged double buffer, so the only exposed global latency is the first
-// tile's; every later tile's loads fly under the previous tile's MFMAs (the streaming-K kernel
-// above re-pays the load latency every 32 k).  Measured at C2: 26.8 us against 22.4 us for the
-// streaming kernel at 2 workgroups per CU -- both are bound by fp32-MFMA issue at the clock the
-// chip holds under matrix load, not by staging -- so this form is kept as an option
-// (PAYNE_OUT_TILE=6), not the default.
-// Wave w owns rows 16w..16w+15 of the tile and both 16-column halves (v_mfma_f32_16x16x4_f32,
-// two accumulators).  LDS: 64 x 312 + 2 x 32 x 312 floats = 156 KiB -> one workgroup per CU,
-// grid = (#64-row tiles) x (runs of pixel tiles) ~ one workgroup per CU.
-// ----------------------------------------------------------------------------
-constexpr int OK_PITCH = 312;                                   // 8*odd floats (conflict-free fragment reads)
-constexpr int OK_KMAX = 304;                                    // padded K handled (19 steps of 16)
-constexpr size_t OK_LDS_BYTES = (size_t)(64 + 2 * 32) * OK_PITCH * sizeof(float);
 
-__global__ void __launch_bounds__(256, 1) payne_dense_out_kernel(DenseParams p, int tiles_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) float ok_sm[];
-  float* As = ok_sm;                                            // [64][OK_PITCH]
-  float* Bs = ok_sm + 64 * OK_PITCH;                            // [2][32][OK_PITCH]
-  const int ngroups = p.grid_n, total = p.grid_m * ngroups;
-  int t = blockIdx.x;
-  if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);  // XCD-contiguous runs (m fastest)
-  const int m0 = (t % p.grid_m) * 64;
-  const int ntiles = (p.N + 31) >> 5;
-  const int tile0 = (t / p.grid_m) * tiles_per_wg;
-  const int tile1 = (tile0 + tiles_per_wg < ntiles) ? tile0 + tiles_per_wg : ntiles;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int K = p.K, K16 = (K + 15) & ~15, nk4 = K16 >> 2;     // K % 4 == 0
-  const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  constexpr int BI = (32 * (OK_KMAX / 4) + 255) / 256;          // f32x4_t per thread per B tile: 10
-
-  // ---- A tile: 64 rows x K, all loads first ---------------------------------------------------
-  {
-    constexpr int AI = (64 * (OK_KMAX / 4) + 255) / 256;        // 19
-    f32x4_t va[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1, kq = (4 * k4 < K) ? 4 * k4 : K - 4;   // clamped: no branch
-      va[i] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kq);
-    }
-    __builtin_amdgcn_sched_barrier(0);        // keep every load ahead of the first LDS store
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      if (k4 < nk4) *reinterpret_cast<f32x4_t*>(&As[rr * OK_PITCH + 4 * k4]) = (m0 + rr < p.B && 4 * k4 < K) ? va[i] : z4;
-    }
-  }
-  f32x4_t vb[BI];
-  auto load_b = [&](int tile) {
-    const int n0 = tile << 5;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      const int nr = (rr < 32 && n0 + rr < p.N) ? n0 + rr : p.N - 1, kq = (4 * k4 < K) ? 4 * k4 : K - 4;
-      vb[i] = *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * K + kq);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto store_b = [&](int buf, int tile) {
-    float* B = Bs + buf * 32 * OK_PITCH;
-    const int n0 = tile << 5;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int idx = tid + 256 * i, rr = idx / (OK_KMAX / 4), k4 = idx - rr * (OK_KMAX / 4);
-      if (rr < 32 && k4 < nk4) *reinterpret_cast<f32x4_t*>(&B[rr * OK_PITCH + 4 * k4]) = (n0 + rr < p.N && 4 * k4 < K) ? vb[i] : z4;
-    }
-  };
-  if (tile0 < tile1) { load_b(tile0); store_b(0, tile0); }
-  __syncthreads();
-
-  const int steps = K16 >> 4;
-  for (int tile = tile0; tile < tile1; ++tile) {
-    const int buf = (tile - tile0) & 1;
-    if (tile + 1 < tile1) load_b(tile + 1);                     // flies under this tile's MFMAs
-    const float* B = Bs + buf * 32 * OK_PITCH;
-    f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    // software pipeline: the fragments of step s+1 are read from LDS while the 8 MFMAs of step s
-    // issue (one wave per SIMD: nothing else would cover the ds_read latency)
-    const float* Arow = &As[(16 * wave + r) * OK_PITCH + 4 * g];
-    const float* B0row = &B[r * OK_PITCH + 4 * g];
-    const float* B1row = &B[(16 + r) * OK_PITCH + 4 * g];
-#define OK_READ(A_, B0_, B1_, S_)                                               \
-    A_ = *reinterpret_cast<const f32x4_t*>(Arow + (S_) * 16);                     \
-    B0_ = *reinterpret_cast<const f32x4_t*>(B0row + (S_) * 16);                   \
-    B1_ = *reinterpret_cast<const f32x4_t*>(B1row + (S_) * 16);                   \
-    __builtin_amdgcn_sched_barrier(0)      /* the reads are ISSUED here, ahead of the MFMAs below */
-#define OK_MFMA8(A_, B0_, B1_)                                                    \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.x, B0_.x, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.x, B1_.x, acc1, 0, 0, 0);      \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.y, B0_.y, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.y, B1_.y, acc1, 0, 0, 0);      \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.z, B0_.z, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.z, B1_.z, acc1, 0, 0, 0);      \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.w, B0_.w, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.w, B1_.w, acc1, 0, 0, 0);      \
-    __builtin_amdgcn_sched_barrier(0)
-    f32x4_t a, b0, b1, an, b0n, b1n;
-    OK_READ(a, b0, b1, 0);
-    int s = 0;
-    for (; s + 2 < steps; s += 2) {
-      OK_READ(an, b0n, b1n, s + 1);
-      OK_MFMA8(a, b0, b1);
-      OK_READ(a, b0, b1, s + 2);
-      OK_MFMA8(an, b0n, b1n);
-    }
-    if (s + 1 < steps) {                       // two steps left
-      OK_READ(an, b0n, b1n, s + 1);
-      OK_MFMA8(a, b0, b1);
-      OK_MFMA8(an, b0n, b1n);
-    } else {                                   // one step left
-      OK_MFMA8(a, b0, b1);
-    }
-#undef OK_READ
-#undef OK_MFMA8
-    if (tile + 1 < tile1) store_b(buf ^ 1, tile + 1);           // before the output stores: vmcnt then only covers the loads
-    // C/D map: col = lane&15, row = 4*(lane>>4) + reg
-    const int n0 = tile << 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + 16 * j + r;
-      if (col < p.N) {
-        const float bv = p.bias[col] - p.bias_shift;
-        const f32x4_t& a4 = j ? acc1 : acc0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = m0 + 16 * wave + 4 * g + q;
-          if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(a4[q] + bv, p.act);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
-// ----------------------------------------------------------------------------
-// Output layer on the bf16 matrix pipe at fp32 accuracy ("3 x bf16" split).
-// Every fp32 operand is written exactly as x = x1 + x2 + x3 with bf16 parts (8 + 8 + 8
-// mantissa bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the subtractions are
-// exact).  A product a*b is then the six partial products with i + j <= 4,
-//   a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1,
-// each exact in fp32 (8b x 8b), the dropped terms being < 2^-23 |ab|; accumulation is fp32 in
-// the MFMA accumulator exactly as for the f32 MFMA.  v_mfma_f32_32x32x16_bf16 retires 16 k per
-// 32 cycles against 2 k per 64 cycles for v_mfma_f32_32x32x2_f32, so six of them cost 3/8 of the
-// fp32 issue time -- and the f32 MFMA kernel above is bound exactly by that issue time.
-// Weights are split once at context creation ([3][Npad][Kp] bf16, zero padded); activations are
-// split while their tile is staged into LDS.  Tile 64 x 128 x 32, 4 waves as 2 x 2, wave tile
-// 32 x 64; LDS rows padded to 80 B (conflict-free ds_read_b128 for the 32-row x 2-half lane map).
-// ----------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
-constexpr int BX_BM = 64, BX_BN = 128, BX_BK = 32, BX_PITCH = 80;            // bytes per LDS row
-constexpr size_t BX_LDS_BYTES = (size_t)2 * 3 * (BX_BM + BX_BN) * BX_PITCH;
-
-__device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
-__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
-  const __bf16 b1 = (__bf16)x;
-  const float r1 = x - (float)b1;
-  const __bf16 b2 = (__bf16)r1;
-  const float r2 = r1 - (float)b2;
-  const __bf16 b3 = (__bf16)r2;
-  h = bf16_bits(b1); m = bf16_bits(b2); l = bf16_bits(b3);
-}
-
-struct Bx3Params {
-  DenseParams d;
-  const unsigned short* Wp;     // [3][Npad][Kp] bf16 planes of W
-  int Kp, Npad;
-  int dbg;                      // timing experiments (PAYNE_BX_DBG): 1 = no output stores, 2 = no MFMAs, 4 = no staging
-};
-
-__global__ void __launch_bounds__(256, 1) payne_dense_bf16x3_kernel(Bx3Params q) {
-  const DenseParams& p = q.d;
-  extern __shared__ __attribute__((aligned(16))) unsigned char bx_sm[];
-  // [buf][plane][A rows 64 | B rows 128][80 B]
-  auto lds_a = [&](int buf, int pl) { return bx_sm + ((size_t)(buf * 3 + pl) * (BX_BM + BX_BN)) * BX_PITCH; };
-  auto lds_b = [&](int buf, int pl) { return lds_a(buf, pl) + (size_t)BX_BM * BX_PITCH; };
-  const int ntiles = p.grid_m * p.grid_n;
-  int t = blockIdx.x;
-  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);             // XCD-contiguous tile runs (m fastest)
-  const int m0 = (t % p.grid_m) * BX_BM, n0 = (t / p.grid_m) * BX_BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
-  const int r = lane & 31, h = lane >> 5;
-
-  // staging registers: A = 2 float4 of fp32 per thread, B = 2 x 16 B per plane per thread
-  f32x4_t ra[2];
-  f32x4_t rb[3][2];
-  auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, k = k0 + (idx & 7) * 4;
-      const int mr = (m0 + row < p.B) ? m0 + row : p.B - 1, kc = (k < p.K) ? k : p.K - 4;
-      ra[i] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kc);
-    }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 2, c16 = idx & 3;
-        rb[pl][i] = *reinterpret_cast<const f32x4_t*>(q.Wp + ((size_t)pl * q.Npad + n0 + row) * q.Kp + k0 + 8 * c16);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto store_tiles = [&](int buf, int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, k4 = idx & 7, k = k0 + k4 * 4;
-      const bool ok = (m0 + row < p.B) && (k < p.K);
-      const float v[4] = {ok ? ra[i].x : 0.f, ok ? ra[i].y : 0.f, ok ? ra[i].z : 0.f, ok ? ra[i].w : 0.f};
-      u16x4_t p1, p2, p3;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned short a1, a2, a3;
-        split3(v[e], a1, a2, a3);
-        p1[e] = a1; p2[e] = a2; p3[e] = a3;
-      }
-      *reinterpret_cast<u16x4_t*>(lds_a(buf, 0) + row * BX_PITCH + k4 * 8) = p1;
-      *reinterpret_cast<u16x4_t*>(lds_a(buf, 1) + row * BX_PITCH + k4 * 8) = p2;
-      *reinterpret_cast<u16x4_t*>(lds_a(buf, 2) + row * BX_PITCH + k4 * 8) = p3;
-    }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 2, c16 = idx & 3;
-        *reinterpret_cast<f32x4_t*>(lds_b(buf, pl) + row * BX_PITCH + c16 * 16) = rb[pl][i];
-      }
-  };
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-
-  const int nk = (p.K + BX_BK - 1) / BX_BK;
-  load_tiles(0);
-  store_tiles(0, 0);
-  __syncthreads();
-  for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk && !(q.dbg & 4)) load_tiles((it + 1) * BX_BK);
-    if (!(q.dbg & 2))
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {                    // two 16-deep MFMA steps per 32-deep tile
-      bf16x8_t a[3], b[2][3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        a[pl] = *reinterpret_cast<const bf16x8_t*>(lds_a(buf, pl) + (wm0 + r) * BX_PITCH + ks * 32 + h * 16);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          b[j][pl] = *reinterpret_cast<const bf16x8_t*>(lds_b(buf, pl) + (wn0 + 32 * j + r) * BX_PITCH + ks * 32 + h * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {                     // smallest partial products first
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
-      }
-    }
-    if (it + 1 < nk && !(q.dbg & 4)) store_tiles(buf ^ 1, (it + 1) * BX_BK);
-    __syncthreads();
-  }
-  if (q.dbg & 1) {   // keep the accumulators alive, store one value per wave
-    float sacc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc += acc[j][e];
-    if (sacc == 12345.678f) p.Y[0] = sacc;
-    return;
-  }
-  // C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn0 + 32 * j + r;
-    if (col >= p.N) continue;
-    const float bv = p.bias[col] - p.bias_shift;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[j][e] + bv, p.act);
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// Output layer, 3 x bf16 split on the LDS-DMA ring: the arithmetic of payne_dense_bf16x3_kernel (six bf16
-// partial products per term, fp32-accurate) with the operand delivery of payne_dense_dma_kernel.  BOTH
-// operands arrive pre-split -- the weights at context creation, the activations from the hidden-layer kernel's
-// epilogue (DenseParams::Yp) -- so the kernel issues nothing but DMA requests, fragment reads and MFMAs:
-// per 32-deep k-step and wave 12 x v_mfma_f32_32x32x16_bf16 = 384 matrix cycles against 1024 for fp32.
-// (The register-staged bf16x3 kernel was only ~10 % faster than fp32 because its barriers drained the loads;
-// with the ring the steady state is matrix-bound again, at 3/8 of the fp32 time.)
-// Stage = 3 planes x (64 A rows + 64 B rows) x 64 B = 24 KB; a 1-KiB DMA piece = 16 rows of one plane;
-// 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3) (conflict-free 16-lane fragment reads).
-// ----------------------------------------------------------------------------
-constexpr int BD_STAGE = 3 * (64 + 64) * 64;               // bytes per stage
-constexpr size_t BD_LDS_BYTES = (size_t)DM_NS * BD_STAGE;
-struct Bd3Params {
-  DenseParams d;
-  const unsigned short* Ap; int lda; size_t a_plane;       // activation planes [3][a_plane], row pitch lda (elements)
-  const unsigned short* Wp; int Kp; int Npad;              // weight planes [3][Npad][Kp]
-  int dbg;                                                 // timing experiments (PAYNE_BD_DBG): 1 no MFMAs, 2 no DMA after the prologue, 4 no fragment reads, 8 no output stores
-};
-__global__ void __launch_bounds__(256) payne_dense_bx3dma_kernel(Bd3Params q) {
-  const DenseParams& p = q.d;
-  extern __shared__ __attribute__((aligned(16))) unsigned char bd_sm[];
-  const int ntiles = p.grid_m * p.grid_n;
-  int t = blockIdx.x;
-  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
-  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 64;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-  // 24 pieces per stage: piece q = (operand, plane, 16-row block); 6 per wave
-  const unsigned char* src[6];
-  int dst[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int qq = wave * 6 + j, isB = qq / 12, pl = (qq % 12) / 4, blk = qq % 4;
-    const int row = 16 * blk + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);           // which 16-byte chunk of the row belongs in this lane's slot
-    if (!isB) {
-      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
-      src[j] = reinterpret_cast<const unsigned char*>(q.Ap + (size_t)pl * q.a_plane + (size_t)r * q.lda) + 16 * c;
-    } else {
-      src[j] = reinterpret_cast<const unsigned char*>(q.Wp + ((size_t)pl * q.Npad + n0 + row) * q.Kp) + 16 * c;
-    }
-    dst[j] = (isB ? 3 * 64 * 64 : 0) + pl * 64 * 64 + blk * 1024;
-  }
-  auto issue = [&](int stage, int k0) {                    // k0 in elements: 2 bytes each
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
-                                       (__attribute__((address_space(3))) void*)(bd_sm + stage * BD_STAGE + dst[j]), 16, 0, 0);
-  };
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
-  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
-  const int nk = q.Kp / 32;
-  issue(0, 0);
-  if (nk > 1) issue(1, 32);
-  for (int it = 0; it < nk; ++it) {
-    if (q.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (it + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    if (it + 2 < nk && !(q.dbg & 2)) issue((it + 2) % DM_NS, (it + 2) * 32);
-    const unsigned char* As = bd_sm + (it % DM_NS) * BD_STAGE;
-    const unsigned char* Bs = As + 3 * 64 * 64;
-    // all twelve fragments of the stage first, then the twelve MFMAs back to back: read -> wait -> MFMA per
-    // fragment pair exposes one LDS round trip per pair (the compiler places reads next to their use)
-    bf16x8_t a[2][3], b[2][3];
-    if (q.dbg & 4) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) { a[ks][pl] = (bf16x8_t)(__bf16)(float)it; b[ks][pl] = (bf16x8_t)(__bf16)1.0f; }
-    } else
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {                       // two 16-deep MFMA steps per 32-deep stage
-      const int c = 2 * ks + h;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        a[ks][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
-        b[ks][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * 4096 + Rb * 64 + 16 * (c ^ sb));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (q.dbg & 1) { acc[0] += (float)a[0][0][0] + (float)b[1][2][3]; continue; }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][2], b[ks][0], acc, 0, 0, 0);   // smallest partial products first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], b[ks][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[ks][2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], b[ks][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[ks][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[ks][0], acc, 0, 0, 0);
-    }
-  }
-  if (q.dbg & 8) { float sacc = 0.f; for (int r = 0; r < 16; ++r) sacc += acc[r]; if (sacc == 12345.678f) p.Y[0] = sacc; return; }
-  const int col = n0 + wn0 + (lane & 31);
-  if (col < p.N) {
-    const float bv = p.bias[col] - p.bias_shift;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.B) p.Y[(size_t)row * p.ldy + col] = act_apply(acc[r] + bv, p.act);
-    }
-  }
-}
+// The instantiations that exist (compiled in k_dense.hip; `extern template` elsewhere).
+#ifdef PAYNE_TU_DENSE
+#define PAYNE_DENSE_T template
+#else
+#define PAYNE_DENSE_T extern template
+#endif
+PAYNE_DENSE_T __global__ void payne_dense_kernel<64, 64, 32, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_kernel<64, 64, 32, false>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(DenseParams, const PrepArgs);

@@ -37,6 +37,12 @@ using namespace payne;
 
 #include "sed_kernel.hpp"
 
+// photometry-only fits: lnL = -0.5 chi2_sed
+__global__ void payne_photonly_kernel(const double* mags, const double* obs, const double* err, int F, int B, double* lnl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) lnl[b] = -0.5 * sed_chi2(mags + (size_t)b * F, obs, err, F);
+}
+
 // ============================================================================
 // context
 // ============================================================================
@@ -59,12 +65,9 @@ struct payne_ctx {
   float* hid[2] = {nullptr, nullptr};
   int ld_hid = 0;
   float* raw = nullptr;
-  unsigned short* w_planes = nullptr;   // bf16 x 3 split of the output layer's weights
   const float* w_out_pad = nullptr;     // output layer's weights [N][w_out_kp], k zero-padded to a multiple of 32 (LDS-DMA kernel)
   int w_out_kp = 0;
   bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
-  unsigned short* a_planes = nullptr;   // [3][b_max][ld_hid] bf16 planes of the last hidden layer's activations (bx3dma kernel)
-  int wp_Kp = 0, wp_Npad = 0;
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
@@ -72,6 +75,7 @@ struct payne_ctx {
   post_kernel_fn post_fn = nullptr;
   float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
   int big_grid = 0;
+  bool big_tiled = false;             // ... with the four-step transform (LDS tile attribute set at create)
   // optional continuum network (payne_ctx_set_continuum; ystpred.py:81-85, 191-209)
   bool has_cont = false;
   int cn_layers = 0, cn_npix = 0, cn_ld_hid = 0;
@@ -294,37 +298,6 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       for (int l = 1; l + 1 < model->n_layers; ++l) same = same && model->layers[l].n_out == model->layers[0].n_out;
       c->dma_ok = same;
     }
-    {   // exact 3 x bf16 split of the output layer's weights (payne_dense_bf16x3_kernel)
-      const payne_layer& L = c->layers[model->n_layers - 1];
-      const int K = L.n_in, N = L.n_out;
-      const int Kp = (K + 31) & ~31, Npad = (N + 127) & ~127;
-      std::vector<float> w((size_t)N * K);
-      he = hipMemcpy(w.data(), L.w, w.size() * 4, hipMemcpyDeviceToHost);
-      if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(W out): ") + hipGetErrorString(he)));
-      std::vector<unsigned short> pl((size_t)3 * Npad * Kp, 0);
-      auto to_bf16 = [](float x) -> unsigned short {            // round to nearest even (NaN kept quiet)
-        unsigned u; std::memcpy(&u, &x, 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-        return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-      };
-      auto from_bf16 = [](unsigned short b) -> float { unsigned u = (unsigned)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
-      for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) {
-          const float x = w[(size_t)n * K + k];
-          const unsigned short b1 = to_bf16(x);
-          const float r1 = x - from_bf16(b1);
-          const unsigned short b2 = to_bf16(r1);
-          const float r2 = r1 - from_bf16(b2);
-          const unsigned short b3 = to_bf16(r2);
-          pl[((size_t)0 * Npad + n) * Kp + k] = b1;
-          pl[((size_t)1 * Npad + n) * Kp + k] = b2;
-          pl[((size_t)2 * Npad + n) * Kp + k] = b3;
-        }
-      const unsigned short* dp = nullptr;
-      if ((rc = upload(c, pl, &dp, c->owned))) return bail(rc);
-      c->w_planes = const_cast<unsigned short*>(dp);
-      c->wp_Kp = Kp; c->wp_Npad = Npad;
-    }
     c->n_layers = model->n_layers;
     c->n_labels = model->n_labels;
     for (int d = 0; d < model->n_labels; ++d) { c->xmin[d] = model->xmin[d]; c->xden[d] = model->xmax[d] - model->xmin[d]; }
@@ -351,20 +324,26 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
-    if (c->dma_ok && (rc = dev_alloc(c, (size_t)3 * opts->b_max * c->ld_hid, &c->a_planes, c->owned))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
       if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
+      c->big_tiled = !(opts->variant & PAYNE_V_BIG_PLAIN);
+      if (c->big_tiled) {
+        he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(2 * fft_tile_complex() * sizeof(c32)));
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute(big): ") + hipGetErrorString(he)));
+      }
     }
     c->post_lds = (size_t)(T.n1 > 16384 ? 64 : fft_buf_floats(T.n1)) * 8 + (size_t)scratch_doubles(kPostThreads) * 8 + ((sizeof(CandState) + 15) & ~(size_t)15) + 16;
     // twiddles in LDS while two workgroups still fit a CU (160 KiB); larger spectra read them from L2
     const size_t tw_bytes = c->H.twf.size() * sizeof(c32);         // ~0.75 n1 entries
     c->post_tw_lds = (c->post_lds + tw_bytes) <= 80 * 1024;
-    if (getenv("PAYNE_TW_GLOBAL")) c->post_tw_lds = false;
+    if (opts->variant & PAYNE_V_TW_GLOBAL) c->post_tw_lds = false;
     if (c->post_tw_lds) c->post_lds += tw_bytes;
-    c->post_fn = pick_post_kernel(getenv("PAYNE_POST_GENERIC") ? 0 : T.n1, c->post_tw_lds);
-    c->post_fn_lean = getenv("PAYNE_POST_FULL") ? c->post_fn : pick_post_kernel(getenv("PAYNE_POST_GENERIC") ? 0 : T.n1, c->post_tw_lds, true);
+    const int geom_n1 = (opts->variant & PAYNE_V_POST_GENERIC) ? 0 : T.n1;
+    c->post_fn = pick_post_kernel(geom_n1, c->post_tw_lds);
+    c->post_fn_lean = (opts->variant & PAYNE_V_POST_FULL) ? c->post_fn : pick_post_kernel(geom_n1, c->post_tw_lds, true);
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn_lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
@@ -540,93 +519,23 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
   PAYNE_LAUNCH((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
-// Timing experiments only (results are invalid): PAYNE_SKIP bit 0 = hidden layers, 1 = output layer, 2 = post kernel.
-static int skip_mask() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_SKIP"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
-static int out_tile_choice() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_OUT_TILE"); v = e ? atoi(e) : 8; }   // 8: fp32 LDS-DMA (default); 9: 3 x bf16 split on the LDS-DMA ring (both need zero-padded operands, else 0); 0: register-staged streaming; 6: K-resident; 7: register-staged bf16x3
-  return v;
-}
-
-static void launch_out_resident(DenseParams& p, hipStream_t s) {
-  p.grid_m = (p.B + 63) / 64;
-  const int ntiles = (p.N + 31) / 32;
-  int groups = 256 / (p.grid_m > 0 ? p.grid_m : 1);             // ~ one workgroup per CU
-  if (groups < 1) groups = 1;
-  if (groups > ntiles) groups = ntiles;
-  const int tiles_per_wg = (ntiles + groups - 1) / groups;
-  p.grid_n = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)OK_LDS_BYTES);
-    attr_set = true;
-  }
-  PAYNE_LAUNCH(payne_dense_out_kernel, dim3(p.grid_m * p.grid_n), dim3(256), OK_LDS_BYTES, s, p, tiles_per_wg);
-}
-
-template <int WN, int BK>
-static void launch_out_dma_t(payne_ctx* c, DenseParams& p, hipStream_t s) {
+// Output layer, LDS-DMA form (64 x 128 tiles, 512 threads, 32-deep stages).
+static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  constexpr int WN = 4, BK = 32;
   p.k_real = p.K;                                          // the layer's own width: the padded tail is skipped
   p.W = c->w_out_pad; p.K = c->w_out_kp;                   // padded pitch; X's pitch (ld_hid) is a multiple of 32 too
   p.grid_m = (p.B + 63) / 64;
   p.grid_n = (p.N + 32 * WN - 1) / (32 * WN);
+  constexpr size_t lds = dm_lds_bytes<WN, BK>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dm_lds_bytes<WN, BK>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
 #ifdef PAYNE_STAMPS
   p.stamps = g_dense_stamps;
 #endif
-  constexpr size_t lds = dm_lds_bytes<WN, BK>();
   PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
-}
-static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
-  static int wide = -1, deep = -1;                         // PAYNE_DMA_WIDE=0: 64 x 64 tiles (default 64 x 128); PAYNE_DMA_BK=64: 64-deep stages
-  if (wide < 0) { const char* e = getenv("PAYNE_DMA_WIDE"); wide = e ? atoi(e) : 1; }
-  if (deep < 0) { const char* e = getenv("PAYNE_DMA_BK"); deep = e ? atoi(e) : 32; }
-  if (wide && deep == 64 && (c->w_out_kp % 64) == 0) launch_out_dma_t<4, 64>(c, p, s);
-  else if (wide) launch_out_dma_t<4, 32>(c, p, s);
-  else launch_out_dma_t<2, 32>(c, p, s);
-}
-
-static void launch_out_bx3dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
-  p.grid_m = (p.B + 63) / 64;
-  p.grid_n = (p.N + 63) / 64;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("PAYNE_BD_DBG"); dbg = e ? atoi(e) : 0; }
-  Bd3Params q{p, c->a_planes, c->ld_hid, (size_t)c->opts.b_max * c->ld_hid, c->w_planes, c->wp_Kp, c->wp_Npad, dbg};
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bx3dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_BYTES);
-    attr_set = true;
-  }
-  PAYNE_LAUNCH(payne_dense_bx3dma_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BD_LDS_BYTES, s, q);
-}
-
-static void launch_out_bf16x3(payne_ctx* c, DenseParams& p, hipStream_t s) {
-  p.grid_m = (p.B + BX_BM - 1) / BX_BM;
-  p.grid_n = (p.N + BX_BN - 1) / BX_BN;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("PAYNE_BX_DBG"); dbg = e ? atoi(e) : 0; }
-  Bx3Params q{p, c->w_planes, c->wp_Kp, c->wp_Npad, dbg};
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BX_LDS_BYTES);
-    attr_set = true;
-  }
-  PAYNE_LAUNCH(payne_dense_bf16x3_kernel, dim3(p.grid_m * p.grid_n), dim3(256), BX_LDS_BYTES, s, q);
-}
-
-static int hidden_kernel_choice() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PAYNE_HIDDEN_KERNEL"); v = e ? atoi(e) : 1; }   // 1: workgroup form, 0: wave-per-tile
-  return v;
 }
 
 template <bool FUSE>
@@ -651,22 +560,7 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
 }
 
-template <bool FUSE>
-static void launch_small(DenseParams& p, PrepArgs& pa, hipStream_t s) {
-  if (hidden_kernel_choice() == 1) { launch_hidden<FUSE>(p, pa, s); return; }
-  pa.out = nullptr;
-  p.grid_m = (p.B + 15) / 16;
-  p.grid_n = (p.N + 15) / 16;
-  PAYNE_LAUNCH((payne_dense_small_kernel<FUSE>), dim3(p.grid_m * p.grid_n), dim3(64), 0, s, p);
-}
-
 // ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
-static bool prep_enabled() {
-  static int v = -1;
-  if (v < 0) v = getenv("PAYNE_NO_PREP") ? 0 : 1;
-  return v == 1;
-}
-
 // One network of the context: the spectral emulator or the continuum network.
 struct NetRef {
   const payne_layer* layers; int n_layers; int n_labels; const double* xmin; const double* xden;
@@ -683,10 +577,6 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     p.bias_shift = last ? N.out_shift : 0.f;
     p.Y = last ? N.out : N.hid[(l - 1) & 1];
     p.ldy = last ? N.ld_out : N.ld_hid;
-    if (N.spectral && l == n - 2 && c->a_planes && out_tile_choice() == 9) {   // feeds the output layer: also as bf16 planes
-      p.Yp = c->a_planes; p.ldyp = c->ld_hid; p.yp_plane = (size_t)c->opts.b_max * c->ld_hid;
-    }
-    if (N.spectral && (skip_mask() & (last ? 2 : 1))) continue;
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
       const payne_layer& L0 = N.layers[0];
@@ -695,25 +585,15 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       for (int d = 0; d < N.n_labels; ++d) { p.xmin[d] = N.xmin[d]; p.xden[d] = N.xden[d]; }
       PrepArgs pa{};
       pa.T = c->T; pa.instr_factor = instr_factor;
-      pa.out = (N.spectral && c->prep && c->obs_bound && prep_enabled()) ? c->prep : nullptr;
+      pa.out = (N.spectral && c->prep && c->obs_bound && !(c->opts.variant & PAYNE_V_NO_PREP)) ? c->prep : nullptr;
       if (last) launch_dense<64, 64, 32, true>(p, s);
-      else { launch_small<true>(p, pa, s); if (N.spectral) c->prep_valid = pa.out != nullptr; }
+      else { launch_hidden<true>(p, pa, s); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
-      if (!last) launch_small<false>(p, pa, s);
-      else if (!N.spectral) launch_dense<64, 64, 32, false>(p, s);
-      else if (out_tile_choice() == 9 && c->dma_ok && c->a_planes && c->w_planes && c->ld_hid >= c->wp_Kp) launch_out_bx3dma(c, p, s);
-      else if ((out_tile_choice() == 8 || out_tile_choice() == 9) && c->dma_ok && c->ld_hid >= c->w_out_kp) launch_out_dma(c, p, s);
-      else if (out_tile_choice() == 7 && c->w_planes) launch_out_bf16x3(c, p, s);
-      else if (out_tile_choice() == 6 && p.K <= OK_KMAX) launch_out_resident(p, s);
-      else switch (out_tile_choice()) {
-        case 1: launch_dense<128, 64, 32, false>(p, s); break;
-        case 2: launch_dense<64, 128, 32, false>(p, s); break;
-        case 3: launch_dense<64, 64, 64, false>(p, s); break;
-        case 4: launch_dense<128, 64, 64, false>(p, s); break;
-        default: launch_dense<64, 64, 32, false>(p, s); break;    // 5 (or K too large for the resident form)
-      }
+      if (!last) launch_hidden<false>(p, pa, s);
+      else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) launch_out_dma(c, p, s);
+      else launch_dense<64, 64, 32, false>(p, s);            // nets whose hidden widths differ, the continuum network
     }
   }
   hipError_t e = hipGetLastError();
@@ -831,18 +711,11 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
   a.prep = c->prep_valid ? c->prep : nullptr;
-  if (skip_mask() & 4) return PAYNE_OK;
   {
     ProfScope ps(c, s, 1);
     if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
-      static int tiled = -1;                               // PAYNE_BIG_TILED=0: the runtime-geometry passes only
-      if (tiled < 0) {
-        const char* e = getenv("PAYNE_BIG_TILED");
-        tiled = e ? atoi(e) : 1;
-        if (tiled) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_big_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * fft_tile_complex() * sizeof(c32)));
-      }
+      const int tiled = c->big_tiled ? 1 : 0;
       const size_t lds = tiled ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
       PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
@@ -1171,8 +1044,7 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
   if (c->big_ws) {                                         // spectra larger than LDS (PAYNE_BIG_TILED=0: plain passes)
     const int grid = B < c->big_grid ? B : c->big_grid;
-    const char* e = getenv("PAYNE_BIG_TILED");
-    const int tiled = e ? atoi(e) : 1;
+    const int tiled = c->big_tiled ? 1 : 0;
     const size_t lds = tiled ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
     if (tiled) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_big_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

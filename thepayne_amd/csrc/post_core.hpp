@@ -31,7 +31,7 @@
 
 #ifdef __HIPCC__
 #define PAYNE_HD __host__ __device__ __forceinline__
-#define PAYNE_HD_COLD __host__ __device__ __attribute__((noinline))
+#define PAYNE_HD_COLD __host__ __device__ inline __attribute__((noinline))
 #else
 #define PAYNE_HD inline
 #define PAYNE_HD_COLD inline

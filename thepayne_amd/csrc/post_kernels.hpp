@@ -146,6 +146,9 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
 // With `tile_lds` the launch carries 2 x fft_tile_complex() complex values of dynamic LDS and the transforms
 // take the four-step form (fft_run_tiled): two round trips through the workspace per transform instead of five.
 constexpr int kBigThreads = 512;
+#ifndef PAYNE_TU_BIG
+__global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B, int tile_lds);
+#else
 __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B, int tile_lds) {
   __shared__ double red[kBigThreads + kBigThreads / 2 + 2];
   __shared__ CandState S;
@@ -179,6 +182,8 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   }
 }
 
+#endif
+
 // ============================================================================
 // LSF-vector instrumental broadening (inst_R = dispersion in AA per observed pixel):
 // ystpred.py:248-269 -> smoothspec(smoothtype='lsf') -> smooth_lsf_fft (smoothing.py:125-151, 482-586).
@@ -199,6 +204,9 @@ struct LsfArgs {
   double* lnl;
   const double* mags; int n_filters; const double* obs_mag; const double* obs_err;
 };
+#ifndef PAYNE_TU_BIG
+__global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfArgs a);
+#else
 // np.interp(x, xp, fp) (arr_interp): clamped outside, slope form inside
 __device__ double interp_np(double x, const double* xp, const double* fp, int n) {
   if (x > xp[n - 1]) return fp[n - 1];
@@ -397,6 +405,25 @@ __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfA
   }
 }
 
+#endif
+
+// The instantiations that exist (each is compiled in one of the k_post_*.hip units; everybody else sees them as
+// `extern template`): X(LOG2N, TW_LDS, LEAN)
+#define PAYNE_POST_LEAN_LIST(X) X(12, true, true) X(11, true, true) X(13, false, true)
+#define PAYNE_POST_FULL_A_LIST(X) X(12, true, false) X(0, true, false)
+#define PAYNE_POST_FULL_B_LIST(X) X(10, true, false) X(11, true, false) X(13, false, false) X(0, false, false)
+#define PAYNE_POST_EXTERN(L, TW, LEAN) extern template __global__ void payne_post_kernel<L, TW, LEAN>(const PostTables, PostArgs);
+#define PAYNE_POST_DEFINE(L, TW, LEAN) template __global__ void payne_post_kernel<L, TW, LEAN>(const PostTables, PostArgs);
+#ifndef PAYNE_TU_POST_LEAN
+PAYNE_POST_LEAN_LIST(PAYNE_POST_EXTERN)
+#endif
+#ifndef PAYNE_TU_POST_FULL_A
+PAYNE_POST_FULL_A_LIST(PAYNE_POST_EXTERN)
+#endif
+#ifndef PAYNE_TU_POST_FULL_B
+PAYNE_POST_FULL_B_LIST(PAYNE_POST_EXTERN)
+#endif
+
 typedef void (*post_kernel_fn)(const PostTables, PostArgs);
 // compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
 static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
@@ -419,8 +446,3 @@ static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
   }
 }
 
-// photometry-only fits: lnL = -0.5 chi2_sed
-__global__ void payne_photonly_kernel(const double* mags, const double* obs, const double* err, int F, int B, double* lnl) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) lnl[b] = -0.5 * sed_chi2(mags + (size_t)b * F, obs, err, F);
-}

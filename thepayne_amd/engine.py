@@ -42,10 +42,11 @@ class PayneEngine(object):
     obs      : (wave, flux, eflux) | (wave,) | None
     phot     : stacked photometric nets (nnio.load_phot_nets / synth.make_phot_nets) or None
     obs_phot : ordered {filter: (mag, err)} matching phot['filters'], or None
+    variant  : payne_opts.variant (PAYNE_V_* bits of include/payne_hip.h; 0 = default kernels)
     """
 
     def __init__(self, spec_net=None, obs=None, phot=None, obs_phot=None, npoly=0, photscale=False,
-                 b_max=512, device=None):
+                 b_max=512, device=None, variant=0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("PayneEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -71,7 +72,7 @@ class PayneEngine(object):
             odesc = self._obs_desc(*obs)
         if phot is not None:
             pdesc = self._phot_desc(phot, obs_phot)
-        opts = _lib.Opts(self.b_max, self.npoly, int(self.photscale))
+        opts = _lib.Opts(self.b_max, self.npoly, int(self.photscale), int(variant))
         rc = self.lib.payne_ctx_create(mdesc, odesc, pdesc, C.byref(opts), self.device.index, C.byref(self._ctx))
         self._release_host()
         if rc != 0:

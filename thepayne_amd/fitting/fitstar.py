@@ -145,12 +145,24 @@ class FitPayne(object):
         fitargs, fitpars = indicts['fitargs'], indicts['fitpars']
         samplerdict, runbools = indicts['sampler'], indicts['runbools']
         self.ndim = sum(1 for pp in fitpars[0] if fitpars[1][pp])
+        # limits of the library's fixed-size records (include/payne_hip.h), reported here and not from inside the
+        # first likelihood batch; the reference itself has none
+        from .._lib import PAYNE_MAX_DIM, PAYNE_MAX_POLY
+        npoly = fitargs.get('norm_polyorder', 0) if runbools[2] else 0
+        if npoly > PAYNE_MAX_POLY:
+            raise ValueError("blaze polynomial with %d coefficients: this build carries at most %d (PAYNE_MAX_POLY); "
+                             "lower spec['polyorder'] / shorten priordict['blaze_coeff']" % (npoly, PAYNE_MAX_POLY))
+        if self.ndim > PAYNE_MAX_DIM:
+            raise ValueError("%d sampled parameters: this build's sampler records carry at most %d (PAYNE_MAX_DIM)"
+                             % (self.ndim, PAYNE_MAX_DIM))
         self.priorobj = self.prior(fitargs, indicts['priordict'], fitpars, runbools)
         nlive = samplerdict.get('npoints', 200)
         kind = samplerdict.get('samplertype', 'Static')
         widest = 2 * nlive if kind == 'Dynamic' else nlive        # the dynamic sampler's batches carry 2 x npoints
         self.likeobj = self.likelihood(fitargs, fitpars, runbools, device=self.device,
                                        b_max=max(64, widest, int(samplerdict.get('queue_size', widest))))
+        if kind == 'Static' and samplerdict.get('use_dynesty', False):
+            return self._rundynesty(samplerdict)
         if kind == 'Static':
             return self._runsampler(samplerdict)
         if kind == 'Dynamic':
@@ -312,6 +324,46 @@ class FitPayne(object):
         if self.verbose:
             sys.stdout.write('\n')
             print('RUN TIME: {0}'.format(datetime.now() - starttime))
+        return sampler
+
+    def _rundynesty(self, samplerdict):
+        """The reference's own loop (fitstar.py:260-463) around REAL dynesty, with the GPU behind a pool-shaped
+        adapter (sampler/pool.py): dynesty maps its queue of proposals over ``pool`` and every set of simultaneous
+        likelihood requests becomes one batch.  Needs dynesty (not part of this image): ``sampler['use_dynesty']``."""
+        import dynesty
+        from ..sampler.pool import BatchPool
+        npoints = samplerdict.get('npoints', 200)
+        delta_logz_final = samplerdict.get('delta_logz_final', 0.01)
+        flushnum = samplerdict.get('flushnum', 10)
+        maxiter = samplerdict.get('maxiter', sys.maxsize)
+        maxcall = samplerdict.get('maxcall', sys.maxsize)
+        self.pool = pool = BatchPool(self.likeobj, self.priorobj)
+        sampler = dynesty.NestedSampler(
+            pool.lnprob, pool.prior_transform, self.ndim, nlive=npoints,
+            bound=samplerdict.get('samplerbounds', 'multi'), sample=samplerdict.get('samplemethod', 'unif'),
+            bootstrap=samplerdict.get('bootstrap', 0), walks=samplerdict.get('walks', 25),
+            slices=samplerdict.get('slices', 5), first_update={'min_ncall': -np.inf, 'min_eff': np.inf},
+            pool=pool, queue_size=min(pool.size, int(samplerdict.get('queue_size', pool.size))),
+            use_pool={'prior_transform': True, 'loglikelihood': True, 'propose_point': False, 'update_bound': False})
+        self.parnames = list(self.likeobj.fitpars_i) + list(self.fitargs['fixedpars'].keys())
+        self.fitargs_fixed = dict(self.fitargs['fixedpars'])
+        self._initoutput(self.parnames)
+        ncall, nit = 0, 0
+        for it, results in enumerate(sampler.sample(dlogz=delta_logz_final, maxiter=maxiter, maxcall=maxcall)):
+            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
+             h, nc, worst_it, boundidx, bounditer, eff, delta_logz) = results[:15]
+            self._row(it, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
+            ncall += nc
+            nit = it
+            if (it % flushnum) == 0 or it == maxiter:
+                self.outff.flush()
+                if self.verbose:
+                    self._progress(nit, nc, ncall, eff, logz, logzvar, delta_logz, delta_logz_final, 0.0)
+        for it2, results in enumerate(sampler.add_live_points()):
+            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
+             h, nc, worst_it, boundidx, bounditer, eff, delta_logz) = results[:15]
+            self._row(nit + it2, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
+        self.outff.close()
         return sampler
 
     def _progress(self, nit, nc, ncall, eff, logz, logzvar, delta_logz, delta_logz_final, mean_time):

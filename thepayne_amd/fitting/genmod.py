@@ -33,7 +33,7 @@ class GenMod(object):
         self.NNtype = kwargs.get('NNtype', 'YST1')
         self._spec_net = nnio.load_spec_net(nnpath, self.NNtype)
         Cnnpath = kwargs.get('Cnnpath', None)              # genmod.py:28-32 (the reference's likelihood never passes it)
-        self._cont_net = nnio.load_spec_net(Cnnpath, self.NNtype) if Cnnpath is not None else None
+        self._cont_net = nnio.load_spec_net(Cnnpath, self.NNtype, rescale_teff=False) if Cnnpath is not None else None
         self._engine = None
 
     def _initphotnn(self, filterarray, nnpath=None):

@@ -58,17 +58,19 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def normalize_spec_net(arrs, NNtype="YST1"):
+def normalize_spec_net(arrs, NNtype="YST1", rescale_teff=True):
     """Arrays of one spectral emulator -> dict(layers=[(W,b,act)...], xmin, xmax,
     wavelength, resolution, kind).  Accepts the file key names and the in-memory
-    names used by thepayne_amd.synth."""
+    names used by thepayne_amd.synth.  ``rescale_teff``: the Teff/1000 -> Teff fix of x_min/x_max that
+    PayneSpecPredict applies to the SPECTRAL network only (ystpred.py:76-79); the continuum network
+    (``Canns``, ystpred.py:81-85) is used as stored, so its loader passes False."""
     g = lambda *names: next((np.asarray(arrs[n]) for n in names if n in arrs), None)
     if NNtype in ("YST1", "YST2"):
         layers = [(_f32(arrs["w_array_%d" % i]), _f32(arrs["b_array_%d" % i]),
                    _lib.ACT_LRELU if i < 2 else _lib.ACT_NONE) for i in range(3)]
         xmin = np.array(g("x_min"), dtype=np.float64).copy()
         xmax = np.array(g("x_max"), dtype=np.float64).copy()
-        if xmin[0] < 1000.0:                      # Teff/1000 convention, ystpred.py:76-79
+        if rescale_teff and xmin[0] < 1000.0:     # Teff/1000 convention, ystpred.py:76-79
             xmin[0] *= 1000.0
             xmax[0] *= 1000.0
         wave = g("wavelength")
@@ -94,10 +96,10 @@ def normalize_spec_net(arrs, NNtype="YST1"):
                 wavelength=np.ascontiguousarray(wave, dtype=np.float64), resolution=float(res))
 
 
-def load_spec_net(nnpath, NNtype="YST1"):
+def load_spec_net(nnpath, NNtype="YST1", rescale_teff=True):
     """nnpath: file path, or an already-loaded {key: array} dict."""
     arrs = nnpath if isinstance(nnpath, dict) else load_arrays(nnpath)
-    return normalize_spec_net(arrs, NNtype)
+    return normalize_spec_net(arrs, NNtype, rescale_teff=rescale_teff)
 
 
 def stack_phot_nets(per_filter, filters):

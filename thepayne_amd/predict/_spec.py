@@ -64,7 +64,7 @@ class ContANN(object):
 
     def __init__(self, nnpath, NNtype, spec_ann):
         self.nnpath = nnpath
-        self.net = nnio.load_spec_net(nnpath, NNtype)
+        self.net = nnio.load_spec_net(nnpath, NNtype, rescale_teff=False)   # Canns is used as stored (ystpred.py:81-85)
         self.xmin, self.xmax = self.net["xmin"], self.net["xmax"]
         self.wavelength = self.net["wavelength"]
         self.resolution = self.net["resolution"]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--npix", type=int, default=4096)
     ap.add_argument("--npoints", type=int, default=512)
     ap.add_argument("--dlogz", type=float, default=0.1)
+    ap.add_argument("--out", default=None, help="rank 0 saves the gathered [stars, summary] table here (.npy)")
     a = ap.parse_args()
     rank, world, local_rank = pdist.init_from_env()
     from thepayne_amd.fitting.fitstar import FitPayne
@@ -57,6 +58,8 @@ def main():
     table = pdist.fit_stars(list(range(a.stars)), fit, summary_length=5 + 5 * 7)
     dt = time.perf_counter() - t0
     if rank == 0:
+        if a.out:
+            np.save(a.out, table)
         for i, row in enumerate(table):
             print("star %2d  Teff truth %7.1f  fit %7.1f +/- %5.1f   lnZ %10.2f +/- %.2f   %7d calls"
                   % (i, truth_of(i)[0], row[5], row[6], row[0], row[1], int(row[3])))

@@ -1,16 +1,9 @@
 #!/bin/bash
-# all GPU tests + C2 bench (with e2e) + C5 bench
-TAG=${1:-f2}
+# every -m gpu test, smoke, the C2 bench line (with end_to_end) and the C5 bench
+TAG=${1:-full}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --steps 300 --warmup 30 --no-cpu-baseline > $OUT/bench_${TAG}_c2.log 2>&1
-python bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > $OUT/bench_${TAG}_c5.log 2>&1
-python - <<PY
-import json
-for f in ("c2","c5"):
-    try:
-        d=json.loads(open("$OUT/bench_${TAG}_%s.log" % f).read().strip().splitlines()[-1])
-        print(f, round(d["value"]), "evals/s", round(d["ms_per_step"]*1e3,1), "us/step", {k: round(v,1) for k,v in d["kernels_us"].items()}, d.get("end_to_end",{}).get("value"))
-    except Exception as e:
-        print(f, "failed", e, open("$OUT/bench_${TAG}_%s.log" % f).read()[-600:])
-PY
+python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -2
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err; tail -c 1500 $OUT/bench_${TAG}.json; tail -5 $OUT/bench_${TAG}.err
+python bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c5_${TAG}.json 2> $OUT/bench_c5_${TAG}.err; tail -c 1200 $OUT/bench_c5_${TAG}.json
