@@ -341,6 +341,9 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     c->post_tw_lds = (c->post_lds + tw_bytes) <= 80 * 1024;
     if (opts->variant & PAYNE_V_TW_GLOBAL) c->post_tw_lds = false;
     if (c->post_tw_lds) c->post_lds += tw_bytes;
+#ifdef PAYNE_STAMPS
+    if (const char* e = getenv("PAYNE_DIAG_LDS")) c->post_lds = std::max(c->post_lds, (size_t)atoi(e));   // diagnostic build: one workgroup per CU
+#endif
     const int geom_n1 = (opts->variant & PAYNE_V_POST_GENERIC) ? 0 : T.n1;
     c->post_fn = pick_post_kernel(geom_n1, c->post_tw_lds);
     c->post_fn_lean = (opts->variant & PAYNE_V_POST_FULL) ? c->post_fn : pick_post_kernel(geom_n1, c->post_tw_lds, true);
@@ -1042,6 +1045,7 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
+  a.stamp_sparse = getenv("PAYNE_DIAG_SPARSE") ? 1 : 0;
   if (c->big_ws) {                                         // spectra larger than LDS (PAYNE_BIG_TILED=0: plain passes)
     const int grid = B < c->big_grid ? B : c->big_grid;
     const int tiled = c->big_tiled ? 1 : 0;

@@ -45,11 +45,17 @@ constexpr double kPi = 3.141592653589793;
 constexpr float kBase = 1.0f;                // the flux shift
 constexpr double kVsTabStep = 1.0 / 64.0;    // vsini taper table spacing in u
 constexpr double kVsTabMax = 256.0;
-// Threads of the per-candidate workgroup.  Measured at C2 (512 candidates, 2 groups per CU):
-// 256 threads (radix-8 passes, 4 barriers per FFT) 41 us per batch; 512 threads (radix-4
-// passes, 6 barriers per FFT, 4 waves per SIMD) 46 us: the extra barriers and LDS traffic of
-// the lower radix cost more than the extra occupancy hides.
-constexpr int kPostThreads = 256;
+// Threads of the per-candidate workgroup, and how many of them own a butterfly in the radix-8 passes.
+// One wave issues a vector instruction every ~5 cycles whatever its kind (tools/exp/pk_rate.hip) while a SIMD
+// keeps four waves going at that rate each, so the per-pixel phases (tapers, resampling, observed grid) are
+// bound by INSTRUCTIONS PER WAVE: eight waves halve them.  The transform keeps radix-8 passes on the first four
+// waves (the other four only take part in the barriers): radix-4 passes on all eight (6 barriers per transform
+// instead of 4) cost more than the occupancy gains -- measured at C2 (512 candidates, 2 groups per CU):
+// 256 / 256 threads 21.8 us per batch, 512 / 512 (radix 4) 32.2 us, 512 / 256 19.5 us.
+constexpr int kPostThreads = 512;
+constexpr int kFftThreads = 256;
+// unroll factor of the per-pixel loops for `ppt` pixels per thread (loads of one unrolled body are in flight together)
+PAYNE_HD constexpr int unroll_for(int ppt) { return ppt >= 16 ? 16 : (ppt >= 8 ? 8 : 4); }
 
 struct c32 { float x, y; };
 PAYNE_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -352,7 +358,7 @@ PAYNE_HD void fft4_s2_pass(int tid, int nthr, LP X, LP Y, GP gdst, int B, int p,
 // exp(-2 pi i k/2M) of the real-FFT split.
 // radix: 8 while that still gives every thread a butterfly (M/8 >= threads), else 4, else 2
 constexpr int plan_radix(int M, int P) {
-  return (M / P >= 8 && M / 8 >= kPostThreads) ? 8 : ((M / P >= 4) ? 4 : 2);
+  return (M / P >= 8 && M / 8 >= kFftThreads) ? 8 : ((M / P >= 4) ? 4 : 2);
 }
 constexpr int plan_offset(int M, int P) {
   int off = 0, p = 1;
@@ -400,7 +406,7 @@ constexpr int plan_prev_p(int M, int P) {
   return p;
 }
 // floats each of the two ping-pong buffers needs for n-point spectra (M = n/2 complex + padding <= M/R)
-PAYNE_HD constexpr int fft_buf_floats(int n) { return n + ((n / 2) / 8 >= kPostThreads ? n / 8 : n / 4); }
+PAYNE_HD constexpr int fft_buf_floats(int n) { return n + ((n / 2) / 8 >= kFftThreads ? n / 8 : n / 4); }
 
 // One pass: M points, sub-length P, NT threads; `sign` = 0x80000000 conjugates the output.
 // SP/DP/TP: pointer types as produced by Ex::buf / Ex::twid.
@@ -512,10 +518,9 @@ PAYNE_HD float taper_far(const TaperArgs& a, int k, float fast) {
 // pairs are issued before any store: the pairs are disjoint, so this is safe in place);
 // the two self-conjugate bins k = 0 and k = M/2 go to the last two threads.
 // tw_step = (twiddle table length)/(2M): exp(-2 pi i k/2M) = tw[k*tw_step].
-template <bool VSINI>
+template <bool VSINI, int PU = 4>
 PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __restrict__ tw, int tw_step,
                                const TaperArgs& ta) {
-  constexpr int PU = 4;
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const int npair = M / 2 - 1;                        // k = 1 .. M/2-1
   // The two self-conjugate bins (0 with M, and M/2) need taper(M) and taper(M/2): they ride in the
@@ -849,13 +854,15 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
 // goes straight into the vsini FFT (identity resampling maps).
 // Split in two so that the global loads of the first kU*nthr float4 (the whole row at 4096
 // pixels) are in flight WHILE phase_setup's fp64 chains run: issue -> setup -> commit.
-struct RowRegs { float v[kU][4]; };
+template <int U> struct RowRegsT { float v[U][4]; };
+typedef RowRegsT<kU> RowRegs;
 PAYNE_HD bool row_vectorised(int npix, const float* raw) { return ((npix & 3) == 0) && ((((uintptr_t)raw) & 15) == 0); }
-PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restrict__ raw, RowRegs& R) {
+template <int U>
+PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restrict__ raw, RowRegsT<U>& R) {
   if (!row_vectorised(npix, raw)) return;
   const int n4 = npix >> 2;
 #pragma unroll
-  for (int q = 0; q < kU; ++q) {                      // clamped index: unconditional loads
+  for (int q = 0; q < U; ++q) {                      // clamped index: unconditional loads
     const int i0 = tid + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
 #ifdef __HIP_DEVICE_COMPILE__
     // read once, produced by other XCDs: streaming loads (no L2 allocation)
@@ -866,27 +873,28 @@ PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restr
 #endif
   }
 }
-PAYNE_HD void phase_load_commit(int tid, int nthr, int npix, const float* __restrict__ raw, const RowRegs& R,
+template <int U>
+PAYNE_HD void phase_load_commit(int tid, int nthr, int npix, const float* __restrict__ raw, const RowRegsT<U>& R,
                                 float* __restrict__ spec, bool scrub) {
   if (row_vectorised(npix, raw)) {
     const int n4 = npix >> 2;
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < U; ++q) {
       const int i = tid + q * nthr;
       if (i < n4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) spec[4 * i + e] = scrub ? nan_to_zero(R.v[q][e]) : R.v[q][e];
       }
     }
-    for (int base = tid + kU * nthr; base < n4; base += kU * nthr) {      // rows longer than kU*nthr float4
-      float v[kU][4];
+    for (int base = tid + U * nthr; base < n4; base += U * nthr) {      // rows longer than U*nthr float4
+      float v[U][4];
 #pragma unroll
-      for (int q = 0; q < kU; ++q) {
+      for (int q = 0; q < U; ++q) {
         const int i0 = base + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
         v[q][0] = raw[4 * i]; v[q][1] = raw[4 * i + 1]; v[q][2] = raw[4 * i + 2]; v[q][3] = raw[4 * i + 3];
       }
 #pragma unroll
-      for (int q = 0; q < kU; ++q) {
+      for (int q = 0; q < U; ++q) {
         const int i = base + q * nthr;
         if (i < n4) {
 #pragma unroll
@@ -999,10 +1007,10 @@ PAYNE_HD Window make_window(const PostTables& T, const CandState& S, const int* 
 }
 
 // R c: resample the masked, Doppler-shifted spectrum onto its pow-2 log grid.
-template <bool GEO>
+template <bool GEO, int RU>
 PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                               const float* __restrict__ spec, float* __restrict__ work) {
-  constexpr int RU = 16;                                 // a whole 4096-point thread-share of gathers in flight
+  // RU: a whole thread-share of gathers in flight
   const double rsBm = W.rsB + kPosMagic, rsD = (double)nthr * W.rsA;
   for (int base = tid; base < W.n2; base += RU * nthr) {
     float a[RU], b[RU], w[RU];
@@ -1028,10 +1036,11 @@ PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const Cand
     }
   }
 }
+template <int RU = 16>
 PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                                const float* __restrict__ spec, float* __restrict__ work) {
-  if (T.geo) R_resample_loop<true>(tid, nthr, T, S, W, spec, work);
-  else R_resample_loop<false>(tid, nthr, T, S, W, spec, work);
+  if (T.geo) R_resample_loop<true, RU>(tid, nthr, T, S, W, spec, work);
+  else R_resample_loop<false, RU>(tid, nthr, T, S, W, spec, work);
 }
 
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
@@ -1039,11 +1048,10 @@ PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const Can
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
 // MODE: 0 = smoothed spectrum on the candidate's uniform log grid; 1 = plain interpolation on a
 // geometric ANN grid; 2 = plain interpolation with a search (non-geometric grid).
-template <int MODE, bool CHEB, bool HASF, bool OUT>
+template <int MODE, bool CHEB, bool HASF, bool OUT, int OU>
 PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                         const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
-  float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the
-  constexpr int OU = 16;                                 // cross-thread reduction is fp64
+  float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the cross-thread reduction is fp64
   const double piA = T.geo_inv_dln, piBm = -(S.dop + T.ln0) * T.geo_inv_dln + kPosMagic;   // MODE 1: t = (lnobs - dop - ln0)/dln
   const double obBm = W.obB + kPosMagic;
   const float hs_ann = (float)(0.5 * T.dln);
@@ -1108,6 +1116,7 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
+template <int OU = 16>
 PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                           const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
   const bool cheb = T.npoly > 0, hasf = T.obs_f1 != nullptr, smooth = S.do_smooth != 0;
@@ -1117,12 +1126,12 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
     return hasf ? (double)nanf_() : 0.0;
   }
 #define PAYNE_OBS(MODE_)                                                                              \
-  (out ? (cheb ? (hasf ? obs_loop<MODE_, true, true, true>(tid, nthr, T, S, W, conv, out, out_stage)    \
-                       : obs_loop<MODE_, true, false, true>(tid, nthr, T, S, W, conv, out, out_stage))  \
-               : (hasf ? obs_loop<MODE_, false, true, true>(tid, nthr, T, S, W, conv, out, out_stage)   \
-                       : obs_loop<MODE_, false, false, true>(tid, nthr, T, S, W, conv, out, out_stage))) \
-       : (cheb ? obs_loop<MODE_, true, true, false>(tid, nthr, T, S, W, conv, out, out_stage)           \
-               : obs_loop<MODE_, false, true, false>(tid, nthr, T, S, W, conv, out, out_stage)))
+  (out ? (cheb ? (hasf ? obs_loop<MODE_, true, true, true, OU>(tid, nthr, T, S, W, conv, out, out_stage)    \
+                       : obs_loop<MODE_, true, false, true, OU>(tid, nthr, T, S, W, conv, out, out_stage))  \
+               : (hasf ? obs_loop<MODE_, false, true, true, OU>(tid, nthr, T, S, W, conv, out, out_stage)   \
+                       : obs_loop<MODE_, false, false, true, OU>(tid, nthr, T, S, W, conv, out, out_stage))) \
+       : (cheb ? obs_loop<MODE_, true, true, false, OU>(tid, nthr, T, S, W, conv, out, out_stage)           \
+               : obs_loop<MODE_, false, true, false, OU>(tid, nthr, T, S, W, conv, out, out_stage)))
   float acc;
   if (smooth) acc = PAYNE_OBS(0);
   else if (T.geo) acc = PAYNE_OBS(1);

@@ -17,6 +17,7 @@ struct PostArgs {
   const double* mags; int n_filters; // SED magnitudes of this batch (null: no photometry)
   const double* obs_mag; const double* obs_err;
   unsigned long long* stamps;        // diagnostic build: [B][kStampRow] cycle stamps (slot 0 = count)
+  int stamp_sparse;                  // diagnostic build: only the first and the last stamp (slots 1 and kStampRow - 1)
   const CandState* prep;             // [B] per-candidate records made by the first dense launch (null: none)
 };
 
@@ -40,6 +41,7 @@ struct DevExecT {
   // diagnostic build only (libpayne_hip_diag.so): cycle stamp after every phase barrier
   unsigned long long* stamps = nullptr;
   int nst = 0;
+  bool sparse = false;
 #endif
   template <class F>
   __device__ __forceinline__ void par(F&& f) {
@@ -52,7 +54,7 @@ struct DevExecT {
   // diagnostic build: an extra cycle stamp inside a phase, written by thread `who`
   __device__ __forceinline__ void mark(int who) {
 #ifdef PAYNE_STAMPS
-    if (stamps && nst < kStampRow - 2) { ++nst; if ((int)threadIdx.x == who) stamps[nst] = __builtin_amdgcn_s_memtime(); }
+    if (stamps && nst < kStampRow - 2) { ++nst; if (!sparse && (int)threadIdx.x == who) stamps[nst] = __builtin_amdgcn_s_memtime(); }
 #else
     (void)who;
 #endif
@@ -117,6 +119,7 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
     ex.stamps = a.stamps + (size_t)b * kStampRow;
     if (threadIdx.x == 0) { ex.stamps[1] = __builtin_amdgcn_s_memtime(); }
     ex.nst = 1;
+    ex.sparse = a.stamp_sparse != 0;
   }
 #endif
   double* chi2 = red + scratch_doubles(kPostThreads) - 1;
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
     a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
   }
 #ifdef PAYNE_STAMPS
-  if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
+  if (a.stamps && threadIdx.x == 0) { ex.stamps[0] = (unsigned long long)ex.nst; ex.stamps[kStampRow - 1] = __builtin_amdgcn_s_memtime(); }
 #endif
 }
 

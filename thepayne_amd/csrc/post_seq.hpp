@@ -123,7 +123,8 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
       c32* z = fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
-      ex.par([&](int t, int) { rfft_taper_phase<VSINI>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
+      constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
+      ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
       float* res = (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
       edge = false;
@@ -144,8 +145,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
                              float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr) {
   // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer
   const bool direct = (out_stage != 0) && T.rot_identity && (th[5] != 0.0);
+  // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
+  constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : 16;
   ex.par([&](int t, int n) {
-    RowRegs row;
+    RowRegsT<UX / 4> row;
     phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     if (prep) phase_take_prep(t, prep, S);             // per-candidate scalars were computed ahead of the kernel
     else phase_setup(t, n, T, th, instr_factor, S);
@@ -204,14 +207,14 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       W = make_window(T, S, cnt, n_slots(nthr));
     }
     if (!W.bad) {
-      ex.par([&](int t, int n) { phase_R_resample(t, n, T, S, W, spec, work); });
+      ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
       bool no_edge = false;
       on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta, no_edge);
     }
   }
-  ex.par([&](int t, int n) { store_partial(t, phase_obs(t, n, T, S, W, on_grid, out, out_stage), red); });
+  ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
   // the sum of the per-wave partials: thread 0 alone, no closing barrier (it is also the only reader)
   ex.single([&](int n) {
     double s = 0.0;

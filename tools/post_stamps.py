@@ -47,7 +47,7 @@ def problem(cfg_name):
 
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C2"
 raw, obs, flux, eflux = problem(cfgname)
-B = synth.CONFIGS[cfgname]["batch"]
+B = int(os.environ.get("STAMP_BATCH", synth.CONFIGS[cfgname]["batch"]))
 eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=B)
 th = eng._theta(theta_full(synth.draw_candidates(B, seed=1)), eng.ncols)
 eng.lnlike_batch(th)
@@ -61,6 +61,10 @@ for rep in range(3):
     rc = fn(eng._ctx, th.data_ptr(), B, st.ctypes.data)
     assert rc == 0, eng.lib.payne_last_error(eng._ctx)
 n = int(st[0, 0])
+whole = st[:, ROW - 1].astype(np.int64) - st[:, 1].astype(np.int64)
+print("whole kernel per candidate (first stamp -> kernel end): median %d cycles" % np.median(whole))
+if os.environ.get("PAYNE_DIAG_SPARSE"):
+    sys.exit(0)
 d = np.diff(st[:, 1:n + 1].astype(np.int64), axis=1)
 med = np.median(d, axis=0)
 names = ["setup+load"]
