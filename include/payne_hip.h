@@ -315,6 +315,20 @@ int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, double* lnprob
                           int n_ell, const int* ell, double scale, double loglstar, int walks,
                           unsigned long long seed, int* nacc, int* ncall, void* stream);
 
+/* One queue of random-walk proposals of the batched static sampler, start to finish (the body of the sampler's "fill the
+ * queue" step: what dynesty does per proposal in sample_rwalk + the pool's queue, Payne/fitting/fitstar.py:309-338): K
+ * chains start from live points drawn at random (splitmix of `seed`); with n_ell > 1 each steps in the metric of an
+ * ellipsoid that holds its start point (ctr [n_ell][ndim] / ainv [n_ell][ndim][ndim] of payne_ns_bound; else the nearest);
+ * upload, `walks` Metropolis steps under lnprob > loglstar on the device (payne_rwalk_begin_ell / _step; a proposal that
+ * leaves the unit cube is redrawn without a likelihood call, as dynesty does), download, and the chains that moved at
+ * least once become the queue: qu, qv [nq][ndim], ql [nq] (NaN -> -inf), qnc [nq] (likelihood calls behind each), HOST
+ * arrays of capacity K owned by the caller.  stats[0..3] = accepted steps, likelihood calls, redrawn proposals, calls of the
+ * chains that never moved.  live_*: HOST; axes_unit: HOST [n_ell][ndim][ndim].  Synchronises `stream`. */
+int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl, int nlive,
+                         int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv, double scale,
+                         double loglstar, int walks, unsigned long long seed, double* qu, double* qv, double* ql, int* qnc,
+                         int* nq, long long* stats, void* stream);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

@@ -382,3 +382,50 @@ def test_fitpayne_slice_sampling_on_the_device(tmp_path):
     T = synth.TRUTH
     truth = np.array([T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]])
     assert np.all(np.abs(mean - truth) < 5 * std + 1e-3 * np.abs(truth)), (mean, std, truth)
+
+
+def test_rwalk_queue_in_one_native_call(tmp_path):
+    """payne_ns_rwalk_queue: start points, ellipsoid assignment, the walk and the selection of the moved chains in one
+    call.  Every queued proposal beats the threshold, is the prior transform of its unit-cube point, carries the
+    lnprob the host path computes for it, and the counters add up; near a face of the cube proposals are redrawn
+    (no likelihood call) instead of being wasted."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    L, P, OL = _fit_objects(tmp_path, photscale=True)
+    prop = _proposer(L, P, k_max=64)
+    rng = np.random.default_rng(21)
+    nd, nlive, K, walks = L.ndim, 96, 64, 8
+    live_u = np.ascontiguousarray(rng.uniform(0.35, 0.65, size=(nlive, nd)))
+    live_v, ll = prop.lnprob_u(live_u)
+    live_v = np.ascontiguousarray(live_v)
+    ll = np.ascontiguousarray(np.where(np.isnan(ll), -np.inf, ll))
+    lstar = float(np.percentile(ll[np.isfinite(ll)], 30))
+    qbuf = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+    # two ellipsoids: left and right half of the cloud along the first axis
+    ctr = np.stack([live_u[live_u[:, 0] < 0.5].mean(0), live_u[live_u[:, 0] >= 0.5].mean(0)])
+    ainv = np.stack([np.eye(nd) / 0.25, np.eye(nd) / 0.25])
+    axes = np.stack([0.03 * np.eye(nd), 0.01 * np.eye(nd)])
+    nq, acc, calls, redrawn, idle = prop.rwalk_queue(live_u, live_v, ll, K, axes, ctr, ainv, 1.0, lstar, walks, 4242, qbuf)
+    qU, qV, ql, qnc = [a[:nq] for a in qbuf]
+    assert 0 < nq <= K and calls == K * walks and redrawn == 0 and acc >= nq
+    assert int(qnc.sum()) + idle == calls
+    assert np.all((qU > 0) & (qU < 1)) and np.all(ql > lstar)
+    np.testing.assert_allclose(qV, P.priortrans_batch(qU), rtol=1e-11, atol=1e-11)
+    host = lnprob_batch(qV, L, P)
+    assert np.all(np.abs(ql - host) <= 1e-9 * np.abs(host) + 1e-9)
+    # every chain stayed within walks steps of SOME live point, in the metric of the larger ellipsoid at most
+    d = np.abs(qU[:, None, :] - live_u[None, :, :]).max(axis=2).min(axis=1)
+    assert np.all(d <= walks * 0.03 + 1e-12)
+    # same seed, same queue; single ellipsoid form
+    again = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+    nq2 = prop.rwalk_queue(live_u, live_v, ll, K, axes, ctr, ainv, 1.0, lstar, walks, 4242, again)[0]
+    assert nq2 == nq and np.array_equal(again[0][:nq], qU) and np.array_equal(again[2][:nq], ql)
+    nq3, acc3, calls3, red3, idle3 = prop.rwalk_queue(live_u, live_v, ll, K, axes[0], None, None, 1.0, -np.inf, walks, 7, again)
+    assert calls3 == K * walks and nq3 == K                      # threshold -inf: every chain moves (finite lnprob rows)
+    # live points on a face of the cube: proposals that leave it are redrawn, every step is still a likelihood call
+    edge_u = live_u.copy(); edge_u[:, 0] = 1e-3
+    edge_v, edge_l = prop.lnprob_u(edge_u)
+    edge_l = np.where(np.isnan(edge_l), -np.inf, edge_l)
+    nq4, acc4, calls4, red4, idle4 = prop.rwalk_queue(edge_u, np.ascontiguousarray(edge_v), np.ascontiguousarray(edge_l), K,
+                                                      0.05 * np.eye(nd), None, None, 1.0, -np.inf, walks, 9, again)
+    assert calls4 == K * walks and red4 > K and np.all(again[0][:nq4] > 0)
+    prop.close()

@@ -838,9 +838,14 @@ struct payne_sampler {
   double *u_prop = nullptr, *v_prop = nullptr, *lnprior = nullptr, *lnl = nullptr, *rows = nullptr, *axes = nullptr;
   int* inside = nullptr;
   int* ell = nullptr;                     // per-chain ellipsoid index of the walk in progress
+  int* nredraw = nullptr;                 // per-chain count of proposals redrawn because they left the unit cube
+  // staging of payne_ns_rwalk_queue: chains (u | v | lnprob) and counters (nacc | ncall | nredraw), device + pinned host
+  double *q_dev = nullptr, *q_host = nullptr;
+  int *qi_dev = nullptr, *qi_host = nullptr;
+  std::vector<int> q_start, q_ell;
   std::vector<void*> owned;
   // a walk in progress (payne_rwalk_begin / payne_rwalk_step)
-  struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; bool multi; } run{};
+  struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; bool multi; int* nredraw; } run{};
 };
 
 extern "C" void payne_sampler_destroy(payne_sampler* s) {
@@ -849,6 +854,8 @@ extern "C" void payne_sampler_destroy(payne_sampler* s) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(s->ctx->device);
   for (void* p : s->owned) (void)hipFree(p);
+  if (s->q_host) (void)hipHostFree(s->q_host);
+  if (s->qi_host) (void)hipHostFree(s->qi_host);
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -883,11 +890,17 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
   if ((rc = alloc(K * nd * 8, (void**)&s->u_prop)) || (rc = alloc(K * nd * 8, (void**)&s->v_prop)) ||
       (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
       (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
-      (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell))) {
+      (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell)) || (rc = alloc(K * 4, (void**)&s->nredraw)) ||
+      (rc = alloc(K * (2 * nd + 1) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev))) {
     payne_sampler_destroy(s);
     return rc;
   }
   (void)hipMemset(s->inside, 0, K * 4);
+  if (hipHostMalloc((void**)&s->q_host, K * (2 * nd + 1) * 8, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&s->qi_host, 3 * K * 4, hipHostMallocDefault) != hipSuccess) {
+    payne_sampler_destroy(s);
+    return fail(c, PAYNE_E_HIP, "hipHostMalloc(sampler staging)");
+  }
   *out = s;
   return PAYNE_OK;
 }
@@ -945,7 +958,8 @@ extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, dou
   if (ell) HIPCHK(s->ctx, hipMemcpyAsync(s->ell, ell, (size_t)K * 4, hipMemcpyHostToDevice, st));
   HIPCHK(s->ctx, hipMemsetAsync(nacc, 0, (size_t)K * 4, st));
   HIPCHK(s->ctx, hipMemsetAsync(ncall, 0, (size_t)K * 4, st));
-  s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr};
+  HIPCHK(s->ctx, hipMemsetAsync(s->nredraw, 0, (size_t)K * 4, st));
+  s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr, s->nredraw};
   return PAYNE_OK;
 }
 extern "C" int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
@@ -963,7 +977,7 @@ extern "C" int payne_rwalk_step(payne_sampler* s, int w) {
   hipLaunchKernelGGL(payne_rwalk_kernel, grid, block, 0, st, s->sd, r.K, r.u, r.v, r.lnprob, r.nacc, r.ncall, s->u_prop,
                      s->v_prop, s->lnprior, s->inside, s->lnl, s->rows, s->axes, r.multi ? s->ell : (const int*)nullptr, r.scale,
                      r.loglstar, r.seed, w,
-                     w > 0 ? 1 : 0, w < r.walks ? 1 : 0);
+                     w > 0 ? 1 : 0, w < r.walks ? 1 : 0, r.nredraw);
   int rc = PAYNE_OK;
   if (w < r.walks) rc = payne_lnlike_batch(s->ctx, s->rows, r.K, s->lnl, r.stream);
   else s->run.open = false;
@@ -977,6 +991,99 @@ extern "C" int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double*
   int rc = payne_rwalk_begin(s, u, v, lnprob, K, axes, scale, loglstar, walks, seed, nacc, ncall, stream);
   for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
   return rc;
+}
+
+// The random-walk queue of the batched nested sampler in one call: start points, ellipsoid assignment, upload, the walk,
+// download, and the chains that moved as the proposal queue (header: payne_ns_rwalk_queue).
+extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
+                                    int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                                    double scale, double loglstar, int walks, unsigned long long seed, double* qu, double* qv,
+                                    double* ql, int* qnc, int* nq, long long* stats, void* stream) {
+  int rc = sampler_check(s, live_u, K, live_v);
+  if (rc) return rc;
+  payne_ctx* c = s->ctx;
+  if (!live_logl || !axes_unit || !qu || !qv || !ql || !qnc || !nq || !stats || nlive <= 0 || walks <= 0)
+    return fail(c, PAYNE_E_INVALID, "bad payne_ns_rwalk_queue arguments");
+  if (n_ell < 1 || n_ell > PAYNE_MAX_ELL || (n_ell > 1 && (!ctr || !ainv))) return fail(c, PAYNE_E_INVALID, "bad ellipsoid list");
+  const int nd = s->sd.ndim;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // ---- start points (uniform among the live points) and, with several ellipsoids, the one each chain steps in: one that
+  //      holds its start point (a random one of those), else the nearest
+  auto mix = [](unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+  };
+  s->q_start.resize(K); s->q_ell.resize(K);
+  double* hu = s->q_host;
+  double* hv = hu + (size_t)K * nd;
+  double* hl = hv + (size_t)K * nd;
+  for (int k = 0; k < K; ++k) {
+    const unsigned long long r0 = mix(seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull));
+    const int i = (int)(r0 % (unsigned long long)nlive);
+    s->q_start[k] = i;
+    std::memcpy(hu + (size_t)k * nd, live_u + (size_t)i * nd, (size_t)nd * 8);
+    std::memcpy(hv + (size_t)k * nd, live_v + (size_t)i * nd, (size_t)nd * 8);
+    hl[k] = live_logl[i];
+    int pick = 0;
+    if (n_ell > 1) {
+      int best = 0, nin = 0;
+      double dbest = INFINITY;
+      unsigned long long r1 = mix(r0);
+      for (int e = 0; e < n_ell; ++e) {
+        const double* ce = ctr + (size_t)e * nd;
+        const double* ai = ainv + (size_t)e * nd * nd;
+        double d2 = 0.0;
+        for (int a = 0; a < nd; ++a) {
+          double y = 0.0;
+          for (int b = 0; b < nd; ++b) y += ai[a * nd + b] * (live_u[(size_t)i * nd + b] - ce[b]);
+          d2 += y * y;
+        }
+        if (d2 < dbest) { dbest = d2; best = e; }
+        if (d2 <= 1.0) {                                   // reservoir choice among the ellipsoids that hold the point
+          ++nin;
+          r1 = mix(r1);
+          if (r1 % (unsigned long long)nin == 0) pick = e;
+        }
+      }
+      if (nin == 0) pick = best;
+    }
+    s->q_ell[k] = pick;
+  }
+  const size_t nq_d = (size_t)K * (2 * nd + 1);
+  HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, nq_d * 8, hipMemcpyHostToDevice, st));
+  double* du = s->q_dev;
+  double* dv = du + (size_t)K * nd;
+  double* dl = dv + (size_t)K * nd;
+  int* dna = s->qi_dev;
+  int* dnc = dna + K;
+  rc = payne_rwalk_begin_ell(s, du, dv, dl, K, axes_unit, n_ell, n_ell > 1 ? s->q_ell.data() : nullptr, scale, loglstar, walks, seed,
+                             dna, dnc, stream);
+  for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, nq_d * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(s->qi_host, s->qi_dev, (size_t)2 * K * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(s->qi_host + 2 * K, s->nredraw, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  // ---- the chains that moved are the queue; a chain that never moved is a copy of a live point
+  long long acc = 0, calls = 0, redraw = 0, idle_calls = 0;
+  int m = 0;
+  const int *na = s->qi_host, *nc = na + K, *nr = nc + K;
+  for (int k = 0; k < K; ++k) {
+    acc += na[k]; calls += nc[k]; redraw += nr[k];
+    if (na[k] > 0) {
+      std::memcpy(qu + (size_t)m * nd, hu + (size_t)k * nd, (size_t)nd * 8);
+      std::memcpy(qv + (size_t)m * nd, hv + (size_t)k * nd, (size_t)nd * 8);
+      const double l = hl[k];
+      ql[m] = (l != l) ? -INFINITY : l;
+      qnc[m] = nc[k] > 1 ? nc[k] : 1;
+      ++m;
+    } else {
+      idle_calls += nc[k];
+    }
+  }
+  *nq = m;
+  stats[0] = acc; stats[1] = calls; stats[2] = redraw; stats[3] = idle_calls;
+  return PAYNE_OK;
 }
 
 extern "C" int payne_bc_batch(payne_ctx* c, const double* x, int B, double* bc, void* stream) {

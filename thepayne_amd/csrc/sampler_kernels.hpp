@@ -71,6 +71,11 @@ __device__ __forceinline__ double u01(unsigned long long seed, unsigned chain, u
   return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);      // (0,1)
 }
 
+__device__ __forceinline__ float u01f(unsigned long long seed, unsigned chain, unsigned step, unsigned draw) {
+  const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)chain << 32 | step)) + draw);
+  return ((float)(unsigned)(x >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0,1), 24 bits
+}
+
 // transform only (mode 0) or transform + ln-prior + theta row (mode 1)
 __global__ void payne_prior_kernel(SamplerDev sd, const double* u, int K, double* v, double* lnprior, double* rows, int mode) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,6 +101,7 @@ __global__ void payne_lnprob_kernel(const double* lnprior, const double* lnl, in
 // normcdfinv chains in fp64) of the dimensions run side by side, the ellipsoid step is a shuffle
 // matvec, sums are wave reductions.  (One thread per chain spent 14 us per step in a ~3000-instruction
 // dependent fp64 chain; the step sits between two likelihood batches, nothing overlaps it.)
+constexpr int kRedrawPasses = 2;
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -104,7 +110,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, int K, double* u, double* v, double* lnprob, int* nacc, int* ncall,
                                    double* u_prop, double* v_prop, double* lnprior_prop, int* inside,
                                    const double* lnl_prop, double* rows, const double* axes, const int* ell, double scale,
-                                   double loglstar, unsigned long long seed, int step, int settle, int propose) {
+                                   double loglstar, unsigned long long seed, int step, int settle, int propose, int* nredraw) {
   const int lane = threadIdx.x & 63;
   const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (c >= K) return;                                           // the whole wave leaves together
@@ -112,36 +118,70 @@ __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, int K, 
   const bool act = lane < nd;
   const int dl = act ? lane : 0;
   const size_t off = (size_t)c * nd + dl;
+  // every global value the step needs is requested up front (valid addresses whatever the flags say): the kernel is a
+  // chain of dependent L2 round trips otherwise, ~1 us each, between two likelihood batches
   double uc = u[off];
-  if (settle && inside[c]) {
-    const double lpr = lnprior_prop[c];
-    const double lp = (lpr == -INFINITY) ? -INFINITY : lpr + lnl_prop[c];
+  double vc = v[off];
+  const int was_in = inside[c];
+  const double lpr = lnprior_prop[c], lnl_p = lnl_prop[c];
+  const double u_p = u_prop[off], v_p = v_prop[off];
+  const int my_ell = ell ? ell[c] : 0;
+  if (settle && was_in) {
+    const double lp = (lpr == -INFINITY) ? -INFINITY : lpr + lnl_p;
     const bool accept = lp > loglstar;                          // false for NaN
-    if (accept && act) { uc = u_prop[off]; u[off] = uc; v[off] = v_prop[off]; }
+    if (accept && act) { uc = u_p; vc = v_p; u[off] = uc; v[off] = vc; }
     if (lane == 0) {
       ncall[c] += 1;
       if (accept) { lnprob[c] = lp; nacc[c] += 1; }
     }
   }
   if (!propose) return;
-  // z uniform in the unit ball: normal direction (one Box-Muller cosine per lane), radius U^(1/n)
-  double z = 0.0;
-  if (act) {
-    const double a = u01(seed, c, step, 2 * lane), b = u01(seed, c, step, 2 * lane + 1);
-    z = sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b);
+  // z uniform in the unit ball: normal direction (one Box-Muller cosine per lane), radius U^(1/n).  A proposal that
+  // leaves the unit cube is redrawn at once, without a likelihood call, as dynesty's rwalk does (it counts such a
+  // draw as a rejection for the scale adaptation: `nredraw`).  The wave draws 64 / NP candidates SIDE BY SIDE (NP =
+  // dimensions rounded up to a power of two: lanes g NP .. g NP + NP - 1 hold candidate g) and takes the first one
+  // inside the cube: one pass costs what one draw costs, and the step is given up only after kRedrawPasses passes.
+  const double* ax = axes + (size_t)my_ell * nd * nd;                // this chain's ellipsoid (bound='multi')
+  int NP = 8;
+  while (NP < nd) NP <<= 1;
+  const int G = 64 / NP, g = lane / NP, dg = lane - g * NP;
+  const bool actg = dg < nd;
+  const int dgl = actg ? dg : 0;
+  const double ucg = __shfl(uc, dgl);                               // the chain's position, seen by every candidate group
+  double up = uc;
+  bool in = false;
+  int skipped = 0;
+  for (int pass = 0; pass < kRedrawPasses && !in; ++pass) {
+    const unsigned d0 = (unsigned)(pass * G + g) * 192u;
+    // the random direction and radius in fp32 (v_log_f32 / v_cos_f32 / v_exp_f32 / v_rsq_f32: a draw carries 24 random
+    // bits per coordinate anyway); the chain's position and the step added to it stay fp64
+    float z = 0.f;
+    if (actg) {
+      const float a = u01f(seed, c, step, d0 + 2 * dg), b = u01f(seed, c, step, d0 + 2 * dg + 1);
+      z = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a)) * __builtin_amdgcn_cosf(b);   // -2 ln a = -2 ln2 log2 a; cos(2 pi b)
+    }
+    float n2 = z * z;
+    for (int o = NP >> 1; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);   // sum over the candidate's own lanes
+    const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01f(seed, c, step, d0 + 128)) / (float)nd) * __builtin_amdgcn_rsqf(n2);
+    double sdot = 0.0;
+    for (int e = 0; e < nd; ++e) {
+      const float ze = __shfl(z, g * NP + e);
+      sdot = fma(ax[dgl * nd + e], (double)ze, sdot);
+    }
+    const double upg = ucg + (scale * (double)rad) * sdot;
+    const unsigned long long bad = __ballot(actg && !((upg > 0.0) && (upg < 1.0)));
+    int first = -1;
+    for (int q = G - 1; q >= 0; --q) {
+      const unsigned long long m = (NP == 64 ? ~0ull : ((1ull << NP) - 1ull)) << (q * NP);
+      if ((bad & m) == 0ull) first = q;
+    }
+    in = first >= 0;
+    skipped += in ? first : G;
+    up = __shfl(upg, (in ? first : 0) * NP + dl);                    // lanes d < nd take candidate `first`
   }
-  const double n2 = wave_sum(z * z);
-  const double rad = pow(u01(seed, c, step, 128), 1.0 / (double)nd) / sqrt(n2);
-  const double* ax = axes + (ell ? (size_t)ell[c] * nd * nd : 0);   // this chain's ellipsoid (bound='multi')
-  double sdot = 0.0;
-  for (int e = 0; e < nd; ++e) {
-    const double ze = __shfl(z, e);
-    sdot = fma(ax[dl * nd + e], ze, sdot);
-  }
-  const double up = uc + scale * rad * sdot;
-  const bool in = __ballot(act && !((up > 0.0) && (up < 1.0))) == 0ull;
+  if (nredraw && lane == 0) nredraw[c] += skipped;
   const payne_prior_dim dim = sd.dims[dl];
-  const double vp = in ? prior_ppf(dim, up) : v[off];           // outside: a harmless valid row
+  const double vp = in ? prior_ppf(dim, up) : vc;               // outside: a harmless valid row
   const double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
   if (act) { u_prop[off] = up; v_prop[off] = vp; }
   if (lane == 0) { inside[c] = in ? 1 : 0; lnprior_prop[c] = lp; }

@@ -69,6 +69,7 @@ class DeviceProposer(object):
         self._nacc = self.torch.empty(self.k_max, dtype=i32, device=dev)
         self._ncall = self.torch.empty(self.k_max, dtype=i32, device=dev)
         self._pack_h = None                  # pinned staging for rwalk, made on first use
+        self._qstats = np.zeros(4, dtype=np.int64)
 
     # -- prior description -----------------------------------------------------------
     def _kind(self, name):
@@ -141,6 +142,30 @@ class DeviceProposer(object):
         for w in range(int(walks) + 1):
             self.rwalk_step(w)
         return self.rwalk_finish()
+
+    def rwalk_queue(self, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed, qbuf):
+        """One whole queue of random-walk proposals in ONE native call (payne_ns_rwalk_queue): start points, ellipsoid
+        assignment, transfers, the walk and the selection of the chains that moved.  ``qbuf`` = (qU[K, nd], qV[K, nd],
+        ql[K], qnc[K] int32) host arrays the queue is written to.  Returns (nq, accepted, calls, redrawn, idle_calls)."""
+        if K > self.k_max:
+            raise ValueError("K > k_max")
+        ax = np.ascontiguousarray(axes_unit, dtype=np.float64)
+        n_ell = 1 if ax.ndim == 2 else ax.shape[0]
+        cp = ap = None
+        if n_ell > 1:
+            ctr = np.ascontiguousarray(ctr, dtype=np.float64)
+            ainv = np.ascontiguousarray(ainv, dtype=np.float64)
+            cp, ap = ctr.ctypes.data, ainv.ctypes.data
+        qU, qV, ql, qnc = qbuf
+        nq = C.c_int(0)
+        stats = self._qstats
+        rc = self.lib.payne_ns_rwalk_queue(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
+                                           len(live_logl), int(K), ax.ctypes.data, n_ell, cp, ap, float(scale), float(loglstar),
+                                           int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, qU.ctypes.data, qV.ctypes.data,
+                                           ql.ctypes.data, qnc.ctypes.data, C.byref(nq), stats.ctypes.data, self._stream())
+        if rc != 0:
+            self.eng._err(rc, "payne_ns_rwalk_queue")
+        return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
 
     # the same in three parts (MultiPopProposer interleaves the steps of several populations)
     def rwalk_begin(self, U, V, lnprob, axes, scale, loglstar, walks, seed, stream=None, ell=None):

@@ -166,6 +166,8 @@ class NestedSampler(object):
         self.scale = 1.0
         self._pending_nc = 0
         self._clear_queue()
+        self._qbuf = None
+        self._ell_stack = None
         self._since_update = 0
         # native bookkeeping (C++); native=False keeps the same loop in Python (cross-check / no library)
         self._lib = None
@@ -214,9 +216,11 @@ class NestedSampler(object):
             if rc != 0:
                 raise RuntimeError("payne_ns_bound failed (%d)" % rc)
             ells = [_Ell.from_arrays(ctr[e], ax[e], au[e], ai[e], lv[e]) for e in range(ne.value)]
+            self._ell_stack = (ctr[:ne.value], au[:ne.value], ai[:ne.value])       # contiguous: handed to the native queue call
         else:
             whole = _Ell(u, self.enlarge)
             ells = _split_ellipsoids(u, whole, self.enlarge, [MAX_ELL]) if split else [whole]
+            self._ell_stack = tuple(np.stack([getattr(e, k) for e in ells]) for k in ("ctr", "axes_unit", "ainv"))
         if split:
             self._split_wait = 1 if len(ells) > 1 else 4
         self._ells = ells                  # (an update without a split attempt always follows a single-cloud result)
@@ -272,6 +276,21 @@ class NestedSampler(object):
                 self._clear_queue()
                 self._update_bound()
             self.ncall += nin
+            return
+        if self.method == 'rwalk' and hasattr(self.proposer, "rwalk_queue"):
+            # the whole queue in one native call: start points, ellipsoid assignment, transfers, walk, selection
+            if self._qbuf is None or len(self._qbuf[2]) < K:
+                self._qbuf = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+            ctr, au, ai = self._ell_stack
+            nq, acc, calls, redrawn, idle = self.proposer.rwalk_queue(
+                self.live_u, self.live_v, self.live_logl, K, au if len(au) > 1 else au[0], ctr, ai, self.scale, lstar,
+                self.walks, int(rng.integers(0, 2 ** 62)), self._qbuf)
+            self.ncall += calls
+            frac = acc / max(1, calls + redrawn)          # a redrawn (out-of-cube) proposal counts as a rejection (dynesty)
+            self.scale = min(max(self.scale * math.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)
+            self._pending_nc += idle
+            qU, qV, ql, qnc = self._qbuf
+            self._qU, self._qV, self._ql, self._qnc, self._qpos = qU[:nq], qV[:nq], ql[:nq], qnc[:nq], 0
             return
         # rwalk / slice: K lock-step chains
         start = rng.integers(0, self.nlive, size=K)
