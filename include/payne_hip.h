@@ -111,6 +111,8 @@ typedef struct payne_opts {
 #define PAYNE_V_POST_FULL 8u     /* likelihood through the full post kernel instead of its likelihood-only build */
 #define PAYNE_V_NO_PREP 16u      /* per-candidate records computed inside the post kernel (what 2-layer nets use) */
 #define PAYNE_V_BIG_PLAIN 32u    /* spectra > 16384 px: plain radix-8 passes instead of the four-step transform */
+#define PAYNE_V_SELECT_MEDIAN 64u /* continuum / LSF medians by radix selection (what rows too long for an LDS sort use) */
+#define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;
 
@@ -131,7 +133,7 @@ int payne_ctx_set_obs(payne_ctx* ctx, const payne_obs_desc* obs);
  * (Payne/predict/ystpred.py:81-85): every spectrum the context produces from then on is the spectral
  * ANN's output times the continuum network's, converted F_nu -> F_lambda, normalised by its
  * NaN-ignoring median and interpolated onto the spectral ANN grid (NaN outside; ystpred.py:191-209).
- * Same descriptor as the spectral model (`resolution` unused); n_labels must match; npix <= 8192. */
+ * Same descriptor as the spectral model (`resolution` unused); n_labels must match; any npix. */
 int payne_ctx_set_continuum(payne_ctx* ctx, const payne_model_desc* cont);
 
 /* LSF-vector instrumental broadening: getspec(inst_R=<array>, outwave=...) (Payne/predict/ystpred.py:248-269
@@ -139,7 +141,8 @@ int payne_ctx_set_continuum(payne_ctx* ctx, const payne_model_desc* cont);
  * lsf: HOST fp64 [n], the Gaussian dispersion (same units as the wavelengths) at every pixel of the bound
  * observed grid (n must equal its length).  While a vector is set, theta's Inst_R column is ignored by
  * payne_lnlike_batch and stages 2/3 of payne_predict_batch; results are never NaN inside the model's range
- * (np.interp clamps).  NULL removes it; payne_ctx_set_obs removes it too.  Spectra up to 8192 pixels. */
+ * (np.interp clamps).  NULL removes it; payne_ctx_set_obs removes it too.  Any spectrum length; the FFT length the
+ * reference derives from the vector (smoothing.py:533-538) must not exceed the model's own (pow2ceil(npix)): NaN then. */
 int payne_ctx_set_lsf(payne_ctx* ctx, const double* lsf, int n);
 
 void payne_ctx_destroy(payne_ctx* ctx);

@@ -435,8 +435,69 @@ def g11_native_grid():
          plain=np.array(plain), poly=np.array(poly))
 
 
+# ------------------------------------------------------------------ G12
+def g12_long_rows():
+    """The branches the build used to cap at 8192 pixels, and the corner its tolerance excepted, at sizes past those
+    caps, as the REFERENCE computes them:
+      * lsf20k: getspec with an LSF vector on a 20 000-pixel model (smooth_lsf_fft, smoothing.py:482-586);
+      * cont_long / cont_kk: a continuum network of 9 001 pixels (median of a row too long for an LDS sort), and one
+        whose x_min / x_max are stored in kK -- PayneSpecPredict rescales the SPECTRAL net only (ystpred.py:76-85);
+      * rot_tiny: rot_vel = 1e-3 km/s on a 32 768-pixel grid, where the reference's fp64 taper expression
+        j1(u)/u - 3 cos(u)/2u^2 + 3 sin(u)/2u^3 (smoothing.py:616-617) is itself dominated by cancellation noise."""
+    out = {}
+    # ---- LSF vector on a 20 000-pixel model
+    net = synth.make_yst_net(npix=20000, H=16, seed=41, line_depth=0.3)
+    rs.register_yst('/g12/yst20k.h5', net)
+    PP = ystpred.PayneSpecPredict(nnpath='/g12/yst20k.h5', NNtype='YST1')
+    obs = synth.obs_grid(net["wavelength"], 3000, inset=30.0)
+    xo = (obs - obs.mean()) / (obs.max() - obs.min())
+    lsfs = np.array([np.full(len(obs), 0.09), 0.08 * (1.0 + 0.4 * xo)])
+    rows = np.array([(0.0, 0.0), (-21.0, 6.0)])
+    lab = np.array([5600.0, 4.3, -0.2, 0.1])
+    fin = np.zeros((len(lsfs), len(rows), len(obs)))
+    for b, lsf in enumerate(lsfs):
+        for c, (vrad, vrot) in enumerate(rows):
+            with np.errstate(all="ignore"):
+                fin[b, c] = PP.getspec(rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=lsf, outwave=obs,
+                                       Teff=lab[0], logg=lab[1], feh=lab[2], afe=lab[3])[1]
+    out.update(lsf_obs=obs, lsf_lsfs=lsfs, lsf_rows=rows, lsf_label=lab, lsf_final=fin)
+    # ---- continuum networks: a long one, and one stored in kK
+    snet = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    rs.register_yst('/g12/yst.h5', snet)
+    cobs = synth.obs_grid(snet["wavelength"], 700, inset=1.5)
+    labs = np.array([[5300.0, 4.1, -0.3, 0.15], [6400.0, 3.2, -1.4, 0.4]])
+    crows = np.array([(0.0, 0.0, 25000.0), (12.0, 4.0, 28000.0)])
+    out.update(cont_obs=cobs, cont_labels=labs, cont_rows=crows)
+    for tag, npc, kk in (("long", 9001, False), ("kk", 600, True)):
+        cnet = synth.make_cont_net(npix=npc, lam_lo=5140.0, lam_hi=5190.0)
+        if kk:
+            cnet["x_min"][0] /= 1000.0
+            cnet["x_max"][0] /= 1000.0
+        rs.register_yst('/g12/cont_%s.h5' % tag, cnet)
+        PC = ystpred.PayneSpecPredict(nnpath='/g12/yst.h5', Cnnpath='/g12/cont_%s.h5' % tag, NNtype='YST1')
+        out["cont_" + tag] = np.array([PC.predictcont(list(l)) for l in labs])
+        fin = []
+        for l in labs:
+            for vrad, vrot, R in crows:
+                with np.errstate(all="ignore"):
+                    fin.append(PC.getspec(rad_vel=vrad, rot_vel=vrot, vmic=np.nan, inst_R=2.355 * R, outwave=cobs,
+                                          Teff=l[0], logg=l[1], feh=l[2], afe=l[3])[1])
+        out["final_" + tag] = np.array(fin).reshape(len(labs), len(crows), len(cobs))
+    # ---- tiny rotation on a long grid
+    rnet = synth.make_yst_net(npix=32768, H=16, seed=43, line_depth=0.3)
+    rs.register_yst('/g12/yst32k.h5', rnet)
+    PR = ystpred.PayneSpecPredict(nnpath='/g12/yst32k.h5', NNtype='YST1')
+    rl = np.array([5900.0, 4.0, 0.1, 0.0])
+    kw = dict(Teff=rl[0], logg=rl[1], feh=rl[2], afe=rl[3])
+    vals = np.array([1e-3])
+    with np.errstate(all="ignore"):
+        rot = np.array([PR.getspec(rot_vel=v, **kw)[1] for v in vals])
+    out.update(rot_label=rl, rot_values=vals, rot_after=rot)
+    save("g12_long_rows", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid}[k]()
+         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows}[k]()

@@ -6,7 +6,7 @@ import pytest
 
 import oracle as O
 from thepayne_amd import synth, nnio
-from helpers import SPEC_PARS, yst_problem, lnl_tol
+from helpers import SPEC_PARS, yst_problem, lnl_tol, theta_full
 
 pytestmark = pytest.mark.gpu
 ALL_PARS = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R',
@@ -333,3 +333,112 @@ def test_genspec_on_any_grid_like_the_reference(tmp_path):
     lnl = GM.engine.lnlike_batch(th).cpu().numpy()[0]
     ref = -0.5 * O.chi2_spec(O.genspec(raw, base + [28000.0] + coef, outwave=obs, modpoly=True)[1], flux, eflux)
     assert abs(lnl - ref) <= lnl_tol(ref)
+
+
+def test_long_rows_against_reference_golden(tmp_path, golden):
+    """Sizes past the former 8192-pixel caps, against vectors frozen from the reference (g12): an LSF vector on a
+    20 000-pixel model (payne_lsf_kernel<GLOBAL>: buffers in global memory, median by radix selection), a 9 001-pixel
+    continuum network (median by selection), and a continuum network stored in kK, which the reference uses as stored
+    (only the spectral net gets the Teff/1000 fix, ystpred.py:76-85)."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    g = golden("g12_long_rows")
+    net = synth.make_yst_net(npix=20000, H=16, seed=41, line_depth=0.3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, net, "yst20k.npz"), NNtype='YST1', b_max=4)
+    lab = g["lsf_label"]
+    for b, lsf in enumerate(g["lsf_lsfs"]):
+        for c, (vrad, vrot) in enumerate(g["lsf_rows"]):
+            w, f = PP.getspec(rad_vel=vrad, rot_vel=vrot, inst_R=lsf, outwave=g["lsf_obs"], Teff=lab[0], logg=lab[1],
+                              feh=lab[2], afe=lab[3])
+            assert not np.isnan(f).any() and np.abs(f - g["lsf_final"][b, c]).max() < 2e-6, (b, c)
+    raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    spath = _save_yst(tmp_path, raw)
+    for tag, npc, kk in (("long", 9001, False), ("kk", 600, True)):
+        cnet = synth.make_cont_net(npix=npc, lam_lo=5140.0, lam_hi=5190.0)
+        if kk:
+            cnet["x_min"][0] /= 1000.0
+            cnet["x_max"][0] /= 1000.0
+        PC = PayneSpecPredict(nnpath=spath, Cnnpath=_save_yst(tmp_path, cnet, "cont_%s.npz" % tag), NNtype='YST1')
+        for i, l in enumerate(g["cont_labels"]):
+            cref = g["cont_" + tag][i]                       # (the kK net's outputs cross zero: error relative to the row's scale)
+            assert np.abs(PC.predictcont(list(l)) - cref).max() < 5e-6 * np.abs(cref).max(), tag
+            for j, (vrad, vrot, R) in enumerate(g["cont_rows"]):
+                _, f = PC.getspec(rad_vel=vrad, rot_vel=vrot, inst_R=2.355 * R, outwave=g["cont_obs"], Teff=l[0], logg=l[1],
+                                  feh=l[2], afe=l[3])
+                ref = g["final_" + tag][i, j]
+                assert np.array_equal(np.isnan(f), np.isnan(ref)) and np.nanmax(np.abs(f - ref)) < 2e-6, (tag, i, j)
+
+
+@pytest.mark.parametrize("variant", [64, 128], ids=["select_median", "lsf_global"])
+def test_long_row_forms_on_the_short_goldens(tmp_path, golden, variant):
+    """The forms long rows take (medians by radix selection, LSF buffers in global memory) forced onto the small
+    problems of g8 / g9, whose every case the reference froze."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    spath = _save_yst(tmp_path, raw)
+    if variant == 64:
+        g = golden("g8_continuum")
+        for tag, (lo, hi, npc) in {"full": (5140.0, 5190.0, 600), "short": (5140.0, 5170.0, 333)}.items():
+            cnet = synth.make_cont_net(npix=npc, lam_lo=lo, lam_hi=hi)
+            PP = PayneSpecPredict(nnpath=spath, Cnnpath=_save_yst(tmp_path, cnet, "c_%s.npz" % tag), NNtype='YST1', variant=variant)
+            for i, l in enumerate(g["labels"]):
+                for j, (vrad, vrot, R) in enumerate(g["rows"]):
+                    _, f = PP.getspec(rad_vel=vrad, rot_vel=vrot, inst_R=2.355 * R, outwave=g["obs"], Teff=l[0], logg=l[1],
+                                      feh=l[2], afe=l[3])
+                    ref = g["final_" + tag][i, j]
+                    assert np.array_equal(np.isnan(f), np.isnan(ref)) and np.nanmax(np.abs(f - ref)) < 2e-6, (tag, i, j)
+    else:
+        g = golden("g9_lsf")
+        PP = PayneSpecPredict(nnpath=spath, NNtype='YST1', variant=variant)
+        for a, l in enumerate(g["labels"]):
+            for b, lsf in enumerate(g["lsfs"]):
+                for c, (vrad, vrot) in enumerate(g["rows"]):
+                    _, f = PP.getspec(rad_vel=vrad, rot_vel=vrot, inst_R=lsf, outwave=g["obs"], Teff=l[0], logg=l[1],
+                                      feh=l[2], afe=l[3])
+                    assert np.abs(f - g["final"][a, b, c]).max() < 2e-6, (a, b, c)
+
+
+def test_tiny_rotation_corner_is_fixed_not_replicated(tmp_path, golden):
+    """rot_vel = 1e-3 km/s on 32 768 pixels.  The reference evaluates the rotational taper
+    j1(u)/u - 3 cos(u)/2u^2 + 3 sin(u)/2u^3 (smoothing.py:616-617) in fp64 where u ~ 1e-8 k: terms of 1e15 cancel to ~1,
+    so ITS lowest Fourier bins carry noise of order 1e-2 and its spectrum differs from the exact convolution (which at
+    1/3000 of a pixel is the identity to 1e-9) by up to a few 1e-5.  SURVEY appendix B's default is to replicate the
+    reference's numerics; this corner is FIXED instead: the kernel interpolates the analytic
+    taper.  The test pins both statements against the reference's own output (g12): the build agrees with the exact
+    answer to 1e-6, and the reference's output is within 5e-5 of it -- the measured size of the reference's noise,
+    which is what tests/test_fuzz_gpu.py allows in this corner."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    g = golden("g12_long_rows")
+    rnet = synth.make_yst_net(npix=32768, H=16, seed=43, line_depth=0.3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, rnet, "yst32k.npz"), NNtype='YST1', b_max=2)
+    rl = g["rot_label"]
+    kw = dict(Teff=rl[0], logg=rl[1], feh=rl[2], afe=rl[3])
+    _, exact = PP.getspec(**kw)                                   # no rotation: what a 1e-3 km/s kernel leaves unchanged
+    _, got = PP.getspec(rot_vel=float(g["rot_values"][0]), **kw)
+    ref = g["rot_after"][0]
+    inner = slice(2, -2)                                          # (the edge rule copies pixels 1 and n-2 outwards)
+    assert np.abs(got[inner] - exact[inner]).max() < 1e-6
+    dev_ref = np.abs(ref[inner] - exact[inner]).max()
+    assert 1e-7 < dev_ref < 5e-5, dev_ref                         # the reference's own noise, measured
+    assert np.abs(got[inner] - ref[inner]).max() < 5e-5
+
+
+def test_lsf_global_form_walks_the_batch_in_chunks(tmp_path):
+    """The global-memory LSF form bounds its workspace by processing 256 candidates per launch: a batch of 300 must
+    give, row for row, what the LDS form gives (same arithmetic apart from the median's algorithm)."""
+    from thepayne_amd.engine import PayneEngine
+    from thepayne_amd import nnio
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    lsf = 0.075 * (1.0 + 0.3 * (obs - obs.mean()) / (obs.max() - obs.min()))
+    th = theta_full(synth.draw_candidates(300, seed=12))
+    th[:, 7] = np.nan
+    res = []
+    for variant in (0, 128):
+        eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=300, variant=variant)
+        eng.set_lsf(lsf)
+        res.append(eng.lnlike_batch(th).cpu().numpy())
+        eng.close()
+    assert np.all(np.isfinite(res[0])) and np.allclose(res[0], res[1], rtol=1e-9, atol=1e-6)
+    L = O.OracleLikelihood(raw, obs, flux, eflux, [p for p in SPEC_PARS if p != 'Inst_R'], fixedpars={'Inst_R': lsf})
+    for k in (0, 255, 256, 299):                                   # both sides of the chunk boundary, against the oracle
+        ref = L.lnlikefn(list(th[k, :6]))
+        assert abs(res[1][k] - ref) <= lnl_tol(np.array([ref]))[0], k

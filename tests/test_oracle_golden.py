@@ -169,3 +169,37 @@ def test_g11_native_grid(golden):
             ok = ~np.isnan(ref)
             np.testing.assert_allclose(got[ok], ref[ok], rtol=0, atol=1e-12)
     assert np.isnan(g["plain"][0]).sum() == 2          # the end pixels fall outside the resampled grid
+
+
+def test_g12_long_rows(golden):
+    """The oracle on the sizes the build used to refuse (LSF vector on 20 000 pixels, a 9 001-pixel continuum net, a
+    continuum net stored in kK) and on the tiny-rotation corner at 32 768 pixels -- vectors from the reference."""
+    g = golden("g12_long_rows")
+    net = synth.make_yst_net(npix=20000, H=16, seed=41, line_depth=0.3)
+    lab = g["lsf_label"]
+    for b, lsf in enumerate(g["lsf_lsfs"]):
+        for c, (vrad, vrot) in enumerate(g["lsf_rows"]):
+            with np.errstate(all="ignore"):
+                f = O.getspec(net, Teff=lab[0], logg=lab[1], feh=lab[2], afe=lab[3], rad_vel=vrad, rot_vel=vrot, vmic=np.nan,
+                              inst_R=lsf, outwave=g["lsf_obs"])[1]
+            np.testing.assert_allclose(f, g["lsf_final"][b, c], rtol=1e-11, atol=1e-12)
+    snet = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
+    for tag, npc, kk in (("long", 9001, False), ("kk", 600, True)):
+        cnet = synth.make_cont_net(npix=npc, lam_lo=5140.0, lam_hi=5190.0)
+        if kk:                                            # the reference uses the continuum net as stored (ystpred.py:81-85)
+            cnet["x_min"][0] /= 1000.0
+            cnet["x_max"][0] /= 1000.0
+        for i, l in enumerate(g["cont_labels"]):
+            np.testing.assert_allclose(O.ann_forward(cnet, list(l)), g["cont_" + tag][i], rtol=1e-12)
+            for j, (vrad, vrot, R) in enumerate(g["cont_rows"]):
+                with np.errstate(all="ignore"):
+                    f = O.getspec(snet, Teff=l[0], logg=l[1], feh=l[2], afe=l[3], rad_vel=vrad, rot_vel=vrot, vmic=np.nan,
+                                  inst_R=2.355 * R, outwave=g["cont_obs"], cnet=cnet)[1]
+                ref = g["final_" + tag][i, j]
+                assert np.array_equal(np.isnan(f), np.isnan(ref))
+                np.testing.assert_allclose(f, ref, rtol=1e-11, atol=1e-12, equal_nan=True)
+    rnet = synth.make_yst_net(npix=32768, H=16, seed=43, line_depth=0.3)
+    rl = g["rot_label"]
+    with np.errstate(all="ignore"):
+        f = O.getspec(rnet, Teff=rl[0], logg=rl[1], feh=rl[2], afe=rl[3], rot_vel=float(g["rot_values"][0]))[1]
+    np.testing.assert_allclose(f, g["rot_after"][0], rtol=1e-12, atol=1e-13)

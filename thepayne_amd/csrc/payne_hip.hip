@@ -36,6 +36,7 @@ using namespace payne;
 #include "post_kernels.hpp"
 
 #include "sed_kernel.hpp"
+#include "select.hpp"
 
 // photometry-only fits: lnL = -0.5 chi2_sed
 __global__ void payne_photonly_kernel(const double* mags, const double* obs, const double* err, int F, int B, double* lnl) {
@@ -91,8 +92,11 @@ struct payne_ctx {
   bool has_lsf = false;
   const double* d_obs_wave = nullptr;   // [nobs] (obs_owned)
   const double* lsf = nullptr;          // [nobs]
-  float* lsf_spec = nullptr;            // [b_max][npix] spectra after vsini, shifted
-  double* lsf_ws = nullptr;             // [b_max][2 npix + n1]
+  float* lsf_spec = nullptr;            // [lsf_chunk][npix] spectra after vsini, shifted
+  double* lsf_ws = nullptr;             // [lsf_chunk][2 npix + n1]
+  float* lsf_fws = nullptr;             // global form: [lsf_chunk][2 fft_buf_floats(n1)] FFT buffers
+  bool lsf_global = false;              // spectra too long for LDS (n1 > 8192): buffers in global memory, median by selection
+  int lsf_chunk = 0;                    // candidates per launch (the global form walks the batch in chunks: bounded workspace)
   std::vector<void*> lsf_owned;
   bool obs_bound = false;
   CandState* prep = nullptr;      // [b_max] per-candidate records of the post kernel (written by the first dense launch)
@@ -424,8 +428,8 @@ extern "C" int payne_ctx_set_continuum(payne_ctx* c, const payne_model_desc* con
   if (!cont) return done(PAYNE_OK);
   if (cont->n_layers < 3 || cont->n_layers > PAYNE_MAX_LAYERS) return done(fail(c, PAYNE_E_INVALID, "continuum.n_layers must be 3..8"));
   if (cont->n_labels != c->n_labels) return done(fail(c, PAYNE_E_INVALID, "continuum.n_labels != model.n_labels"));
-  if (!cont->xmin || !cont->xmax || !cont->wavelength || cont->npix < 2 || cont->npix > 8192)
-    return done(fail(c, PAYNE_E_INVALID, "continuum.xmin/xmax/wavelength missing or npix outside 2..8192"));
+  if (!cont->xmin || !cont->xmax || !cont->wavelength || cont->npix < 2)
+    return done(fail(c, PAYNE_E_INVALID, "continuum.xmin/xmax/wavelength missing or npix < 2"));
   if (cont->layers[0].n_in != cont->n_labels || cont->layers[cont->n_layers - 1].n_out != cont->npix)
     return done(fail(c, PAYNE_E_INVALID, "continuum layer shapes do not match n_labels / npix"));
   int rc = PAYNE_OK, maxh = 0;
@@ -490,17 +494,22 @@ extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) {
   if (!lsf) return done(PAYNE_OK);
   if (!c->obs_bound) return done(fail(c, PAYNE_E_INVALID, "bind the observed grid before its LSF vector"));
   if (n != c->T.nobs) return done(fail(c, PAYNE_E_INVALID, "the LSF vector must have one entry per observed pixel"));
-  if (c->T.n1 > 8192) return done(fail(c, PAYNE_E_UNSUPPORTED, "LSF broadening is built for spectra up to 8192 pixels"));
   for (int i = 0; i < n; ++i)
     if (!(lsf[i] > 0.0)) return done(fail(c, PAYNE_E_INVALID, "LSF dispersions must be positive"));
   std::vector<double> v(lsf, lsf + n);
   int rc;
   if ((rc = upload(c, v, &c->lsf, c->lsf_owned))) return done(rc);
-  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * c->T.npix, &c->lsf_spec, c->lsf_owned, false))) return done(rc);
-  if ((rc = dev_alloc(c, (size_t)c->opts.b_max * (2 * (size_t)c->T.npix + c->T.n1), &c->lsf_ws, c->lsf_owned, false))) return done(rc);
-  const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
-  hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_lsf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (he != hipSuccess) return done(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
+  c->lsf_global = c->T.n1 > 8192 || (c->opts.variant & PAYNE_V_LSF_GLOBAL);
+  c->lsf_chunk = c->lsf_global ? std::min(c->opts.b_max, 256) : c->opts.b_max;
+  if ((rc = dev_alloc(c, (size_t)c->lsf_chunk * c->T.npix, &c->lsf_spec, c->lsf_owned, false))) return done(rc);
+  if ((rc = dev_alloc(c, (size_t)c->lsf_chunk * (2 * (size_t)c->T.npix + c->T.n1), &c->lsf_ws, c->lsf_owned, false))) return done(rc);
+  if (c->lsf_global) {
+    if ((rc = dev_alloc(c, (size_t)c->lsf_chunk * 2 * fft_buf_floats(c->T.n1), &c->lsf_fws, c->lsf_owned, false))) return done(rc);
+  } else {
+    const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_lsf_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he != hipSuccess) return done(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
+  }
   c->has_lsf = true;
   return done(PAYNE_OK);
 }
@@ -612,10 +621,27 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
 __global__ void __launch_bounds__(256) payne_cont_kernel(const float* __restrict__ cont, int npc, int npc2,
                                                           const double* __restrict__ scale, const int* __restrict__ idx,
                                                           const double* __restrict__ frac, float* raw, int npix) {
-  extern __shared__ __attribute__((aligned(16))) double cs[];       // [npc2] sort buffer
+  extern __shared__ __attribute__((aligned(16))) double cs[];       // [npc2] sort buffer (npc2 == 0: none, median by selection)
   __shared__ double med_s;
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* row = cont + (size_t)b * npc;
+  if (npc2 == 0) {                                                   // rows longer than LDS: radix selection, no size limit
+    __shared__ int hist[256], cnt_s;
+    __shared__ unsigned long long bc[2];
+    const double med = nanmedian_select<256>([&](int i) { return (double)row[i] * scale[i]; }, npc, hist, bc, &cnt_s);
+    float* r = raw + (size_t)b * npix;
+    for (int i = tid; i < npix; i += 256) {
+      const int k = idx[i];
+      double C = __builtin_nan("");
+      if (k >= 0) {
+        const double q0 = (double)row[k] * scale[k], q1 = (double)row[k + 1] * scale[k + 1];
+        C = (q0 + frac[i] * (q1 - q0)) / med;
+      }
+      const float m1 = r[i];
+      r[i] = (float)((double)m1 * C + (C - 1.0));
+    }
+    return;
+  }
   int nv = 0;
   for (int i = tid; i < npc2; i += 256) {
     double q = INFINITY;
@@ -670,6 +696,7 @@ static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor
   if ((rc = run_net(c, C, theta, B, instr_factor, s))) return rc;
   int npc2 = 1;
   while (npc2 < c->cn_npix) npc2 <<= 1;
+  if (npc2 > 4096 || (c->opts.variant & PAYNE_V_SELECT_MEDIAN)) npc2 = 0;     // median by selection instead of an LDS sort
   PAYNE_LAUNCH(payne_cont_kernel, dim3(B), dim3(256), (size_t)npc2 * 8, s, c->cont_raw, c->cn_npix, npc2, c->cont_scale,
                      c->cont_idx, c->cont_frac, c->raw, c->T.npix);
   hipError_t e = hipGetLastError();
@@ -730,28 +757,41 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   return PAYNE_OK;
 }
 
-// LSF path: spectra after rotational broadening (post kernel, stage 5) -> payne_lsf_kernel
+// LSF path: spectra after rotational broadening (post kernel, stage 5) -> payne_lsf_kernel, a chunk of the batch at a time
 static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, float* out, int ld_out, double* lnl,
                         bool with_phot, hipStream_t s) {
-  if (c->big_ws) return fail(c, PAYNE_E_UNSUPPORTED, "LSF broadening is built for spectra up to 8192 pixels");
   const bool had = c->has_lsf;
-  c->has_lsf = false;                                      // (the stage-5 pass below goes through run_post)
-  int rc = run_post(c, theta, B, 1.0, 5, c->lsf_spec, c->T.npix, nullptr, false, s);
-  c->has_lsf = had;
-  if (rc) return rc;
-  LsfArgs a{};
-  a.theta = theta; a.ld_theta = c->ncols; a.spec = c->lsf_spec; a.ld_spec = c->T.npix;
-  a.obs_wave = c->d_obs_wave; a.lsf = c->lsf;
-  a.ws = c->lsf_ws; a.ws_stride = 2 * (size_t)c->T.npix + c->T.n1;
-  a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
-  if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
-  const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
-  {
-    ProfScope ps(c, s, 1);
-    PAYNE_LAUNCH(payne_lsf_kernel, dim3(B), dim3(256), lds, s, c->T, a);
+  for (int off = 0; off < B; off += c->lsf_chunk) {
+    const int nb = std::min(c->lsf_chunk, B - off);
+    const double* th = theta + (size_t)off * c->ncols;
+    c->has_lsf = false;                                    // (the stage-5 pass below goes through run_post)
+    const float* raw_all = c->raw;
+    const CandState* prep_all = c->prep;
+    c->raw = const_cast<float*>(raw_all) + (size_t)off * c->T.npix;              // this chunk's rows of the ANN output
+    c->prep = const_cast<CandState*>(prep_all) + off;
+    int rc = run_post(c, th, nb, 1.0, 5, c->lsf_spec, c->T.npix, nullptr, false, s);
+    c->raw = const_cast<float*>(raw_all); c->prep = const_cast<CandState*>(prep_all);
+    c->has_lsf = had;
+    if (rc) return rc;
+    LsfArgs a{};
+    a.theta = th; a.ld_theta = c->ncols; a.spec = c->lsf_spec; a.ld_spec = c->T.npix;
+    a.obs_wave = c->d_obs_wave; a.lsf = c->lsf;
+    a.ws = c->lsf_ws; a.ws_stride = 2 * (size_t)c->T.npix + c->T.n1;
+    a.fws = c->lsf_fws; a.fws_stride = 2 * (size_t)fft_buf_floats(c->T.n1);
+    a.out = out ? out + (size_t)off * ld_out : nullptr; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl ? lnl + off : nullptr;
+    if (with_phot) { a.mags = c->mags_ws + (size_t)off * c->P.F; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
+    {
+      ProfScope ps(c, s, 1);
+      if (c->lsf_global) {
+        PAYNE_LAUNCH(payne_lsf_kernel<true>, dim3(nb), dim3(256), (size_t)(256 + 8) * 8, s, c->T, a);
+      } else {
+        const size_t lds = (size_t)c->T.n1 * 8 + 2 * (size_t)fft_buf_floats(c->T.n1) * 4 + (256 + 8) * 8;
+        PAYNE_LAUNCH(payne_lsf_kernel<false>, dim3(nb), dim3(256), lds, s, c->T, a);
+      }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("lsf launch: ") + hipGetErrorString(e));
   }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("lsf launch: ") + hipGetErrorString(e));
   return PAYNE_OK;
 }
 

@@ -3,6 +3,7 @@
 // payne_post_kernel, the global-workspace payne_post_big_kernel for spectra larger than LDS, and
 // payne_lsf_kernel (LSF-vector broadening, Payne/utils/smoothing.py:482-586).
 #pragma once
+#include "select.hpp"
 
 // ============================================================================
 // per-candidate spectrum pipeline
@@ -203,13 +204,12 @@ struct LsfArgs {
   const float* spec; int ld_spec;        // [B][npix] after vsini, shifted
   const double* obs_wave; const double* lsf; // [nobs]
   double* ws; size_t ws_stride;          // per candidate: a[npix] | cdf[npix] | lam[n1]
+  float* fws; size_t fws_stride;         // GLOBAL form: per candidate the two FFT buffers (2 x fft_buf_floats(n1) floats)
   float* out; int ld_out; int out_stage; // 2 / 3 / -1
   double* lnl;
   const double* mags; int n_filters; const double* obs_mag; const double* obs_err;
 };
-#ifndef PAYNE_TU_BIG
-__global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfArgs a);
-#else
+#ifdef PAYNE_TU_BIG
 // np.interp(x, xp, fp) (arr_interp): clamped outside, slope form inside
 __device__ double interp_np(double x, const double* xp, const double* fp, int n) {
   if (x > xp[n - 1]) return fp[n - 1];
@@ -221,12 +221,17 @@ __device__ double interp_np(double x, const double* xp, const double* fp, int n)
   const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
   return slope * (x - xp[j]) + fp[j];
 }
+// GLOBAL: the median by radix selection (select.hpp) and the two FFT buffers in a global workspace -- no limit on the
+// spectrum's length; otherwise everything in LDS (spectra up to 8192 pixels).
+template <bool GLOBAL>
 __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-  double* sortb = reinterpret_cast<double*>(lsm);                      // [n1] median sort buffer
-  float* bufA = reinterpret_cast<float*>(sortb + T.n1);
+  double* sortb = reinterpret_cast<double*>(lsm);                      // [n1] median sort buffer (LDS form)
+  float* bufA = GLOBAL ? a.fws + (size_t)blockIdx.x * a.fws_stride : reinterpret_cast<float*>(sortb + T.n1);
   float* bufB = bufA + fft_buf_floats(T.n1);
-  double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(T.n1));    // [256 + 8]
+  double* red = GLOBAL ? reinterpret_cast<double*>(lsm) : reinterpret_cast<double*>(bufB + fft_buf_floats(T.n1));    // [256 + 8]
+  __shared__ int hist_s[256];
+  __shared__ unsigned long long bc_s[2];
   __shared__ int cnt_s[2], nvalid_s, nx_s;
   __shared__ double scal_s[4];                                         // 0 max(cdf), 1 x_per_sigma
   const int b = blockIdx.x, tid = threadIdx.x, npix = T.npix, nobs = T.nobs;
@@ -282,7 +287,16 @@ __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfA
     const double cmax = scal_s[0];
     for (int i = tid; i < n; i += 256) wsC[i] = wsC[i] / cmax;           // cdf /= cdf.max()
     __syncthreads();
-    // ---- x_per_sigma = nanmedian(gradient(cdf) / r): bitonic sort of the ratios in LDS
+    // ---- x_per_sigma = nanmedian(gradient(cdf) / r)
+    auto ratio = [&](int i) {
+      const double g = (i == 0) ? (wsC[1] - wsC[0]) : ((i == n - 1) ? (wsC[n - 1] - wsC[n - 2]) : (wsC[i + 1] - wsC[i - 1]) / 2.0);
+      return g / wsA[i];
+    };
+    double xps_sel = 0.0;
+    if (GLOBAL) {
+      xps_sel = nanmedian_select<256>(ratio, n, hist_s, bc_s, &nvalid_s);
+    } else {
+    // bitonic sort of the ratios in LDS
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
     int nv = 0;
@@ -309,9 +323,10 @@ __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfA
         }
       }
     __syncthreads();
+    }
     if (tid == 0) {
       const int m = nvalid_s;
-      const double xps = m == 0 ? __builtin_nan("") : ((m & 1) ? sortb[m >> 1] : 0.5 * (sortb[(m >> 1) - 1] + sortb[m >> 1]));
+      const double xps = GLOBAL ? xps_sel : (m == 0 ? __builtin_nan("") : ((m & 1) ? sortb[m >> 1] : 0.5 * (sortb[(m >> 1) - 1] + sortb[m >> 1])));
       scal_s[1] = xps;
       const double N = 2.0 / xps;                                       // pix_per_sigma = 2
       int nx = 0;
@@ -353,7 +368,7 @@ __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfA
     }
     __syncthreads();
     // ---- smooth_fft(dx = 1/nx, newspec, x_per_sigma): taper exp(-2 pi^2 sigma^2 k^2)
-    DevExecT<true, false> ex;
+    DevExecT<!GLOBAL, false> ex;
     TaperArgs ta{};
     const double xps = scal_s[1];
     ta.g_c2 = (float)(-2.0 * (kPi * kPi) * (xps * xps) * 1.4426950408889634);
@@ -408,6 +423,12 @@ __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfA
   }
 }
 
+template __global__ void payne_lsf_kernel<false>(const PostTables, LsfArgs);
+template __global__ void payne_lsf_kernel<true>(const PostTables, LsfArgs);
+#else
+template <bool GLOBAL> __global__ void payne_lsf_kernel(const PostTables T, LsfArgs a);
+extern template __global__ void payne_lsf_kernel<false>(const PostTables, LsfArgs);
+extern template __global__ void payne_lsf_kernel<true>(const PostTables, LsfArgs);
 #endif
 
 // The instantiations that exist (each is compiled in one of the k_post_*.hip units; everybody else sees them as

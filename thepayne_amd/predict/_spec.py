@@ -28,7 +28,7 @@ class SpecANN(object):
     (ystpred.py:18-58) / ``ANN`` (predictspec.py:29-74).  ``eval(labels)`` returns
     the raw ANN spectrum on ``wavelength``."""
 
-    def __init__(self, nnpath, NNtype, b_max=256, device=None):
+    def __init__(self, nnpath, NNtype, b_max=256, device=None, variant=0):
         self.nnpath = nnpath
         self.NNtype = NNtype
         self.net = nnio.load_spec_net(nnpath, NNtype)
@@ -36,7 +36,7 @@ class SpecANN(object):
         self.xmax = self.net["xmax"]
         self.wavelength = self.net["wavelength"]
         self.resolution = self.net["resolution"]
-        self.engine = PayneEngine(self.net, b_max=b_max, device=device)
+        self.engine = PayneEngine(self.net, b_max=b_max, device=device, variant=variant)
         self.n_labels = self.engine.n_labels
 
     def _theta(self, labels):
@@ -89,7 +89,8 @@ class PayneSpecPredict(object):
                           "README.md:45); pass nnpath=")
         self.nnpath = nnpath
         self.NNtype = kwargs.get('NNtype', self.default_NNtype)
-        self.anns = SpecANN(self.nnpath, self.NNtype, b_max=kwargs.get('b_max', 256), device=kwargs.get('device'))
+        self.anns = SpecANN(self.nnpath, self.NNtype, b_max=kwargs.get('b_max', 256), device=kwargs.get('device'),
+                            variant=kwargs.get('variant', 0))      # (variant: kernel variants of include/payne_hip.h, for tests)
         self.Cnnpath = kwargs.get('Cnnpath', None)
         self.Canns = None
         if self.Cnnpath is not None:                    # ystpred.py:81-85
