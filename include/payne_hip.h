@@ -187,6 +187,24 @@ int payne_predict_batch(payne_ctx* ctx, const double* theta, int B, int stage, u
 int payne_smooth_batch(payne_ctx* ctx, const float* spectra, int ld_spec, const double* theta, int B, int stage,
                        unsigned flags, float* out, int ld_out, void* stream);
 
+/* smoothspec's branches that are not on the sampler's path, on caller-supplied HOST arrays, synchronous (no context: an
+ * analysis helper of PayneSpecPredict.smoothspec, Payne/predict/ystpred.py:279-281 -> Payne/utils/smoothing.py):
+ *   PAYNE_SMOOTH_VEL_DIRECT   smooth_vel       (smoothing.py:171-210)  fftsmooth=False, smoothtype 'vel' / 'R'
+ *   PAYNE_SMOOTH_WAVE_DIRECT  smooth_wave      (:339-393)              fftsmooth=False, smoothtype 'lambda'; sigma scalar or [n]
+ *   PAYNE_SMOOTH_LSF_DIRECT   smooth_lsf       (:435-480)              fftsmooth=False, smoothtype 'lsf'; sigma [nout] (or scalar)
+ *   PAYNE_SMOOTH_WAVE_FFT     smooth_wave_fft  (:395-433)              fftsmooth=True,  smoothtype 'lambda'
+ *   PAYNE_SMOOTH_INTERP       np.interp(outwave, wave, spec)           smooth_lsf with neither sigma nor lsf (:464-465)
+ * wave, spec [n]: the input AFTER smoothspec's mask and nan_to_num (:131-138); sigma in the units the reference's function
+ * takes (km/s for VEL_DIRECT, Angstrom otherwise); inres / in_vel / nsigma: its keywords (defaults 0 / 0 / 10).
+ * Returns PAYNE_E_INVALID where the reference raises ValueError (smooth_wave: target sigma below the input's). */
+#define PAYNE_SMOOTH_VEL_DIRECT 0
+#define PAYNE_SMOOTH_WAVE_DIRECT 1
+#define PAYNE_SMOOTH_LSF_DIRECT 2
+#define PAYNE_SMOOTH_WAVE_FFT 3
+#define PAYNE_SMOOTH_INTERP 4
+int payne_smooth_direct(int device, int kind, const double* wave, const double* spec, int n, const double* outwave, int nout,
+                        const double* sigma, int nsig, double inres, int in_vel, double nsigma, double* out);
+
 /* Magnitudes for B parameter vectors: FastPayneSEDPredict.sed
  * (Payne/predict/predictsed.py:75-103).  pars: device fp64 [B][9] =
  * logt, logg, feh, afe, av, rv, logl, dist, logA  (NaN = kwarg absent; the

@@ -496,8 +496,40 @@ def g12_long_rows():
     save("g12_long_rows", **out)
 
 
+# ------------------------------------------------------------------ G13
+def g13_smoothspec_branches():
+    """smoothspec's branches off the sampler's path, as the reference computes them (Payne/utils/smoothing.py): the direct
+    quadratures (fftsmooth=False: smooth_vel for 'vel' / 'R', smooth_wave for 'lambda', smooth_lsf for 'lsf') and the
+    wavelength-space FFT ('lambda', fftsmooth=True).  Input: a 700-pixel spectrum with two NaN pixels (nan_to_num)."""
+    from Payne.utils.smoothing import smoothspec
+    rng = np.random.default_rng(13)
+    wave = 5150.0 * (1.0 + 1.0 / 70000.0) ** np.arange(700)
+    spec = 1.0 - 0.3 * np.exp(-0.5 * ((wave - 5175.0) / 0.15) ** 2) - 0.2 * np.exp(-0.5 * ((wave - 5190.0) / 0.4) ** 2) \
+        + 0.01 * rng.normal(size=700)
+    spec[[100, 431]] = np.nan
+    outwave = np.linspace(5160.0, 5195.0, 300)
+    lsf_on_wave = 0.12 * (1.0 + 0.4 * (wave - wave.mean()) / (wave.max() - wave.min()))
+    out = dict(wave=wave, spec=spec, outwave=outwave, lsf_on_wave=lsf_on_wave)
+    with np.errstate(all="ignore"):
+        out["vel_direct"] = smoothspec(wave, spec, 8.0, outwave=outwave, smoothtype='vel', fftsmooth=False)
+        out["vel_direct_inres"] = smoothspec(wave, spec, 8.0, outwave=outwave, smoothtype='vel', fftsmooth=False, inres=3.0)
+        out["vel_direct_nsig"] = smoothspec(wave, spec, 8.0, outwave=outwave, smoothtype='vel', fftsmooth=False, nsigma=-1)
+        out["R_direct"] = smoothspec(wave, spec, 30000.0, outwave=outwave, smoothtype='R', fftsmooth=False, inres=90000.0)
+        out["R_direct_native"] = smoothspec(wave, spec, 30000.0, smoothtype='R', fftsmooth=False)
+        out["lambda_direct"] = smoothspec(wave, spec, 0.2, outwave=outwave, smoothtype='lambda', fftsmooth=False)
+        out["lambda_direct_inres"] = smoothspec(wave, spec, 0.2, outwave=outwave, smoothtype='lambda', fftsmooth=False, inres=0.08)
+        out["lambda_direct_invel"] = smoothspec(wave, spec, 0.2, outwave=outwave, smoothtype='lambda', fftsmooth=False,
+                                                inres=60000.0, in_vel=True)
+        out["lambda_fft"] = smoothspec(wave, spec, 0.2, outwave=outwave, smoothtype='lambda', fftsmooth=True)
+        out["lambda_fft_inres"] = smoothspec(wave, spec, 0.2, outwave=outwave, smoothtype='lambda', fftsmooth=True, inres=0.08)
+        out["lambda_fft_native"] = smoothspec(wave, spec, 0.2, smoothtype='lambda', fftsmooth=True)
+        out["lsf_direct"] = smoothspec(wave, spec, lsf_on_wave, outwave=outwave, smoothtype='lsf', fftsmooth=False)
+        out["lsf_direct_none"] = smoothspec(wave, spec, None, outwave=outwave, smoothtype='lsf', fftsmooth=False)
+    save("g13_smoothspec", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows}[k]()
+         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows, "g13": g13_smoothspec_branches}[k]()

@@ -10,7 +10,7 @@ __all__ = [
     "CKMS", "SIGMA_TO_FWHM", "C_KMS_DOPPLER",
     "leaky_relu", "yst_encode", "yst_forward", "torchnet_forward", "ann_forward",
     "mask_range", "resample_pow2", "taper_vsini", "taper_gauss", "fft_convolve",
-    "smooth_vsini", "smooth_R", "smooth_lsf", "getspec", "polycalc", "genspec",
+    "smooth_vsini", "smooth_R", "smooth_lsf", "smoothspec_offpath", "getspec", "polycalc", "genspec",
     "chi2_spec", "chi2_spec_loop", "fastann_forward", "highav_offset", "sed_mags",
     "genphot", "genphot_scaled", "OracleLikelihood", "lnprobfn",
 ]
@@ -162,6 +162,83 @@ def smooth_R(wave, spec, Rsigma, outwave, R_ann, return_parts=False):
         first = int(np.argmax(mask)) if mask.any() else -1
         return out, dict(first=first, count=int(mask.sum()), nfft=len(sr))
     return out
+
+
+def _trapz(y, x):
+    """numpy.trapz (renamed trapezoid in numpy 2): sum of (x[k+1] - x[k]) (y[k] + y[k+1]) / 2."""
+    return np.sum(np.diff(x) * (y[1:] + y[:-1]) / 2.0)
+
+
+def smoothspec_offpath(wave, spec, resolution, outwave=None, smoothtype='vel', fftsmooth=True, **kw):
+    """The branches of ``smoothspec`` (Payne/utils/smoothing.py:19-169) that the sampler's path does not take:
+    ``fftsmooth=False`` -> smooth_vel (:171-210) / smooth_wave (:339-393) / smooth_lsf (:435-480), and smoothtype
+    'lambda' with FFTs -> smooth_wave_fft (:395-433).  Units, mask and nan_to_num as smoothspec does them (:89-138)."""
+    wave, spec = np.asarray(wave, dtype=np.float64), np.asarray(spec, dtype=np.float64)
+    inres = kw.get('inres', 0)
+    if smoothtype in ('vel', 'R'):
+        sigma = float(resolution) if smoothtype == 'vel' else CKMS / float(resolution)
+        width, linear = CKMS / sigma, False
+        if smoothtype == 'R' and 'inres' in kw:
+            inres = CKMS / kw['inres']
+    elif smoothtype == 'lambda':
+        sigma, width, linear = resolution, resolution, True
+    elif smoothtype == 'lsf':
+        sigma, width, linear = resolution, 100, True
+    else:
+        raise ValueError(smoothtype)
+    if outwave is not None:
+        wlim = np.array([np.min(outwave), np.max(outwave)], dtype=np.float64)
+    else:
+        wlim = np.array([kw.get('min_wave_smooth', 0), kw.get('max_wave_smooth', np.inf)], dtype=np.float64)
+    wlim = wlim + 20.0 * width * np.array([-1, 1]) if linear else wlim * (1 + 20.0 / width * np.array([-1, 1]))
+    mask = (wave > wlim[0]) & (wave < wlim[1])
+    w, s = wave[mask], np.nan_to_num(spec[mask], nan=1.0)
+    if outwave is None:
+        outwave = wave
+    outwave = np.asarray(outwave, dtype=np.float64)
+    nsigma = kw.get('nsigma', 10)
+    if smoothtype == 'lsf':                                          # smooth_lsf
+        if sigma is None:
+            return np.interp(outwave, w, s)
+        sig = np.interp(outwave, wave, resolution)
+        dw = np.gradient(w)
+        kernel = outwave[:, None] - w[None, :]
+        kernel = (1 / (sig * np.sqrt(np.pi * 2))[:, None] * np.exp(-kernel ** 2 / (2 * sig[:, None] ** 2)) * dw[None, :])
+        kernel = kernel / kernel.sum(axis=1)[:, None]
+        return np.dot(kernel, s)
+    if smoothtype == 'lambda' and fftsmooth:                         # smooth_wave_fft
+        nnew = int(2.0 ** (np.ceil(np.log2(len(w)))))
+        wg = np.linspace(w.min(), w.max(), nnew)
+        sg = np.interp(wg, w, s)
+        sig = np.sqrt(sigma ** 2 - inres ** 2)
+        dwg = np.median(np.diff(wg))
+        return np.interp(outwave, wg, fft_convolve(sg, taper_gauss(len(sg), dwg, sig)))
+    if smoothtype == 'lambda':                                       # smooth_wave
+        if inres <= 0:
+            sq = sigma ** 2
+        elif kw.get('in_vel', False):
+            sq = sigma ** 2 - (w / inres) ** 2
+        else:
+            sq = sigma ** 2 - inres ** 2
+        if np.any(sq < 0):
+            raise ValueError("Desired wavelength sigma is lower than the value possible for this input spectrum.")
+        se = np.sqrt(sq)
+        xs = lambda wo: (w - wo) / se                                # noqa: E731
+    else:                                                            # smooth_vel
+        se = np.sqrt(sigma ** 2 - inres ** 2) / CKMS
+        lnw = np.log(w)
+        xs = lambda wo: (np.log(wo) - lnw) / se                      # noqa: E731
+    flux = np.zeros(len(outwave))
+    for i, wo in enumerate(outwave):
+        x = xs(wo)
+        _s = s
+        if nsigma > 0:
+            good = np.abs(x) < nsigma
+            x, _s = x[good], s[good]
+        f = np.exp(-0.5 * x ** 2)
+        with np.errstate(all="ignore"):
+            flux[i] = _trapz(f * _s, x) / _trapz(f, x)
+    return flux
 
 
 def smooth_lsf(wave, spec, disparr, outwave, pix_per_sigma=2):

@@ -301,8 +301,10 @@ def test_smoothspec_on_arbitrary_spectra(tmp_path):
     lsf = 0.25 * (1.0 + 0.4 * (wave - wave.mean()) / 120.0)
     got = PP.smoothspec(wave, spec, lsf, outwave=wave, smoothtype='lsf')
     assert np.abs(got - O.smooth_lsf(wave, spec, lsf, wave)).max() < 2e-6
+    got = PP.smoothspec(wave, spec, 0.5, outwave=out, smoothtype='lambda')                 # smooth_wave_fft (see the g13 test)
+    assert np.nanmax(np.abs(got - O.smoothspec_offpath(wave, spec, 0.5, outwave=out, smoothtype='lambda'))) < 1e-6
     with pytest.raises(NotImplementedError):
-        PP.smoothspec(wave, spec, 0.5, outwave=out, smoothtype='lambda')
+        PP.smoothspec(wave, spec, 0.5, outwave=out, smoothtype='boxcar')
 
 
 def test_genspec_on_any_grid_like_the_reference(tmp_path):
@@ -442,3 +444,28 @@ def test_lsf_global_form_walks_the_batch_in_chunks(tmp_path):
     for k in (0, 255, 256, 299):                                   # both sides of the chunk boundary, against the oracle
         ref = L.lnlikefn(list(th[k, :6]))
         assert abs(res[1][k] - ref) <= lnl_tol(np.array([ref]))[0], k
+
+
+def test_smoothspec_branches_off_the_sampler_path(tmp_path, golden):
+    """PayneSpecPredict.smoothspec with fftsmooth=False (smooth_vel / smooth_wave / smooth_lsf) and smoothtype 'lambda'
+    (smooth_wave_fft): payne_smooth_direct against vectors frozen from the reference's smoothspec (g13), through the
+    class method and through the reference's module path Payne.utils.smoothing.smoothspec."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    from Payne.utils.smoothing import smoothspec
+    from test_oracle_golden import G13_CALLS, g13_call
+    g = golden("g13_smoothspec")
+    raw = synth.make_yst_net(npix=256, H=16, seed=3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    for key in G13_CALLS:
+        ref = g[key]
+        for fn in (PP.smoothspec, smoothspec):
+            got = g13_call(fn, g, key)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+            tol = 1e-6 if "fft" in key else 1e-9                   # the FFT branch runs the likelihood's fp32 transform
+            assert np.nanmax(np.abs(got - ref)) < tol, (key, np.nanmax(np.abs(got - ref)))
+    with pytest.raises(ValueError):                                # smooth_wave: target sigma below the input's (:381-383)
+        PP.smoothspec(g["wave"], g["spec"], 0.05, outwave=g["outwave"], smoothtype='lambda', fftsmooth=False, inres=0.08)
+    # the FFT velocity branches still go through the likelihood's kernels
+    a = PP.smoothspec(g["wave"], np.nan_to_num(g["spec"], nan=1.0), 30000.0, outwave=g["outwave"], smoothtype='R')
+    b = O.smooth_R(g["wave"], np.nan_to_num(g["spec"], nan=1.0), 30000.0, g["outwave"], np.inf)
+    assert np.nanmax(np.abs(a - b)) < 1e-6

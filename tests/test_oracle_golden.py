@@ -203,3 +203,38 @@ def test_g12_long_rows(golden):
     with np.errstate(all="ignore"):
         f = O.getspec(rnet, Teff=rl[0], logg=rl[1], feh=rl[2], afe=rl[3], rot_vel=float(g["rot_values"][0]))[1]
     np.testing.assert_allclose(f, g["rot_after"][0], rtol=1e-12, atol=1e-13)
+
+
+G13_CALLS = {
+    "vel_direct": dict(resolution=8.0, smoothtype='vel', fftsmooth=False),
+    "vel_direct_inres": dict(resolution=8.0, smoothtype='vel', fftsmooth=False, inres=3.0),
+    "vel_direct_nsig": dict(resolution=8.0, smoothtype='vel', fftsmooth=False, nsigma=-1),
+    "R_direct": dict(resolution=30000.0, smoothtype='R', fftsmooth=False, inres=90000.0),
+    "R_direct_native": dict(resolution=30000.0, smoothtype='R', fftsmooth=False, native=True),
+    "lambda_direct": dict(resolution=0.2, smoothtype='lambda', fftsmooth=False),
+    "lambda_direct_inres": dict(resolution=0.2, smoothtype='lambda', fftsmooth=False, inres=0.08),
+    "lambda_direct_invel": dict(resolution=0.2, smoothtype='lambda', fftsmooth=False, inres=60000.0, in_vel=True),
+    "lambda_fft": dict(resolution=0.2, smoothtype='lambda', fftsmooth=True),
+    "lambda_fft_inres": dict(resolution=0.2, smoothtype='lambda', fftsmooth=True, inres=0.08),
+    "lambda_fft_native": dict(resolution=0.2, smoothtype='lambda', fftsmooth=True, native=True),
+    "lsf_direct": dict(resolution="lsf_on_wave", smoothtype='lsf', fftsmooth=False),
+    "lsf_direct_none": dict(resolution=None, smoothtype='lsf', fftsmooth=False),
+}
+
+
+def g13_call(fn, g, key):
+    kw = dict(G13_CALLS[key])
+    res = kw.pop("resolution")
+    res = g["lsf_on_wave"] if isinstance(res, str) else res
+    ow = None if kw.pop("native", False) else g["outwave"]
+    return fn(g["wave"], g["spec"], res, outwave=ow, **kw)
+
+
+def test_g13_smoothspec_branches_off_the_path(golden):
+    """smooth_vel / smooth_wave / smooth_lsf / smooth_wave_fft as smoothspec reaches them, against the reference."""
+    g = golden("g13_smoothspec")
+    for key in G13_CALLS:
+        got = g13_call(O.smoothspec_offpath, g, key)
+        ref = g[key]
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12, equal_nan=True, err_msg=key)

@@ -13,11 +13,12 @@ PAYNE_MAX_LAYERS = 8
 PAYNE_MAX_POLY = 12
 ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
 F_FWHM_R = 1
+SMOOTH_VEL_DIRECT, SMOOTH_WAVE_DIRECT, SMOOTH_LSF_DIRECT, SMOOTH_WAVE_FFT, SMOOTH_INTERP = range(5)
 ABI_VERSION = 2
 V_OUT_GENERIC, V_POST_GENERIC, V_TW_GLOBAL, V_POST_FULL, V_NO_PREP, V_BIG_PLAIN, V_SELECT_MEDIAN, V_LSF_GLOBAL = 1, 2, 4, 8, 16, 32, 64, 128
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_destroy", "payne_last_error",
-           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
+           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
            "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_ns_rwalk_queue", "payne_ns_consume", "payne_ns_bound", "payne_format_rows"]
@@ -119,6 +120,9 @@ def load(path=None):
     lib.payne_smooth_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int,
                                        C.c_void_p]
     lib.payne_smooth_batch.restype = C.c_int
+    lib.payne_smooth_direct.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_double, C.c_int, C.c_double, C.c_void_p]
+    lib.payne_smooth_direct.restype = C.c_int
     lib.payne_ctx_destroy.argtypes = [ctxp]
     lib.payne_ctx_destroy.restype = None
     lib.payne_last_error.argtypes = [ctxp]

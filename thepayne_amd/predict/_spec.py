@@ -184,14 +184,17 @@ class PayneSpecPredict(object):
 
     def smoothspec(self, wave, spec, sigma, outwave=None, **kwargs):
         """``smoothspec(wave, spec, resolution=sigma, outwave=outwave, **kwargs)`` (ystpred.py:279-281 ->
-        Payne/utils/smoothing.py:19-169) on the GPU, for the FFT branches this build has kernels for:
-        smoothtype 'vsini' (outwave=None), 'vel' and 'R' (optional ``inres``), 'lsf' (dispersion vector on
-        ``wave``; outwave None or ``wave`` itself).  Anything else raises NotImplementedError."""
+        Payne/utils/smoothing.py:19-169) on the GPU.  The FFT branches the sampler's path uses -- smoothtype 'vsini'
+        (outwave=None), 'vel' and 'R' (optional ``inres``), 'lsf' (dispersion vector on ``wave``) -- run through the
+        likelihood's own kernels; ``fftsmooth=False`` (smooth_vel / smooth_wave / smooth_lsf) and smoothtype
+        'lambda' run through payne_smooth_direct (csrc/k_smooth.hip)."""
         smoothtype = kwargs.get('smoothtype', 'vel')
-        if not kwargs.get('fftsmooth', True):
-            raise NotImplementedError("fftsmooth=False (direct-sum smoothing) is not built")
+        if smoothtype not in ('vel', 'vsini', 'R', 'lambda', 'lsf'):
+            raise NotImplementedError("smoothtype=%r (the reference knows 'vel', 'vsini', 'R', 'lambda', 'lsf')" % (smoothtype,))
+        if smoothtype == 'lambda' or (not kwargs.get('fftsmooth', True) and smoothtype != 'vsini'):
+            return self._smoothspec_direct(wave, spec, sigma, outwave, smoothtype, dict(kwargs))
         if kwargs.get('min_wave_smooth', 0) != 0 or kwargs.get('max_wave_smooth', np.inf) != np.inf:
-            raise NotImplementedError("min_wave_smooth / max_wave_smooth are not built")
+            raise NotImplementedError("min_wave_smooth / max_wave_smooth with the FFT branches are not built")
         wave = np.ascontiguousarray(wave, dtype=np.float64)
         spec = np.asarray(spec, dtype=np.float64)
         ckms = 2.998e5                                                       # smoothing.py:16
@@ -228,6 +231,72 @@ class PayneSpecPredict(object):
             out = native_grid_edges(wave, out)
         return out
 
+    def _smoothspec_direct(self, wave, spec, resolution, outwave, smoothtype, kw):
+        """The branches of smoothspec behind payne_smooth_direct: what the reference does before it calls the smoothing
+        function (units, mask, nan_to_num: smoothing.py:89-138) is argument preparation and stays here; the smoothing
+        itself runs on the GPU."""
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.load()
+        dev = self._device_index()
+        ckms = 2.998e5                                                       # smoothing.py:16
+        wave = np.ascontiguousarray(wave, dtype=np.float64)
+        spec = np.asarray(spec, dtype=np.float64)
+        fft = kw.get('fftsmooth', True)
+        inres = kw.get('inres', 0)
+
+        def run(kind, w, s, ow, sig, inres=0.0, in_vel=False, nsigma=10.0):
+            w, s = np.ascontiguousarray(w, dtype=np.float64), np.ascontiguousarray(s, dtype=np.float64)
+            ow = np.ascontiguousarray(ow, dtype=np.float64)
+            sig = None if sig is None else np.ascontiguousarray(np.atleast_1d(sig), dtype=np.float64)
+            out = np.empty(len(ow))
+            rc = lib.payne_smooth_direct(dev, kind, w.ctypes.data, s.ctypes.data, len(w), ow.ctypes.data, len(ow),
+                                         None if sig is None else sig.ctypes.data, 0 if sig is None else len(sig),
+                                         float(inres), int(bool(in_vel)), float(nsigma), out.ctypes.data)
+            if rc == -1:
+                raise ValueError("Desired wavelength sigma is lower than the value possible for this input spectrum.")
+            if rc != 0:
+                raise RuntimeError("payne_smooth_direct failed (%d)" % rc)
+            return out
+
+        if smoothtype in ('vel', 'R'):                                       # smoothing.py:89-115
+            sig = float(resolution) if smoothtype == 'vel' else ckms / float(resolution)
+            width, linear = ckms / sig, False
+            if smoothtype == 'R' and 'inres' in kw:
+                inres = ckms / kw['inres']
+        elif smoothtype == 'lambda':                                         # :117-124
+            sig, width, linear = resolution, resolution, True
+        else:                                                                # 'lsf', :126-129
+            sig, width, linear = resolution, 100, True
+        # mask_wave (:631-647)
+        if outwave is not None:
+            ow = np.asarray(outwave, dtype=np.float64)
+            wlim = np.array([ow.min(), ow.max()])
+        else:
+            wlim = np.squeeze(np.array([kw.get('min_wave_smooth', 0), kw.get('max_wave_smooth', np.inf)])).astype(np.float64)
+        if linear:
+            wlim = wlim + 20.0 * float(width) * np.array([-1, 1])
+        else:
+            wlim = wlim * (1 + 20.0 / width * np.array([-1, 1]))
+        mask = (wave > wlim[0]) & (wave < wlim[1])
+        w, s = wave[mask], np.nan_to_num(spec[mask], nan=1.0)                # :133-138
+        ow = wave if outwave is None else np.asarray(outwave, dtype=np.float64)
+        nsig = kw.get('nsigma', 10)
+        if smoothtype == 'lsf':                                              # :142-153 (fftsmooth False)
+            if resolution is None:
+                if kw.get('lsf') is None:
+                    return run(_lib.SMOOTH_INTERP, w, s, ow, None)
+                sig_out = np.asarray(kw['lsf'](ow, **{k: v for k, v in kw.items() if k not in ('lsf', 'smoothtype', 'fftsmooth')}))
+            else:
+                sig_out = run(_lib.SMOOTH_INTERP, wave, np.asarray(resolution, dtype=np.float64), ow, None)   # np.interp(outwave, wave, resolution)
+            return run(_lib.SMOOTH_LSF_DIRECT, w, s, ow, sig_out)
+        if smoothtype == 'lambda':
+            if fft:
+                return run(_lib.SMOOTH_WAVE_FFT, w, s, ow, float(sig), inres=inres or 0.0)
+            return run(_lib.SMOOTH_WAVE_DIRECT, w, s, ow, float(sig), inres=inres or 0.0, in_vel=kw.get('in_vel', False),
+                       nsigma=nsig)
+        return run(_lib.SMOOTH_VEL_DIRECT, w, s, ow, sig, inres=inres or 0.0, nsigma=nsig)
+
     def _smooth_engine(self, wave, r_in):
         """A context whose model grid is ``wave`` (a two-layer dummy network: only the broadening stages run)."""
         key = (len(wave), float(wave[0]), float(wave[-1]), hash(wave.tobytes()), float(r_in))
@@ -239,8 +308,11 @@ class PayneSpecPredict(object):
             net = {"layers": [(np.zeros((4, 1), np.float32), np.zeros(4, np.float32), 0),
                               (np.zeros((n, 4), np.float32), np.ones(n, np.float32), 0)],
                    "xmin": np.array([0.0]), "xmax": np.array([1.0]), "wavelength": wave, "resolution": float(r_in)}
-            cache[key] = PayneEngine(net, b_max=8, device=self.anns.engine.device.index)
+            cache[key] = PayneEngine(net, b_max=8, device=self._device_index())
         return cache[key]
+
+    def _device_index(self):
+        return self.anns.engine.device.index
 
     # -- new: batch API ------------------------------------------------------------
     def getspec_batch(self, theta8, outwave, stage=2):
