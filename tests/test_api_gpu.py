@@ -469,3 +469,37 @@ def test_smoothspec_branches_off_the_sampler_path(tmp_path, golden):
     a = PP.smoothspec(g["wave"], np.nan_to_num(g["spec"], nan=1.0), 30000.0, outwave=g["outwave"], smoothtype='R')
     b = O.smooth_R(g["wave"], np.nan_to_num(g["spec"], nan=1.0), 30000.0, g["outwave"], np.inf)
     assert np.nanmax(np.abs(a - b)) < 1e-6
+
+
+def test_two_documented_deviations_from_the_reference(tmp_path):
+    """Where this build does NOT do what the reference does, each pinned by name:
+    (1) an output grid that misses the Doppler-shifted model entirely: the reference's mask is empty and numpy raises
+        ValueError on ``wave[mask].min()`` (Payne/utils/smoothing.py:653, zero-size reduction); a batched kernel cannot
+        raise for one row, so the build returns an all-NaN spectrum (and a NaN likelihood);
+    (2) an instrumental mask of fewer than 8 model pixels: the reference runs its FFT on 1-4 points (or fails inside
+        np.interp); the build returns NaN for every pixel of that spectrum."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    raw = synth.make_yst_net(npix=1024, H=32, seed=9, line_depth=0.3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    kw = dict(Teff=5500.0, logg=4.2, feh=-0.1, afe=0.1, rad_vel=5.0, rot_vel=2.0)
+    # (1) the output grid lies 40 Angstrom beyond the red end of the model
+    far = np.linspace(raw["wavelength"][-1] + 40.0, raw["wavelength"][-1] + 45.0, 50)
+    with pytest.raises(ValueError):
+        O.getspec(raw, inst_R=2.355 * 28000.0, outwave=far, vmic=np.nan, **kw)             # the reference's behaviour
+    _, f = PP.getspec(inst_R=2.355 * 28000.0, outwave=far, **kw)
+    assert f.shape == far.shape and np.isnan(f).all()                                     # the build's
+    # (2) three output pixels inside one model pixel, at a resolution whose +-20 sigma pad adds nothing: a 2-pixel mask
+    w = raw["wavelength"]
+    tight = w[500] + (w[501] - w[500]) * np.array([0.3, 0.5, 0.7])
+    R_huge = 2.0e7                                                                         # pad 20/R = 1e-6: << one pixel
+    n_mask = int(((w * (1 + 5.0 / 299792.458) > tight.min() * (1 - 20.0 / R_huge)) &
+                  (w * (1 + 5.0 / 299792.458) < tight.max() * (1 + 20.0 / R_huge))).sum())
+    assert n_mask < 8
+    sharp = dict(raw); sharp["resolution"] = 1.0e9             # (a net that claims R = 1e9: R_huge is then a legal target)
+    PS = PayneSpecPredict(nnpath=_save_yst(tmp_path, sharp, "sharp.npz"), NNtype='YST1')
+    with np.errstate(all="ignore"), pytest.raises(ValueError):
+        O.getspec(sharp, inst_R=R_huge, outwave=tight, vmic=np.nan, **kw)                  # the reference: numpy's irfft refuses
+    _, f = PS.getspec(inst_R=R_huge, outwave=tight, **kw)
+    assert np.isnan(f).all()
+    _, ok = PS.getspec(inst_R=2.355 * 28000.0, outwave=tight, **kw)                       # an ordinary mask on the same net
+    assert np.isfinite(ok).all()
