@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the short nested-sampling run behind `end_to_end`")
+    ap.add_argument("--variant", type=int, default=0, help="payne_opts.variant (kernel variants of include/payne_hip.h; A/B runs)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight (one engine + HIP stream each); the headline uses 1")
     return ap.parse_args()
@@ -231,7 +232,7 @@ def main():
     flux = clean + rng.normal(0, 0.01, len(obs))
     eflux = np.full(len(obs), 0.01)
     eng0.close()
-    eng = PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank)
+    eng = PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank, variant=args.variant)
     th7 = synth.draw_candidates(B, seed=1 + rank)
     theta = eng.make_theta(B)
     theta[:, 0:6] = torch.as_tensor(th7[:, 0:6], device=theta.device)
@@ -317,7 +318,7 @@ def main():
         "config": {"workload": "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels, batch of %d "
                                "candidate vectors per step (dynesty live points)" % (args.config, N, H, cfg["nobs"], B),
                    "batch": B, "npix": N, "nobs": cfg["nobs"], "stars": world,
-                   "batches_in_flight": S,
+                   "batches_in_flight": S, "kernel_variant": args.variant,
                    "parallelism": "1 star per GPU, no data-path collective"},
         "rccl_world": dist.get_world_size() if world > 1 else 1,
         "per_rank_evals_per_s": [float(v) for v in table[np.argsort(table[:, 6]), 5]],

@@ -22,6 +22,8 @@ struct HostExec {
   template <class F> void single(F&& f) { f(nthr); }
   c32* tile_ = nullptr;                                    // scratch of the four-step transform (null: plain passes)
   c32* tile() const { return tile_; }
+  bool fuse_ = true;
+  bool fuse() const { return fuse_; }
   static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
   static const c32* twid(const c32* p) { return p; }
   static c32* lds(c32* p) { return p; }
@@ -55,10 +57,10 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
   T.npoly = npoly;
-  if (force_general) { T.geo = 0; T.rot_identity = 0; }
+  if (force_general == 1 || force_general == 2) { T.geo = 0; T.rot_identity = 0; }    // (3: runtime geometry on the geometric grid)
   HostExec ex{nthreads};
   std::vector<c32> tilebuf;
-  if (force_general == 2) {                                // + the four-step transform of the global-workspace kernel
+  if (force_general >= 2) {                                // + the four-step transform of the global-workspace kernel
     tilebuf.resize(2 * (size_t)fft_tile_complex());
     ex.tile_ = tilebuf.data();
   }

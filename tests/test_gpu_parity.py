@@ -190,7 +190,7 @@ def test_abi_error_paths(Engine):
     assert rc == -1                                                             # no flux bound
 
 
-@pytest.mark.parametrize("variant", [0, 32], ids=["four_step", "plain_passes"])
+@pytest.mark.parametrize("variant", [0, 256, 32], ids=["four_step", "four_step_fused", "plain_passes"])
 def test_spectra_larger_than_lds_vs_oracle(Engine, variant):
     """n1 > 16384 takes the global-workspace kernel (persistent workgroups): a 40 000-pixel net and the
     65 536-pixel C5 grid (R ~ 100k), a few candidates each (the oracle needs ~0.1 s per evaluation)."""
@@ -239,3 +239,41 @@ def test_full_size_properties(Engine):
     T = synth.TRUTH
     truth = theta_full(np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]]]))
     assert eng.lnlike_batch(truth).cpu().numpy()[0] > lnl.max()
+
+
+def test_c5_at_size(Engine):
+    """BASELINE config 5 at its real shape: 65 536 pixels, H = 300, a batch of 256 candidates through the 256 persistent
+    workgroups of payne_post_big_kernel.  A handful of rows against the oracle (0.2 s each), the rest through
+    size-independent properties: chi^2 recomputed on the host from the predicted spectra, determinism, independence of
+    the position in the batch, the NaN contract of Inst_R above the network's resolution."""
+    cfg = synth.CONFIGS["C5"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    B = 256
+    th7 = synth.draw_candidates(B, seed=55)
+    th7[:, 6] = np.linspace(0.55, 0.9, B) * cfg["R"]
+    th7[7, 6] = 1.2 * raw["resolution"] / 2.355                       # above the ANN's own resolution: NaN by contract
+    rows = [list(theta_full(t)[0, :8]) for t in th7[:3]]
+    clean = np.array([O.genspec(raw, r, outwave=obs)[1] for r in rows])
+    flux = clean[0] + np.random.default_rng(3).normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=B)
+    th = theta_full(th7)
+    lnl = eng.lnlike_batch(th).cpu().numpy()
+    assert np.isnan(lnl[7]) and np.isfinite(np.delete(lnl, 7)).all()
+    L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
+    for k in (0, 1, 2, 200):
+        ref = L.lnlikefn(th7[k])
+        assert abs(lnl[k] - ref) <= lnl_tol(np.array([ref]))[0], (k, lnl[k], ref)
+    spec = eng.predict_batch(th[:3], stage=2, fwhm_R=True).cpu().numpy()
+    assert np.nanmax(np.abs(spec - clean)) <= FLUX_TOL
+    # chi^2 from the predicted spectra (fp64 on the host) agrees with the fused reduction, every row
+    ok = np.isfinite(lnl)
+    for s in range(0, B, 64):
+        sp = eng.predict_batch(th[s:s + 64], stage=3, fwhm_R=True).cpu().numpy().astype(np.float64)
+        chi = -0.5 * (((sp - flux) / eflux) ** 2).sum(axis=1)
+        sel = ok[s:s + 64]
+        assert np.all(np.abs(chi[sel] - lnl[s:s + 64][sel]) <= 2e-5 * np.abs(lnl[s:s + 64][sel]) + 5e-3)
+    # same answers in reverse order (grid-stride walk of the batch) and on a second call
+    assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th[::-1].copy()).cpu().numpy()[::-1]), np.nan_to_num(lnl))
+    assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th).cpu().numpy()), np.nan_to_num(lnl))

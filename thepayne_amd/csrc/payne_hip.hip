@@ -745,8 +745,8 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
     ProfScope ps(c, s, 1);
     if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
-      const int tiled = c->big_tiled ? 1 : 0;
-      const size_t lds = tiled ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
+      const int tiled = (c->big_tiled ? 1 : 0) | ((c->opts.variant & PAYNE_V_BIG_FUSED) ? 2 : 0);
+      const size_t lds = (tiled & 1) ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
       PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
       PAYNE_LAUNCH((stage < 0 && !out && a.prep) ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);

@@ -252,14 +252,22 @@ inline void q_ld2(const c32* p, size_t i, c32& a, c32& b) { a = p[i]; b = p[i + 
 inline void q_st2(c32* p, size_t i, c32 a, c32 b) { p[i] = a; p[i + 1] = b; }
 #endif
 
-// step 1, first pass of a tile: global (strided columns, two adjacent columns per thread) -> X
-template <class GP, class LP>
+// step 1, first pass of a tile: global (strided columns, two adjacent columns per thread) -> X.
+// SCRUB: the source is the raw ANN row read as (even, odd) pairs: NaN -> 0 (nan_to_num of the shifted flux) on the way.
+template <bool SCRUB = false, class GP, class LP>
 PAYNE_HD void fft4_s1_load(int tid, int nthr, GP src, LP X, int B, int c0) {
   for (int idx = tid; idx < (kTileC / 2) * 64; idx += nthr) {
     const int cp = idx % (kTileC / 2), i = idx / (kTileC / 2), cc = 2 * cp;
     c32 u[8], v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) q_ld2(src, (size_t)(c0 + cc) + (size_t)B * (i + 64 * r), u[r], v[r]);
+    if (SCRUB) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        u[r] = {nan_to_zero(u[r].x), nan_to_zero(u[r].y)};
+        v[r] = {nan_to_zero(v[r].x), nan_to_zero(v[r].y)};
+      }
+    }
     dft8(u);
     dft8(v);
 #pragma unroll
@@ -271,9 +279,9 @@ PAYNE_HD void fft4_s1_load(int tid, int nthr, GP src, LP X, int B, int c0) {
 }
 // step 1, middle pass (sub-length 8): X -> Y
 template <class LP, class TP>
-PAYNE_HD void fft4_s1_mid(int tid, int nthr, LP X, LP Y, TP tw, int tw_n) {
+PAYNE_HD void fft4_s1_mid(int tid, int nthr, LP X, LP Y, TP tw, int tw_n, int ncols = kTileC) {
   const int ts = tw_n / 64;
-  for (int idx = tid; idx < kTileC * 64; idx += nthr) {
+  for (int idx = tid; idx < ncols * 64; idx += nthr) {
     const int i = idx & 63, cc = idx >> 6, k = i & 7;
     c32 u[8];
 #pragma unroll
@@ -288,11 +296,15 @@ PAYNE_HD void fft4_s1_mid(int tid, int nthr, LP X, LP Y, TP tw, int tw_n) {
 }
 // step 1, last pass (sub-length 64): Y -> global, natural order within the column's 512 outputs; two adjacent
 // outputs per thread
-template <class LP, class GP, class TP>
-PAYNE_HD void fft4_s1_store(int tid, int nthr, LP Y, GP dst, TP tw, int tw_n, int c0) {
+// (tile column cc holds column colmap(cc) of the transform; < 0: an empty slot)
+struct ColRun { int c0; PAYNE_HD int operator()(int cc) const { return c0 + cc; } };
+template <class LP, class GP, class TP, class CM>
+PAYNE_HD void fft4_s1_store(int tid, int nthr, LP Y, GP dst, TP tw, int tw_n, CM colmap, int ncols = kTileC) {
   const int ts = tw_n / 512;
-  for (int idx = tid; idx < kTileC * 32; idx += nthr) {
+  for (int idx = tid; idx < ncols * 32; idx += nthr) {
     const int i = 2 * (idx & 31), cc = idx >> 5;
+    const int c0 = colmap(cc) - cc;                        // (so that c0 + cc below is the mapped column)
+    if (c0 + cc < 0) continue;
     c32 u[8], v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { u[r] = q_ld(Y, (size_t)cc * kTileLd + i + 64 * r); v[r] = q_ld(Y, (size_t)cc * kTileLd + i + 1 + 64 * r); }
@@ -595,6 +607,114 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
       if (VSINI && far) th = taper_far(ta, k, th);
       Z[k] = cscale(cconj(Z[k]), th * invM);
     }
+  }
+}
+
+// The same middle step for ONE conjugate pair, as a function: zk = Z[k], zmk = Z[M - k] (not conjugated), w = exp(-2 pi i k/2M),
+// tkg / tmg = taper(k) g, taper(M - k) g with g = 1/(4M).  Out: Y[k], Y[M - k].
+PAYNE_HD void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, c32& ymk) {
+  const c32 zm = cconj(zmk);
+  const c32 A = cadd(zk, zm);
+  const c32 C = cmul(w, cmul_negi(csub(zk, zm)));
+  const c32 S1 = cscale(cadd(A, C), tkg), S2 = cscale(csub(A, C), tmg);
+  const c32 E = cadd(S1, S2);
+  const c32 iO = cmul_posi(cmul(cconj(w), csub(S1, S2)));
+  yk = cconj(cadd(E, iO));
+  ymk = csub(E, iO);
+}
+template <bool VSINI> PAYNE_HD float taper_full(const TaperArgs& ta, int k) {
+  bool far = false;
+  float t = taper_at<VSINI>(ta, k, far);
+  if (VSINI && far) t = taper_far(ta, k, t);
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// Four-step transform whose FIRST pass applies the middle step above on the way in: the inverse transform of a
+// convolution reads the forward transform's output Z and needs Y (see rfft_taper_phase) -- a separate pass over the
+// spectrum costs one read and one write of it through the global workspace, here the pair (k, M - k) is combined in
+// registers while it is being loaded.  With k = c + B m the partner sits in column B - c at m' = 511 - m, so a tile
+// holds 8 columns c = 8t + 1 .. 8t + 8 (tile columns 0..7) and their mirrors B - c (tile columns 8..15), and one thread
+// owns butterfly i of column c together with butterfly 63 - i of column B - c: its sixteen loads are eight pairs.
+// Columns 0 and B/2 pair with themselves: a last tile takes them element by element (fft4_s1_special).
+// ---------------------------------------------------------------------------
+constexpr int kTilePairs = kTileC / 2;
+struct ColPairs {                      // column map of pair tile t
+  int t, B;
+  PAYNE_HD int operator()(int cc) const {
+    const int c = kTilePairs * t + 1 + (cc % kTilePairs);
+    return c >= B / 2 ? -1 : (cc < kTilePairs ? c : B - c);
+  }
+};
+struct ColSelf { int B; PAYNE_HD int operator()(int cc) const { return cc == 0 ? 0 : (cc == 1 ? B / 2 : -1); } };
+PAYNE_HD int fft4_pair_tiles(int B) { return (B / 2 - 1 + kTilePairs - 1) / kTilePairs; }
+
+template <bool VSINI, class GP, class LP, class TP>
+PAYNE_HD void fft4_s1_load_tapered(int tid, int nthr, GP src, LP X, int B, int t, TP tw, int tw_step, const TaperArgs& ta, int M) {
+  const float g = 0.25f / (float)M;
+  for (int idx = tid; idx < kTilePairs * 64; idx += nthr) {
+    const int p = idx % kTilePairs, i = idx / kTilePairs, c = kTilePairs * t + 1 + p;
+    if (c >= B / 2) continue;
+    const int c2 = B - c, i2 = 63 - i;
+    c32 u[8], v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      u[r] = q_ld(src, (size_t)c + (size_t)B * (i + 64 * r));
+      v[r] = q_ld(src, (size_t)c2 + (size_t)B * (i2 + 64 * r));
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                         // u[r] is bin k, v[7 - r] is bin M - k
+      const int k = c + B * (i + 64 * r);
+      const float tk = taper_full<VSINI>(ta, k), tm = taper_full<VSINI>(ta, M - k);
+      const c32 w = q_ld(tw, (size_t)k * tw_step);
+      c32 yk, ym;
+      taper_pair(u[r], v[7 - r], w, tk * g, tm * g, yk, ym);
+      u[r] = yk; v[7 - r] = ym;
+    }
+    dft8(u);
+    dft8(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      q_st(X, (size_t)p * kTileLd + 8 * i + r, u[r]);
+      q_st(X, (size_t)(kTilePairs + p) * kTileLd + 8 * i2 + r, v[r]);
+    }
+  }
+}
+// columns 0 and B/2, one element per work item: Y (plain layout [slot][m]) = middle step of Z
+template <bool VSINI, class GP, class LP, class TP>
+PAYNE_HD void fft4_s1_special(int tid, int nthr, GP src, LP P, int B, TP tw, int tw_step, const TaperArgs& ta, int M) {
+  const float invM = 1.0f / (float)M, g = 0.25f * invM;
+  for (int idx = tid; idx < 2 * kTileA; idx += nthr) {
+    const int slot = idx / kTileA, m = idx - slot * kTileA;
+    const int j = (slot ? B / 2 : 0) + B * m;
+    c32 y;
+    if (j == 0) {                                        // real bins X[0] and X[M] (rfft_taper_phase)
+      const c32 z0 = q_ld(src, 0);
+      const float x0 = z0.x + z0.y, xm = taper_full<VSINI>(ta, M) * (z0.x - z0.y);
+      y = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+    } else if (2 * j == M) {                             // the self-conjugate bin
+      y = cscale(cconj(q_ld(src, (size_t)j)), taper_full<VSINI>(ta, j) * invM);
+    } else {
+      const int k = j < M - j ? j : M - j;
+      const c32 zk = q_ld(src, (size_t)k), zmk = q_ld(src, (size_t)(M - k));
+      c32 yk, ym;
+      taper_pair(zk, zmk, q_ld(tw, (size_t)k * tw_step), taper_full<VSINI>(ta, k) * g, taper_full<VSINI>(ta, M - k) * g, yk, ym);
+      y = (j == k) ? yk : ym;
+    }
+    q_st(P, (size_t)slot * kTileLd + m, y);
+  }
+}
+// ... and the first radix-8 pass of those two columns, LDS -> LDS (what fft4_s1_load does on the way in)
+template <class LP>
+PAYNE_HD void fft4_s1_first_lds(int tid, int nthr, LP P, LP Q, int ncols) {
+  for (int idx = tid; idx < ncols * 64; idx += nthr) {
+    const int cc = idx >> 6, i = idx & 63;
+    c32 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = q_ld(P, (size_t)cc * kTileLd + i + 64 * r);
+    dft8(u);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q_st(Q, (size_t)cc * kTileLd + 8 * i + r, u[r]);
   }
 }
 

@@ -64,6 +64,9 @@ struct DevExecT {
   // LDS tile of the four-step transform (2 x fft_tile_complex()); null: runtime-geometry passes
   c32* tile_ = nullptr;
   __device__ __forceinline__ c32* tile() const { return tile_; }
+  // the four-step transform reads the raw row itself and applies the taper while loading (fft_run_tiled_x)
+  bool fuse_ = false;
+  __device__ __forceinline__ bool fuse() const { return fuse_; }
 };
 
 __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs, const double* err, int F) {
@@ -160,7 +163,8 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
   float* bufB = bufA + T.n1;
   DevExecT<false, false> ex;
-  if (tile_lds) ex.tile_ = reinterpret_cast<c32*>(big_sm);
+  if (tile_lds & 1) ex.tile_ = reinterpret_cast<c32*>(big_sm);
+  ex.fuse_ = (tile_lds & 2) != 0;
   double* chi2 = red + scratch_doubles(kBigThreads) - 1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
 #ifdef PAYNE_STAMPS

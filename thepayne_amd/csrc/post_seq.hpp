@@ -46,23 +46,48 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
 // Four-step form (fft4_* in post_core.hpp) for executors that own an LDS tile (`ex.tile()`): two round trips
 // through the global workspace per transform.  The closing pass of one tile and the opening pass of the next
 // touch different buffers and share a barrier interval.
-template <class Ex>
-PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile) {
+//   a -> b (step 1), b -> a (step 2); the result is in a.
+//   src0 (optional): step 1 reads its input from there instead of a (the raw ANN row: SCRUB0 = NaN -> 0 on the way) --
+//   the copy of the row into the workspace is then not needed at all;
+//   TAPER: step 1 applies the convolution's middle step while it loads (fft4_s1_load_tapered): no separate taper pass.
+enum { kNoTaper = 0, kTaperGauss = 1, kTaperVsini = 2 };
+template <int TAPER, bool SCRUB0, class Ex>
+PAYNE_SEQ c32* fft_run_tiled_x(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile,
+                               const c32* src0_, const TaperArgs* ta) {
   auto a = Ex::buf(a_);
   auto b = Ex::buf(b_);
+  auto s0 = Ex::buf(const_cast<c32*>(src0_ ? src0_ : a_));
   auto tw = Ex::twid(tw_);
   auto X = Ex::lds(tile);
   auto Y = Ex::lds(tile + fft_tile_complex());
   const int B = M / kTileA;
-  // step 1: a -> b
-  ex.par([&](int t, int n) { fft4_s1_load(t, n, a, X, B, 0); });
-  for (int c0 = 0; c0 < B; c0 += kTileC) {
-    ex.par([&](int t, int n) { fft4_s1_mid(t, n, X, Y, tw, tw_n); });
-    const bool more = c0 + kTileC < B;
-    ex.par([&](int t, int n) {
-      fft4_s1_store(t, n, Y, b, tw, tw_n, c0);
-      if (more) fft4_s1_load(t, n, a, X, B, c0 + kTileC);
-    });
+  // step 1: a (or src0) -> b
+  if constexpr (TAPER == kNoTaper) {
+    ex.par([&](int t, int n) { fft4_s1_load<SCRUB0>(t, n, s0, X, B, 0); });
+    for (int c0 = 0; c0 < B; c0 += kTileC) {
+      ex.par([&](int t, int n) { fft4_s1_mid(t, n, X, Y, tw, tw_n); });
+      const bool more = c0 + kTileC < B;
+      ex.par([&](int t, int n) {
+        fft4_s1_store(t, n, Y, b, tw, tw_n, ColRun{c0});
+        if (more) fft4_s1_load<SCRUB0>(t, n, s0, X, B, c0 + kTileC);
+      });
+    }
+  } else {
+    constexpr bool VS = TAPER == kTaperVsini;
+    const int tw_step = tw_n / (2 * M), nt = fft4_pair_tiles(B);
+    ex.par([&](int t, int n) { fft4_s1_load_tapered<VS>(t, n, a, X, B, 0, tw, tw_step, *ta, M); });
+    for (int pt = 0; pt < nt; ++pt) {
+      ex.par([&](int t, int n) { fft4_s1_mid(t, n, X, Y, tw, tw_n); });
+      const bool more = pt + 1 < nt;
+      ex.par([&](int t, int n) {
+        fft4_s1_store(t, n, Y, b, tw, tw_n, ColPairs{pt, B});
+        if (more) fft4_s1_load_tapered<VS>(t, n, a, X, B, pt + 1, tw, tw_step, *ta, M);
+        else fft4_s1_special<VS>(t, n, a, X, B, tw, tw_step, *ta, M);        // columns 0 and B/2 -> X (plain layout)
+      });
+    }
+    ex.par([&](int t, int n) { fft4_s1_first_lds(t, n, X, Y, 2); });
+    ex.par([&](int t, int n) { fft4_s1_mid(t, n, Y, X, tw, tw_n, 2); });
+    ex.par([&](int t, int n) { fft4_s1_store(t, n, X, b, tw, tw_n, ColSelf{B}, 2); });
   }
   // step 2: b -> a.  The tile buffers alternate, so the closing pass of a tile (which reads one buffer) and the
   // opening pass of the next (which fills the other) share a barrier interval as well.
@@ -86,6 +111,10 @@ PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, in
     }
   }
   return a_;
+}
+template <class Ex>
+PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile) {
+  return fft_run_tiled_x<kNoTaper, false>(ex, a_, b_, M, tw_, tw_n, conj_last, tile, nullptr, nullptr);
 }
 
 // The same with compile-time geometry (M points, NT threads, pass-ordered twiddles `twf`).
@@ -117,7 +146,7 @@ PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsign
 // out: whether that is still to be done (the fixed-geometry transform does it in its last pass).
 template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
-                            const TaperArgs& ta, bool& edge) {
+                            const TaperArgs& ta, bool& edge, const float* src0 = nullptr) {
   const int M = n / 2;
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
@@ -132,6 +161,15 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
     }
   }
   const c32* tw = T.tw;
+  if (c32* tile = ex.tile())
+    if (fft_tiled_ok(M) && ex.fuse()) {
+      // global workspace: the row (when it is handed over as `src0`) is read straight into the first pass, and the
+      // middle step rides on the inverse transform's loads: 8 transfers of the spectrum per stage instead of 12
+      c32* z = src0 ? fft_run_tiled_x<kNoTaper, true>(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false, tile, (const c32*)src0, nullptr)
+                    : fft_run_tiled_x<kNoTaper, false>(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false, tile, nullptr, nullptr);
+      c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
+      return (float*)fft_run_tiled_x<VSINI ? kTaperVsini : kTaperGauss, false>(ex, z, zo, M, tw, T.nmax, true, tile, nullptr, &ta);
+    }
   c32* z = fft_run(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false);
   ex.par([&](int t, int nt) { rfft_taper_phase<VSINI>(t, nt, z, M, tw, T.nmax / (2 * M), ta); });
   c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
@@ -147,13 +185,15 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   const bool direct = (out_stage != 0) && T.rot_identity && (th[5] != 0.0);
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
   constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : 16;
+  // global-workspace executor with the four-step transform: the first pass of the vsini transform reads the row itself
+  const bool fused_row = direct && ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2) && row_vectorised(T.npix, raw);
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
-    phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
+    if (!fused_row) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     if (prep) phase_take_prep(t, prep, S);             // per-candidate scalars were computed ahead of the kernel
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
-    phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
+    if (!fused_row) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -172,7 +212,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
     // transform's last pass can apply the edge rule itself
     bool edge = T.rot_identity != 0 && out_stage != 6;   // 6 = smoothspec('vsini') itself: no edge rule
-    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge);
+    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge, fused_row ? raw : nullptr);
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
     else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = out_stage != 6; }

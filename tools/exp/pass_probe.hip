@@ -26,6 +26,7 @@ struct ProbeEx {
   __device__ __forceinline__ void mark(int) {}
   __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
   __device__ __forceinline__ c32* tile() const { return nullptr; }
+  __device__ __forceinline__ bool fuse() const { return false; }
 };
 
 template <int KIND>
