@@ -89,6 +89,12 @@ def build_diag(verbose=False):
     return _compile_link(DIAG_LIB, extra=["-DPAYNE_STAMPS"], tag="_diag", verbose=verbose)
 
 
+def build_variant(tag, flags, verbose=False):
+    """An experimental twin thepayne_amd/libpayne_hip_<tag>.so built with extra compiler flags (tools/ only: timing
+    experiments such as -DPAYNE_EXP_SKIP=<phase mask>; never loaded by the product path)."""
+    return _compile_link(os.path.join(HERE, "libpayne_hip_%s.so" % tag), extra=list(flags), tag="_" + tag, verbose=verbose)
+
+
 def build_lib(force=False, verbose=False):
     """Compile csrc/*.hip -> thepayne_amd/libpayne_hip.so; returns the path."""
     if not force and not _stale():

@@ -19,6 +19,12 @@
 #define PAYNE_SEQ_CALL inline
 #endif
 
+// Timing experiments (tools/exp/ablate.py builds twins with -DPAYNE_EXP_SKIP=<mask>; results are WRONG by design):
+// 1 forward transforms | 2 taper phases | 4 inverse transforms | 8 resampling | 16 observed grid + chi^2 | 32 row load
+#ifndef PAYNE_EXP_SKIP
+#define PAYNE_EXP_SKIP 0
+#endif
+
 namespace payne {
 
 // scratch layout (doubles): [0, nthr) chi^2 partials | [nthr, nthr + nthr/2) mask counts (ints) | result
@@ -151,11 +157,11 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
-      c32* z = fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
+      c32* z = (PAYNE_EXP_SKIP & 1) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
       constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
-      ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
+      if (!(PAYNE_EXP_SKIP & 2)) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
-      float* res = (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
+      float* res = (PAYNE_EXP_SKIP & 4) ? (float*)z : (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
       edge = false;
       return res;
     }
@@ -189,11 +195,11 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   const bool fused_row = direct && ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2) && row_vectorised(T.npix, raw);
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
-    if (!fused_row) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
+    if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     if (prep) phase_take_prep(t, prep, S);             // per-candidate scalars were computed ahead of the kernel
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
-    if (!fused_row) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
+    if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -247,14 +253,14 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       W = make_window(T, S, cnt, n_slots(nthr));
     }
     if (!W.bad) {
-      ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
+      if (!(PAYNE_EXP_SKIP & 8)) ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
       bool no_edge = false;
       on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta, no_edge);
     }
   }
-  ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
+  if (!(PAYNE_EXP_SKIP & 16)) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
   // the sum of the per-wave partials: thread 0 alone, no closing barrier (it is also the only reader)
   ex.single([&](int n) {
     double s = 0.0;
