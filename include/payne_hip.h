@@ -232,6 +232,8 @@ int payne_bc_batch(payne_ctx* ctx, const double* x, int B, double* bc, void* str
 #define PAYNE_PRIOR_EXP 3        /* p = loc, scale             expon.ppf                prior.py:167-168 */
 #define PAYNE_PRIOR_TEXP 4       /* p = lo, hi, scale          truncexpon.ppf, inf -> hi prior.py:169-174 */
 #define PAYNE_PRIOR_LOGUNIFORM 5 /* p = lo, hi */
+#define PAYNE_PRIOR_TABLE 6      /* p[0] * np.interp(u, adv.tab_cdf, adv.tab_val): Dist under a GAL prior = 1000 * gal_ppf(u)
+                                  * (prior.py:231-234 -> advancedpriors.py:665-670); one such dimension per sampler */
 
 typedef struct payne_prior_dim {
   int kind;      /* PAYNE_PRIOR_* */
@@ -242,12 +244,32 @@ typedef struct payne_prior_dim {
   double g_mu, g_sigma, box_lo, box_hi;
 } payne_prior_dim;
 
+/* The priors on DERIVED quantities prior.lnpriorfn adds (Payne/fitting/prior.py:286-336, :425-465 via
+ * Payne/fitting/advancedpriors.py:93-137, :691-733): everything below is off when zero-initialised.
+ * A parameter they need is named by the sampled dimension that carries it (dim_* >= 0) or, when it is fixed or absent
+ * (dim_* < 0), by its value (NaN = absent). */
+typedef struct payne_adv_priors {
+  int imf;   /* + imf_lnprior(mass), Kroupa (alpha 1.3 / 2.3, break 0.5, -inf at <= 0.08), mass = 10^(logg + 2 logR - 4.437) */
+  int vrot;  /* + vrot_lnprior(Vrot, mass, eep = 350, logg); mass = 10^(logg + 2 logR) when both are finite and
+              * vrot_mass_one == 0, else 1 (prior.py:320-334: a photscale fit has no radius) */
+  int vrot_mass_one;
+  int dim_logg, dim_logr, dim_vrot;
+  double val_logg, val_logr, val_vrot;
+  int plx_dim;          /* dimension holding Dist for the derived 'Parallax' = 1000 / Dist (prior.py:449-451); < 0: none */
+  int plx_has_gauss, plx_has_box;
+  double plx_mu, plx_sigma, plx_lo, plx_hi;
+  const double* tab_cdf; /* HOST [tab_n], non-decreasing in [0, 1]: abscissae of PAYNE_PRIOR_TABLE (copied at create) */
+  const double* tab_val; /* HOST [tab_n] */
+  int tab_n;
+} payne_adv_priors;
+
 typedef struct payne_sampler_desc {
   int ndim; /* <= PAYNE_MAX_DIM */
   payne_prior_dim dims[PAYNE_MAX_DIM];
   int n_fixed; /* 'fixed' parameters merged into every theta row (likelihood.py:47-48) */
   int fixed_col[PAYNE_MAX_FIXED];
   double fixed_val[PAYNE_MAX_FIXED];
+  payne_adv_priors adv;
 } payne_sampler_desc;
 
 typedef struct payne_sampler payne_sampler;

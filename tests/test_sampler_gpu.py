@@ -429,3 +429,46 @@ def test_rwalk_queue_in_one_native_call(tmp_path):
                                                       0.05 * np.eye(nd), None, None, 1.0, -np.inf, walks, 9, again)
     assert calls4 == K * walks and red4 > K and np.all(again[0][:nq4] > 0)
     prop.close()
+
+
+@pytest.mark.parametrize("photscale", [False, True])
+def test_device_advanced_priors(tmp_path, photscale):
+    """The priors on derived quantities on the device: IMF and VROT terms of lnpriorfn (prior.py:286-336 ->
+    advancedpriors.py:93-137, :691-733), Dist = 1000 gal_ppf(u) under a GAL prior (prior.py:231-234) and the derived
+    'Parallax' = 1000 / Dist (prior.py:449-451), against the host prior class, which golden g10 pins to the reference."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    L, P0, OL = _fit_objects(tmp_path, photscale=photscale)
+    pd = synth.demo_priordict()
+    pd['VROT'] = {}
+    pd['Av'] = {'pv_uniform': [0.0, 2.0]}
+    if photscale:
+        pd['log(A)'] = {'pv_uniform': [-1.0, 1.0]}                 # no radius: VROT takes mass = 1 (prior.py:324-325)
+    else:
+        pd['IMF'] = {'IMF_type': 'Kroupa'}
+        pd['GAL'] = {'lb_coords': [70.0, 25.0]}
+        pd['Dist'] = {'pv_uniform': [50.0, 4000.0]}
+        pd['log(R)'] = {'pv_uniform': [-0.8, 1.2]}
+        pd['Parallax'] = {'gaussian': [2.0, 0.8], 'uniform': [0.3, 15.0]}
+    P = _clone_prior(P0, pd)
+    assert P.vrot_bool and P.imf_bool == (not photscale) and P.gal_bool == (not photscale)
+    prop = _proposer(L, P)                                         # (used to decline: NotImplementedError)
+    U = np.random.default_rng(31).uniform(size=(64, L.ndim))
+    V, lp = prop.lnprob_u(U)
+    theta = P.priortrans_batch(U)
+    np.testing.assert_allclose(V, theta, rtol=1e-10, atol=1e-10)
+    lnp = P.lnprior_batch(theta)
+    if not photscale:
+        assert np.isinf(lnp).any() and np.isfinite(lnp).any()      # the parallax box and the IMF cut both bite
+    host = lnprob_batch(theta, L, P)
+    assert np.array_equal(np.isinf(lp), np.isinf(host)) and np.array_equal(np.isnan(lp), np.isnan(host))
+    ok = np.isfinite(host)
+    assert np.all(np.abs(lp[ok] - host[ok]) <= 1e-9 * np.abs(host[ok]) + 1e-8)
+    # the walk applies the same priors: every accepted point beats the threshold under the HOST's lnprob
+    lp0 = np.where(np.isnan(lp), -np.inf, lp)
+    lstar = float(np.percentile(lp0[np.isfinite(lp0)], 40))
+    Uw, Vw, lw, nacc, ncall = prop.rwalk(U, V, lp0, 0.03 * np.eye(L.ndim), 1.0, lstar, 6, seed=5)
+    moved = nacc > 0
+    assert moved.any()
+    hw = lnprob_batch(Vw[moved], L, P)
+    assert np.all(np.abs(lw[moved] - hw) <= 1e-9 * np.abs(hw) + 1e-8) and np.all(lw[moved] > lstar)
+    prop.close()

@@ -24,7 +24,7 @@ SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_
            "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_ns_rwalk_queue", "payne_ns_consume", "payne_ns_bound", "payne_format_rows"]
 
 PAYNE_MAX_DIM, PAYNE_MAX_FIXED = 24, 16
-PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_TGAUSSIAN, PRIOR_EXP, PRIOR_TEXP, PRIOR_LOGUNIFORM = range(6)
+PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_TGAUSSIAN, PRIOR_EXP, PRIOR_TEXP, PRIOR_LOGUNIFORM, PRIOR_TABLE = range(7)
 
 _dp = C.POINTER(C.c_double)
 
@@ -59,9 +59,18 @@ class PriorDim(C.Structure):
                 ("g_mu", C.c_double), ("g_sigma", C.c_double), ("box_lo", C.c_double), ("box_hi", C.c_double)]
 
 
+class AdvPriors(C.Structure):
+    _fields_ = [("imf", C.c_int), ("vrot", C.c_int), ("vrot_mass_one", C.c_int),
+                ("dim_logg", C.c_int), ("dim_logr", C.c_int), ("dim_vrot", C.c_int),
+                ("val_logg", C.c_double), ("val_logr", C.c_double), ("val_vrot", C.c_double),
+                ("plx_dim", C.c_int), ("plx_has_gauss", C.c_int), ("plx_has_box", C.c_int),
+                ("plx_mu", C.c_double), ("plx_sigma", C.c_double), ("plx_lo", C.c_double), ("plx_hi", C.c_double),
+                ("tab_cdf", C.c_void_p), ("tab_val", C.c_void_p), ("tab_n", C.c_int)]
+
+
 class SamplerDesc(C.Structure):
     _fields_ = [("ndim", C.c_int), ("dims", PriorDim * 24), ("n_fixed", C.c_int),
-                ("fixed_col", C.c_int * 16), ("fixed_val", C.c_double * 16)]
+                ("fixed_col", C.c_int * 16), ("fixed_val", C.c_double * 16), ("adv", AdvPriors)]
 
 
 class NsState(C.Structure):

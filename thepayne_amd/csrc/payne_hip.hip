@@ -907,10 +907,18 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
   if (d->n_fixed < 0 || d->n_fixed > PAYNE_MAX_FIXED) return fail(c, PAYNE_E_INVALID, "sampler.n_fixed out of range");
   if (k_max <= 0 || k_max > c->opts.b_max) return fail(c, PAYNE_E_INVALID, "sampler.k_max must be in 1..opts.b_max");
   for (int i = 0; i < d->ndim; ++i)
-    if (d->dims[i].theta_col >= c->ncols || d->dims[i].kind < 0 || d->dims[i].kind > PAYNE_PRIOR_LOGUNIFORM)
+    if (d->dims[i].theta_col >= c->ncols || d->dims[i].kind < 0 || d->dims[i].kind > PAYNE_PRIOR_TABLE)
       return fail(c, PAYNE_E_INVALID, "sampler dimension with bad theta_col / kind");
   for (int i = 0; i < d->n_fixed; ++i)
     if (d->fixed_col[i] < 0 || d->fixed_col[i] >= c->ncols) return fail(c, PAYNE_E_INVALID, "fixed parameter with bad column");
+  {
+    const payne_adv_priors& a = d->adv;
+    int ntab = 0;
+    for (int i = 0; i < d->ndim; ++i) ntab += d->dims[i].kind == PAYNE_PRIOR_TABLE;
+    if (ntab > 1 || (ntab == 1 && (!a.tab_cdf || !a.tab_val || a.tab_n < 2))) return fail(c, PAYNE_E_INVALID, "PAYNE_PRIOR_TABLE needs adv.tab_* (one table per sampler)");
+    if (a.dim_logg >= d->ndim || a.dim_logr >= d->ndim || a.dim_vrot >= d->ndim || a.plx_dim >= d->ndim)
+      return fail(c, PAYNE_E_INVALID, "adv.dim_* out of range");
+  }
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev != c->device) (void)hipSetDevice(c->device);
@@ -919,6 +927,8 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
   s->sd.ndim = d->ndim; s->sd.ncols = c->ncols; s->sd.nfixed = d->n_fixed;
   for (int i = 0; i < d->ndim; ++i) s->sd.dims[i] = d->dims[i];
   for (int i = 0; i < d->n_fixed; ++i) { s->sd.fixed_col[i] = d->fixed_col[i]; s->sd.fixed_val[i] = d->fixed_val[i]; }
+  s->sd.adv = d->adv;
+  s->sd.adv.tab_cdf = nullptr; s->sd.adv.tab_val = nullptr;
   auto alloc = [&](size_t bytes, void** p) -> int {
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("hipMalloc(sampler): ") + hipGetErrorString(e));
@@ -934,6 +944,14 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       (rc = alloc(K * (2 * nd + 1) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev))) {
     payne_sampler_destroy(s);
     return rc;
+  }
+  if (d->adv.tab_cdf && d->adv.tab_val && d->adv.tab_n >= 2) {          // the tabulated inverse CDF (PAYNE_PRIOR_TABLE)
+    double *tc = nullptr, *tv = nullptr;
+    const size_t nb = (size_t)d->adv.tab_n * 8;
+    if ((rc = alloc(nb, (void**)&tc)) || (rc = alloc(nb, (void**)&tv))) { payne_sampler_destroy(s); return rc; }
+    (void)hipMemcpy(tc, d->adv.tab_cdf, nb, hipMemcpyHostToDevice);
+    (void)hipMemcpy(tv, d->adv.tab_val, nb, hipMemcpyHostToDevice);
+    s->sd.adv.tab_cdf = tc; s->sd.adv.tab_val = tv;
   }
   (void)hipMemset(s->inside, 0, K * 4);
   if (hipHostMalloc((void**)&s->q_host, K * (2 * nd + 1) * 8, hipHostMallocDefault) != hipSuccess ||

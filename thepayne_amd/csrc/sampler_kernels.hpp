@@ -11,11 +11,55 @@ struct SamplerDev {
   payne_prior_dim dims[PAYNE_MAX_DIM];
   int fixed_col[PAYNE_MAX_FIXED];
   double fixed_val[PAYNE_MAX_FIXED];
+  payne_adv_priors adv;             // (tab_cdf / tab_val: DEVICE copies here)
 };
 
+// np.interp(u, xp, fp), xp non-decreasing: the last j with xp[j] <= u, slope form (advancedpriors.gal_ppf)
+__device__ double table_interp(const payne_adv_priors& a, double u) {
+  const double* xp = a.tab_cdf;
+  const double* fp = a.tab_val;
+  const int n = a.tab_n;
+  if (!(u == u)) return u;
+  if (u > xp[n - 1]) return fp[n - 1];
+  if (u < xp[0]) return fp[0];
+  int lo = 0, hi = n;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= u) lo = mid; else hi = mid; }
+  if (lo == n - 1 || xp[lo] == u) return fp[lo];
+  return (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]) * (u - xp[lo]) + fp[lo];
+}
+// imf_lnprior (advancedpriors.py:93-137) and vrot_lnprior (:691-733) of the values gathered by the caller
+__device__ double adv_lnprior(const payne_adv_priors& a, double logg, double logr, double vrot, double dist) {
+  double lp = 0.0;
+  if (a.imf) {
+    const double m = pow(10.0, logg + 2.0 * logr - 4.437);                     // prior.py:291-294
+    const double al = 1.3, ah = 2.3, mb = 0.5;
+    double v;
+    if (m > mb) v = -ah * log(m) + (ah - al) * log(mb);
+    else if (m > 0.08) v = -al * log(m);
+    else v = (m == m) ? -INFINITY : m;
+    const double norm = pow(mb, 1.0 - al) / (ah - 1.0) + pow(0.08, 1.0 - al) / (al - 1.0) - pow(mb, 1.0 - al) / (al - 1.0);
+    lp += v - log(norm);
+  }
+  if (a.vrot) {
+    const bool have = !a.vrot_mass_one && (logg - logg == 0.0) && (logr - logr == 0.0);   // both finite
+    const double mass = have ? pow(10.0, logg + 2.0 * logr) : 1.0;              // prior.py:320-331 (no zero point here)
+    const bool hot = mass > 1.25, gi = !hot && (logg < 3.5);                     // eep = 350 < 450
+    const double aa = hot ? -1.0 : -10.0, cc = hot ? 100.0 : (gi ? 7.0 : 10.0), nn = hot ? 1.0 : (gi ? 1.0 : 0.4);
+    lp += aa / (1.0 + nn * exp(-(vrot - cc)));
+  }
+  if (a.plx_dim >= 0) {                                                        // 'Parallax' = 1000 / Dist, prior.py:449-451
+    const double plx = 1000.0 / dist;
+    if (a.plx_has_gauss) { const double z = plx - a.plx_mu; lp += -0.5 * ((z * z) / (a.plx_sigma * a.plx_sigma)); }
+    if (a.plx_has_box && ((plx < a.plx_lo) || (plx > a.plx_hi))) lp = -INFINITY;
+  }
+  return lp;
+}
+__device__ __forceinline__ bool adv_any(const payne_adv_priors& a) { return a.imf || a.vrot || a.plx_dim >= 0; }
+
 // unit cube -> parameter (Payne/fitting/prior.py:151-178, scipy.stats ppf's restated)
-__device__ double prior_ppf(const payne_prior_dim& d, double u) {
+__device__ double prior_ppf(const payne_prior_dim& d, double u, const payne_adv_priors& adv) {
   switch (d.kind) {
+    case PAYNE_PRIOR_TABLE: return d.p[0] * table_interp(adv, u);
     case PAYNE_PRIOR_UNIFORM: {
       const double lo = fmin(d.p[0], d.p[1]), hi = fmax(d.p[0], d.p[1]);
       return (hi - lo) * u + lo;
@@ -83,9 +127,15 @@ __global__ void payne_prior_kernel(SamplerDev sd, const double* u, int K, double
   double vv[PAYNE_MAX_DIM];
   double lp = 0.0;
   for (int d = 0; d < sd.ndim; ++d) {
-    vv[d] = prior_ppf(sd.dims[d], u[(size_t)c * sd.ndim + d]);
+    vv[d] = prior_ppf(sd.dims[d], u[(size_t)c * sd.ndim + d], sd.adv);
     v[(size_t)c * sd.ndim + d] = vv[d];
     lp += prior_ln(sd.dims[d], vv[d]);
+  }
+  if (adv_any(sd.adv)) {
+    const payne_adv_priors& a = sd.adv;
+    const double add = adv_lnprior(a, a.dim_logg >= 0 ? vv[a.dim_logg] : a.val_logg, a.dim_logr >= 0 ? vv[a.dim_logr] : a.val_logr,
+                                   a.dim_vrot >= 0 ? vv[a.dim_vrot] : a.val_vrot, a.plx_dim >= 0 ? vv[a.plx_dim] : 1.0);
+    lp = (lp == -INFINITY || add == -INFINITY) ? -INFINITY : lp + add;
   }
   if (mode) { lnprior[c] = lp; write_theta_row(sd, vv, rows + (size_t)c * sd.ncols); }
 }
@@ -181,8 +231,16 @@ __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, int K, 
   }
   if (nredraw && lane == 0) nredraw[c] += skipped;
   const payne_prior_dim dim = sd.dims[dl];
-  const double vp = in ? prior_ppf(dim, up) : vc;               // outside: a harmless valid row
-  const double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
+  const double vp = in ? prior_ppf(dim, up, sd.adv) : vc;       // outside: a harmless valid row
+  double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
+  if (adv_any(sd.adv)) {                                       // priors on derived quantities: the values they need by shuffle
+    const payne_adv_priors& a = sd.adv;
+    const double g_ = __shfl(vp, a.dim_logg >= 0 ? a.dim_logg : 0), r_ = __shfl(vp, a.dim_logr >= 0 ? a.dim_logr : 0);
+    const double v_ = __shfl(vp, a.dim_vrot >= 0 ? a.dim_vrot : 0), d_ = __shfl(vp, a.plx_dim >= 0 ? a.plx_dim : 0);
+    const double add = adv_lnprior(a, a.dim_logg >= 0 ? g_ : a.val_logg, a.dim_logr >= 0 ? r_ : a.val_logr,
+                                   a.dim_vrot >= 0 ? v_ : a.val_vrot, a.plx_dim >= 0 ? d_ : 1.0);
+    lp = (lp == -INFINITY || add == -INFINITY) ? -INFINITY : lp + add;
+  }
   if (act) { u_prop[off] = up; v_prop[off] = vp; }
   if (lane == 0) { inside[c] = in ? 1 : 0; lnprior_prop[c] = lp; }
   // theta row, lane = column: NaN = absent, fixed values, then the sampled dimensions

@@ -47,10 +47,8 @@ class DeviceProposer(object):
                 dim.has_gauss, dim.g_mu, dim.g_sigma = 1, float(add['gaussian'][0]), float(add['gaussian'][1])
             if 'uniform' in add:
                 dim.has_box, dim.box_lo, dim.box_hi = 1, float(add['uniform'][0]), float(add['uniform'][1])
-        if getattr(priorobj, 'advanced', False):
-            raise NotImplementedError("IMF / VROT / GAL priors are evaluated on the host; use the host sampler path")
-        if 'Parallax' in priorobj.additionalpriors:
-            raise NotImplementedError("a 'Parallax' prior is a derived quantity; use the host sampler path")
+        self._adv_tables = None
+        self._advanced(d, priorobj, likeobj)
         if len(fixed) > _lib.PAYNE_MAX_FIXED:
             raise ValueError("too many fixed parameters")
         d.n_fixed = len(fixed)
@@ -70,6 +68,54 @@ class DeviceProposer(object):
         self._ncall = self.torch.empty(self.k_max, dtype=i32, device=dev)
         self._pack_h = None                  # pinned staging for rwalk, made on first use
         self._qstats = np.zeros(4, dtype=np.int64)
+
+    # -- priors on derived quantities (prior.py:286-336, :449-451) ----------------------
+    def _advanced(self, d, P, L):
+        """IMF / VROT terms, the GAL distance transform and the derived 'Parallax' prior as the library's
+        payne_adv_priors; the cases the reference itself cannot evaluate stay on the host path (which raises as the
+        reference does)."""
+        a = d.adv
+        a.dim_logg = a.dim_logr = a.dim_vrot = a.plx_dim = -1
+        a.val_logg = a.val_logr = a.val_vrot = float("nan")
+        names = list(P.fitpars_i)
+        fixed = dict(P.fixedpars)
+
+        def locate(name):
+            if name in names:
+                return names.index(name), float("nan")
+            v = fixed.get(name, float("nan"))
+            return -1, (float(v) if np.ndim(v) == 0 else float("nan"))
+
+        if getattr(P, 'imf_bool', False) or getattr(P, 'vrot_bool', False):
+            a.dim_logg, a.val_logg = locate('log(g)')
+            a.dim_logr, a.val_logr = locate('log(R)')
+            a.dim_vrot, a.val_vrot = locate('Vrot')
+        if getattr(P, 'imf_bool', False):
+            if 'log(R)' not in names and 'log(R)' not in fixed:
+                raise NotImplementedError("IMF prior without log(R): the reference raises KeyError; host path")
+            a.imf = 1
+        if getattr(P, 'vrot_bool', False):
+            if a.dim_vrot < 0 and not np.isfinite(a.val_vrot):
+                raise NotImplementedError("VROT prior without Vrot: host path")
+            a.vrot = 1
+            a.vrot_mass_one = 1 if ('log(A)' in names or 'log(A)' in fixed or
+                                    ('log(R)' not in names and 'log(R)' not in fixed)) else 0
+        if getattr(P, 'gal_bool', False) and 'Dist' in names and P.phot_bool:          # prior.py:231-234
+            j = names.index('Dist')
+            d.dims[j].kind = _lib.PRIOR_TABLE
+            d.dims[j].p[0] = 1000.0
+            self._adv_tables = (np.ascontiguousarray(P.AP._cdf, dtype=np.float64),
+                                np.ascontiguousarray(P.AP.distarr, dtype=np.float64))
+            a.tab_cdf, a.tab_val = self._adv_tables[0].ctypes.data, self._adv_tables[1].ctypes.data
+            a.tab_n = len(self._adv_tables[0])
+        plx = P.additionalpriors.get('Parallax', {})
+        plx = {k: v for k, v in plx.items() if k in ('gaussian', 'uniform')}
+        if plx and P.phot_bool and 'Dist' in names:
+            a.plx_dim = names.index('Dist')
+            if 'gaussian' in plx:
+                a.plx_has_gauss, a.plx_mu, a.plx_sigma = 1, float(plx['gaussian'][0]), float(plx['gaussian'][1])
+            if 'uniform' in plx:
+                a.plx_has_box, a.plx_lo, a.plx_hi = 1, float(plx['uniform'][0]), float(plx['uniform'][1])
 
     # -- prior description -----------------------------------------------------------
     def _kind(self, name):
