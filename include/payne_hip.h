@@ -114,6 +114,8 @@ typedef struct payne_opts {
 #define PAYNE_V_SELECT_MEDIAN 64u /* continuum / LSF medians by radix selection (what rows too long for an LDS sort use) */
 #define PAYNE_V_BIG_FUSED 256u   /* spectra > 16384 px: the row read by the first transform pass, the taper applied while the inverse
                                   * transform loads (19 instead of 25 transfers of the spectrum; measured 3 % slower: kept as the record) */
+#define PAYNE_V_NO_WALK_TAIL 512u /* the sampler's chain step as a launch of its own between two likelihood batches (what
+                                  * contexts without a likelihood-only post kernel use) instead of at the post kernel's tail */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;
@@ -373,6 +375,12 @@ int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* l
                          int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv, double scale,
                          double loglstar, int walks, unsigned long long seed, double* qu, double* qv, double* ql, int* qnc,
                          int* nq, long long* stats, void* stream);
+
+/* How the chain steps of this sampler ran so far: out[0] at the tail of the likelihood-only post kernel (the workgroup of
+ * candidate k settles chain k's proposal and draws the next one as soon as it has the likelihood), out[1] as launches of
+ * their own (the first step of every walk; every step under PAYNE_V_NO_WALK_TAIL, with an LSF, or when the spectrum length
+ * has no likelihood-only kernel).  Measurement / test aid, no reference counterpart. */
+int payne_sampler_counters(const payne_sampler* s, long long out[2]);
 
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);

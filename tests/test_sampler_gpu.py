@@ -149,6 +149,35 @@ def test_device_rwalk_invariants(tmp_path):
     prop.close()
 
 
+@pytest.mark.parametrize("photscale,modpoly", [(True, False), (False, True)])
+def test_walk_step_at_the_post_kernels_tail_is_the_same_walk(tmp_path, photscale, modpoly):
+    """The chain step runs at the tail of the likelihood-only post kernel (default) or as a launch of its own
+    (PAYNE_V_NO_WALK_TAIL): same counter-based draws, same arithmetic -> the same chains to the bit."""
+    from thepayne_amd import _lib
+    res = []
+    for variant in (0, _lib.V_NO_WALK_TAIL):
+        L, P, _ = _fit_objects(tmp_path, photscale=photscale, modpoly=modpoly, variant=variant)
+        prop = _proposer(L, P)
+        rng = np.random.default_rng(11)
+        K, nd = 64, L.ndim
+        U0 = rng.uniform(0.25, 0.75, size=(K, nd))
+        V0, lp0 = prop.lnprob_u(U0)
+        lp0 = np.where(np.isnan(lp0), -np.inf, lp0)
+        lstar = float(np.median(lp0[np.isfinite(lp0)]))
+        out = [prop.rwalk(U0, V0, lp0, 0.05 * np.eye(nd), 1.0, lstar, w, seed=77) for w in (1, 2, 9)]
+        K2 = 24                                                                   # a shorter batch right after a longer one
+        out.append(prop.rwalk(U0[:K2], V0[:K2], lp0[:K2], 0.03 * np.eye(nd), 1.3, lstar, 5, seed=3))
+        res.append(out)
+        at_tail, own = prop.step_counters()
+        # 1 + 2 + 9 + 5 walks' steps (+ the closing call of each): all but each walk's first at the tail, or none
+        assert (at_tail, own) == ((17, 4) if variant == 0 else (0, 21))
+        prop.close()
+    for a, b in zip(*res):
+        assert a[3].sum() > 0
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 def test_device_rwalk_step_distribution(tmp_path):
     """One step with threshold -inf accepts every in-cube proposal: the displacement must be uniform in the
     ellipsoid axes @ unit ball (mean 0, covariance axes axes^T / (n+2), |z| <= 1)."""

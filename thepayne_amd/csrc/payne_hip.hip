@@ -72,6 +72,7 @@ struct payne_ctx {
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
+  bool lean_available = false;          // a likelihood-only instantiation exists for this spectrum length (it can carry a walk's tail)
   PostTables* d_T = nullptr;          // device copy of T
   post_kernel_fn post_fn = nullptr;
   float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
@@ -351,6 +352,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     const int geom_n1 = (opts->variant & PAYNE_V_POST_GENERIC) ? 0 : T.n1;
     c->post_fn = pick_post_kernel(geom_n1, c->post_tw_lds);
     c->post_fn_lean = (opts->variant & PAYNE_V_POST_FULL) ? c->post_fn : pick_post_kernel(geom_n1, c->post_tw_lds, true);
+    c->lean_available = c->post_fn_lean != c->post_fn;
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn_lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
@@ -732,8 +734,9 @@ static int run_sed(payne_ctx* c, const double* in, int ld, int mode, int B, doub
 static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, float* out, int ld_out, double* lnl,
                         bool with_phot, hipStream_t s);
 
+struct TailReq { const WalkTail* dev; int step, propose; bool done; };
 static int run_post(payne_ctx* c, const double* theta, int B, double instr_factor, int stage, float* out, int ld_out,
-                    double* lnl, bool with_phot, hipStream_t s) {
+                    double* lnl, bool with_phot, hipStream_t s, TailReq* tail = nullptr) {
   if (c->has_lsf && (stage < 0 || stage == 2 || stage == 3)) return run_post_lsf(c, theta, B, stage, out, ld_out, lnl, with_phot, s);
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = instr_factor;
@@ -741,6 +744,8 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
   a.prep = c->prep_valid ? c->prep : nullptr;
+  const bool lean = stage < 0 && !out && a.prep && !c->big_ws;
+  if (tail && lean && c->lean_available) { a.tail = tail->dev; a.tail_step = tail->step; a.tail_propose = tail->propose; tail->done = true; }
   {
     ProfScope ps(c, s, 1);
     if (c->big_ws) {
@@ -749,7 +754,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
       const size_t lds = (tiled & 1) ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
       PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
-      PAYNE_LAUNCH((stage < 0 && !out && a.prep) ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+      PAYNE_LAUNCH(lean ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
     }
   }
   hipError_t e = hipGetLastError();
@@ -795,7 +800,11 @@ static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, flo
   return PAYNE_OK;
 }
 
+static int lnlike_impl(payne_ctx* c, const double* theta, int B, double* lnl, void* stream, TailReq* tail);
 extern "C" int payne_lnlike_batch(payne_ctx* c, const double* theta, int B, double* lnl, void* stream) {
+  return lnlike_impl(c, theta, B, lnl, stream, nullptr);
+}
+static int lnlike_impl(payne_ctx* c, const double* theta, int B, double* lnl, void* stream, TailReq* tail) {
   int rc = check_call(c, theta, B, lnl);
   if (rc) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -805,7 +814,7 @@ extern "C" int payne_lnlike_batch(payne_ctx* c, const double* theta, int B, doub
     if ((rc = run_ann(c, theta, B, 2.355, s))) return rc;
   }
   if (c->has_phot && (rc = run_sed(c, theta, c->ncols, 1, B, c->mags_ws, s))) return rc;
-  if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s);
+  if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s, (c->has_lsf || (c->opts.variant & PAYNE_V_NO_WALK_TAIL)) ? nullptr : tail);
   hipLaunchKernelGGL(payne_photonly_kernel, dim3((B + 127) / 128), dim3(128), 0, s, c->mags_ws, c->obs_mag, c->obs_err, c->P.F, B, lnl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("photonly launch: ") + hipGetErrorString(e));
@@ -883,6 +892,10 @@ struct payne_sampler {
   double *q_dev = nullptr, *q_host = nullptr;
   int *qi_dev = nullptr, *qi_host = nullptr;
   std::vector<int> q_start, q_ell;
+  WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
+  WalkState walk{};                       // the walk in progress
+  bool tail_done = false;                 // the last likelihood batch ran the next step at its tail
+  long long n_tail = 0, n_own = 0;        // chain steps at the post kernel's tail / as launches of their own
   std::vector<void*> owned;
   // a walk in progress (payne_rwalk_begin / payne_rwalk_step)
   struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; bool multi; int* nredraw; } run{};
@@ -927,6 +940,9 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
   s->sd.ndim = d->ndim; s->sd.ncols = c->ncols; s->sd.nfixed = d->n_fixed;
   for (int i = 0; i < d->ndim; ++i) s->sd.dims[i] = d->dims[i];
   for (int i = 0; i < d->n_fixed; ++i) { s->sd.fixed_col[i] = d->fixed_col[i]; s->sd.fixed_val[i] = d->fixed_val[i]; }
+  for (int k = 0; k < kMaxThetaCols; ++k) { s->sd.col_src[k] = -1; s->sd.col_val[k] = std::nan(""); }
+  for (int i = 0; i < d->n_fixed; ++i) s->sd.col_val[d->fixed_col[i]] = d->fixed_val[i];
+  for (int i = 0; i < d->ndim; ++i) if (d->dims[i].theta_col >= 0) s->sd.col_src[d->dims[i].theta_col] = i;
   s->sd.adv = d->adv;
   s->sd.adv.tab_cdf = nullptr; s->sd.adv.tab_val = nullptr;
   auto alloc = [&](size_t bytes, void** p) -> int {
@@ -941,7 +957,8 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
       (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
       (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell)) || (rc = alloc(K * 4, (void**)&s->nredraw)) ||
-      (rc = alloc(K * (2 * nd + 1) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev))) {
+      (rc = alloc(K * (2 * nd + 1) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
+      (rc = alloc(sizeof(WalkTail), (void**)&s->tail_dev))) {
     payne_sampler_destroy(s);
     return rc;
   }
@@ -1018,6 +1035,9 @@ extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, dou
   HIPCHK(s->ctx, hipMemsetAsync(ncall, 0, (size_t)K * 4, st));
   HIPCHK(s->ctx, hipMemsetAsync(s->nredraw, 0, (size_t)K * 4, st));
   s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr, s->nredraw};
+  s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, s->axes,
+                              ell ? s->ell : (const int*)nullptr, s->nredraw, scale, loglstar, seed, K};
+  s->tail_done = false;
   return PAYNE_OK;
 }
 extern "C" int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
@@ -1031,17 +1051,29 @@ extern "C" int payne_rwalk_step(payne_sampler* s, int w) {
   if (!s->run.open || w < 0 || w > s->run.walks) return fail(s->ctx, PAYNE_E_INVALID, "payne_rwalk_step outside a walk");
   const auto& r = s->run;
   hipStream_t st = reinterpret_cast<hipStream_t>(r.stream);
-  const dim3 grid((r.K + 3) / 4), block(256);                  // one wave per chain
-  hipLaunchKernelGGL(payne_rwalk_kernel, grid, block, 0, st, s->sd, r.K, r.u, r.v, r.lnprob, r.nacc, r.ncall, s->u_prop,
-                     s->v_prop, s->lnprior, s->inside, s->lnl, s->rows, s->axes, r.multi ? s->ell : (const int*)nullptr, r.scale,
-                     r.loglstar, r.seed, w,
-                     w > 0 ? 1 : 0, w < r.walks ? 1 : 0, r.nredraw);
+  // step w: settle proposal w-1, draw proposal w -- unless the previous likelihood batch already did it at its tail
+  if (s->tail_done) s->n_tail += 1;
+  else {
+    s->n_own += 1;
+    const dim3 grid((r.K + 3) / 4), block(256);                // one wave per chain
+    hipLaunchKernelGGL(payne_rwalk_kernel, grid, block, 0, st, s->sd, s->walk, s->lnl, w, w > 0 ? 1 : 0, w < r.walks ? 1 : 0,
+                       w == 0 ? s->tail_dev : (WalkTail*)nullptr);
+  }
+  s->tail_done = false;
   int rc = PAYNE_OK;
-  if (w < r.walks) rc = payne_lnlike_batch(s->ctx, s->rows, r.K, s->lnl, r.stream);
-  else s->run.open = false;
+  if (w < r.walks) {
+    TailReq tr{s->tail_dev, w + 1, w + 1 < r.walks ? 1 : 0, false};
+    rc = lnlike_impl(s->ctx, s->rows, r.K, s->lnl, r.stream, &tr);
+    s->tail_done = tr.done;
+  } else s->run.open = false;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(s->ctx, PAYNE_E_HIP, std::string("rwalk launch: ") + hipGetErrorString(e));
   return rc;
+}
+extern "C" int payne_sampler_counters(const payne_sampler* s, long long out[2]) {
+  if (!s || !out) return PAYNE_E_INVALID;
+  out[0] = s->n_tail; out[1] = s->n_own;
+  return PAYNE_OK;
 }
 extern "C" int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
                                  double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,

@@ -4,6 +4,7 @@
 // payne_lsf_kernel (LSF-vector broadening, Payne/utils/smoothing.py:482-586).
 #pragma once
 #include "select.hpp"
+#include "sampler_core.hpp"
 
 // ============================================================================
 // per-candidate spectrum pipeline
@@ -20,6 +21,10 @@ struct PostArgs {
   unsigned long long* stamps;        // diagnostic build: [B][kStampRow] cycle stamps (slot 0 = count)
   int stamp_sparse;                  // diagnostic build: only the first and the last stamp (slots 1 and kStampRow - 1)
   const CandState* prep;             // [B] per-candidate records made by the first dense launch (null: none)
+  // the sampler's walk (payne_rwalk_step): the likelihood-only kernel runs chain b's NEXT step (settle this proposal, draw the
+  // next) at its tail -- the workgroup of candidate b has just produced the one value that step waits for -- instead of a
+  // launch of its own between two likelihood batches (null: no walk in progress)
+  const WalkTail* tail; int tail_step, tail_propose;
 };
 
 // BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
@@ -73,6 +78,16 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
   double s = 0.0;   // likelihood.py:109-112
   for (int f = 0; f < F; ++f) { const double d = mags[f] - obs[f]; s += (d * d) / (err[f] * err[f]); }
   return s;
+}
+
+// (a call, not inlined: the walk's registers must not count against the per-pixel phases' budget of 128 -- two
+// workgroups per CU -- and pinning the kernel to that budget by attribute costs the FFT passes 2.5 us of scheduling freedom)
+#ifndef PAYNE_EXP_TAIL_ATTR
+#define PAYNE_EXP_TAIL_ATTR __attribute__((noinline))
+#endif
+__device__ PAYNE_EXP_TAIL_ATTR static void walk_tail(const WalkTail* t, int b, int lane, double lnl, int step, int propose) {
+  const WalkState W = uniform_copy(&t->w);
+  rwalk_step_wave(t->sd, W, b, lane, lnl, step, 1, propose);
 }
 
 // LEAN: the likelihood-only instantiation (out_stage == -1, no spectrum output, per-candidate records present):
@@ -133,10 +148,18 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   if (LEAN) { prep = a.prep + b; __builtin_assume(prep != nullptr); }     // LEAN is launched only with records
   run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
                                      a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep);
+  double lnl_v = 0.0;
   if (threadIdx.x == 0 && a.lnl && ostage < 0) {
     double x2 = *chi2;
     if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
-    a.lnl[b] = -0.5 * x2;                                       // likelihood.py:117
+    lnl_v = -0.5 * x2;                                          // likelihood.py:117
+    a.lnl[b] = lnl_v;
+  }
+  if constexpr (LEAN) {
+    if (a.tail && threadIdx.x < 64) {                           // (wave 0: thread 0 holds the value, the others get it by shuffle)
+      const double l = __shfl(lnl_v, 0);
+      walk_tail(a.tail, b, (int)threadIdx.x, l, a.tail_step, a.tail_propose);
+    }
   }
 #ifdef PAYNE_STAMPS
   if (a.stamps && threadIdx.x == 0) { ex.stamps[0] = (unsigned long long)ex.nst; ex.stamps[kStampRow - 1] = __builtin_amdgcn_s_memtime(); }
@@ -437,7 +460,7 @@ extern template __global__ void payne_lsf_kernel<true>(const PostTables, LsfArgs
 
 // The instantiations that exist (each is compiled in one of the k_post_*.hip units; everybody else sees them as
 // `extern template`): X(LOG2N, TW_LDS, LEAN)
-#define PAYNE_POST_LEAN_LIST(X) X(12, true, true) X(11, true, true) X(13, false, true)
+#define PAYNE_POST_LEAN_LIST(X) X(12, true, true) X(11, true, true) X(10, true, true) X(13, false, true)
 #define PAYNE_POST_FULL_A_LIST(X) X(12, true, false) X(0, true, false)
 #define PAYNE_POST_FULL_B_LIST(X) X(10, true, false) X(11, true, false) X(13, false, false) X(0, false, false)
 #define PAYNE_POST_EXTERN(L, TW, LEAN) extern template __global__ void payne_post_kernel<L, TW, LEAN>(const PostTables, PostArgs);
@@ -455,9 +478,10 @@ PAYNE_POST_FULL_B_LIST(PAYNE_POST_EXTERN)
 typedef void (*post_kernel_fn)(const PostTables, PostArgs);
 // compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
 static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
-  if (lean) {                                   // likelihood-only builds of the two LDS-twiddle sizes that matter
+  if (lean) {                                   // likelihood-only builds of the LDS-twiddle sizes that matter
     if (tw_lds && n1 == 4096) return payne_post_kernel<12, true, true>;
     if (tw_lds && n1 == 2048) return payne_post_kernel<11, true, true>;
+    if (tw_lds && n1 == 1024) return payne_post_kernel<10, true, true>;
     if (!tw_lds && n1 == 8192) return payne_post_kernel<13, false, true>;
   }
   if (tw_lds) {

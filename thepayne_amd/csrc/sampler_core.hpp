@@ -1,0 +1,310 @@
+// sampler_kernels.hpp -- the sampler step on the device: prior transform and ln-prior
+// (Payne/fitting/prior.py:126-465), theta rows, random-walk proposals (one wave per chain).
+// Device functions only (no kernels): included by sampler_kernels.hpp (payne_hip.hip) and by post_kernels.hpp, whose
+// likelihood-only kernel runs a chain's next step at its tail.
+#pragma once
+#include "../../include/payne_hip.h"
+#ifdef __HIPCC__
+
+// ============================================================================
+// device-side sampler step: prior transform, ln-prior, theta rows, random-walk proposals
+// ============================================================================
+constexpr int kMaxThetaCols = 8 + PAYNE_MAX_POLY + 4;
+struct SamplerDev {
+  int ndim, ncols, nfixed;
+  payne_prior_dim dims[PAYNE_MAX_DIM];
+  int fixed_col[PAYNE_MAX_FIXED];
+  double fixed_val[PAYNE_MAX_FIXED];
+  payne_adv_priors adv;             // (tab_cdf / tab_val: DEVICE copies here)
+  // the theta row by column (what write_theta_row does, resolved once): col_src >= 0 the sampled dimension that fills the
+  // column, < 0 the constant col_val (a fixed value or NaN = absent)
+  int col_src[kMaxThetaCols];
+  double col_val[kMaxThetaCols];
+};
+
+// np.interp(u, xp, fp), xp non-decreasing: the last j with xp[j] <= u, slope form (advancedpriors.gal_ppf)
+__device__ inline double table_interp(const payne_adv_priors& a, double u) {
+  const double* xp = a.tab_cdf;
+  const double* fp = a.tab_val;
+  const int n = a.tab_n;
+  if (!(u == u)) return u;
+  if (u > xp[n - 1]) return fp[n - 1];
+  if (u < xp[0]) return fp[0];
+  int lo = 0, hi = n;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= u) lo = mid; else hi = mid; }
+  if (lo == n - 1 || xp[lo] == u) return fp[lo];
+  return (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]) * (u - xp[lo]) + fp[lo];
+}
+// imf_lnprior (advancedpriors.py:93-137) and vrot_lnprior (:691-733) of the values gathered by the caller
+__device__ inline double adv_lnprior(const payne_adv_priors& a, double logg, double logr, double vrot, double dist) {
+  double lp = 0.0;
+  if (a.imf) {
+    const double m = pow(10.0, logg + 2.0 * logr - 4.437);                     // prior.py:291-294
+    const double al = 1.3, ah = 2.3, mb = 0.5;
+    double v;
+    if (m > mb) v = -ah * log(m) + (ah - al) * log(mb);
+    else if (m > 0.08) v = -al * log(m);
+    else v = (m == m) ? -INFINITY : m;
+    const double norm = pow(mb, 1.0 - al) / (ah - 1.0) + pow(0.08, 1.0 - al) / (al - 1.0) - pow(mb, 1.0 - al) / (al - 1.0);
+    lp += v - log(norm);
+  }
+  if (a.vrot) {
+    const bool have = !a.vrot_mass_one && (logg - logg == 0.0) && (logr - logr == 0.0);   // both finite
+    const double mass = have ? pow(10.0, logg + 2.0 * logr) : 1.0;              // prior.py:320-331 (no zero point here)
+    const bool hot = mass > 1.25, gi = !hot && (logg < 3.5);                     // eep = 350 < 450
+    const double aa = hot ? -1.0 : -10.0, cc = hot ? 100.0 : (gi ? 7.0 : 10.0), nn = hot ? 1.0 : (gi ? 1.0 : 0.4);
+    lp += aa / (1.0 + nn * exp(-(vrot - cc)));
+  }
+  if (a.plx_dim >= 0) {                                                        // 'Parallax' = 1000 / Dist, prior.py:449-451
+    const double plx = 1000.0 / dist;
+    if (a.plx_has_gauss) { const double z = plx - a.plx_mu; lp += -0.5 * ((z * z) / (a.plx_sigma * a.plx_sigma)); }
+    if (a.plx_has_box && ((plx < a.plx_lo) || (plx > a.plx_hi))) lp = -INFINITY;
+  }
+  return lp;
+}
+__device__ __forceinline__ bool adv_any(const payne_adv_priors& a) { return a.imf || a.vrot || a.plx_dim >= 0; }
+
+// unit cube -> parameter (Payne/fitting/prior.py:151-178, scipy.stats ppf's restated)
+__device__ inline double prior_ppf(const payne_prior_dim& d, double u, const payne_adv_priors& adv) {
+  switch (d.kind) {
+    case PAYNE_PRIOR_TABLE: return d.p[0] * table_interp(adv, u);
+    case PAYNE_PRIOR_UNIFORM: {
+      const double lo = fmin(d.p[0], d.p[1]), hi = fmax(d.p[0], d.p[1]);
+      return (hi - lo) * u + lo;
+    }
+    case PAYNE_PRIOR_GAUSSIAN: return d.p[0] + d.p[1] * normcdfinv(u);
+    case PAYNE_PRIOR_TGAUSSIAN: {
+      const double a = (d.p[0] - d.p[2]) / d.p[3], b = (d.p[1] - d.p[2]) / d.p[3];
+      double x;
+      if (a > 0.0) {                    // both limits in the upper tail: work with survival functions
+        const double sa = normcdf(-a), sb = normcdf(-b);
+        x = -normcdfinv(sa - u * (sa - sb));
+      } else {
+        const double ca = normcdf(a), cb = normcdf(b);
+        x = normcdfinv(ca + u * (cb - ca));
+      }
+      double v = d.p[2] + d.p[3] * x;
+      if (!(v <= d.p[1])) v = (v != v) ? v : d.p[1];           // +inf (u = 1) -> hi, prior.py:165-166
+      return v;
+    }
+    case PAYNE_PRIOR_EXP: return d.p[0] - d.p[1] * log1p(-u);
+    case PAYNE_PRIOR_TEXP: {
+      const double b = (d.p[1] - d.p[0]) / d.p[2];
+      double v = d.p[0] - d.p[2] * log1p(u * expm1(-b));        // truncexpon.ppf
+      if (!(v <= d.p[1])) v = (v != v) ? v : d.p[1];
+      return v;
+    }
+    case PAYNE_PRIOR_LOGUNIFORM: return exp(log(d.p[0]) + u * (log(d.p[1]) - log(d.p[0])));
+    default: return u;
+  }
+}
+__device__ inline double prior_ln(const payne_prior_dim& d, double v) {
+  double lp = 0.0;
+  if (d.has_gauss) { const double z = v - d.g_mu; lp += -0.5 * ((z * z) / (d.g_sigma * d.g_sigma)); }
+  if (d.has_box && ((v < d.box_lo) || (v > d.box_hi))) lp = -INFINITY;
+  return lp;
+}
+// one theta row: NaN = absent, fixed values, then the sampled dimensions
+__device__ inline void write_theta_row(const SamplerDev& sd, const double* v, double* row) {
+  for (int c = 0; c < sd.ncols; ++c) row[c] = __builtin_nan("");
+  for (int i = 0; i < sd.nfixed; ++i) row[sd.fixed_col[i]] = sd.fixed_val[i];
+  for (int d = 0; d < sd.ndim; ++d) if (sd.dims[d].theta_col >= 0) row[sd.dims[d].theta_col] = v[d];
+}
+
+// counter-based generator: splitmix64 of (seed, chain, step, draw)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ double u01(unsigned long long seed, unsigned chain, unsigned step, unsigned draw) {
+  const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)chain << 32 | step)) + draw);
+  return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);      // (0,1)
+}
+
+__device__ __forceinline__ float u01f(unsigned long long seed, unsigned chain, unsigned step, unsigned draw) {
+  const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)chain << 32 | step)) + draw);
+  return ((float)(unsigned)(x >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0,1), 24 bits
+}
+
+
+// Everything one walk touches (device pointers) and its constants.
+struct WalkState {
+  double *u, *v, *lnprob;
+  int *nacc, *ncall;
+  double *u_prop, *v_prop, *lnprior_prop;
+  int* inside;
+  double* rows;
+  const double* axes;
+  const int* ell;
+  int* nredraw;
+  double scale, loglstar;
+  unsigned long long seed;
+  int K;
+};
+// device-resident copy for the post kernel's tail (payne_post_kernel<.., LEAN>: PostArgs::tail)
+struct WalkTail { SamplerDev sd; WalkState w; };
+
+// One random-walk step for every chain: first settle the previous proposal (accept iff inside the
+// cube and lnprob > loglstar), then draw the next one.  `propose` = 0 on the closing call.
+// ONE WAVE PER CHAIN, lane d = sampled dimension d: the inverse CDFs (the expensive part: normcdf /
+// normcdfinv chains in fp64) of the dimensions run side by side, the ellipsoid step is a shuffle
+// matvec, sums are wave reductions.  (One thread per chain spent 14 us per step in a ~3000-instruction
+// dependent fp64 chain; the step sits between two likelihood batches, nothing overlaps it.)
+constexpr int kRedrawPasses = 2;
+#ifndef PAYNE_AX_BATCH
+#define PAYNE_AX_BATCH 4
+#endif
+constexpr int kAxBatch = PAYNE_AX_BATCH;
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+// What a step reads from global memory before it can do anything: requested in one go -- first what hangs off the
+// sampler's tables, then what hangs off the walk's pointers (the step is a chain of dependent L2 / HBM round trips
+// otherwise, 0.3-1 us each: seven of them as first written).
+struct WalkLoads {
+  double uc, vc, u_p, v_p, lpr;
+  int was_in, my_ell, ncall0, nacc0, nredraw0;
+  int col_src; double col_val;                                  // this lane's theta column
+  int nd, ncols, adv_on;
+};
+__device__ __forceinline__ WalkLoads walk_loads(const SamplerDev& sd, const WalkState& W, int c, int lane) {
+  WalkLoads L;                                                  // (valid addresses whatever the flags say)
+  L.nd = sd.ndim; L.ncols = sd.ncols;
+  L.adv_on = adv_any(sd.adv) ? 1 : 0;
+  const int nd = L.nd;
+  const int dl = lane < nd ? lane : 0;
+  const int colc = lane < L.ncols ? lane : 0;
+  L.col_src = sd.col_src[colc]; L.col_val = sd.col_val[colc];
+  const size_t off = (size_t)c * nd + dl;
+  L.uc = W.u[off]; L.vc = W.v[off];
+  L.was_in = W.inside[c]; L.lpr = W.lnprior_prop[c];
+  L.u_p = W.u_prop[off]; L.v_p = W.v_prop[off];
+  L.ncall0 = W.ncall[c]; L.nacc0 = W.nacc[c];
+  L.nredraw0 = W.nredraw ? W.nredraw[c] : 0;
+  L.my_ell = W.ell ? W.ell[c] : 0;
+  return L;
+}
+// A wave-uniform record behind a pointer, as scalars: every lane loads it (one round trip for the whole record, where
+// field-by-field reads interleaved with stores make one each), the first lane's copy goes to SGPRs.
+template <class T>
+__device__ __forceinline__ T uniform_copy(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword-sized records");
+  constexpr int N = (int)(sizeof(T) / 4);
+  union U { T t; unsigned w[N]; __device__ U() {} } x;
+  const unsigned* q = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x.w[i] = q[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) x.w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)x.w[i]);
+  return x.t;
+}
+
+// The step of chain c on one wave (lane = dimension), its loads done.  lnl_p: the likelihood of the pending proposal.
+__device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const WalkState& W, const WalkLoads& L, int c, int lane,
+                                                double lnl_p, int step, int settle, int propose) {
+  double* const u = W.u; double* const v = W.v; double* const lnprob = W.lnprob;
+  int* const nacc = W.nacc; int* const ncall = W.ncall;
+  double* const u_prop = W.u_prop; double* const v_prop = W.v_prop; double* const lnprior_prop = W.lnprior_prop;
+  int* const inside = W.inside; double* const rows = W.rows;
+  const double* const axes = W.axes; int* const nredraw = W.nredraw;
+  const double scale = W.scale, loglstar = W.loglstar;
+  const unsigned long long seed = W.seed;
+  const int nd = L.nd;
+  const bool act = lane < nd;
+  const int dl = act ? lane : 0;
+  const size_t off = (size_t)c * nd + dl;
+  double uc = L.uc;
+  double vc = L.vc;
+  const int was_in = L.was_in;
+  const double lpr = L.lpr;
+  const double u_p = L.u_p, v_p = L.v_p;
+  const int my_ell = L.my_ell;
+  if (settle && was_in) {
+    const double lp = (lpr == -INFINITY) ? -INFINITY : lpr + lnl_p;
+    const bool accept = lp > loglstar;                          // false for NaN
+    if (accept && act) { uc = u_p; vc = v_p; u[off] = uc; v[off] = vc; }
+    if (lane == 0) {
+      ncall[c] = L.ncall0 + 1;
+      if (accept) { lnprob[c] = lp; nacc[c] = L.nacc0 + 1; }
+    }
+  }
+  if (!propose) return;
+  // z uniform in the unit ball: normal direction (one Box-Muller cosine per lane), radius U^(1/n).  A proposal that
+  // leaves the unit cube is redrawn at once, without a likelihood call, as dynesty's rwalk does (it counts such a
+  // draw as a rejection for the scale adaptation: `nredraw`).  The wave draws 64 / NP candidates SIDE BY SIDE (NP =
+  // dimensions rounded up to a power of two: lanes g NP .. g NP + NP - 1 hold candidate g) and takes the first one
+  // inside the cube: one pass costs what one draw costs, and the step is given up only after kRedrawPasses passes.
+  const double* ax = axes + (size_t)my_ell * nd * nd;                // this chain's ellipsoid (bound='multi')
+  int NP = 8;
+  while (NP < nd) NP <<= 1;
+  const int G = 64 / NP, g = lane / NP, dg = lane - g * NP;
+  const bool actg = dg < nd;
+  const int dgl = actg ? dg : 0;
+  const double ucg = __shfl(uc, dgl);                               // the chain's position, seen by every candidate group
+  double up = uc;
+  bool in = false;
+  int skipped = 0;
+  for (int pass = 0; pass < kRedrawPasses && !in; ++pass) {
+    const unsigned d0 = (unsigned)(pass * G + g) * 192u;
+    // the random direction and radius in fp32 (v_log_f32 / v_cos_f32 / v_exp_f32 / v_rsq_f32: a draw carries 24 random
+    // bits per coordinate anyway); the chain's position and the step added to it stay fp64
+    float z = 0.f;
+    if (actg) {
+      const float a = u01f(seed, c, step, d0 + 2 * dg), b = u01f(seed, c, step, d0 + 2 * dg + 1);
+      z = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a)) * __builtin_amdgcn_cosf(b);   // -2 ln a = -2 ln2 log2 a; cos(2 pi b)
+    }
+    float n2 = z * z;
+    for (int o = NP >> 1; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);   // sum over the candidate's own lanes
+    const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01f(seed, c, step, d0 + 128)) / (float)nd) * __builtin_amdgcn_rsqf(n2);
+    double sdot = 0.0;
+    // (kAxBatch coefficients requested at a time: a load -> wait -> fma loop pays one L2 round trip per dimension)
+    for (int e0 = 0; e0 < nd; e0 += kAxBatch) {
+      double ab[kAxBatch];
+#pragma unroll
+      for (int k = 0; k < kAxBatch; ++k) ab[k] = ax[dgl * nd + (e0 + k < nd ? e0 + k : nd - 1)];
+#pragma unroll
+      for (int k = 0; k < kAxBatch; ++k) {
+        const float ze = __shfl(z, g * NP + ((e0 + k) & (NP - 1)));
+        sdot = (e0 + k < nd) ? fma(ab[k], (double)ze, sdot) : sdot;
+      }
+    }
+    const double upg = ucg + (scale * (double)rad) * sdot;
+    const unsigned long long bad = __ballot(actg && !((upg > 0.0) && (upg < 1.0)));
+    int first = -1;
+    for (int q = G - 1; q >= 0; --q) {
+      const unsigned long long m = (NP == 64 ? ~0ull : ((1ull << NP) - 1ull)) << (q * NP);
+      if ((bad & m) == 0ull) first = q;
+    }
+    in = first >= 0;
+    skipped += in ? first : G;
+    up = __shfl(upg, (in ? first : 0) * NP + dl);                    // lanes d < nd take candidate `first`
+  }
+  if (nredraw && lane == 0) nredraw[c] = L.nredraw0 + skipped;
+  const payne_prior_dim dim = sd.dims[dl];                      // (an L2 hit; twenty registers the loop above could not spare)
+  const double vp = in ? prior_ppf(dim, up, sd.adv) : vc;       // outside: a harmless valid row
+  double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
+  if (L.adv_on) {                                       // priors on derived quantities: the values they need by shuffle
+    const payne_adv_priors& a = sd.adv;
+    const double g_ = __shfl(vp, a.dim_logg >= 0 ? a.dim_logg : 0), r_ = __shfl(vp, a.dim_logr >= 0 ? a.dim_logr : 0);
+    const double v_ = __shfl(vp, a.dim_vrot >= 0 ? a.dim_vrot : 0), d_ = __shfl(vp, a.plx_dim >= 0 ? a.plx_dim : 0);
+    const double add = adv_lnprior(a, a.dim_logg >= 0 ? g_ : a.val_logg, a.dim_logr >= 0 ? r_ : a.val_logr,
+                                   a.dim_vrot >= 0 ? v_ : a.val_vrot, a.plx_dim >= 0 ? d_ : 1.0);
+    lp = (lp == -INFINITY || add == -INFINITY) ? -INFINITY : lp + add;
+  }
+  if (act) { u_prop[off] = up; v_prop[off] = vp; }
+  if (lane == 0) { inside[c] = in ? 1 : 0; lnprior_prop[c] = lp; }
+  // theta row, lane = column: NaN = absent, fixed values, then the sampled dimensions
+  const double vs = __shfl(vp, L.col_src >= 0 ? L.col_src : 0);
+  const double val = L.col_src >= 0 ? vs : L.col_val;
+  if (lane < L.ncols) rows[(size_t)c * L.ncols + lane] = val;
+}
+__device__ __forceinline__ void rwalk_step_wave(const SamplerDev& sd, const WalkState& W, int c, int lane, double lnl_p, int step,
+                                                int settle, int propose) {
+  const WalkLoads L = walk_loads(sd, W, c, lane);
+  rwalk_step_core(sd, W, L, c, lane, lnl_p, step, settle, propose);
+}
+#endif

@@ -18,6 +18,7 @@ class GenMod(object):
         self.verbose = kwargs.get('verbose', False)
         self.device = kwargs.get('device', None)
         self.b_max = kwargs.get('b_max', 512)
+        self.variant = int(kwargs.get('variant', 0))      # payne_opts.variant (PAYNE_V_* bits; 0 = default kernels)
         self._spec_net = None
         self._phot = None
         self._obs = None
@@ -52,7 +53,8 @@ class GenMod(object):
     def new_engine(self):
         """Another context with the same networks and data (own workspaces: a second batch can be in flight)."""
         eng = PayneEngine(self._spec_net, obs=self._obs, phot=self._phot, obs_phot=self._obs_phot,
-                          npoly=self._npoly, photscale=self._photscale, b_max=self.b_max, device=self.device)
+                          npoly=self._npoly, photscale=self._photscale, b_max=self.b_max, device=self.device,
+                          variant=self.variant)
         if getattr(self, "_cont_net", None) is not None:
             eng.set_continuum(self._cont_net)
         return eng

@@ -16,7 +16,8 @@ class likelihood(object):
         self.fitargs = fitargs
         self.spec_bool, self.phot_bool, self.modpoly_bool, self.photscale_bool, self.carbon_bool = runbools[:5]
         self.fixedpars = self.fitargs['fixedpars']
-        self.GM = GenMod(device=kwargs.get('device', None), b_max=kwargs.get('b_max', 512))
+        self.GM = GenMod(device=kwargs.get('device', None), b_max=kwargs.get('b_max', 512),
+                         variant=kwargs.get('variant', 0))
         if self.spec_bool:
             self.GM._initspecnn(nnpath=fitargs['specANNpath'], NNtype=self.fitargs['NNtype'],
                                 carbon_bool=self.carbon_bool)

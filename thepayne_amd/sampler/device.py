@@ -269,6 +269,12 @@ class DeviceProposer(object):
         return (h[:K * nd].reshape(K, nd).copy(), h[K * nd:2 * K * nd].reshape(K, nd).copy(), h[2 * K * nd:n].copy(),
                 ih[:K].astype(np.int64), ih[K:2 * K].astype(np.int64))
 
+    def step_counters(self):
+        """(chain steps run at the likelihood-only post kernel's tail, chain steps launched on their own) so far."""
+        out = (C.c_longlong * 2)()
+        self.lib.payne_sampler_counters(self._handle, out)
+        return int(out[0]), int(out[1])
+
     def close(self):
         if self._handle.value:
             self.torch.cuda.synchronize(self.eng.device)

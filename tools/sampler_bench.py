@@ -28,7 +28,7 @@ ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', '
 
 
 def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
-        verbose=False, bound='multi'):
+        verbose=False, bound='multi', variant=0):
     """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
     bookkeeping included).  Returns {mode: {...}}."""
     cfg = synth.CONFIGS[config]
@@ -47,7 +47,7 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
     clean = L.GM.engine.predict_batch(L.theta_rows(truth), stage=3, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
     L.GM.engine.close()
     fitargs['obs_flux_fit'] = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
-    L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False)
+    L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False, variant=variant)
     P = prior(fitargs, synth.demo_priordict(), fitpars, rb)
     out = {}
     for mode in modes:
@@ -91,8 +91,9 @@ def main():
     ap.add_argument("--walks", type=int, default=25)
     ap.add_argument("--modes", default="host,device,device_chunks,device2_chunks")
     ap.add_argument("--bound", default="multi")
+    ap.add_argument("--variant", type=int, default=0, help="payne_opts.variant (PAYNE_V_* bits)")
     a = ap.parse_args()
-    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True, bound=a.bound)
+    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True, bound=a.bound, variant=a.variant)
     print(json.dumps({"sampler_bench": out, "config": a.config, "nlive": a.nlive, "walks": a.walks}))
 
 
