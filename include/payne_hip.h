@@ -116,6 +116,8 @@ typedef struct payne_opts {
                                   * transform loads (19 instead of 25 transfers of the spectrum; measured 3 % slower: kept as the record) */
 #define PAYNE_V_NO_WALK_TAIL 512u /* the sampler's chain step as a launch of its own between two likelihood batches (what
                                   * contexts without a likelihood-only post kernel use) instead of at the post kernel's tail */
+#define PAYNE_V_OUT_BK64 1024u   /* output layer: 64-deep stages (half as many barrier steps) when the padded width allows */
+#define PAYNE_V_OUT_ROLLED 2048u /* output layer: the loop over k-steps as other hidden widths than 300 run it (not unrolled) */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -28,7 +28,7 @@ def _net(raw, kind="YST1"):
 # every kernel variant that ships (payne_opts.variant, include/payne_hip.h): the defaults, and the code paths that
 # differently shaped nets / spectra take, forced onto the C2 problem
 VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
-            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8}
+            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))

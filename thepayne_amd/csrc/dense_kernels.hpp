@@ -213,9 +213,9 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 
 // ----------------------------------------------------------------------------
 // Output layer, LDS-DMA form: the same 64x64x32 tiling and MFMA schedule as payne_dense_kernel, but
-// the operand tiles go from global memory straight into a 3-stage LDS ring with
+// the operand tiles go from global memory straight into a 4-stage LDS ring with
 // global_load_lds_dwordx4 (no VGPR staging, no address-clamp/select VALU work, no LDS store
-// instructions), requested TWO k-steps ahead and waited for with explicit vmcnt counts.  The
+// instructions), requested THREE k-steps ahead and waited for with explicit vmcnt counts.  The
 // register-staged kernel cannot keep loads in flight across its barriers (measured: a k-step
 // that issues loads takes 2750 cycles, one that does not 1550).
 //   * A lane's 16 bytes land at (wave-uniform base) + 16*lane, so padding rows is impossible; bank
@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 //   * nothing can be masked on the way, so both operands must be zero-padded in k to a multiple
 //     of 32 in memory (X: the hidden buffers' pitch; W: ctx->w_out_pad) and rows are clamped.
 // ----------------------------------------------------------------------------
-constexpr int DM_NS = 3;                                   // ring stages
+// ring stages: four of 32 columns (three requested ahead) or three of 64 (two ahead) -- 96 / 144 KB at WN = 4
+template <int BK> constexpr int dm_ns() { return BK == 32 ? 4 : 3; }
 // WN = wave columns: tile = 64 x (32 WN), 2 WN waves.  WN = 2 is the 64 x 64 / 256-thread form (two workgroups
 // per CU); WN = 4 the 64 x 128 / 512-thread form (one per CU, same waves per SIMD): the activation tile is then
 // fetched once per 128 columns, 24 KB instead of 2 x 16 KB per k-step and CU -- the kernel is bound by the CU's
@@ -233,11 +234,15 @@ constexpr int DM_NS = 3;                                   // ring stages
 // BK = k-depth of a stage: 32 (rows of 128 B, 8 chunks, swizzle by (r >> 1) & 7) or 64 (rows of 256 B = one full
 // bank cycle, 16 chunks, swizzle by r & 15): half as many barrier steps for the same bytes.
 template <int WN, int BK> constexpr int dm_stage_floats() { return (64 + 32 * WN) * BK; }
-template <int WN, int BK> constexpr size_t dm_lds_bytes() { return (size_t)DM_NS * dm_stage_floats<WN, BK>() * sizeof(float); }
+template <int WN, int BK> constexpr size_t dm_lds_bytes() { return (size_t)dm_ns<BK>() * dm_stage_floats<WN, BK>() * sizeof(float); }
 
-template <int WN, int BK>
+// NK: the number of k-steps when known at compile time (10 = the 300-wide hidden layer of the usual nets at BK = 32), 0 =
+// read from the launch.  With NK the loop below unrolls and the bookkeeping of the ring folds away: 15.6 us against
+// 17.0 us for the rolled form of the same statements (C2).
+template <int WN, int BK, int NK>
 __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p) {
   constexpr int BN = 32 * WN, NW = 2 * WN;                 // tile columns, waves
+  constexpr int DM_NS = dm_ns<BK>(), AHEAD = DM_NS - 1;    // ring stages; stages requested beyond the one being consumed
   constexpr int STAGE = dm_stage_floats<WN, BK>();
   constexpr int CH = BK / 4, RP = 256 / BK;                // 16-byte chunks per row, rows per 1-KiB piece
   constexpr int NBLK = (64 + BN) / RP, NA = 64 / RP;       // pieces per stage, of which A
@@ -285,46 +290,116 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), half = lane >> 5;
   const int sa = swz(Ra), sb = swz(Rb);
 
-  const int nk = p.K / BK;                                 // padded: exact
+  const int nk = NK > 0 ? NK : p.K / BK;                   // padded: exact
   const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * BK;
   const int kk_last = __builtin_amdgcn_readfirstlane(k_tail >= BK ? BK / 8 : (k_tail <= 0 ? 1 : (k_tail + 7) / 8));
   HK_STAMP(0);
-  issue(0, 0);
-  if (nk > 1) issue(1, BK);
-  for (int it = 0; it < nk; ++it) {
-    // my pieces of stage `it` have landed once at most the PER younger loads (stage it+1) are outstanding
-    if (it + 1 < nk) {
+  // Three stages are requested ahead; the fragments of step it+1 are read from LDS BEFORE the matrix instructions of
+  // step it are issued, so the LDS round trip of a step (8 ds_read_b128 per wave, ~300 cycles during which neither wave of
+  // a SIMD had anything for the matrix pipe: both had just left the same barrier) runs under the 1024 cycles of the
+  // previous step's v_mfma chain.
+  auto wait_landed = [&](int younger) {                    // my pieces of a stage have landed once only `younger` stages' loads are outstanding
+    static_assert(PER == 3 || PER == 4 || PER == 6 || PER == 8, "vmcnt literal");
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) {
       if (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_assert(PER == 3 || PER == 4 || PER == 6 || PER == 8, "vmcnt literal");
-    asm volatile("s_barrier" ::: "memory");                // everybody's pieces landed; everybody finished step it-1
-    if (it < 13) HK_STAMP(1 + it);
-    if (it + 2 < nk) issue((it + 2) % DM_NS, (it + 2) * BK);    // into the buffer step it-1 just released
-    const float* Asb = dm_sm + (it % DM_NS) * STAGE;
+    } else {
+      if (PER == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (PER == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+  };
+  auto frags = [&](int stage, f32x4_t (&a)[BK / 8], f32x4_t (&b)[BK / 8]) {
+    const float* Asb = dm_sm + stage * STAGE;
     const float* Bsb = Asb + 64 * BK;
-    f32x4_t a[BK / 8], b[BK / 8];                           // all fragments first (one LDS round trip per step)
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       const int c = 2 * kk + half;
       a[kk] = *reinterpret_cast<const f32x4_t*>(Asb + Ra * BK + 4 * (c ^ sa));
       b[kk] = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * BK + 4 * (c ^ sb));
     }
+  };
+  const int npro = nk < AHEAD ? nk : AHEAD;
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q)
+    if (q < npro) issue(q, q * BK);
+  wait_landed(npro - 1);
+  asm volatile("s_barrier" ::: "memory");
+  f32x4_t a0[BK / 8], b0[BK / 8], a1[BK / 8], b1[BK / 8];
+  frags(0, a0, b0);
+  // the head of step it (it + 1 < nk): stage it+1 has landed for everybody, the next stage is requested, the fragments
+  // of step it+1 are on their way from LDS
+  auto head = [&](int it, f32x4_t (&an)[BK / 8], f32x4_t (&bn)[BK / 8], const f32x4_t (&ac)[BK / 8], const f32x4_t (&bc)[BK / 8]) {
+    // (the fragments of THIS step were requested a whole step ago: naming them here puts the compiler's LDS wait for
+    //  them -- which it can only express as "everything outstanding" around the loop's back edge -- ahead of the next
+    //  request instead of between that request and the matrix instructions)
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) asm volatile("" :: "v"(ac[kk]), "v"(bc[kk]));
+    {                                                       // requested so far: stages .. min(nk, it + AHEAD) - 1; stage it+1 must have landed
+      const int last = (it + AHEAD < nk ? it + AHEAD : nk) - 1;
+      wait_landed(last - (it + 1));
+    }
+    asm volatile("s_barrier" ::: "memory");                // everybody's pieces of stage it+1 landed; everybody finished step it-1
+#ifndef PAYNE_NO_LOOP_STAMPS
+    if (it < 13) HK_STAMP(1 + it);                       // (diagnostic build; the loop is then fully unrolled)
+#endif
+    // ORDER MATTERS: a ds_read issued after a global_load_lds of the same wave does not issue until that transfer has
+    // landed (the hardware keeps LDS-DMA writes and DS operations of a wave in order), and the matrix instructions queue
+    // up behind it: with the request first a step cost one memory latency more (3 340 cycles against 2 380; stamps of
+    // the diagnostic build, tools/post_stamps.py).  So: fragments of the next step, THEN the request.
+    frags((it + 1) % DM_NS, an, bn);
     __builtin_amdgcn_sched_barrier(0);
-    // the zero-padded tail of the last step (K = 300 -> 320: 20 of its 32 columns) contributes exact zeros: skip
-    // those matrix instructions (groups of 8 columns; a uniform branch)
-    const int nkk = (it + 1 == nk) ? kk_last : BK / 8;
+#if !(defined(PAYNE_EXP_GEMM) && (PAYNE_EXP_GEMM & 2))
+    if (it + AHEAD < nk) issue((it + AHEAD) % DM_NS, (it + AHEAD) * BK);     // into the buffer whose fragments step it-1 consumed
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_step = [&](const f32x4_t (&a)[BK / 8], const f32x4_t (&b)[BK / 8]) {
+#if defined(PAYNE_EXP_GEMM) && (PAYNE_EXP_GEMM & 1)
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) asm volatile("" :: "v"(a[kk]), "v"(b[kk]));
+    return;
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      if (kk < nkk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].w, b[kk].w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the zero-padded tail of the last step (K = 300 -> 320: 20 of its 32 columns) contributes exact zeros: skip those
+  // matrix instructions (groups of 8 columns; a uniform branch)
+  auto mfma_last = [&](const f32x4_t (&a)[BK / 8], const f32x4_t (&b)[BK / 8]) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      if (kk < kk_last) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].w, b[kk].w, acc, 0, 0, 0);
       }
     }
+  };
+  int it = 0;
+#pragma unroll
+  for (; it + 2 < nk; it += 2) {                           // two steps per trip: the fragment registers swap roles
+    head(it, a1, b1, a0, b0);
+    mfma_step(a0, b0);
+    head(it + 1, a0, b0, a1, b1);
+    mfma_step(a1, b1);
+  }
+  if (it + 1 < nk) {
+    head(it, a1, b1, a0, b0);
+    mfma_step(a0, b0);
+    mfma_last(a1, b1);
+  } else {
+    mfma_last(a0, b0);
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col = n0 + wn0 + (lane & 31);
@@ -573,7 +648,10 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 #endif
 PAYNE_DENSE_T __global__ void payne_dense_kernel<64, 64, 32, true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_kernel<64, 64, 32, false>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 0>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 10>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 0>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 5>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(DenseParams, const PrepArgs);

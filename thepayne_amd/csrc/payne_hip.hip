@@ -533,23 +533,31 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
   PAYNE_LAUNCH((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
-// Output layer, LDS-DMA form (64 x 128 tiles, 512 threads, 32-deep stages).
+// Output layer, LDS-DMA form (64 x 128 tiles, 512 threads, BK-deep stages; NK: k-steps fixed at compile time or 0).
+template <int BK, int NK>
+static void launch_out_dma_nk(DenseParams& p, hipStream_t s) {
+  constexpr int WN = 4;
+  constexpr size_t lds = dm_lds_bytes<WN, BK>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK, NK>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
+}
+template <int BK>
 static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
-  constexpr int WN = 4, BK = 32;
+  constexpr int WN = 4;
   p.k_real = p.K;                                          // the layer's own width: the padded tail is skipped
   p.W = c->w_out_pad; p.K = c->w_out_kp;                   // padded pitch; X's pitch (ld_hid) is a multiple of 32 too
   p.grid_m = (p.B + 63) / 64;
   p.grid_n = (p.N + 32 * WN - 1) / (32 * WN);
-  constexpr size_t lds = dm_lds_bytes<WN, BK>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
 #ifdef PAYNE_STAMPS
   p.stamps = g_dense_stamps;
 #endif
-  PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
+  constexpr int NKC = 320 / BK;                            // H = 300 -> 320 columns
+  if (p.K == NKC * BK && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) launch_out_dma_nk<BK, NKC>(p, s);
+  else launch_out_dma_nk<BK, 0>(p, s);
 }
 
 template <bool FUSE>
@@ -606,7 +614,10 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last) launch_hidden<false>(p, pa, s);
-      else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) launch_out_dma(c, p, s);
+      else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) {
+        if ((c->w_out_kp % 64) == 0 && (c->opts.variant & PAYNE_V_OUT_BK64)) launch_out_dma<64>(c, p, s);
+        else launch_out_dma<32>(c, p, s);
+      }
       else launch_dense<64, 64, 32, false>(p, s);            // nets whose hidden widths differ, the continuum network
     }
   }

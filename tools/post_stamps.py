@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 
 from thepayne_amd import build, _lib  # noqa: E402
 
-path = build.build_diag()
+# STAMP_LIB: a stamped twin built by hand (build.build_variant(tag, ['-DPAYNE_STAMPS', ...])) instead of the diagnostic build
+path = os.environ.get("STAMP_LIB") or build.build_diag()
 os.environ["PAYNE_HIP_LIB"] = path
 from thepayne_amd import synth, nnio  # noqa: E402
 from thepayne_amd.engine import PayneEngine  # noqa: E402
