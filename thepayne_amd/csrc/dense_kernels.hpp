@@ -225,8 +225,9 @@ __global__ void __launch_bounds__(256) payne_dense_kernel(DenseParams p) {
 //   * nothing can be masked on the way, so both operands must be zero-padded in k to a multiple
 //     of 32 in memory (X: the hidden buffers' pitch; W: ctx->w_out_pad) and rows are clamped.
 // ----------------------------------------------------------------------------
-// ring stages: four of 32 columns (three requested ahead) or three of 64 (two ahead) -- 96 / 144 KB at WN = 4
-template <int BK> constexpr int dm_ns() { return BK == 32 ? 4 : 3; }
+// ring stages NS (NS - 1 requested ahead): at WN = 4 four of 32 columns = 96 KB -- one workgroup per CU, for launches of at
+// most one tile per CU (C2: 256 tiles) -- or three = 72 KB, two workgroups per CU, which cover each other's first loads and
+// last stores when a CU works through many tiles (C5: 16 384); three of 64 columns = 144 KB.
 // WN = wave columns: tile = 64 x (32 WN), 2 WN waves.  WN = 2 is the 64 x 64 / 256-thread form (two workgroups
 // per CU); WN = 4 the 64 x 128 / 512-thread form (one per CU, same waves per SIMD): the activation tile is then
 // fetched once per 128 columns, 24 KB instead of 2 x 16 KB per k-step and CU -- the kernel is bound by the CU's
@@ -234,15 +235,19 @@ template <int BK> constexpr int dm_ns() { return BK == 32 ? 4 : 3; }
 // BK = k-depth of a stage: 32 (rows of 128 B, 8 chunks, swizzle by (r >> 1) & 7) or 64 (rows of 256 B = one full
 // bank cycle, 16 chunks, swizzle by r & 15): half as many barrier steps for the same bytes.
 template <int WN, int BK> constexpr int dm_stage_floats() { return (64 + 32 * WN) * BK; }
-template <int WN, int BK> constexpr size_t dm_lds_bytes() { return (size_t)dm_ns<BK>() * dm_stage_floats<WN, BK>() * sizeof(float); }
+template <int WN, int BK, int NS> constexpr size_t dm_lds_bytes() { return (size_t)NS * dm_stage_floats<WN, BK>() * sizeof(float); }
 
 // NK: the number of k-steps when known at compile time (10 = the 300-wide hidden layer of the usual nets at BK = 32), 0 =
 // read from the launch.  With NK the loop below unrolls and the bookkeeping of the ring folds away: 15.6 us against
 // 17.0 us for the rolled form of the same statements (C2).
-template <int WN, int BK, int NK>
+// PIPE: the schedule above (one tile per CU).  !PIPE: request, then the fragments of the SAME step, a rolled loop, three
+// stages -- what a CU that works through many tiles with two resident workgroups runs fastest (C5: 792 us against 866 us;
+// the other workgroup's matrix instructions fill the wait, and the leaner loop leaves it more issue slots).
+template <int WN, int BK, int NK, int NS, bool PIPE>
 __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p) {
   constexpr int BN = 32 * WN, NW = 2 * WN;                 // tile columns, waves
-  constexpr int DM_NS = dm_ns<BK>(), AHEAD = DM_NS - 1;    // ring stages; stages requested beyond the one being consumed
+  constexpr int DM_NS = NS, AHEAD = DM_NS - 1;             // ring stages; stages requested beyond the one being consumed
+  static_assert(NS == 3 || NS == 4, "ring depth");
   constexpr int STAGE = dm_stage_floats<WN, BK>();
   constexpr int CH = BK / 4, RP = 256 / BK;                // 16-byte chunks per row, rows per 1-KiB piece
   constexpr int NBLK = (64 + BN) / RP, NA = 64 / RP;       // pieces per stage, of which A
@@ -323,6 +328,30 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
       b[kk] = *reinterpret_cast<const f32x4_t*>(Bsb + Rb * BK + 4 * (c ^ sb));
     }
   };
+  if constexpr (!PIPE) {
+    static_assert(PIPE || (NS == 3 && NK == 0), "the plain schedule: three stages, run-time step count");
+    issue(0, 0);
+    if (nk > 1) issue(1, BK);
+    for (int it = 0; it < nk; ++it) {
+      wait_landed(it + 1 < nk ? 1 : 0);                    // my pieces of stage `it` have landed once only stage it+1's loads are outstanding
+      asm volatile("s_barrier" ::: "memory");              // everybody's pieces landed; everybody finished step it-1
+      if (it < 13) HK_STAMP(1 + it);
+      if (it + 2 < nk) issue((it + 2) % DM_NS, (it + 2) * BK);    // into the buffer step it-1 just released
+      f32x4_t a[BK / 8], b[BK / 8];                         // all fragments first (one LDS round trip per step)
+      frags(it % DM_NS, a, b);
+      __builtin_amdgcn_sched_barrier(0);
+      const int nkk = (it + 1 == nk) ? kk_last : BK / 8;   // (the zero-padded tail of the last step is skipped)
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        if (kk < nkk) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].y, b[kk].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].z, b[kk].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].w, b[kk].w, acc, 0, 0, 0);
+        }
+      }
+    }
+  } else {
   const int npro = nk < AHEAD ? nk : AHEAD;
 #pragma unroll
   for (int q = 0; q < AHEAD; ++q)
@@ -400,6 +429,7 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
     mfma_last(a1, b1);
   } else {
     mfma_last(a0, b0);
+  }
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col = n0 + wn0 + (lane & 31);
@@ -648,10 +678,11 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 #endif
 PAYNE_DENSE_T __global__ void payne_dense_kernel<64, 64, 32, true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_kernel<64, 64, 32, false>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 0>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 10>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 0>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 5>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 0, 4, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 10, 4, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 0, 3, false>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 0, 3, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 5, 3, true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(DenseParams, const PrepArgs);

@@ -72,6 +72,7 @@ struct payne_ctx {
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
+  int n_cu = 256;                       // compute units of the device (MI355X: 256)
   bool lean_available = false;          // a likelihood-only instantiation exists for this spectrum length (it can carry a walk's tail)
   PostTables* d_T = nullptr;          // device copy of T
   post_kernel_fn post_fn = nullptr;
@@ -262,6 +263,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
   if (he != hipSuccess) return fail(nullptr, PAYNE_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
   payne_ctx* c = new payne_ctx();
   c->device = device;
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
   c->opts = *opts;
   c->ncols = 8 + opts->npoly + 4;
   int rc = PAYNE_OK;
@@ -533,17 +535,18 @@ static void launch_dense(DenseParams& p, hipStream_t s) {
   PAYNE_LAUNCH((payne_dense_kernel<BM, BN, BK, FUSE>), dim3(p.grid_m * p.grid_n), dim3(256), lds, s, p);
 }
 
-// Output layer, LDS-DMA form (64 x 128 tiles, 512 threads, BK-deep stages; NK: k-steps fixed at compile time or 0).
-template <int BK, int NK>
+// Output layer, LDS-DMA form (64 x 128 tiles, 512 threads, BK-deep stages; NK: k-steps fixed at compile time or 0; NS: ring;
+// PIPE: schedule -- see the kernel).
+template <int BK, int NK, int NS, bool PIPE>
 static void launch_out_dma_nk(DenseParams& p, hipStream_t s) {
   constexpr int WN = 4;
-  constexpr size_t lds = dm_lds_bytes<WN, BK>();
+  constexpr size_t lds = dm_lds_bytes<WN, BK, NS>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK, NK, NS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK, NK>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
+  PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK, NK, NS, PIPE>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
 }
 template <int BK>
 static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
@@ -556,8 +559,14 @@ static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
   p.stamps = g_dense_stamps;
 #endif
   constexpr int NKC = 320 / BK;                            // H = 300 -> 320 columns
-  if (p.K == NKC * BK && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) launch_out_dma_nk<BK, NKC>(p, s);
-  else launch_out_dma_nk<BK, 0>(p, s);
+  const bool fixed = p.K == NKC * BK && !(c->opts.variant & PAYNE_V_OUT_ROLLED);
+  if constexpr (BK == 64) {                                // (variant: three 64-deep stages)
+    if (fixed) launch_out_dma_nk<64, NKC, 3, true>(p, s); else launch_out_dma_nk<64, 0, 3, true>(p, s);
+  } else if (p.grid_m * p.grid_n <= c->n_cu) {             // one tile per CU at most: the pipelined schedule, four stages
+    if (fixed) launch_out_dma_nk<32, NKC, 4, true>(p, s); else launch_out_dma_nk<32, 0, 4, true>(p, s);
+  } else {
+    launch_out_dma_nk<32, 0, 3, false>(p, s);              // many tiles per CU: two workgroups per CU, the plain schedule
+  }
 }
 
 template <bool FUSE>
