@@ -881,17 +881,23 @@ PAYNE_HD int count_search(const PostTables& T, double op, double lim, int guess)
   return lo;
 }
 PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr_factor, CandState& S) {
-  const double rv = th[4];
+  // the whole row is requested before anything is computed (clamped column for the coefficients past npoly: a guarded
+  // load is a branch and a wait of its own, fifteen round trips in a row as first written -- and the two workgroups that
+  // run this are the last of the hidden-layer launch to finish)
+  const double rv = th[4], vrot = th[5], r_in = th[7];
+  double pc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pc[i] = th[i < T.npoly ? 8 + i : 7];     // (column 7 exists in every row)
   S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;       // ystpred.py:228-232
   S.dop = log(S.one_plus);
-  const double vrot = th[5];
   S.do_rot = (vrot != 0.0);                                         // ystpred.py:214 (NaN passes)
   S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);                     // smoothing.py:297,614
-  const double Rs = th[7] * instr_factor;                           // genmod.py:82-85
+  const double Rs = r_in * instr_factor;                            // genmod.py:82-85
   S.do_smooth = (Rs > 0.0);                                         // ystpred.py:238-240 (false for NaN)
   S.g_a = 0.0; S.wl = 0.0; S.wh = 0.0;
   S.win_ready = 0; S.win_below = 0; S.win_notabove = 0; S.w_ready = 0;
-  for (int i = 0; i < 12; ++i) S.poly[i] = (i < T.npoly) ? th[8 + i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) S.poly[i] = (i < T.npoly) ? pc[i] : 0.0;
   Window W{};
   if (Rs > 0.0 && T.nobs > 0) {
     const double sig_out = kCkms / Rs, inres = kCkms / T.r_ann;     // smoothing.py:107,113
