@@ -252,6 +252,7 @@ extern "C" void payne_ctx_destroy(payne_ctx* c) {
   delete c;
 }
 
+static hipError_t set_dense_attributes();
 extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_desc* obs, const payne_phot_desc* phot,
                                 const payne_opts* opts, int device, payne_ctx** out) {
   if (!out) return fail(nullptr, PAYNE_E_INVALID, "out is NULL");
@@ -268,6 +269,8 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
   c->ncols = 8 + opts->npoly + 4;
   int rc = PAYNE_OK;
   auto bail = [&](int code) { g_create_error = c->err; payne_ctx_destroy(c); return code; };
+  he = set_dense_attributes();
+  if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute(dense): ") + hipGetErrorString(he)));
 
   if (model) {
     if (model->n_layers < 2 || model->n_layers > PAYNE_MAX_LAYERS) return bail(fail(c, PAYNE_E_INVALID, "model.n_layers must be 2..8"));
@@ -519,16 +522,32 @@ extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) {
 }
 
 // ---- launches --------------------------------------------------------------
+// Dynamic-LDS limits of the dense kernels, set on the context's device when the context is created (the attribute belongs
+// to the function ON A DEVICE: a flag shared by every context would leave a second device of the same process without it).
+static hipError_t set_dense_attributes() {
+  hipError_t e = hipSuccess;
+  auto set = [&](const void* f, size_t lds) {
+    const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = r;
+  };
+  set(reinterpret_cast<const void*>(payne_dense_kernel<64, 64, 32, true>), dense_lds_bytes<64, 64, 32>());
+  set(reinterpret_cast<const void*>(payne_dense_kernel<64, 64, 32, false>), dense_lds_bytes<64, 64, 32>());
+  set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 32, 0, 4, true>), dm_lds_bytes<4, 32, 4>());
+  set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 32, 10, 4, true>), dm_lds_bytes<4, 32, 4>());
+  set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 32, 0, 3, false>), dm_lds_bytes<4, 32, 3>());
+  set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 64, 0, 3, true>), dm_lds_bytes<4, 64, 3>());
+  set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 64, 5, 3, true>), dm_lds_bytes<4, 64, 3>());
+  set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
+  set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
+  set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
+  return e;
+}
+
 template <int BM, int BN, int BK, bool FUSE>
 static void launch_dense(DenseParams& p, hipStream_t s) {
   p.grid_m = (p.B + BM - 1) / BM;
   p.grid_n = (p.N + BN - 1) / BN;
   constexpr size_t lds = dense_lds_bytes<BM, BN, BK>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_kernel<BM, BN, BK, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
 #ifdef PAYNE_STAMPS
   p.stamps = FUSE ? nullptr : g_dense_stamps;
 #endif
@@ -541,11 +560,6 @@ template <int BK, int NK, int NS, bool PIPE>
 static void launch_out_dma_nk(DenseParams& p, hipStream_t s) {
   constexpr int WN = 4;
   constexpr size_t lds = dm_lds_bytes<WN, BK, NS>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_dma_kernel<WN, BK, NK, NS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   PAYNE_LAUNCH((payne_dense_dma_kernel<WN, BK, NK, NS, PIPE>), dim3(p.grid_m * p.grid_n), dim3(128 * WN), lds, s, p);
 }
 template <int BK>
@@ -573,13 +587,6 @@ template <bool FUSE>
 static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   p.grid_m = (p.B + 31) / 32;
   p.grid_n = (p.N + 31) / 32;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
-    attr_set = true;
-  }
   pa.n_gemm = p.grid_m * p.grid_n;
   if (!FUSE) pa.out = nullptr;
 #ifdef PAYNE_STAMPS
