@@ -183,7 +183,7 @@ def pmc_bytes(path, key):
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
-KERNEL_KEYS = {"dense_out": "payne_dense_dma_kernel", "post": "payne_post", "dense_hidden": "payne_dense_hidden_kernel"}
+KERNEL_KEYS = {"dense_out": "payne_dense_dma", "post": "payne_post", "dense_hidden": "payne_dense_hidden_kernel"}
 
 
 # ----------------------------------------------------------------------------
@@ -321,6 +321,11 @@ def main():
                                "candidate vectors per step (dynesty live points)" % (args.config, N, H, cfg["nobs"], B),
                    "batch": B, "npix": N, "nobs": cfg["nobs"], "stars": world,
                    "batches_in_flight": S, "kernel_variant": args.variant,
+                   "arithmetic": "fp32 storage and accumulation throughout (wavelengths, tapers, chi^2 sums fp64); the output "
+                                 "layer's products: " + ("v_mfma_f32_32x32x2_f32" if args.variant & 4096 else
+                                 "operands split exactly in three bf16 parts, six exact partial products, fp32 accumulator "
+                                 "(as accurate as the fp32 fma chain against an fp64 product: tests/test_gpu_parity.py; "
+                                 "--variant 4096 = the fp32 matrix instruction)"),
                    "parallelism": "1 star per GPU, no data-path collective"},
         **({"invalid": "--unchecked: a timing experiment, not a benchmark result"} if args.unchecked else {}),
         "rccl_world": dist.get_world_size() if world > 1 else 1,

@@ -28,7 +28,7 @@ def _net(raw, kind="YST1"):
 # every kernel variant that ships (payne_opts.variant, include/payne_hip.h): the defaults, and the code paths that
 # differently shaped nets / spectra take, forced onto the C2 problem
 VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
-            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048}
+            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -47,6 +47,39 @@ def test_lnlike_c2_against_reference_golden(Engine, golden, variant):
     big = np.tile(theta_full(g["theta"]), (2, 1))[:700]
     lnl3 = eng.lnlike_batch(big).cpu().numpy()
     assert np.array_equal(lnl3[:512], lnl) and np.array_equal(lnl3[512:], lnl[:188])
+
+
+def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engine):
+    """The default output layer multiplies operands split in three bf16 parts (six exact partial products, fp32
+    accumulation); PAYNE_V_OUT_F32 is the fp32 matrix instruction.  Both against the SAME network evaluated in fp64:
+    the split form must not be less accurate than the fp32 fma chain, and both sit far inside the flux tolerance."""
+    from thepayne_amd import _lib
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    net = _net(raw)
+    rng = np.random.default_rng(8)
+    B = 512
+    lab = net["xmin"][:4] + rng.uniform(0.02, 0.98, size=(B, 4)) * (net["xmax"][:4] - net["xmin"][:4])
+    th7 = np.column_stack([lab, np.zeros(B), np.zeros(B), np.full(B, 20000.0)])
+    th = theta_full(th7)
+    # fp64 forward with the fp32 weights (ystpred.py:41-58): encode, two leaky-ReLU layers, linear output
+    x = (lab - net["xmin"][:4]) / (net["xmax"][:4] - net["xmin"][:4]) - 0.5
+    h = x.astype(np.float32).astype(np.float64)             # (the kernel encodes in fp64 and rounds to fp32)
+    for W, b, act in net["layers"]:
+        h = h @ W.astype(np.float64).T + b.astype(np.float64)
+        if act == _lib.ACT_LRELU:
+            h = np.maximum(h, 0.01 * h)
+    errs = {}
+    for name, variant in (("split", 0), ("f32", _lib.V_OUT_F32)):
+        eng = Engine(net, obs=None, b_max=B, variant=variant)
+        got = eng.predict_batch(th, stage=0).cpu().numpy().astype(np.float64)
+        errs[name] = np.abs(got - h)
+        eng.close()
+    # the hidden layers are the same fp32 kernels in both runs: their rounding is common to both errors
+    assert errs["f32"].max() <= FLUX_TOL and errs["split"].max() <= FLUX_TOL, (errs["f32"].max(), errs["split"].max())
+    rms = {k: float(np.sqrt(np.mean(v ** 2))) for k, v in errs.items()}
+    assert rms["split"] <= 1.25 * rms["f32"] + 1e-9, rms
+    assert errs["split"].max() <= 1.5 * errs["f32"].max() + 1e-8, (errs["split"].max(), errs["f32"].max())
 
 
 def test_predict_stages_against_reference_golden(Engine, golden):

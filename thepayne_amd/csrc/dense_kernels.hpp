@@ -24,6 +24,10 @@ struct DenseParams {
   const double* theta; int ld_theta;
   const float* W0; const float* b0; int n_labels; int act0;
   int K0;                      // real width of the first layer (W0 has K0 rows)
+  // 3 x bf16 planes (payne_dense_dma3_kernel): the hidden-layer kernel ALSO writes its output split in three (Yp, row pitch
+  // ldp elements, planes plane_y elements apart); the output layer reads activations Xp and weights Wp [3][N][K] that way
+  unsigned short* Yp; const unsigned short* Xp; const unsigned short* Wp;
+  int ldp; size_t plane_y, plane_x, plane_w;
   double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
@@ -445,6 +449,198 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
 }
 
 // ----------------------------------------------------------------------------
+// Output layer as SIX bf16 matrix products on the same LDS-DMA ring (one tile per CU: C2).
+// Every fp32 operand is the EXACT sum of three bf16 parts (8 + 8 + 8 significant bits: x = x1 + x2 + x3, each part the
+// bf16 rounding of what the previous ones left), so a product a b is the sum of nine exact 16-bit products, of which the
+// three smallest (a2 b3, a3 b2, a3 b3 < 2^-23 |a b| together) are dropped:
+//   a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// accumulated in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, smallest terms first -- the error of a dot product is
+// that of an fp32 fma chain (tests/test_gpu_parity.py compares both forms with an fp64 product).  The matrix pipe retires
+// 16 k of a bf16 product in the time it retires 0.5 k of an fp32 one, so the six products cost 384 cycles per wave and
+// 32-deep step against 1024: the k-step, which the fp32 form leaves at 2 380 cycles (2 048 of them matrix instructions), drops
+// to ~1 100.  Weights are split at context creation, the activations by the hidden-layer kernel's epilogue.
+// Stage: 3 planes x (64 A rows + 128 B rows) x 64 B = 36 KB, four stages; a 1-KiB DMA piece = 16 rows of one plane (36 pieces:
+// waves 0-3 move five, waves 4-7 four); 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3): the sixteen lanes of a
+// fragment read cover sixteen different bank groups.
+// ----------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 b1 = (__bf16)x;
+  const float r1 = x - (float)b1;                          // exact
+  const __bf16 b2 = (__bf16)r1;
+  const float r2 = r1 - (float)b2;                         // exact
+  const __bf16 b3 = (__bf16)r2;
+  h = bf16_bits(b1); m = bf16_bits(b2); l = bf16_bits(b3);
+}
+// [rows][pitch] fp32 -> three bf16 planes of the same shape (context creation: the output layer's padded weights)
+__global__ void payne_split3_kernel(const float* __restrict__ src, size_t n, unsigned short* __restrict__ dst, size_t plane);
+#ifdef PAYNE_TU_DENSE
+__global__ void __launch_bounds__(256) payne_split3_kernel(const float* __restrict__ src, size_t n, unsigned short* __restrict__ dst, size_t plane) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned short h, m, l;
+  split3(src[i], h, m, l);
+  dst[i] = h; dst[plane + i] = m; dst[2 * plane + i] = l;
+}
+#endif
+
+constexpr int D3_STAGE = 3 * (64 + 128) * 64;              // bytes per stage
+// NS = 4, PIPE: one tile per CU (C2).  NS = 2, !PIPE: many tiles per CU (C5) -- two stages = 72 KB, two workgroups per CU, and per
+// step: wait, barrier, this step's fragments, the request for the next stage, the products (the other workgroup's products fill
+// the LDS round trip; the loop is bound by the 36 KB a step brings in either way).
+template <int NS> constexpr size_t d3_lds_bytes() { return (size_t)NS * D3_STAGE; }
+template <int NK, int NS, bool PIPE>
+__global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
+  constexpr int D3_NS = NS, AHEAD = PIPE ? D3_NS - 1 : 1;
+  static_assert((PIPE && NS >= 3) || (!PIPE && NS == 2 && NK == 0), "ring depth / schedule");
+  extern __shared__ __attribute__((aligned(16))) unsigned char d3_sm[];
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
+  const bool five = wave < 4;                              // pieces this wave moves per stage: 5 (waves 0-3) or 4
+  const unsigned char* src[5];
+  int dst[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int q = five ? wave * 5 + j : 20 + (wave - 4) * 4 + j;
+    if (q > 35) q = 35;                                    // (slot 4 of the four-piece waves: never issued)
+    const bool isA = q < 12;
+    const int pl = isA ? q >> 2 : (q - 12) >> 3, blk = isA ? (q & 3) : ((q - 12) & 7);
+    const int row = 16 * blk + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);           // which 16-byte chunk of the row belongs in this lane's slot
+    if (isA) {
+      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)pl * p.plane_x + (size_t)r * p.ldp) + 16 * c;
+      dst[j] = pl * 4096 + blk * 1024;
+    } else {
+      const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(p.Wp + (size_t)pl * p.plane_w + (size_t)r * p.K) + 16 * c;
+      dst[j] = 3 * 4096 + pl * 8192 + blk * 1024;
+    }
+  }
+  auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < 4 || five)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
+                                         (__attribute__((address_space(3))) void*)(d3_sm + stage * D3_STAGE + dst[j]), 16, 0, 0);
+  };
+  auto wait_landed = [&](int younger) {                    // my pieces of a stage have landed once only `younger` stages' loads are outstanding
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (five) { if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+    else { if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
+  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
+  struct Frag { bf16x8_t a[2][3], b[2][3]; };
+  auto frags = [&](int stage, Frag& f) {
+    const unsigned char* As = d3_sm + stage * D3_STAGE;
+    const unsigned char* Bs = As + 3 * 4096;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                       // two 16-deep matrix steps per 32-deep stage
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        f.a[ks][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
+        f.b[ks][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * 8192 + Rb * 64 + 16 * (c ^ sb));
+      }
+    }
+  };
+  auto products = [&](const Frag& f, int ks) {             // smallest partial products first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
+  };
+  const int nk = NK > 0 ? NK : p.K / 32;                   // padded: exact
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
+  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
+  HK_STAMP(0);
+  if constexpr (!PIPE) {
+    issue(0, 0);
+    for (int it = 0; it < nk; ++it) {
+      wait_landed(0);                                      // stage `it` (the only one outstanding)
+      asm volatile("s_barrier" ::: "memory");              // everybody's pieces landed; everybody finished step it-1
+      Frag f;
+      frags(it % D3_NS, f);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < nk) issue((it + 1) % D3_NS, (it + 1) * 32);   // into the buffer step it-1 consumed
+      __builtin_amdgcn_sched_barrier(0);
+      products(f, 0);
+      if (it + 1 < nk || last_both) products(f, 1);
+    }
+  } else {
+  const int npro = nk < AHEAD ? nk : AHEAD;
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q)
+    if (q < npro) issue(q, q * 32);
+  wait_landed(npro - 1);
+  asm volatile("s_barrier" ::: "memory");
+  Frag f0, f1;
+  frags(0, f0);
+  // (the schedule of payne_dense_dma_kernel<.., PIPE>: fragments of the next step, THEN the request, then this step's products)
+  auto head = [&](int it, Frag& fn, const Frag& fc) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(fc.a[ks][pl]), "v"(fc.b[ks][pl]));
+    {
+      const int last = (it + AHEAD < nk ? it + AHEAD : nk) - 1;
+      wait_landed(last - (it + 1));
+    }
+    asm volatile("s_barrier" ::: "memory");
+#ifndef PAYNE_NO_LOOP_STAMPS
+    if (it < 13) HK_STAMP(1 + it);
+#endif
+    frags((it + 1) % D3_NS, fn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + AHEAD < nk) issue((it + AHEAD) % D3_NS, (it + AHEAD) * 32);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int it = 0;
+#pragma unroll
+  for (; it + 2 < nk; it += 2) {
+    head(it, f1, f0);
+    products(f0, 0); products(f0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    head(it + 1, f0, f1);
+    products(f1, 0); products(f1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (it + 1 < nk) {
+    head(it, f1, f0);
+    products(f0, 0); products(f0, 1);
+    products(f1, 0);
+    if (last_both) products(f1, 1);
+  } else {
+    products(f0, 0);
+    if (last_both) products(f0, 1);
+  }
+  }
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = n0 + wn0 + (lane & 31);
+  if (col < p.N) {
+    const float bv = p.bias[col] - p.bias_shift;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);
+    }
+  }
+  HK_STAMP(15);
+}
+
+// ----------------------------------------------------------------------------
 // Hidden layers, workgroup form: one 256-thread group per 32x32 output tile, the whole K
 // extent (<= 320 per chunk) of both operands staged in LDS by coalesced f32x4_t loads issued
 // together (one L2 latency), then the four waves split K between them (v_mfma_f32_16x16x4_f32,
@@ -657,12 +853,35 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 #pragma unroll
       for (int q = 0; q < 4; ++q) Red[(wave * 32 + 16 * i + 4 * g + q) * 33 + 16 * j + r] = acc[i][j][q];
   __syncthreads();
-  for (int idx = tid; idx < 32 * 32; idx += 256) {
-    const int rr = idx >> 5, cc = idx & 31, row = m0 + rr, col = n0 + cc;
+  // two adjacent columns per thread: 8-byte stores of the fp32 tile, 4-byte stores of each bf16 plane
+  const bool pairs_ok = ((p.ldy | n0) & 1) == 0 && (!p.Yp || (p.ldp & 1) == 0);
+  for (int idx = tid; idx < 32 * 16; idx += 256) {
+    const int rr = idx >> 4, cc = 2 * (idx & 15), row = m0 + rr, col = n0 + cc;
     if (row < p.B && col < p.N) {
-      const float v = Red[rr * 33 + cc] + Red[(32 + rr) * 33 + cc] + Red[(64 + rr) * 33 + cc] + Red[(96 + rr) * 33 + cc];
-      const float y = act_apply(v + (p.bias[col] - p.bias_shift), p.act);
-      p.Y[(size_t)row * p.ldy + col] = y;
+      float y[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float v = Red[rr * 33 + cc + e] + Red[(32 + rr) * 33 + cc + e] + Red[(64 + rr) * 33 + cc + e] + Red[(96 + rr) * 33 + cc + e];
+        y[e] = act_apply(v + (p.bias[col + e < p.N ? col + e : col] - p.bias_shift), p.act);
+      }
+      const bool two = col + 1 < p.N;
+      float* yo = &p.Y[(size_t)row * p.ldy + col];
+      if (two && pairs_ok) *reinterpret_cast<float2*>(yo) = make_float2(y[0], y[1]);
+      else { yo[0] = y[0]; if (two) yo[1] = y[1]; }
+      if (p.Yp) {                                                  // ... and as three bf16 parts for payne_dense_dma3_kernel
+        unsigned short h3[2], m3[2], l3[2];
+        split3(y[0], h3[0], m3[0], l3[0]);
+        split3(y[1], h3[1], m3[1], l3[1]);
+        const size_t o = (size_t)row * p.ldp + col;
+        if (two && pairs_ok) {                                     // (streamed: the next reader is another XCD)
+          __builtin_nontemporal_store((unsigned)h3[0] | ((unsigned)h3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
+          __builtin_nontemporal_store((unsigned)m3[0] | ((unsigned)m3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
+          __builtin_nontemporal_store((unsigned)l3[0] | ((unsigned)l3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]));
+        } else {
+          p.Yp[o] = h3[0]; p.Yp[p.plane_y + o] = m3[0]; p.Yp[2 * p.plane_y + o] = l3[0];
+          if (two) { p.Yp[o + 1] = h3[1]; p.Yp[p.plane_y + o + 1] = m3[1]; p.Yp[2 * p.plane_y + o + 1] = l3[1]; }
+        }
+      }
     }
   }
   HK_STAMP(5);
@@ -683,6 +902,9 @@ PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 10, 4, true>(DensePa
 PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 0, 3, false>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 0, 3, true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 5, 3, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 4, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<10, 4, true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(DenseParams, const PrepArgs);

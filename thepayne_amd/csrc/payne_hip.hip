@@ -69,6 +69,9 @@ struct payne_ctx {
   const float* w_out_pad = nullptr;     // output layer's weights [N][w_out_kp], k zero-padded to a multiple of 32 (LDS-DMA kernel)
   int w_out_kp = 0;
   bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
+  // 3 x bf16 planes for payne_dense_dma3_kernel: the output layer's weights [3][N][w_out_kp], the last hidden layer's output
+  // [3][b_max][ld_hid] (written by the hidden-layer kernel's epilogue; zero beyond the hidden width)
+  unsigned short* w_out_p3 = nullptr; unsigned short* hid_p3 = nullptr;
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
@@ -307,6 +310,13 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       bool same = model->n_layers >= 3;
       for (int l = 1; l + 1 < model->n_layers; ++l) same = same && model->layers[l].n_out == model->layers[0].n_out;
       c->dma_ok = same;
+      if (same) {
+        const size_t nw = (size_t)L.n_out * Kp;
+        if ((rc = dev_alloc(c, 3 * nw, &c->w_out_p3, c->owned))) return bail(rc);
+        hipLaunchKernelGGL(payne_split3_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, nullptr, wp, nw, c->w_out_p3, nw);
+        he = hipDeviceSynchronize();
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("weight split: ") + hipGetErrorString(he)));
+      }
     }
     c->n_layers = model->n_layers;
     c->n_labels = model->n_labels;
@@ -332,6 +342,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if (model->n_layers > 2) {
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[0], c->owned))) return bail(rc);
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
+      if (c->w_out_p3 && (rc = dev_alloc(c, (size_t)3 * opts->b_max * c->ld_hid, &c->hid_p3, c->owned))) return bail(rc);
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
@@ -537,6 +548,9 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 32, 0, 3, false>), dm_lds_bytes<4, 32, 3>());
   set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 64, 0, 3, true>), dm_lds_bytes<4, 64, 3>());
   set(reinterpret_cast<const void*>(payne_dense_dma_kernel<4, 64, 5, 3, true>), dm_lds_bytes<4, 64, 3>());
+  set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 4, true>), d3_lds_bytes<4>());
+  set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<10, 4, true>), d3_lds_bytes<4>());
+  set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 2, false>), d3_lds_bytes<2>());
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
@@ -583,6 +597,26 @@ static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
   }
 }
 
+// Output layer as six bf16 products (payne_dense_dma3_kernel): equal hidden widths.
+static bool out_dma3_ok(const payne_ctx* c, int, int) {
+  return c->w_out_p3 && c->hid_p3 && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & (PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64));
+}
+static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s) {
+  p.k_real = p.K;
+  p.K = c->w_out_kp;
+  p.Wp = c->w_out_p3; p.plane_w = (size_t)p.N * c->w_out_kp;
+  p.Xp = c->hid_p3; p.plane_x = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
+  p.grid_m = (p.B + 63) / 64;
+  p.grid_n = (p.N + 127) / 128;
+#ifdef PAYNE_STAMPS
+  p.stamps = g_dense_stamps;
+#endif
+  const dim3 grid(p.grid_m * p.grid_n), block(512);
+  if ((int)grid.x > c->n_cu) PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 2, false>), grid, block, d3_lds_bytes<2>(), s, p);   // many tiles per CU
+  else if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+  else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+}
+
 template <bool FUSE>
 static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   p.grid_m = (p.B + 31) / 32;
@@ -615,6 +649,8 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     p.bias_shift = last ? N.out_shift : 0.f;
     p.Y = last ? N.out : N.hid[(l - 1) & 1];
     p.ldy = last ? N.ld_out : N.ld_hid;
+    const bool use3 = N.spectral && out_dma3_ok(c, B, N.layers[n - 1].n_out);
+    if (use3 && l == n - 2) { p.Yp = c->hid_p3; p.plane_y = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid; }
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
       const payne_layer& L0 = N.layers[0];
@@ -630,6 +666,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last) launch_hidden<false>(p, pa, s);
+      else if (use3) launch_out_dma3(c, p, s);
       else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) {
         if ((c->w_out_kp % 64) == 0 && (c->opts.variant & PAYNE_V_OUT_BK64)) launch_out_dma<64>(c, p, s);
         else launch_out_dma<32>(c, p, s);
