@@ -34,7 +34,11 @@ struct DenseParams {
 #endif
 };
 #ifdef PAYNE_STAMPS
+#ifdef PAYNE_STAMPS_ENDS_ONLY   /* stamps 0 / 5 / 15 only: the phases in between keep their production shape */
+#define HK_STAMP(k) do { if (((k) == 0 || (k) == 5 || (k) == 15) && p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define HK_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 static unsigned long long* g_hidden_stamps = nullptr;
 static unsigned long long* g_dense_stamps = nullptr;
 #else
@@ -711,20 +715,26 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       const int row = (m0 + xrr < p.B) ? m0 + xrr : p.B - 1;
       xlab = p.theta[(size_t)row * p.ld_theta + (xd < 4 ? xd : 6)];
     }
-    const int nE = kn16 > 256 ? kn16 - 256 : 0;                  // extra columns
-    const int G = nE ? 256 / nE : 1, eg = nE ? tid / nE : 0, ec = nE ? 256 + (tid - eg * nE) : 0;
-    const bool eact = nE && eg < G;
-    float w0[2][NL], bz[2];
+    // The first layer runs on the matrix cores too: [32 rows x 4 labels] . [4 x 16 columns] is ONE v_mfma_f32_16x16x4_f32 per
+    // 16 x 16 block of the A tile (bias in the accumulator), 2 x 19 of them at H = 300 shared by the four waves -- against
+    // 32 x (4 fma + activation) per thread, behind 40 LDS reads, in the vector form this replaces (4 900 of the workgroup's
+    // 15 000 cycles).  Wave w owns the 16-column blocks w, w + 4, ..; NLG label groups of four (the fifth label: a second one).
+    constexpr int NLG = (NL + 3) / 4, MAXT = (HK_KC / 16 + 3) / 4;   // label groups; column blocks per wave (5)
+    const int ntile = kn16 >> 4;
+    float w0t[MAXT][NLG], bzt[MAXT];
     if (FUSE_L0) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = kc + (h ? ec : tid);
+      for (int tt = 0; tt < MAXT; ++tt) {
+        const int tcol = wave + 4 * tt;                            // column block; clamped loads, masked below
+        const int k = kc + 16 * (tcol < ntile ? tcol : 0) + r;
         const int kq = k < p.K0 ? k : p.K0 - 1;
-        bz[h] = p.b0[kq];
+        bzt[tt] = p.b0[kq];
 #pragma unroll
-        for (int d = 0; d < NL; ++d) w0[h][d] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
-#pragma unroll
-        for (int d = 0; d < NL; ++d) w0[h][d] = (d < p.n_labels) ? w0[h][d] : 0.f;
+        for (int lg = 0; lg < NLG; ++lg) {
+          const int d = 4 * lg + g;
+          const float w = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
+          w0t[tt][lg] = (d < p.n_labels) ? w : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -751,57 +761,31 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         lds_barrier();                        // LDS only: the weight-tile loads stay in flight
       }
       HK_STAMP(2);
-      // the encoded labels into registers first: As and Xh are the same LDS array to the compiler, so a read
-      // of Xh cannot move above a store to As, and a loop that alternates them pays one LDS round trip per
-      // row (measured: 14 600 of the kernel's 25 000 cycles)
-      float xr[32][NL], xe[8][NL];
+      // A operand: lane (r, g) holds xhat[row 16 i + r][label 4 lg + g]; B operand: W0[column][label 4 lg + g]; C: column r,
+      // rows 4 g + q of the block
+      float xa[2][NLG];
 #pragma unroll
-      for (int rr = 0; rr < 32; ++rr)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int d = 0; d < NL; ++d) xr[rr][d] = Xh[rr * PAYNE_MAX_LABELS + d];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int rr = eg + G * j, rc = rr < 32 ? rr : 31;
-#pragma unroll
-        for (int d = 0; d < NL; ++d) xe[j][d] = Xh[rc * PAYNE_MAX_LABELS + d];
-      }
+        for (int lg = 0; lg < NLG; ++lg) xa[i][lg] = Xh[(16 * i + r) * PAYNE_MAX_LABELS + 4 * lg + g];
       const bool lre = p.act0 == PAYNE_ACT_LRELU, plain = !lre && p.act0 != PAYNE_ACT_SIGMOID;
-      {
-        const bool live = (kc + tid) < p.K0;
-        float zz[32];
 #pragma unroll
-        for (int rr = 0; rr < 32; ++rr) {
-          float z = bz[0];
+      for (int tt = 0; tt < MAXT; ++tt) {
+        const int tcol = wave + 4 * tt;
+        if (tcol < ntile) {                                      // (wave-uniform)
+          const int col = 16 * tcol + r;
+          const bool live = (kc + col) < p.K0;
 #pragma unroll
-          for (int d = 0; d < NL; ++d) z = fmaf(w0[0][d], xr[rr][d], z);
-          zz[rr] = z;
-        }
-        if (lre) {
+          for (int i = 0; i < 2; ++i) {
+            f32x4_t z = (f32x4_t){bzt[tt], bzt[tt], bzt[tt], bzt[tt]};
 #pragma unroll
-          for (int rr = 0; rr < 32; ++rr) zz[rr] = lrelu01(zz[rr]);
-        } else if (!plain) {
+            for (int lg = 0; lg < NLG; ++lg) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][lg], w0t[tt][lg], z, 0, 0, 0);
 #pragma unroll
-          for (int rr = 0; rr < 32; ++rr) zz[rr] = 1.0f / (1.0f + expf(-zz[rr]));
-        }
-        if (tid < kn16) {
-#pragma unroll
-          for (int rr = 0; rr < 32; ++rr) As[rr * HK_PITCH + tid] = live ? zz[rr] : 0.f;
-        }
-      }
-      if (nE) {                               // (G * 8 >= 32 for every nE <= 64)
-        const bool live = (kc + ec) < p.K0;
-        float ze[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float z = bz[1];
-#pragma unroll
-          for (int d = 0; d < NL; ++d) z = fmaf(w0[1][d], xe[j][d], z);
-          ze[j] = lre ? lrelu01(z) : (plain ? z : 1.0f / (1.0f + expf(-z)));
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int rr = eg + G * j;
-          if (eact && rr < 32) As[rr * HK_PITCH + ec] = live ? ze[j] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+              const float y = lre ? lrelu01(z[q]) : (plain ? z[q] : 1.0f / (1.0f + expf(-z[q])));
+              As[(16 * i + 4 * g + q) * HK_PITCH + col] = live ? y : 0.f;
+            }
+          }
         }
       }
     } else {
