@@ -82,6 +82,43 @@ def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engi
     assert errs["split"].max() <= 1.5 * errs["f32"].max() + 1e-8, (errs["split"].max(), errs["f32"].max())
 
 
+def _fp64_forward(net, lab):
+    from thepayne_amd import _lib
+    nl = lab.shape[1]
+    x = (lab - net["xmin"][:nl]) / (net["xmax"][:nl] - net["xmin"][:nl]) - 0.5
+    h = x.astype(np.float32).astype(np.float64)
+    for W, b, act in net["layers"]:
+        h = h @ W.astype(np.float64).T + b.astype(np.float64)
+        if act == _lib.ACT_LRELU:
+            h = np.maximum(h, 0.01 * h)
+    return h
+
+
+@pytest.mark.parametrize("H,npix,B,D", [(16, 160, 1, 4), (40, 1000, 63, 4), (64, 1029, 65, 4), (100, 4101, 130, 4),
+                                        (300, 777, 200, 5), (320, 2048, 64, 4), (352, 1500, 100, 4)])
+def test_dense_layers_on_odd_shapes(Engine, H, npix, B, D):
+    """Ragged sizes through every form of the dense layers: hidden widths that are / are not multiples of 32 (one, two,
+    ten, eleven k-steps; 352 > 320 takes the chunked hidden layers), pixel counts that are not multiples of the 128-column
+    tile, batches around the 64-row tile, the fifth label.  Output of the network (stage 0) against fp64."""
+    from thepayne_amd import _lib
+    raw = synth.make_yst_net(npix=npix, H=H, seed=H + npix, D=D)
+    net = _net(raw)
+    rng = np.random.default_rng(B)
+    lab = net["xmin"][:D] + rng.uniform(0.05, 0.95, size=(B, D)) * (net["xmax"][:D] - net["xmin"][:D])
+    ref = _fp64_forward(net, lab)
+    for variant in (0, _lib.V_OUT_F32, _lib.V_OUT_ROLLED, _lib.V_OUT_GENERIC):
+        eng = Engine(net, obs=None, b_max=max(B, 8), variant=variant)
+        th = np.full((B, eng.ncols), np.nan)
+        th[:, 0:4] = lab[:, 0:4]
+        if D == 5:
+            th[:, 6] = lab[:, 4]
+        th[:, 4], th[:, 5], th[:, 7] = 0.0, 0.0, 20000.0
+        got = eng.predict_batch(th, stage=0).cpu().numpy().astype(np.float64)
+        eng.close()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= FLUX_TOL, (variant, np.abs(got - ref).max())
+
+
 def test_predict_stages_against_reference_golden(Engine, golden):
     g = golden("g2_getspec")
     raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
