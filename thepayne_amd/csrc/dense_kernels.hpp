@@ -443,10 +443,19 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   const int col = n0 + wn0 + (lane & 31);
   if (col < p.N) {
     const float bv = p.bias[col] - p.bias_shift;
+    const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;   // (the usual output layer: one test, not sixteen)
+    if (act_none) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(acc[r] + bv, &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);
+      }
     }
   }
   HK_STAMP(15);
@@ -635,10 +644,19 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
   const int col = n0 + wn0 + (lane & 31);
   if (col < p.N) {
     const float bv = p.bias[col] - p.bias_shift;
+    const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;   // (the usual output layer: one test, not sixteen)
+    if (act_none) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(acc[r] + bv, &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);
+      }
     }
   }
   HK_STAMP(15);
@@ -651,6 +669,9 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 // 2x2 tiles each) and their partial tiles are summed through LDS.  With FUSE_L0 the A tile is
 // produced in place from theta (label encoding + first layer + activation).
 // ----------------------------------------------------------------------------
+#ifndef PAYNE_EXP_HK
+#define PAYNE_EXP_HK 0                // (timing experiments: 1 no first layer, 2 no matrix phase, 4 no weight-tile loads)
+#endif
 constexpr int HK_KC = 320;          // K chunk
 constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
@@ -742,7 +763,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
       const int kcl = (4 * k4 < kn) ? kc + 4 * k4 : kc + kn - 4;
       const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
-      vb[it] = *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * p.K + kcl);
+      vb[it] = (PAYNE_EXP_HK & 4) ? z4 : *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * p.K + kcl);
       if (!FUSE_L0) {
         const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1;
         va[it] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kcl);
@@ -768,26 +789,29 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int lg = 0; lg < NLG; ++lg) xa[i][lg] = Xh[(16 * i + r) * PAYNE_MAX_LABELS + 4 * lg + g];
-      const bool lre = p.act0 == PAYNE_ACT_LRELU, plain = !lre && p.act0 != PAYNE_ACT_SIGMOID;
+      // One specialised copy of the loop per activation: chosen inside it, the choice is three scalar branches PER VALUE
+      // (eighty values a lane) around an inlined sigmoid -- 3 800 of the workgroup's cycles as first written.
+      float* const arow = As + (4 * g) * HK_PITCH + 16 * wave + r;   // + (16 i + q) rows, + 64 tt columns: immediates
+      auto first_layer = [&](auto actf) {
 #pragma unroll
-      for (int tt = 0; tt < MAXT; ++tt) {
-        const int tcol = wave + 4 * tt;
-        if (tcol < ntile) {                                      // (wave-uniform)
-          const int col = 16 * tcol + r;
-          const bool live = (kc + col) < p.K0;
+        for (int tt = 0; tt < MAXT; ++tt) {
+          const int tcol = wave + 4 * tt;
+          if (tcol < ntile && !(PAYNE_EXP_HK & 1)) {             // (wave-uniform)
+            const bool live = (kc + 16 * tcol + r) < p.K0;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            f32x4_t z = (f32x4_t){bzt[tt], bzt[tt], bzt[tt], bzt[tt]};
+            for (int i = 0; i < 2; ++i) {
+              f32x4_t z = (f32x4_t){bzt[tt], bzt[tt], bzt[tt], bzt[tt]};
 #pragma unroll
-            for (int lg = 0; lg < NLG; ++lg) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][lg], w0t[tt][lg], z, 0, 0, 0);
+              for (int lg = 0; lg < NLG; ++lg) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][lg], w0t[tt][lg], z, 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float y = lre ? lrelu01(z[q]) : (plain ? z[q] : 1.0f / (1.0f + expf(-z[q])));
-              As[(16 * i + 4 * g + q) * HK_PITCH + col] = live ? y : 0.f;
+              for (int q = 0; q < 4; ++q) arow[(16 * i + q) * HK_PITCH + 64 * tt] = live ? actf(z[q]) : 0.f;
             }
           }
         }
-      }
+      };
+      if (p.act0 == PAYNE_ACT_LRELU) first_layer([](float z) { return lrelu01(z); });
+      else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer([](float z) { return 1.0f / (1.0f + expf(-z)); });
+      else first_layer([](float z) { return z; });
     } else {
       HK_STAMP(2);
     }
@@ -804,7 +828,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     __syncthreads();
     HK_STAMP(3);
     // ---- the four waves split the K steps of this chunk -------------------------------------
-    const int steps = kn16 >> 4;
+    const int steps = (PAYNE_EXP_HK & 2) ? 0 : (kn16 >> 4);
     for (int s = wave; s < steps; s += 4) {
       const int k = s * 16 + 4 * g;
       f32x4_t a[2], b[2];
