@@ -161,3 +161,38 @@ def test_engine_refuses_to_run_without_gpu():
     from thepayne_amd import nnio
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         PayneEngine(nnio.normalize_spec_net(synth.make_yst_net(npix=256, H=16)))
+
+
+def _bf16_rne(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32, as the device's (__bf16) cast does."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def test_three_bf16_parts_hold_an_fp32_value_exactly():
+    """The output layer multiplies operands split as x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+    (thepayne_amd/csrc/dense_kernels.hpp, split3).  The claim its accuracy rests on: the three parts sum to x EXACTLY
+    (24 significant bits = 8 + 8 + 8, with the signs of the remainders absorbing the rounding), and the six partial products
+    the kernel keeps differ from the full product by less than 2^-22 |a b|."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(0, 1, 200000), rng.normal(0, 1e-3, 50000), rng.uniform(-300, 300, 50000),
+                        [0.0, 1.0, -1.0, 0.1, 3.0e-30, 1.0e30, 1.0 + 2.0 ** -23, 255.99998]]).astype(np.float32)
+    x1 = _bf16_rne(x)
+    r1 = (x - x1).astype(np.float32)
+    assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - x1.astype(np.float64))      # the subtraction is exact
+    x2 = _bf16_rne(r1)
+    r2 = (r1 - x2).astype(np.float32)
+    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - x2.astype(np.float64))
+    x3 = _bf16_rne(r2)
+    assert np.array_equal(x3, r2)                                                                    # nothing is left over
+    tot = x1.astype(np.float64) + x2.astype(np.float64) + x3.astype(np.float64)
+    assert np.array_equal(tot, x.astype(np.float64))
+    # the six products kept: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1
+    a, b = x[:100000], x[100000:200000]
+    parts = lambda v: (lambda v1: (lambda v2: (v1, v2, _bf16_rne((v - v1 - v2).astype(np.float32))))(_bf16_rne((v - v1).astype(np.float32))))(_bf16_rne(v))
+    a1, a2, a3 = [t.astype(np.float64) for t in parts(a)]
+    b1, b2, b3 = [t.astype(np.float64) for t in parts(b)]
+    kept = a1 * b1 + a1 * b2 + a2 * b1 + a1 * b3 + a2 * b2 + a3 * b1
+    full = a.astype(np.float64) * b.astype(np.float64)
+    assert np.all(np.abs(kept - full) <= 2.0 ** -22 * np.abs(full) + 1e-300)
