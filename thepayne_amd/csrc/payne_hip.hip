@@ -1021,7 +1021,7 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
       (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
       (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell)) || (rc = alloc(K * 4, (void**)&s->nredraw)) ||
-      (rc = alloc(K * (2 * nd + 1) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
+      (rc = alloc(std::max<size_t>(K * (2 * nd + 1), 2 * PAYNE_MAX_DIM) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
       (rc = alloc(sizeof(WalkTail), (void**)&s->tail_dev))) {
     payne_sampler_destroy(s);
     return rc;
@@ -1033,6 +1033,15 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     (void)hipMemcpy(tc, d->adv.tab_cdf, nb, hipMemcpyHostToDevice);
     (void)hipMemcpy(tv, d->adv.tab_val, nb, hipMemcpyHostToDevice);
     s->sd.adv.tab_cdf = tc; s->sd.adv.tab_val = tv;
+  }
+  {   // the transforms' per-dimension constants, computed by the device functions the steps use (q_dev: staging, free here)
+    double qh[2 * PAYNE_MAX_DIM];
+    hipLaunchKernelGGL(payne_prior_cache_kernel, dim3(1), dim3(64), 0, nullptr, s->sd, s->q_dev);
+    if (hipMemcpy(qh, s->q_dev, sizeof(qh), hipMemcpyDeviceToHost) != hipSuccess) {
+      payne_sampler_destroy(s);
+      return fail(c, PAYNE_E_HIP, "prior cache kernel");
+    }
+    for (int i = 0; i < PAYNE_MAX_DIM; ++i) { s->sd.q0[i] = qh[i]; s->sd.q1[i] = qh[PAYNE_MAX_DIM + i]; }
   }
   (void)hipMemset(s->inside, 0, K * 4);
   if (hipHostMalloc((void**)&s->q_host, K * (2 * nd + 1) * 8, hipHostMallocDefault) != hipSuccess ||

@@ -20,6 +20,9 @@ struct SamplerDev {
   // column, < 0 the constant col_val (a fixed value or NaN = absent)
   int col_src[kMaxThetaCols];
   double col_val[kMaxThetaCols];
+  // what a transform computes from its parameters alone, once (prior_cache): the truncated normal's two (survival) CDF values --
+  // two normcdf and two divisions a call otherwise, half of a chain step's instructions --, expm1(-b), the logarithms of log-uniform
+  double q0[PAYNE_MAX_DIM], q1[PAYNE_MAX_DIM];
 };
 
 // np.interp(u, xp, fp), xp non-decreasing: the last j with xp[j] <= u, slope form (advancedpriors.gal_ppf)
@@ -65,7 +68,21 @@ __device__ inline double adv_lnprior(const payne_adv_priors& a, double logg, dou
 __device__ __forceinline__ bool adv_any(const payne_adv_priors& a) { return a.imf || a.vrot || a.plx_dim >= 0; }
 
 // unit cube -> parameter (Payne/fitting/prior.py:151-178, scipy.stats ppf's restated)
-__device__ inline double prior_ppf(const payne_prior_dim& d, double u, const payne_adv_priors& adv) {
+__device__ inline void prior_cache(const payne_prior_dim& d, double& q0, double& q1) {
+  q0 = 0.0; q1 = 0.0;
+  switch (d.kind) {
+    case PAYNE_PRIOR_TGAUSSIAN: {
+      const double a = (d.p[0] - d.p[2]) / d.p[3], b = (d.p[1] - d.p[2]) / d.p[3];
+      if (a > 0.0) { const double sa = normcdf(-a), sb = normcdf(-b); q0 = sa; q1 = sa - sb; }   // upper tail: survival functions
+      else { const double ca = normcdf(a), cb = normcdf(b); q0 = ca; q1 = cb - ca; }
+      break;
+    }
+    case PAYNE_PRIOR_TEXP: q0 = expm1(-((d.p[1] - d.p[0]) / d.p[2])); break;
+    case PAYNE_PRIOR_LOGUNIFORM: q0 = log(d.p[0]); q1 = log(d.p[1]) - log(d.p[0]); break;
+    default: break;
+  }
+}
+__device__ inline double prior_ppf(const payne_prior_dim& d, double q0, double q1, double u, const payne_adv_priors& adv) {
   switch (d.kind) {
     case PAYNE_PRIOR_TABLE: return d.p[0] * table_interp(adv, u);
     case PAYNE_PRIOR_UNIFORM: {
@@ -74,27 +91,19 @@ __device__ inline double prior_ppf(const payne_prior_dim& d, double u, const pay
     }
     case PAYNE_PRIOR_GAUSSIAN: return d.p[0] + d.p[1] * normcdfinv(u);
     case PAYNE_PRIOR_TGAUSSIAN: {
-      const double a = (d.p[0] - d.p[2]) / d.p[3], b = (d.p[1] - d.p[2]) / d.p[3];
-      double x;
-      if (a > 0.0) {                    // both limits in the upper tail: work with survival functions
-        const double sa = normcdf(-a), sb = normcdf(-b);
-        x = -normcdfinv(sa - u * (sa - sb));
-      } else {
-        const double ca = normcdf(a), cb = normcdf(b);
-        x = normcdfinv(ca + u * (cb - ca));
-      }
+      // both limits in the upper tail (lo > mu): survival functions, q0 = S(a), q1 = S(a) - S(b); else q0 = C(a), q1 = C(b) - C(a)
+      const double x = (d.p[0] > d.p[2]) ? -normcdfinv(q0 - u * q1) : normcdfinv(q0 + u * q1);
       double v = d.p[2] + d.p[3] * x;
       if (!(v <= d.p[1])) v = (v != v) ? v : d.p[1];           // +inf (u = 1) -> hi, prior.py:165-166
       return v;
     }
     case PAYNE_PRIOR_EXP: return d.p[0] - d.p[1] * log1p(-u);
     case PAYNE_PRIOR_TEXP: {
-      const double b = (d.p[1] - d.p[0]) / d.p[2];
-      double v = d.p[0] - d.p[2] * log1p(u * expm1(-b));        // truncexpon.ppf
+      double v = d.p[0] - d.p[2] * log1p(u * q0);               // truncexpon.ppf, q0 = expm1(-b)
       if (!(v <= d.p[1])) v = (v != v) ? v : d.p[1];
       return v;
     }
-    case PAYNE_PRIOR_LOGUNIFORM: return exp(log(d.p[0]) + u * (log(d.p[1]) - log(d.p[0])));
+    case PAYNE_PRIOR_LOGUNIFORM: return exp(q0 + u * q1);
     default: return u;
   }
 }
@@ -285,7 +294,7 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   }
   if (nredraw && lane == 0) nredraw[c] = L.nredraw0 + skipped;
   const payne_prior_dim dim = sd.dims[dl];                      // (an L2 hit; twenty registers the loop above could not spare)
-  const double vp = in ? prior_ppf(dim, up, sd.adv) : vc;       // outside: a harmless valid row
+  const double vp = in ? prior_ppf(dim, sd.q0[dl], sd.q1[dl], up, sd.adv) : vc;       // outside: a harmless valid row
   double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
   if (L.adv_on) {                                       // priors on derived quantities: the values they need by shuffle
     const payne_adv_priors& a = sd.adv;

@@ -9,7 +9,7 @@ __global__ void payne_prior_kernel(SamplerDev sd, const double* u, int K, double
   double vv[PAYNE_MAX_DIM];
   double lp = 0.0;
   for (int d = 0; d < sd.ndim; ++d) {
-    vv[d] = prior_ppf(sd.dims[d], u[(size_t)c * sd.ndim + d], sd.adv);
+    vv[d] = prior_ppf(sd.dims[d], sd.q0[d], sd.q1[d], u[(size_t)c * sd.ndim + d], sd.adv);
     v[(size_t)c * sd.ndim + d] = vv[d];
     lp += prior_ln(sd.dims[d], vv[d]);
   }
@@ -20,6 +20,12 @@ __global__ void payne_prior_kernel(SamplerDev sd, const double* u, int K, double
     lp = (lp == -INFINITY || add == -INFINITY) ? -INFINITY : lp + add;
   }
   if (mode) { lnprior[c] = lp; write_theta_row(sd, vv, rows + (size_t)c * sd.ncols); }
+}
+// the per-dimension constants of the transforms, by the device's own normcdf / expm1 / log (sampler creation)
+__global__ void payne_prior_cache_kernel(SamplerDev sd, double* q) {
+  const int d = threadIdx.x;
+  if (d >= sd.ndim) return;
+  prior_cache(sd.dims[d], q[d], q[PAYNE_MAX_DIM + d]);
 }
 // lnprob = lnprior + lnlike (-inf prior wins; NaN likelihood stays NaN)
 __global__ void payne_lnprob_kernel(const double* lnprior, const double* lnl, int K, double* out) {
