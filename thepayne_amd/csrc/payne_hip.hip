@@ -1109,7 +1109,8 @@ extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, dou
   HIPCHK(s->ctx, hipMemsetAsync(s->nredraw, 0, (size_t)K * 4, st));
   s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr, s->nredraw};
   s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, s->axes,
-                              ell ? s->ell : (const int*)nullptr, s->nredraw, scale, loglstar, seed, K};
+                              ell ? s->ell : (const int*)nullptr, s->nredraw, scale, loglstar, seed, K,
+                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0};
   s->tail_done = false;
   return PAYNE_OK;
 }

@@ -151,6 +151,7 @@ struct WalkState {
   double scale, loglstar;
   unsigned long long seed;
   int K;
+  int nd, ncols, adv_on;       // of the sampler (SamplerDev::ndim / ncols / adv_any): the step's first loads need no table read first
 };
 // device-resident copy for the post kernel's tail (payne_post_kernel<.., LEAN>: PostArgs::tail)
 struct WalkTail { SamplerDev sd; WalkState w; };
@@ -161,6 +162,9 @@ struct WalkTail { SamplerDev sd; WalkState w; };
 // normcdfinv chains in fp64) of the dimensions run side by side, the ellipsoid step is a shuffle
 // matvec, sums are wave reductions.  (One thread per chain spent 14 us per step in a ~3000-instruction
 // dependent fp64 chain; the step sits between two likelihood batches, nothing overlaps it.)
+#ifndef PAYNE_EXP_TAIL
+#define PAYNE_EXP_TAIL 0   // (timing experiments: 1 no prior transform / ln-prior, 2 no random draw, 4 no theta row)
+#endif
 constexpr int kRedrawPasses = 2;
 #ifndef PAYNE_AX_BATCH
 #define PAYNE_AX_BATCH 4
@@ -182,8 +186,8 @@ struct WalkLoads {
 };
 __device__ __forceinline__ WalkLoads walk_loads(const SamplerDev& sd, const WalkState& W, int c, int lane) {
   WalkLoads L;                                                  // (valid addresses whatever the flags say)
-  L.nd = sd.ndim; L.ncols = sd.ncols;
-  L.adv_on = adv_any(sd.adv) ? 1 : 0;
+  L.nd = W.nd; L.ncols = W.ncols;
+  L.adv_on = W.adv_on;
   const int nd = L.nd;
   const int dl = lane < nd ? lane : 0;
   const int colc = lane < L.ncols ? lane : 0;
@@ -232,6 +236,17 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   const double lpr = L.lpr;
   const double u_p = L.u_p, v_p = L.v_p;
   const int my_ell = L.my_ell;
+  // the ellipsoid coefficients of this lane's coordinate (up to eight: the usual fits) are requested before the settle and
+  // the random numbers are worked out: one L2 round trip under ~800 cycles of arithmetic instead of two in the draw
+  int NP = 8;
+  while (NP < nd) NP <<= 1;
+  const int G = 64 / NP, g = lane / NP, dg = lane - g * NP;
+  const bool actg = dg < nd;
+  const int dgl = actg ? dg : 0;
+  const double* ax = axes + (size_t)my_ell * nd * nd;                // this chain's ellipsoid (bound='multi')
+  double ax8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ax8[k] = propose ? ax[dgl * nd + (k < nd ? k : nd - 1)] : 0.0;
   if (settle && was_in) {
     const double lp = (lpr == -INFINITY) ? -INFINITY : lpr + lnl_p;
     const bool accept = lp > loglstar;                          // false for NaN
@@ -247,16 +262,11 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   // draw as a rejection for the scale adaptation: `nredraw`).  The wave draws 64 / NP candidates SIDE BY SIDE (NP =
   // dimensions rounded up to a power of two: lanes g NP .. g NP + NP - 1 hold candidate g) and takes the first one
   // inside the cube: one pass costs what one draw costs, and the step is given up only after kRedrawPasses passes.
-  const double* ax = axes + (size_t)my_ell * nd * nd;                // this chain's ellipsoid (bound='multi')
-  int NP = 8;
-  while (NP < nd) NP <<= 1;
-  const int G = 64 / NP, g = lane / NP, dg = lane - g * NP;
-  const bool actg = dg < nd;
-  const int dgl = actg ? dg : 0;
   const double ucg = __shfl(uc, dgl);                               // the chain's position, seen by every candidate group
   double up = uc;
   bool in = false;
   int skipped = 0;
+  if (PAYNE_EXP_TAIL & 2) { in = true; up = uc * 0.999 + 0.0005; }
   for (int pass = 0; pass < kRedrawPasses && !in; ++pass) {
     const unsigned d0 = (unsigned)(pass * G + g) * 192u;
     // the random direction and radius in fp32 (v_log_f32 / v_cos_f32 / v_exp_f32 / v_rsq_f32: a draw carries 24 random
@@ -270,8 +280,13 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
     for (int o = NP >> 1; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);   // sum over the candidate's own lanes
     const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01f(seed, c, step, d0 + 128)) / (float)nd) * __builtin_amdgcn_rsqf(n2);
     double sdot = 0.0;
-    // (kAxBatch coefficients requested at a time: a load -> wait -> fma loop pays one L2 round trip per dimension)
-    for (int e0 = 0; e0 < nd; e0 += kAxBatch) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                                   // the first eight coordinates: coefficients already here
+      const float ze = __shfl(z, g * NP + (k & (NP - 1)));
+      sdot = (k < nd) ? fma(ax8[k], (double)ze, sdot) : sdot;
+    }
+    // (the rest, kAxBatch coefficients requested at a time: a load -> wait -> fma loop pays one L2 round trip per dimension)
+    for (int e0 = 8; e0 < nd; e0 += kAxBatch) {
       double ab[kAxBatch];
 #pragma unroll
       for (int k = 0; k < kAxBatch; ++k) ab[k] = ax[dgl * nd + (e0 + k < nd ? e0 + k : nd - 1)];
@@ -294,8 +309,8 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   }
   if (nredraw && lane == 0) nredraw[c] = L.nredraw0 + skipped;
   const payne_prior_dim dim = sd.dims[dl];                      // (an L2 hit; twenty registers the loop above could not spare)
-  const double vp = in ? prior_ppf(dim, sd.q0[dl], sd.q1[dl], up, sd.adv) : vc;       // outside: a harmless valid row
-  double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
+  const double vp = (PAYNE_EXP_TAIL & 1) ? up : (in ? prior_ppf(dim, sd.q0[dl], sd.q1[dl], up, sd.adv) : vc);       // outside: a harmless valid row
+  double lp = (PAYNE_EXP_TAIL & 1) ? 0.0 : wave_sum(act ? prior_ln(dim, vp) : 0.0);
   if (L.adv_on) {                                       // priors on derived quantities: the values they need by shuffle
     const payne_adv_priors& a = sd.adv;
     const double g_ = __shfl(vp, a.dim_logg >= 0 ? a.dim_logg : 0), r_ = __shfl(vp, a.dim_logr >= 0 ? a.dim_logr : 0);
