@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA = packed-fp32 vector peak (spec)
 PEAK_HBM_GBS = 8000.0
 
@@ -372,10 +373,20 @@ def main():
                                            "packed-fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s). The MFMA kernel of "
                                            "the step is under `mfma_kernel`.")
             t_out = max(per["dense_out"], 1e-9) * 1e-6
-            out["mfma_kernel"] = {"kernel": "payne_dense_dma_kernel (output layer)", "alg_flops_per_launch": flops["dense_out"],
+            split = not (args.variant & (4096 | 1 | 1024))          # the default output layer: six bf16 products per fp32 product
+            out["mfma_kernel"] = {"kernel": "payne_dense_dma3_kernel (output layer, 3 x bf16 split)" if split else
+                                            "payne_dense_dma_kernel (output layer, fp32 matrix instruction)",
+                                  "alg_flops_per_launch": flops["dense_out"],
                                   "avg_us_per_launch": per["dense_out"],
                                   "achieved_tflops": flops["dense_out"] / t_out / 1e12,
                                   "frac_of_fp32_peak": flops["dense_out"] / t_out / 1e12 / PEAK_FP32_TFLOPS}
+            if split:                                                # what the matrix pipe executes: 6 bf16 flops per algorithmic flop
+                out["mfma_kernel"].update({"executed_bf16_tflops": 6.0 * flops["dense_out"] / t_out / 1e12,
+                                           "frac_of_bf16_peak": 6.0 * flops["dense_out"] / t_out / 1e12 / PEAK_BF16_TFLOPS,
+                                           "note": "fp32-accurate products as six bf16 partial products: `frac_of_fp32_peak` compares the "
+                                                   "algorithmic fp32 work with what the fp32 matrix instruction could do at best, "
+                                                   "`frac_of_bf16_peak` the executed bf16 work with the dense bf16 peak (2.5 PFLOP/s); "
+                                                   "the kernel is bound by the 36 KB of operand planes a k-step brings in"})
         out["kernels_us"] = per
         out["alg_flops_per_eval"] = flops_eval
         t_k = max(sum(per.values()), 1e-9) * 1e-6
