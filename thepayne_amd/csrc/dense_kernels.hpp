@@ -874,7 +874,8 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       }
       const bool two = col + 1 < p.N;
       float* yo = &p.Y[(size_t)row * p.ldy + col];
-      if (two && pairs_ok) *reinterpret_cast<float2*>(yo) = make_float2(y[0], y[1]);
+      if (p.Yp) { /* the only reader of this layer's output is the output layer, and it reads the planes */ }
+      else if (two && pairs_ok) *reinterpret_cast<float2*>(yo) = make_float2(y[0], y[1]);
       else { yo[0] = y[0]; if (two) yo[1] = y[1]; }
       if (p.Yp) {                                                  // ... and as three bf16 parts for payne_dense_dma3_kernel
         unsigned short h3[2], m3[2], l3[2];
