@@ -306,6 +306,9 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   const int nk = NK > 0 ? NK : p.K / BK;                   // padded: exact
   const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * BK;
   const int kk_last = __builtin_amdgcn_readfirstlane(k_tail >= BK ? BK / 8 : (k_tail <= 0 ? 1 : (k_tail + 7) / 8));
+  // (the epilogue's bias, requested before the first transfer: asked for at the end it is a memory round trip of its own)
+  const int col = n0 + wn0 + (lane & 31);
+  const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
   HK_STAMP(0);
   // Three stages are requested ahead; the fragments of step it+1 are read from LDS BEFORE the matrix instructions of
   // step it are issued, so the LDS round trip of a step (8 ds_read_b128 per wave, ~300 cycles during which neither wave of
@@ -440,9 +443,7 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
   }
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col = n0 + wn0 + (lane & 31);
   if (col < p.N) {
-    const float bv = p.bias[col] - p.bias_shift;
     const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;   // (the usual output layer: one test, not sixteen)
     if (act_none) {
 #pragma unroll
@@ -578,6 +579,9 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
   const int nk = NK > 0 ? NK : p.K / 32;                   // padded: exact
   const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
   const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
+  // (the epilogue's bias, requested before the first transfer: asked for at the end it is a memory round trip of its own)
+  const int col = n0 + wn0 + (lane & 31);
+  const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
   HK_STAMP(0);
   if constexpr (!PIPE) {
     issue(0, 0);
@@ -641,9 +645,7 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
   }
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col = n0 + wn0 + (lane & 31);
   if (col < p.N) {
-    const float bv = p.bias[col] - p.bias_shift;
     const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;   // (the usual output layer: one test, not sixteen)
     if (act_none) {
 #pragma unroll
@@ -710,6 +712,14 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // the epilogue's two bias values (thread -> columns 2 (tid & 15), + 1 of the tile, in both of its trips): requested now --
+  // asked for in the epilogue they are one more memory round trip at the end of the workgroup's life
+  float bias2[2];
+  {
+    const int c0 = n0 + 2 * (tid & 15);
+    bias2[0] = p.bias[c0 < p.N ? c0 : p.N - 1];
+    bias2[1] = p.bias[c0 + 1 < p.N ? c0 + 1 : p.N - 1];
+  }
 
   // one K chunk; the usual single-chunk case (K <= 320) is called outside any loop: around a loop the
   // compiler's wait-count bookkeeping turns conservative (a vmcnt(0) right after the first load)
@@ -870,7 +880,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const float v = Red[rr * 33 + cc + e] + Red[(32 + rr) * 33 + cc + e] + Red[(64 + rr) * 33 + cc + e] + Red[(96 + rr) * 33 + cc + e];
-        y[e] = act_apply(v + (p.bias[col + e < p.N ? col + e : col] - p.bias_shift), p.act);
+        y[e] = act_apply(v + (bias2[e] - p.bias_shift), p.act);
       }
       const bool two = col + 1 < p.N;
       float* yo = &p.Y[(size_t)row * p.ldy + col];
