@@ -925,13 +925,25 @@ PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr
   }
   S.W = W;
 }
-// Phase 0 of the kernel when the record exists: a dword copy into the workgroup's state.
-PAYNE_HD void phase_take_prep(int tid, const CandState* __restrict__ prep, CandState& S) {
-  constexpr int ND = (int)(sizeof(CandState) / 4);
-  static_assert(sizeof(CandState) % 4 == 0, "dword copy");
+// Phase 0 of the kernel when the record exists: a dword copy into the workgroup's state, in two halves so that the load is
+// in flight with the row's (request, ..., store): one memory round trip at the start of the workgroup instead of two.
+constexpr int kPrepDwords = (int)(sizeof(CandState) / 4);
+static_assert(sizeof(CandState) % 4 == 0, "dword copy");
+constexpr int kPrepPerThread = (kPrepDwords + 63) / 64;
+struct PrepRegs { unsigned v[kPrepPerThread]; };
+PAYNE_HD void phase_take_prep_issue(int tid, const CandState* __restrict__ prep, PrepRegs& R) {
   const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(prep);
+  if (tid < 64) {
+#pragma unroll
+    for (int q = 0; q < kPrepPerThread; ++q) { const int i = tid + 64 * q; R.v[q] = src[i < kPrepDwords ? i : kPrepDwords - 1]; }
+  }
+}
+PAYNE_HD void phase_take_prep_commit(int tid, const PrepRegs& R, CandState& S) {
   unsigned* dst = reinterpret_cast<unsigned*>(&S);
-  if (tid < 64) for (int i = tid; i < ND; i += 64) dst[i] = src[i];
+  if (tid < 64) {
+#pragma unroll
+    for (int q = 0; q < kPrepPerThread; ++q) { const int i = tid + 64 * q; if (i < kPrepDwords) dst[i] = R.v[q]; }
+  }
 }
 
 // P0: per-candidate scalars from theta.  The independent fp64 chains (log / sqrt / the

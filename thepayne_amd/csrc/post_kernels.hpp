@@ -120,6 +120,10 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
         const int i0 = (int)threadIdx.x + q * kPostThreads;
         tmp[q] = g[i0 < NTW ? i0 : NTW - 1];
       }
+      // (every value named before the first store: the compiler otherwise sinks the load of a slot whose store is conditional
+      //  -- the last one -- into that condition, behind the wait for the others: a second round trip)
+#pragma unroll
+      for (int q = 0; q < PER; ++q) asm volatile("" : "+v"(tmp[q]));
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int i0 = (int)threadIdx.x + q * kPostThreads;

@@ -187,16 +187,23 @@ template <int LOG2N, int NT, class Ex>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
                              float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr) {
-  // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer
-  const bool direct = (out_stage != 0) && T.rot_identity && (th[5] != 0.0);
+  // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer.  The test reads theta: with the plain
+  // executors it is made AFTER the row has been requested (a global load and its wait ahead of that request was a round trip
+  // of its own at the start of every workgroup); only the fused four-step form needs it before.
+  const bool maybe_direct = (out_stage != 0) && T.rot_identity;
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
   constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : 16;
   // global-workspace executor with the four-step transform: the first pass of the vsini transform reads the row itself
-  const bool fused_row = direct && ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2) && row_vectorised(T.npix, raw);
+  const bool may_fuse = maybe_direct && ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2) && row_vectorised(T.npix, raw);
+  bool direct = may_fuse ? (th[5] != 0.0) : false;
+  const bool fused_row = may_fuse && direct;
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
     if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
-    if (prep) phase_take_prep(t, prep, S);             // per-candidate scalars were computed ahead of the kernel
+    PrepRegs pr;
+    if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
+    if (!may_fuse) direct = maybe_direct && (th[5] != 0.0);
+    if (prep) phase_take_prep_commit(t, pr, S);
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
     if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
