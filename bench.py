@@ -8,11 +8,17 @@ smoothing -> chi^2) over the batch, theta already resident in HBM.  With --gpus 
 every rank fits its own synthetic star (weak scaling, no data-path collective);
 posterior-style summaries are all-gathered over RCCL once after the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C5|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C5|small] [--shard-batch]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` without a torchrun environment starts the N ranks itself (fresh child
 processes, before this process touches a GPU).  Prints ONE JSON line (rank 0).
+
+The headline is C2.  On one GPU the same line also carries, under `also_measured`, short runs of C3 (C2 + photometry in
+seven filters, the joint likelihood of SURVEY 8(d)) and C5 (65 536 pixels, 2048 candidates: the HBM-bound regime), each
+with its own kernel times and roofline block.  `--shard-batch` (N > 1) is SURVEY 8(e)-2: ONE star, every batch split
+in contiguous blocks over the ranks, the B log-likelihoods rebuilt on every rank by one all_gather per step
+(strong scaling; pays for C5-class batches).
 """
 import argparse
 import json
@@ -46,37 +52,21 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=0, help="payne_opts.variant (kernel variants of include/payne_hip.h; A/B runs)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight (one engine + HIP stream each); the headline uses 1")
+    ap.add_argument("--shard-batch", action="store_true",
+                    help="N > 1: one star, each batch split over the ranks, one all_gather of lnL per step (SURVEY 8(e)-2)")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also_measured` runs (C3, C5) behind the C2 headline")
+    ap.add_argument("--e2e-calls", type=int, default=700000, help="likelihood calls per end-to-end sampler run (three runs)")
     return ap.parse_args()
 
 
 # ----------------------------------------------------------------------------
-# N ranks from one command line.  The parent never imports torch or touches HIP: it only
-# starts N copies of this script with the torchrun environment and relays rank 0's line.
+# N ranks from one command line (thepayne_amd/launch.py).  The parent never imports torch or touches HIP: it builds
+# the library once, starts N copies of this script with the torchrun environment and relays rank 0's line.
 # ----------------------------------------------------------------------------
 def launch_ranks(n):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    pending = list(procs)
-    while pending:
-        for p in list(pending):
-            code = p.poll()
-            if code is None:
-                continue
-            pending.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in pending:            # a failed rank leaves the others waiting in a collective: end them
-                    q.terminate()
-        time.sleep(0.05)
-    return rc
+    from thepayne_amd.launch import launch_ranks as _launch
+    from thepayne_amd.build import build_lib
+    return _launch(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], prepare=build_lib)
 
 
 # ----------------------------------------------------------------------------
@@ -84,7 +74,7 @@ def launch_ranks(n):
 # lnprobfn call, fp64 numpy), one process per core.  Runs BEFORE the GPU is touched.
 # ----------------------------------------------------------------------------
 def _cpu_worker(args):
-    cfg_name, budget_s, seed = args
+    cfg_name, budgets, seed = args
     import numpy as np
     import oracle as O
     from thepayne_amd import synth
@@ -98,7 +88,7 @@ def _cpu_worker(args):
     names = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
     th = synth.draw_candidates(4096, seed=100 + seed)
     out = []
-    for loop in (True, False):                # the reference's per-pixel chi^2 loop (likelihood.py:95-97), then vectorised
+    for loop, budget in zip((True, False), budgets):   # the reference's per-pixel chi^2 loop (likelihood.py:95-97), then vectorised
         L = O.OracleLikelihood(net, obs, flux, np.full(len(obs), 0.01), names, pixel_loop=loop)
         O.lnprobfn(th[0], L)                  # warm
         n, t0 = 0, time.perf_counter()
@@ -106,7 +96,7 @@ def _cpu_worker(args):
             O.lnprobfn(th[n % len(th)], L)
             n += 1
             dt = time.perf_counter() - t0
-            if dt >= budget_s / 2:
+            if dt >= budget:
                 break
         out.append((n, dt))
     return out
@@ -125,7 +115,8 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(cfg_name, budget_s=12.0, max_procs=32):
+def cpu_baseline(cfg_name, budgets=(12.0, 6.0), max_procs=32):
+    """budgets: seconds of the SURVEY 8(d) leg (chi^2 by the reference's per-pixel loop) and of the vectorised-chi^2 leg."""
     import multiprocessing as mp
     cores = min(usable_cores(), max_procs)
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -133,7 +124,7 @@ def cpu_baseline(cfg_name, budget_s=12.0, max_procs=32):
     ctx = mp.get_context("spawn")             # never fork a process that may hold a GPU
     with ctx.Pool(cores) as pool:
         t0 = time.perf_counter()
-        res = pool.map(_cpu_worker, [(cfg_name, budget_s, i) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(cfg_name, tuple(budgets), i) for i in range(cores)])
         wall = time.perf_counter() - t0
     loop = [r[0][0] / r[0][1] for r in res]
     vect = [r[1][0] / r[1][1] for r in res]
@@ -145,7 +136,7 @@ def cpu_baseline(cfg_name, budget_s=12.0, max_procs=32):
                 sample="numpy oracle lnprobfn, one theta per call, fp64, chi^2 by the per-pixel Python loop of "
                        "Payne/fitting/likelihood.py:95-97, %s workload: %d processes x %.0f s (%d calls; then %.0f s "
                        "with vectorised chi^2, %d calls; %.1f s wall incl. start-up)"
-                       % (cfg_name, cores, budget_s / 2, sum(r[0][0] for r in res), budget_s / 2,
+                       % (cfg_name, cores, budgets[0], sum(r[0][0] for r in res), budgets[1],
                           sum(r[1][0] for r in res), wall),
                 reference_measured_elsewhere="251 evals/s/core (C2), 11.6 (C5): the reference itself on the survey "
                                              "container's CPU (BASELINE.md)")
@@ -184,7 +175,257 @@ def pmc_bytes(path, key):
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
-KERNEL_KEYS = {"dense_out": "payne_dense_dma", "post": "payne_post", "dense_hidden": "payne_dense_hidden_kernel"}
+KERNEL_KEYS = {"dense_out": "payne_dense_dma", "post": "payne_post", "dense_hidden": "payne_dense_hidden_kernel",
+               "sed": "payne_sed"}
+METRIC_C2 = "likelihood-evals/sec (4k-pixel ANN, 512 live points)"
+
+
+# ----------------------------------------------------------------------------
+# One configuration on this rank's GPU: problem, timed steps, per-kernel device times.
+# ----------------------------------------------------------------------------
+def make_problem(cfg_name, B, rank, local_rank, variant=0, streams=1):
+    """Engines (one per batch in flight) + resident theta / lnL for config `cfg_name`; star seed = rank."""
+    import numpy as np
+    import torch
+    from thepayne_amd import nnio, synth
+    from thepayne_amd.engine import PayneEngine
+    cfg = dict(synth.CONFIGS[cfg_name])
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    net = nnio.normalize_spec_net(raw)
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    eng0 = PayneEngine(net, obs=(obs,), b_max=1, device=local_rank)
+    T = synth.TRUTH
+    rng = np.random.default_rng(rank)
+    truth = np.full((1, eng0.ncols), np.nan)
+    truth[0, :8] = [T["Teff"] + 20.0 * rank, T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], np.nan, T["inst_R"]]
+    clean = eng0.predict_batch(truth, stage=2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+    flux = clean + rng.normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    eng0.close()
+    kw = {}
+    phot = None
+    if cfg.get("phot"):                       # C3: + seven filters, photscale parametrisation
+        phot = synth.make_phot_nets()
+        kw = dict(phot=phot, obs_phot=synth.c3_obs_phot(phot["filters"]), photscale=True)
+    S = max(1, streams)
+    engines = [PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank, variant=(variant if j == 0 else 0), **kw)
+               for j in range(S)]
+    eng = engines[0]
+    theta = eng.make_theta(B)
+    if phot is None:
+        th = synth.draw_candidates(B, seed=1 + rank)
+    else:
+        th = synth.draw_candidates_c3(B, seed=1 + rank)
+        theta[:, eng.phot_off] = torch.as_tensor(th[:, 7], device=theta.device)          # log(A)
+        theta[:, eng.phot_off + 2] = torch.as_tensor(th[:, 8], device=theta.device)      # Av
+    theta[:, 0:6] = torch.as_tensor(th[:, 0:6], device=theta.device)
+    theta[:, 7] = torch.as_tensor(th[:, 6], device=theta.device)
+    lnl = torch.empty(B, dtype=torch.float64, device=theta.device)
+    D, H, N = net["layers"][0][0].shape[1], net["layers"][0][0].shape[0], cfg["npix"]
+    dims = dict(D=D, H=H, N=N, nobs=cfg["nobs"], B=B, n1=1 << int(np.ceil(np.log2(N))),
+                F=(len(phot["filters"]) if phot else 0), HP=(phot["w1"].shape[1] if phot else 0))
+    return dict(cfg=cfg, engines=engines, theta=theta, lnl=lnl, dims=dims)
+
+
+def alg_work(d):
+    """algorithmic FLOPs per evaluation and compulsory HBM bytes per batch (+ the photometric nets of C3:
+    F x (6 -> HP -> HP -> 1), fp64 arithmetic on fp32 weights)."""
+    import numpy as np
+    D, H, N, B, F, HP = d["D"], d["H"], d["N"], d["B"], d["F"], d["HP"]
+    L2N = np.log2(N)
+    fl_post = 2 * 2 * 2.5 * N * L2N + 60.0 * N
+    fl_sed = F * 2.0 * (6 * HP + HP * HP + HP)
+    flops_eval = 2.0 * (D * H + H * H + H * N) + fl_post + fl_sed
+    bytes_batch = 4.0 * (D * H + H + H * H + H + H * N + N) + 8.0 * N + 16.0 * d["nobs"] + B * (8.0 * 12 + 4) \
+        + 4.0 * F * (6 * HP + HP + HP * HP + HP + HP + 1)
+    return dict(flops_eval=flops_eval, bytes_batch=bytes_batch, flops_post=fl_post, flops_sed=fl_sed,
+                flops_out=2.0 * H * N)
+
+
+def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, streams=1, shard=False):
+    """Time `steps` steps of config `cfg_name` (after `warmup`) between barriers; MAX over ranks.  Returns the numbers the
+    JSON line is made of.  shard: one star, the batch split over the ranks, one all_gather of lnL per step."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from thepayne_amd import synth
+    B = B or synth.CONFIGS[cfg_name]["batch"]
+    star = 0 if shard else rank
+    P = make_problem(cfg_name, B, star, local_rank, variant=args.variant, streams=streams)
+    engines, theta, lnl = P["engines"], P["theta"], P["lnl"]
+    eng = engines[0]
+    S = len(engines)
+    sts = [torch.cuda.Stream(device=local_rank) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
+    thetas = [theta] + [theta.clone() for _ in range(S - 1)]
+    lnls = [lnl] + [torch.empty_like(lnl) for _ in range(S - 1)]
+    if shard and world > 1:
+        per = (B + world - 1) // world
+        lo, hi = min(B, rank * per), min(B, (rank + 1) * per)
+        mine = torch.full((per,), float("nan"), dtype=torch.float64, device=theta.device)
+        full = torch.empty(per * world, dtype=torch.float64, device=theta.device)
+        th_blk = theta[lo:hi].contiguous()
+    torch.cuda.synchronize()
+
+    def step(i):
+        if shard and world > 1:
+            if hi > lo:
+                eng.lnlike_batch(th_blk, out=mine[:hi - lo])
+            dist.all_gather_into_tensor(full, mine)          # the per-iteration exchange: <= ceil(B/G) doubles per rank
+            return
+        j = i % S
+        if S == 1:
+            eng.lnlike_batch(theta, out=lnl)
+        else:
+            with torch.cuda.stream(sts[j]):
+                engines[j].lnlike_batch(thetas[j], out=lnls[j])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    barrier()
+    dt_local = time.perf_counter() - t0
+    tmax = torch.tensor([dt_local], dtype=torch.float64, device=theta.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if shard and world > 1:
+        lnl = torch.cat([full[r * per:r * per + max(0, min(B, (r + 1) * per) - min(B, r * per))] for r in range(world)])
+    for l_ in lnls[1:]:                  # every in-flight batch evaluated the same candidates: same answers
+        assert args.unchecked or bool(torch.equal(torch.nan_to_num(l_), torch.nan_to_num(lnl)))
+    assert args.unchecked or int(torch.isfinite(lnl).sum()) >= B - max(4, B // 128), \
+        "non-finite lnL in the benchmark batch"   # Inst_R tail draws are NaN by contract
+
+    kern = None
+    if not args.no_kernel_timing and not (shard and world > 1):
+        # per-kernel device time (HIP events attached to the launches, on the launch stream), same steps replayed
+        eng.profile(True)
+        for _ in range(steps):
+            eng.lnlike_batch(theta, out=lnl)
+        torch.cuda.synchronize()
+        kern = eng.profile_read()
+        eng.profile(False)
+    res = dict(P, dt=dt, dt_local=dt_local, steps=steps, warmup=warmup, B=B, S=S, kern=kern, lnl=lnl, shard=bool(shard and world > 1),
+               evals=(B * steps if shard else world * B * steps))
+    return res
+
+
+def roofline_blocks(cfg_name, res, args):
+    """roofline / mfma_kernel / kernels_us / whole_step / hbm blocks of one configuration's run."""
+    d, kern = res["dims"], res["kern"]
+    B, H, N, n1 = d["B"], d["H"], d["N"], d["n1"]
+    W = alg_work(d)
+    ms_per_step = 1e3 * res["dt"] / res["steps"]
+    out = {}
+    per = {k: (1e3 * v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}      # us per launch
+    dom = max(("dense_out", "post"), key=lambda k: per[k])
+    csv_path, meta = pmc_file(cfg_name)
+    traffic = {k: (pmc_bytes(csv_path, key) if csv_path else None) for k, key in KERNEL_KEYS.items()}
+    if not d["F"] or not per.get("sed"):
+        traffic.pop("sed", None)
+    tsrc = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build %s = the running one)"
+            % (os.path.relpath(csv_path, ROOT), meta["source_hash"])) if csv_path else \
+           ("none: no PMC passes under profiles/ were taken with the running build (%s)" % meta["source_hash"])
+    big = n1 > 16384
+    if big and dom == "post":
+        # spectra larger than LDS stream through a global workspace: HBM/L2-bound (SURVEY 8(d)).
+        # `achieved` = SURVEY 8(d)'s ALGORITHMIC bytes (compulsory bytes + 8 spectrum passes x 4N per evaluation) over the
+        # kernel's measured time: a modelled byte count over a measured duration; what the kernel really moves is in
+        # `traffic` (counters) and `workspace_bytes_per_launch` (passes_used transfers of the row), each with its own rate.
+        transfers = eng_round_trips(n1, args.variant)
+        alg8 = (W["bytes_batch"] / B + 8 * 4.0 * N) * B
+        t = max(per[dom], 1e-9) * 1e-6
+        ach = alg8 / t / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic["post"],
+                           "traffic_source": tsrc,
+                           "alg_bytes_per_launch": alg8,
+                           "alg_basis": "SURVEY 8(d): compulsory %.1f KB + 8 spectrum passes x 4N = %.2f MB per evaluation "
+                                        "(modelled bytes over the measured kernel time)"
+                                        % (W["bytes_batch"] / B / 1e3, alg8 / B / 1e6),
+                           "passes_used": transfers,
+                           "workspace_bytes_per_launch": transfers * 4.0 * n1 * B,
+                           "workspace_rate_GBs": transfers * 4.0 * n1 * B / t / 1e9,
+                           "avg_us_per_launch": per[dom]}
+        if traffic["post"]:
+            out["roofline"]["counter_rate_GBs"] = traffic["post"] / t / 1e9
+    else:
+        flops = {"dense_out": B * W["flops_out"], "post": B * W["flops_post"]}
+        ach = flops[dom] / (max(per[dom], 1e-9) * 1e-6) / 1e12
+        out["roofline"] = {"bound": "mfma" if dom == "dense_out" else "fp32-vector",
+                           "kernel": "payne_dense_dma_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
+                           "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                           "traffic": traffic[dom], "traffic_source": tsrc,
+                           "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
+        if dom == "post":
+            out["roofline"]["note"] = ("FFT / interpolation pipeline in LDS: no MFMA instructions; priced against the "
+                                       "packed-fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s). The MFMA kernel of "
+                                       "the step is under `mfma_kernel`.")
+        t_out = max(per["dense_out"], 1e-9) * 1e-6
+        split = not (args.variant & (4096 | 1 | 1024))          # the default output layer: six bf16 products per fp32 product
+        out["mfma_kernel"] = {"kernel": "payne_dense_dma3_kernel (output layer, 3 x bf16 split)" if split else
+                                        "payne_dense_dma_kernel (output layer, fp32 matrix instruction)",
+                              "alg_flops_per_launch": flops["dense_out"],
+                              "avg_us_per_launch": per["dense_out"],
+                              "achieved_tflops": flops["dense_out"] / t_out / 1e12,
+                              "frac_of_fp32_peak": flops["dense_out"] / t_out / 1e12 / PEAK_FP32_TFLOPS}
+        if split:                                                # what the matrix pipe executes: 6 bf16 flops per algorithmic flop
+            out["mfma_kernel"].update({"executed_bf16_tflops": 6.0 * flops["dense_out"] / t_out / 1e12,
+                                       "frac_of_bf16_peak": 6.0 * flops["dense_out"] / t_out / 1e12 / PEAK_BF16_TFLOPS,
+                                       "note": "fp32-accurate products as six bf16 partial products: `frac_of_fp32_peak` compares the "
+                                               "algorithmic fp32 work with what the fp32 matrix instruction could do at best, "
+                                               "`frac_of_bf16_peak` the executed bf16 work with the dense bf16 peak (2.5 PFLOP/s)"})
+    out["kernels_us"] = per
+    out["alg_flops_per_eval"] = W["flops_eval"]
+    t_k = max(sum(per.values()), 1e-9) * 1e-6
+    out["whole_step"] = {"alg_flops": W["flops_eval"] * B,
+                         "tflops_on_kernel_time": W["flops_eval"] * B / t_k / 1e12,
+                         "tflops_on_wall_time": W["flops_eval"] * B / (1e-3 * ms_per_step) / 1e12,
+                         "frac_of_fp32_peak_on_wall_time": W["flops_eval"] * B / (1e-3 * ms_per_step) / 1e12 / PEAK_FP32_TFLOPS}
+    # whole-step HBM rate (the north star asks for the achieved HBM-bandwidth fraction)
+    alg_step = W["bytes_batch"] + (0.0 if big else 2.0 * 4.0 * B * N)   # + spectra written by the output layer, read back once
+    hbm = {"alg_bytes_per_step": alg_step, "alg_rate_GBs": alg_step / (1e-3 * ms_per_step) / 1e9,
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "source": tsrc}
+    if traffic and all(v is not None for v in traffic.values()):
+        sb = float(sum(traffic.values()))
+        hbm.update({"pmc_bytes_per_step": sb, "achieved": sb / (1e-3 * ms_per_step) / 1e9,
+                    "frac": sb / (1e-3 * ms_per_step) / 1e9 / PEAK_HBM_GBS})
+    out["hbm"] = hbm
+    return out
+
+
+def workload_text(cfg_name, d):
+    s = "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels" % (cfg_name, d["N"], d["H"], d["nobs"])
+    if d["F"]:
+        s += ", photometry in %d filters (6-%d-%d-1 nets, log(A) parametrisation)" % (d["F"], d["HP"], d["HP"])
+    return s + ", batch of %d candidate vectors per step (dynesty live points)" % d["B"]
+
+
+def end_to_end(cfg_name, B, value, calls, runs=3):
+    """the same likelihood as the batched nested sampler sees it -- prior transform, random-walk
+    proposals (device), transfers and the dead-point bookkeeping included.  `runs` runs of `calls` likelihood calls
+    each (different sampler seeds; dlogz small enough that none stops early); the median rate is quoted."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sampler_bench
+    rs = [sampler_bench.run(cfg_name, maxcall=calls, nlive=B, walks=25, modes=("device_chunks",), seed=1 + i,
+                            dlogz=1e-9)["device_chunks"] for i in range(runs)]
+    rates = sorted(r["evals_per_s"] for r in rs)
+    med = float(np.median(rates))
+    return {"value": med, "unit": "likelihood-evals/s", "runs": runs, "rates": rates,
+            "calls": int(sum(r["calls"] for r in rs)), "iterations": int(sum(r["iterations"] for r in rs)),
+            "seconds": float(sum(r["seconds"] for r in rs)),
+            "frac_of_kernel_only": med / value,
+            "what": "static nested sampler, %d live points, rwalk x25 on the device, bound='multi' (ellipsoid decomposition "
+                    "by recursive 2-means), dead points consumed in bulk; median of %d runs" % (B, runs)}
 
 
 # ----------------------------------------------------------------------------
@@ -201,17 +442,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    cfg = dict(synth.CONFIGS[args.config])
-    B = args.batch or cfg["batch"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.config)
+        cpu = cpu_baseline("C2" if args.config == "C3" else args.config)
 
     import torch
     import torch.distributed as dist
-    from thepayne_amd import nnio
-    from thepayne_amd.engine import PayneEngine
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
     if world > ndev:
@@ -222,216 +459,99 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- this rank's star (seed = rank): same ANN replicated, own noise + truth jitter
-    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
-    net = nnio.normalize_spec_net(raw)
-    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
-    eng0 = PayneEngine(net, obs=(obs,), b_max=1, device=local_rank)
-    T = synth.TRUTH
-    rng = np.random.default_rng(rank)
-    truth = np.full((1, eng0.ncols), np.nan)
-    truth[0, :8] = [T["Teff"] + 20.0 * rank, T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], np.nan, T["inst_R"]]
-    clean = eng0.predict_batch(truth, stage=2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
-    flux = clean + rng.normal(0, 0.01, len(obs))
-    eflux = np.full(len(obs), 0.01)
-    eng0.close()
-    eng = PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank, variant=args.variant)
-    th7 = synth.draw_candidates(B, seed=1 + rank)
-    theta = eng.make_theta(B)
-    theta[:, 0:6] = torch.as_tensor(th7[:, 0:6], device=theta.device)
-    theta[:, 7] = torch.as_tensor(th7[:, 6], device=theta.device)
-    lnl = torch.empty(B, dtype=torch.float64, device=theta.device)
-    # extra in-flight batches: own context (workspaces), own stream, own theta / lnL
-    S = max(1, args.streams)
-    engines = [eng] + [PayneEngine(net, obs=(obs, flux, eflux), b_max=B, device=local_rank) for _ in range(S - 1)]
-    streams = [torch.cuda.Stream(device=local_rank) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
-    thetas = [theta] + [theta.clone() for _ in range(S - 1)]
-    lnls = [lnl] + [torch.empty_like(lnl) for _ in range(S - 1)]
-    torch.cuda.synchronize()
-
-    def step(i):
-        j = i % S
-        if S == 1:
-            engines[0].lnlike_batch(thetas[0], out=lnls[0])
-        else:
-            with torch.cuda.stream(streams[j]):
-                engines[j].lnlike_batch(thetas[j], out=lnls[j])
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt_local = time.perf_counter() - t0
-    tmax = torch.tensor([dt_local], dtype=torch.float64, device=theta.device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    for l_ in lnls[1:]:                  # every in-flight batch evaluated the same candidates: same answers
-        assert args.unchecked or bool(torch.equal(torch.nan_to_num(l_), torch.nan_to_num(lnl)))
-    assert args.unchecked or int(torch.isfinite(lnl).sum()) >= B - 4, "non-finite lnL in the benchmark batch"   # Inst_R tail draws are NaN by contract
-
-    # ---- per-kernel device time (HIP events on the launch stream), same K steps replayed
-    kern = None
-    if not args.no_kernel_timing:
-        eng.profile(True)
-        for _ in range(args.steps):
-            eng.lnlike_batch(theta, out=lnl)
-        torch.cuda.synchronize()
-        kern = eng.profile_read()
-        eng.profile(False)
+    res = run_config(args.config, args, args.steps, args.warmup, rank, world, local_rank, B=args.batch,
+                     streams=args.streams, shard=args.shard_batch)
+    B, d, lnl, theta = res["B"], res["dims"], res["lnl"], res["theta"]
 
     # ---- the one collective of the multi-star job: gather per-star summaries (RCCL)
     summary = torch.stack([lnl.max(), lnl.mean(), lnl.std(), theta[lnl.argmax(), 0], theta[lnl.argmax(), 1],
-                           torch.tensor(B * args.steps / dt_local, dtype=torch.float64, device=theta.device),
+                           torch.tensor(B * args.steps / res["dt_local"], dtype=torch.float64, device=theta.device),
                            torch.tensor(float(rank), dtype=torch.float64, device=theta.device)])
     gathered = [summary]
     if world > 1:
         gathered = [torch.empty_like(summary) for _ in range(world)]
         dist.all_gather(gathered, summary)
     if rank != 0:
+        for e in res["engines"]:
+            e.close()
         if world > 1:
             dist.destroy_process_group()
         return
     table = torch.stack(gathered).cpu().numpy()
     assert sorted(int(r) for r in table[:, 6]) == list(range(world)), "the gather did not see every rank"
 
-    D, H, N = net["layers"][0][0].shape[1], net["layers"][0][0].shape[0], cfg["npix"]
-    n1 = 1 << int(np.ceil(np.log2(N)))
-    L2N = np.log2(N)
-    flops_eval = 2.0 * (D * H + H * H + H * N) + 2 * 2 * 2.5 * N * L2N + 60.0 * N
-    bytes_batch = 4.0 * (D * H + H + H * H + H + H * N + N) + 8.0 * N + 16.0 * cfg["nobs"] + B * (8.0 * 12 + 4)   # compulsory
-    evals = world * B * args.steps
     out = {
-        "metric": "likelihood-evals/sec (4k-pixel ANN, 512 live points)" if args.config == "C2" else
-                  "likelihood-evals/sec (%s)" % args.config,
-        "value": evals / dt, "unit": "likelihood-evals/s",
+        "metric": METRIC_C2 if args.config == "C2" else "likelihood-evals/sec (%s)" % args.config,
+        "value": res["evals"] / res["dt"], "unit": "likelihood-evals/s",
         "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * res["dt"] / args.steps,
+        "higher_is_better": True, "scaling": "strong" if res["shard"] else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels, batch of %d "
-                               "candidate vectors per step (dynesty live points)" % (args.config, N, H, cfg["nobs"], B),
-                   "batch": B, "npix": N, "nobs": cfg["nobs"], "stars": world,
-                   "batches_in_flight": S, "kernel_variant": args.variant,
-                   "arithmetic": "fp32 storage and accumulation throughout (wavelengths, tapers, chi^2 sums fp64); the output "
-                                 "layer's products: " + ("v_mfma_f32_32x32x2_f32" if args.variant & 4096 else
+        "config": {"workload": workload_text(args.config, d),
+                   "batch": B, "npix": d["N"], "nobs": d["nobs"], "stars": 1 if res["shard"] else world,
+                   "batches_in_flight": res["S"], "kernel_variant": args.variant,
+                   "arithmetic": "fp32 storage and accumulation throughout (wavelengths, tapers, chi^2 sums, photometric nets fp64); "
+                                 "the output layer's products: " + ("v_mfma_f32_32x32x2_f32" if args.variant & 4096 else
                                  "operands split exactly in three bf16 parts, six exact partial products, fp32 accumulator "
                                  "(as accurate as the fp32 fma chain against an fp64 product: tests/test_gpu_parity.py; "
                                  "--variant 4096 = the fp32 matrix instruction)"),
-                   "parallelism": "1 star per GPU, no data-path collective"},
+                   "parallelism": ("1 star, every batch split in %d contiguous blocks, one all_gather of lnL per step (RCCL)" % world)
+                                  if res["shard"] else "1 star per GPU, no data-path collective"},
         **({"invalid": "--unchecked: a timing experiment, not a benchmark result"} if args.unchecked else {}),
         "rccl_world": dist.get_world_size() if world > 1 else 1,
         "per_rank_evals_per_s": [float(v) for v in table[np.argsort(table[:, 6]), 5]],
     }
-    if kern is not None:
-        per = {k: (1e3 * v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}      # us per launch
-        dom = max(("dense_out", "post"), key=lambda k: per[k])
-        csv_path, meta = pmc_file(args.config)
-        traffic = {k: (pmc_bytes(csv_path, key) if csv_path else None) for k, key in KERNEL_KEYS.items()}
-        tsrc = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build %s = the running one)"
-                % (os.path.relpath(csv_path, ROOT), meta["source_hash"])) if csv_path else \
-               ("none: no PMC passes under profiles/ were taken with the running build (%s)" % meta["source_hash"])
-        big = n1 > 16384
-        if big and dom == "post":
-            # spectra larger than LDS stream through a global workspace: HBM/L2-bound.
-            # SURVEY 8(d) prices the streaming variant at the compulsory bytes + passes x 4N per evaluation with passes = 8.
-            passes_used = eng_round_trips(n1)
-            alg8 = (bytes_batch / B + 8 * 4.0 * N) * B
-            t = max(per[dom], 1e-9) * 1e-6
-            ach = alg8 / t / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic["post"],
-                               "traffic_source": tsrc,
-                               "alg_bytes_per_launch": alg8,
-                               "alg_basis": "SURVEY 8(d): compulsory %.1f KB + 8 spectrum passes x 4N = %.2f MB per evaluation"
-                                            % (bytes_batch / B / 1e3, alg8 / B / 1e6),
-                               "passes_used": passes_used,
-                               "workspace_bytes_per_launch": passes_used * 4.0 * n1 * B,
-                               "workspace_rate_GBs": passes_used * 4.0 * n1 * B / t / 1e9,
-                               "avg_us_per_launch": per[dom]}
-            if traffic["post"]:
-                out["roofline"]["counter_rate_GBs"] = traffic["post"] / t / 1e9
-        else:
-            flops = {"dense_out": 2.0 * B * H * N, "post": B * (2 * 2 * 2.5 * N * L2N + 60.0 * N)}
-            ach = flops[dom] / (max(per[dom], 1e-9) * 1e-6) / 1e12
-            out["roofline"] = {"bound": "mfma" if dom == "dense_out" else "fp32-vector",
-                               "kernel": "payne_dense_dma_kernel (output layer)" if dom == "dense_out" else "payne_post_kernel",
-                               "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                               "traffic": traffic[dom], "traffic_source": tsrc,
-                               "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
-            if dom == "post":
-                out["roofline"]["note"] = ("FFT / interpolation pipeline in LDS: no MFMA instructions; priced against the "
-                                           "packed-fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s). The MFMA kernel of "
-                                           "the step is under `mfma_kernel`.")
-            t_out = max(per["dense_out"], 1e-9) * 1e-6
-            split = not (args.variant & (4096 | 1 | 1024))          # the default output layer: six bf16 products per fp32 product
-            out["mfma_kernel"] = {"kernel": "payne_dense_dma3_kernel (output layer, 3 x bf16 split)" if split else
-                                            "payne_dense_dma_kernel (output layer, fp32 matrix instruction)",
-                                  "alg_flops_per_launch": flops["dense_out"],
-                                  "avg_us_per_launch": per["dense_out"],
-                                  "achieved_tflops": flops["dense_out"] / t_out / 1e12,
-                                  "frac_of_fp32_peak": flops["dense_out"] / t_out / 1e12 / PEAK_FP32_TFLOPS}
-            if split:                                                # what the matrix pipe executes: 6 bf16 flops per algorithmic flop
-                out["mfma_kernel"].update({"executed_bf16_tflops": 6.0 * flops["dense_out"] / t_out / 1e12,
-                                           "frac_of_bf16_peak": 6.0 * flops["dense_out"] / t_out / 1e12 / PEAK_BF16_TFLOPS,
-                                           "note": "fp32-accurate products as six bf16 partial products: `frac_of_fp32_peak` compares the "
-                                                   "algorithmic fp32 work with what the fp32 matrix instruction could do at best, "
-                                                   "`frac_of_bf16_peak` the executed bf16 work with the dense bf16 peak (2.5 PFLOP/s); "
-                                                   "the kernel is bound by the 36 KB of operand planes a k-step brings in"})
-        out["kernels_us"] = per
-        out["alg_flops_per_eval"] = flops_eval
-        t_k = max(sum(per.values()), 1e-9) * 1e-6
-        out["whole_step"] = {"alg_flops": flops_eval * B,
-                             "tflops_on_kernel_time": flops_eval * B / t_k / 1e12,
-                             "tflops_on_wall_time": flops_eval * B / (1e-3 * out["ms_per_step"]) / 1e12,
-                             "frac_of_fp32_peak_on_wall_time": flops_eval * B / (1e-3 * out["ms_per_step"]) / 1e12 / PEAK_FP32_TFLOPS}
-        # whole-step HBM rate (the north star asks for the achieved HBM-bandwidth fraction)
-        alg_step = bytes_batch + (0.0 if big else 2.0 * 4.0 * B * N)   # + spectra written by the output layer, read back once
-        hbm = {"alg_bytes_per_step": alg_step, "alg_rate_GBs": alg_step / (1e-3 * out["ms_per_step"]) / 1e9,
-               "peak": PEAK_HBM_GBS, "unit": "GB/s", "source": tsrc}
-        if all(v is not None for v in traffic.values()):
-            sb = float(sum(traffic.values()))
-            hbm.update({"pmc_bytes_per_step": sb, "achieved": sb / (1e-3 * out["ms_per_step"]) / 1e9,
-                        "frac": sb / (1e-3 * out["ms_per_step"]) / 1e9 / PEAK_HBM_GBS})
-        out["hbm"] = hbm
+    if res["kern"] is not None:
+        out.update(roofline_blocks(args.config, res, args))
     if cpu is not None:
         out["cpu_baseline"] = cpu
-    if world == 1 and not args.no_e2e and B <= 4096 and cfg["npix"] <= 16384:
-        # the same likelihood as the batched nested sampler sees it -- prior transform,
-        # random-walk proposals (device), transfers and the dead-point bookkeeping included
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import sampler_bench
-        eng.close()
-        e2e = sampler_bench.run(args.config, maxcall=250000, nlive=B, walks=25, modes=("device_chunks",))["device_chunks"]
-        out["end_to_end"] = {"value": e2e["evals_per_s"], "unit": "likelihood-evals/s", "calls": e2e["calls"],
-                             "iterations": e2e["iterations"], "seconds": e2e["seconds"],
-                             "frac_of_kernel_only": e2e["evals_per_s"] / out["value"],
-                             "what": "static nested sampler, %d live points, rwalk x25 on the device, bound='multi' "
-                                     "(ellipsoid decomposition by recursive 2-means), dead points consumed in bulk" % B}
+    for e in res["engines"]:
+        e.close()
+    res = None
+    torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_also and args.config == "C2" and not args.batch and args.streams == 1:
+        # the configurations the headline does not show: short runs, same code path, own kernel times and roofline blocks
+        also = {}
+        for name, (k, w) in (("C3", (max(20, args.steps // 2), 10)), ("C5", (3, 1))):
+            try:
+                r = run_config(name, args, k, w, 0, 1, local_rank)
+                blk = {"value": r["evals"] / r["dt"], "unit": "likelihood-evals/s", "steps": k, "warmup": w,
+                       "ms_per_step": 1e3 * r["dt"] / k, "workload": workload_text(name, r["dims"])}
+                if r["kern"] is not None:
+                    blk.update(roofline_blocks(name, r, args))
+                for e in r["engines"]:
+                    e.close()
+                also[name] = blk
+            except Exception as ex:                          # the headline must not die with a side run
+                also[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            r = None
+            torch.cuda.empty_cache()
+        out["also_measured"] = also
+
+    if world == 1 and not args.no_e2e and B <= 4096 and d["N"] <= 16384:
+        out["end_to_end"] = end_to_end(args.config, B, out["value"], args.e2e_calls)
+        if args.config == "C2" and "also_measured" in out and "value" in out["also_measured"].get("C3", {}):
+            try:
+                out["also_measured"]["C3"]["end_to_end"] = end_to_end("C3", B, out["also_measured"]["C3"]["value"], args.e2e_calls)
+            except Exception as ex:
+                out["also_measured"]["C3"]["end_to_end"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def eng_round_trips(n1):
-    """Spectrum-sized round trips through the global workspace per evaluation in payne_post_big_kernel: the row
-    load, per convolution stage 2 transforms x (2 with the four-step form | one per radix-8 pass) + the taper
-    pass, the resampling pass and the closing interpolation read."""
+def eng_round_trips(n1, variant=0):
+    """Transfers of the spectrum (4 n1 bytes each, a read or a write) through the global workspace per evaluation in
+    payne_post_big_kernel: the row in and its copy out (2), per convolution stage the forward and the inverse
+    transform at 2 transfers per pass (the four-step form has 2 passes, the plain form one per radix-8 pass) + the taper
+    pass (2), the resampling pass between the stages (2) and the closing interpolation read (1)."""
     import numpy as np
     M = n1 // 2
-    tiled = (M % 512 == 0) and (M // 512 in (32, 64, 128))
+    tiled = (M % 512 == 0) and (M // 512 in (32, 64, 128)) and not (variant & 32)
     per_fft = 2 if tiled else int(np.ceil(np.log2(M) / 3.0))
-    # each pass reads and writes the spectrum once: count a pass as 2 transfers of 4 n1 bytes
-    return 1 + 2 * (2 * per_fft + 1) * 2 + 2 + 1
+    per_stage = 2 * (2 * per_fft) + 2            # two transforms + the taper pass, reads and writes
+    return 2 + 2 * per_stage + 2 + 1
 
 
 if __name__ == "__main__":

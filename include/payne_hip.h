@@ -120,6 +120,9 @@ typedef struct payne_opts {
 #define PAYNE_V_OUT_ROLLED 2048u /* output layer: the loop over k-steps as other hidden widths than 300 run it (not unrolled) */
 #define PAYNE_V_OUT_F32 4096u    /* output layer: the fp32 matrix instruction (v_mfma_f32_32x32x2_f32) instead of six bf16 products of
                                   * operands split in three (fp32-accurate either way; what launches with several tiles per CU use) */
+#define PAYNE_V_SED_OWN_LAUNCH 8192u /* joint likelihoods: the photometric nets as a launch of their own (one wave per candidate and
+                                    * filter: what payne_sed_batch and nets wider than 64 use) instead of extra workgroups of the
+                                    * hidden-layer launch */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

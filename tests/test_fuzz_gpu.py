@@ -61,7 +61,7 @@ def test_random_getspec_calls(tmp_path, D, seed, cont):
             kw['inst_R'] = float(rng.uniform(8000, 60000))
         elif mode == 2:
             kw['inst_R'] = [np.nan, 0.0, -5.0, float(net["resolution"]) * 1.2][rng.integers(4)]
-        elif mode == 4 and outwave is not None and len(wave) <= 8192:        # (the LSF path is built up to 8192 pixels)
+        elif mode == 4 and outwave is not None:        # an LSF vector (any spectrum length: LDS form up to 8192 pixels, global form above)
             x = np.linspace(-0.5, 0.5, nobs)
             kw['inst_R'] = 0.08 * (1.0 + rng.uniform(-0.5, 0.5) * x + rng.uniform(0, 0.5) * x ** 2)
         canon.update({k: v for k, v in kw.items() if k in ('vmic', 'rot_vel', 'rad_vel', 'inst_R', 'outwave')})

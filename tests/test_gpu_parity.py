@@ -347,3 +347,55 @@ def test_c5_at_size(Engine):
     # same answers in reverse order (grid-stride walk of the batch) and on a second call
     assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th[::-1].copy()).cpu().numpy()[::-1]), np.nan_to_num(lnl))
     assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th).cpu().numpy()), np.nan_to_num(lnl))
+
+
+@pytest.mark.parametrize("variant", [0, 8192])
+def test_c3_at_size(Engine, variant):
+    """BASELINE config 3 at its real shape: C2's 4096-pixel 2 x 300 network and 3600 observed pixels PLUS
+    photometry in seven filters (6-64-64-1 sigmoid nets, observed magnitudes 5.0 +- 0.05, the log(A) parametrisation),
+    512 candidates.  Six rows against the oracle's joint likelihood (likelihood.py:84-117); every row against chi^2_spec
+    recomputed on the host from the predicted spectra + chi^2_sed recomputed from the oracle's magnitudes
+    (predictsed.py:75-103 in fp64, a few ms per row).  variant 8192 = the photometric nets as a launch of their own
+    (PAYNE_V_SED_OWN_LAUNCH) instead of extra workgroups of the hidden-layer launch."""
+    cfg = synth.CONFIGS["C3"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    phot = synth.make_phot_nets()
+    obs_phot = synth.c3_obs_phot(phot["filters"])
+    B = cfg["batch"]
+    th9 = synth.draw_candidates_c3(B, seed=31)
+    th9[5, 8] = 5.5                                          # one candidate in the high-Av branch (predictsed.py:86-90)
+    T = synth.TRUTH
+    row = [T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], np.nan, T["inst_R"]]
+    clean = O.genspec(raw, row, outwave=obs)[1]
+    flux = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    eng = Engine(_net(raw), obs=(obs, flux, eflux), phot=phot, obs_phot=obs_phot, photscale=True, b_max=B, variant=variant)
+    th = np.full((B, eng.ncols), np.nan)
+    th[:, 0:6] = th9[:, 0:6]
+    th[:, 7] = th9[:, 6]
+    th[:, eng.phot_off] = th9[:, 7]
+    th[:, eng.phot_off + 2] = th9[:, 8]
+    lnl = eng.lnlike_batch(th).cpu().numpy()
+    names = SPEC_PARS + ['log(A)', 'Av']
+    L = O.OracleLikelihood(raw, obs, flux, eflux, names, phot=phot, obs_phot=obs_phot, photscale=True)
+    for k in (0, 1, 2, 5, 300, 511):
+        ref = L.lnlikefn(th9[k])
+        assert np.isnan(lnl[k]) if np.isnan(ref) else abs(lnl[k] - ref) <= lnl_tol(np.array([ref]))[0], (k, lnl[k], ref)
+    # all 512: chi^2_spec from the predicted spectra (fp64 on the host) + chi^2_sed from the oracle's magnitudes
+    mo = np.array([v[0] for v in obs_phot.values()]); me = np.array([v[1] for v in obs_phot.values()])
+    chi_sed = np.empty(B)
+    for k in range(B):
+        mags = np.atleast_1d(O.genphot_scaled(phot, [th9[k, 0], th9[k, 1], th9[k, 2], th9[k, 3], th9[k, 7], th9[k, 8], None]))
+        chi_sed[k] = np.sum(((mags - mo) ** 2) / me ** 2)
+    mg = eng.sed_batch(np.column_stack([np.log10(th9[:, 0]), th9[:, 1], th9[:, 2], th9[:, 3], th9[:, 8], np.full(B, 3.1),
+                                        np.full(B, np.nan), np.full(B, np.nan), th9[:, 7]])).cpu().numpy()
+    assert np.allclose(np.sum(((mg - mo) ** 2) / me ** 2, axis=1), chi_sed, rtol=1e-9, atol=1e-9)
+    ok = np.isfinite(lnl)
+    assert ok.sum() >= B - 4
+    for s in range(0, B, 128):
+        sp = eng.predict_batch(th[s:s + 128], stage=3, fwhm_R=True).cpu().numpy().astype(np.float64)
+        chi = -0.5 * ((((sp - flux) / eflux) ** 2).sum(axis=1) + chi_sed[s:s + 128])
+        sel = ok[s:s + 128]
+        assert np.all(np.abs(chi[sel] - lnl[s:s + 128][sel]) <= 2e-5 * np.abs(lnl[s:s + 128][sel]) + 5e-3)
+    assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th[::-1].copy()).cpu().numpy()[::-1]), np.nan_to_num(lnl))

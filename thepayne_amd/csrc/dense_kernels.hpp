@@ -4,6 +4,8 @@
 // payne_dense_dma_kernel (LDS-DMA ring + MFMA f32), the hidden layers payne_dense_hidden_kernel.
 #pragma once
 
+#include "sed_core.hpp"
+
 // ============================================================================
 // dense layer on the matrix cores
 // ============================================================================
@@ -681,25 +683,38 @@ constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABE
 // Workgroups past the GEMM tiles (first-layer launch only) compute the per-candidate records of
 // the post kernel (prep_candidate: Doppler / rotation / instrument scalars, mask counts, R-stage
 // window), one thread per candidate, on compute units the 160 GEMM tiles leave idle.
+// ... and, for joint spectrum + photometry likelihoods, workgroups past those run the photometric nets (sed_tile, sed_core.hpp:
+// one (filter, 64 candidates) tile each): the magnitudes the post kernel's chi^2_SED needs, without a launch of their own.
 struct PrepArgs {
   PostTables T;
   CandState* out;            // [B] (null: no records from this launch)
   double instr_factor;
   int n_gemm;                // workgroups that are GEMM tiles
+  int n_prep;                // ... that write per-candidate records (256 candidates each)
+  PhotTables P;              // photometric nets (sed_mags != null)
+  double* sed_mags;          // [B][F] magnitudes of this batch (null: no photometry in this launch)
+  int sed_off, sed_photscale;   // theta column of the photometric block; the log(A) parametrisation
 };
 
 // NL: label slots the fused first layer loops over (4 for the usual Teff/logg/FeH/aFe nets, else PAYNE_MAX_LABELS)
 template <bool FUSE_L0, int NL>
 __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p, const PrepArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) float hk_sm[];
   if ((int)blockIdx.x >= pa.n_gemm) {
-    if (FUSE_L0 && pa.out) {
-      const int cand = ((int)blockIdx.x - pa.n_gemm) * 256 + (int)threadIdx.x;
-      if (cand < p.B) prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+    if constexpr (FUSE_L0) {
+      const int x = (int)blockIdx.x - pa.n_gemm;
+      if (x < pa.n_prep) {
+        const int cand = x * 256 + (int)threadIdx.x;
+        if (pa.out && cand < p.B) prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+      } else if (pa.sed_mags) {
+        const int j = x - pa.n_prep, f = j % pa.P.F, blk = j / pa.P.F;
+        sed_tile(pa.P, p.theta, p.ld_theta, pa.sed_off, pa.sed_photscale, p.B, f, blk * kSedCands, pa.sed_mags,
+                 reinterpret_cast<unsigned char*>(hk_sm));
+      }
     }
     return;
   }
   HK_STAMP(0);
-  extern __shared__ __attribute__((aligned(16))) float hk_sm[];
   float* As = hk_sm;
   float* Bs = As + 32 * HK_PITCH;
   float* Xh = Bs + 32 * HK_PITCH;

@@ -622,11 +622,13 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
   p.grid_m = (p.B + 31) / 32;
   p.grid_n = (p.N + 31) / 32;
   pa.n_gemm = p.grid_m * p.grid_n;
-  if (!FUSE) pa.out = nullptr;
+  if (!FUSE) { pa.out = nullptr; pa.sed_mags = nullptr; }
+  pa.n_prep = pa.out ? (p.B + 255) / 256 : 0;
+  const int n_sed = pa.sed_mags ? pa.P.F * ((p.B + kSedCands - 1) / kSedCands) : 0;
 #ifdef PAYNE_STAMPS
   p.stamps = FUSE ? g_hidden_stamps : nullptr;
 #endif
-  const dim3 grid(pa.n_gemm + (pa.out ? (p.B + 255) / 256 : 0)), block(256);
+  const dim3 grid(pa.n_gemm + pa.n_prep + n_sed), block(256);
   if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
   else if (p.n_labels <= 4) PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
   else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
@@ -639,7 +641,8 @@ struct NetRef {
   float* const* hid; int ld_hid; float* out; int ld_out; float out_shift;
   bool spectral;                      // the spectral net owns the DMA / bf16x3 operand copies and the prep records
 };
-static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, double instr_factor, hipStream_t s) {
+// `sed`: a joint likelihood's photometric nets ride in the first hidden-layer launch (sed_tile); *sed is cleared when they did.
+static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, double instr_factor, hipStream_t s, bool* sed = nullptr) {
   const int n = N.n_layers;
   for (int l = 1; l < n; ++l) {
     DenseParams p{};
@@ -660,6 +663,10 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       PrepArgs pa{};
       pa.T = c->T; pa.instr_factor = instr_factor;
       pa.out = (N.spectral && c->prep && c->obs_bound && !(c->opts.variant & PAYNE_V_NO_PREP)) ? c->prep : nullptr;
+      if (!last && sed && *sed && N.spectral && sed_tile_ok(c->P.H) && !(c->opts.variant & PAYNE_V_SED_OWN_LAUNCH)) {
+        pa.P = c->P; pa.sed_mags = c->mags_ws; pa.sed_off = 8 + c->opts.npoly; pa.sed_photscale = c->opts.photscale;
+        *sed = false;
+      }
       if (last) launch_dense<64, 64, 32, true>(p, s);
       else { launch_hidden<true>(p, pa, s); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
@@ -753,10 +760,10 @@ __global__ void __launch_bounds__(256) payne_cont_kernel(const float* __restrict
 
 // `instr_factor`: what Inst_R is multiplied by (2.355 in the likelihood / genspec, 1 in getspec): the
 // first-layer launch also writes the post kernel's per-candidate records (c->prep) for that factor.
-static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s, bool with_cont = true) {
+static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s, bool with_cont = true, bool* sed = nullptr) {
   c->prep_valid = false;
   NetRef N{c->layers, c->n_layers, c->n_labels, c->xmin, c->xden, c->hid, c->ld_hid, c->raw, c->T.npix, kBase, true};
-  int rc = run_net(c, N, theta, B, instr_factor, s);
+  int rc = run_net(c, N, theta, B, instr_factor, s, sed);
   if (rc || !c->has_cont || !with_cont) return rc;
   NetRef C{c->clayers, c->cn_layers, c->n_labels, c->cxmin, c->cxden, c->chid, c->cn_ld_hid, c->cont_raw, c->cn_npix, 0.f, false};
   if ((rc = run_net(c, C, theta, B, instr_factor, s))) return rc;
@@ -875,9 +882,10 @@ static int lnlike_impl(payne_ctx* c, const double* theta, int B, double* lnl, vo
   if (c->has_phot && !c->has_obs_phot) return fail(c, PAYNE_E_INVALID, "photometric model without observed magnitudes");
   if (c->has_model) {
     if (!c->obs_bound || !c->T.obs_f1) return fail(c, PAYNE_E_INVALID, "no observed spectrum (flux, eflux) bound");
-    if ((rc = run_ann(c, theta, B, 2.355, s))) return rc;
   }
-  if (c->has_phot && (rc = run_sed(c, theta, c->ncols, 1, B, c->mags_ws, s))) return rc;
+  bool sed_pending = c->has_phot;                           // the photometric nets: in the hidden-layer launch when there is one
+  if (c->has_model && (rc = run_ann(c, theta, B, 2.355, s, true, &sed_pending))) return rc;
+  if (sed_pending && (rc = run_sed(c, theta, c->ncols, 1, B, c->mags_ws, s))) return rc;
   if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s, (c->has_lsf || (c->opts.variant & PAYNE_V_NO_WALK_TAIL)) ? nullptr : tail);
   hipLaunchKernelGGL(payne_photonly_kernel, dim3((B + 127) / 128), dim3(128), 0, s, c->mags_ws, c->obs_mag, c->obs_err, c->P.F, B, lnl);
   hipError_t e = hipGetLastError();

@@ -3,9 +3,14 @@
 The reference stores its emulators in HDF5 files (keys: YST1
 Payne/predict/ystpred.py:22-38; LinNet/SMLP Payne/train/NNmodels.py:44-89 +
 Payne/predict/predictspec.py:45-49; photometric nets Payne/predict/photANN.py:60-80).
-h5py is not part of this image, so the native container here is an ``.npz`` with
-the SAME key names ('/' in HDF5 group paths kept verbatim); ``.h5`` files are read
-when h5py is importable.  ``convert_h5_to_npz`` turns one into the other.
+h5py is not part of this image's main interpreter, so the native container here is an
+``.npz`` with the SAME key names ('/' in HDF5 group paths kept verbatim); ``.h5`` files are
+read when h5py is importable.  ``convert_h5_to_npz`` turns one into the other; it needs only
+numpy + h5py, so it runs under any interpreter that has them:
+
+    /opt/conda/bin/python3.9 -m thepayne_amd.nnio NN.h5 [NN.npz]        (from the repository root)
+
+(tests/test_h5_route.py does exactly that with files in the reference's three layouts.)
 """
 import os
 
@@ -27,7 +32,10 @@ def _read_h5(path):
 
     def visit(name, obj):
         if hasattr(obj, "shape"):
-            out[name] = np.array(obj)
+            a = np.array(obj)
+            if a.dtype == object:              # variable-length strings (label names): fixed-length bytes, loadable without pickle
+                a = np.array([x if isinstance(x, bytes) else str(x).encode("utf-8") for x in a.ravel()]).reshape(a.shape)
+            out[name] = a
     with h5py.File(path, "r") as f:
         f.visititems(visit)
     return out
@@ -141,3 +149,10 @@ def load_phot_nets(filters, nnpath):
             raise IOError("Cannot find NN file for {0} under {1}".format(f, nnpath))
         per.append(load_arrays(path))
     return stack_phot_nets(per, filters)
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) < 2:
+        raise SystemExit("usage: python -m thepayne_amd.nnio FILE.h5 [FILE.npz]")
+    print(convert_h5_to_npz(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None))

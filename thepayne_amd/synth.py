@@ -13,6 +13,9 @@ SPEC_LABEL_MAX = np.array([8000.0, 5.5, 0.5, 0.6])
 CONFIGS = {
     # name: (npix, lambda0, R_fwhm, nobs, batch)
     "C2": dict(npix=4096, lam0=5150.0, R=32000.0, nobs=3600, batch=512),
+    # C3: C2 + photometry in 7 filters (Bessell_BVRI, 2MASS_JHKs), H = 64 sigmoid nets (make_phot_nets seed 1),
+    # observed magnitudes 5.0 +- 0.05, the `photscale` parametrisation: log(A) U[-3, 7], Av U[0, 1]
+    "C3": dict(npix=4096, lam0=5150.0, R=32000.0, nobs=3600, batch=512, phot=True),
     "C5": dict(npix=65536, lam0=4000.0, R=100000.0, nobs=60000, batch=2048),
     "tiny": dict(npix=256, lam0=5150.0, R=32000.0, nobs=200, batch=16),
     "small": dict(npix=1024, lam0=5150.0, R=32000.0, nobs=900, batch=32),
@@ -142,6 +145,26 @@ def demo_priordict():
         'Vrot': {'pv_uniform': [0.0, 5.0]},
         'Inst_R': {'pv_tgaussian': [25000.0, 37000.0, 28800.0, 1000.0]},
     }
+
+
+def c3_obs_phot(filters=PHOT_FILTERS):
+    """C3's observed photometry: every filter 5.0 +- 0.05 mag."""
+    return {f: (5.0, 0.05) for f in filters}
+
+
+def c3_priordict():
+    """C2's priors + the photometric block of C3 (photscale): log(A) U[-3, 7], Av U[0, 1]."""
+    d = demo_priordict()
+    d['log(A)'] = {'pv_uniform': [-3.0, 7.0]}
+    d['Av'] = {'pv_uniform': [0.0, 1.0]}
+    return d
+
+
+def draw_candidates_c3(B, seed=1):
+    """theta[B, 9] = C2's seven columns + (log(A), Av) drawn through c3_priordict's boxes from the same stream."""
+    th7 = draw_candidates(B, seed=seed)
+    u = np.random.default_rng(seed + 7919).uniform(size=(B, 2))
+    return np.column_stack([th7, -3.0 + 10.0 * u[:, 0], u[:, 1]])
 
 
 def draw_candidates(B, seed=1, ndim=7):

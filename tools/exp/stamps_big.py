@@ -3,7 +3,8 @@ PAYNE_BIG_TILED=0/1.  Prints the median cycles of every barrier interval."""
 import ctypes as C, os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["PAYNE_HIP_LIB"] = os.path.join(ROOT, "thepayne_amd", "libpayne_hip_diag.so")
+from thepayne_amd import build
+os.environ["PAYNE_HIP_LIB"] = build.build_diag()
 from thepayne_amd import synth, nnio
 from thepayne_amd.engine import PayneEngine
 cfg = synth.CONFIGS["C5"]

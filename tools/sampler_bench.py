@@ -28,27 +28,33 @@ ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', '
 
 
 def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
-        verbose=False, bound='multi', variant=0):
+        verbose=False, bound='multi', variant=0, seed=1, dlogz=0.01):
     """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
-    bookkeeping included).  Returns {mode: {...}}."""
+    bookkeeping included).  Returns {mode: {...}}.  config 'C3' = C2 + photometry in seven filters (joint fit, photscale).
+    `seed`: the sampler's random stream; `dlogz`: stopping threshold (tiny: the run ends at `maxcall`)."""
     cfg = synth.CONFIGS[config]
+    joint = bool(cfg.get("phot"))
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0, line_depth=0.3)
     obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
     tmp = tempfile.mkdtemp()
     path = os.path.join(tmp, "yst.npz")
     nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
-    fitpars = [list(ALL), {p: p in SPEC for p in ALL}]
-    rb = [True, False, False, False, False]
+    free = SPEC + (['log(A)', 'Av'] if joint else [])
+    fitpars = [list(ALL), {p: p in free for p in ALL}]
+    rb = [True, joint, False, joint, False]                 # spec, phot, modpoly, photscale, carbon
     fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': np.ones(len(obs)), 'obs_eflux_fit': np.full(len(obs), 0.01),
                'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {}}
+    if joint:
+        phot = synth.make_phot_nets()
+        fitargs.update({'photANNpath': phot, 'obs_phot': synth.c3_obs_phot(phot["filters"])})
     L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False)
     T = synth.TRUTH
-    truth = np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]]])
+    truth = np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]] + ([0.0, 0.1] if joint else [])])
     clean = L.GM.engine.predict_batch(L.theta_rows(truth), stage=3, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
     L.GM.engine.close()
     fitargs['obs_flux_fit'] = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
     L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False, variant=variant)
-    P = prior(fitargs, synth.demo_priordict(), fitpars, rb)
+    P = prior(fitargs, synth.c3_priordict() if joint else synth.demo_priordict(), fitpars, rb)
     out = {}
     for mode in modes:
         proposer = None
@@ -62,15 +68,15 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
             proposer = DeviceProposer(L, P, k_max=nlive)
         S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound=bound,
                           sample='rwalk', walks=walks, batched=True, queue_size=queue,
-                          rstate=np.random.default_rng(1), proposer=proposer)
+                          rstate=np.random.default_rng(seed), proposer=proposer)
         t0 = time.perf_counter()
         c0 = S.ncall
         nell = 1
         if mode.endswith("chunks"):
-            for _ in S.sample_chunks(maxcall=maxcall, dlogz=0.01):
+            for _ in S.sample_chunks(maxcall=maxcall, dlogz=dlogz):
                 nell = max(nell, len(S._ells))
         else:
-            for _ in S.sample(maxcall=maxcall, dlogz=0.01):
+            for _ in S.sample(maxcall=maxcall, dlogz=dlogz):
                 pass
         dt = time.perf_counter() - t0
         out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 4),
