@@ -28,7 +28,7 @@ def emul():
     def P(a, t):
         return a.ctypes.data_as(t) if a is not None else None
 
-    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=256, prep=1):
+    def run(net, obs, flux, eflux, theta8, stage, npoly=0, pcs=None, factor=2.355, general=0, nthreads=512, prep=1):
         theta8 = np.atleast_2d(theta8)
         B, npix = len(theta8), len(net["wavelength"])
         raw = np.array([O.yst_forward(net, t[:4]) - 1.0 for t in theta8]).astype(np.float32)

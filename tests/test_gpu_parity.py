@@ -360,7 +360,9 @@ def test_c3_at_size(Engine, variant):
     cfg = synth.CONFIGS["C3"]
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
     obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    from thepayne_amd.engine import highav_coefficients
     phot = synth.make_phot_nets()
+    phot["hiav"] = highav_coefficients(phot["filters"])       # highred.py's table, as the oracle's sed reads it
     obs_phot = synth.c3_obs_phot(phot["filters"])
     B = cfg["batch"]
     th9 = synth.draw_candidates_c3(B, seed=31)

@@ -679,6 +679,7 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 constexpr int HK_KC = 320;          // K chunk
 constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
+static_assert(sed_tile_lds_bytes() <= HK_LDS_BYTES, "the photometric tile runs in the hidden-layer launch's LDS");
 
 // Workgroups past the GEMM tiles (first-layer launch only) compute the per-candidate records of
 // the post kernel (prep_candidate: Doppler / rotation / instrument scalars, mask counts, R-stage
@@ -694,6 +695,7 @@ struct PrepArgs {
   PhotTables P;              // photometric nets (sed_mags != null)
   double* sed_mags;          // [B][F] magnitudes of this batch (null: no photometry in this launch)
   int sed_off, sed_photscale;   // theta column of the photometric block; the log(A) parametrisation
+  int sed_cb;                // candidates per photometric tile (<= kSedCandsMax, chosen so that the tiles fit the idle compute units)
 };
 
 // NL: label slots the fused first layer loops over (4 for the usual Teff/logg/FeH/aFe nets, else PAYNE_MAX_LABELS)
@@ -708,8 +710,13 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
         if (pa.out && cand < p.B) prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
       } else if (pa.sed_mags) {
         const int j = x - pa.n_prep, f = j % pa.P.F, blk = j / pa.P.F;
-        sed_tile(pa.P, p.theta, p.ld_theta, pa.sed_off, pa.sed_photscale, p.B, f, blk * kSedCands, pa.sed_mags,
-                 reinterpret_cast<unsigned char*>(hk_sm));
+#ifdef PAYNE_STAMPS
+        unsigned long long* st = p.stamps ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
+#else
+        unsigned long long* st = nullptr;
+#endif
+        sed_tile(pa.P, p.theta, p.ld_theta, pa.sed_off, pa.sed_photscale, p.B, f, blk * pa.sed_cb, pa.sed_cb, pa.sed_mags,
+                 reinterpret_cast<unsigned char*>(hk_sm), st);
       }
     }
     return;

@@ -618,13 +618,21 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s) {
 }
 
 template <bool FUSE>
-static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s) {
+static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu = 256) {
   p.grid_m = (p.B + 31) / 32;
   p.grid_n = (p.N + 31) / 32;
   pa.n_gemm = p.grid_m * p.grid_n;
   if (!FUSE) { pa.out = nullptr; pa.sed_mags = nullptr; }
   pa.n_prep = pa.out ? (p.B + 255) / 256 : 0;
-  const int n_sed = pa.sed_mags ? pa.P.F * ((p.B + kSedCands - 1) / kSedCands) : 0;
+  int n_sed = 0;
+  if (pa.sed_mags) {
+    // candidates per photometric tile: as few as keeps F x blocks within the compute units the GEMM tiles leave idle (16..48)
+    const int idle = n_cu - pa.n_gemm - pa.n_prep, nblk = idle >= pa.P.F ? idle / pa.P.F : 1;
+    int cb = ((p.B + nblk - 1) / nblk + 15) & ~15;
+    cb = cb < 16 ? 16 : (cb > kSedCandsMax ? kSedCandsMax : cb);
+    pa.sed_cb = cb;
+    n_sed = pa.P.F * ((p.B + cb - 1) / cb);
+  }
 #ifdef PAYNE_STAMPS
   p.stamps = FUSE ? g_hidden_stamps : nullptr;
 #endif
@@ -668,7 +676,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         *sed = false;
       }
       if (last) launch_dense<64, 64, 32, true>(p, s);
-      else { launch_hidden<true>(p, pa, s); if (N.spectral) c->prep_valid = pa.out != nullptr; }
+      else { launch_hidden<true>(p, pa, s, c->n_cu); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
@@ -1302,7 +1310,8 @@ extern "C" int payne_diag_hidden_stamps(payne_ctx* c, const double* theta, int B
   HIPCHK(c, hipMalloc(&d, nb_ * 16 * 8));
   HIPCHK(c, hipMemset(d, 0, nb_ * 16 * 8));
   if (max_blocks < 0) { max_blocks = -max_blocks; g_dense_stamps = d; } else g_hidden_stamps = d;   // negative: the output layer
-  rc = run_ann(c, theta, B, 2.355, nullptr);
+  bool sed = c->has_phot;
+  rc = run_ann(c, theta, B, 2.355, nullptr, true, &sed);
   g_hidden_stamps = nullptr; g_dense_stamps = nullptr;
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(host, d, (size_t)max_blocks * 16 * 8, hipMemcpyDeviceToHost));
