@@ -259,18 +259,14 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
     thetas = [theta] + [theta.clone() for _ in range(S - 1)]
     lnls = [lnl] + [torch.empty_like(lnl) for _ in range(S - 1)]
     if shard and world > 1:
-        per = (B + world - 1) // world
-        lo, hi = min(B, rank * per), min(B, (rank + 1) * per)
-        mine = torch.full((per,), float("nan"), dtype=torch.float64, device=theta.device)
-        full = torch.empty(per * world, dtype=torch.float64, device=theta.device)
-        th_blk = theta[lo:hi].contiguous()
+        from thepayne_amd.dist import ShardedBatch
+        sb = ShardedBatch(B, rank, world, theta.device)
+        th_blk = theta[sb.lo:sb.hi].contiguous()
     torch.cuda.synchronize()
 
     def step(i):
         if shard and world > 1:
-            if hi > lo:
-                eng.lnlike_batch(th_blk, out=mine[:hi - lo])
-            dist.all_gather_into_tensor(full, mine)          # the per-iteration exchange: <= ceil(B/G) doubles per rank
+            sb.step(lambda lo, hi, out: eng.lnlike_batch(th_blk, out=out))   # the per-iteration exchange: <= ceil(B/G) doubles per rank
             return
         j = i % S
         if S == 1:
@@ -298,7 +294,7 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     if shard and world > 1:
-        lnl = torch.cat([full[r * per:r * per + max(0, min(B, (r + 1) * per) - min(B, r * per))] for r in range(world)])
+        lnl = sb.result()
     for l_ in lnls[1:]:                  # every in-flight batch evaluated the same candidates: same answers
         assert args.unchecked or bool(torch.equal(torch.nan_to_num(l_), torch.nan_to_num(lnl)))
     assert args.unchecked or int(torch.isfinite(lnl).sum()) >= B - max(4, B // 128), \

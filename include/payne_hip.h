@@ -383,6 +383,14 @@ int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* l
                          double loglstar, int walks, unsigned long long seed, double* qu, double* qv, double* ql, int* qnc,
                          int* nq, long long* stats, void* stream);
 
+/* The same in two parts: _begin returns when everything is enqueued on `stream` (nothing of its host arguments is read
+ * afterwards), _end waits for the stream and writes the queue.  Between the two the host is free: the batched sampler computes
+ * the bounding ellipsoids of its NEXT update there (thepayne_amd/sampler/nested.py, overlap_bound). */
+int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl, int nlive,
+                               int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv, double scale,
+                               double loglstar, int walks, unsigned long long seed, void* stream);
+int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats);
+
 /* How the chain steps of this sampler ran so far: out[0] at the tail of the likelihood-only post kernel (the workgroup of
  * candidate k settles chain k's proposal and draws the next one as soon as it has the likelihood), out[1] as launches of
  * their own (the first step of every walk; every step under PAYNE_V_NO_WALK_TAIL, with an LSF, or when the spectrum length

@@ -106,3 +106,47 @@ def test_two_ranks_split_one_batch_and_gather_lnl(tmp_path):
         assert np.array_equal(r0["B%d" % B], r0["ref%d" % B]) and np.array_equal(r1["B%d" % B], r0["ref%d" % B])
         per = (B + 1) // 2
         assert r0["n%d" % B].sum() == per and r1["n%d" % B].sum() == B - per      # each rank evaluated only its block
+
+
+WORKER3 = textwrap.dedent('''
+    import sys, numpy as np, torch
+    sys.path.insert(0, %r)
+    from thepayne_amd import dist as pdist
+    rank, world, _ = pdist.init_from_env("gloo")
+    out = {}
+    for B in (1, 3, 64, 67):
+        theta = torch.as_tensor(np.random.default_rng(B).normal(size=(B, 4)))
+        sb = pdist.ShardedBatch(B, rank, world, torch.device("cpu"))
+        n = []
+        def fn(lo, hi, dst):
+            n.append(hi - lo)
+            dst.copy_((theta[lo:hi] ** 2).sum(dim=1) - 1.0)
+        for it in range(3):                                  # buffers are reused: three iterations of a sampler
+            sb.step(fn)
+        out["B%%d" %% B] = sb.result().numpy()
+        out["ref%%d" %% B] = ((theta ** 2).sum(dim=1) - 1.0).numpy()
+        out["n%%d" %% B] = np.array(n)
+    np.savez(sys.argv[1] + "/sb_%%d.npz" %% rank, **out)
+    pdist.finalize()
+''') % ROOT
+
+
+def test_sharded_batch_keeps_its_buffers_over_iterations(tmp_path):
+    """bench.py --shard-batch / a sampler iteration over G ranks: ShardedBatch.step, three times, two gloo ranks."""
+    script = tmp_path / "worker3.py"
+    script.write_text(WORKER3)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-3000:]
+    r0, r1 = np.load(tmp_path / "sb_0.npz"), np.load(tmp_path / "sb_1.npz")
+    for B in (1, 3, 64, 67):
+        assert np.array_equal(r0["B%d" % B], r0["ref%d" % B]) and np.array_equal(r1["B%d" % B], r0["ref%d" % B])
+        per = (B + 1) // 2
+        assert list(r0["n%d" % B]) == [per] * 3 and list(r1["n%d" % B]) == ([B - per] * 3 if B > per else [])

@@ -47,17 +47,31 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
   const double logdfac = log(0.5 * expm1(dlv));          // ln(0.5 (X_{i-1} - X_i)) - ln X_i
   int qpos = 0, emitted = 0;
   *stop = PAYNE_NS_QUEUE_EMPTY;
-  // the maximum only ever grows (the point that leaves is the minimum), so it is tracked; the
-  // minimum is one pass over the live set per iteration
+  // the maximum only ever grows (the point that leaves is the minimum), so it is tracked; the minimum is the top of a binary
+  // heap of live-point indices ordered by (logl, index) -- the index breaks ties the way a first-minimum scan does (several -inf
+  // points at the start of a run), so the records are those of the scan, at O(log n) per dead point instead of a pass over the
+  // live set (0.5 us of the 0.76 us an iteration took at 512 live points)
   double lmax = live_logl[0];
   for (int i = 1; i < n; ++i) lmax = live_logl[i] > lmax ? live_logl[i] : lmax;
-  while (true) {
-    int worst = 0;
-    double lmin = live_logl[0];
-    for (int i = 1; i < n; ++i) {
-      const double l = live_logl[i];
-      if (l < lmin) { lmin = l; worst = i; }
+  std::vector<int> heap(n);
+  for (int i = 0; i < n; ++i) heap[i] = i;
+  auto less = [&](int a, int b) { const double la = live_logl[a], lb = live_logl[b]; return la < lb || (la == lb && a < b); };
+  auto sift = [&](int pos) {
+    const int v = heap[pos];
+    while (true) {
+      int c = 2 * pos + 1;
+      if (c >= n) break;
+      if (c + 1 < n && less(heap[c + 1], heap[c])) ++c;
+      if (!less(heap[c], v)) break;
+      heap[pos] = heap[c];
+      pos = c;
     }
+    heap[pos] = v;
+  };
+  for (int i = n / 2 - 1; i >= 0; --i) sift(i);
+  while (true) {
+    const int worst = heap[0];
+    const double lmin = live_logl[worst];
     const double delta = (s->logz > -1e299) ? logaddexp(s->logz, lmax + s->logvol) - s->logz : INFINITY;
     if (delta < dlogz) { *stop = PAYNE_NS_CONVERGED; break; }
     if (emitted >= max_emit) { *stop = PAYNE_NS_LIMIT; break; }
@@ -90,6 +104,7 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
     for (int d = 0; d < nd; ++d) { live_u[(size_t)worst * nd + d] = qu[(size_t)qpos * nd + d]; live_v[(size_t)worst * nd + d] = qv[(size_t)qpos * nd + d]; }
     live_logl[worst] = ql[qpos];
     live_it[worst] = (int)s->it;
+    sift(0);                                              // the new point (logl above the old minimum) sinks to its place
     if (ql[qpos] > lmax) lmax = ql[qpos];
     ++qpos;
     out->delta_logz[e] = logaddexp(s->logz, lmax + s->logvol) - s->logz;

@@ -974,6 +974,7 @@ struct payne_sampler {
   std::vector<int> q_start, q_ell;
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
   WalkState walk{};                       // the walk in progress
+  bool queue_open = false; int queue_K = 0; void* queue_stream = nullptr;   // payne_ns_rwalk_queue_begin .. _end
   bool tail_done = false;                 // the last likelihood batch ran the next step at its tail
   long long n_tail = 0, n_own = 0;        // chain steps at the post kernel's tail / as launches of their own
   std::vector<void*> owned;
@@ -1175,14 +1176,17 @@ extern "C" int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double*
 
 // The random-walk queue of the batched nested sampler in one call: start points, ellipsoid assignment, upload, the walk,
 // download, and the chains that moved as the proposal queue (header: payne_ns_rwalk_queue).
-extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
-                                    int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
-                                    double scale, double loglstar, int walks, unsigned long long seed, double* qu, double* qv,
-                                    double* ql, int* qnc, int* nq, long long* stats, void* stream) {
+// In two parts, so that the caller's host work (the next bound, bookkeeping of another fit) can run while the GPU walks:
+// _begin returns once everything is enqueued (start points, ellipsoid assignment, upload, walks + 1 steps, download requests),
+// _end waits for the stream and selects the chains that moved.  payne_ns_rwalk_queue is the two back to back.
+extern "C" int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
+                                          int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                                          double scale, double loglstar, int walks, unsigned long long seed, void* stream) {
   int rc = sampler_check(s, live_u, K, live_v);
   if (rc) return rc;
   payne_ctx* c = s->ctx;
-  if (!live_logl || !axes_unit || !qu || !qv || !ql || !qnc || !nq || !stats || nlive <= 0 || walks <= 0)
+  s->queue_open = false;
+  if (!live_logl || !axes_unit || nlive <= 0 || walks <= 0)
     return fail(c, PAYNE_E_INVALID, "bad payne_ns_rwalk_queue arguments");
   if (n_ell < 1 || n_ell > PAYNE_MAX_ELL || (n_ell > 1 && (!ctr || !ainv))) return fail(c, PAYNE_E_INVALID, "bad ellipsoid list");
   const int nd = s->sd.ndim;
@@ -1243,6 +1247,20 @@ extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, cons
   HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, nq_d * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(s->qi_host, s->qi_dev, (size_t)2 * K * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(s->qi_host + 2 * K, s->nredraw, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+  s->queue_open = true; s->queue_K = K; s->queue_stream = stream;
+  return PAYNE_OK;
+}
+extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats) {
+  if (!s) return PAYNE_E_INVALID;
+  payne_ctx* c = s->ctx;
+  if (!s->queue_open) return fail(c, PAYNE_E_INVALID, "payne_ns_rwalk_queue_end without a queue in flight");
+  if (!qu || !qv || !ql || !qnc || !nq || !stats) return fail(c, PAYNE_E_INVALID, "bad payne_ns_rwalk_queue_end arguments");
+  s->queue_open = false;
+  const int K = s->queue_K, nd = s->sd.ndim;
+  hipStream_t st = reinterpret_cast<hipStream_t>(s->queue_stream);
+  const double* hu = s->q_host;
+  const double* hv = hu + (size_t)K * nd;
+  const double* hl = hv + (size_t)K * nd;
   HIPCHK(c, hipStreamSynchronize(st));
   // ---- the chains that moved are the queue; a chain that never moved is a copy of a live point
   long long acc = 0, calls = 0, redraw = 0, idle_calls = 0;
@@ -1264,6 +1282,15 @@ extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, cons
   *nq = m;
   stats[0] = acc; stats[1] = calls; stats[2] = redraw; stats[3] = idle_calls;
   return PAYNE_OK;
+}
+extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
+                                    int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                                    double scale, double loglstar, int walks, unsigned long long seed, double* qu, double* qv,
+                                    double* ql, int* qnc, int* nq, long long* stats, void* stream) {
+  if (s && (!qu || !qv || !ql || !qnc || !nq || !stats)) return fail(s->ctx, PAYNE_E_INVALID, "bad payne_ns_rwalk_queue arguments");
+  const int rc = payne_ns_rwalk_queue_begin(s, live_u, live_v, live_logl, nlive, K, axes_unit, n_ell, ctr, ainv, scale, loglstar,
+                                            walks, seed, stream);
+  return rc ? rc : payne_ns_rwalk_queue_end(s, qu, qv, ql, qnc, nq, stats);
 }
 
 extern "C" int payne_bc_batch(payne_ctx* c, const double* x, int B, double* bc, void* stream) {

@@ -179,7 +179,10 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
 // phases exactly as it orders LDS.  This is the HBM/L2-bandwidth-bound regime of SURVEY.md 8(d).
 // With `tile_lds` the launch carries 2 x fft_tile_complex() complex values of dynamic LDS and the transforms
 // take the four-step form (fft_run_tiled): two round trips through the workspace per transform instead of five.
-constexpr int kBigThreads = 512;
+#ifndef PAYNE_BIG_THREADS
+#define PAYNE_BIG_THREADS 512
+#endif
+constexpr int kBigThreads = PAYNE_BIG_THREADS;
 #ifndef PAYNE_TU_BIG
 __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostTables T, PostArgs a, float* ws, int B, int tile_lds);
 #else

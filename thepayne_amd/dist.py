@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-__all__ = ["init_from_env", "shard", "gather_summaries", "fit_stars", "sharded_lnlike", "finalize"]
+__all__ = ["init_from_env", "shard", "gather_summaries", "fit_stars", "sharded_lnlike", "ShardedBatch", "finalize"]
 
 
 def init_from_env(backend=None):
@@ -112,6 +112,36 @@ def sharded_lnlike(lnlike_fn, theta, rank, world):
     dist.all_gather_into_tensor(full, mine)
     full = full.cpu().numpy().reshape(world, per)
     return np.concatenate([full[r, :max(0, min(B, (r + 1) * per) - min(B, r * per))] for r in range(world)])
+
+
+class ShardedBatch(object):
+    """The same exchange with its buffers kept (what a sampler iteration or `bench.py --shard-batch` repeats): one batch of B
+    candidates, rank r owns the contiguous block [lo, hi), `step(fn)` has `fn(lo, hi, out)` write the block's B/G
+    log-likelihoods into `out` (a float64 view on `device`) and rebuilds all B on every rank with ONE
+    all_gather_into_tensor (<= ceil(B/G) doubles per rank; RCCL over xGMI on GPUs, gloo on CPU)."""
+
+    def __init__(self, B, rank, world, device):
+        import torch
+        self.B, self.rank, self.world = int(B), int(rank), int(world)
+        self.per = (self.B + self.world - 1) // self.world
+        self.lo, self.hi = min(self.B, self.rank * self.per), min(self.B, (self.rank + 1) * self.per)
+        self.mine = torch.full((self.per,), float("nan"), dtype=torch.float64, device=device)
+        self.full = torch.empty(self.per * self.world, dtype=torch.float64, device=device)
+
+    def step(self, fn):
+        import torch.distributed as dist
+        if self.hi > self.lo:
+            fn(self.lo, self.hi, self.mine[:self.hi - self.lo])
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.full, self.mine)
+        else:
+            self.full.copy_(self.mine)
+
+    def result(self):
+        """lnL[B] (the padding of the last blocks dropped), on the device of the buffers."""
+        import torch
+        per, B = self.per, self.B
+        return torch.cat([self.full[r * per:r * per + max(0, min(B, (r + 1) * per) - min(B, r * per))] for r in range(self.world)])
 
 
 def finalize():

@@ -189,10 +189,11 @@ class DeviceProposer(object):
             self.rwalk_step(w)
         return self.rwalk_finish()
 
-    def rwalk_queue(self, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed, qbuf):
+    def rwalk_queue(self, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed, qbuf, between=None):
         """One whole queue of random-walk proposals in ONE native call (payne_ns_rwalk_queue): start points, ellipsoid
         assignment, transfers, the walk and the selection of the chains that moved.  ``qbuf`` = (qU[K, nd], qV[K, nd],
-        ql[K], qnc[K] int32) host arrays the queue is written to.  Returns (nq, accepted, calls, redrawn, idle_calls)."""
+        ql[K], qnc[K] int32) host arrays the queue is written to.  Returns (nq, accepted, calls, redrawn, idle_calls).
+        ``between``: a callable run on the host while the GPU walks (payne_ns_rwalk_queue_begin .. _end)."""
         if K > self.k_max:
             raise ValueError("K > k_max")
         ax = np.ascontiguousarray(axes_unit, dtype=np.float64)
@@ -205,10 +206,21 @@ class DeviceProposer(object):
         qU, qV, ql, qnc = qbuf
         nq = C.c_int(0)
         stats = self._qstats
-        rc = self.lib.payne_ns_rwalk_queue(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
-                                           len(live_logl), int(K), ax.ctypes.data, n_ell, cp, ap, float(scale), float(loglstar),
-                                           int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, qU.ctypes.data, qV.ctypes.data,
-                                           ql.ctypes.data, qnc.ctypes.data, C.byref(nq), stats.ctypes.data, self._stream())
+        if between is None:
+            rc = self.lib.payne_ns_rwalk_queue(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
+                                               len(live_logl), int(K), ax.ctypes.data, n_ell, cp, ap, float(scale), float(loglstar),
+                                               int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, qU.ctypes.data, qV.ctypes.data,
+                                               ql.ctypes.data, qnc.ctypes.data, C.byref(nq), stats.ctypes.data, self._stream())
+        else:
+            rc = self.lib.payne_ns_rwalk_queue_begin(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
+                                                     len(live_logl), int(K), ax.ctypes.data, n_ell, cp, ap, float(scale),
+                                                     float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, self._stream())
+            if rc == 0:
+                try:
+                    between()
+                finally:                          # (the queue in flight is always collected, whatever the host work did)
+                    rc = self.lib.payne_ns_rwalk_queue_end(self._handle, qU.ctypes.data, qV.ctypes.data, ql.ctypes.data,
+                                                           qnc.ctypes.data, C.byref(nq), stats.ctypes.data)
         if rc != 0:
             self.eng._err(rc, "payne_ns_rwalk_queue")
         return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])

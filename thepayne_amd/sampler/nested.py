@@ -118,7 +118,7 @@ class NestedSampler(object):
     def __init__(self, loglikelihood, prior_transform, ndim, nlive=500, bound='multi', sample='unif',
                  logl_args=None, bootstrap=0, walks=25, slices=5, enlarge=None, rstate=None,
                  batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None,
-                 native=True, live_points=None, loglstar=None, **ignored):
+                 native=True, live_points=None, loglstar=None, overlap_bound=None, **ignored):
         if sample not in ('unif', 'rwalk', 'slice', 'rslice'):
             raise NotImplementedError("sample=%r: this driver provides 'unif', 'rwalk', 'slice' and 'rslice'" % (sample,))
         if bound not in ('none', 'single', 'multi'):
@@ -178,6 +178,16 @@ class NestedSampler(object):
         self._native_bound = self._lib is not None
         self._axes = None
         self._ells = []
+        # overlap_bound: with random-walk proposals made on the device, the ellipsoids of the NEXT bound update are fitted on the
+        # host while the GPU walks (to the live points as they are when the walk starts: one consumed queue older than an update
+        # made at the loop's head would see).  For 'rwalk' the bound is only the proposal metric -- dynesty itself lets it age
+        # by update_interval iterations -- so nothing but a slightly staler step shape changes; 'unif' (the bound IS the
+        # sampling region) never uses it.  Default: on when the proposer can run the walk in two parts.
+        self.overlap_bound = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue")) if overlap_bound is None else bool(overlap_bound)
+        self._bound_next = None
+        self._cycle = 0                            # queues filled so far
+        self._last_m = 0                           # dead points the last consumed queue gave
+        self._m_acc = 0
         self._split_wait = 0
         self.nbound = 1
         self.update_interval = int(update_interval) if update_interval and update_interval >= 1 else max(1, int(0.6 * self.nlive))
@@ -199,6 +209,22 @@ class NestedSampler(object):
         if self.bound == 'none' and self.method == 'unif':
             self._axes = None
             return
+        if self._bound_next is not None and self._bound_next[3] == self._cycle:    # fitted while the GPU walked this cycle
+            ells, stack, split, _ = self._bound_next
+            self._bound_next = None
+            self._adopt_bound(ells, stack, split)
+            return
+        self._bound_next = None
+        ells, stack, split = self._fit_bound()
+        self._adopt_bound(ells, stack, split)
+
+    def _prefetch_bound(self):
+        """The fit of the next bound update, made on the host while the GPU walks (see overlap_bound) -- only when that update is
+        expected at the head of the next loop (as many dead points as the last queue gave would reach update_interval)."""
+        if self._since_update + self._last_m >= self.update_interval:
+            self._bound_next = self._fit_bound() + (self._cycle,)
+
+    def _fit_bound(self):
         u = self.live_u
         # the decomposition is tried at every update while it finds several ellipsoids, at every fourth one
         # while the live points keep forming a single cloud
@@ -216,13 +242,17 @@ class NestedSampler(object):
             if rc != 0:
                 raise RuntimeError("payne_ns_bound failed (%d)" % rc)
             ells = [_Ell.from_arrays(ctr[e], ax[e], au[e], ai[e], lv[e]) for e in range(ne.value)]
-            self._ell_stack = (ctr[:ne.value], au[:ne.value], ai[:ne.value])       # contiguous: handed to the native queue call
+            stack = (ctr[:ne.value], au[:ne.value], ai[:ne.value])                  # contiguous: handed to the native queue call
         else:
             whole = _Ell(u, self.enlarge)
             ells = _split_ellipsoids(u, whole, self.enlarge, [MAX_ELL]) if split else [whole]
-            self._ell_stack = tuple(np.stack([getattr(e, k) for e in ells]) for k in ("ctr", "axes_unit", "ainv"))
+            stack = tuple(np.stack([getattr(e, k) for e in ells]) for k in ("ctr", "axes_unit", "ainv"))
         if split:
             self._split_wait = 1 if len(ells) > 1 else 4
+        return ells, stack, split
+
+    def _adopt_bound(self, ells, stack, split):
+        self._ell_stack = stack
         self._ells = ells                  # (an update without a split attempt always follows a single-cloud result)
         e0 = self._ells[0]
         self._ctr, self._axes, self._axes_unit = e0.ctr, e0.axes, e0.axes_unit
@@ -277,6 +307,8 @@ class NestedSampler(object):
                 self._update_bound()
             self.ncall += nin
             return
+        self._cycle += 1
+        self._last_m, self._m_acc = self._m_acc, 0
         if self.method == 'rwalk' and hasattr(self.proposer, "rwalk_queue"):
             # the whole queue in one native call: start points, ellipsoid assignment, transfers, walk, selection
             if self._qbuf is None or len(self._qbuf[2]) < K:
@@ -284,7 +316,8 @@ class NestedSampler(object):
             ctr, au, ai = self._ell_stack
             nq, acc, calls, redrawn, idle = self.proposer.rwalk_queue(
                 self.live_u, self.live_v, self.live_logl, K, au if len(au) > 1 else au[0], ctr, ai, self.scale, lstar,
-                self.walks, int(rng.integers(0, 2 ** 62)), self._qbuf)
+                self.walks, int(rng.integers(0, 2 ** 62)), self._qbuf,
+                **({"between": self._prefetch_bound} if self.overlap_bound else {}))
             self.ncall += calls
             frac = acc / max(1, calls + redrawn)          # a redrawn (out-of-cube) proposal counts as a rejection (dynesty)
             self.scale = min(max(self.scale * math.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)
@@ -536,6 +569,7 @@ class NestedSampler(object):
                 rec["scale"] = np.full(m, self.scale)
                 self.eff = float(rec["eff"][-1])
                 self._since_update += m
+                self._m_acc += m
                 niter_here += m
                 self._chunks.append(rec)
                 yield rec
