@@ -69,10 +69,11 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
     heap[pos] = v;
   };
   for (int i = n / 2 - 1; i >= 0; --i) sift(i);
+  // delta ln Z of the state at the head of an iteration IS the delta_logz recorded at the end of the one before: computed once
+  double delta = (s->logz > -1e299) ? logaddexp(s->logz, lmax + s->logvol) - s->logz : INFINITY;
   while (true) {
     const int worst = heap[0];
     const double lmin = live_logl[worst];
-    const double delta = (s->logz > -1e299) ? logaddexp(s->logz, lmax + s->logvol) - s->logz : INFINITY;
     if (delta < dlogz) { *stop = PAYNE_NS_CONVERGED; break; }
     if (emitted >= max_emit) { *stop = PAYNE_NS_LIMIT; break; }
     if (lmin >= logl_max) { *stop = PAYNE_NS_LOGL_MAX; break; }
@@ -107,7 +108,8 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
     sift(0);                                              // the new point (logl above the old minimum) sinks to its place
     if (ql[qpos] > lmax) lmax = ql[qpos];
     ++qpos;
-    out->delta_logz[e] = logaddexp(s->logz, lmax + s->logvol) - s->logz;
+    delta = (s->logz > -1e299) ? logaddexp(s->logz, lmax + s->logvol) - s->logz : INFINITY;
+    out->delta_logz[e] = delta;
     s->it += 1;
   }
   *consumed = qpos;

@@ -104,6 +104,8 @@ struct payne_ctx {
   int lsf_chunk = 0;                    // candidates per launch (the global form walks the batch in chunks: bounded workspace)
   std::vector<void*> lsf_owned;
   bool obs_bound = false;
+  unsigned long long* fuse_cnt = nullptr;   // PAYNE_V_DENSE_FUSED: [0] ticket, [8 .. 8 + 64) hidden tiles published per 64-row block; [80] (as int) timeout flag
+  unsigned long long fuse_tickets = 0, fuse_done[64] = {0};   // running totals of those counters (host side)
   CandState* prep = nullptr;      // [b_max] per-candidate records of the post kernel (written by the first dense launch)
   bool prep_valid = false;        // ... as of the last run_ann
   // photometry
@@ -346,6 +348,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
+    if ((opts->variant & PAYNE_V_DENSE_FUSED) && (rc = dev_alloc(c, (size_t)96, &c->fuse_cnt, c->owned))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
       if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
@@ -554,6 +557,7 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
+  set(reinterpret_cast<const void*>(payne_dense_fused_kernel<4>), d3_lds_bytes<4>());
   return e;
 }
 
@@ -652,6 +656,50 @@ struct NetRef {
 // `sed`: a joint likelihood's photometric nets ride in the first hidden-layer launch (sed_tile); *sed is cleared when they did.
 static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, double instr_factor, hipStream_t s, bool* sed = nullptr) {
   const int n = N.n_layers;
+  // PAYNE_V_DENSE_FUSED: the hidden layers and the output layer of a 3-layer net in ONE launch (payne_dense_fused_kernel)
+  if (N.spectral && n == 3 && c->fuse_cnt && out_dma3_ok(c, B, N.layers[2].n_out) && c->w_out_kp == 320 && N.layers[1].n_in <= HK_KC &&
+      N.n_labels <= 4 && (B % 64) == 0 && !(sed && *sed && sed_tile_ok(c->P.H) && !(c->opts.variant & PAYNE_V_SED_OWN_LAUNCH))) {
+    const payne_layer &L0 = N.layers[0], &L1 = N.layers[1], &L2 = N.layers[2];
+    DenseParams ph{}, po{};
+    ph.W = L1.w; ph.K = L1.n_in; ph.bias = L1.b; ph.N = L1.n_out; ph.B = B; ph.act = L1.act; ph.bias_shift = 0.f;
+    ph.Y = N.hid[0]; ph.ldy = N.ld_hid;
+    ph.Yp = c->hid_p3; ph.plane_y = (size_t)c->opts.b_max * c->ld_hid; ph.ldp = c->ld_hid;
+    ph.theta = theta; ph.ld_theta = c->ncols;
+    ph.W0 = L0.w; ph.b0 = L0.b; ph.n_labels = N.n_labels; ph.act0 = L0.act; ph.K0 = L0.n_out;
+    for (int d = 0; d < N.n_labels; ++d) { ph.xmin[d] = N.xmin[d]; ph.xden[d] = N.xden[d]; }
+    ph.grid_m = (B + 31) / 32; ph.grid_n = (ph.N + 31) / 32;
+    po.K = L2.n_in; po.bias = L2.b; po.N = L2.n_out; po.B = B; po.act = L2.act; po.bias_shift = N.out_shift;
+    po.Y = N.out; po.ldy = N.ld_out;
+    po.k_real = po.K; po.K = c->w_out_kp;
+    po.Wp = c->w_out_p3; po.plane_w = (size_t)po.N * c->w_out_kp;
+    po.Xp = c->hid_p3; po.plane_x = (size_t)c->opts.b_max * c->ld_hid; po.ldp = c->ld_hid;
+    po.grid_m = (B + 63) / 64; po.grid_n = (po.N + 127) / 128;
+    const int grid = po.grid_m * po.grid_n;
+    if (grid <= c->n_cu && po.grid_m <= 64) {
+      PrepArgs pa{};
+      pa.T = c->T; pa.instr_factor = instr_factor;
+      pa.out = (c->prep && c->obs_bound && !(c->opts.variant & PAYNE_V_NO_PREP)) ? c->prep : nullptr;
+      FuseSync fs{};
+      fs.ticket = c->fuse_cnt; fs.done = c->fuse_cnt + 8;
+      fs.ticket_base = c->fuse_tickets;
+      for (int rb = 0; rb < 64; ++rb) fs.done_target[rb] = c->fuse_done[rb] + (rb < po.grid_m ? (unsigned long long)(2 * ph.grid_n) : 0ull);
+      fs.n_hid = ph.grid_m * ph.grid_n; fs.n_prep = pa.out ? (B + 511) / 512 : 0;
+      fs.timeout = reinterpret_cast<int*>(c->fuse_cnt + 80);
+      if (fs.n_hid + fs.n_prep <= grid) {
+        c->fuse_tickets += (unsigned long long)grid;
+        for (int rb = 0; rb < po.grid_m; ++rb) c->fuse_done[rb] += (unsigned long long)(2 * ph.grid_n);
+#ifdef PAYNE_STAMPS
+        po.stamps = g_dense_stamps; ph.stamps = nullptr;
+#endif
+        ProfScope ps(c, s, 0);
+        PAYNE_LAUNCH((payne_dense_fused_kernel<4>), dim3(grid), dim3(512), d3_lds_bytes<4>(), s, ph, pa, po, fs);
+        c->prep_valid = pa.out != nullptr;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("fused dense launch: ") + hipGetErrorString(e));
+        return PAYNE_OK;
+      }
+    }
+  }
   for (int l = 1; l < n; ++l) {
     DenseParams p{};
     const payne_layer& L = N.layers[l];
