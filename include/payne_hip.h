@@ -126,6 +126,8 @@ typedef struct payne_opts {
 #define PAYNE_V_DENSE_FUSED 32768u /* hidden layers + output layer in ONE launch: output-layer workgroups take the hidden tiles on first
                                     * (roles by ticket), publish them write-through and hand them over through agent-scope counters
                                     * (3-layer nets of equal hidden width <= 320, batch a multiple of 64, one output tile per CU) */
+#define PAYNE_V_BIG_WORKSPACE 65536u /* 65 536-point spectra: both convolution stages through the global workspace (the four-step transform: what
+                                      * other lengths above 16 384 use) instead of on the compute unit */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -82,6 +82,7 @@ struct payne_ctx {
   float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
   int big_grid = 0;
   bool big_tiled = false;             // ... with the four-step transform (LDS tile attribute set at create)
+  bool big_chip = false;              // ... or with the convolution stages on the compute unit (65 536 points: payne_post_chip_kernel)
   // optional continuum network (payne_ctx_set_continuum; ystpred.py:81-85, 191-209)
   bool has_cont = false;
   int cn_layers = 0, cn_npix = 0, cn_ld_hid = 0;
@@ -353,6 +354,13 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
       if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
       c->big_tiled = !(opts->variant & PAYNE_V_BIG_PLAIN);
+      // 65 536-point spectra on a geometric grid: the convolution stages stay on the compute unit (payne_post_chip_kernel)
+      c->big_chip = T.n1 == kChipN1 && c->H.geo && !(opts->variant & (PAYNE_V_BIG_PLAIN | PAYNE_V_BIG_FUSED | PAYNE_V_BIG_WORKSPACE));
+      if (c->big_chip) {
+        he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_chip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kChipLdsBytes);
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute(chip): ") + hipGetErrorString(he)));
+      }
       if (c->big_tiled) {
         he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(2 * fft_tile_complex() * sizeof(c32)));
@@ -875,7 +883,10 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   if (tail && lean && c->lean_available) { a.tail = tail->dev; a.tail_step = tail->step; a.tail_propose = tail->propose; tail->done = true; }
   {
     ProfScope ps(c, s, 1);
-    if (c->big_ws) {
+    if (c->big_ws && c->big_chip) {
+      const int grid = B < c->big_grid ? B : c->big_grid;
+      PAYNE_LAUNCH(payne_post_chip_kernel, dim3(grid), dim3(kChipThreads), kChipLdsBytes, s, c->T, a, c->big_ws, B);
+    } else if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
       const int tiled = (c->big_tiled ? 1 : 0) | ((c->opts.variant & PAYNE_V_BIG_FUSED) ? 2 : 0);
       const size_t lds = (tiled & 1) ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
@@ -1409,7 +1420,10 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
   a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
   a.stamp_sparse = getenv("PAYNE_DIAG_SPARSE") ? 1 : 0;
-  if (c->big_ws) {                                         // spectra larger than LDS (PAYNE_BIG_TILED=0: plain passes)
+  if (c->big_ws && c->big_chip) {
+    const int grid = B < c->big_grid ? B : c->big_grid;
+    hipLaunchKernelGGL(payne_post_chip_kernel, dim3(grid), dim3(kChipThreads), kChipLdsBytes, nullptr, c->T, a, c->big_ws, B);
+  } else if (c->big_ws) {                                  // spectra larger than LDS (PAYNE_BIG_TILED=0: plain passes)
     const int grid = B < c->big_grid ? B : c->big_grid;
     const int tiled = c->big_tiled ? 1 : 0;
     const size_t lds = tiled ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;

@@ -5,6 +5,7 @@
 #pragma once
 #include "select.hpp"
 #include "sampler_core.hpp"
+#include "post_onchip.hpp"
 
 // ============================================================================
 // per-candidate spectrum pipeline
@@ -220,6 +221,70 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   }
 }
 
+#endif
+
+// The same walk of the batch with each convolution stage of a 65 536-point spectrum kept on the compute unit (post_onchip.hpp):
+// 512 threads, the stage's 32 768 complex points in registers, 128 KB of LDS as the transpose buffer.  The phases around the
+// two stages (mask window, resampling, observed grid, chi^2) are the global-workspace phases of payne_post_big_kernel; a
+// candidate whose instrumental window needs a shorter transform takes that kernel's runtime-geometry passes for that stage.
+struct ChipExec : DevExecT<false, false> {
+#ifdef __HIP_DEVICE_COMPILE__
+  ChipLds L;
+#endif
+};
+namespace payne { template <> struct ex_chip<ChipExec> { static constexpr bool value = true; }; }
+#ifdef __HIP_DEVICE_COMPILE__
+namespace payne {
+template <bool VSINI, class Ex>
+PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0) {
+  if constexpr (ex_chip<Ex>::value) {
+    chip_conv<VSINI>(ex.L, src0 ? src0 : work, work, ta, src0 != nullptr, edge, (int)threadIdx.x);
+    ex.mark(0);
+    edge = false;
+  }
+  return work;
+}
+}  // namespace payne
+#endif
+#ifndef PAYNE_TU_BIG
+__global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const PostTables T, PostArgs a, float* ws, int B);
+#else
+__global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const PostTables T, PostArgs a, float* ws, int B) {
+#ifdef __HIP_DEVICE_COMPILE__
+  __shared__ double red[kChipThreads + kChipThreads / 2 + 2];
+  __shared__ CandState S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chip_sm[];
+  float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
+  float* bufB = bufA + T.n1;
+  ChipExec ex;
+  ex.L = chip_lds(chip_sm);
+  chip_fill_tables(ex.L, T.tw, (int)threadIdx.x);
+  __syncthreads();
+  double* chi2 = red + scratch_doubles(kChipThreads) - 1;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+#ifdef PAYNE_STAMPS
+    if (a.stamps) {                                        // diagnostic build: cycle stamps of every candidate's phases
+      ex.stamps = a.stamps + (size_t)b * kStampRow;
+      if (threadIdx.x == 0) ex.stamps[1] = __builtin_amdgcn_s_memtime();
+      ex.nst = 1;
+    }
+#endif
+    run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+                           a.raw + (size_t)b * a.ld_raw, bufA, bufB, S, red,
+                           a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
+                           a.prep ? a.prep + b : nullptr);
+    if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
+      double x2 = *chi2;
+      if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+      a.lnl[b] = -0.5 * x2;
+    }
+#ifdef PAYNE_STAMPS
+    if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
+#endif
+    __syncthreads();
+  }
+#endif
+}
 #endif
 
 // ============================================================================

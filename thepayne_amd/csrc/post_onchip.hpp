@@ -1,0 +1,326 @@
+// post_onchip.hpp -- one FFT convolution stage of a 65 536-pixel spectrum WITHOUT leaving the compute unit.
+//
+// payne_post_big_kernel keeps the two spectrum buffers of a candidate in a global workspace; its four-step transforms move
+// the 256 KB spectrum through that workspace twelve times per convolution stage (25 transfers per candidate in all: the
+// HBM / L2-bound regime of SURVEY 8(d)).  Here the 32 768 complex points z[n] = s[2n] + i s[2n+1] of a stage live in the
+// REGISTERS of the workgroup from the load of the stage's input to the store of its output, and LDS (128 KB) is only the
+// transpose buffer between the three radix-32 register stages of a transform.  The algorithm is written for 1024 "virtual
+// threads" of 32 points each; a 512-thread workgroup runs two of them per thread (t and t + 512: 128 of its 256 registers hold
+// data -- 1024 real threads would have 128 registers each, and the compiler spills two hundred of them):
+//
+//   n = t + 1024 a   (thread t = 32 h + l, register a)                                      [layout L0]
+//   S1: DFT_32 over a -> k1        T1: x W_32768^(t k1)         X1: (h, l; reg k1)  <-> (k1, l; reg h)
+//   S2: DFT_32 over h -> k2a       T2: x W_1024^(l k2a)         X2: (h, l; reg k2a) <-> (h, k2a; reg l)
+//   S3: DFT_32 over l -> k2b       => thread (k1, k2a), register k2b holds Z[k], k = k1 + 32 k2a + 1024 k2b
+//   P : the partner of thread low = k1 + 32 k2a is thread 1024 - low (register 31 - k2b): each sends half of its
+//       registers, so every conjugate pair (k, M - k) meets in one thread, which applies the taper and the real-FFT
+//       split / merge (taper_pair of post_core.hpp) and sends the partner's half back
+//   then the TRANSPOSED transform (the DFT matrix is symmetric): S3, X2, T2, S2, X1, T1, S1 -> layout L0, conjugate.
+//
+// X1 / X2 are 32 x 32 transposes between the register index and a digit of the thread index; done in two rounds of 16
+// registers chosen by the PARITY of that digit ((q + h) & 1), each thread sends sixteen registers and receives sixteen into
+// the same slots: 64 VGPRs of data at every moment, 128 KB of LDS per round.  Global traffic of a stage: its input once, its
+// output once.  Twiddles: W_65536^j from two LDS tables (j >> 6: 1024 entries, j & 63: 64 entries), one complex product.
+// Device code only (included by post_kernels.hpp under PAYNE_TU_BIG).
+#pragma once
+namespace payne {
+constexpr int kChipThreads = 512;                  // real threads; kChipVT virtual ones
+constexpr int kChipVT = 1024;
+constexpr int kChipM = 32768;                      // complex points of a stage (n1 = 65536 real)
+constexpr int kChipXch = 16 * 1024;                // complex slots of an exchange round
+constexpr size_t kChipLdsBytes = (size_t)kChipXch * 8 + 1024 * 8 + 64 * 8;   // exchange buffer | W_1024 | W_65536 (fine)
+}
+#ifdef __HIP_DEVICE_COMPILE__
+
+namespace payne {
+
+struct ChipLds {             // (LDS address space in the pointer types: ds_read / ds_write, not flat accesses)
+  PAYNE_AS_LDS f2v* xch;     // [16][32][32]
+  PAYNE_AS_LDS f2v* w1024;   // exp(-2 pi i j / 1024), j < 1024
+  PAYNE_AS_LDS f2v* wfine;   // exp(-2 pi i j / 65536), j < 64
+};
+__device__ __forceinline__ ChipLds chip_lds(unsigned char* base) {
+  ChipLds L;
+  L.xch = (PAYNE_AS_LDS f2v*)base;
+  L.w1024 = L.xch + kChipXch;
+  L.wfine = L.w1024 + 1024;
+  return L;
+}
+// the two tables from the context's full-circle table tw[j] = exp(-2 pi i j / 65536) (every thread a share; barrier by the caller)
+__device__ __forceinline__ void chip_fill_tables(const ChipLds& L, const c32* __restrict__ tw, int tid) {
+  for (int j = tid; j < 1024; j += kChipThreads) stc(L.w1024, j, tw[64 * j]);
+  if (tid < 64) stc(L.wfine, tid, tw[tid]);
+}
+
+__device__ __forceinline__ c32 chip_w65536(const ChipLds& L, int e) {           // exp(-2 pi i e / 65536), 0 <= e < 65536
+  const c32 a = ldc(L.w1024, (e >> 6) & 1023), b = ldc(L.wfine, e & 63);
+  return cmul(a, b);
+}
+
+// Every value of a thread's share named at this point of the instruction stream: computations are neither sunk past it nor
+// pulled above it (without it the compiler carries the twiddle products of a stage into the exchange that follows and keeps
+// a hundred table values alive meanwhile: 326 registers spilled in the forward transform alone).
+__device__ __forceinline__ void chip_pin(c32 (&u)[32]) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(u[i].x), "+v"(u[i].y));
+}
+
+// ---- DFT_32 in registers (natural order in, natural order out; forward sign) --------------------------------
+//   X[k1 + 4 k2] = sum_a2 W32^(a2 k1) [ sum_a1 x[8 a1 + a2] W4^(a1 k1) ] W8^(a2 k2)
+__device__ __forceinline__ void chip_dft32(c32 (&u)[32]) {
+  // (scheduling fences between the pieces: 64 of the 128 registers a thread has hold the data; left alone the scheduler
+  //  pulls every table read of a stage forward and spills two hundred registers)
+#pragma unroll
+  for (int a2 = 0; a2 < 8; ++a2) { dft4(u[a2], u[a2 + 8], u[a2 + 16], u[a2 + 24]); if (a2 & 1) __builtin_amdgcn_sched_barrier(0); }   // -> index k1 at a2 + 8 k1
+  // W32^m, m = a2 k1 (k1 = 1..3, a2 = 1..7)
+  constexpr float C[22] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                           0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f,
+                           -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                           -0.92387953251128675613f, -0.98078528040323044913f, -1.0f, -0.98078528040323044913f, -0.92387953251128675613f,
+                           -0.83146961230254523708f, -0.70710678118654752440f, -0.55557023301960222474f};
+  constexpr float S[22] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                           0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.0f, 0.98078528040323044913f,
+                           0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                           0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                           -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f};
+#pragma unroll
+  for (int k1 = 1; k1 < 4; ++k1)
+#pragma unroll
+    for (int a2 = 1; a2 < 8; ++a2) {
+      const int m = a2 * k1;                                     // <= 21
+      const c32 w = {C[m], -S[m]};                               // exp(-2 pi i m / 32)
+      u[a2 + 8 * k1] = cmul(u[a2 + 8 * k1], w);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  c32 v[32];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    dft8(&u[8 * k1]);                                            // -> k2 at 8 k1 + k2
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[k1 + 4 * k2] = u[8 * k1 + k2];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) u[k] = v[k];
+}
+
+// ---- the two transposes (each its own inverse) -----------------------------------------------------------------
+// HI: (h, l; reg r) <-> (r, l; reg h).  Round q: the registers of parity (q + h) & 1 travel: send, workgroup barrier, receive,
+// barrier (the barriers are the caller's: it runs two virtual threads between them).
+// (the thread index is laundered at every use: the exchanges' LDS addresses are otherwise computed once for all of them and
+//  kept in a hundred registers from the first exchange to the last)
+__device__ __forceinline__ int chip_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+template <bool HI>
+__device__ __forceinline__ void chip_xch_send(const ChipLds& L, const c32 (&u)[32], int vt_, int q) {
+  const int vt = chip_fresh(vt_);
+  const int h = vt >> 5, l = vt & 31;
+  const int d = HI ? h : l;                                      // the digit that trades places with the register index
+  const bool odd = ((q + d) & 1) != 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const c32 e = u[2 * j], o = u[2 * j + 1];
+    const c32 v = {odd ? o.x : e.x, odd ? o.y : e.y};              // register r = 2 j + parity
+    // HI: [j][h][l];  LO: [h][j][l ^ 2 j] (the reader's lanes differ in j: the XOR spreads them over the banks)
+    const int idx = HI ? ((j * 32 + h) * 32 + l) : ((h * 16 + j) * 32 + (l ^ (2 * j)));
+    stc(L.xch, idx, v);
+  }
+}
+template <bool HI>
+__device__ __forceinline__ void chip_xch_recv(const ChipLds& L, c32 (&u)[32], int vt_, int q) {
+  const int vt = chip_fresh(vt_);
+  const int h = vt >> 5, l = vt & 31;
+  const int d = HI ? h : l;
+  const bool odd = ((q + d) & 1) != 0;
+  const int J = d >> 1;                                          // the slot the senders used for register r = d
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int s = 2 * j + (odd ? 1 : 0);                         // the sender's digit (the parity class this thread just sent)
+    const int idx = HI ? ((J * 32 + s) * 32 + l) : ((h * 16 + J) * 32 + (s ^ (2 * J)));
+    const c32 v = ldc(L.xch, idx);
+    // (selects, not a branch around the store: a conditional store keeps the whole array in scratch memory)
+    const c32 e = u[2 * j], o = u[2 * j + 1];
+    u[2 * j] = {odd ? e.x : v.x, odd ? e.y : v.y};
+    u[2 * j + 1] = {odd ? v.x : o.x, odd ? v.y : o.y};
+  }
+}
+template <bool HI>
+__device__ __forceinline__ void chip_xch(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    chip_xch_send<HI>(L, u0, tid, q);
+    __builtin_amdgcn_sched_barrier(0);
+    chip_xch_send<HI>(L, u1, tid + kChipThreads, q);
+    __syncthreads();
+    chip_xch_recv<HI>(L, u0, tid, q); chip_pin(u0);
+    chip_xch_recv<HI>(L, u1, tid + kChipThreads, q); chip_pin(u1);
+    __syncthreads();
+  }
+}
+
+// ---- twiddles between the stages -----------------------------------------------------------------------------
+__device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int tid_) {    // x W_32768^(t k1) = W_65536^(2 t k1)
+  const int tid = chip_fresh(tid_);
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) {
+    u[k1] = cmul(u[k1], chip_w65536(L, (2 * tid * k1) & 65535));
+    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);        // four twiddles (eight table reads) in flight at a time
+  }
+}
+__device__ __forceinline__ void chip_tw2(const ChipLds& L, c32 (&u)[32], int tid_) {    // x W_1024^(l k2a)
+  const int l = chip_fresh(tid_) & 31;
+#pragma unroll
+  for (int k = 1; k < 32; ++k) {
+    u[k] = cmul(u[k], ldc(L.w1024, (l * k) & 1023));
+    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// natural (layout L0) -> spectrum (thread (k1, k2a), reg k2b) and back (transposed order: the same operators); two virtual threads
+__device__ __forceinline__ void chip_fft_fwd(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid) {
+  const int t1 = tid + kChipThreads;
+  chip_dft32(u0); chip_pin(u0); chip_tw1(L, u0, tid); chip_pin(u0); chip_dft32(u1); chip_pin(u1); chip_tw1(L, u1, t1); chip_pin(u1);
+  chip_xch<true>(L, u0, u1, tid);
+  chip_dft32(u0); chip_pin(u0); chip_tw2(L, u0, tid); chip_pin(u0); chip_dft32(u1); chip_pin(u1); chip_tw2(L, u1, t1); chip_pin(u1);
+  chip_xch<false>(L, u0, u1, tid);
+  chip_dft32(u0); chip_pin(u0); chip_dft32(u1); chip_pin(u1);
+}
+__device__ __forceinline__ void chip_fft_back(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid) {
+  const int t1 = tid + kChipThreads;
+  chip_dft32(u0); chip_pin(u0); chip_dft32(u1); chip_pin(u1); chip_xch<false>(L, u0, u1, tid);
+  chip_tw2(L, u0, tid); chip_pin(u0); chip_dft32(u0); chip_pin(u0); chip_tw2(L, u1, t1); chip_pin(u1); chip_dft32(u1); chip_pin(u1);
+  chip_xch<true>(L, u0, u1, tid);
+  chip_tw1(L, u0, tid); chip_pin(u0); chip_dft32(u0); chip_pin(u0); chip_tw1(L, u1, t1); chip_pin(u1); chip_dft32(u1); chip_pin(u1);
+}
+
+// ---- the convolution's middle: conjugate pairs, taper, real-FFT split / merge ------------------------------------
+// In: thread (h = k1, l = k2a), register r = k2b holds Z[k], k = h + 32 l + 1024 r.  Out: the same layout holds Y with
+// FFT_M(Y) = conj(z'), z' the packed smoothed spectrum (rfft_taper_phase of post_core.hpp, same arithmetic per pair).
+struct ChipPair { int low, pt, sh; bool t0; };
+__device__ __forceinline__ ChipPair chip_pair(int vt_) {
+  const int vt = chip_fresh(vt_);
+  ChipPair p;
+  const int h = vt >> 5, l = vt & 31;
+  p.low = h + 32 * l;
+  const int plow = (1024 - p.low) & 1023;
+  p.pt = 32 * (plow & 31) + (plow >> 5);                           // the partner's (virtual) thread index (itself for low = 0 and 512)
+  p.t0 = vt == 0;                                                  // thread 0 (k = 1024 r) pairs r with 32 - r; r = 0 and 16 pair with themselves
+  p.sh = p.t0 ? 1 : 0;
+  return p;
+}
+// round 1: the upper half of the registers goes to the partner (slot j = register 16 + j)
+__device__ __forceinline__ void chip_taper_send1(const ChipLds& L, const c32 (&u)[32], int vt_) {
+  const int vt = chip_fresh(vt_);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) stc(L.xch, j * 1024 + vt, u[16 + j]);
+}
+template <bool VSINI>
+__device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32], int vt, const TaperArgs& ta) {
+  constexpr int M = kChipM;
+  const float invM = 1.0f / (float)M, g = 0.25f * invM;
+  const ChipPair P = chip_pair(vt);
+  const c32 z0 = u[0];                                             // thread 0: Z[0] (holds the real bins X[0] and X[M])
+  const c32 zh = ldc(L.xch, vt);                                   // thread 0: Z[M/2] (its register 16, slot 0)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int slot = 15 - r + P.sh;                                      // the partner's register 31 - r (thread 0: 32 - r)
+    slot = slot > 15 ? 15 : slot;                                  // (thread 0, r = 0: not a pair, the value is not used)
+    u[16 + r] = ldc(L.xch, slot * 1024 + P.pt);
+  }
+  // the pairs (k, M - k), k = low + 1024 r, r < 16: taper and real-FFT split / merge
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k0 = P.low + 1024 * r;
+    const int k = (k0 == 0) ? 1 : k0;                              // (k = 0 is replaced below; keep its lane's arithmetic ordinary)
+    const float tk = taper_full<VSINI>(ta, k), tm = taper_full<VSINI>(ta, M - k);
+    const c32 w = chip_w65536(L, k);                               // exp(-2 pi i k / 2M)
+    c32 yk, ym;
+    taper_pair(u[r], u[16 + r], w, tk * g, tm * g, yk, ym);
+    u[r] = yk; u[16 + r] = ym;
+    asm volatile("" : "+v"(u[r].x), "+v"(u[r].y), "+v"(u[16 + r].x), "+v"(u[16 + r].y));
+    __builtin_amdgcn_sched_barrier(0);                             // one pair (two taper values) at a time
+  }
+  if (P.t0) {                                                      // the self-conjugate bins (rfft_taper_phase, same statements)
+    const float tM = taper_full<VSINI>(ta, M), th = taper_full<VSINI>(ta, M / 2);
+    const float x0 = z0.x + z0.y, xm = tM * (z0.x - z0.y);
+    u[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+    u[16] = cscale(cconj(zh), th * invM);                          // (Y[M/2]: parked in the slot that round 2 skips for thread 0)
+  }
+}
+// round 2: the partner's halves of the pairs go back (slot r = the pair index of the thread that computed it)
+__device__ __forceinline__ void chip_taper_send2(const ChipLds& L, const c32 (&u)[32], int vt_) {
+  const int vt = chip_fresh(vt_);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stc(L.xch, r * 1024 + vt, u[16 + r]);
+}
+__device__ __forceinline__ void chip_taper_recv2(const ChipLds& L, c32 (&u)[32], int vt) {
+  const ChipPair P = chip_pair(vt);
+  const c32 yh = u[16];                                            // thread 0: Y[M/2]
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {                                   // my register 16 + j was the partner's pair 31 - (16 + j) = 15 - j
+    int slot = 15 - j + P.sh;                                      // (thread 0: 32 - (16 + j) = 16 - j; j = 0 is Y[M/2])
+    slot = slot > 15 ? 15 : slot;
+    u[16 + j] = ldc(L.xch, slot * 1024 + P.pt);
+  }
+  if (P.t0) u[16] = yh;
+}
+template <bool VSINI>
+__device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid, const TaperArgs& ta) {
+  const int t1 = tid + kChipThreads;
+  chip_taper_send1(L, u0, tid); chip_taper_send1(L, u1, t1);
+  __syncthreads();
+  chip_taper_pairs<VSINI>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI>(L, u1, t1, ta); chip_pin(u1);
+  __syncthreads();
+  chip_taper_send2(L, u0, tid); chip_taper_send2(L, u1, t1);
+  __syncthreads();
+  chip_taper_recv2(L, u0, tid); chip_pin(u0); chip_taper_recv2(L, u1, t1); chip_pin(u1);
+  __syncthreads();
+}
+
+// ---- one stage: input (real, global) -> registers -> convolution -> output (real, global) -------------------------
+// scrub: NaN -> 0 on the way in (nan_to_num of the shifted flux, smoothing.py:138: the raw row); edge: spec[0] = spec[1],
+// spec[-1] = spec[-2] on the way out (ystpred.py:223-224).  Every thread of the 1024 takes part (barriers inside).
+// (a CALL: the stage needs 224 of the 256 registers a thread has; inlined into the candidate's phase sequence, what that keeps
+//  alive around it costs three hundred spills)
+template <bool VSINI>
+__device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* __restrict__ in, float* __restrict__ out, const TaperArgs ta,
+                                                    bool scrub, bool edge, int tid) {
+  typedef float f2g __attribute__((ext_vector_type(2)));
+  const PAYNE_AS_GLOBAL f2g* g = (const PAYNE_AS_GLOBAL f2g*)in;
+  const int t1 = tid + kChipThreads;
+  c32 u0[32], u1[32];
+  // (uniform base + the thread's 32-bit offset: the 64 addresses live in scalar registers, not in 128 vector ones)
+#pragma unroll
+  for (int a = 0; a < 32; ++a) {
+    const PAYNE_AS_GLOBAL f2g* ga = g + 1024 * a;
+    const PAYNE_AS_GLOBAL f2g* gb = g + 1024 * a + kChipThreads;
+    const f2g v = ga[tid], w = gb[tid];
+    u0[a] = {v.x, v.y}; u1[a] = {w.x, w.y};
+  }
+  if (scrub) {
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+      u0[a] = {nan_to_zero(u0[a].x), nan_to_zero(u0[a].y)};
+      u1[a] = {nan_to_zero(u1[a].x), nan_to_zero(u1[a].y)};
+    }
+  }
+  chip_pin(u0); chip_pin(u1);
+  chip_fft_fwd(L, u0, u1, tid);
+  chip_taper<VSINI>(L, u0, u1, tid, ta);
+  chip_fft_back(L, u0, u1, tid);
+  chip_pin(u0); chip_pin(u1);
+  PAYNE_AS_GLOBAL f2g* o = (PAYNE_AS_GLOBAL f2g*)out;
+#pragma unroll
+  for (int a = 0; a < 32; ++a) {
+    f2g v, w;                                                      // z' = conj(FFT(Y))
+    v.x = u0[a].x; v.y = -u0[a].y; w.x = u1[a].x; w.y = -u1[a].y;
+    if (edge && a == 0 && tid == 0) v.x = v.y;                     // element 0     = (spec[0], spec[1])
+    if (edge && a == 31 && t1 == kChipVT - 1) w.y = w.x;           // element M - 1 = (spec[n-2], spec[n-1])
+    PAYNE_AS_GLOBAL f2g* oa = o + 1024 * a;
+    PAYNE_AS_GLOBAL f2g* ob = o + 1024 * a + kChipThreads;
+    oa[tid] = v; ob[tid] = w;
+  }
+  __syncthreads();                                                 // (one CU, one L1: the next phase of this workgroup reads what was just written)
+}
+
+}  // namespace payne
+#endif

@@ -146,6 +146,13 @@ PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsign
   return fft_fixed_passes<M, 1, NT>(ex, s, d, Ex::twid(twf), sign_last, edge) == s ? src : dst;
 }
 
+// Executors that keep a 65 536-point stage on the compute unit (post_onchip.hpp: the spectrum in registers, LDS as the
+// transpose buffer) say so through this trait; their convolution stage is chip_conv_stage (post_kernels.hpp).
+constexpr int kChipN1 = 65536;
+template <class Ex> struct ex_chip { static constexpr bool value = false; };
+template <bool VSINI, class Ex>
+PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0);
+
 // One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
 // `twf`: pass-ordered table of the fixed geometry (LDS or global); T.tw: plain full circle.
 // `edge` in: the caller wants spec[0]=spec[1], spec[-1]=spec[-2] applied to the result;
@@ -154,6 +161,9 @@ template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
                             const TaperArgs& ta, bool& edge, const float* src0 = nullptr) {
   const int M = n / 2;
+  if constexpr (ex_chip<Ex>::value) {
+    if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0);
+  }
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
@@ -192,9 +202,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   // of its own at the start of every workgroup); only the fused four-step form needs it before.
   const bool maybe_direct = (out_stage != 0) && T.rot_identity;
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
-  constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : 16;
+  constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : (NT >= 1024 ? 8 : 16);   // (1024 threads: 128 registers each)
   // global-workspace executor with the four-step transform: the first pass of the vsini transform reads the row itself
-  const bool may_fuse = maybe_direct && ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2) && row_vectorised(T.npix, raw);
+  const bool may_fuse = maybe_direct && row_vectorised(T.npix, raw) &&
+                        ((ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2)) || (ex_chip<Ex>::value && T.n1 == kChipN1));
   bool direct = may_fuse ? (th[5] != 0.0) : false;
   const bool fused_row = may_fuse && direct;
   ex.par([&](int t, int n) {

@@ -4,7 +4,7 @@ import ctypes as C, os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from thepayne_amd import build
-os.environ["PAYNE_HIP_LIB"] = build.build_diag()
+os.environ["PAYNE_HIP_LIB"] = os.environ.get("STAMP_LIB") or build.build_diag()
 from thepayne_amd import synth, nnio
 from thepayne_amd.engine import PayneEngine
 cfg = synth.CONFIGS["C5"]
