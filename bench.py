@@ -340,7 +340,8 @@ def roofline_blocks(cfg_name, res, args):
         alg8 = (W["bytes_batch"] / B + 8 * 4.0 * N) * B
         t = max(per[dom], 1e-9) * 1e-6
         ach = alg8 / t / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
+        chip = n1 == 65536 and not (args.variant & (32 | 256 | 65536))
+        out["roofline"] = {"bound": "hbm", "kernel": "payne_post_chip_kernel" if chip else "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic["post"],
                            "traffic_source": tsrc,
                            "alg_bytes_per_launch": alg8,
@@ -538,11 +539,15 @@ def main():
 
 
 def eng_round_trips(n1, variant=0):
-    """Transfers of the spectrum (4 n1 bytes each, a read or a write) through the global workspace per evaluation in
-    payne_post_big_kernel: the row in and its copy out (2), per convolution stage the forward and the inverse
-    transform at 2 transfers per pass (the four-step form has 2 passes, the plain form one per radix-8 pass) + the taper
-    pass (2), the resampling pass between the stages (2) and the closing interpolation read (1)."""
+    """Transfers of the spectrum (4 n1 bytes each, a read or a write) per evaluation.  payne_post_chip_kernel (65 536 points,
+    DESIGN.md 3.4b): the raw row in (1), the rotation stage's result out (1), the instrumental stage's gather of it (1), its
+    result out (1), the observed grid's gather (1) = 5.  payne_post_big_kernel (other lengths above 16 384, or
+    PAYNE_V_BIG_WORKSPACE): the row in and its copy out (2), per convolution stage the forward and the inverse transform at 2
+    transfers per pass (the four-step form has 2 passes, the plain form one per radix-8 pass) + the taper pass (2), the resampling
+    pass between the stages (2) and the closing interpolation read (1)."""
     import numpy as np
+    if n1 == 65536 and not (variant & (32 | 256 | 65536)):
+        return 5
     M = n1 // 2
     tiled = (M % 512 == 0) and (M // 512 in (32, 64, 128)) and not (variant & 32)
     per_fft = 2 if tiled else int(np.ceil(np.log2(M) / 3.0))

@@ -236,9 +236,16 @@ namespace payne { template <> struct ex_chip<ChipExec> { static constexpr bool v
 #ifdef __HIP_DEVICE_COMPILE__
 namespace payne {
 template <bool VSINI, class Ex>
-PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0) {
+PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0, const Window* rs) {
   if constexpr (ex_chip<Ex>::value) {
-    chip_conv<VSINI>(ex.L, src0 ? src0 : work, work, ta, src0 != nullptr, edge, (int)threadIdx.x);
+    if (rs) {                                                // the instrumental stage: its load resamples `src0` itself
+      __shared__ ChipResample R;                             // (handed to the out-of-line stage through LDS)
+      if (threadIdx.x == 0) { R.rsA = rs->rsA; R.rsBm = rs->rsB + kPosMagic; R.hs = rs->hs_ann; R.i0 = rs->i0; R.i1 = rs->i1; }
+      __syncthreads();
+      chip_conv<VSINI>(ex.L, src0, work, ta, false, edge, (int)threadIdx.x, &R);
+    } else {
+      chip_conv<VSINI>(ex.L, src0 ? src0 : work, work, ta, src0 != nullptr, edge, (int)threadIdx.x, nullptr);
+    }
     ex.mark(0);
     edge = false;
   }

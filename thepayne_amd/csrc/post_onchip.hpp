@@ -61,18 +61,22 @@ __device__ __forceinline__ c32 chip_w65536(const ChipLds& L, int e) {           
 // pulled above it (without it the compiler carries the twiddle products of a stage into the exchange that follows and keeps
 // a hundred table values alive meanwhile: 326 registers spilled in the forward transform alone).
 __device__ __forceinline__ void chip_pin(c32 (&u)[32]) {
+  // (as register PAIRS: the packed instructions want a complex value in two consecutive, even-aligned registers; pinned as
+  //  two separate values the halves land anywhere and every packed operation starts with moves)
 #pragma unroll
-  for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(u[i].x), "+v"(u[i].y));
+  for (int i = 0; i < 32; ++i) { f2v t; t.x = u[i].x; t.y = u[i].y; asm volatile("" : "+v"(t)); u[i] = {t.x, t.y}; }
 }
 
-// ---- DFT_32 in registers (natural order in, natural order out; forward sign) --------------------------------
-//   X[k1 + 4 k2] = sum_a2 W32^(a2 k1) [ sum_a1 x[8 a1 + a2] W4^(a1 k1) ] W8^(a2 k2)
-__device__ __forceinline__ void chip_dft32(c32 (&u)[32]) {
-  // (scheduling fences between the pieces: 64 of the 128 registers a thread has hold the data; left alone the scheduler
-  //  pulls every table read of a stage forward and spills two hundred registers)
-#pragma unroll
-  for (int a2 = 0; a2 < 8; ++a2) { dft4(u[a2], u[a2 + 8], u[a2 + 16], u[a2 + 24]); if (a2 & 1) __builtin_amdgcn_sched_barrier(0); }   // -> index k1 at a2 + 8 k1
-  // W32^m, m = a2 k1 (k1 = 1..3, a2 = 1..7)
+// ---- DFT_32 in registers (forward sign), in two forms that hand the result to each other WITHOUT moving it: ---------------
+//   A  natural in -> "permuted" out: logical index k sits at position P(k) = 8 (k & 3) + (k >> 2)
+//        X[k1 + 4 k2] = sum_a2 W32^(a2 k1) [ sum_a1 x[8 a1 + a2] W4^(a1 k1) ] W8^(a2 k2)      (DFT_4 strided, twiddle, DFT_8 contiguous)
+//   B  permuted in -> natural out:
+//        X[ka + 8 kb] = sum_alo W4^(alo kb) W32^(alo ka) [ sum_ahi x[alo + 4 ahi] W8^(ahi ka) ] (DFT_8 contiguous, twiddle, DFT_4 strided)
+// Everything between two transforms (twiddles, exchanges, the taper) addresses the registers through the layout it was
+// handed (template parameter PERM): the 64 register moves per transform of a reordering copy are a quarter of a stage's
+// vector instructions.
+constexpr int chip_pos(bool perm, int k) { return perm ? (8 * (k & 3) + (k >> 2)) : k; }
+__device__ __forceinline__ void chip_tw32(c32 (&u)[32]) {             // position 8 i + j (i = 1..3, j = 1..7) x W32^(i j): both forms
   constexpr float C[22] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
                            0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f,
                            -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
@@ -84,112 +88,133 @@ __device__ __forceinline__ void chip_dft32(c32 (&u)[32]) {
                            0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
                            -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f};
 #pragma unroll
-  for (int k1 = 1; k1 < 4; ++k1)
+  for (int i = 1; i < 4; ++i)
 #pragma unroll
-    for (int a2 = 1; a2 < 8; ++a2) {
-      const int m = a2 * k1;                                     // <= 21
+    for (int j = 1; j < 8; ++j) {
+      const int m = i * j;                                       // <= 21
       const c32 w = {C[m], -S[m]};                               // exp(-2 pi i m / 32)
-      u[a2 + 8 * k1] = cmul(u[a2 + 8 * k1], w);
+      u[j + 8 * i] = cmul(u[j + 8 * i], w);
     }
+}
+// (scheduling fences between the pieces: half of a thread's registers hold the data; left alone the scheduler pulls every table
+//  read of a stage forward and spills hundreds of registers)
+__device__ __forceinline__ void chip_dft32_A(c32 (&u)[32]) {          // natural -> permuted
+#pragma unroll
+  for (int a2 = 0; a2 < 8; ++a2) { dft4(u[a2], u[a2 + 8], u[a2 + 16], u[a2 + 24]); if (a2 & 1) __builtin_amdgcn_sched_barrier(0); }
+  chip_tw32(u);                                                  // element (a2, k1) at a2 + 8 k1
   __builtin_amdgcn_sched_barrier(0);
-  c32 v[32];
 #pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) {
-    dft8(&u[8 * k1]);                                            // -> k2 at 8 k1 + k2
+  for (int k1 = 0; k1 < 4; ++k1) { dft8(&u[8 * k1]); __builtin_amdgcn_sched_barrier(0); }   // -> X[k1 + 4 k2] at 8 k1 + k2
+}
+__device__ __forceinline__ void chip_dft32_B(c32 (&u)[32]) {          // permuted -> natural
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) v[k1 + 4 * k2] = u[8 * k1 + k2];
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  for (int al = 0; al < 4; ++al) { dft8(&u[8 * al]); __builtin_amdgcn_sched_barrier(0); }    // over ahi -> ka at 8 alo + ka
+  chip_tw32(u);                                                  // element (alo, ka) at ka + 8 alo
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = 0; k < 32; ++k) u[k] = v[k];
+  for (int ka = 0; ka < 8; ++ka) { dft4(u[ka], u[ka + 8], u[ka + 16], u[ka + 24]); if (ka & 1) __builtin_amdgcn_sched_barrier(0); }   // -> X[ka + 8 kb] at ka + 8 kb
 }
 
 // ---- the two transposes (each its own inverse) -----------------------------------------------------------------
-// HI: (h, l; reg r) <-> (r, l; reg h).  Round q: the registers of parity (q + h) & 1 travel: send, workgroup barrier, receive,
-// barrier (the barriers are the caller's: it runs two virtual threads between them).
+// HI: (h, l; reg r) <-> (r, l; reg h).  Round q: the registers of parity (q + d) & 1 travel (d = h resp. l): send, workgroup
+// barrier, receive, barrier (the barriers are the caller's: it runs two virtual threads between them).  PERM: the layout of the
+// register array (chip_pos).  HPAR: the parity of h, known at compile time (a thread's two virtual threads have h = 2 i and
+// 2 i + 1): the HI exchange then needs no selects; the LO one picks by the lane's parity.
 // (the thread index is laundered at every use: the exchanges' LDS addresses are otherwise computed once for all of them and
 //  kept in a hundred registers from the first exchange to the last)
 __device__ __forceinline__ int chip_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
-template <bool HI>
+template <bool HI, bool PERM, int HPAR>
 __device__ __forceinline__ void chip_xch_send(const ChipLds& L, const c32 (&u)[32], int vt_, int q) {
   const int vt = chip_fresh(vt_);
   const int h = vt >> 5, l = vt & 31;
-  const int d = HI ? h : l;                                      // the digit that trades places with the register index
-  const bool odd = ((q + d) & 1) != 0;
+  const bool odd = HI ? (((q + HPAR) & 1) != 0) : (((q + l) & 1) != 0);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const c32 e = u[2 * j], o = u[2 * j + 1];
-    const c32 v = {odd ? o.x : e.x, odd ? o.y : e.y};              // register r = 2 j + parity
+    c32 v;
+    if constexpr (HI) {
+      v = u[chip_pos(PERM, 2 * j + ((q + HPAR) & 1))];           // register r = 2 j + parity
+    } else {
+      const c32 e = u[chip_pos(PERM, 2 * j)], o = u[chip_pos(PERM, 2 * j + 1)];
+      v = {odd ? o.x : e.x, odd ? o.y : e.y};
+    }
     // HI: [j][h][l];  LO: [h][j][l ^ 2 j] (the reader's lanes differ in j: the XOR spreads them over the banks)
     const int idx = HI ? ((j * 32 + h) * 32 + l) : ((h * 16 + j) * 32 + (l ^ (2 * j)));
     stc(L.xch, idx, v);
   }
 }
-template <bool HI>
+template <bool HI, bool PERM, int HPAR>
 __device__ __forceinline__ void chip_xch_recv(const ChipLds& L, c32 (&u)[32], int vt_, int q) {
   const int vt = chip_fresh(vt_);
   const int h = vt >> 5, l = vt & 31;
   const int d = HI ? h : l;
-  const bool odd = ((q + d) & 1) != 0;
+  const bool odd = HI ? (((q + HPAR) & 1) != 0) : (((q + l) & 1) != 0);
   const int J = d >> 1;                                          // the slot the senders used for register r = d
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int s = 2 * j + (odd ? 1 : 0);                         // the sender's digit (the parity class this thread just sent)
     const int idx = HI ? ((J * 32 + s) * 32 + l) : ((h * 16 + J) * 32 + (s ^ (2 * J)));
     const c32 v = ldc(L.xch, idx);
-    // (selects, not a branch around the store: a conditional store keeps the whole array in scratch memory)
-    const c32 e = u[2 * j], o = u[2 * j + 1];
-    u[2 * j] = {odd ? e.x : v.x, odd ? e.y : v.y};
-    u[2 * j + 1] = {odd ? v.x : o.x, odd ? v.y : o.y};
+    if constexpr (HI) {
+      u[chip_pos(PERM, 2 * j + ((q + HPAR) & 1))] = v;
+    } else {
+      // (selects, not a branch around the store: a conditional store keeps the whole array in scratch memory)
+      const c32 e = u[chip_pos(PERM, 2 * j)], o = u[chip_pos(PERM, 2 * j + 1)];
+      u[chip_pos(PERM, 2 * j)] = {odd ? e.x : v.x, odd ? e.y : v.y};
+      u[chip_pos(PERM, 2 * j + 1)] = {odd ? v.x : o.x, odd ? v.y : o.y};
+    }
   }
 }
-template <bool HI>
-__device__ __forceinline__ void chip_xch(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid) {
+template <bool HI, bool PERM>
+__device__ __forceinline__ void chip_xch(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    chip_xch_send<HI>(L, u0, tid, q);
+    chip_xch_send<HI, PERM, 0>(L, u0, vt0, q);
     __builtin_amdgcn_sched_barrier(0);
-    chip_xch_send<HI>(L, u1, tid + kChipThreads, q);
+    chip_xch_send<HI, PERM, 1>(L, u1, vt0 + 32, q);
     __syncthreads();
-    chip_xch_recv<HI>(L, u0, tid, q); chip_pin(u0);
-    chip_xch_recv<HI>(L, u1, tid + kChipThreads, q); chip_pin(u1);
+    chip_xch_recv<HI, PERM, 0>(L, u0, vt0, q); chip_pin(u0);
+    chip_xch_recv<HI, PERM, 1>(L, u1, vt0 + 32, q); chip_pin(u1);
     __syncthreads();
   }
 }
 
 // ---- twiddles between the stages -----------------------------------------------------------------------------
-__device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int tid_) {    // x W_32768^(t k1) = W_65536^(2 t k1)
-  const int tid = chip_fresh(tid_);
+template <bool PERM>
+__device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_32768^(t k1) = W_65536^(2 t k1)
+  const int vt = chip_fresh(vt_);
 #pragma unroll
   for (int k1 = 1; k1 < 32; ++k1) {
-    u[k1] = cmul(u[k1], chip_w65536(L, (2 * tid * k1) & 65535));
+    u[chip_pos(PERM, k1)] = cmul(u[chip_pos(PERM, k1)], chip_w65536(L, (2 * vt * k1) & 65535));
     if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);        // four twiddles (eight table reads) in flight at a time
   }
 }
-__device__ __forceinline__ void chip_tw2(const ChipLds& L, c32 (&u)[32], int tid_) {    // x W_1024^(l k2a)
-  const int l = chip_fresh(tid_) & 31;
+template <bool PERM>
+__device__ __forceinline__ void chip_tw2(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_1024^(l k2a)
+  const int l = chip_fresh(vt_) & 31;
 #pragma unroll
   for (int k = 1; k < 32; ++k) {
-    u[k] = cmul(u[k], ldc(L.w1024, (l * k) & 1023));
+    u[chip_pos(PERM, k)] = cmul(u[chip_pos(PERM, k)], ldc(L.w1024, (l * k) & 1023));
     if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// natural (layout L0) -> spectrum (thread (k1, k2a), reg k2b) and back (transposed order: the same operators); two virtual threads
-__device__ __forceinline__ void chip_fft_fwd(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid) {
-  const int t1 = tid + kChipThreads;
-  chip_dft32(u0); chip_pin(u0); chip_tw1(L, u0, tid); chip_pin(u0); chip_dft32(u1); chip_pin(u1); chip_tw1(L, u1, t1); chip_pin(u1);
-  chip_xch<true>(L, u0, u1, tid);
-  chip_dft32(u0); chip_pin(u0); chip_tw2(L, u0, tid); chip_pin(u0); chip_dft32(u1); chip_pin(u1); chip_tw2(L, u1, t1); chip_pin(u1);
-  chip_xch<false>(L, u0, u1, tid);
-  chip_dft32(u0); chip_pin(u0); chip_dft32(u1); chip_pin(u1);
+// natural (layout L0) -> spectrum (thread (k1, k2a), reg k2b, PERMUTED register layout) and back (transposed order: the same
+// operators); two virtual threads vt0 and vt0 + 32
+__device__ __forceinline__ void chip_fft_fwd(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0) {
+  const int vt1 = vt0 + 32;
+  chip_dft32_A(u0); chip_pin(u0); chip_tw1<true>(L, u0, vt0); chip_pin(u0); chip_dft32_A(u1); chip_pin(u1); chip_tw1<true>(L, u1, vt1); chip_pin(u1);
+  chip_xch<true, true>(L, u0, u1, vt0);
+  chip_dft32_B(u0); chip_pin(u0); chip_tw2<false>(L, u0, vt0); chip_pin(u0); chip_dft32_B(u1); chip_pin(u1); chip_tw2<false>(L, u1, vt1); chip_pin(u1);
+  chip_xch<false, false>(L, u0, u1, vt0);
+  chip_dft32_A(u0); chip_pin(u0); chip_dft32_A(u1); chip_pin(u1);
 }
-__device__ __forceinline__ void chip_fft_back(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid) {
-  const int t1 = tid + kChipThreads;
-  chip_dft32(u0); chip_pin(u0); chip_dft32(u1); chip_pin(u1); chip_xch<false>(L, u0, u1, tid);
-  chip_tw2(L, u0, tid); chip_pin(u0); chip_dft32(u0); chip_pin(u0); chip_tw2(L, u1, t1); chip_pin(u1); chip_dft32(u1); chip_pin(u1);
-  chip_xch<true>(L, u0, u1, tid);
-  chip_tw1(L, u0, tid); chip_pin(u0); chip_dft32(u0); chip_pin(u0); chip_tw1(L, u1, t1); chip_pin(u1); chip_dft32(u1); chip_pin(u1);
+__device__ __forceinline__ void chip_fft_back(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0) {
+  const int vt1 = vt0 + 32;
+  chip_dft32_B(u0); chip_pin(u0); chip_dft32_B(u1); chip_pin(u1);
+  chip_xch<false, false>(L, u0, u1, vt0);
+  chip_tw2<false>(L, u0, vt0); chip_pin(u0); chip_dft32_A(u0); chip_pin(u0); chip_tw2<false>(L, u1, vt1); chip_pin(u1); chip_dft32_A(u1); chip_pin(u1);
+  chip_xch<true, true>(L, u0, u1, vt0);
+  chip_tw1<true>(L, u0, vt0); chip_pin(u0); chip_dft32_B(u0); chip_pin(u0); chip_tw1<true>(L, u1, vt1); chip_pin(u1); chip_dft32_B(u1); chip_pin(u1);
 }
 
 // ---- the convolution's middle: conjugate pairs, taper, real-FFT split / merge ------------------------------------
@@ -211,20 +236,21 @@ __device__ __forceinline__ ChipPair chip_pair(int vt_) {
 __device__ __forceinline__ void chip_taper_send1(const ChipLds& L, const c32 (&u)[32], int vt_) {
   const int vt = chip_fresh(vt_);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) stc(L.xch, j * 1024 + vt, u[16 + j]);
+  for (int j = 0; j < 16; ++j) stc(L.xch, j * 1024 + vt, u[chip_pos(true, 16 + j)]);
 }
 template <bool VSINI>
 __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32], int vt, const TaperArgs& ta) {
   constexpr int M = kChipM;
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const ChipPair P = chip_pair(vt);
-  const c32 z0 = u[0];                                             // thread 0: Z[0] (holds the real bins X[0] and X[M])
+  // (the registers are in the permuted layout the forward transform leaves: logical r at chip_pos(true, r))
+  const c32 z0 = u[chip_pos(true, 0)];                             // thread 0: Z[0] (holds the real bins X[0] and X[M])
   const c32 zh = ldc(L.xch, vt);                                   // thread 0: Z[M/2] (its register 16, slot 0)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int slot = 15 - r + P.sh;                                      // the partner's register 31 - r (thread 0: 32 - r)
     slot = slot > 15 ? 15 : slot;                                  // (thread 0, r = 0: not a pair, the value is not used)
-    u[16 + r] = ldc(L.xch, slot * 1024 + P.pt);
+    u[chip_pos(true, 16 + r)] = ldc(L.xch, slot * 1024 + P.pt);
   }
   // the pairs (k, M - k), k = low + 1024 r, r < 16: taper and real-FFT split / merge
 #pragma unroll
@@ -234,38 +260,40 @@ __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32],
     const float tk = taper_full<VSINI>(ta, k), tm = taper_full<VSINI>(ta, M - k);
     const c32 w = chip_w65536(L, k);                               // exp(-2 pi i k / 2M)
     c32 yk, ym;
-    taper_pair(u[r], u[16 + r], w, tk * g, tm * g, yk, ym);
-    u[r] = yk; u[16 + r] = ym;
-    asm volatile("" : "+v"(u[r].x), "+v"(u[r].y), "+v"(u[16 + r].x), "+v"(u[16 + r].y));
+    c32& ua = u[chip_pos(true, r)];
+    c32& ub = u[chip_pos(true, 16 + r)];
+    taper_pair(ua, ub, w, tk * g, tm * g, yk, ym);
+    ua = yk; ub = ym;
+    { f2v t; t.x = ua.x; t.y = ua.y; f2v v2; v2.x = ub.x; v2.y = ub.y; asm volatile("" : "+v"(t), "+v"(v2)); ua = {t.x, t.y}; ub = {v2.x, v2.y}; }
     __builtin_amdgcn_sched_barrier(0);                             // one pair (two taper values) at a time
   }
   if (P.t0) {                                                      // the self-conjugate bins (rfft_taper_phase, same statements)
     const float tM = taper_full<VSINI>(ta, M), th = taper_full<VSINI>(ta, M / 2);
     const float x0 = z0.x + z0.y, xm = tM * (z0.x - z0.y);
-    u[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
-    u[16] = cscale(cconj(zh), th * invM);                          // (Y[M/2]: parked in the slot that round 2 skips for thread 0)
+    u[chip_pos(true, 0)] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+    u[chip_pos(true, 16)] = cscale(cconj(zh), th * invM);          // (Y[M/2]: parked in the slot that round 2 skips for thread 0)
   }
 }
 // round 2: the partner's halves of the pairs go back (slot r = the pair index of the thread that computed it)
 __device__ __forceinline__ void chip_taper_send2(const ChipLds& L, const c32 (&u)[32], int vt_) {
   const int vt = chip_fresh(vt_);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) stc(L.xch, r * 1024 + vt, u[16 + r]);
+  for (int r = 0; r < 16; ++r) stc(L.xch, r * 1024 + vt, u[chip_pos(true, 16 + r)]);
 }
 __device__ __forceinline__ void chip_taper_recv2(const ChipLds& L, c32 (&u)[32], int vt) {
   const ChipPair P = chip_pair(vt);
-  const c32 yh = u[16];                                            // thread 0: Y[M/2]
+  const c32 yh = u[chip_pos(true, 16)];                            // thread 0: Y[M/2]
 #pragma unroll
   for (int j = 0; j < 16; ++j) {                                   // my register 16 + j was the partner's pair 31 - (16 + j) = 15 - j
     int slot = 15 - j + P.sh;                                      // (thread 0: 32 - (16 + j) = 16 - j; j = 0 is Y[M/2])
     slot = slot > 15 ? 15 : slot;
-    u[16 + j] = ldc(L.xch, slot * 1024 + P.pt);
+    u[chip_pos(true, 16 + j)] = ldc(L.xch, slot * 1024 + P.pt);
   }
-  if (P.t0) u[16] = yh;
+  if (P.t0) u[chip_pos(true, 16)] = yh;
 }
 template <bool VSINI>
 __device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid, const TaperArgs& ta) {
-  const int t1 = tid + kChipThreads;
+  const int t1 = tid + 32;                                         // (tid: the first virtual thread's index)
   chip_taper_send1(L, u0, tid); chip_taper_send1(L, u1, t1);
   __syncthreads();
   chip_taper_pairs<VSINI>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI>(L, u1, t1, ta); chip_pin(u1);
@@ -281,22 +309,54 @@ __device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 
 // spec[-1] = spec[-2] on the way out (ystpred.py:223-224).  Every thread of the 1024 takes part (barriers inside).
 // (a CALL: the stage needs 224 of the 256 registers a thread has; inlined into the candidate's phase sequence, what that keeps
 //  alive around it costs three hundred spills)
+// What the instrumental stage reads is the masked, Doppler-shifted spectrum resampled onto its pow-2 log grid (smoothing.py:649-668;
+// R_resample_loop of post_core.hpp, geometric grids): with `rs` the stage's load gathers and interpolates its points itself
+// (positions by one fp64 fma each, as there) instead of reading a resampled copy a phase of its own wrote -- two transfers of
+// the spectrum and one phase fewer.
+struct ChipResample { double rsA, rsBm; float hs; int i0, i1; };
+__device__ __forceinline__ void chip_gather(const float* __restrict__ spec, const ChipResample& R, int vt, c32 (&u)[32]) {
+#pragma unroll
+  for (int a0 = 0; a0 < 32; a0 += 4) {                              // four complex points (sixteen gathers) at a time
+    float va[8], vb[8], vw[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = 2 * (vt + 1024 * (a0 + (q >> 1))) + (q & 1);
+      int k; float ww;
+      magic_locate(fma((double)j, R.rsA, R.rsBm), R.i0, R.i1, R.hs, k, ww);
+      va[q] = spec[k]; vb[q] = spec[k + 1]; vw[q] = ww;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a0_ = nan_to_zero(va[2 * q]), b0_ = nan_to_zero(vb[2 * q]), a1_ = nan_to_zero(va[2 * q + 1]), b1_ = nan_to_zero(vb[2 * q + 1]);
+      u[a0 + q] = {a0_ + (b0_ - a0_) * vw[2 * q], a1_ + (b1_ - a1_) * vw[2 * q + 1]};    // nan_to_num, smoothing.py:138
+      f2v t; t.x = u[a0 + q].x; t.y = u[a0 + q].y; asm volatile("" : "+v"(t)); u[a0 + q] = {t.x, t.y};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 template <bool VSINI>
 __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* __restrict__ in, float* __restrict__ out, const TaperArgs ta,
-                                                    bool scrub, bool edge, int tid) {
+                                                    bool scrub, bool edge, int tid, const ChipResample* rs) {
   typedef float f2g __attribute__((ext_vector_type(2)));
   const PAYNE_AS_GLOBAL f2g* g = (const PAYNE_AS_GLOBAL f2g*)in;
-  const int t1 = tid + kChipThreads;
+  // the thread's two virtual threads: vt0 = (h = 2 i, l), vt1 = (h = 2 i + 1, l), i = tid / 32, l = tid % 32
+  const int vt0 = 64 * (tid >> 5) + (tid & 31);
   c32 u0[32], u1[32];
+  if (rs) {
+    const ChipResample R = *rs;
+    chip_gather(in, R, vt0, u0);
+    chip_gather(in, R, vt0 + 32, u1);
+  } else {
   // (uniform base + the thread's 32-bit offset: the 64 addresses live in scalar registers, not in 128 vector ones)
 #pragma unroll
   for (int a = 0; a < 32; ++a) {
     const PAYNE_AS_GLOBAL f2g* ga = g + 1024 * a;
-    const PAYNE_AS_GLOBAL f2g* gb = g + 1024 * a + kChipThreads;
-    const f2g v = ga[tid], w = gb[tid];
+    const PAYNE_AS_GLOBAL f2g* gb = g + 1024 * a + 32;
+    const f2g v = ga[vt0], w = gb[vt0];
     u0[a] = {v.x, v.y}; u1[a] = {w.x, w.y};
   }
-  if (scrub) {
+  }
+  if (scrub && !rs) {
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
       u0[a] = {nan_to_zero(u0[a].x), nan_to_zero(u0[a].y)};
@@ -304,20 +364,20 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
     }
   }
   chip_pin(u0); chip_pin(u1);
-  chip_fft_fwd(L, u0, u1, tid);
-  chip_taper<VSINI>(L, u0, u1, tid, ta);
-  chip_fft_back(L, u0, u1, tid);
+  chip_fft_fwd(L, u0, u1, vt0);
+  chip_taper<VSINI>(L, u0, u1, vt0, ta);
+  chip_fft_back(L, u0, u1, vt0);
   chip_pin(u0); chip_pin(u1);
   PAYNE_AS_GLOBAL f2g* o = (PAYNE_AS_GLOBAL f2g*)out;
 #pragma unroll
   for (int a = 0; a < 32; ++a) {
     f2g v, w;                                                      // z' = conj(FFT(Y))
     v.x = u0[a].x; v.y = -u0[a].y; w.x = u1[a].x; w.y = -u1[a].y;
-    if (edge && a == 0 && tid == 0) v.x = v.y;                     // element 0     = (spec[0], spec[1])
-    if (edge && a == 31 && t1 == kChipVT - 1) w.y = w.x;           // element M - 1 = (spec[n-2], spec[n-1])
+    if (edge && a == 0 && vt0 == 0) v.x = v.y;                     // element 0     = (spec[0], spec[1])
+    if (edge && a == 31 && vt0 + 32 == kChipVT - 1) w.y = w.x;     // element M - 1 = (spec[n-2], spec[n-1])
     PAYNE_AS_GLOBAL f2g* oa = o + 1024 * a;
-    PAYNE_AS_GLOBAL f2g* ob = o + 1024 * a + kChipThreads;
-    oa[tid] = v; ob[tid] = w;
+    PAYNE_AS_GLOBAL f2g* ob = o + 1024 * a + 32;
+    oa[vt0] = v; ob[vt0] = w;
   }
   __syncthreads();                                                 // (one CU, one L1: the next phase of this workgroup reads what was just written)
 }

@@ -151,18 +151,19 @@ PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsign
 constexpr int kChipN1 = 65536;
 template <class Ex> struct ex_chip { static constexpr bool value = false; };
 template <bool VSINI, class Ex>
-PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0);
+PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0, const Window* rs);
 
 // One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
 // `twf`: pass-ordered table of the fixed geometry (LDS or global); T.tw: plain full circle.
 // `edge` in: the caller wants spec[0]=spec[1], spec[-1]=spec[-2] applied to the result;
 // out: whether that is still to be done (the fixed-geometry transform does it in its last pass).
+// `rs` (chip executors only): the stage's input is `src0` resampled through this window (the resampling phase was skipped).
 template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
-                            const TaperArgs& ta, bool& edge, const float* src0 = nullptr) {
+                            const TaperArgs& ta, bool& edge, const float* src0 = nullptr, const Window* rs = nullptr) {
   const int M = n / 2;
   if constexpr (ex_chip<Ex>::value) {
-    if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0);
+    if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0, rs);
   }
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
@@ -271,11 +272,13 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       W = make_window(T, S, cnt, n_slots(nthr));
     }
     if (!W.bad) {
-      if (!(PAYNE_EXP_SKIP & 8)) ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
+      // (an executor that keeps the stage on the compute unit gathers the resampled points while it loads them)
+      const bool gather = ex_chip<Ex>::value && T.geo && W.n2 == kChipN1;
+      if (!gather && !(PAYNE_EXP_SKIP & 8)) ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
       bool no_edge = false;
-      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta, no_edge);
+      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta, no_edge, gather ? spec : nullptr, gather ? &W : nullptr);
     }
   }
   if (!(PAYNE_EXP_SKIP & 16)) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
