@@ -1,21 +1,22 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench command: kernel stats, HBM counters (FETCH_SIZE, WRITE_SIZE: separate passes) and one SQ
 # pass; the summaries land in gpurun_out/ under the names profiles/ uses (copy them there: gpurun_out/ is scratch).
-#   bash tools/gpu_profiles.sh [round-tag r2] [config C2|C5]
-TAG=${1:-r2}; CFG=${2:-C2}
+#   bash tools/gpu_profiles.sh [round-tag r3] [config C2|C3|C5]
+TAG=${1:-r3}; CFG=${2:-C2}
 cfg=$(echo $CFG | tr A-Z a-z)
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 REPO=$PWD
 STEPS=200; PSTEPS=20
 if [ $CFG = C5 ]; then STEPS=5; PSTEPS=3; fi
-python bench.py --config $CFG --steps $STEPS --warmup 5 > $OUT/${TAG}_${cfg}_bench.json 2> $OUT/${TAG}_${cfg}_bench.err; tail -c 400 $OUT/${TAG}_${cfg}_bench.json
+EXTRA=""; if [ $CFG != C2 ]; then EXTRA="--no-cpu-baseline"; fi
+python bench.py --config $CFG --steps $STEPS --warmup 5 $EXTRA > $OUT/${TAG}_${cfg}_bench.json 2> $OUT/${TAG}_${cfg}_bench.err; tail -c 400 $OUT/${TAG}_${cfg}_bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$cfg -o kt -- python3 $REPO/bench.py --config $CFG --steps $STEPS --warmup 5 --no-cpu-baseline --no-kernel-timing --no-e2e > $OUT/rocprof_${TAG}_$cfg.log 2>&1; echo "rocprof stats rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$cfg -o kt -- python3 $REPO/bench.py --config $CFG --steps $STEPS --warmup 5 --no-cpu-baseline --no-kernel-timing --no-e2e --no-also > $OUT/rocprof_${TAG}_$cfg.log 2>&1; echo "rocprof stats rc=$?"
 for cn in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $cn --output-format csv -d $OUT/pmc_${TAG}_${cfg}_$cn -o c -- python3 $REPO/bench.py --config $CFG --steps $PSTEPS --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e > $OUT/pmc_${TAG}_${cfg}_$cn.log 2>&1; echo "pmc $cn rc=$?"
+  rocprofv3 --kernel-trace --pmc $cn --output-format csv -d $OUT/pmc_${TAG}_${cfg}_$cn -o c -- python3 $REPO/bench.py --config $CFG --steps $PSTEPS --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e --no-also > $OUT/pmc_${TAG}_${cfg}_$cn.log 2>&1; echo "pmc $cn rc=$?"
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_${TAG}_${cfg}_sq1 -o c -- python3 $REPO/bench.py --config $CFG --steps $PSTEPS --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e > $OUT/pmc_${TAG}_${cfg}_sq1.log 2>&1; echo "pmc sq1 rc=$?"
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${TAG}_${cfg}_sq2 -o c -- python3 $REPO/bench.py --config $CFG --steps $PSTEPS --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e > $OUT/pmc_${TAG}_${cfg}_sq2.log 2>&1; echo "pmc sq2 rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_${TAG}_${cfg}_sq1 -o c -- python3 $REPO/bench.py --config $CFG --steps $PSTEPS --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e --no-also > $OUT/pmc_${TAG}_${cfg}_sq1.log 2>&1; echo "pmc sq1 rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${TAG}_${cfg}_sq2 -o c -- python3 $REPO/bench.py --config $CFG --steps $PSTEPS --warmup 3 --no-cpu-baseline --no-kernel-timing --no-e2e --no-also > $OUT/pmc_${TAG}_${cfg}_sq2.log 2>&1; echo "pmc sq2 rc=$?"
 cd $REPO
 python3 - <<PY
 import csv, glob, collections, json, subprocess
