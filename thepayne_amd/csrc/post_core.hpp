@@ -58,7 +58,74 @@ constexpr int kFftThreads = 256;
 PAYNE_HD constexpr int unroll_for(int ppt) { return ppt >= 16 ? 16 : (ppt >= 8 ? 8 : 4); }
 
 struct c32 { float x, y; };
+#ifdef __HIP_DEVICE_COMPILE__
+// Complex arithmetic on the packed-fp32 unit, one instruction per line (the compiler's own selection from the scalar
+// statements spends four instructions on a complex product -- both halves computed twice, merged by a move -- and a
+// quarter of a transform's vector instructions on moves that re-pair halves): a complex value is a 64-bit register pair
+// from the LDS read to the LDS write; which half of a source feeds which half of the result (op_sel / op_sel_hi) and its
+// sign (neg_lo / neg_hi) are part of the instruction, so multiplications by +-i and conjugations cost nothing.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 to_pk(c32 a) { pk2 t; t.x = a.x; t.y = a.y; return t; }
+__device__ __forceinline__ c32 un_pk(pk2 t) { return {t.x, t.y}; }
+__device__ __forceinline__ pk2 pk_add(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a + (-i) b = (a.x + b.y, a.y - b.x)       a - (-i) b = a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ pk2 pk_add_mi(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pk2 pk_add_pi(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a + conj(b), a - conj(b), conj(a + b)
+__device__ __forceinline__ pk2 pk_add_cj(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pk2 pk_sub_cj(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pk2 pk_cj_add(pk2 a, pk2 b) { pk2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// c + a h, c - a h with the constant pair hh = (h, h) in scalar registers
+__device__ __forceinline__ pk2 pk_fma_c(pk2 a, pk2 hh, pk2 c) { pk2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(hh), "v"(c)); return r; }
+__device__ __forceinline__ pk2 pk_fnma_c(pk2 a, pk2 hh, pk2 c) { pk2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(hh), "v"(c)); return r; }
+// (several instructions per asm statement where one feeds the next: the compiler cannot see into a statement and separates two
+//  DEPENDENT statements by an s_nop -- it has to assume the first might write half a register --, which costs the issue slot
+//  the packed form was meant to save; inside a statement the hardware's own interlock applies)
+// a w  and  a conj(w)
+__device__ __forceinline__ pk2 pk_cmul(pk2 a, pk2 w) {
+  pk2 t, r;
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"                                   // (a.y w.y, a.y w.x)
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"                // (a.x w.x - t.x, a.x w.y + t.y)
+      : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
+  return r;
+}
+__device__ __forceinline__ pk2 pk_cmul_cj(pk2 a, pk2 w) {
+  pk2 t, r;
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"                // (a.x w.x + t.x, -a.x w.y + t.y)
+      : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
+  return r;
+}
+// two products at once (the second product's first instruction sits between the two dependent ones of the first)
+__device__ __forceinline__ void pk_cmul2(pk2& a, pk2 wa, pk2& b, pk2 wb) {
+  pk2 t, s;
+  asm("v_pk_mul_f32 %2, %0, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %3, %1, %5 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %4, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+      "v_pk_fma_f32 %1, %1, %5, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+      : "+v"(a), "+v"(b), "=&v"(t), "=&v"(s) : "v"(wa), "v"(wb));
+}
+// a (c - i s) with the constant pair cs = (c, s) in scalar registers: (a.x c + a.y s, a.y c - a.x s)
+__device__ __forceinline__ pk2 pk_cmul_k(pk2 a, pk2 cs) {
+  pk2 t, r;
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"                                               // (a.x c, a.y c)
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"                // (a.y s + t.x, -a.x s + t.y)
+      : "=v"(r), "=&v"(t) : "v"(a), "s"(cs));
+  return r;
+}
+__device__ __forceinline__ void pk_cmul_k2(pk2& a, pk2 ca, pk2& b, pk2 cb) {
+  pk2 t, s;
+  asm("v_pk_mul_f32 %2, %0, %4 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %3, %1, %5 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %5, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+      : "+v"(a), "+v"(b), "=&v"(t), "=&v"(s) : "s"(ca), "s"(cb));
+}
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) { return un_pk(pk_cmul(to_pk(a), to_pk(b))); }
+#else
 PAYNE_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+#endif
 PAYNE_HD c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
 PAYNE_HD c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
 PAYNE_HD c32 cconj(c32 a) { return {a.x, -a.y}; }
@@ -155,10 +222,59 @@ PAYNE_HD int n_slots(int nthr) { return nthr >> kSlotShift; }
 // exp(-2 pi i k r/(pR)) (k = i mod p), writes dst[(i-k)R + k + r p].
 // ---------------------------------------------------------------------------
 PAYNE_HD void dft2(c32* u) { c32 a = u[0], b = u[1]; u[0] = cadd(a, b); u[1] = csub(a, b); }
+#ifdef __HIP_DEVICE_COMPILE__
+// 8 and 26 packed instructions, no instruction next to the one it depends on
+__device__ __forceinline__ void pk_dft4(pk2& a0, pk2& a1, pk2& a2, pk2& a3) {
+  pk2 t0, t2;
+  asm("v_pk_add_f32 %4, %0, %2\n\t"                                                   // t0 = a0 + a2
+      "v_pk_add_f32 %5, %1, %3\n\t"                                                   // t2 = a1 + a3
+      "v_pk_add_f32 %2, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // t1 = a0 - a2      (in a2's place)
+      "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // d  = a1 - a3      (in a3's place)
+      "v_pk_add_f32 %0, %4, %5\n\t"                                                   // a0 = t0 + t2
+      "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // a1 = t1 - i d
+      "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // a3 = t1 + i d
+      "v_pk_add_f32 %2, %4, %5 neg_lo:[0,1] neg_hi:[0,1]"                               // a2 = t0 - t2
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t2));
+}
+__device__ __forceinline__ void pk_dft8(pk2* u) {
+  pk2 e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
+  pk_dft4(e0, e1, e2, e3); pk_dft4(o0, o1, o2, o3);
+  const pk2 hh = {0.70710678118654752f, 0.70710678118654752f};
+  pk2 tA, tB;
+  asm("v_pk_add_f32 %6, %4, %4 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // s1 = o1 (1 - i)
+      "v_pk_add_f32 %7, %5, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // s3 = o3 (1 + i)
+      "v_pk_fma_f32 %4, %6, %10, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"                // u5 = e1 - h s1    (in o1's place)
+      "v_pk_fma_f32 %1, %6, %10, %1\n\t"                                              // u1 = e1 + h s1
+      "v_pk_fma_f32 %5, %7, %10, %3\n\t"                                              // u7 = e3 + h s3    (in o3's place)
+      "v_pk_fma_f32 %3, %7, %10, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"                // u3 = e3 - h s3
+      "v_pk_add_f32 %6, %0, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // u4 = e0 - o0
+      "v_pk_add_f32 %0, %0, %8\n\t"                                                   // u0 = e0 + o0
+      "v_pk_add_f32 %7, %2, %9 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // u6 = e2 + i o2
+      "v_pk_add_f32 %2, %2, %9 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"               // u2 = e2 - i o2
+      : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o1), "+v"(o3), "=&v"(tA), "=&v"(tB)
+      : "v"(o0), "v"(o2), "s"(hh));
+  u[0] = e0; u[1] = e1; u[2] = e2; u[3] = e3; u[4] = tA; u[5] = o1; u[6] = tB; u[7] = o3;
+}
+__device__ __forceinline__ void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
+  pk2 p0 = to_pk(a0), p1 = to_pk(a1), p2 = to_pk(a2), p3 = to_pk(a3);
+  pk_dft4(p0, p1, p2, p3);
+  a0 = un_pk(p0); a1 = un_pk(p1); a2 = un_pk(p2); a3 = un_pk(p3);
+}
+__device__ __forceinline__ void dft8(c32* u) {
+  pk2 p[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) p[r] = to_pk(u[r]);
+  pk_dft8(p);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) u[r] = un_pk(p[r]);
+}
+#else
 PAYNE_HD void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
   c32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmul_negi(csub(a1, a3));
   a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
 }
+#endif
+#ifndef __HIP_DEVICE_COMPILE__
 PAYNE_HD void dft8(c32* u) {
   c32 e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
   dft4(e0, e1, e2, e3); dft4(o0, o1, o2, o3);
@@ -170,6 +286,21 @@ PAYNE_HD void dft8(c32* u) {
   u[1] = cadd(e1, w1o); u[5] = csub(e1, w1o);
   u[2] = cadd(e2, w2o); u[6] = csub(e2, w2o);
   u[3] = cadd(e3, w3o); u[7] = csub(e3, w3o);
+}
+#endif
+// u[r] *= w[r], r = 1 .. R-1 (GPU: two products per statement)
+template <int R> PAYNE_HD void twiddle_all(c32* u, const c32* w) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+  for (int r = 1; r + 1 < R; r += 2) {
+    pk2 a = to_pk(u[r]), b = to_pk(u[r + 1]);
+    pk_cmul2(a, to_pk(w[r]), b, to_pk(w[r + 1]));
+    u[r] = un_pk(a); u[r + 1] = un_pk(b);
+  }
+  if (((R - 1) & 1) != 0) u[R - 1] = cmul(u[R - 1], w[R - 1]);
+#else
+  for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
+#endif
 }
 template <int R> PAYNE_HD void dftR(c32* u) {
   if (R == 8) dft8(u);
@@ -446,8 +577,7 @@ PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign, boo
       c32 w[R];
 #pragma unroll
       for (int r = 1; r < R; ++r) w[r] = ldc(twf, OFF + (r - 1) * P + k);
-#pragma unroll
-      for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
+      twiddle_all<R>(u, w);
     }
     dftR<R>(u);
     const int j = fft_lay<PO, R>((i - k) * R + k);
@@ -523,6 +653,48 @@ PAYNE_HD float taper_far(const TaperArgs& a, int k, float fast) {
   return (k != 0 && !(t < (double)(a.vs_tab_n - 3))) ? (float)vsini_sb_exact((double)k * a.vs_c) : fast;
 }
 
+// The convolution's middle step for ONE conjugate pair: zk = Z[k], zmk = Z[M - k] (not conjugated), w = exp(-2 pi i k/2M),
+// tkg / tmg = taper(k) g, taper(M - k) g with g = 1/(4M).  Out: Y[k], Y[M - k] (see rfft_taper_phase).
+#ifdef __HIP_DEVICE_COMPILE__
+// thirteen packed instructions; T = (tkg, tmg); zk / zmk are replaced by Y[k] / Y[M - k]
+#define PAYNE_TAPER_PAIR_ASM(ZK, ZM, W, T, A, D, X)                                                                           \
+      "v_pk_add_f32 " A ", " ZK ", " ZM " neg_hi:[0,1]\n\t"                                 /* A = zk + conj(zmk) */          \
+      "v_pk_add_f32 " D ", " ZK ", " ZM " neg_lo:[0,1]\n\t"                                 /* D = zk - conj(zmk) */          \
+      "v_pk_mul_f32 " X ", " W ", " D " op_sel:[1,0] op_sel_hi:[1,1]\n\t"                   /* (w.y D.x, w.y D.y) */          \
+      "v_pk_fma_f32 " X ", " W ", " D ", " X " op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"   /* C = w (-i D) */       \
+      "v_pk_add_f32 " D ", " A ", " X " neg_lo:[0,1] neg_hi:[0,1]\n\t"                      /* Q = A - C */                   \
+      "v_pk_add_f32 " A ", " A ", " X "\n\t"                                                /* P = A + C */                   \
+      "v_pk_mul_f32 " D ", " D ", " T " op_sel:[0,1] op_sel_hi:[1,1]\n\t"                   /* S2 = Q T.y */                  \
+      "v_pk_fma_f32 " X ", " A ", " T ", " D " op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"   /* F = P T.x - S2 */ \
+      "v_pk_fma_f32 " A ", " A ", " T ", " D " op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"        /* E = P T.x + S2 */              \
+      "v_pk_mul_f32 " D ", " W ", " X " op_sel:[1,0] op_sel_hi:[1,1]\n\t"                   /* (w.y F.x, w.y F.y) */          \
+      "v_pk_fma_f32 " D ", " W ", " X ", " D " op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]\n\t"   /* iO = i conj(w) F */   \
+      "v_pk_add_f32 " ZK ", " A ", " D " neg_hi:[1,1]\n\t"                                  /* Y[k] = conj(E + iO) */         \
+      "v_pk_add_f32 " ZM ", " A ", " D " neg_lo:[0,1] neg_hi:[0,1]"                          /* Y[M-k] = E - iO */
+__device__ __forceinline__ void pk_taper_pair(pk2& zk, pk2& zmk, pk2 w, pk2 T) {
+  pk2 A, D, X;
+  asm(PAYNE_TAPER_PAIR_ASM("%0", "%1", "%5", "%6", "%2", "%3", "%4")
+      : "+v"(zk), "+v"(zmk), "=&v"(A), "=&v"(D), "=&v"(X) : "v"(w), "v"(T));
+}
+__device__ __forceinline__ void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, c32& ymk) {
+  pk2 T, a = to_pk(zk), b = to_pk(zmk);
+  T.x = tkg; T.y = tmg;
+  pk_taper_pair(a, b, to_pk(w), T);
+  yk = un_pk(a); ymk = un_pk(b);
+}
+#else
+PAYNE_HD void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, c32& ymk) {
+  const c32 zm = cconj(zmk);
+  const c32 A = cadd(zk, zm);
+  const c32 C = cmul(w, cmul_negi(csub(zk, zm)));
+  const c32 S1 = cscale(cadd(A, C), tkg), S2 = cscale(csub(A, C), tmg);
+  const c32 E = cadd(S1, S2);
+  const c32 iO = cmul_posi(cmul(cconj(w), csub(S1, S2)));
+  yk = cconj(cadd(E, iO));
+  ymk = csub(E, iO);
+}
+#endif
+
 // Middle step of a real convolution done with a half-length complex FFT.
 // In: Z = FFT_M(z), z[n] = s[2n] + i s[2n+1].  Out (in place): Y with
 // FFT_M(Y) = conj(z'), z'[n] = s'[2n] + i s'[2n+1], s' = irfft(rfft(s) * taper).
@@ -548,7 +720,7 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
       const int k0 = 1 + base + q * nthr;
       const bool pair = k0 <= npair;
       const int k = pair ? k0 : npair;
-      zk[q] = Z[k]; zm[q] = cconj(Z[M - k]); w[q] = tw[k * tw_step];
+      zk[q] = Z[k]; zm[q] = Z[M - k]; w[q] = tw[k * tw_step];
       tk[q] = taper_at<VSINI>(ta, pair ? k : M / 2, far);
       tm[q] = taper_at<VSINI>(ta, pair ? M - k : M, far);
     }
@@ -565,14 +737,11 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
 #pragma unroll
     for (int q = 0; q < PU; ++q) {
       const int k = 1 + base + q * nthr;
-      const c32 A = cadd(zk[q], zm[q]);
-      const c32 C = cmul(w[q], cmul_negi(csub(zk[q], zm[q])));
-      const c32 S1 = cscale(cadd(A, C), tk[q] * g), S2 = cscale(csub(A, C), tm[q] * g);
-      const c32 E = cadd(S1, S2);
-      const c32 iO = cmul_posi(cmul(cconj(w[q]), csub(S1, S2)));
+      c32 yk, ymk;
+      taper_pair(zk[q], zm[q], w[q], tk[q] * g, tm[q] * g, yk, ymk);
       if (k <= npair) {
-        Z[k] = cconj(cadd(E, iO));
-        Z[M - k] = csub(E, iO);
+        Z[k] = yk;
+        Z[M - k] = ymk;
       } else if (k == M / 2) {                         // tk = taper(M/2), tm = taper(M); taper(0) = 1
         const c32 z0 = Z[0], zh = Z[M / 2];
         const float x0 = z0.x + z0.y, xm = tm[q] * (z0.x - z0.y);
@@ -610,18 +779,6 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
   }
 }
 
-// The same middle step for ONE conjugate pair, as a function: zk = Z[k], zmk = Z[M - k] (not conjugated), w = exp(-2 pi i k/2M),
-// tkg / tmg = taper(k) g, taper(M - k) g with g = 1/(4M).  Out: Y[k], Y[M - k].
-PAYNE_HD void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, c32& ymk) {
-  const c32 zm = cconj(zmk);
-  const c32 A = cadd(zk, zm);
-  const c32 C = cmul(w, cmul_negi(csub(zk, zm)));
-  const c32 S1 = cscale(cadd(A, C), tkg), S2 = cscale(csub(A, C), tmg);
-  const c32 E = cadd(S1, S2);
-  const c32 iO = cmul_posi(cmul(cconj(w), csub(S1, S2)));
-  yk = cconj(cadd(E, iO));
-  ymk = csub(E, iO);
-}
 template <bool VSINI> PAYNE_HD float taper_full(const TaperArgs& ta, int k) {
   bool far = false;
   float t = taper_at<VSINI>(ta, k, far);

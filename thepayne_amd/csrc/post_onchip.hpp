@@ -88,13 +88,17 @@ __device__ __forceinline__ void chip_tw32(c32 (&u)[32]) {             // positio
                            0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
                            -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f};
 #pragma unroll
-  for (int i = 1; i < 4; ++i)
+  for (int i = 1; i < 4; ++i) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      const int m = i * j;                                       // <= 21
-      const c32 w = {C[m], -S[m]};                               // exp(-2 pi i m / 32)
-      u[j + 8 * i] = cmul(u[j + 8 * i], w);
+    for (int j = 1; j < 7; j += 2) {                             // x exp(-2 pi i m / 32) = cos - i sin: the pairs sit in scalar registers
+      const pk2 c0 = {C[i * j], S[i * j]}, c1 = {C[i * (j + 1)], S[i * (j + 1)]};
+      pk2 a = to_pk(u[j + 8 * i]), b = to_pk(u[j + 1 + 8 * i]);
+      pk_cmul_k2(a, c0, b, c1);
+      u[j + 8 * i] = un_pk(a); u[j + 1 + 8 * i] = un_pk(b);
     }
+    const pk2 c7 = {C[i * 7], S[i * 7]};
+    u[7 + 8 * i] = un_pk(pk_cmul_k(to_pk(u[7 + 8 * i]), c7));
+  }
 }
 // (scheduling fences between the pieces: half of a thread's registers hold the data; left alone the scheduler pulls every table
 //  read of a stage forward and spills hundreds of registers)
@@ -179,23 +183,35 @@ __device__ __forceinline__ void chip_xch(const ChipLds& L, c32 (&u0)[32], c32 (&
 }
 
 // ---- twiddles between the stages -----------------------------------------------------------------------------
+// (two products per statement -- pk_cmul2 of post_core.hpp: the second product's first instruction sits between the two
+//  dependent instructions of the first)
+__device__ __forceinline__ void chip_mul2(c32& a, c32 wa, c32& b, c32 wb) {
+  pk2 pa = to_pk(a), pb = to_pk(b);
+  pk_cmul2(pa, to_pk(wa), pb, to_pk(wb));
+  a = un_pk(pa); b = un_pk(pb);
+}
 template <bool PERM>
 __device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_32768^(t k1) = W_65536^(2 t k1)
   const int vt = chip_fresh(vt_);
 #pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) {
-    u[chip_pos(PERM, k1)] = cmul(u[chip_pos(PERM, k1)], chip_w65536(L, (2 * vt * k1) & 65535));
+  for (int k1 = 1; k1 < 31; k1 += 2) {
+    const int e0 = (2 * vt * k1) & 65535, e1 = (2 * vt * (k1 + 1)) & 65535;
+    c32 w0 = ldc(L.w1024, (e0 >> 6) & 1023), w1 = ldc(L.w1024, (e1 >> 6) & 1023);
+    chip_mul2(w0, ldc(L.wfine, e0 & 63), w1, ldc(L.wfine, e1 & 63));
+    chip_mul2(u[chip_pos(PERM, k1)], w0, u[chip_pos(PERM, k1 + 1)], w1);
     if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);        // four twiddles (eight table reads) in flight at a time
   }
+  u[chip_pos(PERM, 31)] = cmul(u[chip_pos(PERM, 31)], chip_w65536(L, (2 * vt * 31) & 65535));
 }
 template <bool PERM>
 __device__ __forceinline__ void chip_tw2(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_1024^(l k2a)
   const int l = chip_fresh(vt_) & 31;
 #pragma unroll
-  for (int k = 1; k < 32; ++k) {
-    u[chip_pos(PERM, k)] = cmul(u[chip_pos(PERM, k)], ldc(L.w1024, (l * k) & 1023));
+  for (int k = 1; k < 31; k += 2) {
+    chip_mul2(u[chip_pos(PERM, k)], ldc(L.w1024, (l * k) & 1023), u[chip_pos(PERM, k + 1)], ldc(L.w1024, (l * (k + 1)) & 1023));
     if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
+  u[chip_pos(PERM, 31)] = cmul(u[chip_pos(PERM, 31)], ldc(L.w1024, (l * 31) & 1023));
 }
 
 // natural (layout L0) -> spectrum (thread (k1, k2a), reg k2b, PERMUTED register layout) and back (transposed order: the same
