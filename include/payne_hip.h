@@ -33,6 +33,7 @@ extern "C" {
 #define PAYNE_E_UNSUPPORTED (-2) /* valid in the reference, not (yet) by this library */
 #define PAYNE_E_HIP (-3)         /* HIP runtime error */
 #define PAYNE_E_BATCH (-4)       /* B exceeds opts.b_max */
+#define PAYNE_E_SIGMA (-5)       /* payne_smooth_direct: target sigma below the input's (the reference raises ValueError) */
 
 /* activation codes */
 #define PAYNE_ACT_NONE 0
@@ -212,7 +213,8 @@ int payne_smooth_batch(payne_ctx* ctx, const float* spectra, int ld_spec, const 
  *   PAYNE_SMOOTH_INTERP       np.interp(outwave, wave, spec)           smooth_lsf with neither sigma nor lsf (:464-465)
  * wave, spec [n]: the input AFTER smoothspec's mask and nan_to_num (:131-138); sigma in the units the reference's function
  * takes (km/s for VEL_DIRECT, Angstrom otherwise); inres / in_vel / nsigma: its keywords (defaults 0 / 0 / 10).
- * Returns PAYNE_E_INVALID where the reference raises ValueError (smooth_wave: target sigma below the input's). */
+ * Returns PAYNE_E_SIGMA where the reference raises ValueError (smooth_wave: target sigma below the input's, :381-383);
+ * PAYNE_E_INVALID is a malformed call (null pointers, n < 2, a sigma vector of the wrong length). */
 #define PAYNE_SMOOTH_VEL_DIRECT 0
 #define PAYNE_SMOOTH_WAVE_DIRECT 1
 #define PAYNE_SMOOTH_LSF_DIRECT 2

@@ -465,6 +465,12 @@ def test_smoothspec_branches_off_the_sampler_path(tmp_path, golden):
             assert np.nanmax(np.abs(got - ref)) < tol, (key, np.nanmax(np.abs(got - ref)))
     with pytest.raises(ValueError):                                # smooth_wave: target sigma below the input's (:381-383)
         PP.smoothspec(g["wave"], g["spec"], 0.05, outwave=g["outwave"], smoothtype='lambda', fftsmooth=False, inres=0.08)
+    # an output grid beyond the input's range leaves an empty mask: the quadrature branches return NaN (the reference's
+    # trapz(.)/trapz(.) over an empty set), not the "sigma too low" error
+    far = g["wave"][-1] * 1.5 + np.arange(5.0)
+    with np.errstate(all="ignore"):
+        assert np.isnan(PP.smoothspec(g["wave"], g["spec"], 0.3, outwave=far, smoothtype='lambda', fftsmooth=False)).all()
+        assert np.isnan(PP.smoothspec(g["wave"], g["spec"], 30.0, outwave=far, smoothtype='vel', fftsmooth=False)).all()
     # the FFT velocity branches still go through the likelihood's kernels
     a = PP.smoothspec(g["wave"], np.nan_to_num(g["spec"], nan=1.0), 30000.0, outwave=g["outwave"], smoothtype='R')
     b = O.smooth_R(g["wave"], np.nan_to_num(g["spec"], nan=1.0), 30000.0, g["outwave"], np.inf)

@@ -258,6 +258,16 @@ def test_abi_error_paths(Engine):
     assert rc == -4 and b"b_max" in eng.lib.payne_last_error(eng._ctx)          # PAYNE_E_BATCH
     rc = eng.lib.payne_lnlike_batch(eng._ctx, th.data_ptr(), 4, out.data_ptr(), None)
     assert rc == -1                                                             # no flux bound
+    # payne_smooth_direct: "the reference raises ValueError here" (PAYNE_E_SIGMA) is not "malformed call" (PAYNE_E_INVALID)
+    from thepayne_amd import _lib
+    w = np.linspace(5000.0, 5010.0, 64); sp = np.ones(64); ow = w[8:56].copy(); res = np.empty(len(ow))
+    def direct(kind, sig, inres=0.0):
+        sig = np.ascontiguousarray(sig, dtype=np.float64)
+        return eng.lib.payne_smooth_direct(eng.device.index, kind, w.ctypes.data, sp.ctypes.data, len(w), ow.ctypes.data, len(ow),
+                                           sig.ctypes.data, len(sig), float(inres), 0, 10.0, res.ctypes.data)
+    assert direct(_lib.SMOOTH_WAVE_DIRECT, [0.05], inres=0.08) == _lib.E_SIGMA    # target sigma below the input's (smoothing.py:381-383)
+    assert direct(_lib.SMOOTH_WAVE_DIRECT, np.full(7, 0.3)) == _lib.E_INVALID     # a sigma vector that is neither scalar nor [n]
+    assert direct(_lib.SMOOTH_WAVE_DIRECT, [0.3]) == 0 and np.allclose(res, 1.0, atol=1e-12)
 
 
 @pytest.mark.parametrize("variant", [0, 256, 32], ids=["four_step", "four_step_fused", "plain_passes"])
@@ -312,14 +322,15 @@ def test_full_size_properties(Engine):
 
 
 def test_c5_at_size(Engine):
-    """BASELINE config 5 at its real shape: 65 536 pixels, H = 300, a batch of 256 candidates through the 256 persistent
-    workgroups of payne_post_big_kernel.  A handful of rows against the oracle (0.2 s each), the rest through
+    """BASELINE config 5 at its real shape AND its real batch: 65 536 pixels, H = 300, 2048 candidates (eight per persistent
+    workgroup of payne_post_chip_kernel).  Eight rows spread over the batch against the oracle (0.2 s each), every row through
     size-independent properties: chi^2 recomputed on the host from the predicted spectra, determinism, independence of
     the position in the batch, the NaN contract of Inst_R above the network's resolution."""
     cfg = synth.CONFIGS["C5"]
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
     obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
-    B = 256
+    B = cfg["batch"]
+    assert B == 2048
     th7 = synth.draw_candidates(B, seed=55)
     th7[:, 6] = np.linspace(0.55, 0.9, B) * cfg["R"]
     th7[7, 6] = 1.2 * raw["resolution"] / 2.355                       # above the ANN's own resolution: NaN by contract
@@ -332,7 +343,7 @@ def test_c5_at_size(Engine):
     lnl = eng.lnlike_batch(th).cpu().numpy()
     assert np.isnan(lnl[7]) and np.isfinite(np.delete(lnl, 7)).all()
     L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
-    for k in (0, 1, 2, 200):
+    for k in (0, 1, 2, 200, 255, 256, 1023, 2047):                   # (first and last of a workgroup's walk, both ends of the batch)
         ref = L.lnlikefn(th7[k])
         assert abs(lnl[k] - ref) <= lnl_tol(np.array([ref]))[0], (k, lnl[k], ref)
     spec = eng.predict_batch(th[:3], stage=2, fwhm_R=True).cpu().numpy()

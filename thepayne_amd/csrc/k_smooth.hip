@@ -176,7 +176,7 @@ extern "C" int payne_smooth_direct(int device, int kind, const double* wave, con
     for (int j = 0; j < (nsig > 1 ? n : 1); ++j) {
       const double s = sigma[j];
       const double sq = inres <= 0.0 ? s * s : (in_vel ? s * s - (wave[j] / inres) * (wave[j] / inres) : s * s - inres * inres);
-      if (sq < 0.0) return PAYNE_E_INVALID;
+      if (sq < 0.0) return PAYNE_E_SIGMA;
     }
   }
   int prev = 0;

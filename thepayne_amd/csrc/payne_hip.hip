@@ -1106,14 +1106,17 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     double *tc = nullptr, *tv = nullptr;
     const size_t nb = (size_t)d->adv.tab_n * 8;
     if ((rc = alloc(nb, (void**)&tc)) || (rc = alloc(nb, (void**)&tv))) { payne_sampler_destroy(s); return rc; }
-    (void)hipMemcpy(tc, d->adv.tab_cdf, nb, hipMemcpyHostToDevice);
-    (void)hipMemcpy(tv, d->adv.tab_val, nb, hipMemcpyHostToDevice);
-    s->sd.adv.tab_cdf = tc; s->sd.adv.tab_val = tv;
+    s->sd.adv.tab_cdf = tc; s->sd.adv.tab_val = tv;                     // (owned by the sampler from here on)
+    if (hipMemcpy(tc, d->adv.tab_cdf, nb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(tv, d->adv.tab_val, nb, hipMemcpyHostToDevice) != hipSuccess) {
+      payne_sampler_destroy(s);
+      return fail(c, PAYNE_E_HIP, "upload of the tabulated prior");
+    }
   }
   {   // the transforms' per-dimension constants, computed by the device functions the steps use (q_dev: staging, free here)
     double qh[2 * PAYNE_MAX_DIM];
     hipLaunchKernelGGL(payne_prior_cache_kernel, dim3(1), dim3(64), 0, nullptr, s->sd, s->q_dev);
-    if (hipMemcpy(qh, s->q_dev, sizeof(qh), hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipGetLastError() != hipSuccess || hipMemcpy(qh, s->q_dev, sizeof(qh), hipMemcpyDeviceToHost) != hipSuccess) {
       payne_sampler_destroy(s);
       return fail(c, PAYNE_E_HIP, "prior cache kernel");
     }

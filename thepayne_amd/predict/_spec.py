@@ -250,11 +250,23 @@ class PayneSpecPredict(object):
             ow = np.ascontiguousarray(ow, dtype=np.float64)
             sig = None if sig is None else np.ascontiguousarray(np.atleast_1d(sig), dtype=np.float64)
             out = np.empty(len(ow))
+            if len(w) < 2:
+                # a mask that leaves fewer than two input pixels (an output grid outside the input's range): the reference's
+                # quadratures divide trapz over an empty or one-point set by itself (0 / 0 = NaN); np.interp raises on an
+                # empty set of sample points and returns the one sample otherwise
+                if kind == _lib.SMOOTH_INTERP:
+                    if len(w) == 0:
+                        raise ValueError("array of sample points is empty")
+                    return np.full(len(ow), float(s[0]))
+                return np.full(len(ow), np.nan)
             rc = lib.payne_smooth_direct(dev, kind, w.ctypes.data, s.ctypes.data, len(w), ow.ctypes.data, len(ow),
                                          None if sig is None else sig.ctypes.data, 0 if sig is None else len(sig),
                                          float(inres), int(bool(in_vel)), float(nsigma), out.ctypes.data)
-            if rc == -1:
+            if rc == _lib.E_SIGMA:                                            # smoothing.py:381-383
                 raise ValueError("Desired wavelength sigma is lower than the value possible for this input spectrum.")
+            if rc == _lib.E_INVALID:
+                raise ValueError("payne_smooth_direct: invalid arguments (kind %d, %d input pixels, %d sigma values)"
+                                 % (kind, len(w), 0 if sig is None else len(sig)))
             if rc != 0:
                 raise RuntimeError("payne_smooth_direct failed (%d)" % rc)
             return out

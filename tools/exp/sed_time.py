@@ -2,10 +2,8 @@
 (variant 8192, PAYNE_V_SED_OWN_LAUNCH) and as extra workgroups of the first dense launch (default).  A third form, the
 photometric kernel on a side stream beside the dense layers (fork / join by events), took 62.6 us against 51.7 us in line -- two
 cross-queue dependencies cost more than the kernel they would hide -- and was dropped."""
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
-import os
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+import os, sys, time, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # the repository this file sits in
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from thepayne_amd import synth, nnio
 from thepayne_amd.engine import PayneEngine, highav_coefficients
