@@ -124,6 +124,8 @@ typedef struct payne_opts {
 #define PAYNE_V_SED_OWN_LAUNCH 8192u /* joint likelihoods: the photometric nets as a launch of their own (one wave per candidate and
                                     * filter: what payne_sed_batch and nets wider than 64 use) instead of extra workgroups of the
                                     * hidden-layer launch */
+#define PAYNE_V_OUT_SMALL_TILES 16384u /* output layer with many tiles per CU (C5): 64 x 128 tiles, two workgroups per CU (what batches that
+                                       * are not whole 128 x 256 tiles use) instead of persistent workgroups on 128 x 256 tiles */
 #define PAYNE_V_DENSE_FUSED 32768u /* hidden layers + output layer in ONE launch: output-layer workgroups take the hidden tiles on first
                                     * (roles by ticket), publish them write-through and hand them over through agent-scope counters
                                     * (3-layer nets of equal hidden width <= 320, batch a multiple of 64, one output tile per CU) */

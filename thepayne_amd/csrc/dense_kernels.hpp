@@ -667,6 +667,179 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// The same six-product output layer for MANY tiles per CU (C5: 2048 x 65 536 outputs): 128 x 256 tiles, persistent workgroups.
+// payne_dense_dma3_kernel<0, 2, false> brings in 36 KB of operand planes per 32-deep step for 64 x 128 outputs and runs at what the
+// LDS-DMA path delivers (~14 B per clock and CU at C5: its matrix instructions are busy 29 % of the time); a 128 x 256 tile
+// brings in 72 KB per step for FOUR times the outputs -- half the bytes per product.  One 512-thread workgroup per CU walks its
+// share of the tiles (XCD-aware: the workgroups of an XCD take a contiguous run of tiles, row tiles fastest, so the XCD's L2
+// holds two weight tiles and the activations); eight waves as 2 x 4, a wave owns 64 x 64 outputs (four 32 x 32 accumulators).
+// The steps of all its tiles form ONE sequence through the two-stage ring: the first stage of the next tile is requested
+// during the last step of this one, ahead of the epilogue's stores, so neither a tile's first load nor its stores are exposed.
+// Whole tiles only (B % 128 == 0, N % 256 == 0: the launch falls back to payne_dense_dma3_kernel otherwise).
+// Stage: 3 planes x (128 A rows + 256 B rows) x 64 B = 72 KB (two stages: 144 KB); a 1-KiB DMA piece = 16 rows of one plane,
+// 72 pieces, nine per wave; 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3) (as payne_dense_dma3_kernel).
+// ----------------------------------------------------------------------------
+#ifndef PAYNE_EXP_B3
+#define PAYNE_EXP_B3 0              // (timing experiments, results WRONG by design: 1 no matrix instructions, 2 no requests after the first, 4 no stores)
+#endif
+constexpr int B3_TM = 128, B3_TN = 256;
+constexpr int B3_A_PLANE = B3_TM * 64, B3_B_PLANE = B3_TN * 64;            // bytes per plane and stage
+constexpr int B3_STAGE = 3 * (B3_A_PLANE + B3_B_PLANE);
+constexpr size_t b3_lds_bytes() { return (size_t)2 * B3_STAGE; }
+__global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p);
+#ifdef PAYNE_TU_DENSE
+__global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char b3_sm[];
+  const int ntiles = p.grid_m * p.grid_n;
+  // workgroup b sits on XCD b & 7 (round-robin dispatch); XCD x takes tiles [x per, (x + 1) per), its workgroups stride through them
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nx = (gridDim.x + 7 - xcd) >> 3;     // my index among the XCD's nx workgroups
+  const int per = (ntiles + 7) >> 3, t_lo = xcd * per, t_hi = (t_lo + per < ntiles) ? t_lo + per : ntiles;
+  const int my_n = (t_lo + jx < t_hi) ? (t_hi - t_lo - jx + nx - 1) / nx : 0;
+  if (my_n <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
+  // the nine pieces this wave moves per stage: plane, 16-row block, and where they land
+  int prow[9], pdst[9];
+  bool pA[9];
+  int ppl[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int q = wave * 9 + j;
+    pA[j] = q < 24;
+    ppl[j] = pA[j] ? q >> 3 : (q - 24) >> 4;
+    const int blk = pA[j] ? (q & 7) : ((q - 24) & 15);
+    prow[j] = 16 * blk + (lane >> 2);
+    pdst[j] = pA[j] ? ppl[j] * B3_A_PLANE + blk * 1024 : 3 * B3_A_PLANE + ppl[j] * B3_B_PLANE + blk * 1024;
+  }
+  const unsigned char* src[9];
+  auto set_src = [&](int t) {
+    const int m0 = (t % p.grid_m) * B3_TM, n0 = (t / p.grid_m) * B3_TN;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int row = prow[j];
+      const int c = (lane & 3) ^ ((row >> 2) & 3);         // which 16-byte chunk of the row belongs in this lane's slot
+      if (pA[j]) {
+        const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
+        src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)ppl[j] * p.plane_x + (size_t)r * p.ldp) + 16 * c;
+      } else {
+        const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
+        src[j] = reinterpret_cast<const unsigned char*>(p.Wp + (size_t)ppl[j] * p.plane_w + (size_t)r * p.K) + 16 * c;
+      }
+    }
+  };
+  auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
+                                       (__attribute__((address_space(3))) void*)(b3_sm + stage * B3_STAGE + pdst[j]), 16, 0, 0);
+  };
+  f32x16 acc[2][2];
+  const int h = lane >> 5;
+  int Ra[2], Rb[2], sa[2], sb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    Ra[i] = wm0 + 32 * i + (lane & 31); Rb[i] = wn0 + 32 * i + (lane & 31);
+    sa[i] = (Ra[i] >> 2) & 3; sb[i] = (Rb[i] >> 2) & 3;
+  }
+  struct Frag { bf16x8_t a[2][3], b[2][3]; };              // one 16-deep matrix step: two row blocks, two column blocks, three planes
+  auto frags = [&](int stage, int ks, Frag& f) {
+    const unsigned char* As = b3_sm + stage * B3_STAGE;
+    const unsigned char* Bs = As + 3 * B3_A_PLANE;
+    const int c = 2 * ks + h;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        f.a[i][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * B3_A_PLANE + Ra[i] * 64 + 16 * (c ^ sa[i]));
+        f.b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * B3_B_PLANE + Rb[i] * 64 + 16 * (c ^ sb[i]));
+      }
+  };
+  auto products = [&](const Frag& f) {                     // smallest partial products first, block by block
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 a = acc[i][j];
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], a, 0, 0, 0);
+        acc[i][j] = a;
+      }
+  };
+  const int nk = p.K / 32;                                 // padded: exact
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
+  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
+  const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
+  int t = t_lo + jx;
+  set_src(t);
+  issue(0, 0);
+  int s = 0;                                               // running step count: stage = s & 1
+  bool after_stores = false;                               // the previous step ended with a tile's 64 stores
+  for (int n = 0; n < my_n; ++n) {
+    const int m0 = (t % p.grid_m) * B3_TM, n0 = (t / p.grid_m) * B3_TN;
+    const int t_next = t + nx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bv[2];
+    for (int it = 0; it < nk; ++it, ++s) {
+      // this step's stage has landed: everything of mine but the stores that followed its request (they complete in order)
+      if (after_stores) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      after_stores = false;
+      asm volatile("s_barrier" ::: "memory");              // everybody's pieces landed; everybody finished the step before
+      Frag f0, f1;
+      frags(s & 1, 0, f0);
+      frags(s & 1, 1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+#if !(PAYNE_EXP_B3 & 2)
+      if (it + 1 < nk) issue((s + 1) & 1, (it + 1) * 32);  // into the buffer the step before consumed
+      else if (n + 1 < my_n) { set_src(t_next); issue((s + 1) & 1, 0); }
+#endif
+      if (it == 0) {                                       // the epilogue's bias (younger than the request: waited for with the next stage)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn0 + 32 * j + (lane & 31);
+          bv[j] = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#if !(PAYNE_EXP_B3 & 1)
+      products(f0);
+      if (it + 1 < nk || last_both) products(f1);
+#else
+      asm volatile("" :: "v"(f0.a[0][0]), "v"(f0.b[1][2]), "v"(f1.a[1][1]), "v"(f1.b[0][0]));
+#endif
+    }
+    // C/D map of a 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn0 + 32 * j + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          // (unconditional: the launch guarantees whole tiles -- B % 128 == 0, N % 256 == 0 --, so every wave issues exactly 64
+          //  stores behind the next tile's request, which is what the vmcnt(63) above counts on)
+          const float v = acc[i][j][r] + bv[j];
+          if (!(PAYNE_EXP_B3 & 4) || v == 1.2345e30f) __builtin_nontemporal_store(act_none ? v : act_apply(v, p.act), &p.Y[(size_t)row * p.ldy + col]);
+        }
+      }
+    after_stores = true;
+    t = t_next;
+  }
+}
+#endif
+
+// ----------------------------------------------------------------------------
 // Hidden layers, workgroup form: one 256-thread group per 32x32 output tile, the whole K
 // extent (<= 320 per chunk) of both operands staged in LDS by coalesced f32x4_t loads issued
 // together (one L2 latency), then the four waves split K between them (v_mfma_f32_16x16x4_f32,

@@ -562,6 +562,7 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 4, true>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<10, 4, true>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 2, false>), d3_lds_bytes<2>());
+  set(reinterpret_cast<const void*>(payne_dense_big3_kernel), b3_lds_bytes());
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
@@ -623,9 +624,21 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s) {
 #ifdef PAYNE_STAMPS
   p.stamps = g_dense_stamps;
 #endif
-  const dim3 grid(p.grid_m * p.grid_n), block(512);
+  const dim3 block(512);
+  if (p.B % B3_TM == 0 && p.N % B3_TN == 0 && (p.B / B3_TM) * (p.N / B3_TN) >= 2 * c->n_cu && !(c->opts.variant & PAYNE_V_OUT_SMALL_TILES)) {
+    // many whole 128 x 256 tiles per CU (C5): persistent workgroups, half the operand bytes per product
+    p.grid_m = p.B / B3_TM; p.grid_n = p.N / B3_TN;
+    PAYNE_LAUNCH(payne_dense_big3_kernel, dim3(c->n_cu), block, b3_lds_bytes(), s, p);
+    return;
+  }
+  const dim3 grid(p.grid_m * p.grid_n);
   if ((int)grid.x > c->n_cu) PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 2, false>), grid, block, d3_lds_bytes<2>(), s, p);   // many tiles per CU
-  else if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+  else if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) {
+    PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+#ifdef PAYNE_EXP_OUT2X   /* timing experiment: the same launch again, its operands now wherever the first one left them */
+    hipLaunchKernelGGL((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+#endif
+  }
   else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
 }
 

@@ -52,7 +52,10 @@ constexpr double kVsTabMax = 256.0;
 // waves (the other four only take part in the barriers): radix-4 passes on all eight (6 barriers per transform
 // instead of 4) cost more than the occupancy gains -- measured at C2 (512 candidates, 2 groups per CU):
 // 256 / 256 threads 21.8 us per batch, 512 / 512 (radix 4) 32.2 us, 512 / 256 19.5 us.
-constexpr int kPostThreads = 512;
+#ifndef PAYNE_POST_THREADS
+#define PAYNE_POST_THREADS 512
+#endif
+constexpr int kPostThreads = PAYNE_POST_THREADS;
 constexpr int kFftThreads = 256;
 // unroll factor of the per-pixel loops for `ppt` pixels per thread (loads of one unrolled body are in flight together)
 PAYNE_HD constexpr int unroll_for(int ppt) { return ppt >= 16 ? 16 : (ppt >= 8 ? 8 : 4); }

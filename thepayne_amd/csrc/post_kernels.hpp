@@ -95,7 +95,12 @@ __device__ PAYNE_EXP_TAIL_ATTR static void walk_tail(const WalkTail* t, int b, i
 // the output variants of the observed-grid loop, the stage branches and the in-kernel setup are compiled out
 // (most of the 270 KB of the full kernel).
 template <int LOG2N, bool TW_LDS, bool LEAN = false>
-__global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTables T, PostArgs a) {
+#if PAYNE_POST_THREADS > 512
+#define PAYNE_POST_BOUNDS __launch_bounds__(kPostThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define PAYNE_POST_BOUNDS __launch_bounds__(kPostThreads)
+#endif
+__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs a) {
   // T by value: its pointer members then live in the kernarg segment and are known to be
   // global (a struct read through a device pointer yields generic pointers -> flat_load,
   // which also ties every table load to the LDS wait counter)
@@ -137,6 +142,16 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
     twf = twl;                                                 // made visible by the first phase barrier
   }
   const int b = blockIdx.x;
+  // joint likelihoods: the photometric terms ((m - o) / e)^2 by one lane per filter of the second wave, requested NOW -- asked for by
+  // thread 0 after the spectrum's chi^2 they were a memory round trip and seven dependent fp64 divisions at the end of the
+  // workgroup's life (C3: 1.3 us of the post kernel)
+  __shared__ double sed_terms[64];
+  const bool sed_early = a.mags != nullptr && a.n_filters <= 64;
+  if (sed_early && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + a.n_filters) {
+    const int f = (int)threadIdx.x - 64;
+    const double d = a.mags[(size_t)b * a.n_filters + f] - a.obs_mag[f], e = a.obs_err[f];
+    sed_terms[f] = (d * d) / (e * e);                       // likelihood.py:109-112 (read by thread 0 behind the phases' barriers)
+  }
   DevExecT<true, TW_LDS> ex;
 #ifdef PAYNE_STAMPS
   if (a.stamps) {
@@ -156,7 +171,8 @@ __global__ void __launch_bounds__(kPostThreads) payne_post_kernel(const PostTabl
   double lnl_v = 0.0;
   if (threadIdx.x == 0 && a.lnl && ostage < 0) {
     double x2 = *chi2;
-    if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+    if (sed_early) { double sx = 0.0; for (int f = 0; f < a.n_filters; ++f) sx += sed_terms[f]; x2 += sx; }   // (sed_chi2's order)
+    else if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
     lnl_v = -0.5 * x2;                                          // likelihood.py:117
     a.lnl[b] = lnl_v;
   }

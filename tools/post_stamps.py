@@ -49,7 +49,7 @@ def problem(cfg_name):
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C2"
 raw, obs, flux, eflux = problem(cfgname)
 B = int(os.environ.get("STAMP_BATCH", synth.CONFIGS[cfgname]["batch"]))
-eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=B)
+eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=B, variant=int(os.environ.get("STAMP_VARIANT", "0")))
 th = eng._theta(theta_full(synth.draw_candidates(B, seed=1)), eng.ncols)
 eng.lnlike_batch(th)
 eng.torch.cuda.synchronize()
