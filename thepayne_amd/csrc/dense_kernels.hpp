@@ -774,14 +774,27 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
   const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
   const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
   const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
-  int t = t_lo + jx;
+  // The n-th tile of this workgroup.  Blocked order (whole XCD shares: 32 workgroups per XCD, row tiles a multiple of 8, the XCD's
+  // column tiles a multiple of 4): at any time the XCD works on 8 row tiles x 4 column tiles -- 3.9 MB of operand planes, the least
+  // for 32 tiles --, and keeps the SAME 8 row tiles while it sweeps its column tiles four at a time, so their activation planes
+  // (2 MB) stay in its L2 and only the weights stream through.  Otherwise: the XCD's tiles in order, row tiles fastest.
+  const int xcols = p.grid_n >> 3;                          // column tiles per XCD (blocked order only)
+  const bool blocked = nx == 32 && (p.grid_n & 7) == 0 && (p.grid_m & 7) == 0 && (xcols & 3) == 0 && per * 8 == ntiles;
+  auto tile_at = [&](int n) {
+    if (!blocked) return t_lo + jx + n * nx;
+    const int sweeps = xcols >> 2;                          // steps of four column tiles per row group
+    const int g = n / sweeps, c4 = n - g * sweeps;
+    const int row = g * 8 + (jx & 7), colt = xcd * xcols + c4 * 4 + (jx >> 3);
+    return colt * p.grid_m + row;
+  };
+  int t = tile_at(0);
   set_src(t);
   issue(0, 0);
   int s = 0;                                               // running step count: stage = s & 1
   bool after_stores = false;                               // the previous step ended with a tile's 64 stores
   for (int n = 0; n < my_n; ++n) {
     const int m0 = (t % p.grid_m) * B3_TM, n0 = (t / p.grid_m) * B3_TN;
-    const int t_next = t + nx;
+    const int t_next = tile_at(n + 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
