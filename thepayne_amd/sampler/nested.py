@@ -262,16 +262,16 @@ class NestedSampler(object):
     # ---- proposal generation: fills the queue with batched evaluations -------------------
     def _clear_queue(self):
         nd = self.ndim
-        self._qU, self._qV = np.empty((0, nd)), np.empty((0, nd))
-        self._ql, self._qnc = np.empty(0), np.empty(0, dtype=np.int32)
-        self._qpos = 0
+        self._q_assign(np.empty((0, nd)), np.empty((0, nd)), np.empty(0), np.empty(0, dtype=np.int32))
 
     def _set_queue(self, U, V, ll, nc):
-        self._qU = np.ascontiguousarray(U, dtype=np.float64)
-        self._qV = np.ascontiguousarray(V, dtype=np.float64)
-        self._ql = np.ascontiguousarray(ll, dtype=np.float64)
-        self._qnc = np.ascontiguousarray(nc, dtype=np.int32)
-        self._qpos = 0
+        self._q_assign(np.ascontiguousarray(U, dtype=np.float64), np.ascontiguousarray(V, dtype=np.float64),
+                       np.ascontiguousarray(ll, dtype=np.float64), np.ascontiguousarray(nc, dtype=np.int32))
+
+    def _q_assign(self, U, V, ll, nc):
+        """The queue's four arrays and, once per queue, their addresses for the native consume call."""
+        self._qU, self._qV, self._ql, self._qnc, self._qpos = U, V, ll, nc, 0
+        self._q_addr = tuple(a.__array_interface__['data'][0] for a in (U, V, ll, nc))
 
     def _fill_queue(self):
         K, nd, rng = self.queue_size, self.ndim, self.rng
@@ -323,7 +323,7 @@ class NestedSampler(object):
             self.scale = min(max(self.scale * math.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)
             self._pending_nc += idle
             qU, qV, ql, qnc = self._qbuf
-            self._qU, self._qV, self._ql, self._qnc, self._qpos = qU[:nq], qV[:nq], ql[:nq], qnc[:nq], 0
+            self._q_assign(qU[:nq], qV[:nq], ql[:nq], qnc[:nq])
             return
         # rwalk / slice: K lock-step chains
         start = rng.integers(0, self.nlive, size=K)
@@ -459,12 +459,33 @@ class NestedSampler(object):
         self._set_queue(U, V, ll, np.maximum(1, ncalls))
 
     # ---- the bookkeeping loop over one queue --------------------------------------------------
+    _REC_F = ("logl", "logvol", "logwt", "logz", "logzvar", "h", "delta_logz")     # fp64 columns besides u / v
+    _REC_I = ("worst", "nc", "worst_it")                                           # int32 columns
+
     def _records(self, m):
+        """A dict of record arrays for m dead points: views of ONE fp64 block and ONE int32 block (fourteen separate allocations
+        and their addresses were a third of a consume call on the host)."""
         nd = self.ndim
-        return {"worst": np.empty(m, np.int32), "u": np.empty((m, nd)), "v": np.empty((m, nd)), "logl": np.empty(m),
-                "logvol": np.empty(m), "logwt": np.empty(m), "logz": np.empty(m), "logzvar": np.empty(m),
-                "h": np.empty(m), "nc": np.empty(m, np.int32), "worst_it": np.empty(m, np.int32),
-                "delta_logz": np.empty(m)}
+        fb = np.empty(m * (2 * nd + len(self._REC_F)))
+        ib = np.empty(m * len(self._REC_I), np.int32)
+        rec = {"u": fb[:m * nd].reshape(m, nd), "v": fb[m * nd:2 * m * nd].reshape(m, nd)}
+        o = 2 * m * nd
+        for k in self._REC_F:
+            rec[k] = fb[o:o + m]
+            o += m
+        for j, k in enumerate(self._REC_I):
+            rec[k] = ib[j * m:(j + 1) * m]
+        rec["_base"] = (fb, ib)
+        return rec
+
+    def _live_addr(self):
+        """Addresses of the four live-point arrays (asked of numpy only when one of them has been replaced: an address costs
+        1.5 us through __array_interface__, more through ndarray.ctypes, and a consume call needs twelve)."""
+        arrs = (self.live_u, self.live_v, self.live_logl, self.live_it)
+        key = tuple(map(id, arrs))
+        if getattr(self, "_live_key", None) != key:
+            self._live_key, self._live_ptr, self._live_ref = key, tuple(a.__array_interface__['data'][0] for a in arrs), arrs
+        return self._live_ptr
 
     def _consume(self, dlogz, max_emit, logl_max):
         """Walk the queue: returns (records, stop) with stop in {'queue', 'converged', 'limit', 'logl_max'}."""
@@ -475,14 +496,17 @@ class NestedSampler(object):
             L = self._L
             st = L.NsState(self.nlive, self.ndim, int(self.it), int(self._pending_nc), self.logz, self.logzvar, self.h,
                            self.logvol, self.loglstar)
-            A = lambda a: a.ctypes.data                                              # noqa: E731
-            dead = L.NsDead(*[A(rec[k]) for k in ("worst", "u", "v", "logl", "logvol", "logwt", "logz", "logzvar", "h",
-                                                  "nc", "worst_it", "delta_logz")])
-            q0, nd = self._qpos, self.ndim
+            fb, ib = rec["_base"]
+            f0, i0, nd = fb.__array_interface__['data'][0], ib.__array_interface__['data'][0], self.ndim
+            col = lambda j: f0 + 8 * cap * (2 * nd + j)                           # noqa: E731  (the j-th fp64 column of the block)
+            dead = L.NsDead(i0, f0, f0 + 8 * cap * nd, col(0), col(1), col(2), col(3), col(4), col(5), i0 + 4 * cap,
+                            i0 + 8 * cap, col(6))
+            q0 = self._qpos
             consumed, stop = C.c_int(0), C.c_int(0)
-            m = self._lib.payne_ns_consume(C.byref(st), A(self.live_u), A(self.live_v), A(self.live_logl),
-                                           A(self.live_it), A(self._qU) + q0 * nd * 8, A(self._qV) + q0 * nd * 8,
-                                           A(self._ql) + q0 * 8, A(self._qnc) + q0 * 4, nq, float(dlogz),
+            lu, lv, lll, lit = self._live_addr()
+            aU, aV, al, anc = self._q_addr
+            m = self._lib.payne_ns_consume(C.byref(st), lu, lv, lll, lit, aU + q0 * nd * 8, aV + q0 * nd * 8,
+                                           al + q0 * 8, anc + q0 * 4, nq, float(dlogz),
                                            int(min(max_emit, 2 ** 62)), float(logl_max), C.byref(dead), cap,
                                            C.byref(consumed), C.byref(stop))
             if m < 0:
@@ -493,6 +517,7 @@ class NestedSampler(object):
             stop = ('queue', 'converged', 'limit', 'logl_max')[stop.value]
         else:
             m, stop = self._consume_py(rec, dlogz, max_emit, logl_max, cap)
+        del rec["_base"]
         if m < cap:
             rec = {k: v[:m] for k, v in rec.items()}
         return rec, stop
