@@ -669,23 +669,26 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 // ----------------------------------------------------------------------------
 // The same six-product output layer for MANY tiles per CU (C5: 2048 x 65 536 outputs): 128 x 256 tiles, persistent workgroups.
 // payne_dense_dma3_kernel<0, 2, false> brings in 36 KB of operand planes per 32-deep step for 64 x 128 outputs and runs at what the
-// LDS-DMA path delivers (~14 B per clock and CU at C5: its matrix instructions are busy 29 % of the time); a 128 x 256 tile
-// brings in 72 KB per step for FOUR times the outputs -- half the bytes per product.  One 512-thread workgroup per CU walks its
-// share of the tiles (XCD-aware: the workgroups of an XCD take a contiguous run of tiles, row tiles fastest, so the XCD's L2
-// holds two weight tiles and the activations); eight waves as 2 x 4, a wave owns 64 x 64 outputs (four 32 x 32 accumulators).
-// The steps of all its tiles form ONE sequence through the two-stage ring: the first stage of the next tile is requested
-// during the last step of this one, ahead of the epilogue's stores, so neither a tile's first load nor its stores are exposed.
+// memory side delivers to a CU (13-14 B per clock from the Infinity Cache, 22 from L2: tools/exp/stage_rate.hip -- by LDS-DMA and
+// through registers alike); its matrix instructions are busy 29 % of the time.  A 128 x 256 tile brings in 36 KB per 16-deep step
+// for FOUR times the outputs per k -- half the bytes per product.  One 512-thread workgroup per CU walks its share of the tiles;
+// eight waves as 2 x 4, a wave owns 64 x 64 outputs (four 32 x 32 accumulators).
+// The 16-deep steps of ALL its tiles form one sequence through a FOUR-stage ring with three stages in flight: the requests never
+// drain at a barrier, the first stages of the next tile are requested during the last steps of this one (ahead of the epilogue's
+// stores), so neither a tile's first load nor its stores stop the stream.
+// Tile order: see tile_at below (blocked: an XCD keeps 8 row tiles in its L2 while it sweeps its column tiles four at a time).
 // Whole tiles only (B % 128 == 0, N % 256 == 0: the launch falls back to payne_dense_dma3_kernel otherwise).
-// Stage: 3 planes x (128 A rows + 256 B rows) x 64 B = 72 KB (two stages: 144 KB); a 1-KiB DMA piece = 16 rows of one plane,
-// 72 pieces, nine per wave; 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3) (as payne_dense_dma3_kernel).
+// Stage: 3 planes x (128 A rows + 256 B rows) x 32 B = 36 KB (four stages: 144 KB); a 1-KiB DMA piece = 32 rows of one plane
+// (two lanes per row), 36 pieces: waves 0-3 move five, waves 4-7 four; the two 16-byte chunks of tile row r are swapped where
+// bit 4 of r is set: the sixteen lanes a ds_read_b128 serves together then cover sixteen different bank groups.
 // ----------------------------------------------------------------------------
 #ifndef PAYNE_EXP_B3
 #define PAYNE_EXP_B3 0              // (timing experiments, results WRONG by design: 1 no matrix instructions, 2 no requests after the first, 4 no stores)
 #endif
-constexpr int B3_TM = 128, B3_TN = 256;
-constexpr int B3_A_PLANE = B3_TM * 64, B3_B_PLANE = B3_TN * 64;            // bytes per plane and stage
+constexpr int B3_TM = 128, B3_TN = 256, B3_NS = 4;
+constexpr int B3_A_PLANE = B3_TM * 32, B3_B_PLANE = B3_TN * 32;            // bytes per plane and stage
 constexpr int B3_STAGE = 3 * (B3_A_PLANE + B3_B_PLANE);
-constexpr size_t b3_lds_bytes() { return (size_t)2 * B3_STAGE; }
+constexpr size_t b3_lds_bytes() { return (size_t)B3_NS * B3_STAGE; }
 __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p);
 #ifdef PAYNE_TU_DENSE
 __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
@@ -699,26 +702,27 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
-  // the nine pieces this wave moves per stage: plane, 16-row block, and where they land
-  int prow[9], pdst[9];
-  bool pA[9];
-  int ppl[9];
+  const bool five = wave < 4;                              // pieces this wave moves per stage: 5 (waves 0-3) or 4
+  // the pieces this wave moves per stage: plane, 32-row block, and where they land
+  int prow[5], pdst[5], ppl[5];
+  bool pA[5];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int q = wave * 9 + j;
-    pA[j] = q < 24;
-    ppl[j] = pA[j] ? q >> 3 : (q - 24) >> 4;
-    const int blk = pA[j] ? (q & 7) : ((q - 24) & 15);
-    prow[j] = 16 * blk + (lane >> 2);
+  for (int j = 0; j < 5; ++j) {
+    int q = five ? wave * 5 + j : 20 + (wave - 4) * 4 + j;
+    if (q > 35) q = 35;                                    // (slot 4 of the four-piece waves: never issued)
+    pA[j] = q < 12;
+    ppl[j] = pA[j] ? q >> 2 : (q - 12) >> 3;
+    const int blk = pA[j] ? (q & 3) : ((q - 12) & 7);
+    prow[j] = 32 * blk + (lane >> 1);
     pdst[j] = pA[j] ? ppl[j] * B3_A_PLANE + blk * 1024 : 3 * B3_A_PLANE + ppl[j] * B3_B_PLANE + blk * 1024;
   }
-  const unsigned char* src[9];
+  const unsigned char* src[5];
   auto set_src = [&](int t) {
     const int m0 = (t % p.grid_m) * B3_TM, n0 = (t / p.grid_m) * B3_TN;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < 5; ++j) {
       const int row = prow[j];
-      const int c = (lane & 3) ^ ((row >> 2) & 3);         // which 16-byte chunk of the row belongs in this lane's slot
+      const int c = (lane & 1) ^ ((row >> 4) & 1);         // which 16-byte chunk of the row belongs in this lane's slot
       if (pA[j]) {
         const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
         src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)ppl[j] * p.plane_x + (size_t)r * p.ldp) + 16 * c;
@@ -730,29 +734,30 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
   };
   auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
-                                       (__attribute__((address_space(3))) void*)(b3_sm + stage * B3_STAGE + pdst[j]), 16, 0, 0);
+    for (int j = 0; j < 5; ++j)
+      if (j < 4 || five)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
+                                         (__attribute__((address_space(3))) void*)(b3_sm + stage * B3_STAGE + pdst[j]), 16, 0, 0);
   };
   f32x16 acc[2][2];
   const int h = lane >> 5;
-  int Ra[2], Rb[2], sa[2], sb[2];
+  int oa[2], ob[2];                                        // byte offsets of this lane's fragment rows inside a plane
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    Ra[i] = wm0 + 32 * i + (lane & 31); Rb[i] = wn0 + 32 * i + (lane & 31);
-    sa[i] = (Ra[i] >> 2) & 3; sb[i] = (Rb[i] >> 2) & 3;
+    const int Ra = wm0 + 32 * i + (lane & 31), Rb = wn0 + 32 * i + (lane & 31);
+    oa[i] = Ra * 32 + 16 * (h ^ ((Ra >> 4) & 1));
+    ob[i] = Rb * 32 + 16 * (h ^ ((Rb >> 4) & 1));
   }
   struct Frag { bf16x8_t a[2][3], b[2][3]; };              // one 16-deep matrix step: two row blocks, two column blocks, three planes
-  auto frags = [&](int stage, int ks, Frag& f) {
+  auto frags = [&](int stage, Frag& f) {
     const unsigned char* As = b3_sm + stage * B3_STAGE;
     const unsigned char* Bs = As + 3 * B3_A_PLANE;
-    const int c = 2 * ks + h;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
-        f.a[i][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * B3_A_PLANE + Ra[i] * 64 + 16 * (c ^ sa[i]));
-        f.b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * B3_B_PLANE + Rb[i] * 64 + 16 * (c ^ sb[i]));
+        f.a[i][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * B3_A_PLANE + oa[i]);
+        f.b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * B3_B_PLANE + ob[i]);
       }
   };
   auto products = [&](const Frag& f) {                     // smallest partial products first, block by block
@@ -770,9 +775,8 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
         acc[i][j] = a;
       }
   };
-  const int nk = p.K / 32;                                 // padded: exact
-  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
-  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
+  // 16-deep steps that hold real columns (the zero-padded tail of the padded width is skipped)
+  const int nk = ((p.k_real > 0 ? p.k_real : p.K) + 15) / 16;
   const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
   // The n-th tile of this workgroup.  Blocked order (whole XCD shares: 32 workgroups per XCD, row tiles a multiple of 8, the XCD's
   // column tiles a multiple of 4): at any time the XCD works on 8 row tiles x 4 column tiles -- 3.9 MB of operand planes, the least
@@ -787,14 +791,22 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
     const int row = g * 8 + (jx & 7), colt = xcd * xcols + c4 * 4 + (jx >> 3);
     return colt * p.grid_m + row;
   };
-  int t = tile_at(0);
-  set_src(t);
-  issue(0, 0);
-  int s = 0;                                               // running step count: stage = s & 1
-  bool after_stores = false;                               // the previous step ended with a tile's 64 stores
+  // the request stream: step q of the whole sequence = (tile q / nk, k-step q % nk); three steps ahead of the step being multiplied
+  const int total = my_n * nk;
+  int rq = 0, rq_n = 0, rq_it = 0;                          // next step to request: its number, tile ordinal, k-step
+  set_src(tile_at(0));
+  auto request_next = [&]() {
+    if (rq >= total) return;
+    issue(rq & (B3_NS - 1), rq_it * 16);
+    ++rq;
+    if (++rq_it == nk) { rq_it = 0; ++rq_n; if (rq_n < my_n) set_src(tile_at(rq_n)); }
+  };
+  request_next(); request_next(); request_next();
+  int s = 0;                                               // running step count: stage = s & 3
+  int since_stores = 3;                                    // steps since a tile's 64 stores were issued (>= 3: none among the waited-for)
   for (int n = 0; n < my_n; ++n) {
+    const int t = tile_at(n);
     const int m0 = (t % p.grid_m) * B3_TM, n0 = (t / p.grid_m) * B3_TN;
-    const int t_next = tile_at(n + 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -803,20 +815,23 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float bv[2];
     for (int it = 0; it < nk; ++it, ++s) {
-      // this step's stage has landed: everything of mine but the stores that followed its request (they complete in order)
-      if (after_stores) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      // This step's stage has landed once only what was issued after it is outstanding: the requests of (up to) two younger
+      // stages -- and, for three steps after an epilogue, its 64 stores, which sit among them in issue order (the counter holds 63
+      // at most: "all but the youngest 63" then covers this stage's pieces, at the price of waiting for a few of the stores).
+      const int younger = (rq - s - 1);                    // stages requested after this one: 2, fewer at the very end
+      if (since_stores < 3) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else if (younger >= 2) { if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else if (younger == 1) { if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      after_stores = false;
+      ++since_stores;
       asm volatile("s_barrier" ::: "memory");              // everybody's pieces landed; everybody finished the step before
-      Frag f0, f1;
-      frags(s & 1, 0, f0);
-      frags(s & 1, 1, f1);
+      Frag f;
+      frags(s & (B3_NS - 1), f);
       __builtin_amdgcn_sched_barrier(0);
 #if !(PAYNE_EXP_B3 & 2)
-      if (it + 1 < nk) issue((s + 1) & 1, (it + 1) * 32);  // into the buffer the step before consumed
-      else if (n + 1 < my_n) { set_src(t_next); issue((s + 1) & 1, 0); }
+      request_next();                                      // into the buffer the step before consumed
 #endif
-      if (it == 0) {                                       // the epilogue's bias (younger than the request: waited for with the next stage)
+      if (it == 0) {                                       // the epilogue's bias (younger than the request: long landed by then)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = n0 + wn0 + 32 * j + (lane & 31);
@@ -825,10 +840,9 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
 #if !(PAYNE_EXP_B3 & 1)
-      products(f0);
-      if (it + 1 < nk || last_both) products(f1);
+      products(f);
 #else
-      asm volatile("" :: "v"(f0.a[0][0]), "v"(f0.b[1][2]), "v"(f1.a[1][1]), "v"(f1.b[0][0]));
+      asm volatile("" :: "v"(f.a[0][0]), "v"(f.b[1][2]), "v"(f.a[1][1]), "v"(f.b[0][0]));
 #endif
     }
     // C/D map of a 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -841,13 +855,12 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           // (unconditional: the launch guarantees whole tiles -- B % 128 == 0, N % 256 == 0 --, so every wave issues exactly 64
-          //  stores behind the next tile's request, which is what the vmcnt(63) above counts on)
+          //  stores here, which is what the vmcnt(63) above counts on)
           const float v = acc[i][j][r] + bv[j];
           if (!(PAYNE_EXP_B3 & 4) || v == 1.2345e30f) __builtin_nontemporal_store(act_none ? v : act_apply(v, p.act), &p.Y[(size_t)row * p.ldy + col]);
         }
       }
-    after_stores = true;
-    t = t_next;
+    since_stores = 0;
   }
 }
 #endif
