@@ -82,6 +82,33 @@ def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engi
     assert errs["split"].max() <= 1.5 * errs["f32"].max() + 1e-8, (errs["split"].max(), errs["f32"].max())
 
 
+def test_output_layer_on_many_big_tiles_against_fp64(Engine):
+    """The output layer with many tiles per compute unit (C5's 65 536 pixels): payne_dense_big3_kernel -- persistent workgroups,
+    128 x 256 tiles, a four-stage ring across tile boundaries, blocked tile order -- against the SAME network in fp64 and against the
+    64 x 128-tile form (PAYNE_V_OUT_SMALL_TILES), which must give the same values to the last bit but the order of the k-steps'
+    partial sums (both accumulate a 32 x 32 block's six products per 16-deep step in the same order: bit-equal).  Two batch sizes:
+    512 (whole tiles: the big-tile kernel) and 500 (not a multiple of 128: the launch must fall back by itself)."""
+    from thepayne_amd import _lib
+    cfg = synth.CONFIGS["C5"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    net = _net(raw)
+    rng = np.random.default_rng(21)
+    B = 512
+    lab = net["xmin"][:4] + rng.uniform(0.02, 0.98, size=(B, 4)) * (net["xmax"][:4] - net["xmin"][:4])
+    th = theta_full(np.column_stack([lab, np.zeros(B), np.zeros(B), np.full(B, 60000.0)]))
+    ref = _fp64_forward(net, lab)
+    got = {}
+    for name, variant in (("big", 0), ("small", _lib.V_OUT_SMALL_TILES)):
+        eng = Engine(net, obs=None, b_max=B, variant=variant)
+        got[name] = eng.predict_batch(th, stage=0).cpu().numpy()
+        if name == "big":
+            part = eng.predict_batch(th[:500], stage=0).cpu().numpy()       # 500 rows: not whole 128-row tiles
+        eng.close()
+    assert np.abs(got["big"].astype(np.float64) - ref).max() <= FLUX_TOL
+    assert np.array_equal(got["big"], got["small"])
+    assert np.array_equal(part, got["small"][:500])
+
+
 def _fp64_forward(net, lab):
     from thepayne_amd import _lib
     nl = lab.shape[1]
