@@ -28,7 +28,7 @@ constexpr int kChipThreads = 512;                  // real threads; kChipVT virt
 constexpr int kChipVT = 1024;
 constexpr int kChipM = 32768;                      // complex points of a stage (n1 = 65536 real)
 constexpr int kChipXch = 16 * 1024;                // complex slots of an exchange round
-constexpr size_t kChipLdsBytes = (size_t)kChipXch * 8 + 1024 * 8 + 64 * 8;   // exchange buffer | W_1024 | W_65536 (fine)
+constexpr size_t kChipLdsBytes = 256 + (size_t)kChipXch * 8 + 1024 * 8 + 64 * 8;   // (alignment) | exchange buffer | W_1024 | W_65536 (fine)
 }
 #ifdef __HIP_DEVICE_COMPILE__
 
@@ -41,7 +41,8 @@ struct ChipLds {             // (LDS address space in the pointer types: ds_read
 };
 __device__ __forceinline__ ChipLds chip_lds(unsigned char* base) {
   ChipLds L;
-  L.xch = (PAYNE_AS_LDS f2v*)base;
+  // (the exchange buffer on a 256-byte boundary: chip_xlo's slot addresses are then one XOR away from a per-call constant)
+  L.xch = (PAYNE_AS_LDS f2v*)(((unsigned)(uintptr_t)(PAYNE_AS_LDS unsigned char*)base + 255u) & ~255u);
   L.w1024 = L.xch + kChipXch;
   L.wfine = L.w1024 + 1024;
   return L;
@@ -168,8 +169,41 @@ __device__ __forceinline__ void chip_xch_recv(const ChipLds& L, c32 (&u)[32], in
     }
   }
 }
+// LO without selects: (h, l; reg k) <-> (h, k; reg l) permutes within one h, so the two virtual threads of a thread (h = 2 i and
+// 2 i + 1) belong to two DISJOINT exchanges: one round per set, all 32 registers of a virtual thread in it (512 virtual threads x 32
+// registers = the same 128 KB), no parity classes.  Slot [i][k][l ^ k] (8 bytes each): the writers' lanes differ in l, the readers' in
+// k -- the XOR spreads both over the 32 bank pairs.  Byte address = (per-call constant) ^ 8 k + 256 k: one vector instruction per access.
+template <bool PERM>
+__device__ __forceinline__ void chip_xlo_send(const ChipLds& L, const c32 (&u)[32], int vt_) {
+  const int vt = chip_fresh(vt_);
+  const unsigned a0 = (unsigned)(uintptr_t)L.xch + (unsigned)((vt >> 6) * 8192 + (vt & 31) * 8);      // [i][0][l]
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    stc((PAYNE_AS_LDS f2v*)(uintptr_t)((a0 ^ (unsigned)(8 * k)) + (unsigned)(256 * k)), 0, u[chip_pos(PERM, k)]);
+}
+template <bool PERM>
+__device__ __forceinline__ void chip_xlo_recv(const ChipLds& L, c32 (&u)[32], int vt_) {
+  const int vt = chip_fresh(vt_);
+  const int l = vt & 31;
+  const unsigned a0 = ((unsigned)(uintptr_t)L.xch + (unsigned)((vt >> 6) * 8192 + l * 256)) ^ (unsigned)(8 * l);   // [i][k = l][0 ^ l]
+#pragma unroll
+  for (int r = 0; r < 32; ++r)
+    u[chip_pos(PERM, r)] = ldc((PAYNE_AS_LDS f2v*)(uintptr_t)(a0 ^ (unsigned)(8 * r)), 0);                      // [i][l][r ^ l]
+}
+template <bool PERM>
+__device__ __forceinline__ void chip_xlo(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0) {
+  chip_xlo_send<PERM>(L, u0, vt0);
+  __syncthreads();
+  chip_xlo_recv<PERM>(L, u0, vt0); chip_pin(u0);
+  __syncthreads();
+  chip_xlo_send<PERM>(L, u1, vt0 + 32);
+  __syncthreads();
+  chip_xlo_recv<PERM>(L, u1, vt0 + 32); chip_pin(u1);
+  __syncthreads();
+}
 template <bool HI, bool PERM>
 __device__ __forceinline__ void chip_xch(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0) {
+  if constexpr (!HI) { chip_xlo<PERM>(L, u0, u1, vt0); return; }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     chip_xch_send<HI, PERM, 0>(L, u0, vt0, q);
