@@ -88,11 +88,40 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
     // evidence update for the point that dies
     const double logvol = s->logvol - dlv;
     const double logdvol = logdfac + logvol;
-    const double logwt = logaddexp(lmin, s->loglstar) + logdvol;
-    const double logz_new = logaddexp(s->logz, logwt);
-    const double lz = ((s->loglstar > -1e299) ? exp(s->loglstar - logz_new + logdvol) * s->loglstar : 0.0) +
-                      (isfinite(lmin) ? exp(lmin - logz_new + logdvol) * lmin : 0.0);
-    const double h_new = lz + ((s->logz > -1e299) ? exp(s->logz - logz_new) * (s->h + s->logz) : 0.0) - logz_new;
+    // logaddexp(lmin, loglstar) with its exponential kept: e1 = exp(-|lmin - loglstar|) is also the ratio of the two weights below
+    double lae, e1;
+    const bool min_big = lmin >= s->loglstar;
+    if (lmin == s->loglstar) { lae = lmin + 0.6931471805599453; e1 = 1.0; }
+    else {
+      const double d1 = min_big ? s->loglstar - lmin : lmin - s->loglstar;
+      if (d1 == d1) { e1 = exp(d1); lae = (min_big ? lmin : s->loglstar) + log1p(e1); }
+      else { e1 = 0.0; lae = lmin + s->loglstar; }
+    }
+    const double logwt = lae + logdvol;
+    // logz_new = logaddexp(logz, logwt) and, from the same exponential, exp(logz - logz_new) (H's weight of the old evidence):
+    // with d = -|logz - logwt| and e = exp(d), logz_new = max + log1p(e) and the weight is 1 / (1 + e) or e / (1 + e)
+    double logz_new, w_old;
+    if (s->logz == logwt) { logz_new = logwt + 0.6931471805599453; w_old = 0.5; }
+    else {
+      const bool zbig = s->logz > logwt;
+      const double d = zbig ? logwt - s->logz : s->logz - logwt;
+      if (d == d) {
+        const double e = exp(d), q = 1.0 / (1.0 + e);
+        logz_new = (zbig ? s->logz : logwt) + log1p(e);
+        w_old = zbig ? q : e * q;
+      } else { logz_new = s->logz + logwt; w_old = exp(s->logz - logz_new); }     // (NaN / inf - inf: as logaddexp)
+    }
+    // exp(loglstar - logz_new + logdvol) loglstar + exp(lmin - logz_new + logdvol) lmin: one exponential (of the larger), the other is e1 times it
+    double lz = 0.0;
+    {
+      const bool has_star = s->loglstar > -1e299, has_min = isfinite(lmin);
+      if (has_star && has_min) {
+        const double xb = exp((min_big ? lmin : s->loglstar) - logz_new + logdvol), xs = xb * e1;
+        lz = (min_big ? xs : xb) * s->loglstar + (min_big ? xb : xs) * lmin;
+      } else if (has_star) lz = exp(s->loglstar - logz_new + logdvol) * s->loglstar;
+      else if (has_min) lz = exp(lmin - logz_new + logdvol) * lmin;
+    }
+    const double h_new = lz + ((s->logz > -1e299) ? w_old * (s->h + s->logz) : 0.0) - logz_new;
     const double dh = h_new - s->h;
     s->h = h_new; s->logz = logz_new; s->logzvar += dh * dlv; s->logvol = logvol; s->loglstar = lmin;
     // record
