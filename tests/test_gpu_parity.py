@@ -82,15 +82,17 @@ def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engi
     assert errs["split"].max() <= 1.5 * errs["f32"].max() + 1e-8, (errs["split"].max(), errs["f32"].max())
 
 
-def test_output_layer_on_many_big_tiles_against_fp64(Engine):
+@pytest.mark.parametrize("H", [300, 100])
+def test_output_layer_on_many_big_tiles_against_fp64(Engine, H):
     """The output layer with many tiles per compute unit (C5's 65 536 pixels): payne_dense_big3_kernel -- persistent workgroups,
     128 x 256 tiles, a four-stage ring across tile boundaries, blocked tile order -- against the SAME network in fp64 and against the
     64 x 128-tile form (PAYNE_V_OUT_SMALL_TILES), which must give the same values to the last bit but the order of the k-steps'
     partial sums (both accumulate a 32 x 32 block's six products per 16-deep step in the same order: bit-equal).  Two batch sizes:
-    512 (whole tiles: the big-tile kernel) and 500 (not a multiple of 128: the launch must fall back by itself)."""
+    512 (whole tiles: the big-tile kernel) and 500 (not a multiple of 128: the launch must fall back by itself).  H = 100: a width
+    whose padded tail (128 columns) is cut at the seventh 16-deep step."""
     from thepayne_amd import _lib
     cfg = synth.CONFIGS["C5"]
-    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=H, seed=0)
     net = _net(raw)
     rng = np.random.default_rng(21)
     B = 512
