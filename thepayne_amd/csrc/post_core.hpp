@@ -60,7 +60,10 @@ constexpr int kFftThreads = 256;
 // unroll factor of the per-pixel loops for `ppt` pixels per thread (loads of one unrolled body are in flight together)
 PAYNE_HD constexpr int unroll_for(int ppt) { return ppt >= 16 ? 16 : (ppt >= 8 ? 8 : 4); }
 
-struct c32 { float x, y; };
+// (8-byte aligned: a complex value is then ONE 8-byte LDS access -- ds_read_b64 / ds_write_b64, conflict-free for consecutive lanes --;
+//  as two floats of 4-byte alignment the taper phases read and wrote it as ds_read2_b32 / ds_write2_b32, whose lanes i and i + 16
+//  share a bank: a third of the kernel's bank-conflict cycles.  Every complex buffer of this build sits on an 8-byte boundary.)
+struct alignas(8) c32 { float x, y; };
 #ifdef __HIP_DEVICE_COMPILE__
 // Complex arithmetic on the packed-fp32 unit, one instruction per line (the compiler's own selection from the scalar
 // statements spends four instructions on a complex product -- both halves computed twice, merged by a move -- and a
@@ -1171,6 +1174,17 @@ PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restr
 #endif
   }
 }
+// four consecutive values of the spectrum buffer (16-byte aligned: both buffers start on 16-byte boundaries) as ONE 16-byte store
+// (four 4-byte stores put lanes i and i + 8 on the same bank: 4-way conflicts on the whole row)
+PAYNE_HD void row_store4(float* __restrict__ spec, int i, float a, float b, float c, float d) {
+#ifdef __HIP_DEVICE_COMPILE__
+  typedef float row4 __attribute__((ext_vector_type(4)));
+  row4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+  *reinterpret_cast<row4*>(spec + 4 * i) = v;
+#else
+  spec[4 * i] = a; spec[4 * i + 1] = b; spec[4 * i + 2] = c; spec[4 * i + 3] = d;
+#endif
+}
 template <int U>
 PAYNE_HD void phase_load_commit(int tid, int nthr, int npix, const float* __restrict__ raw, const RowRegsT<U>& R,
                                 float* __restrict__ spec, bool scrub) {
@@ -1179,10 +1193,8 @@ PAYNE_HD void phase_load_commit(int tid, int nthr, int npix, const float* __rest
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const int i = tid + q * nthr;
-      if (i < n4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) spec[4 * i + e] = scrub ? nan_to_zero(R.v[q][e]) : R.v[q][e];
-      }
+      if (i < n4) row_store4(spec, i, scrub ? nan_to_zero(R.v[q][0]) : R.v[q][0], scrub ? nan_to_zero(R.v[q][1]) : R.v[q][1],
+                             scrub ? nan_to_zero(R.v[q][2]) : R.v[q][2], scrub ? nan_to_zero(R.v[q][3]) : R.v[q][3]);
     }
     for (int base = tid + U * nthr; base < n4; base += U * nthr) {      // rows longer than U*nthr float4
       float v[U][4];
@@ -1194,10 +1206,8 @@ PAYNE_HD void phase_load_commit(int tid, int nthr, int npix, const float* __rest
 #pragma unroll
       for (int q = 0; q < U; ++q) {
         const int i = base + q * nthr;
-        if (i < n4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) spec[4 * i + e] = scrub ? nan_to_zero(v[q][e]) : v[q][e];
-        }
+        if (i < n4) row_store4(spec, i, scrub ? nan_to_zero(v[q][0]) : v[q][0], scrub ? nan_to_zero(v[q][1]) : v[q][1],
+                               scrub ? nan_to_zero(v[q][2]) : v[q][2], scrub ? nan_to_zero(v[q][3]) : v[q][3]);
       }
     }
   } else {
