@@ -532,6 +532,12 @@ __device__ __forceinline__ c32 ldc1(const PAYNE_AS_LDS f2v* p, int i) { const f2
 __device__ __forceinline__ c32 ldc1(PAYNE_AS_LDS f2v* p, int i) { const f2v v = *(const volatile PAYNE_AS_LDS f2v*)(p + i); return {v.x, v.y}; }
 __device__ __forceinline__ c32 ldc1(const PAYNE_AS_GLOBAL f2v* p, int i) { const f2v v = p[i]; return {v.x, v.y}; }
 __device__ __forceinline__ c32 ldc1(PAYNE_AS_GLOBAL f2v* p, int i) { const f2v v = p[i]; return {v.x, v.y}; }
+__device__ __forceinline__ c32 ld1(const PAYNE_AS_LDS f2v* p, int i) { return ldc1(p, i); }
+__device__ __forceinline__ c32 ld1(PAYNE_AS_LDS f2v* p, int i) { return ldc1(p, i); }
+__device__ __forceinline__ c32 ld1(const PAYNE_AS_GLOBAL f2v* p, int i) { return ldc1(p, i); }
+__device__ __forceinline__ c32 ld1(PAYNE_AS_GLOBAL f2v* p, int i) { return ldc1(p, i); }
+__device__ __forceinline__ void st1(PAYNE_AS_LDS f2v* p, int i, c32 v) { stc(p, i, v); }
+__device__ __forceinline__ void st1(PAYNE_AS_GLOBAL f2v* p, int i, c32 v) { stc(p, i, v); }
 #else
 inline c32 ldc1(const c32* p, int i) { return p[i]; }
 inline c32 ldc(const c32* p, int i) { return p[i]; }
@@ -708,6 +714,9 @@ PAYNE_HD void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, 
 }
 #endif
 
+PAYNE_HD c32 ld1(const c32* p, int i) { return p[i]; }
+PAYNE_HD c32 ld1(c32* p, int i) { return p[i]; }
+PAYNE_HD void st1(c32* p, int i, c32 v) { p[i] = v; }
 // Middle step of a real convolution done with a half-length complex FFT.
 // In: Z = FFT_M(z), z[n] = s[2n] + i s[2n+1].  Out (in place): Y with
 // FFT_M(Y) = conj(z'), z'[n] = s'[2n] + i s'[2n+1], s' = irfft(rfft(s) * taper).
@@ -715,8 +724,10 @@ PAYNE_HD void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, 
 // pairs are issued before any store: the pairs are disjoint, so this is safe in place);
 // the two self-conjugate bins k = 0 and k = M/2 go to the last two threads.
 // tw_step = (twiddle table length)/(2M): exp(-2 pi i k/2M) = tw[k*tw_step].
-template <bool VSINI, int PU = 4>
-PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __restrict__ tw, int tw_step,
+// (ZP / TP: plain pointers, or -- the kernel's compile-time geometry -- the typed LDS / global pointers of Ex::buf / Ex::twid, whose
+//  reads are then single ds_read_b64: ld1 / st1 above)
+template <bool VSINI, int PU = 4, class ZP = c32*, class TP = const c32*>
+PAYNE_HD void rfft_taper_phase(int tid, int nthr, ZP Z, int M, TP tw, int tw_step,
                                const TaperArgs& ta) {
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const int npair = M / 2 - 1;                        // k = 1 .. M/2-1
@@ -733,7 +744,7 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
       const int k0 = 1 + base + q * nthr;
       const bool pair = k0 <= npair;
       const int k = pair ? k0 : npair;
-      zk[q] = Z[k]; zm[q] = Z[M - k]; w[q] = tw[k * tw_step];
+      zk[q] = ld1(Z, k); zm[q] = ld1(Z, M - k); w[q] = ld1(tw, k * tw_step);
       tk[q] = taper_at<VSINI>(ta, pair ? k : M / 2, far);
       tm[q] = taper_at<VSINI>(ta, pair ? M - k : M, far);
     }
@@ -753,13 +764,13 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
       c32 yk, ymk;
       taper_pair(zk[q], zm[q], w[q], tk[q] * g, tm[q] * g, yk, ymk);
       if (k <= npair) {
-        Z[k] = yk;
-        Z[M - k] = ymk;
+        st1(Z, k, yk);
+        st1(Z, M - k, ymk);
       } else if (k == M / 2) {                         // tk = taper(M/2), tm = taper(M); taper(0) = 1
-        const c32 z0 = Z[0], zh = Z[M / 2];
+        const c32 z0 = ld1(Z, 0), zh = ld1(Z, M / 2);
         const float x0 = z0.x + z0.y, xm = tm[q] * (z0.x - z0.y);
-        Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
-        Z[M / 2] = cscale(cconj(zh), tk[q] * invM);
+        st1(Z, 0, c32{0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM});
+        st1(Z, M / 2, cscale(cconj(zh), tk[q] * invM));
         special_done = true;
       }
     }
@@ -778,16 +789,16 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, c32* Z, int M, const c32* __re
       const float t0 = taper_at<VSINI>(ta, 0, far);
       float tM = taper_at<VSINI>(ta, M, far);
       if (VSINI && far) tM = taper_far(ta, M, tM);
-      const c32 z0 = Z[0];
+      const c32 z0 = ld1(Z, 0);
       const float x0 = t0 * (z0.x + z0.y), xm = tM * (z0.x - z0.y);
-      Z[0] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
+      st1(Z, 0, c32{0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM});
     }
     if (tid == (nthr > 1 ? nthr - 2 : 0) && M >= 2) {    // k = M/2 (self-conjugate)
       const int k = M / 2;
       bool far = false;
       float th = taper_at<VSINI>(ta, k, far);
       if (VSINI && far) th = taper_far(ta, k, th);
-      Z[k] = cscale(cconj(Z[k]), th * invM);
+      st1(Z, k, cscale(cconj(ld1(Z, k)), th * invM));
     }
   }
 }

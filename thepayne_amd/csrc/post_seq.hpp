@@ -170,7 +170,7 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
     if (M == MF) {
       c32* z = (PAYNE_EXP_SKIP & 1) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
       constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
-      if (!(PAYNE_EXP_SKIP & 2)) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, z, MF, twf + plan_total(MF), 1, ta); });
+      if (!(PAYNE_EXP_SKIP & 2)) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
       float* res = (PAYNE_EXP_SKIP & 4) ? (float*)z : (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
       edge = false;
