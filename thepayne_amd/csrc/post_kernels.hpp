@@ -110,30 +110,24 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   float* bufB = bufA + fft_buf_floats(n1);                     // room for the padded FFT intermediates
   double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(n1));          // scratch_doubles(256)
   CandState* S = reinterpret_cast<CandState*>(red + scratch_doubles(kPostThreads));
+  // Start-up traffic of the kernel itself, REQUESTED here and committed inside run_candidate's first phase (`early`), after that
+  // phase has requested the row, the record and theta: one memory round trip at the start of a workgroup's life, not two (as first
+  // written the table's six loads were waited for and stored before the row was even asked for: ~0.8 us).
   const c32* twf = T.twf;
+  typedef float f2g __attribute__((ext_vector_type(2)));
+  constexpr int NTW = LOG2N > 0 ? plan_table_len((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : 1, PER = (NTW + kPostThreads - 1) / kPostThreads;
+  f2g tw_tmp[PER];
   if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
     c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
-    typedef float f2g __attribute__((ext_vector_type(2)));
     const f2g* __restrict__ g = reinterpret_cast<const f2g*>(T.twf);
     f2g* tl = reinterpret_cast<f2g*>(twl);
     if constexpr (LOG2N > 0) {
       // every load of the table in flight at once (a load -> store loop pays one L2 round trip per
       // iteration: twelve of them at 4096 points, ~3.5 us before the first phase could start)
-      constexpr int NTW = plan_table_len((1 << LOG2N) / 2), PER = (NTW + kPostThreads - 1) / kPostThreads;
-      f2g tmp[PER];
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int i0 = (int)threadIdx.x + q * kPostThreads;
-        tmp[q] = g[i0 < NTW ? i0 : NTW - 1];
-      }
-      // (every value named before the first store: the compiler otherwise sinks the load of a slot whose store is conditional
-      //  -- the last one -- into that condition, behind the wait for the others: a second round trip)
-#pragma unroll
-      for (int q = 0; q < PER; ++q) asm volatile("" : "+v"(tmp[q]));
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int i0 = (int)threadIdx.x + q * kPostThreads;
-        if (i0 < NTW) tl[i0] = tmp[q];
+        tw_tmp[q] = g[i0 < NTW ? i0 : NTW - 1];
       }
     } else {
       const int nt = T.twf_n;
@@ -147,11 +141,32 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   // workgroup's life (C3: 1.3 us of the post kernel)
   __shared__ double sed_terms[64];
   const bool sed_early = a.mags != nullptr && a.n_filters <= 64;
-  if (sed_early && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + a.n_filters) {
+  const bool sed_lane = sed_early && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + a.n_filters;
+  double sed_m = 0.0, sed_o = 0.0, sed_e = 1.0;
+  if (sed_lane) {
     const int f = (int)threadIdx.x - 64;
-    const double d = a.mags[(size_t)b * a.n_filters + f] - a.obs_mag[f], e = a.obs_err[f];
-    sed_terms[f] = (d * d) / (e * e);                       // likelihood.py:109-112 (read by thread 0 behind the phases' barriers)
+    sed_m = a.mags[(size_t)b * a.n_filters + f]; sed_o = a.obs_mag[f]; sed_e = a.obs_err[f];
   }
+  auto early = [&]() {
+    // (what it needs beyond the loaded values is worked out again here: every scalar it captured was a scalar register the whole
+    //  first phase could not use, and the kernel sits one spilled scalar away from 129 vector registers = one workgroup per CU)
+    if constexpr (TW_LDS && LOG2N > 0) {
+      f2g* tl = reinterpret_cast<f2g*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
+      // (every value named before the first store: the compiler otherwise sinks the load of a slot whose store is conditional
+      //  -- the last one -- into that condition, behind the wait for the others: a second round trip)
+#pragma unroll
+      for (int q = 0; q < PER; ++q) asm volatile("" : "+v"(tw_tmp[q]));
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i0 = (int)threadIdx.x + q * kPostThreads;
+        if (i0 < NTW) tl[i0] = tw_tmp[q];
+      }
+    }
+    if (a.mags != nullptr && a.n_filters <= 64 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + a.n_filters) {
+      const double d = sed_m - sed_o;
+      sed_terms[(int)threadIdx.x - 64] = (d * d) / (sed_e * sed_e);   // likelihood.py:109-112 (read by thread 0 behind the phases' barriers)
+    }
+  };
   DevExecT<true, TW_LDS> ex;
 #ifdef PAYNE_STAMPS
   if (a.stamps) {
@@ -167,7 +182,7 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   const CandState* prep = a.prep ? a.prep + b : nullptr;
   if (LEAN) { prep = a.prep + b; __builtin_assume(prep != nullptr); }     // LEAN is launched only with records
   run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
-                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep);
+                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep, early);
   double lnl_v = 0.0;
   if (threadIdx.x == 0 && a.lnl && ostage < 0) {
     double x2 = *chi2;

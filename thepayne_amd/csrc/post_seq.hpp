@@ -194,10 +194,14 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
 }
 
 // out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze) | 5 after vsini, shifted | 6 after vsini, without the spec[0]=spec[1] edge rule
-template <int LOG2N, int NT, class Ex>
+// `early`: called by every thread in the first phase once ALL of the phase's global loads have been requested (the row, the
+// record, theta) and before any of them is waited for -- the caller's own start-up traffic (the LDS kernel's twiddle table and
+// photometric terms, requested before this function) is committed there, so its round trip and the row's are ONE round trip.
+struct NoEarly { PAYNE_HD void operator()() const {} };
+template <int LOG2N, int NT, class Ex, class Early = NoEarly>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
-                             float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr) {
+                             float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr, Early early = Early()) {
   // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer.  The test reads theta: with the plain
   // executors it is made AFTER the row has been requested (a global load and its wait ahead of that request was a round trip
   // of its own at the start of every workgroup); only the fused four-step form needs it before.
@@ -214,7 +218,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     PrepRegs pr;
     if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
-    if (!may_fuse) direct = maybe_direct && (th[5] != 0.0);
+    double th5 = 0.0;
+    if (!may_fuse && maybe_direct) th5 = th[5];        // (requested with the others; looked at below)
+    early();
+    if (!may_fuse) direct = maybe_direct && (th5 != 0.0);
     if (prep) phase_take_prep_commit(t, pr, S);
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
