@@ -479,6 +479,9 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
 // waves 0-3 move five, waves 4-7 four); 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3): the sixteen lanes of a
 // fragment read cover sixteen different bank groups.
 // ----------------------------------------------------------------------------
+#ifndef PAYNE_EXP_NT
+#define PAYNE_EXP_NT 0               // (timing experiments: 1 the output layer's stores ordinary, 2 the post kernel's row loads ordinary)
+#endif
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -653,7 +656,11 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#if PAYNE_EXP_NT & 1   /* timing experiment: ordinary stores */
+        if (row < p.B) p.Y[(size_t)row * p.ldy + col] = acc[r] + bv;
+#else
         if (row < p.B) __builtin_nontemporal_store(acc[r] + bv, &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+#endif
       }
     } else {
 #pragma unroll

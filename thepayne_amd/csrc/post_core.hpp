@@ -1183,7 +1183,7 @@ PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restr
 #pragma unroll
   for (int q = 0; q < U; ++q) {                      // clamped index: unconditional loads
     const int i0 = tid + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(PAYNE_EXP_NT) && (PAYNE_EXP_NT & 2))
     // read once, produced by other XCDs: streaming loads (no L2 allocation)
     R.v[q][0] = __builtin_nontemporal_load(&raw[4 * i]); R.v[q][1] = __builtin_nontemporal_load(&raw[4 * i + 1]);
     R.v[q][2] = __builtin_nontemporal_load(&raw[4 * i + 2]); R.v[q][3] = __builtin_nontemporal_load(&raw[4 * i + 3]);
