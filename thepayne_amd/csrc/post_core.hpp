@@ -1380,6 +1380,9 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
   float acc = 0.f;                                       // <= ~16 terms per thread: fp32 is ample; the cross-thread reduction is fp64
   const double piA = T.geo_inv_dln, piBm = -(S.dop + T.ln0) * T.geo_inv_dln + kPosMagic;   // MODE 1: t = (lnobs - dop - ln0)/dln
   const double obBm = W.obB + kPosMagic;
+  // MODE 0: positions (+ kPosMagic) of the window's ends with and without the edge tolerance
+  const double obTA = fma(W.lnmin - kEdgeTol, W.obA, obBm), obTD = fma(W.lnmax + kEdgeTol, W.obA, obBm);
+  const double obTT = fmax(fma(W.lnmax, W.obA, obBm), kPosMagic);
   const float hs_ann = (float)(0.5 * T.dln);
   const int nc = T.npoly;
   for (int base = tid; base < T.nobs; base += OU * nthr) {
@@ -1398,9 +1401,20 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
       // the model grid itself) is inside or outside by one rounding of exp(log(.)) in the reference; here it
       // is always inside (kEdgeTol in ln lambda, ~1e-7 pixel), the host applies numpy's verdict for that case.
       if (MODE == 0) {
-        nanv[q] = (lo < W.lnmin - kEdgeTol) || (lo > W.lnmax + kEdgeTol);
-        const double lc = fmin(fmax(lo, W.lnmin), W.lnmax);
-        magic_locate(nanv[q] ? kPosMagic : fmax(fma(lc, W.obA, obBm), kPosMagic), 0, W.n2, W.hs_step, k, ww);
+        // the window test and the clamp on the POSITION (one fma of the pixel's ln lambda, monotone in it): inside iff tA <= tm <= tD
+        // (the positions of lnmin - tol and lnmax + tol), clamped to [position 0, position of lnmax] -- the same pixels as the test
+        // on ln lambda itself up to one rounding of a bound that carries a 1e-12 tolerance for exactly that; a clamped position
+        // needs neither magic_locate's lower clamp nor its exponent test
+        const double tm = fma(lo, W.obA, obBm);
+        nanv[q] = !(tm >= obTA && tm <= obTD);             // (true for NaN)
+        union { double d; unsigned long long u; } cv;
+        cv.d = fmin(fmax(tm, kPosMagic), obTT);
+        const unsigned lo_dw = (unsigned)cv.u;
+        const int kk = (int)((unsigned)(cv.u >> 32) & 0x7FFFFu);
+        const bool above = kk > W.n2 - 2;
+        k = above ? W.n2 - 2 : kk;
+        const float f = above ? 1.f : (float)lo_dw * 2.3283064365386963e-10f;      // 2^-32
+        ww = f * (1.0f + W.hs_step * (f - 1.0f));
       } else {
         const double v0 = lo - S.dop;
         nanv[q] = (v0 < T.ln0 - kEdgeTol) || (v0 > T.ln_last + kEdgeTol);
