@@ -1392,7 +1392,11 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
 #pragma unroll
     for (int q = 0; q < OU; ++q) {                       // clamped index: every load unconditional
       const int i0 = base + q * nthr, i = i0 < T.nobs ? i0 : T.nobs - 1;
+#if defined(PAYNE_EXP_OBS8)   /* timing experiment (WRONG results): 8 bytes per pixel instead of 16 -- the phase is bound by these bytes */
+      ObsRec rec; rec.lnw = T.lnobs[i]; rec.f1 = 0.5f; rec.ivar = 1e4f;
+#else
       const ObsRec rec = T.obs_rec[i];                   // one 16-byte load
+#endif
       const double lo = rec.lnw;
       if (HASF) { of1[q] = rec.f1; iv[q] = rec.ivar; }
       if (CHEB) xc[q] = T.xcheb[i];
