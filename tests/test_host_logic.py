@@ -196,3 +196,24 @@ def test_three_bf16_parts_hold_an_fp32_value_exactly():
     kept = a1 * b1 + a1 * b2 + a2 * b1 + a1 * b3 + a2 * b2 + a3 * b1
     full = a.astype(np.float64) * b.astype(np.float64)
     assert np.all(np.abs(kept - full) <= 2.0 ** -22 * np.abs(full) + 1e-300)
+
+
+def test_likelihood_post_kernels_keep_two_workgroups_per_cu(tmp_path):
+    """The likelihood-only post kernels of the LDS-resident sizes must stay at <= 128 vector registers: at 129 the hardware runs ONE
+    512-thread workgroup per compute unit instead of two and the C2 step loses 6 us (it happened three times while
+    unrelated code moved).  Read off the compiler's own resource summary of the unit that holds them."""
+    import re
+    import subprocess
+    from thepayne_amd import build
+    asm = tmp_path / "k_post_lean.s"
+    cmd = [build._hipcc()] + [f for f in build.HIPCC_FLAGS if f != "-fPIC"] + ["-I", os.path.join(build.ROOT, "include"), "-S", "--cuda-device-only",
+                                                                           os.path.join(build.CSRC, "k_post_lean.hip"), "-o", str(asm)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = asm.read_text()
+    seen = {}
+    for m in re.finditer(r"^(_Z17payne_post_kernelILi(1[012])ELb1ELb1EE\w*):.*?; NumVgprs: (\d+).*?; Occupancy: (\d+)", text, re.S | re.M):
+        seen[int(m.group(2))] = (int(m.group(3)), int(m.group(4)))
+    assert set(seen) == {10, 11, 12}, seen
+    for log2n, (vgprs, occ) in seen.items():
+        assert vgprs <= 128 and occ >= 4, (log2n, vgprs, occ)

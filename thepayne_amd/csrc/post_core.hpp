@@ -1469,12 +1469,16 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
     if (out) for (int i = tid; i < T.nobs; i += nthr) out[i] = nanf_();
     return hasf ? (double)nanf_() : 0.0;
   }
+  // (the blaze variants four pixels at a time: their fp64 recurrences, eight side by side, are the register peak of the whole kernel,
+  //  which sits at the 128 registers that still allow two workgroups per CU -- unrelated edits moved it between 126 and 129; a fit
+  //  without a blaze polynomial must not pay for that with half its occupancy)
+  constexpr int OUC = OU > 4 ? 4 : OU;
 #define PAYNE_OBS(MODE_)                                                                              \
-  (out ? (cheb ? (hasf ? obs_loop<MODE_, true, true, true, OU>(tid, nthr, T, S, W, conv, out, out_stage)    \
-                       : obs_loop<MODE_, true, false, true, OU>(tid, nthr, T, S, W, conv, out, out_stage))  \
+  (out ? (cheb ? (hasf ? obs_loop<MODE_, true, true, true, OUC>(tid, nthr, T, S, W, conv, out, out_stage)    \
+                       : obs_loop<MODE_, true, false, true, OUC>(tid, nthr, T, S, W, conv, out, out_stage))  \
                : (hasf ? obs_loop<MODE_, false, true, true, OU>(tid, nthr, T, S, W, conv, out, out_stage)   \
                        : obs_loop<MODE_, false, false, true, OU>(tid, nthr, T, S, W, conv, out, out_stage))) \
-       : (cheb ? obs_loop<MODE_, true, true, false, OU>(tid, nthr, T, S, W, conv, out, out_stage)           \
+       : (cheb ? obs_loop<MODE_, true, true, false, OUC>(tid, nthr, T, S, W, conv, out, out_stage)           \
                : obs_loop<MODE_, false, true, false, OU>(tid, nthr, T, S, W, conv, out, out_stage)))
   float acc;
   if (smooth) acc = PAYNE_OBS(0);
