@@ -131,6 +131,9 @@ typedef struct payne_opts {
                                     * (3-layer nets of equal hidden width <= 320, batch a multiple of 64, one output tile per CU) */
 #define PAYNE_V_BIG_WORKSPACE 65536u /* 65 536-point spectra: both convolution stages through the global workspace (the four-step transform: what
                                       * other lengths above 16 384 use) instead of on the compute unit */
+#define PAYNE_V_NO_WALK_SPEC 131072u /* the sampler's next proposal drawn at the post kernel's tail, after the likelihood it waits for (what fits
+                                     * with more than 16 sampled dimensions or 32 theta columns use), instead of made ahead for both outcomes by
+                                     * idle workgroups of the hidden-layer launch */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

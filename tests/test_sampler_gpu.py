@@ -151,11 +151,12 @@ def test_device_rwalk_invariants(tmp_path):
 
 @pytest.mark.parametrize("photscale,modpoly", [(True, False), (False, True)])
 def test_walk_step_at_the_post_kernels_tail_is_the_same_walk(tmp_path, photscale, modpoly):
-    """The chain step runs at the tail of the likelihood-only post kernel (default) or as a launch of its own
-    (PAYNE_V_NO_WALK_TAIL): same counter-based draws, same arithmetic -> the same chains to the bit."""
+    """The chain step's next proposal is made ahead for both outcomes of the pending one by idle workgroups of the hidden-layer
+    launch and chosen at the tail of the likelihood-only post kernel (default), drawn at that tail (PAYNE_V_NO_WALK_SPEC), or the
+    whole step is a launch of its own (PAYNE_V_NO_WALK_TAIL): same counter-based draws, same arithmetic -> the same chains to the bit."""
     from thepayne_amd import _lib
     res = []
-    for variant in (0, _lib.V_NO_WALK_TAIL):
+    for variant in (0, _lib.V_NO_WALK_SPEC, _lib.V_NO_WALK_TAIL):
         L, P, _ = _fit_objects(tmp_path, photscale=photscale, modpoly=modpoly, variant=variant)
         prop = _proposer(L, P)
         rng = np.random.default_rng(11)
@@ -167,15 +168,26 @@ def test_walk_step_at_the_post_kernels_tail_is_the_same_walk(tmp_path, photscale
         out = [prop.rwalk(U0, V0, lp0, 0.05 * np.eye(nd), 1.0, lstar, w, seed=77) for w in (1, 2, 9)]
         K2 = 24                                                                   # a shorter batch right after a longer one
         out.append(prop.rwalk(U0[:K2], V0[:K2], lp0[:K2], 0.03 * np.eye(nd), 1.3, lstar, 5, seed=3))
+        # steps as long as the cube, started near its faces, two ellipsoids: most candidates leave the cube and are redrawn, some
+        # chains run out of candidates; an odd number of chains (the last pair of a wave half empty where proposals are made ahead)
+        K3 = 61
+        U1 = rng.uniform(0.02, 0.98, size=(K3, nd))
+        V1, lp1 = prop.lnprob_u(U1)
+        lp1 = np.where(np.isnan(lp1), -np.inf, lp1)
+        ax2 = np.stack([0.45 * np.eye(nd), np.tril(rng.normal(size=(nd, nd))) * 0.15 + 0.2 * np.eye(nd)])
+        out.append(prop.rwalk(U1, V1, lp1, ax2, 1.0, -np.inf, 7, seed=19, ell=(np.arange(K3) % 2).astype(np.int32)))
         res.append(out)
         at_tail, own = prop.step_counters()
-        # 1 + 2 + 9 + 5 walks' steps (+ the closing call of each): all but each walk's first at the tail, or none
-        assert (at_tail, own) == ((17, 4) if variant == 0 else (0, 21))
+        # 1 + 2 + 9 + 5 + 7 walks' steps (+ the closing call of each): all but each walk's first at the tail, or none
+        assert (at_tail, own) == ((0, 29) if variant == _lib.V_NO_WALK_TAIL else (24, 5))
         prop.close()
-    for a, b in zip(*res):
-        assert a[3].sum() > 0
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert a[3].sum() > 0
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+    moved = res[0][-1][3]
+    assert (moved > 0).sum() > 10
 
 
 def test_device_rwalk_step_distribution(tmp_path):

@@ -5,6 +5,7 @@
 #pragma once
 
 #include "sed_core.hpp"
+#include "sampler_core.hpp"
 
 // ============================================================================
 // dense layer on the matrix cores
@@ -902,6 +903,9 @@ struct PrepArgs {
   double* sed_mags;          // [B][F] magnitudes of this batch (null: no photometry in this launch)
   int sed_off, sed_photscale;   // theta column of the photometric block; the log(A) parametrisation
   int sed_cb;                // candidates per photometric tile (<= kSedCandsMax, chosen so that the tiles fit the idle compute units)
+  // the sampler's walk: workgroups past those make the NEXT chain step's proposal for both outcomes of the one this batch evaluates
+  // (rwalk_spec_wave, sampler_core.hpp; eight chains per workgroup)
+  const WalkTail* spec_walk; WalkState spec_w; int spec_step, n_spec, n_sed;
 };
 
 // One 32 x 32 tile of a hidden layer by the first 256 threads of the workgroup (`tile`: index in the launch's grid_m x grid_n).
@@ -1136,6 +1140,9 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       if (x < pa.n_prep) {
         const int cand = x * 256 + (int)threadIdx.x;
         if (pa.out && cand < p.B) prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+      } else if (x >= pa.n_prep + pa.n_sed) {
+        const int w = (x - pa.n_prep - pa.n_sed) * 4 + (int)(threadIdx.x >> 6);
+        if (pa.spec_walk) rwalk_spec_wave(pa.spec_walk->sd, pa.spec_w, w, (int)threadIdx.x & 63, pa.spec_step);
       } else if (pa.sed_mags) {
         const int j = x - pa.n_prep, f = j % pa.P.F, blk = j / pa.P.F;
 #ifdef PAYNE_STAMPS

@@ -77,6 +77,9 @@ struct payne_ctx {
   bool post_tw_lds = false;
   int n_cu = 256;                       // compute units of the device (MI355X: 256)
   bool lean_available = false;          // a likelihood-only instantiation exists for this spectrum length (it can carry a walk's tail)
+  // a sampler's walk in progress asks the likelihood batch being enqueued to make the next step's proposals ahead (rwalk_spec_wave,
+  // in the hidden-layer launch): set by lnlike_impl for the duration of the call; spec_launched: that launch carried them
+  const void* spec_walk = nullptr; const void* spec_w = nullptr; int spec_step = 0, spec_K = 0; bool spec_launched = false;
   PostTables* d_T = nullptr;          // device copy of T
   post_kernel_fn post_fn = nullptr;
   float* big_ws = nullptr;            // global spectrum buffers of payne_post_big_kernel (n1 > 16384)
@@ -643,12 +646,13 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s) {
 }
 
 template <bool FUSE>
-static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu = 256) {
+static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu = 256, int spec_K = 0) {
   p.grid_m = (p.B + 31) / 32;
   p.grid_n = (p.N + 31) / 32;
   pa.n_gemm = p.grid_m * p.grid_n;
   if (!FUSE) { pa.out = nullptr; pa.sed_mags = nullptr; }
   pa.n_prep = pa.out ? (p.B + 255) / 256 : 0;
+  pa.n_spec = pa.spec_walk ? (spec_K + kSpecChainsPerWg - 1) / kSpecChainsPerWg : 0;
   int n_sed = 0;
   if (pa.sed_mags) {
     // candidates per photometric tile: as few as keeps F x blocks within the compute units the GEMM tiles leave idle (16..48)
@@ -661,7 +665,8 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
 #ifdef PAYNE_STAMPS
   p.stamps = FUSE ? g_hidden_stamps : nullptr;
 #endif
-  const dim3 grid(pa.n_gemm + pa.n_prep + n_sed), block(256);
+  pa.n_sed = n_sed;
+  const dim3 grid(pa.n_gemm + pa.n_prep + n_sed + pa.n_spec), block(256);
   if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
   else if (p.n_labels <= 4) {
     PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
@@ -749,8 +754,14 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         pa.P = c->P; pa.sed_mags = c->mags_ws; pa.sed_off = 8 + c->opts.npoly; pa.sed_photscale = c->opts.photscale;
         *sed = false;
       }
+      // the walk's next proposals ride along when this batch's post kernel will run the chain step at its tail (run_post)
+      const bool spec = !last && N.spectral && c->spec_walk && pa.out && c->lean_available && !c->big_ws;
+      if (spec) {
+        pa.spec_walk = static_cast<const WalkTail*>(c->spec_walk); pa.spec_w = *static_cast<const WalkState*>(c->spec_w);
+        pa.spec_step = c->spec_step; c->spec_launched = true;
+      }
       if (last) launch_dense<64, 64, 32, true>(p, s);
-      else { launch_hidden<true>(p, pa, s, c->n_cu); if (N.spectral) c->prep_valid = pa.out != nullptr; }
+      else { launch_hidden<true>(p, pa, s, c->n_cu, spec ? c->spec_K : 0); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
@@ -887,7 +898,7 @@ static int run_sed(payne_ctx* c, const double* in, int ld, int mode, int B, doub
 static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, float* out, int ld_out, double* lnl,
                         bool with_phot, hipStream_t s);
 
-struct TailReq { const WalkTail* dev; int step, propose; bool done; };
+struct TailReq { const WalkTail* dev; int step, propose; bool done; const WalkState* spec; };   // spec: the walk (host copy) when proposals can be made ahead
 static int run_post(payne_ctx* c, const double* theta, int B, double instr_factor, int stage, float* out, int ld_out,
                     double* lnl, bool with_phot, hipStream_t s, TailReq* tail = nullptr) {
   if (c->has_lsf && (stage < 0 || stage == 2 || stage == 3)) return run_post_lsf(c, theta, B, stage, out, ld_out, lnl, with_phot, s);
@@ -898,7 +909,10 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
   a.prep = c->prep_valid ? c->prep : nullptr;
   const bool lean = stage < 0 && !out && a.prep && !c->big_ws;
-  if (tail && lean && c->lean_available) { a.tail = tail->dev; a.tail_step = tail->step; a.tail_propose = tail->propose; tail->done = true; }
+  if (tail && lean && c->lean_available) {
+    a.tail = tail->dev; a.tail_step = tail->step; a.tail_propose = tail->propose; tail->done = true;
+    a.tail_spec = (c->spec_launched && tail->propose && tail->spec) ? 1 : 0;
+  }
   {
     ProfScope ps(c, s, 1);
     if (c->big_ws && c->big_chip) {
@@ -969,9 +983,14 @@ static int lnlike_impl(payne_ctx* c, const double* theta, int B, double* lnl, vo
     if (!c->obs_bound || !c->T.obs_f1) return fail(c, PAYNE_E_INVALID, "no observed spectrum (flux, eflux) bound");
   }
   bool sed_pending = c->has_phot;                           // the photometric nets: in the hidden-layer launch when there is one
-  if (c->has_model && (rc = run_ann(c, theta, B, 2.355, s, true, &sed_pending))) return rc;
+  TailReq* const tl = (c->has_lsf || (c->opts.variant & PAYNE_V_NO_WALK_TAIL)) ? nullptr : tail;
+  c->spec_launched = false;
+  if (tl && tl->propose && tl->spec && !(c->opts.variant & PAYNE_V_NO_WALK_SPEC)) { c->spec_walk = tl->dev; c->spec_w = tl->spec; c->spec_step = tl->step; c->spec_K = B; }
+  if (c->has_model) rc = run_ann(c, theta, B, 2.355, s, true, &sed_pending);
+  c->spec_walk = nullptr;
+  if (rc) return rc;
   if (sed_pending && (rc = run_sed(c, theta, c->ncols, 1, B, c->mags_ws, s))) return rc;
-  if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s, (c->has_lsf || (c->opts.variant & PAYNE_V_NO_WALK_TAIL)) ? nullptr : tail);
+  if (c->has_model) return run_post(c, theta, B, 2.355, -1, nullptr, 0, lnl, c->has_phot, s, tl);
   hipLaunchKernelGGL(payne_photonly_kernel, dim3((B + 127) / 128), dim3(128), 0, s, c->mags_ws, c->obs_mag, c->obs_err, c->P.F, B, lnl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("photonly launch: ") + hipGetErrorString(e));
@@ -1045,6 +1064,7 @@ struct payne_sampler {
   int* inside = nullptr;
   int* ell = nullptr;                     // per-chain ellipsoid index of the walk in progress
   int* nredraw = nullptr;                 // per-chain count of proposals redrawn because they left the unit cube
+  double* spec = nullptr;                 // [k_max][2][kSpecStride] the next step's proposals made ahead (null: more dimensions / columns than a record holds)
   // staging of payne_ns_rwalk_queue: chains (u | v | lnprob) and counters (nacc | ncall | nredraw), device + pinned host
   double *q_dev = nullptr, *q_host = nullptr;
   int *qi_dev = nullptr, *qi_host = nullptr;
@@ -1116,7 +1136,8 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
       (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell)) || (rc = alloc(K * 4, (void**)&s->nredraw)) ||
       (rc = alloc(std::max<size_t>(K * (2 * nd + 1), 2 * PAYNE_MAX_DIM) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
-      (rc = alloc(sizeof(WalkTail), (void**)&s->tail_dev))) {
+      (rc = alloc(sizeof(WalkTail), (void**)&s->tail_dev)) ||
+      (spec_fits(d->ndim, c->ncols) && (rc = alloc(K * 2 * kSpecStride * 8, (void**)&s->spec)))) {
     payne_sampler_destroy(s);
     return rc;
   }
@@ -1207,7 +1228,7 @@ extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, dou
   s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr, s->nredraw};
   s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, s->axes,
                               ell ? s->ell : (const int*)nullptr, s->nredraw, scale, loglstar, seed, K,
-                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0};
+                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0, s->spec};
   s->tail_done = false;
   return PAYNE_OK;
 }
@@ -1233,7 +1254,7 @@ extern "C" int payne_rwalk_step(payne_sampler* s, int w) {
   s->tail_done = false;
   int rc = PAYNE_OK;
   if (w < r.walks) {
-    TailReq tr{s->tail_dev, w + 1, w + 1 < r.walks ? 1 : 0, false};
+    TailReq tr{s->tail_dev, w + 1, w + 1 < r.walks ? 1 : 0, false, s->spec ? &s->walk : nullptr};
     rc = lnlike_impl(s->ctx, s->rows, r.K, s->lnl, r.stream, &tr);
     s->tail_done = tr.done;
   } else s->run.open = false;

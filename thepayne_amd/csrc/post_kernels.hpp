@@ -26,6 +26,7 @@ struct PostArgs {
   // next) at its tail -- the workgroup of candidate b has just produced the one value that step waits for -- instead of a
   // launch of its own between two likelihood batches (null: no walk in progress)
   const WalkTail* tail; int tail_step, tail_propose;
+  int tail_spec;                     // the next proposal was made ahead by this batch's hidden-layer launch (rwalk_spec_wave): the tail only settles and copies
 };
 
 // BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
@@ -89,6 +90,13 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
 __device__ PAYNE_EXP_TAIL_ATTR static void walk_tail(const WalkTail* t, int b, int lane, double lnl, int step, int propose) {
   const WalkState W = uniform_copy(&t->w);
   rwalk_step_wave(t->sd, W, b, lane, lnl, step, 1, propose);
+}
+
+// (the walk stays behind the pointer here: by value in PostArgs it was 150 more bytes of kernel arguments whose scalar loads the
+// compiler hoists to the kernel's start -- 93 spilled scalar registers against 52 --, and handed to a call by reference a stack copy)
+__device__ PAYNE_EXP_TAIL_ATTR static void walk_tail_spec(const WalkTail* t, int b, int lane, double lnl) {
+  const WalkState W = uniform_copy(&t->w);
+  rwalk_settle_spec(W, b, lane, lnl);
 }
 
 // LEAN: the likelihood-only instantiation (out_stage == -1, no spectrum output, per-candidate records present):
@@ -194,7 +202,8 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   if constexpr (LEAN) {
     if (a.tail && threadIdx.x < 64) {                           // (wave 0: thread 0 holds the value, the others get it by shuffle)
       const double l = __shfl(lnl_v, 0);
-      walk_tail(a.tail, b, (int)threadIdx.x, l, a.tail_step, a.tail_propose);
+      if (a.tail_spec) walk_tail_spec(a.tail, b, (int)threadIdx.x, l);
+      else walk_tail(a.tail, b, (int)threadIdx.x, l, a.tail_step, a.tail_propose);
     }
   }
 #ifdef PAYNE_STAMPS

@@ -152,6 +152,7 @@ struct WalkState {
   unsigned long long seed;
   int K;
   int nd, ncols, adv_on;       // of the sampler (SamplerDev::ndim / ncols / adv_any): the step's first loads need no table read first
+  double* spec;                // [K][2][kSpecStride] the next proposal made ahead for both outcomes of the pending one (rwalk_spec_wave); null: none
 };
 // device-resident copy for the post kernel's tail (payne_post_kernel<.., LEAN>: PostArgs::tail)
 struct WalkTail { SamplerDev sd; WalkState w; };
@@ -330,5 +331,156 @@ __device__ __forceinline__ void rwalk_step_wave(const SamplerDev& sd, const Walk
                                                 int settle, int propose) {
   const WalkLoads L = walk_loads(sd, W, c, lane);
   rwalk_step_core(sd, W, L, c, lane, lnl_p, step, settle, propose);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// The next proposal made AHEAD.  While the likelihood of proposal w is being computed, both things step w + 1 can start from are
+// already known: the chain's position (proposal w rejected) and proposal w itself (accepted).  The draws are counter-based
+// (seed, chain, step, draw), so the step's random direction and radius are the same either way; only the point they are added to,
+// the redraws that follow from it, and the prior transform differ.  rwalk_spec_wave makes BOTH next proposals -- in workgroups of
+// the hidden-layer launch that would otherwise idle (payne_dense_hidden_kernel) -- and the post kernel's tail only settles the
+// pending proposal and copies the outcome's record (rwalk_settle_spec): a memory round trip instead of ~1 200 dependent fp64
+// instructions on one wave at the end of every likelihood batch.  Same draws, same arithmetic, same order of every sum as
+// rwalk_step_core: the chains are the same TO THE BIT (tests/test_sampler_gpu.py).
+// Sixteen lanes per (chain, outcome): a wave makes two chains' records, a 256-thread workgroup eight chains'.  The walk's pointers and
+// constants come by value (kernel arguments): behind the WalkTail pointer they were one more dependent memory round trip.
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int kSpecLanes = 16;                                   // lanes per (chain, outcome): sampled dimensions <= 16
+constexpr int kSpecCols = 32;                                    // theta columns a record holds
+constexpr int kSpecStride = 2 * kSpecLanes + kSpecCols + 2;      // doubles per record: u' | v' | theta row | ln-prior | (inside, skipped)
+constexpr int kSpecChainsPerWg = 8;
+__host__ __device__ inline bool spec_fits(int nd, int ncols) { return nd <= kSpecLanes && ncols <= kSpecCols; }
+
+__device__ __forceinline__ void rwalk_spec_wave(const SamplerDev& sd, const WalkState& W, int pair, int lane, int step) {
+  const int nd = W.nd, ncols = W.ncols;
+  // lane = [chain of the pair][outcome][16]: o = 0 from the chain's position, 1 from the pending proposal
+  const int l = lane & (kSpecLanes - 1), gb = lane & ~(kSpecLanes - 1), cb = lane & ~31, l32 = lane & 31, o = (lane >> 4) & 1;
+  const int c_ = pair * 2 + (lane >> 5);
+  const bool live = c_ < W.K;
+  const int c = live ? c_ : W.K - 1;                             // (a dead half computes the last chain again and stores nothing)
+  const bool act = l < nd;
+  const int dl = act ? l : 0;
+  const size_t off = (size_t)c * nd + dl;
+  const double uc = (o ? W.u_prop : W.u)[off], vc = (o ? W.v_prop : W.v)[off];
+  const int my_ell = W.ell ? W.ell[c] : 0;
+  const payne_prior_dim dim = sd.dims[dl];
+  const double q0 = sd.q0[dl], q1 = sd.q1[dl];
+  int col_src[2]; double col_val[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = l + kSpecLanes * j, colc = col < ncols ? col : 0;
+    col_src[j] = sd.col_src[colc]; col_val[j] = sd.col_val[colc];
+  }
+  // The candidates' displacements do not depend on the outcome: the chain's 32 lanes draw 32 / NP of them per pass (NP: the
+  // dimensions rounded up as rwalk_step_core does), each is added to both starting points.  rwalk_step_core tries candidates
+  // 0 .. kRedrawPasses * 64 / NP - 1 in order and keeps the first one inside the cube: the same ones in the same order here.
+  const int NP = nd <= 8 ? 8 : 16;
+  const int G = 32 / NP, g = l32 / NP, dg = l32 - g * NP;
+  const bool actg = dg < nd;
+  const int dgl = actg ? dg : 0;
+  const double* ax = W.axes + (size_t)my_ell * nd * nd;
+  double ax16[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) ax16[k] = ax[dgl * nd + (k < nd ? k : nd - 1)];
+  const double ucgA = __shfl(uc, cb + dgl), ucgB = __shfl(uc, cb + kSpecLanes + dgl);
+  const int gold = 64 / NP, maxcand = kRedrawPasses * gold;
+  bool in = false;
+  int skipped = 0;
+  double up = uc, up_fail = uc;
+  for (int c0 = 0; c0 < maxcand && __any(!in); c0 += G) {
+    const unsigned d0 = (unsigned)(c0 + g) * 192u;
+    float z = 0.f;
+    if (actg) {
+      const float a = u01f(W.seed, c, step, d0 + 2 * dg), b = u01f(W.seed, c, step, d0 + 2 * dg + 1);
+      z = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a)) * __builtin_amdgcn_cosf(b);
+    }
+    float n2 = z * z;
+    for (int x = NP >> 1; x > 0; x >>= 1) n2 += __shfl_xor(n2, x);
+    const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01f(W.seed, c, step, d0 + 128)) / (float)nd) * __builtin_amdgcn_rsqf(n2);
+    double sdot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float ze = __shfl(z, cb + g * NP + (k & (NP - 1)));
+      sdot = (k < nd) ? fma(ax16[k], (double)ze, sdot) : sdot;
+    }
+    const double upgA = ucgA + (W.scale * (double)rad) * sdot;
+    const double upgB = ucgB + (W.scale * (double)rad) * sdot;
+    const unsigned gmA = (unsigned)(__ballot(actg && !((upgA > 0.0) && (upgA < 1.0))) >> cb);
+    const unsigned gmB = (unsigned)(__ballot(actg && !((upgB > 0.0) && (upgB < 1.0))) >> cb);
+    int fA = -1, fB = -1;
+    for (int q = G - 1; q >= 0; --q) {
+      const unsigned m = (NP == 16 ? 0xFFFFu : 0xFFu) << (q * NP);
+      if ((gmA & m) == 0u) fA = q;
+      if ((gmB & m) == 0u) fB = q;
+    }
+    const double candA = __shfl(upgA, cb + (fA >= 0 ? fA : 0) * NP + dl), candB = __shfl(upgB, cb + (fB >= 0 ? fB : 0) * NP + dl);
+    const double cand0A = __shfl(upgA, cb + dl), cand0B = __shfl(upgB, cb + dl);
+    const int first = o ? fB : fA;
+    const bool found = first >= 0;
+    if (c0 == gold * (kRedrawPasses - 1)) up_fail = o ? cand0B : cand0A;   // what rwalk_step_core leaves in u_prop when every candidate is outside
+    if (!in) { up = o ? candB : candA; skipped += found ? first : G; in = found; }
+  }
+  if (!in) up = up_fail;
+  const double vp = in ? prior_ppf(dim, q0, q1, up, sd.adv) : vc;
+  double lp = act ? prior_ln(dim, vp) : 0.0;
+#pragma unroll
+  for (int x = kSpecLanes >> 1; x > 0; x >>= 1) lp += __shfl_xor(lp, x);     // (wave_sum's last four levels: the others add zeros)
+  if (W.adv_on) {
+    const payne_adv_priors& a = sd.adv;
+    const double g_ = __shfl(vp, gb + (a.dim_logg >= 0 ? a.dim_logg : 0)), r_ = __shfl(vp, gb + (a.dim_logr >= 0 ? a.dim_logr : 0));
+    const double v_ = __shfl(vp, gb + (a.dim_vrot >= 0 ? a.dim_vrot : 0)), d_ = __shfl(vp, gb + (a.plx_dim >= 0 ? a.plx_dim : 0));
+    const double add = adv_lnprior(a, a.dim_logg >= 0 ? g_ : a.val_logg, a.dim_logr >= 0 ? r_ : a.val_logr,
+                                   a.dim_vrot >= 0 ? v_ : a.val_vrot, a.plx_dim >= 0 ? d_ : 1.0);
+    lp = (lp == -INFINITY || add == -INFINITY) ? -INFINITY : lp + add;
+  }
+  double* rec = W.spec + ((size_t)c * 2 + o) * kSpecStride;
+  if (live && act) { rec[l] = up; rec[kSpecLanes + l] = vp; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = l + kSpecLanes * j;
+    const double vs = __shfl(vp, gb + (col_src[j] >= 0 ? col_src[j] : 0));
+    if (live && col < ncols) rec[2 * kSpecLanes + col] = col_src[j] >= 0 ? vs : col_val[j];
+  }
+  if (live && l == 0) {
+    rec[2 * kSpecLanes + kSpecCols] = lp;
+    int* m = reinterpret_cast<int*>(rec + 2 * kSpecLanes + kSpecCols + 1);
+    m[0] = in ? 1 : 0; m[1] = skipped;
+  }
+}
+
+// The tail's half: settle the pending proposal of chain c with its likelihood, take the next proposal from the record of the outcome.
+__device__ __forceinline__ void rwalk_settle_spec(const WalkState& W, int c, int lane, double lnl_p) {
+  const int nd = W.nd, ncols = W.ncols;
+  const bool act = lane < nd;
+  const int dl = act ? lane : 0, colc = lane < ncols ? lane : 0;
+  const size_t off = (size_t)c * nd + dl;
+  const double* rA = W.spec + (size_t)c * 2 * kSpecStride;
+  const double* rB = rA + kSpecStride;
+  // every load before the first store
+  const int was_in = W.inside[c];
+  const double lpr = W.lnprior_prop[c];
+  const double u_p = W.u_prop[off], v_p = W.v_prop[off];
+  const int ncall0 = W.ncall[c], nacc0 = W.nacc[c], nredraw0 = W.nredraw ? W.nredraw[c] : 0;
+  const double upA = rA[dl], vpA = rA[kSpecLanes + dl], rowA = rA[2 * kSpecLanes + colc], lpA = rA[2 * kSpecLanes + kSpecCols];
+  const double upB = rB[dl], vpB = rB[kSpecLanes + dl], rowB = rB[2 * kSpecLanes + colc], lpB = rB[2 * kSpecLanes + kSpecCols];
+  const int* mA = reinterpret_cast<const int*>(rA + 2 * kSpecLanes + kSpecCols + 1);
+  const int* mB = reinterpret_cast<const int*>(rB + 2 * kSpecLanes + kSpecCols + 1);
+  const int inA = mA[0], skA = mA[1], inB = mB[0], skB = mB[1];
+  const double lp = (lpr == -INFINITY) ? -INFINITY : lpr + lnl_p;
+  const bool accept = was_in && (lp > W.loglstar);                // false for NaN
+  if (was_in) {
+    if (accept && act) { W.u[off] = u_p; W.v[off] = v_p; }
+    if (lane == 0) {
+      W.ncall[c] = ncall0 + 1;
+      if (accept) { W.lnprob[c] = lp; W.nacc[c] = nacc0 + 1; }
+    }
+  }
+  if (act) { W.u_prop[off] = accept ? upB : upA; W.v_prop[off] = accept ? vpB : vpA; }
+  if (lane == 0) {
+    W.inside[c] = accept ? inB : inA;
+    W.lnprior_prop[c] = accept ? lpB : lpA;
+    if (W.nredraw) W.nredraw[c] = nredraw0 + (accept ? skB : skA);
+  }
+  if (lane < ncols) W.rows[(size_t)c * ncols + lane] = accept ? rowB : rowA;
 }
 #endif
