@@ -883,8 +883,8 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
 #ifndef PAYNE_EXP_HK
 #define PAYNE_EXP_HK 0                // (timing experiments: 1 no first layer, 2 no matrix phase, 4 no weight-tile loads)
 #endif
-constexpr int HK_KC = 320;          // K chunk
-constexpr int HK_PITCH = 328;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
+constexpr int HK_KC = 304;          // K chunk (a multiple of 16; with the pitch below two workgroups' tiles are 79.9 KB: two fit a CU)
+constexpr int HK_PITCH = 312;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
 static_assert(sed_tile_lds_bytes() <= HK_LDS_BYTES, "the photometric tile runs in the hidden-layer launch's LDS");
 

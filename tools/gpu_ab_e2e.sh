@@ -13,5 +13,5 @@ for i in $(seq $REP); do
   one new
   if [ -f $OLD ]; then PAYNE_HIP_LIB=$OLD one old; fi
 done
-echo "--- kernels inside the sampler loop: new"; bash tools/exp/sampler_gaps.sh
-if [ -f $OLD ]; then echo "--- old"; rm -rf gpurun_out/sampler_gaps; PAYNE_HIP_LIB=$OLD bash tools/exp/sampler_gaps.sh; fi
+echo "--- kernels inside the sampler loop: new"; bash tools/exp/sampler_gaps.sh $CFG
+if [ -f $OLD ]; then echo "--- old"; rm -rf gpurun_out/sampler_gaps; PAYNE_HIP_LIB=$OLD bash tools/exp/sampler_gaps.sh $CFG; fi
