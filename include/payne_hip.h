@@ -310,7 +310,8 @@ int payne_lnprob_u_batch(payne_sampler* s, const double* u, int K, double* v, do
  * unit ball; a step is accepted iff u' is inside the unit cube and lnprob(u') > loglstar.
  * u, v: device fp64 [K][ndim] in/out (chain positions); lnprob: device fp64 [K] in/out;
  * axes: HOST fp64 [ndim][ndim] row-major; nacc, ncall: device int32 [K] (accepted steps,
- * likelihood calls) overwritten.  One small kernel + one payne_lnlike_batch per step. */
+ * likelihood calls) overwritten (zeroed by the walk's first step).  One small kernel + one payne_lnlike_batch for the first
+ * step; the steps after it ride in the likelihood batch's own launches (payne_sampler_counters). */
 int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
                       double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall,
                       void* stream);
@@ -404,7 +405,8 @@ int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u, const dou
 int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats);
 
 /* How the chain steps of this sampler ran so far: out[0] at the tail of the likelihood-only post kernel (the workgroup of
- * candidate k settles chain k's proposal and draws the next one as soon as it has the likelihood), out[1] as launches of
+ * candidate k settles chain k's proposal as soon as it has the likelihood and takes the next one from the two that idle workgroups
+ * of the batch's hidden-layer launch made ahead, one per outcome -- or draws it there: PAYNE_V_NO_WALK_SPEC), out[1] as launches of
  * their own (the first step of every walk; every step under PAYNE_V_NO_WALK_TAIL, with an LSF, or when the spectrum length
  * has no likelihood-only kernel).  Measurement / test aid, no reference counterpart. */
 int payne_sampler_counters(const payne_sampler* s, long long out[2]);

@@ -1079,6 +1079,10 @@ struct payne_sampler {
   struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; bool multi; int* nredraw; } run{};
 };
 
+// doubles of the queue's staging block (device and pinned host): chains (u | v | lnprob), then the ellipsoids' axes and the
+// chains' ellipsoid indices, which travel with them in ONE transfer
+static size_t q_doubles(size_t K, size_t nd) { return K * (2 * nd + 1) + (size_t)PAYNE_MAX_ELL * nd * nd + (K + 1) / 2; }
+
 extern "C" void payne_sampler_destroy(payne_sampler* s) {
   if (!s) return;
   int prev = 0;
@@ -1135,7 +1139,7 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
       (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
       (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell)) || (rc = alloc(K * 4, (void**)&s->nredraw)) ||
-      (rc = alloc(std::max<size_t>(K * (2 * nd + 1), 2 * PAYNE_MAX_DIM) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
+      (rc = alloc(std::max<size_t>(q_doubles(K, nd), 2 * PAYNE_MAX_DIM) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
       (rc = alloc(sizeof(WalkTail), (void**)&s->tail_dev)) ||
       (spec_fits(d->ndim, c->ncols) && (rc = alloc(K * 2 * kSpecStride * 8, (void**)&s->spec)))) {
     payne_sampler_destroy(s);
@@ -1162,7 +1166,7 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     for (int i = 0; i < PAYNE_MAX_DIM; ++i) { s->sd.q0[i] = qh[i]; s->sd.q1[i] = qh[PAYNE_MAX_DIM + i]; }
   }
   (void)hipMemset(s->inside, 0, K * 4);
-  if (hipHostMalloc((void**)&s->q_host, K * (2 * nd + 1) * 8, hipHostMallocDefault) != hipSuccess ||
+  if (hipHostMalloc((void**)&s->q_host, q_doubles(K, nd) * 8, hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&s->qi_host, 3 * K * 4, hipHostMallocDefault) != hipSuccess) {
     payne_sampler_destroy(s);
     return fail(c, PAYNE_E_HIP, "hipHostMalloc(sampler staging)");
@@ -1208,6 +1212,16 @@ extern "C" int payne_lnprob_u_batch(payne_sampler* s, const double* u, int K, do
 // The walk in two parts, so that a caller can interleave the steps of several samplers (one context and
 // one HIP stream each) from one host thread: two independent batches in flight fill the idle time a single
 // chain of dependent launches leaves (13.6 M against 10.6 M evaluations/s at 512 x 4096 pixels).
+// (the walk's counters -- nacc, ncall, nredraw -- are zeroed by its first step: payne_rwalk_kernel with settle = 0)
+static void rwalk_begin_impl(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes_dev, const int* ell_dev,
+                             double scale, double loglstar, int walks, unsigned long long seed, int* nacc, int* ncall, int* nredraw,
+                             void* stream) {
+  s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell_dev != nullptr, nredraw};
+  s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, axes_dev,
+                      ell_dev, nredraw, scale, loglstar, seed, K,
+                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0, s->spec};
+  s->tail_done = false;
+}
 extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
                                      int n_ell, const int* ell, double scale, double loglstar, int walks,
                                      unsigned long long seed, int* nacc, int* ncall, void* stream) {
@@ -1222,14 +1236,7 @@ extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, dou
   const int nd = s->sd.ndim;
   HIPCHK(s->ctx, hipMemcpyAsync(s->axes, axes, (size_t)n_ell * nd * nd * 8, hipMemcpyHostToDevice, st));
   if (ell) HIPCHK(s->ctx, hipMemcpyAsync(s->ell, ell, (size_t)K * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(s->ctx, hipMemsetAsync(nacc, 0, (size_t)K * 4, st));
-  HIPCHK(s->ctx, hipMemsetAsync(ncall, 0, (size_t)K * 4, st));
-  HIPCHK(s->ctx, hipMemsetAsync(s->nredraw, 0, (size_t)K * 4, st));
-  s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell != nullptr, s->nredraw};
-  s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, s->axes,
-                              ell ? s->ell : (const int*)nullptr, s->nredraw, scale, loglstar, seed, K,
-                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0, s->spec};
-  s->tail_done = false;
+  rwalk_begin_impl(s, u, v, lnprob, K, s->axes, ell ? s->ell : (const int*)nullptr, scale, loglstar, walks, seed, nacc, ncall, s->nredraw, stream);
   return PAYNE_OK;
 }
 extern "C" int payne_rwalk_begin(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
@@ -1334,20 +1341,25 @@ extern "C" int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u
     }
     s->q_ell[k] = pick;
   }
-  const size_t nq_d = (size_t)K * (2 * nd + 1);
-  HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, nq_d * 8, hipMemcpyHostToDevice, st));
+  // one transfer each way: chains, axes and ellipsoid indices up; chains, then the three counters down
+  const size_t nq_d = (size_t)K * (2 * nd + 1), n_ax = (size_t)n_ell * nd * nd;
+  std::memcpy(hl + K, axes_unit, n_ax * 8);
+  int* hell = reinterpret_cast<int*>(hl + K + n_ax);
+  if (n_ell > 1) std::memcpy(hell, s->q_ell.data(), (size_t)K * 4);
+  HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, (nq_d + n_ax + (n_ell > 1 ? (size_t)(K + 1) / 2 : 0)) * 8, hipMemcpyHostToDevice, st));
   double* du = s->q_dev;
   double* dv = du + (size_t)K * nd;
   double* dl = dv + (size_t)K * nd;
+  const double* dax = dl + K;
+  const int* dell = n_ell > 1 ? reinterpret_cast<const int*>(dax + n_ax) : nullptr;
   int* dna = s->qi_dev;
   int* dnc = dna + K;
-  rc = payne_rwalk_begin_ell(s, du, dv, dl, K, axes_unit, n_ell, n_ell > 1 ? s->q_ell.data() : nullptr, scale, loglstar, walks, seed,
-                             dna, dnc, stream);
+  int* dnr = dnc + K;
+  rwalk_begin_impl(s, du, dv, dl, K, dax, dell, scale, loglstar, walks, seed, dna, dnc, dnr, stream);
   for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, nq_d * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(s->qi_host, s->qi_dev, (size_t)2 * K * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(s->qi_host + 2 * K, s->nredraw, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(s->qi_host, s->qi_dev, (size_t)3 * K * 4, hipMemcpyDeviceToHost, st));
   s->queue_open = true; s->queue_K = K; s->queue_stream = stream;
   return PAYNE_OK;
 }

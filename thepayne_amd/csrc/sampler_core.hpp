@@ -248,6 +248,7 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   double ax8[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) ax8[k] = propose ? ax[dgl * nd + (k < nd ? k : nd - 1)] : 0.0;
+  if (!settle && lane == 0) { ncall[c] = 0; nacc[c] = 0; }     // a walk's first step: its counters start here (no memsets before it)
   if (settle && was_in) {
     const double lp = (lpr == -INFINITY) ? -INFINITY : lpr + lnl_p;
     const bool accept = lp > loglstar;                          // false for NaN
@@ -308,7 +309,7 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
     skipped += in ? first : G;
     up = __shfl(upg, (in ? first : 0) * NP + dl);                    // lanes d < nd take candidate `first`
   }
-  if (nredraw && lane == 0) nredraw[c] = L.nredraw0 + skipped;
+  if (nredraw && lane == 0) nredraw[c] = (settle ? L.nredraw0 : 0) + skipped;
   const payne_prior_dim dim = sd.dims[dl];                      // (an L2 hit; twenty registers the loop above could not spare)
   const double vp = (PAYNE_EXP_TAIL & 1) ? up : (in ? prior_ppf(dim, sd.q0[dl], sd.q1[dl], up, sd.adv) : vc);       // outside: a harmless valid row
   double lp = (PAYNE_EXP_TAIL & 1) ? 0.0 : wave_sum(act ? prior_ln(dim, vp) : 0.0);
