@@ -190,6 +190,38 @@ def test_walk_step_at_the_post_kernels_tail_is_the_same_walk(tmp_path, photscale
     assert (moved > 0).sum() > 10
 
 
+def test_walk_forms_agree_under_advanced_priors(tmp_path):
+    """The three forms of the chain step (proposal made ahead / drawn at the tail / own launch) with priors on derived quantities
+    and a tabulated inverse CDF in play (IMF, VROT, GAL -> Dist, Parallax): the same chains to the bit; more than eight sampled
+    dimensions, so the proposals made ahead use sixteen lanes per candidate."""
+    from thepayne_amd import _lib
+    res = []
+    for variant in (0, _lib.V_NO_WALK_SPEC, _lib.V_NO_WALK_TAIL):
+        L, P0, _ = _fit_objects(tmp_path, photscale=False, modpoly=True, variant=variant)
+        pd = synth.demo_priordict()
+        pd.update({'VROT': {}, 'Av': {'pv_uniform': [0.0, 2.0]}, 'IMF': {'IMF_type': 'Kroupa'}, 'GAL': {'lb_coords': [70.0, 25.0]},
+                   'Dist': {'pv_uniform': [50.0, 4000.0]}, 'log(R)': {'pv_uniform': [-0.8, 1.2]},
+                   'Parallax': {'gaussian': [2.0, 0.8], 'uniform': [0.3, 15.0]},
+                   'blaze_coeff': [[0.0, 0.05], [0.0, 0.02], [0.0, 0.01]]})
+        P = _clone_prior(P0, pd)
+        prop = _proposer(L, P)
+        nd = L.ndim
+        assert 8 < nd <= 16
+        rng = np.random.default_rng(4)
+        U0 = rng.uniform(0.05, 0.95, size=(37, nd))
+        V0, lp0 = prop.lnprob_u(U0)
+        lp0 = np.where(np.isnan(lp0), -np.inf, lp0)
+        lstar = float(np.percentile(lp0[np.isfinite(lp0)], 30))
+        res.append([prop.rwalk(U0, V0, lp0, 0.04 * np.eye(nd), 1.0, lstar, 8, seed=23),
+                    prop.rwalk(U0, V0, lp0, 0.5 * np.eye(nd), 1.0, -np.inf, 5, seed=29)])
+        prop.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert a[3].sum() > 0
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+
+
 def test_device_rwalk_step_distribution(tmp_path):
     """One step with threshold -inf accepts every in-cube proposal: the displacement must be uniform in the
     ellipsoid axes @ unit ball (mean 0, covariance axes axes^T / (n+2), |z| <= 1)."""
