@@ -351,6 +351,14 @@ int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_v, double* 
                      double dlogz, long long max_emit, double logl_max, payne_ns_dead* out, int cap,
                      int* consumed, int* stop);
 
+/* The live set and the threshold as payne_ns_consume WILL leave them once it has walked the whole queue (replacements only:
+ * no evidence arithmetic, no records, no stop condition but the queue's end), into copies out_* of the live arrays;
+ * *loglstar is written only when *n_dead > 0.  The batched sampler starts its next queue of proposals from this state and
+ * consumes the current one while the GPU walks (no reference counterpart: dynesty proposes one point at a time). */
+int payne_ns_peek(int nlive, int ndim, const double* live_u, const double* live_v, const double* live_logl, const double* qu,
+                  const double* qv, const double* ql, int nq, double* out_u, double* out_v, double* out_logl, double* loglstar,
+                  int* n_dead);
+
 /* Bounding ellipsoid(s) of n live points u[n][ndim] (unit cube): dynesty's bound='single' (multi = 0) or
  * 'multi' (recursive 2-means split while the children hold less than half the parent's volume, at most
  * max_ell <= PAYNE_MAX_ELL pieces).  Outputs, one entry per ellipsoid {ctr + axes z, |z| <= 1}: ctr [.][ndim],

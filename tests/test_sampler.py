@@ -109,6 +109,130 @@ def test_native_bookkeeping_matches_python_loop():
     assert abs(rn.logz[-1] - (0.5 * nd * np.log(2 * np.pi) + nd * np.log(0.05))) < 5 * rn.logzerr[-1] + 0.3
 
 
+class _QueueProposer(object):
+    """A host stand-in for DeviceProposer's queue calls (rwalk_queue / _begin / _end): K random-walk chains from random live
+    points, isotropic steps (the bound is ignored, so a queue depends on the live set, the threshold, the scale and the seed only)."""
+    def __init__(self, ll):
+        self.ll, self.pending, self.begun, self.dropped = ll, None, 0, 0
+
+    def _make(self, live_u, live_v, live_logl, K, scale, lstar, walks, seed):
+        rng = np.random.default_rng(seed)
+        st = rng.integers(0, len(live_logl), size=K)
+        U, L = np.array(live_u)[st], np.array(live_logl)[st]
+        nacc, ncall = np.zeros(K, np.int64), np.zeros(K, np.int64)
+        for _ in range(walks):
+            P = U + 0.03 * scale * rng.normal(size=U.shape)
+            ins = np.all((P > 0) & (P < 1), axis=1)
+            lp = np.where(ins, self.ll(P), -np.inf)
+            ncall += ins
+            ok = ins & (lp > lstar)
+            U[ok], L[ok] = P[ok], lp[ok]
+            nacc += ok
+        mv = nacc > 0
+        return U[mv], L[mv], np.maximum(1, ncall[mv]).astype(np.int32), int(nacc.sum()), int(ncall.sum()), int(ncall[~mv].sum())
+
+    def rwalk_queue_begin(self, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed):
+        assert self.pending is None
+        self.begun += 1
+        self.pending = self._make(live_u, live_v, live_logl, K, scale, loglstar, walks, seed)
+
+    def rwalk_queue_end(self, qbuf):
+        U, L, nc, acc, calls, idle = self.pending
+        self.pending = None
+        n = len(L)
+        qbuf[0][:n], qbuf[1][:n], qbuf[2][:n], qbuf[3][:n] = U, U, L, nc
+        return n, acc, calls, 0, idle
+
+    def rwalk_queue(self, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed, qbuf, between=None):
+        self.rwalk_queue_begin(live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed)
+        if between is not None:
+            between()
+        return self.rwalk_queue_end(qbuf)
+
+    def lnprob_u(self, U):
+        return np.array(U), self.ll(np.asarray(U))
+
+
+def test_queue_launched_ahead_is_the_queue_launched_after():
+    """pipeline=True launches the next queue from the state payne_ns_peek predicts BEFORE the current queue is consumed:
+    with a proposer whose queues do not depend on the bound, the run is the serial run to the last bit -- every dead point,
+    the evidence, the live set --, through bound updates in mid-queue, a stop on maxiter in mid-queue (the queue in flight is
+    collected and dropped), a second call that resumes, and convergence."""
+    from thepayne_amd.build import build_lib
+    build_lib()
+    nd = 3
+
+    def ll(V):
+        return -0.5 * np.sum(((V - 0.5) / 0.07) ** 2, axis=1)
+
+    runs = []
+    for pipeline in (True, False):
+        prop = _QueueProposer(ll)
+        S = NestedSampler(ll, lambda U: U, nd, nlive=96, bound='single', sample='rwalk', walks=8, batched=True,
+                          queue_size=96, rstate=np.random.default_rng(3), proposer=prop, pipeline=pipeline, overlap_bound=False,
+                          update_interval=40)
+        assert S.pipeline == pipeline
+        recs = list(S.sample_chunks(maxiter=333, dlogz=1e-9))             # stops inside a queue
+        assert S._ahead is None and prop.pending is None                  # nothing left in flight
+        recs += list(S.sample_chunks(dlogz=0.05, maxcall=400000))         # resumes, runs to convergence
+        assert S._ahead is None and prop.pending is None
+        tuples = list(S.add_live_points())
+        runs.append((S, recs, tuples, prop))
+    (Sa, ra, ta, pa), (Sb, rb, tb, pb) = runs
+    assert Sa.it == Sb.it > 600 and Sa.ncall == Sb.ncall
+    ca = {k: np.concatenate([r[k] for r in ra]) for k in ("worst", "u", "logl", "logz", "logwt", "nc", "delta_logz", "scale")}
+    cb = {k: np.concatenate([r[k] for r in rb]) for k in ca}
+    for k in ca:
+        assert np.array_equal(ca[k], cb[k]), k
+    assert np.array_equal(Sa.live_u, Sb.live_u) and Sa.logz == Sb.logz
+    assert pa.begun >= pb.begun + 1                                       # (queues launched ahead and dropped at the two stops)
+    assert abs(Sa.results.logz[-1] - (0.5 * nd * np.log(2 * np.pi) + nd * np.log(0.07))) < 5 * Sa.results.logzerr[-1] + 0.3
+
+
+def test_peek_predicts_the_consumed_state():
+    """payne_ns_peek against payne_ns_consume on the same queue: the same live points and threshold, the same number of dead
+    points; ties and -inf values included; an empty and a useless queue."""
+    import ctypes as C
+    from thepayne_amd import _lib
+    from thepayne_amd.build import build_lib
+    build_lib()
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    n, nd = 50, 3
+    A = lambda a: a.ctypes.data                                          # noqa: E731
+    for case in range(4):
+        lu, lv = rng.uniform(size=(n, nd)), rng.uniform(size=(n, nd))
+        ll = np.round(rng.normal(size=n), 1)                              # ties
+        ll[:5] = -np.inf
+        nq = (0, 40, 40, 200)[case]
+        qu, qv = rng.uniform(size=(nq, nd)), rng.uniform(size=(nq, nd))
+        ql = np.round(rng.normal(size=nq) + (-9.0 if case == 2 else 0.3), 1)   # case 2: nothing beats the threshold
+        qnc = np.ones(nq, np.int32)
+        ou, ov, ol = np.empty((n, nd)), np.empty((n, nd)), np.empty(n)
+        ls, m = C.c_double(-1e300), C.c_int(-1)
+        assert lib.payne_ns_peek(n, nd, A(lu), A(lv), A(ll), A(qu), A(qv), A(ql), nq, A(ou), A(ov), A(ol), C.byref(ls), C.byref(m)) == 0
+        cu, cv, cl, cit = lu.copy(), lv.copy(), ll.copy(), np.zeros(n, np.int32)
+        st = _lib.NsState(n, nd, 1, 0, -1e300, 0.0, 0.0, 0.0, -1e300)
+        cap = max(nq, 1)
+        fb, ib = np.empty(cap * (2 * nd + 7)), np.empty(cap * 3, np.int32)
+        f0, i0 = A(fb), A(ib)
+        col = lambda j: f0 + 8 * cap * (2 * nd + j)                      # noqa: E731
+        dead = _lib.NsDead(i0, f0, f0 + 8 * cap * nd, col(0), col(1), col(2), col(3), col(4), col(5), i0 + 4 * cap, i0 + 8 * cap, col(6))
+        used, stop = C.c_int(0), C.c_int(0)
+        # in two calls, as the sampling loop consumes a queue around a bound update
+        m1 = lib.payne_ns_consume(C.byref(st), A(cu), A(cv), A(cl), A(cit), A(qu), A(qv), A(ql), A(qnc), nq, 0.0, 7, np.inf,
+                                  C.byref(dead), cap, C.byref(used), C.byref(stop))
+        u1 = used.value
+        m2 = lib.payne_ns_consume(C.byref(st), A(cu), A(cv), A(cl), A(cit), A(qu[u1:]), A(qv[u1:]), A(ql[u1:]), A(qnc[u1:]), nq - u1,
+                                  0.0, 2 ** 40, np.inf, C.byref(dead), cap, C.byref(used), C.byref(stop))
+        assert m1 >= 0 and m2 >= 0 and m.value == m1 + m2
+        assert np.array_equal(ou, cu) and np.array_equal(ov, cv) and np.array_equal(ol, cl)
+        if m.value:
+            assert ls.value == st.loglstar
+        else:
+            assert ls.value == -1e300 and case in (0, 2)
+
+
 def test_fitpayne_bulk_rows_equal_single_rows(tmp_path):
     import io
     from thepayne_amd.fitting.fitstar import FitPayne

@@ -145,6 +145,54 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
   return emitted;
 }
 
+// What the live set and the threshold WILL be once payne_ns_consume has walked the whole queue (no stop condition but the
+// queue's end): the replacements only -- same heap order, same test -- into copies of the live arrays; no evidence arithmetic,
+// no records.  The batched sampler launches its next queue of proposals from this state before it consumes the current one,
+// so that the GPU walks while the host does the bookkeeping (thepayne_amd/sampler/nested.py: pipeline).
+extern "C" int payne_ns_peek(int nlive, int ndim, const double* live_u, const double* live_v, const double* live_logl,
+                             const double* qu, const double* qv, const double* ql, int nq, double* out_u, double* out_v,
+                             double* out_logl, double* loglstar, int* n_dead) {
+  if (nlive <= 0 || ndim <= 0 || nq < 0 || !live_u || !live_v || !live_logl || !out_u || !out_v || !out_logl || !loglstar || !n_dead)
+    return PAYNE_E_INVALID;
+  if (nq > 0 && (!qu || !qv || !ql)) return PAYNE_E_INVALID;
+  const int n = nlive, nd = ndim;
+  std::memcpy(out_u, live_u, (size_t)n * nd * 8);
+  std::memcpy(out_v, live_v, (size_t)n * nd * 8);
+  std::memcpy(out_logl, live_logl, (size_t)n * 8);
+  std::vector<int> heap(n);
+  for (int i = 0; i < n; ++i) heap[i] = i;
+  auto less = [&](int a, int b) { const double la = out_logl[a], lb = out_logl[b]; return la < lb || (la == lb && a < b); };
+  auto sift = [&](int pos) {
+    const int v = heap[pos];
+    while (true) {
+      int c = 2 * pos + 1;
+      if (c >= n) break;
+      if (c + 1 < n && less(heap[c + 1], heap[c])) ++c;
+      if (!less(heap[c], v)) break;
+      heap[pos] = heap[c];
+      pos = c;
+    }
+    heap[pos] = v;
+  };
+  for (int i = n / 2 - 1; i >= 0; --i) sift(i);
+  int qpos = 0, m = 0;
+  while (true) {
+    const int worst = heap[0];
+    const double lmin = out_logl[worst];
+    while (qpos < nq && !(ql[qpos] > lmin)) ++qpos;
+    if (qpos >= nq) break;
+    *loglstar = lmin;
+    std::memcpy(out_u + (size_t)worst * nd, qu + (size_t)qpos * nd, (size_t)nd * 8);
+    std::memcpy(out_v + (size_t)worst * nd, qv + (size_t)qpos * nd, (size_t)nd * 8);
+    out_logl[worst] = ql[qpos];
+    sift(0);
+    ++qpos;
+    ++m;
+  }
+  *n_dead = m;
+  return PAYNE_OK;
+}
+
 // ---- bounding ellipsoids of the live points ------------------------------------------------
 // dynesty's bound='single' / 'multi' as the reference requests them (fitstar.py:314): the smallest
 // scaled covariance ellipsoid holding every live point (unit-cube coordinates), enlarged in volume;

@@ -1067,8 +1067,6 @@ struct payne_sampler {
   double* spec = nullptr;                 // [k_max][2][kSpecStride] the next step's proposals made ahead (null: more dimensions / columns than a record holds)
   // staging of payne_ns_rwalk_queue: chains (u | v | lnprob) and counters (nacc | ncall | nredraw), device + pinned host
   double *q_dev = nullptr, *q_host = nullptr;
-  int *qi_dev = nullptr, *qi_host = nullptr;
-  std::vector<int> q_start, q_ell;
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
   WalkState walk{};                       // the walk in progress
   bool queue_open = false; int queue_K = 0; void* queue_stream = nullptr;   // payne_ns_rwalk_queue_begin .. _end
@@ -1079,9 +1077,10 @@ struct payne_sampler {
   struct { double *u, *v, *lnprob; int K, walks; double scale, loglstar; unsigned long long seed; int *nacc, *ncall; void* stream; bool open; bool multi; int* nredraw; } run{};
 };
 
-// doubles of the queue's staging block (device and pinned host): chains (u | v | lnprob), then the ellipsoids' axes and the
-// chains' ellipsoid indices, which travel with them in ONE transfer
-static size_t q_doubles(size_t K, size_t nd) { return K * (2 * nd + 1) + (size_t)PAYNE_MAX_ELL * nd * nd + (K + 1) / 2; }
+// doubles of the queue's staging block (device and pinned host): chains (u | v | lnprob) and the walk's three counters (what
+// comes back, in ONE transfer), then the ellipsoids' axes, centres and inverse axes (they travel up with the chains in one
+// transfer; the counters' slots go along unused), then (device only) the chains' ellipsoid indices
+static size_t q_doubles(size_t K, size_t nd) { return K * (2 * nd + 1) + (3 * K + 1) / 2 + (size_t)PAYNE_MAX_ELL * (2 * nd * nd + nd) + (K + 1) / 2; }
 
 extern "C" void payne_sampler_destroy(payne_sampler* s) {
   if (!s) return;
@@ -1090,7 +1089,6 @@ extern "C" void payne_sampler_destroy(payne_sampler* s) {
   (void)hipSetDevice(s->ctx->device);
   for (void* p : s->owned) (void)hipFree(p);
   if (s->q_host) (void)hipHostFree(s->q_host);
-  if (s->qi_host) (void)hipHostFree(s->qi_host);
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -1139,7 +1137,7 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       (rc = alloc(K * 8, (void**)&s->lnprior)) || (rc = alloc(K * 8, (void**)&s->lnl)) ||
       (rc = alloc(K * c->ncols * 8, (void**)&s->rows)) || (rc = alloc((size_t)PAYNE_MAX_ELL * nd * nd * 8, (void**)&s->axes)) ||
       (rc = alloc(K * 4, (void**)&s->inside)) || (rc = alloc(K * 4, (void**)&s->ell)) || (rc = alloc(K * 4, (void**)&s->nredraw)) ||
-      (rc = alloc(std::max<size_t>(q_doubles(K, nd), 2 * PAYNE_MAX_DIM) * 8, (void**)&s->q_dev)) || (rc = alloc(3 * K * 4, (void**)&s->qi_dev)) ||
+      (rc = alloc(std::max<size_t>(q_doubles(K, nd), 2 * PAYNE_MAX_DIM) * 8, (void**)&s->q_dev)) ||
       (rc = alloc(sizeof(WalkTail), (void**)&s->tail_dev)) ||
       (spec_fits(d->ndim, c->ncols) && (rc = alloc(K * 2 * kSpecStride * 8, (void**)&s->spec)))) {
     payne_sampler_destroy(s);
@@ -1166,8 +1164,7 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     for (int i = 0; i < PAYNE_MAX_DIM; ++i) { s->sd.q0[i] = qh[i]; s->sd.q1[i] = qh[PAYNE_MAX_DIM + i]; }
   }
   (void)hipMemset(s->inside, 0, K * 4);
-  if (hipHostMalloc((void**)&s->q_host, q_doubles(K, nd) * 8, hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&s->qi_host, 3 * K * 4, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&s->q_host, q_doubles(K, nd) * 8, hipHostMallocDefault) != hipSuccess) {
     payne_sampler_destroy(s);
     return fail(c, PAYNE_E_HIP, "hipHostMalloc(sampler staging)");
   }
@@ -1219,7 +1216,8 @@ static void rwalk_begin_impl(payne_sampler* s, double* u, double* v, double* lnp
   s->run = {u, v, lnprob, K, walks, scale, loglstar, seed, nacc, ncall, stream, true, ell_dev != nullptr, nredraw};
   s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, axes_dev,
                       ell_dev, nredraw, scale, loglstar, seed, K,
-                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0, s->spec};
+                      s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0, s->spec,
+                      nullptr, nullptr, nullptr, 0};
   s->tail_done = false;
 }
 extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
@@ -1299,67 +1297,46 @@ extern "C" int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u
   if (n_ell < 1 || n_ell > PAYNE_MAX_ELL || (n_ell > 1 && (!ctr || !ainv))) return fail(c, PAYNE_E_INVALID, "bad ellipsoid list");
   const int nd = s->sd.ndim;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // ---- start points (uniform among the live points) and, with several ellipsoids, the one each chain steps in: one that
-  //      holds its start point (a random one of those), else the nearest
+  // ---- start points: uniform among the live points (splitmix of the seed).  With several ellipsoids the walk's first step finds
+  //      the one each chain steps in on the device (walk_assign_ell: on the host that loop was 8 us per ellipsoid, before the GPU
+  //      could start)
   auto mix = [](unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
   };
-  s->q_start.resize(K); s->q_ell.resize(K);
   double* hu = s->q_host;
   double* hv = hu + (size_t)K * nd;
   double* hl = hv + (size_t)K * nd;
   for (int k = 0; k < K; ++k) {
     const unsigned long long r0 = mix(seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull));
     const int i = (int)(r0 % (unsigned long long)nlive);
-    s->q_start[k] = i;
     std::memcpy(hu + (size_t)k * nd, live_u + (size_t)i * nd, (size_t)nd * 8);
     std::memcpy(hv + (size_t)k * nd, live_v + (size_t)i * nd, (size_t)nd * 8);
     hl[k] = live_logl[i];
-    int pick = 0;
-    if (n_ell > 1) {
-      int best = 0, nin = 0;
-      double dbest = INFINITY;
-      unsigned long long r1 = mix(r0);
-      for (int e = 0; e < n_ell; ++e) {
-        const double* ce = ctr + (size_t)e * nd;
-        const double* ai = ainv + (size_t)e * nd * nd;
-        double d2 = 0.0;
-        for (int a = 0; a < nd; ++a) {
-          double y = 0.0;
-          for (int b = 0; b < nd; ++b) y += ai[a * nd + b] * (live_u[(size_t)i * nd + b] - ce[b]);
-          d2 += y * y;
-        }
-        if (d2 < dbest) { dbest = d2; best = e; }
-        if (d2 <= 1.0) {                                   // reservoir choice among the ellipsoids that hold the point
-          ++nin;
-          r1 = mix(r1);
-          if (r1 % (unsigned long long)nin == 0) pick = e;
-        }
-      }
-      if (nin == 0) pick = best;
-    }
-    s->q_ell[k] = pick;
   }
-  // one transfer each way: chains, axes and ellipsoid indices up; chains, then the three counters down
-  const size_t nq_d = (size_t)K * (2 * nd + 1), n_ax = (size_t)n_ell * nd * nd;
-  std::memcpy(hl + K, axes_unit, n_ax * 8);
-  int* hell = reinterpret_cast<int*>(hl + K + n_ax);
-  if (n_ell > 1) std::memcpy(hell, s->q_ell.data(), (size_t)K * 4);
-  HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, (nq_d + n_ax + (n_ell > 1 ? (size_t)(K + 1) / 2 : 0)) * 8, hipMemcpyHostToDevice, st));
+  // one transfer each way: chains, axes and (several ellipsoids) centres and inverse axes up; chains, then the three counters down
+  const size_t nq_d = (size_t)K * (2 * nd + 1), n_cnt = ((size_t)3 * K + 1) / 2, n_ax = (size_t)n_ell * nd * nd;
+  const size_t n_as = n_ell > 1 ? (size_t)n_ell * nd + n_ax : 0;
+  double* hax = hl + K + n_cnt;
+  std::memcpy(hax, axes_unit, n_ax * 8);
+  if (n_ell > 1) {
+    std::memcpy(hax + n_ax, ctr, (size_t)n_ell * nd * 8);
+    std::memcpy(hax + n_ax + (size_t)n_ell * nd, ainv, n_ax * 8);
+  }
+  HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, (nq_d + n_cnt + n_ax + n_as) * 8, hipMemcpyHostToDevice, st));
   double* du = s->q_dev;
   double* dv = du + (size_t)K * nd;
   double* dl = dv + (size_t)K * nd;
-  const double* dax = dl + K;
-  const int* dell = n_ell > 1 ? reinterpret_cast<const int*>(dax + n_ax) : nullptr;
-  int* dna = s->qi_dev;
+  int* dna = reinterpret_cast<int*>(dl + K);
   int* dnc = dna + K;
   int* dnr = dnc + K;
+  const double* dax = dl + K + n_cnt;
+  int* dell = n_ell > 1 ? reinterpret_cast<int*>(const_cast<double*>(dax) + n_ax + n_as) : nullptr;   // (device only: written by the first step)
   rwalk_begin_impl(s, du, dv, dl, K, dax, dell, scale, loglstar, walks, seed, dna, dnc, dnr, stream);
+  if (n_ell > 1) { s->walk.as_ctr = dax + n_ax; s->walk.as_ainv = dax + n_ax + (size_t)n_ell * nd; s->walk.ell_out = dell; s->walk.n_ell = n_ell; }
   for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, nq_d * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(s->qi_host, s->qi_dev, (size_t)3 * K * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, (nq_d + n_cnt) * 8, hipMemcpyDeviceToHost, st));
   s->queue_open = true; s->queue_K = K; s->queue_stream = stream;
   return PAYNE_OK;
 }
@@ -1378,7 +1355,7 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   // ---- the chains that moved are the queue; a chain that never moved is a copy of a live point
   long long acc = 0, calls = 0, redraw = 0, idle_calls = 0;
   int m = 0;
-  const int *na = s->qi_host, *nc = na + K, *nr = nc + K;
+  const int *na = reinterpret_cast<const int*>(hl + K), *nc = na + K, *nr = nc + K;
   for (int k = 0; k < K; ++k) {
     acc += na[k]; calls += nc[k]; redraw += nr[k];
     if (na[k] > 0) {

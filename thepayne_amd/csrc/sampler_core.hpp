@@ -153,6 +153,9 @@ struct WalkState {
   int K;
   int nd, ncols, adv_on;       // of the sampler (SamplerDev::ndim / ncols / adv_any): the step's first loads need no table read first
   double* spec;                // [K][2][kSpecStride] the next proposal made ahead for both outcomes of the pending one (rwalk_spec_wave); null: none
+  // the queue call (payne_ns_rwalk_queue_begin): the walk's first step also finds the ellipsoid each chain steps in -- one that holds
+  // its start point (a random one of those), else the nearest -- and writes it to ell_out; null: `ell` came from the host
+  const double* as_ctr; const double* as_ainv; int* ell_out; int n_ell;
 };
 // device-resident copy for the post kernel's tail (payne_post_kernel<.., LEAN>: PostArgs::tail)
 struct WalkTail { SamplerDev sd; WalkState w; };
@@ -328,9 +331,43 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   const double val = L.col_src >= 0 ? vs : L.col_val;
   if (lane < L.ncols) rows[(size_t)c * L.ncols + lane] = val;
 }
+// The ellipsoid chain c steps in (the queue call's first step; on the host this loop was 8 us per ellipsoid for 512 chains, on the
+// queue's critical path): d^2 = |Ainv (u - ctr)|^2 per ellipsoid, lane a = row a of the product, the sums in index order and without
+// contraction (the host form of this loop, payne_ns_rwalk_queue_begin before it moved here, rounds the same way); among the
+// ellipsoids that hold the point a reservoir choice on the chain's own hash stream, else the nearest.
+__device__ __forceinline__ int walk_assign_ell(const WalkState& W, int c, int lane) {
+#pragma clang fp contract(off)
+  const int nd = W.nd;
+  const bool act = lane < nd;
+  const int a = act ? lane : 0;
+  const double uc = W.u[(size_t)c * nd + a];
+  unsigned long long r1 = mix64(mix64(W.seed ^ (0xA5A5A5A5ull + (unsigned long long)c * 0x100000001B3ull)));
+  int pick = 0, best = 0, nin = 0;
+  double dbest = INFINITY;
+  for (int e = 0; e < W.n_ell; ++e) {
+    const double* ce = W.as_ctr + (size_t)e * nd;
+    const double* ai = W.as_ainv + (size_t)e * nd * nd;
+    const double diff = uc - ce[a];
+    double y = 0.0;
+    for (int b = 0; b < nd; ++b) y += ai[a * nd + b] * __shfl(diff, b);
+    const double y2 = act ? y * y : 0.0;
+    double d2 = 0.0;
+    for (int b = 0; b < nd; ++b) d2 += __shfl(y2, b);
+    if (d2 < dbest) { dbest = d2; best = e; }
+    if (d2 <= 1.0) {
+      ++nin;
+      r1 = mix64(r1);
+      if (r1 % (unsigned long long)nin == 0) pick = e;
+    }
+  }
+  if (nin == 0) pick = best;
+  if (lane == 0) W.ell_out[c] = pick;
+  return pick;
+}
 __device__ __forceinline__ void rwalk_step_wave(const SamplerDev& sd, const WalkState& W, int c, int lane, double lnl_p, int step,
                                                 int settle, int propose) {
-  const WalkLoads L = walk_loads(sd, W, c, lane);
+  WalkLoads L = walk_loads(sd, W, c, lane);
+  if (!settle && W.as_ctr) L.my_ell = walk_assign_ell(W, c, lane);
   rwalk_step_core(sd, W, L, c, lane, lnl_p, step, settle, propose);
 }
 

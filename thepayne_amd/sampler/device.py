@@ -194,35 +194,66 @@ class DeviceProposer(object):
         assignment, transfers, the walk and the selection of the chains that moved.  ``qbuf`` = (qU[K, nd], qV[K, nd],
         ql[K], qnc[K] int32) host arrays the queue is written to.  Returns (nq, accepted, calls, redrawn, idle_calls).
         ``between``: a callable run on the host while the GPU walks (payne_ns_rwalk_queue_begin .. _end)."""
-        if K > self.k_max:
-            raise ValueError("K > k_max")
+        if between is None:
+            if K > self.k_max:
+                raise ValueError("K > k_max")
+            axp, n_ell, cp, ap, keep = self._queue_bound(axes_unit, ctr, ainv)
+            qU, qV, ql, qnc = qbuf
+            nq = C.c_int(0)
+            stats = self._qstats
+            rc = self.lib.payne_ns_rwalk_queue(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
+                                               len(live_logl), int(K), axp, n_ell, cp, ap, float(scale), float(loglstar),
+                                               int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, qU.ctypes.data, qV.ctypes.data,
+                                               ql.ctypes.data, qnc.ctypes.data, C.byref(nq), stats.ctypes.data, self._stream())
+            if rc != 0:
+                self.eng._err(rc, "payne_ns_rwalk_queue")
+            return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
+        self.rwalk_queue_begin(live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed)
+        try:
+            between()
+        finally:                                  # (the queue in flight is always collected, whatever the host work did)
+            out = self.rwalk_queue_end(qbuf)
+        return out
+
+    def _queue_bound(self, axes_unit, ctr, ainv):
+        """The bound's arrays as the native call takes them; remembered while the caller hands the same objects (a bound lives for
+        several queues, and three ascontiguousarray + six attribute lookups are 10 us between two queues)."""
+        key = (id(axes_unit), id(ctr), id(ainv))
+        if getattr(self, "_qb_key", None) == key:
+            return self._qb
         ax = np.ascontiguousarray(axes_unit, dtype=np.float64)
         n_ell = 1 if ax.ndim == 2 else ax.shape[0]
         cp = ap = None
+        keep = (ax, axes_unit, ctr, ainv)
         if n_ell > 1:
-            ctr = np.ascontiguousarray(ctr, dtype=np.float64)
-            ainv = np.ascontiguousarray(ainv, dtype=np.float64)
-            cp, ap = ctr.ctypes.data, ainv.ctypes.data
+            c2 = np.ascontiguousarray(ctr, dtype=np.float64)
+            a2 = np.ascontiguousarray(ainv, dtype=np.float64)
+            cp, ap, keep = c2.ctypes.data, a2.ctypes.data, keep + (c2, a2)
+        self._qb_key, self._qb = key, (ax.ctypes.data, n_ell, cp, ap, keep)     # (keep: the objects stay alive, so do their ids)
+        return self._qb
+
+    def rwalk_queue_begin(self, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed):
+        """payne_ns_rwalk_queue_begin: everything of one queue enqueued on the stream (nothing of the arguments is read after the
+        call returns); the host is free until rwalk_queue_end."""
+        if K > self.k_max:
+            raise ValueError("K > k_max")
+        axp, n_ell, cp, ap, keep = self._queue_bound(axes_unit, ctr, ainv)
+        rc = self.lib.payne_ns_rwalk_queue_begin(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
+                                                 len(live_logl), int(K), axp, n_ell, cp, ap, float(scale),
+                                                 float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, self._stream())
+        if rc != 0:
+            self.eng._err(rc, "payne_ns_rwalk_queue_begin")
+
+    def rwalk_queue_end(self, qbuf):
+        """payne_ns_rwalk_queue_end: waits for the stream, writes the queue to ``qbuf``; returns (nq, accepted, calls, redrawn,
+        idle_calls)."""
         qU, qV, ql, qnc = qbuf
         nq = C.c_int(0)
         stats = self._qstats
-        if between is None:
-            rc = self.lib.payne_ns_rwalk_queue(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
-                                               len(live_logl), int(K), ax.ctypes.data, n_ell, cp, ap, float(scale), float(loglstar),
-                                               int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, qU.ctypes.data, qV.ctypes.data,
-                                               ql.ctypes.data, qnc.ctypes.data, C.byref(nq), stats.ctypes.data, self._stream())
-        else:
-            rc = self.lib.payne_ns_rwalk_queue_begin(self._handle, live_u.ctypes.data, live_v.ctypes.data, live_logl.ctypes.data,
-                                                     len(live_logl), int(K), ax.ctypes.data, n_ell, cp, ap, float(scale),
-                                                     float(loglstar), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, self._stream())
-            if rc == 0:
-                try:
-                    between()
-                finally:                          # (the queue in flight is always collected, whatever the host work did)
-                    rc = self.lib.payne_ns_rwalk_queue_end(self._handle, qU.ctypes.data, qV.ctypes.data, ql.ctypes.data,
-                                                           qnc.ctypes.data, C.byref(nq), stats.ctypes.data)
+        rc = self.lib.payne_ns_rwalk_queue_end(self._handle, qU.ctypes.data, qV.ctypes.data, ql.ctypes.data, qnc.ctypes.data,
+                                               C.byref(nq), stats.ctypes.data)
         if rc != 0:
-            self.eng._err(rc, "payne_ns_rwalk_queue")
+            self.eng._err(rc, "payne_ns_rwalk_queue_end")
         return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
 
     # the same in three parts (MultiPopProposer interleaves the steps of several populations)

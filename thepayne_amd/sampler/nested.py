@@ -118,7 +118,7 @@ class NestedSampler(object):
     def __init__(self, loglikelihood, prior_transform, ndim, nlive=500, bound='multi', sample='unif',
                  logl_args=None, bootstrap=0, walks=25, slices=5, enlarge=None, rstate=None,
                  batched=False, queue_size=None, update_interval=None, first_update=None, proposer=None,
-                 native=True, live_points=None, loglstar=None, overlap_bound=None, **ignored):
+                 native=True, live_points=None, loglstar=None, overlap_bound=None, pipeline=None, **ignored):
         if sample not in ('unif', 'rwalk', 'slice', 'rslice'):
             raise NotImplementedError("sample=%r: this driver provides 'unif', 'rwalk', 'slice' and 'rslice'" % (sample,))
         if bound not in ('none', 'single', 'multi'):
@@ -185,6 +185,18 @@ class NestedSampler(object):
         # sampling region) never uses it.  Default: on when the proposer can run the walk in two parts.
         self.overlap_bound = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue")) if overlap_bound is None else bool(overlap_bound)
         self._bound_next = None
+        # pipeline: with the whole queue made on the device, the NEXT queue is launched before the current one is consumed, from
+        # the live set and the threshold the consumption will leave (payne_ns_peek: the replacements only, no evidence
+        # arithmetic) -- the GPU walks while the host does the bookkeeping of the queue before, fits the bound and yields the
+        # records.  The queue is the one a launch after the consumption would have made, except for the bound it steps in (one
+        # consumed queue older: the proposal metric only, as under overlap_bound).  A queue launched ahead is dropped when the
+        # consumption ended elsewhere (a stop condition, maxiter).  Default: on when the proposer can run the queue in two parts.
+        self.pipeline = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native) if pipeline is None else bool(pipeline)
+        if self.pipeline and not (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native):
+            raise ValueError("pipeline=True needs sample='rwalk', native bookkeeping and a proposer with rwalk_queue_begin / _end")
+        self._ahead = None                         # the queue in flight: {"it", "lstar"} the consumption must arrive at, its "seed"
+        self._seed_again = None                    # the seed of a queue that was dropped: the queue made in its place takes it
+        self._qbufs = [None, None]
         self._cycle = 0                            # queues filled so far
         self._last_m = 0                           # dead points the last consumed queue gave
         self._m_acc = 0
@@ -253,6 +265,7 @@ class NestedSampler(object):
 
     def _adopt_bound(self, ells, stack, split):
         self._ell_stack = stack
+        self._ax_arg = stack[1] if len(stack[1]) > 1 else stack[1][0]      # (one object per bound: the proposer remembers its address)
         self._ells = ells                  # (an update without a split attempt always follows a single-cloud result)
         e0 = self._ells[0]
         self._ctr, self._axes, self._axes_unit = e0.ctr, e0.axes, e0.axes_unit
@@ -311,19 +324,33 @@ class NestedSampler(object):
         self._last_m, self._m_acc = self._m_acc, 0
         if self.method == 'rwalk' and hasattr(self.proposer, "rwalk_queue"):
             # the whole queue in one native call: start points, ellipsoid assignment, transfers, walk, selection
-            if self._qbuf is None or len(self._qbuf[2]) < K:
-                self._qbuf = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
-            ctr, au, ai = self._ell_stack
-            nq, acc, calls, redrawn, idle = self.proposer.rwalk_queue(
-                self.live_u, self.live_v, self.live_logl, K, au if len(au) > 1 else au[0], ctr, ai, self.scale, lstar,
-                self.walks, int(rng.integers(0, 2 ** 62)), self._qbuf,
-                **({"between": self._prefetch_bound} if self.overlap_bound else {}))
+            # (two host buffers in turn: the queue launched ahead is collected while the one before may still hold proposals)
+            self._qbufs.reverse()
+            if self._qbufs[0] is None or len(self._qbufs[0][2]) < K:
+                self._qbufs[0] = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+            self._qbuf = self._qbufs[0]
+            res = None
+            if self._ahead is not None:                                      # launched before the last queue was consumed
+                ok = self.it == self._ahead["it"] and self.loglstar == self._ahead["lstar"]
+                seed, self._ahead = self._ahead["seed"], None
+                res = self.proposer.rwalk_queue_end(self._qbuf)              # (collected either way: the stream must drain)
+                if not ok:
+                    res, self._seed_again = None, seed
+            if res is None:
+                ctr, au, ai = self._ell_stack
+                res = self.proposer.rwalk_queue(
+                    self.live_u, self.live_v, self.live_logl, K, self._ax_arg, ctr, ai, self.scale, lstar,
+                    self.walks, self._queue_seed(), self._qbuf,
+                    **({"between": self._prefetch_bound} if self.overlap_bound and not self.pipeline else {}))
+            nq, acc, calls, redrawn, idle = res
             self.ncall += calls
             frac = acc / max(1, calls + redrawn)          # a redrawn (out-of-cube) proposal counts as a rejection (dynesty)
             self.scale = min(max(self.scale * math.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)
             self._pending_nc += idle
             qU, qV, ql, qnc = self._qbuf
             self._q_assign(qU[:nq], qV[:nq], ql[:nq], qnc[:nq])
+            if self.pipeline:
+                self._launch_ahead()
             return
         # rwalk / slice: K lock-step chains
         start = rng.integers(0, self.nlive, size=K)
@@ -368,6 +395,44 @@ class NestedSampler(object):
         moved = nacc > 0                                      # a chain that never moved is a copy of a live point
         self._pending_nc += int(ncalls[~moved].sum())
         self._set_queue(U[moved], V[moved], ll[moved], np.maximum(1, ncalls[moved]))
+
+    def _launch_ahead(self):
+        """The next queue, launched from the state the consumption of the current one will leave (payne_ns_peek)."""
+        K, nd, n = self.queue_size, self.ndim, self.nlive
+        if getattr(self, "_peek", None) is None:
+            self._peek = (np.empty((n, nd)), np.empty((n, nd)), np.empty(n))
+        pu, pv, pl = self._peek
+        lstar, m = C.c_double(self.loglstar), C.c_int(0)
+        lu, lv, lll, _ = self._live_addr()
+        aU, aV, al, _ = self._q_addr
+        rc = self._lib.payne_ns_peek(n, nd, lu, lv, lll, aU, aV, al, len(self._ql), pu.ctypes.data, pv.ctypes.data, pl.ctypes.data,
+                                     C.byref(lstar), C.byref(m))
+        if rc != 0:
+            raise RuntimeError("payne_ns_peek failed (%d)" % rc)
+        ctr, au, ai = self._ell_stack
+        seed = self._queue_seed()
+        self.proposer.rwalk_queue_begin(pu, pv, pl, K, self._ax_arg, ctr, ai, self.scale, lstar.value, self.walks, seed)
+        self._ahead = {"it": self.it + m.value, "lstar": lstar.value if m.value else self.loglstar, "seed": seed}
+
+    def _queue_seed(self):
+        """The next queue's seed: from the sampler's stream, or the seed of a queue that was launched ahead and dropped (so that
+        a run with queues launched ahead draws what the serial run draws)."""
+        seed, self._seed_again = self._seed_again, None
+        return int(self.rng.integers(0, 2 ** 62)) if seed is None else seed
+
+    def _drop_ahead(self):
+        """Collect and discard a queue still in flight (the sampling loop ended before it was needed)."""
+        if self._ahead is not None:
+            self._seed_again, self._ahead = self._ahead["seed"], None
+            self._qbufs.reverse()
+            if self._qbufs[0] is None:
+                K, nd = self.queue_size, self.ndim
+                self._qbufs[0] = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+            try:
+                self.proposer.rwalk_queue_end(self._qbufs[0])
+            except Exception:                  # (a proposer closed before an abandoned generator was finalised: nothing to collect)
+                pass
+            self._qbufs.reverse()
 
     def _eval_u(self, U):
         """Unit-cube points -> (V, lnprob), one batch."""
@@ -577,29 +642,32 @@ class NestedSampler(object):
         maxiter = np.inf if maxiter is None else maxiter
         maxcall = np.inf if maxcall is None else maxcall
         niter_here = 0
-        while niter_here < maxiter and self.ncall < maxcall:
-            if self._since_update >= self.update_interval or (self._axes is None and self.bound != 'none'):
-                self._update_bound()      # (queued proposals stay: each is still tested against the current threshold)
-            if self._qpos >= len(self._ql):
-                self._fill_queue()
-            room = min(maxiter - niter_here, self.update_interval - self._since_update)
-            it0 = self.it
-            rec, stop = self._consume(dlogz, max(1, room), logl_max)
-            m = len(rec["logl"])
-            if m:
-                its = np.arange(it0, it0 + m)
-                rec["it0"] = it0
-                rec["bounditer"] = np.full(m, self.nbound, dtype=np.int64)
-                rec["eff"] = 100.0 * its / self.ncall
-                rec["scale"] = np.full(m, self.scale)
-                self.eff = float(rec["eff"][-1])
-                self._since_update += m
-                self._m_acc += m
-                niter_here += m
-                self._chunks.append(rec)
-                yield rec
-            if stop in ('converged', 'logl_max'):
-                break
+        try:
+            while niter_here < maxiter and self.ncall < maxcall:
+                if self._since_update >= self.update_interval or (self._axes is None and self.bound != 'none'):
+                    self._update_bound()      # (queued proposals stay: each is still tested against the current threshold)
+                if self._qpos >= len(self._ql):
+                    self._fill_queue()
+                room = min(maxiter - niter_here, self.update_interval - self._since_update)
+                it0 = self.it
+                rec, stop = self._consume(dlogz, max(1, room), logl_max)
+                m = len(rec["logl"])
+                if m:
+                    its = np.arange(it0, it0 + m)
+                    rec["it0"] = it0
+                    rec["bounditer"] = np.full(m, self.nbound, dtype=np.int64)
+                    rec["eff"] = 100.0 * its / self.ncall
+                    rec["scale"] = np.full(m, self.scale)
+                    self.eff = float(rec["eff"][-1])
+                    self._since_update += m
+                    self._m_acc += m
+                    niter_here += m
+                    self._chunks.append(rec)
+                    yield rec
+                if stop in ('converged', 'logl_max'):
+                    break
+        finally:
+            self._drop_ahead()                 # (a queue launched ahead of a loop that ended: collected, never used)
 
     def sample(self, maxiter=None, maxcall=None, dlogz=0.01, logl_max=np.inf, **ignored):
         """dynesty's generator contract: one 15-tuple per dead point (fitstar.py:337-338)."""

@@ -16,15 +16,17 @@ def wrap(cls, name, key=None):
         finally:
             e = acc[key or name]; e[0] += 1; e[1] += time.perf_counter() - t
     setattr(cls, name, g)
-for n in ("_consume", "_update_bound", "_fit_bound", "_fill_queue", "_prefetch_bound"):
+for n in ("_consume", "_update_bound", "_fit_bound", "_fill_queue", "_prefetch_bound", "_launch_ahead"):
     wrap(nested.NestedSampler, n)
-wrap(device.DeviceProposer, "rwalk_queue")
+for n in ("rwalk_queue", "rwalk_queue_begin", "rwalk_queue_end"):
+    wrap(device.DeviceProposer, n)
 lib_calls = {}
 orig_load = None
-sampler_bench.run("C2", maxcall=60000, modes=("device_chunks",))            # warm-up
+CFG = sys.argv[1] if len(sys.argv) > 1 else "C2"
+sampler_bench.run(CFG, maxcall=60000, modes=("device_chunks",))            # warm-up
 acc.clear()
 t0 = time.perf_counter()
-r = sampler_bench.run("C2", maxcall=700000, modes=("device_chunks",), dlogz=1e-9)["device_chunks"]
+r = sampler_bench.run(CFG, maxcall=700000, modes=("device_chunks",), dlogz=1e-9)["device_chunks"]
 print(r)
 ncyc = acc["_fill_queue"][0]
 print("cycles", ncyc, " seconds in the sampler loop", r["seconds"], " per cycle %.1f us" % (1e6 * r["seconds"] / ncyc))

@@ -59,6 +59,12 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
     for mode in modes:
         proposer = None
         queue = nlive
+        kw = {}
+        if mode.endswith("_serial"):                        # "device_chunks_serial": every queue launched after the one before is consumed
+            kw["pipeline"] = False
+            mode_ = mode[:-len("_serial")]
+        else:
+            mode_ = mode
         if mode.startswith("device2"):                      # two chain populations in flight
             from thepayne_amd.sampler.device import MultiPopProposer
             proposer = MultiPopProposer(L, P, k_max=nlive, n_pop=2)
@@ -68,11 +74,11 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
             proposer = DeviceProposer(L, P, k_max=nlive)
         S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound=bound,
                           sample='rwalk', walks=walks, batched=True, queue_size=queue,
-                          rstate=np.random.default_rng(seed), proposer=proposer)
+                          rstate=np.random.default_rng(seed), proposer=proposer, **kw)
         t0 = time.perf_counter()
         c0 = S.ncall
         nell = 1
-        if mode.endswith("chunks"):
+        if mode_.endswith("chunks"):
             for _ in S.sample_chunks(maxcall=maxcall, dlogz=dlogz):
                 nell = max(nell, len(S._ells))
         else:
