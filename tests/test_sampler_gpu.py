@@ -372,6 +372,36 @@ def test_evidence_agrees_between_scalar_cpu_and_batched_gpu_likelihoods(tmp_path
     assert np.all(np.abs(sg / sc - 1.0) < 0.35), (sg, sc)
 
 
+def test_queue_launched_ahead_on_the_device(tmp_path):
+    """The sampling loop with the next queue launched ahead of the bookkeeping (default with device proposals) against the serial
+    loop: a stop in mid-queue drops the queue in flight and leaves the proposer usable, a second call resumes, and both loops
+    integrate the same evidence (they differ by the age of the bound the chains step in, nothing else)."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    from thepayne_amd.sampler import NestedSampler
+    L, P, _ = _fit_objects(tmp_path, photscale=True)
+    out = []
+    for pipeline in (True, False):
+        prop = _proposer(L, P, k_max=64)
+        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=64, bound='multi', sample='rwalk',
+                          walks=10, batched=True, queue_size=64, rstate=np.random.default_rng(9), proposer=prop, pipeline=pipeline)
+        assert S.pipeline == pipeline
+        n1 = sum(len(r["logl"]) for r in S.sample_chunks(maxiter=150, dlogz=1e-9))
+        assert n1 == 150 and S._ahead is None
+        U = np.random.default_rng(1).uniform(0.3, 0.7, size=(8, L.ndim))
+        V, lp = prop.lnprob_u(U)                                         # the proposer between two calls of the loop
+        assert np.all(np.abs(lp - lnprob_batch(V, L, P)) <= 1e-9 * np.abs(lp) + 1e-9)
+        for _ in S.sample_chunks(dlogz=0.5, maxcall=300000):
+            pass
+        for _ in S.add_live_points():
+            pass
+        r = S.results
+        assert np.all(np.diff(r.logl[:-64]) >= 0) and np.all(np.diff(r.logz) >= -1e-12)
+        out.append((r.logz[-1], r.logzerr[-1], S.ncall))
+        prop.close()
+    (za, ea, _), (zb, eb, _) = out
+    assert abs(za - zb) < 4 * np.hypot(ea, eb) + 0.2, out
+
+
 def test_device_rwalk_with_one_ellipsoid_per_chain(tmp_path):
     """payne_rwalk_begin_ell (bound='multi'): every chain steps in the metric of its own ellipsoid; with a
     single ellipsoid the call is payne_rwalk_begin."""
