@@ -412,6 +412,16 @@ int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u, const dou
                                double loglstar, int walks, unsigned long long seed, void* stream);
 int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats);
 
+/* One turn of a loop that keeps a queue in flight: _end of the queue in flight (-> qu .. stats), the step scale adapted to its
+ * acceptance (*scale in/out: scale * exp((acc / (calls + redrawn) - 0.5) / ndim / 0.5), clamped to [1e-4, 4]), payne_ns_peek of
+ * that queue against the live arrays (*loglstar in: the current threshold; out: the one the queue's consumption will leave;
+ * *n_dead: the dead points it will give), and _begin of the next queue from the predicted state, on the stream of the queue
+ * collected.  The caller consumes the collected queue (payne_ns_consume) while the GPU walks. */
+int payne_ns_rwalk_queue_turn(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats,
+                              const double* live_u, const double* live_v, const double* live_logl, int nlive, int K,
+                              const double* axes_unit, int n_ell, const double* ctr, const double* ainv, double* scale,
+                              double* loglstar, int walks, unsigned long long seed, int* n_dead);
+
 /* How the chain steps of this sampler ran so far: out[0] at the tail of the likelihood-only post kernel (the workgroup of
  * candidate k settles chain k's proposal as soon as it has the likelihood and takes the next one from the two that idle workgroups
  * of the batch's hidden-layer launch made ahead, one per outcome -- or draws it there: PAYNE_V_NO_WALK_SPEC), out[1] as launches of

@@ -375,16 +375,18 @@ def test_evidence_agrees_between_scalar_cpu_and_batched_gpu_likelihoods(tmp_path
 def test_queue_launched_ahead_on_the_device(tmp_path):
     """The sampling loop with the next queue launched ahead of the bookkeeping (default with device proposals) against the serial
     loop: a stop in mid-queue drops the queue in flight and leaves the proposer usable, a second call resumes, and both loops
-    integrate the same evidence (they differ by the age of the bound the chains step in, nothing else)."""
+    integrate the same evidence (they differ by the age of the bound the chains step in, nothing else).  One native call per turn
+    (payne_ns_rwalk_queue_turn) or its four parts called from Python: the same run to the bit."""
     from thepayne_amd.fitting.fitstar import lnprob_batch
     from thepayne_amd.sampler import NestedSampler
     L, P, _ = _fit_objects(tmp_path, photscale=True)
     out = []
-    for pipeline in (True, False):
+    for pipeline, turn in ((True, True), (True, False), (False, False)):
         prop = _proposer(L, P, k_max=64)
         S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=64, bound='multi', sample='rwalk',
                           walks=10, batched=True, queue_size=64, rstate=np.random.default_rng(9), proposer=prop, pipeline=pipeline)
-        assert S.pipeline == pipeline
+        assert S.pipeline == pipeline and S._use_turn == pipeline
+        S._use_turn = turn
         n1 = sum(len(r["logl"]) for r in S.sample_chunks(maxiter=150, dlogz=1e-9))
         assert n1 == 150 and S._ahead is None
         U = np.random.default_rng(1).uniform(0.3, 0.7, size=(8, L.ndim))
@@ -396,10 +398,11 @@ def test_queue_launched_ahead_on_the_device(tmp_path):
             pass
         r = S.results
         assert np.all(np.diff(r.logl[:-64]) >= 0) and np.all(np.diff(r.logz) >= -1e-12)
-        out.append((r.logz[-1], r.logzerr[-1], S.ncall))
+        out.append((r, S.ncall, S.scale))
         prop.close()
-    (za, ea, _), (zb, eb, _) = out
-    assert abs(za - zb) < 4 * np.hypot(ea, eb) + 0.2, out
+    (ra, na, sa), (rb, nb, sb), (rc, _, _) = out
+    assert na == nb and sa == sb and np.array_equal(ra.logz, rb.logz) and np.array_equal(ra.samples_u, rb.samples_u)
+    assert abs(ra.logz[-1] - rc.logz[-1]) < 4 * np.hypot(ra.logzerr[-1], rc.logzerr[-1]) + 0.2
 
 
 def test_device_rwalk_with_one_ellipsoid_per_chain(tmp_path):

@@ -1067,6 +1067,7 @@ struct payne_sampler {
   double* spec = nullptr;                 // [k_max][2][kSpecStride] the next step's proposals made ahead (null: more dimensions / columns than a record holds)
   // staging of payne_ns_rwalk_queue: chains (u | v | lnprob) and counters (nacc | ncall | nredraw), device + pinned host
   double *q_dev = nullptr, *q_host = nullptr;
+  std::vector<double> pk_u, pk_v, pk_l;   // payne_ns_rwalk_queue_turn: the live set its peek predicts (start points of the queue it launches)
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
   WalkState walk{};                       // the walk in progress
   bool queue_open = false; int queue_K = 0; void* queue_stream = nullptr;   // payne_ns_rwalk_queue_begin .. _end
@@ -1372,6 +1373,34 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   *nq = m;
   stats[0] = acc; stats[1] = calls; stats[2] = redraw; stats[3] = idle_calls;
   return PAYNE_OK;
+}
+// One turn of the sampler's pipelined loop in ONE call: collect the queue in flight (_end), adapt the step scale to its acceptance
+// (dynesty's rule, as thepayne_amd/sampler/nested.py applies it), predict the live set and threshold its consumption will leave
+// (payne_ns_peek) and launch the next queue from there (_begin) -- between a queue's last transfer and the next one's first
+// kernel the GPU idles, and every microsecond of interpreter there is one of those.
+extern "C" int payne_ns_rwalk_queue_turn(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats,
+                                         const double* live_u, const double* live_v, const double* live_logl, int nlive, int K,
+                                         const double* axes_unit, int n_ell, const double* ctr, const double* ainv, double* scale,
+                                         double* loglstar, int walks, unsigned long long seed, int* n_dead) {
+  if (!s) return PAYNE_E_INVALID;
+  if (!scale || !loglstar || !n_dead || !live_u || !live_v || !live_logl || nlive <= 0) return fail(s->ctx, PAYNE_E_INVALID, "bad payne_ns_rwalk_queue_turn arguments");
+  void* stream = s->queue_stream;
+  int rc = payne_ns_rwalk_queue_end(s, qu, qv, ql, qnc, nq, stats);
+  if (rc) return rc;
+  const int nd = s->sd.ndim;
+  {
+    const long long denom = stats[1] + stats[2] > 1 ? stats[1] + stats[2] : 1;
+    const double frac = (double)stats[0] / (double)denom;          // a redrawn (out-of-cube) proposal counts as a rejection
+    double sc = *scale * exp((frac - 0.5) / nd / 0.5);
+    sc = sc > 1e-4 ? sc : 1e-4;
+    *scale = sc < 4.0 ? sc : 4.0;
+  }
+  s->pk_u.resize((size_t)nlive * nd); s->pk_v.resize((size_t)nlive * nd); s->pk_l.resize((size_t)nlive);
+  if ((rc = payne_ns_peek(nlive, nd, live_u, live_v, live_logl, qu, qv, ql, *nq, s->pk_u.data(), s->pk_v.data(), s->pk_l.data(),
+                          loglstar, n_dead)))
+    return fail(s->ctx, rc, "payne_ns_peek");
+  return payne_ns_rwalk_queue_begin(s, s->pk_u.data(), s->pk_v.data(), s->pk_l.data(), nlive, K, axes_unit, n_ell, ctr, ainv, *scale,
+                                    *loglstar, walks, seed, stream);
 }
 extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
                                     int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,

@@ -256,6 +256,25 @@ class DeviceProposer(object):
             self.eng._err(rc, "payne_ns_rwalk_queue_end")
         return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
 
+    def rwalk_queue_turn(self, qbuf, live_u, live_v, live_logl, K, axes_unit, ctr, ainv, scale, loglstar, walks, seed):
+        """payne_ns_rwalk_queue_turn: collect the queue in flight into ``qbuf``, adapt the scale, predict the state its consumption
+        will leave and launch the next queue from there -- one native call between two queues.  Returns (nq, accepted, calls,
+        redrawn, idle_calls, scale, loglstar_after, n_dead)."""
+        if K > self.k_max:
+            raise ValueError("K > k_max")
+        axp, n_ell, cp, ap, keep = self._queue_bound(axes_unit, ctr, ainv)
+        qU, qV, ql, qnc = qbuf
+        nq, m = C.c_int(0), C.c_int(0)
+        sc, ls = C.c_double(scale), C.c_double(loglstar)
+        stats = self._qstats
+        rc = self.lib.payne_ns_rwalk_queue_turn(self._handle, qU.ctypes.data, qV.ctypes.data, ql.ctypes.data, qnc.ctypes.data,
+                                                C.byref(nq), stats.ctypes.data, live_u.ctypes.data, live_v.ctypes.data,
+                                                live_logl.ctypes.data, len(live_logl), int(K), axp, n_ell, cp, ap, C.byref(sc),
+                                                C.byref(ls), int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(m))
+        if rc != 0:
+            self.eng._err(rc, "payne_ns_rwalk_queue_turn")
+        return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]), sc.value, ls.value, m.value
+
     # the same in three parts (MultiPopProposer interleaves the steps of several populations)
     def rwalk_begin(self, U, V, lnprob, axes, scale, loglstar, walks, seed, stream=None, ell=None):
         K, nd = len(U), self.ndim

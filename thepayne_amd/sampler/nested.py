@@ -194,6 +194,7 @@ class NestedSampler(object):
         self.pipeline = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native) if pipeline is None else bool(pipeline)
         if self.pipeline and not (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native):
             raise ValueError("pipeline=True needs sample='rwalk', native bookkeeping and a proposer with rwalk_queue_begin / _end")
+        self._use_turn = self.pipeline and hasattr(proposer, "rwalk_queue_turn")    # (end + scale + peek + begin as one native call)
         self._ahead = None                         # the queue in flight: {"it", "lstar"} the consumption must arrive at, its "seed"
         self._seed_again = None                    # the seed of a queue that was dropped: the queue made in its place takes it
         self._qbufs = [None, None]
@@ -333,6 +334,19 @@ class NestedSampler(object):
             if self._ahead is not None:                                      # launched before the last queue was consumed
                 ok = self.it == self._ahead["it"] and self.loglstar == self._ahead["lstar"]
                 seed, self._ahead = self._ahead["seed"], None
+                if ok and self._use_turn:
+                    # collected, and the next one launched from the state ITS consumption will leave, in one native call
+                    seed = self._queue_seed()
+                    ctr, au, ai = self._ell_stack
+                    nq, acc, calls, redrawn, idle, self.scale, lnext, m = self.proposer.rwalk_queue_turn(
+                        self._qbuf, self.live_u, self.live_v, self.live_logl, K, self._ax_arg, ctr, ai, self.scale, lstar,
+                        self.walks, seed)
+                    self.ncall += calls
+                    self._pending_nc += idle
+                    qU, qV, ql, qnc = self._qbuf
+                    self._q_assign(qU[:nq], qV[:nq], ql[:nq], qnc[:nq])
+                    self._ahead = {"it": self.it + m, "lstar": lnext if m else self.loglstar, "seed": seed}
+                    return
                 res = self.proposer.rwalk_queue_end(self._qbuf)              # (collected either way: the stream must drain)
                 if not ok:
                     res, self._seed_again = None, seed
