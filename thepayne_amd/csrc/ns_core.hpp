@@ -146,22 +146,18 @@ extern "C" int payne_ns_consume(payne_ns_state* s, double* live_u, double* live_
 }
 
 // What the live set and the threshold WILL be once payne_ns_consume has walked the whole queue (no stop condition but the
-// queue's end): the replacements only -- same heap order, same test -- into copies of the live arrays; no evidence arithmetic,
-// no records.  The batched sampler launches its next queue of proposals from this state before it consumes the current one,
-// so that the GPU walks while the host does the bookkeeping (thepayne_amd/sampler/nested.py: pipeline).
-extern "C" int payne_ns_peek(int nlive, int ndim, const double* live_u, const double* live_v, const double* live_logl,
-                             const double* qu, const double* qv, const double* ql, int nq, double* out_u, double* out_v,
-                             double* out_logl, double* loglstar, int* n_dead) {
-  if (nlive <= 0 || ndim <= 0 || nq < 0 || !live_u || !live_v || !live_logl || !out_u || !out_v || !out_logl || !loglstar || !n_dead)
-    return PAYNE_E_INVALID;
-  if (nq > 0 && (!qu || !qv || !ql)) return PAYNE_E_INVALID;
-  const int n = nlive, nd = ndim;
-  std::memcpy(out_u, live_u, (size_t)n * nd * 8);
-  std::memcpy(out_v, live_v, (size_t)n * nd * 8);
-  std::memcpy(out_logl, live_logl, (size_t)n * 8);
-  std::vector<int> heap(n);
+// queue's end): the replacements only -- same heap order, same test; no evidence arithmetic, no records.  The batched sampler
+// launches its next queue of proposals from this state before it consumes the current one, so that the GPU walks while the host
+// does the bookkeeping (thepayne_amd/sampler/nested.py: pipeline).
+namespace payne_ns {
+// By index: src[i] = the queue row that will sit in live slot i, or -1 (the live point stays); lg[i] its lnprob.
+inline void peek_index(int n, const double* live_logl, const double* ql, int nq, std::vector<int>& src, std::vector<double>& lg,
+                       std::vector<int>& heap, double* loglstar, int* n_dead) {
+  src.assign(n, -1);
+  lg.assign(live_logl, live_logl + n);
+  heap.resize(n);
   for (int i = 0; i < n; ++i) heap[i] = i;
-  auto less = [&](int a, int b) { const double la = out_logl[a], lb = out_logl[b]; return la < lb || (la == lb && a < b); };
+  auto less = [&](int a, int b) { const double la = lg[a], lb = lg[b]; return la < lb || (la == lb && a < b); };
   auto sift = [&](int pos) {
     const int v = heap[pos];
     while (true) {
@@ -178,18 +174,36 @@ extern "C" int payne_ns_peek(int nlive, int ndim, const double* live_u, const do
   int qpos = 0, m = 0;
   while (true) {
     const int worst = heap[0];
-    const double lmin = out_logl[worst];
+    const double lmin = lg[worst];
     while (qpos < nq && !(ql[qpos] > lmin)) ++qpos;
     if (qpos >= nq) break;
     *loglstar = lmin;
-    std::memcpy(out_u + (size_t)worst * nd, qu + (size_t)qpos * nd, (size_t)nd * 8);
-    std::memcpy(out_v + (size_t)worst * nd, qv + (size_t)qpos * nd, (size_t)nd * 8);
-    out_logl[worst] = ql[qpos];
+    src[worst] = qpos;
+    lg[worst] = ql[qpos];
     sift(0);
     ++qpos;
     ++m;
   }
   *n_dead = m;
+}
+}  // namespace payne_ns
+
+extern "C" int payne_ns_peek(int nlive, int ndim, const double* live_u, const double* live_v, const double* live_logl,
+                             const double* qu, const double* qv, const double* ql, int nq, double* out_u, double* out_v,
+                             double* out_logl, double* loglstar, int* n_dead) {
+  if (nlive <= 0 || ndim <= 0 || nq < 0 || !live_u || !live_v || !live_logl || !out_u || !out_v || !out_logl || !loglstar || !n_dead)
+    return PAYNE_E_INVALID;
+  if (nq > 0 && (!qu || !qv || !ql)) return PAYNE_E_INVALID;
+  const int n = nlive, nd = ndim;
+  std::vector<int> src, heap;
+  std::vector<double> lg;
+  payne_ns::peek_index(n, live_logl, ql, nq, src, lg, heap, loglstar, n_dead);
+  for (int i = 0; i < n; ++i) {
+    const bool q = src[i] >= 0;
+    std::memcpy(out_u + (size_t)i * nd, q ? qu + (size_t)src[i] * nd : live_u + (size_t)i * nd, (size_t)nd * 8);
+    std::memcpy(out_v + (size_t)i * nd, q ? qv + (size_t)src[i] * nd : live_v + (size_t)i * nd, (size_t)nd * 8);
+    out_logl[i] = lg[i];
+  }
   return PAYNE_OK;
 }
 

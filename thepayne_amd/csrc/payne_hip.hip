@@ -1067,7 +1067,8 @@ struct payne_sampler {
   double* spec = nullptr;                 // [k_max][2][kSpecStride] the next step's proposals made ahead (null: more dimensions / columns than a record holds)
   // staging of payne_ns_rwalk_queue: chains (u | v | lnprob) and counters (nacc | ncall | nredraw), device + pinned host
   double *q_dev = nullptr, *q_host = nullptr;
-  std::vector<double> pk_u, pk_v, pk_l;   // payne_ns_rwalk_queue_turn: the live set its peek predicts (start points of the queue it launches)
+  std::vector<int> pk_src, pk_heap;       // payne_ns_rwalk_queue_turn: the live set its peek predicts, by index (payne_ns::peek_index)
+  std::vector<double> pk_l;
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
   WalkState walk{};                       // the walk in progress
   bool queue_open = false; int queue_K = 0; void* queue_stream = nullptr;   // payne_ns_rwalk_queue_begin .. _end
@@ -1286,9 +1287,22 @@ extern "C" int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double*
 // In two parts, so that the caller's host work (the next bound, bookkeeping of another fit) can run while the GPU walks:
 // _begin returns once everything is enqueued (start points, ellipsoid assignment, upload, walks + 1 steps, download requests),
 // _end waits for the stream and selects the chains that moved.  payne_ns_rwalk_queue is the two back to back.
+// `src` (payne_ns_rwalk_queue_turn): live slot i holds row src[i] of (qu, qv) with lnprob lg[i] when src[i] >= 0 -- the live set a
+// queue's consumption will leave, by index (payne_ns::peek_index), never copied
+static int queue_begin_core(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
+                            int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                            double scale, double loglstar, int walks, unsigned long long seed, void* stream,
+                            const int* src, const double* qu, const double* qv, const double* lg);
 extern "C" int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
                                           int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
                                           double scale, double loglstar, int walks, unsigned long long seed, void* stream) {
+  return queue_begin_core(s, live_u, live_v, live_logl, nlive, K, axes_unit, n_ell, ctr, ainv, scale, loglstar, walks, seed, stream,
+                          nullptr, nullptr, nullptr, nullptr);
+}
+static int queue_begin_core(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
+                            int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                            double scale, double loglstar, int walks, unsigned long long seed, void* stream,
+                            const int* src, const double* qu, const double* qv, const double* lg) {
   int rc = sampler_check(s, live_u, K, live_v);
   if (rc) return rc;
   payne_ctx* c = s->ctx;
@@ -1311,9 +1325,10 @@ extern "C" int payne_ns_rwalk_queue_begin(payne_sampler* s, const double* live_u
   for (int k = 0; k < K; ++k) {
     const unsigned long long r0 = mix(seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull));
     const int i = (int)(r0 % (unsigned long long)nlive);
-    std::memcpy(hu + (size_t)k * nd, live_u + (size_t)i * nd, (size_t)nd * 8);
-    std::memcpy(hv + (size_t)k * nd, live_v + (size_t)i * nd, (size_t)nd * 8);
-    hl[k] = live_logl[i];
+    const bool q = src && src[i] >= 0;
+    std::memcpy(hu + (size_t)k * nd, q ? qu + (size_t)src[i] * nd : live_u + (size_t)i * nd, (size_t)nd * 8);
+    std::memcpy(hv + (size_t)k * nd, q ? qv + (size_t)src[i] * nd : live_v + (size_t)i * nd, (size_t)nd * 8);
+    hl[k] = src ? lg[i] : live_logl[i];
   }
   // one transfer each way: chains, axes and (several ellipsoids) centres and inverse axes up; chains, then the three counters down
   const size_t nq_d = (size_t)K * (2 * nd + 1), n_cnt = ((size_t)3 * K + 1) / 2, n_ax = (size_t)n_ell * nd * nd;
@@ -1395,12 +1410,9 @@ extern "C" int payne_ns_rwalk_queue_turn(payne_sampler* s, double* qu, double* q
     sc = sc > 1e-4 ? sc : 1e-4;
     *scale = sc < 4.0 ? sc : 4.0;
   }
-  s->pk_u.resize((size_t)nlive * nd); s->pk_v.resize((size_t)nlive * nd); s->pk_l.resize((size_t)nlive);
-  if ((rc = payne_ns_peek(nlive, nd, live_u, live_v, live_logl, qu, qv, ql, *nq, s->pk_u.data(), s->pk_v.data(), s->pk_l.data(),
-                          loglstar, n_dead)))
-    return fail(s->ctx, rc, "payne_ns_peek");
-  return payne_ns_rwalk_queue_begin(s, s->pk_u.data(), s->pk_v.data(), s->pk_l.data(), nlive, K, axes_unit, n_ell, ctr, ainv, *scale,
-                                    *loglstar, walks, seed, stream);
+  payne_ns::peek_index(nlive, live_logl, ql, *nq, s->pk_src, s->pk_l, s->pk_heap, loglstar, n_dead);
+  return queue_begin_core(s, live_u, live_v, live_logl, nlive, K, axes_unit, n_ell, ctr, ainv, *scale, *loglstar, walks, seed, stream,
+                          s->pk_src.data(), qu, qv, s->pk_l.data());
 }
 extern "C" int payne_ns_rwalk_queue(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
                                     int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
