@@ -140,11 +140,13 @@ inline int build_model_tables(const double* wave, int npix, HostTables& H) {
     for (int P = 1; P < M; P *= plan_radix(M, P)) {
       const int R = plan_radix(M, P);
       if (P == 1) continue;
-      for (int r = 1; r < R; ++r)
+      for (int j = 0; j < plan_tw_rows(R); ++j) {            // the powers that are read: 1, 2, 4 (radix 8) or 1 (post_core.hpp, plan)
+        const int r = 1 << j;
         for (int k = 0; k < P; ++k) {
           const double a = 2.0 * kPi * (double)k * (double)r / ((double)P * (double)R);
           H.twf.push_back({(float)std::cos(a), (float)(-std::sin(a))});
         }
+      }
     }
     for (int k = 0; k < M / 2; ++k) {
       const double a = 2.0 * kPi * (double)k / (double)(2 * M);

@@ -500,18 +500,22 @@ PAYNE_HD void fft4_s2_pass(int tid, int nthr, LP X, LP Y, GP gdst, int B, int p,
   }
 }
 // Compile-time geometry ("plan") of an M-point FFT on kPostThreads threads.
-// Its twiddles are stored PASS-ORDERED: for every pass with sub-length P > 1 and radix R,
-// (R-1)*P entries  twf[off(P) + (r-1)*P + k] = exp(-2 pi i k r/(P R))  -- the lanes of a wave
-// read consecutive k, so the LDS reads are conflict-free (a plain full-circle table is read
-// with stride 2M/(P R): 8- to 16-way bank conflicts) -- followed by the M/2 factors
-// exp(-2 pi i k/2M) of the real-FFT split.
+// Its twiddles are stored PASS-ORDERED: for every pass with sub-length P > 1 and radix R, the powers w^r = exp(-2 pi i k r/(P R))
+// that are READ -- r = 1, 2, 4 for radix 8 (w^3 = w w^2, w^5 = w w^4, w^6 = w^2 w^4, w^7 = w^3 w^4 are products: one or two more
+// roundings, four packed multiplies a butterfly), r = 1 for radix 4 (w^2 = w w, w^3 = w^2 w) and radix 2 --
+// twf[off(P) + j P + k], j = 0 .. plan_tw_rows(R) - 1  -- the lanes of a wave read consecutive k, so the LDS reads are
+// conflict-free (a plain full-circle table is read with stride 2M/(P R): 8- to 16-way bank conflicts) -- followed by the M/2
+// factors exp(-2 pi i k/2M) of the real-FFT split.  (All R - 1 powers stored: 24.5 KB at 2048 points, which every workgroup
+// pulls from L2 at its start -- with the row, 82 KB per CU at ~22 B/clk --, and 15 instead of 11 LDS reads per radix-8 butterfly;
+// 14 KB this way.)
 // radix: 8 while that still gives every thread a butterfly (M/8 >= threads), else 4, else 2
 constexpr int plan_radix(int M, int P) {
   return (M / P >= 8 && M / 8 >= kFftThreads) ? 8 : ((M / P >= 4) ? 4 : 2);
 }
+constexpr int plan_tw_rows(int R) { return R == 8 ? 3 : 1; }
 constexpr int plan_offset(int M, int P) {
   int off = 0, p = 1;
-  while (p < P) { const int r = plan_radix(M, p); if (p > 1) off += (r - 1) * p; p *= r; }
+  while (p < P) { const int r = plan_radix(M, p); if (p > 1) off += plan_tw_rows(r) * p; p *= r; }
   return off;
 }
 constexpr int plan_total(int M) { return plan_offset(M, M); }
@@ -594,8 +598,13 @@ PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign, boo
     for (int r = 0; r < R; ++r) u[r] = ldc1(src, ib + fft_lay<PI, RI>(r * NB));
     if (P > 1) {
       c32 w[R];
-#pragma unroll
-      for (int r = 1; r < R; ++r) w[r] = ldc1(twf, OFF + (r - 1) * P + k);
+      w[1] = ldc1(twf, OFF + k);
+      if constexpr (R == 8) {
+        w[2] = ldc1(twf, OFF + P + k); w[4] = ldc1(twf, OFF + 2 * P + k);
+        w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+      } else if constexpr (R == 4) {
+        w[2] = cmul(w[1], w[1]); w[3] = cmul(w[2], w[1]);
+      }
       twiddle_all<R>(u, w);
     }
     dftR<R>(u);
