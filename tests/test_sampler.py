@@ -233,6 +233,63 @@ def test_peek_predicts_the_consumed_state():
             assert ls.value == -1e300 and case in (0, 2)
 
 
+def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
+    """payne_ns_peek / payne_ns_consume / payne_ns_bound (csrc/ns_core.hpp: host code) built with g++ -fsanitize=address,undefined and
+    run on random queues with ties, -inf values and an empty queue: the peek's live set equals the consumed one."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    main = tmp_path / "main.cpp"
+    main.write_text(r'''
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "thepayne_amd/csrc/ns_core.hpp"
+int main() {
+  const int n = 37, nd = 3;
+  int bad = 0;
+  for (int rep = 0; rep < 40; ++rep) {
+    srand(rep);
+    const int nq = rep == 0 ? 0 : 1 + rand() % 90;
+    std::vector<double> lu(n * nd), lv(n * nd), ll(n), qu(nq * nd + 1), qv(nq * nd + 1), ql(nq + 1);
+    std::vector<int> qnc(nq + 1, 1), lit(n, 0);
+    for (auto& x : lu) x = rand() / (double)RAND_MAX;
+    for (auto& x : lv) x = rand() / (double)RAND_MAX;
+    for (auto& x : ll) x = std::round(10.0 * rand() / RAND_MAX) / 5.0;
+    ll[0] = ll[5] = -INFINITY;
+    for (auto& x : qu) x = rand() / (double)RAND_MAX;
+    for (auto& x : qv) x = rand() / (double)RAND_MAX;
+    for (auto& x : ql) x = std::round(10.0 * rand() / RAND_MAX) / 5.0 + 0.2;
+    std::vector<double> ou(n * nd), ov(n * nd), ol(n);
+    double ls = -1e300; int m = -1;
+    if (payne_ns_peek(n, nd, lu.data(), lv.data(), ll.data(), qu.data(), qv.data(), ql.data(), nq, ou.data(), ov.data(), ol.data(), &ls, &m)) return 2;
+    payne_ns_state st{n, nd, 1, 0, -1e300, 0.0, 0.0, 0.0, -1e300};
+    const int cap = nq + 1;
+    std::vector<int> wi(cap), nc(cap), wit(cap);
+    std::vector<double> du(cap * nd), dv(cap * nd), c0(cap), c1(cap), c2(cap), c3(cap), c4(cap), c5(cap), c6(cap);
+    payne_ns_dead dead{wi.data(), du.data(), dv.data(), c0.data(), c1.data(), c2.data(), c3.data(), c4.data(), c5.data(), nc.data(), wit.data(), c6.data()};
+    int used = 0, stop = 0;
+    const int e = payne_ns_consume(&st, lu.data(), lv.data(), ll.data(), lit.data(), qu.data(), qv.data(), ql.data(), qnc.data(), nq, 0.0,
+                                   1LL << 40, INFINITY, &dead, cap, &used, &stop);
+    if (e != m) ++bad;
+    for (int i = 0; i < n * nd; ++i) if (ou[i] != lu[i] || ov[i] != lv[i]) ++bad;
+    for (int i = 0; i < n; ++i) if (ol[i] != ll[i]) ++bad;
+    if (m > 0 && ls != st.loglstar) ++bad;
+  }
+  std::vector<double> u(64 * 3), ctr(4 * 3), ax(4 * 9), au(4 * 9), ai(4 * 9), lv(4);
+  for (auto& x : u) x = rand() / (double)RAND_MAX;
+  int ne = 0;
+  if (payne_ns_bound(u.data(), 64, 3, 1.25, 1, 4, ctr.data(), ax.data(), au.data(), ai.data(), lv.data(), &ne) || ne < 1) return 3;
+  std::printf("bad=%d\\n", bad);
+  return bad != 0;
+}''')
+    exe = tmp_path / "ns_san"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", root,
+                    "-I", os.path.join(root, "include"), str(main), "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0 and "bad=0" in res.stdout, (res.stdout, res.stderr[-2000:])
+
+
 def test_fitpayne_bulk_rows_equal_single_rows(tmp_path):
     import io
     from thepayne_amd.fitting.fitstar import FitPayne
