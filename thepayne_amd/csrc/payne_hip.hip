@@ -655,8 +655,10 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   pa.n_spec = pa.spec_walk ? (spec_K + kSpecChainsPerWg - 1) / kSpecChainsPerWg : 0;
   int n_sed = 0;
   if (pa.sed_mags) {
-    // candidates per photometric tile: as few as keeps F x blocks within the compute units the GEMM tiles leave idle (16..48)
-    const int idle = n_cu - pa.n_gemm - pa.n_prep, nblk = idle >= pa.P.F ? idle / pa.P.F : 1;
+    // candidates per photometric tile: as few as keeps F x blocks within the workgroup slots the GEMM tiles, the record writers
+    // and the proposals made ahead leave free -- TWO per CU (the launch's 79.9 KB of LDS): 16-candidate tiles at C3 (224 of them,
+    // hidden launch 10.2 -> 9.4 us; a tile's time is mostly its fixed cost, 32-candidate tiles on one slot per CU measured 10.6)
+    const int idle = 2 * n_cu - pa.n_gemm - pa.n_prep - pa.n_spec, nblk = idle >= pa.P.F ? idle / pa.P.F : 1;
     int cb = ((p.B + nblk - 1) / nblk + 15) & ~15;
     cb = cb < 16 ? 16 : (cb > kSedCandsMax ? kSedCandsMax : cb);
     pa.sed_cb = cb;
