@@ -7,6 +7,7 @@
 //     no launch of its own (C3: 9.1 us as a launch between the dense kernels and the post kernel).
 // Arithmetic: fp64 on fp32 weights, as numpy promotes them (photANN.py:125-131).
 #pragma once
+#include <type_traits>
 
 struct PhotTables {
   int F, H;
@@ -181,8 +182,15 @@ __device__ inline void sed_tile(const PhotTables& P, const double* __restrict__ 
   const int c = c0 + rt;
   const bool rowt = rt < kSedCandsMax && wave < 2, live = rt < cb && c < B;
   const double* rowp = theta + (size_t)(live ? c : (c0 < B ? c0 : B - 1)) * ld;
+  // (wave 1's terms -- a log10 or two a row -- are worked out HERE, while the weight tile is still on its way: behind the
+  //  operands' barrier they sat in front of the first layer's own barrier, 2 700 of that layer's 5 500 cycles)
   double xs[6], av = 0.0; bool hi = false;
-  if (rowt) sed_row_labels(P, rowp, off, xs, av, hi);
+  double mt1 = 0.0, mt2 = 0.0;
+  if (rowt && wave == 0) sed_row_labels(P, rowp, off, xs, av, hi);
+  if (rowt && wave == 1) {
+    const SedRow s = sed_row(P, rowp, 1, off, photscale);
+    sed_mag_terms(s, mt1, mt2);
+  }
   SED_STAMP(1);
   // ---- commit to LDS
   if (rowt && wave == 0) {
@@ -199,14 +207,9 @@ __device__ inline void sed_tile(const PhotTables& P, const double* __restrict__ 
   for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q; if (i < 6 * H) { const int h = i / 6, d = i - 6 * h; W1[d * kSedPitchW + h] = w1reg[q]; } }
   if (tid < 2 * kSedMaxH) W1[(6 + tid / kSedMaxH) * kSedPitchW + (tid % kSedMaxH)] = 0.f;
   if (tid < 3 * kSedMaxH) Bv[tid] = vreg;
+  if (rowt && wave == 1) { Mt[2 * rt] = mt1; Mt[2 * rt + 1] = mt2; }
   __syncthreads();
   SED_STAMP(3);
-  if (rowt && wave == 1) {                                                  // (behind the barrier: off the first layer's path)
-    const SedRow s = sed_row(P, rowp, 1, off, photscale);
-    double a1, a2;
-    sed_mag_terms(s, a1, a2);
-    Mt[2 * rt] = a1; Mt[2 * rt + 1] = a2;
-  }
   const int mt_n = (cb + 15) >> 4, nt_n = H >> 4;                           // row tiles (<= 3), column tiles (<= 4)
   const int li = lane & 15, lk = lane >> 4;
   // one layer: X[.][0..K) -> sigmoid(X W + b) back into X[.][0..H); every wave reads all of X before anyone writes.
@@ -214,53 +217,58 @@ __device__ inline void sed_tile(const PhotTables& P, const double* __restrict__ 
   // from LDS before the first matrix instruction (K/4 <= 16 steps: 64 doubles a lane).
   const bool on = wave < nt_n;
   const int nt = on ? wave : 0;
-  auto layer = [&](const float* Wl, int K, const float* bias) {
-    sed_d4 acc[3];
+  // (MT = the tile's row tiles, a compile-time copy per count: a 16-candidate tile reads a third of the fragments and runs four
+  //  sigmoid chains a lane instead of twelve -- as one body sized for 48 candidates every tile paid for three)
+  auto layer = [&](auto mtc, const float* Wl, int K, const float* bias) {
+    constexpr int MT = decltype(mtc)::value;
+    sed_d4 acc[MT];
     const double bz = (double)bias[16 * nt + li];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) acc[mt] = (sed_d4){bz, bz, bz, bz};
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (sed_d4){bz, bz, bz, bz};
     if (on) {
       constexpr int KS = kSedMaxH / 4;
-      float bfr[KS]; double afr[3][KS];
+      float bfr[KS]; double afr[MT][KS];
       const int ks_n = K >> 2;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int k0 = 4 * (ks < ks_n ? ks : 0);
         bfr[ks] = Wl[(k0 + lk) * kSedPitchW + 16 * nt + li];
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) afr[mt][ks] = X[(16 * (mt < mt_n ? mt : 0) + li) * kSedPitchA + k0 + lk];
+        for (int mt = 0; mt < MT; ++mt) afr[mt][ks] = X[(16 * mt + li) * kSedPitchA + k0 + lk];
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks < ks_n) {
           const double bfrag = (double)bfr[ks];
 #pragma unroll
-          for (int mt = 0; mt < 3; ++mt)
-            if (mt < mt_n) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[mt][ks], bfrag, acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[mt][ks], bfrag, acc[mt], 0, 0, 0);
         }
       }
     }
     __syncthreads();
     if (on) {
-      double y[12];
+      double y[4 * MT];
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) y[4 * mt + v] = acc[mt][v];
-      sed_sigmoid_n<12>(y);                                                 // twelve chains side by side
+      sed_sigmoid_n<4 * MT>(y);                                             // 4 MT chains side by side
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt) {
-        if (mt < mt_n) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) X[(16 * mt + lk + 4 * v) * kSedPitchA + 16 * nt + li] = y[4 * mt + v];
-        }
+        for (int v = 0; v < 4; ++v) X[(16 * mt + lk + 4 * v) * kSedPitchA + 16 * nt + li] = y[4 * mt + v];
       }
     }
     __syncthreads();
   };
-  layer(W1, 8, Bv);                                                         // photANN.py:127
-  SED_STAMP(4);
-  layer(W2, H, Bv + kSedMaxH);                                              // :128
+  auto layers = [&](auto mtc) {
+    layer(mtc, W1, 8, Bv);                                                  // photANN.py:127
+    SED_STAMP(4);
+    layer(mtc, W2, H, Bv + kSedMaxH);                                       // :128
+  };
+  if (mt_n == 1) layers(std::integral_constant<int, 1>{});
+  else if (mt_n == 2) layers(std::integral_constant<int, 2>{});
+  else layers(std::integral_constant<int, 3>{});
   SED_STAMP(6);
   // ---- layer 3 (:129-131): wave w sums the outputs h = 16 w .. 16 w + 15 of row `rt`, wave 0 adds the four partials
   {

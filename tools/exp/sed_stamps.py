@@ -19,7 +19,7 @@ th = np.full((B, eng.ncols), np.nan); th[:, 0:6] = th9[:, 0:6]; th[:, 7] = th9[:
 t = eng._theta(th, eng.ncols)
 fh = eng.lib.payne_diag_hidden_stamps
 fh.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]; fh.restype = C.c_int
-NB = 256
+NB = 512
 hs = np.zeros((NB, 16), dtype=np.uint64)
 for rep in range(3):
     assert fh(eng._ctx, t.data_ptr(), B, hs.ctypes.data, NB) == 0
