@@ -113,7 +113,9 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   // global (a struct read through a device pointer yields generic pointers -> flat_load,
   // which also ties every table load to the LDS wait counter)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int n1 = T.n1;
+  // (the fixed-geometry instantiations know their length: read from the kernel arguments it was a scalar load, a wait and two
+  //  branches in front of everything else the kernel asks for)
+  const int n1 = LOG2N > 0 ? (1 << LOG2N) : T.n1;
   float* bufA = reinterpret_cast<float*>(smem);
   float* bufB = bufA + fft_buf_floats(n1);                     // room for the padded FFT intermediates
   double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(n1));          // scratch_doubles(256)
