@@ -1328,8 +1328,12 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
     const unsigned long long r0 = mix(seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull));
     const int i = (int)(r0 % (unsigned long long)nlive);
     const bool q = src && src[i] >= 0;
-    std::memcpy(hu + (size_t)k * nd, q ? qu + (size_t)src[i] * nd : live_u + (size_t)i * nd, (size_t)nd * 8);
-    std::memcpy(hv + (size_t)k * nd, q ? qv + (size_t)src[i] * nd : live_v + (size_t)i * nd, (size_t)nd * 8);
+    // (rows of a dozen doubles, 2 K of them between two queues: copied in place -- a memcpy call each was 20 us of the turn)
+    const double* su = q ? qu + (size_t)src[i] * nd : live_u + (size_t)i * nd;
+    const double* sv = q ? qv + (size_t)src[i] * nd : live_v + (size_t)i * nd;
+    double* du_ = hu + (size_t)k * nd;
+    double* dv_ = hv + (size_t)k * nd;
+    for (int d = 0; d < nd; ++d) { du_[d] = su[d]; dv_[d] = sv[d]; }
     hl[k] = src ? lg[i] : live_logl[i];
   }
   // one transfer each way: chains, axes and (several ellipsoids) centres and inverse axes up; chains, then the three counters down
@@ -1377,8 +1381,11 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   for (int k = 0; k < K; ++k) {
     acc += na[k]; calls += nc[k]; redraw += nr[k];
     if (na[k] > 0) {
-      std::memcpy(qu + (size_t)m * nd, hu + (size_t)k * nd, (size_t)nd * 8);
-      std::memcpy(qv + (size_t)m * nd, hv + (size_t)k * nd, (size_t)nd * 8);
+      const double* su = hu + (size_t)k * nd;
+      const double* sv = hv + (size_t)k * nd;
+      double* du_ = qu + (size_t)m * nd;
+      double* dv_ = qv + (size_t)m * nd;
+      for (int d = 0; d < nd; ++d) { du_[d] = su[d]; dv_[d] = sv[d]; }
       const double l = hl[k];
       ql[m] = (l != l) ? -INFINITY : l;
       qnc[m] = nc[k] > 1 ? nc[k] : 1;
