@@ -56,6 +56,12 @@ def parse_args():
                     help="N > 1: one star, each batch split over the ranks, one all_gather of lnL per step (SURVEY 8(e)-2)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also_measured` runs (C3, C5) behind the C2 headline")
     ap.add_argument("--e2e-calls", type=int, default=700000, help="likelihood calls per end-to-end sampler run (three runs)")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="the block of --steps steps is timed this many times back to back (each between barriers); the MEDIAN "
+                         "block is the headline, min / max ride along: a 20-step block is 0.8 ms, one clock ramp moved it 3 %%")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank, but through a torch.distributed process group (RCCL, world size 1): the collectives of "
+                         "the N > 1 path on a one-GPU box (tests/test_rccl_world1_gpu.py)")
     return ap.parse_args()
 
 
@@ -87,9 +93,20 @@ def _cpu_worker(args):
     flux = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
     names = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Inst_R']
     th = synth.draw_candidates(4096, seed=100 + seed)
+    kw = {}
+    if cfg.get("phot"):                       # C3: the joint likelihood (+ seven filters, log(A) parametrisation)
+        phot = synth.make_phot_nets()
+        from thepayne_amd.engine import highav_coefficients
+        phot["hiav"] = highav_coefficients(phot["filters"])
+        names = names + ['log(A)', 'Av']
+        th = synth.draw_candidates_c3(4096, seed=100 + seed)
+        kw = dict(phot=phot, obs_phot=synth.c3_obs_phot(phot["filters"]), photscale=True)
     out = []
     for loop, budget in zip((True, False), budgets):   # the reference's per-pixel chi^2 loop (likelihood.py:95-97), then vectorised
-        L = O.OracleLikelihood(net, obs, flux, np.full(len(obs), 0.01), names, pixel_loop=loop)
+        if budget <= 0:
+            out.append((0, 1.0))
+            continue
+        L = O.OracleLikelihood(net, obs, flux, np.full(len(obs), 0.01), names, pixel_loop=loop, **kw)
         O.lnprobfn(th[0], L)                  # warm
         n, t0 = 0, time.perf_counter()
         while True:                           # time-boxed: the sample is whatever fits the budget
@@ -130,16 +147,16 @@ def cpu_baseline(cfg_name, budgets=(12.0, 6.0), max_procs=32):
     vect = [r[1][0] / r[1][1] for r in res]
     return dict(value=float(sum(loop)), unit="likelihood-evals/s", cores=cores, kind="port",
                 per_core=float(sum(loop) / cores),
-                vectorised_chi2={"value": float(sum(vect)), "per_core": float(sum(vect) / cores),
-                                 "what": "the same port with chi^2 as one numpy expression instead of the reference's "
-                                         "per-pixel Python loop"},
+                **({"vectorised_chi2": {"value": float(sum(vect)), "per_core": float(sum(vect) / cores),
+                                        "what": "the same port with chi^2 as one numpy expression instead of the reference's "
+                                                "per-pixel Python loop"}} if budgets[1] > 0 else {}),
                 sample="numpy oracle lnprobfn, one theta per call, fp64, chi^2 by the per-pixel Python loop of "
                        "Payne/fitting/likelihood.py:95-97, %s workload: %d processes x %.0f s (%d calls; then %.0f s "
                        "with vectorised chi^2, %d calls; %.1f s wall incl. start-up)"
                        % (cfg_name, cores, budgets[0], sum(r[0][0] for r in res), budgets[1],
                           sum(r[1][0] for r in res), wall),
-                reference_measured_elsewhere="251 evals/s/core (C2), 11.6 (C5): the reference itself on the survey "
-                                             "container's CPU (BASELINE.md)")
+                reference_measured_elsewhere="251 evals/s/core (C2), 212 (C3, joint), 11.6 (C5): the reference itself on the "
+                                             "survey container's CPU (BASELINE.md)")
 
 
 # ----------------------------------------------------------------------------
@@ -189,9 +206,13 @@ def make_problem(cfg_name, B, rank, local_rank, variant=0, streams=1):
     import torch
     from thepayne_amd import nnio, synth
     from thepayne_amd.engine import PayneEngine
-    cfg = dict(synth.CONFIGS[cfg_name])
-    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
-    net = nnio.normalize_spec_net(raw)
+    cfg = dict(synth.CONFIGS["C2" if cfg_name == "LinNet300" else cfg_name])
+    if cfg_name == "LinNet300":               # FitPayne's default network (fitstar.py:81) as the reference defines it, on the C2 shape
+        raw = synth.make_torch_net("LinNet", npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=(300, 300, 300), seed=21)
+        net = nnio.normalize_spec_net(raw, "LinNet")
+    else:
+        raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+        net = nnio.normalize_spec_net(raw)
     obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
     eng0 = PayneEngine(net, obs=(obs,), b_max=1, device=local_rank)
     T = synth.TRUTH
@@ -222,7 +243,7 @@ def make_problem(cfg_name, B, rank, local_rank, variant=0, streams=1):
     theta[:, 7] = torch.as_tensor(th[:, 6], device=theta.device)
     lnl = torch.empty(B, dtype=torch.float64, device=theta.device)
     D, H, N = net["layers"][0][0].shape[1], net["layers"][0][0].shape[0], cfg["npix"]
-    dims = dict(D=D, H=H, N=N, nobs=cfg["nobs"], B=B, n1=1 << int(np.ceil(np.log2(N))),
+    dims = dict(D=D, H=H, N=N, nobs=cfg["nobs"], B=B, n1=1 << int(np.ceil(np.log2(N))), n_hh=len(net["layers"]) - 2, kind=net["kind"],
                 F=(len(phot["filters"]) if phot else 0), HP=(phot["w1"].shape[1] if phot else 0))
     return dict(cfg=cfg, engines=engines, theta=theta, lnl=lnl, dims=dims)
 
@@ -232,24 +253,26 @@ def alg_work(d):
     F x (6 -> HP -> HP -> 1), fp64 arithmetic on fp32 weights)."""
     import numpy as np
     D, H, N, B, F, HP = d["D"], d["H"], d["N"], d["B"], d["F"], d["HP"]
+    nhh = d.get("n_hh", 1)                    # H x H layers: 1 (YST1), 4 (LinNet), 2 (SMLP)
     L2N = np.log2(N)
     fl_post = 2 * 2 * 2.5 * N * L2N + 60.0 * N
     fl_sed = F * 2.0 * (6 * HP + HP * HP + HP)
-    flops_eval = 2.0 * (D * H + H * H + H * N) + fl_post + fl_sed
-    bytes_batch = 4.0 * (D * H + H + H * H + H + H * N + N) + 8.0 * N + 16.0 * d["nobs"] + B * (8.0 * 12 + 4) \
+    flops_eval = 2.0 * (D * H + nhh * H * H + H * N) + fl_post + fl_sed
+    bytes_batch = 4.0 * (D * H + H + nhh * (H * H + H) + H * N + N) + 8.0 * N + 16.0 * d["nobs"] + B * (8.0 * 12 + 4) \
         + 4.0 * F * (6 * HP + HP + HP * HP + HP + HP + 1)
     return dict(flops_eval=flops_eval, bytes_batch=bytes_batch, flops_post=fl_post, flops_sed=fl_sed,
                 flops_out=2.0 * H * N)
 
 
-def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, streams=1, shard=False):
+def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, streams=1, shard=False, repeats=1):
     """Time `steps` steps of config `cfg_name` (after `warmup`) between barriers; MAX over ranks.  Returns the numbers the
     JSON line is made of.  shard: one star, the batch split over the ranks, one all_gather of lnL per step."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from thepayne_amd import synth
-    B = B or synth.CONFIGS[cfg_name]["batch"]
+    grouped = dist.is_available() and dist.is_initialized()      # (--force-dist: a group of one rank still runs its collectives)
+    B = B or synth.CONFIGS["C2" if cfg_name == "LinNet300" else cfg_name]["batch"]
     star = 0 if shard else rank
     P = make_problem(cfg_name, B, star, local_rank, variant=args.variant, streams=streams)
     engines, theta, lnl = P["engines"], P["theta"], P["lnl"]
@@ -277,22 +300,30 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(warmup):
         step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    barrier()
-    dt_local = time.perf_counter() - t0
-    tmax = torch.tensor([dt_local], dtype=torch.float64, device=theta.device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    # `repeats` blocks of EXACTLY `steps` steps, each between barrier + synchronize on both sides, each block's time the MAX over
+    # ranks; the median block is the result (the first block after a warm-up of five steps rides a clock ramp: min / max say so)
+    blocks, blocks_local = [], []
+    for _ in range(max(1, repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        dl = time.perf_counter() - t0
+        tmax = torch.tensor([dl], dtype=torch.float64, device=theta.device)
+        if world > 1 or grouped:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        blocks.append(float(tmax.item()))
+        blocks_local.append(dl)
+    order = sorted(range(len(blocks)), key=lambda j: blocks[j])
+    mid = order[len(order) // 2]
+    dt, dt_local = blocks[mid], blocks_local[mid]
     if shard and world > 1:
         lnl = sb.result()
     for l_ in lnls[1:]:                  # every in-flight batch evaluated the same candidates: same answers
@@ -309,7 +340,7 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
         torch.cuda.synchronize()
         kern = eng.profile_read()
         eng.profile(False)
-    res = dict(P, dt=dt, dt_local=dt_local, steps=steps, warmup=warmup, B=B, S=S, kern=kern, lnl=lnl, shard=bool(shard and world > 1),
+    res = dict(P, dt=dt, dt_local=dt_local, blocks=blocks, steps=steps, warmup=warmup, B=B, S=S, kern=kern, lnl=lnl, shard=bool(shard and world > 1),
                evals=(B * steps if shard else world * B * steps))
     return res
 
@@ -332,28 +363,38 @@ def roofline_blocks(cfg_name, res, args):
            ("none: no PMC passes under profiles/ were taken with the running build (%s)" % meta["source_hash"])
     big = n1 > 16384
     if big and dom == "post":
-        # spectra larger than LDS stream through a global workspace: HBM/L2-bound.
-        # `achieved` = SURVEY 8(d)'s ALGORITHMIC bytes (compulsory bytes + 8 spectrum passes x 4N per evaluation) over the
-        # kernel's measured time: a modelled byte count over a measured duration; what the kernel really moves is in
-        # `traffic` (counters) and `workspace_bytes_per_launch` (passes_used transfers of the row), each with its own rate.
+        # Spectra larger than LDS.  What binds the kernel depends on its form: payne_post_chip_kernel / payne_post_chip32_kernel keep
+        # a convolution stage on the compute unit (5 transfers of the spectrum) and are bound by VECTOR ISSUE ->
+        # `frac` is the algorithmic FLOP rate against the fp32 vector peak; payne_post_big_kernel streams the spectrum through a
+        # global workspace 25 times and is HBM/L2-bound -> `frac` is SURVEY 8(d)'s modelled streaming bytes over the measured time.
+        # Both figures and the counter rate are printed for either kernel.
         transfers = eng_round_trips(n1, args.variant)
         alg8 = (W["bytes_batch"] / B + 8 * 4.0 * N) * B
         t = max(per[dom], 1e-9) * 1e-6
         ach = alg8 / t / 1e9
-        chip = n1 == 65536 and not (args.variant & (32 | 256 | 65536))
-        out["roofline"] = {"bound": "hbm", "kernel": "payne_post_chip_kernel" if chip else "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
-                           "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic["post"],
-                           "traffic_source": tsrc,
-                           "alg_bytes_per_launch": alg8,
-                           "alg_basis": "SURVEY 8(d): compulsory %.1f KB + 8 spectrum passes x 4N = %.2f MB per evaluation "
-                                        "(modelled bytes over the measured kernel time)"
-                                        % (W["bytes_batch"] / B / 1e3, alg8 / B / 1e6),
-                           "passes_used": transfers,
-                           "workspace_bytes_per_launch": transfers * 4.0 * n1 * B,
-                           "workspace_rate_GBs": transfers * 4.0 * n1 * B / t / 1e9,
-                           "avg_us_per_launch": per[dom]}
+        kname = res["engines"][0].kernels_used()["post"] if res.get("engines") else ""
+        chip = "chip" in kname
+        fl = B * W["flops_post"]
+        tf = fl / t / 1e12
+        extra = {"traffic": traffic["post"], "traffic_source": tsrc, "avg_us_per_launch": per[dom],
+                 "alg_flops_per_launch": fl, "fp32_vector_tflops": tf, "fp32_vector_frac": tf / PEAK_FP32_TFLOPS,
+                 "alg_bytes_per_launch": alg8, "modelled_hbm_GBs": ach, "modelled_hbm_frac": ach / PEAK_HBM_GBS,
+                 "alg_basis": "SURVEY 8(d): compulsory %.1f KB + 8 spectrum passes x 4N = %.2f MB per evaluation "
+                              "(modelled bytes over the measured kernel time)" % (W["bytes_batch"] / B / 1e3, alg8 / B / 1e6),
+                 "passes_used": transfers, "workspace_bytes_per_launch": transfers * 4.0 * n1 * B,
+                 "workspace_rate_GBs": transfers * 4.0 * n1 * B / t / 1e9}
         if traffic["post"]:
-            out["roofline"]["counter_rate_GBs"] = traffic["post"] / t / 1e9
+            extra["counter_rate_GBs"] = traffic["post"] / t / 1e9
+            extra["hbm_frac_counters"] = traffic["post"] / t / 1e9 / PEAK_HBM_GBS
+        if chip:
+            out["roofline"] = dict({"bound": "fp32-vector", "kernel": kname, "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                                    "note": "stages on the compute unit: bound by vector issue, not by bytes (the counters' HBM rate is "
+                                            "`hbm_frac_counters`; `modelled_hbm_frac` prices SURVEY 8(d)'s eight streaming passes, which this "
+                                            "kernel does not make)"}, **extra)
+        else:
+            out["roofline"] = dict({"bound": "hbm", "kernel": kname or "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
+                                    "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}, **extra)
     else:
         flops = {"dense_out": B * W["flops_out"], "post": B * W["flops_post"]}
         ach = flops[dom] / (max(per[dom], 1e-9) * 1e-6) / 1e12
@@ -400,7 +441,8 @@ def roofline_blocks(cfg_name, res, args):
 
 
 def workload_text(cfg_name, d):
-    s = "%s: single star per GPU, %d-pixel 2x%d YST1 ANN, %d observed pixels" % (cfg_name, d["N"], d["H"], d["nobs"])
+    net = {"YST1": "2x%d YST1" % d["H"], "LinNet": "5x%d LinNet (sigmoid; FitPayne's default NNtype)" % d["H"], "SMLP": "3x%d SMLP" % d["H"]}[d.get("kind", "YST1")]
+    s = "%s: single star per GPU, %d-pixel %s ANN, %d observed pixels" % (cfg_name, d["N"], net, d["nobs"])
     if d["F"]:
         s += ", photometry in %d filters (6-%d-%d-1 nets, log(A) parametrisation)" % (d["F"], d["HP"], d["HP"])
     return s + ", batch of %d candidate vectors per step (dynesty live points)" % d["B"]
@@ -440,9 +482,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    cpu = None
+    cpu = cpu_c3 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline("C2" if args.config == "C3" else args.config)
+        cpu = cpu_baseline("C2" if args.config == "LinNet300" else args.config)
+        if args.config == "C2" and not args.no_also:
+            cpu_c3 = cpu_baseline("C3", budgets=(6.0, 0.0))   # the joint likelihood's baseline (the reference itself: 212 evals/s/core)
 
     import torch
     import torch.distributed as dist
@@ -452,12 +496,14 @@ def main():
         raise SystemExit("--gpus %d but this node shows %d GPU(s): one rank per GPU (RCCL refuses two ranks on a device)"
                          % (world, ndev))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     res = run_config(args.config, args, args.steps, args.warmup, rank, world, local_rank, B=args.batch,
-                     streams=args.streams, shard=args.shard_batch)
+                     streams=args.streams, shard=args.shard_batch, repeats=args.repeats)
     B, d, lnl, theta = res["B"], res["dims"], res["lnl"], res["theta"]
 
     # ---- the one collective of the multi-star job: gather per-star summaries (RCCL)
@@ -465,14 +511,13 @@ def main():
                            torch.tensor(B * args.steps / res["dt_local"], dtype=torch.float64, device=theta.device),
                            torch.tensor(float(rank), dtype=torch.float64, device=theta.device)])
     gathered = [summary]
-    if world > 1:
+    if grouped:
         gathered = [torch.empty_like(summary) for _ in range(world)]
         dist.all_gather(gathered, summary)
     if rank != 0:
         for e in res["engines"]:
             e.close()
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     table = torch.stack(gathered).cpu().numpy()
     assert sorted(int(r) for r in table[:, 6]) == list(range(world)), "the gather did not see every rank"
@@ -480,8 +525,11 @@ def main():
     out = {
         "metric": METRIC_C2 if args.config == "C2" else "likelihood-evals/sec (%s)" % args.config,
         "value": res["evals"] / res["dt"], "unit": "likelihood-evals/s",
-        "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": dist.get_world_size() if grouped else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * res["dt"] / args.steps,
+        "repeats": len(res["blocks"]), "ms_per_step_min": 1e3 * min(res["blocks"]) / args.steps,
+        "ms_per_step_max": 1e3 * max(res["blocks"]) / args.steps,
+        "timing": "median of `repeats` blocks of `steps` steps, each block between barrier + synchronize, MAX over ranks",
         "higher_is_better": True, "scaling": "strong" if res["shard"] else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_text(args.config, d),
@@ -495,7 +543,8 @@ def main():
                    "parallelism": ("1 star, every batch split in %d contiguous blocks, one all_gather of lnL per step (RCCL)" % world)
                                   if res["shard"] else "1 star per GPU, no data-path collective"},
         **({"invalid": "--unchecked: a timing experiment, not a benchmark result"} if args.unchecked else {}),
-        "rccl_world": dist.get_world_size() if world > 1 else 1,
+        "rccl_world": dist.get_world_size() if grouped else 1,
+        "collective_backend": dist.get_backend() if grouped else None,
         "per_rank_evals_per_s": [float(v) for v in table[np.argsort(table[:, 6]), 5]],
     }
     if res["kern"] is not None:
@@ -510,11 +559,16 @@ def main():
     if world == 1 and not args.no_also and args.config == "C2" and not args.batch and args.streams == 1:
         # the configurations the headline does not show: short runs, same code path, own kernel times and roofline blocks
         also = {}
-        for name, (k, w) in (("C3", (args.steps, args.warmup)), ("C5", (3, 1))):   # (C3 as long as the headline: a step is 0.04 ms)
+        for name, (k, w, rep) in (("C3", (args.steps, args.warmup, args.repeats)), ("LinNet300", (args.steps, args.warmup, min(args.repeats, 5))),
+                                  ("C32k", (5, 2, 3)), ("C5", (3, 1, 3))):   # (C3 as long as the headline: a step is 0.04 ms)
             try:
-                r = run_config(name, args, k, w, 0, 1, local_rank)
-                blk = {"value": r["evals"] / r["dt"], "unit": "likelihood-evals/s", "steps": k, "warmup": w,
-                       "ms_per_step": 1e3 * r["dt"] / k, "workload": workload_text(name, r["dims"])}
+                r = run_config(name, args, k, w, 0, 1, local_rank, repeats=rep)
+                blk = {"value": r["evals"] / r["dt"], "unit": "likelihood-evals/s", "steps": k, "warmup": w, "repeats": rep,
+                       "ms_per_step": 1e3 * r["dt"] / k, "ms_per_step_min": 1e3 * min(r["blocks"]) / k,
+                       "ms_per_step_max": 1e3 * max(r["blocks"]) / k, "workload": workload_text(name, r["dims"]),
+                       "kernels": r["engines"][0].kernels_used()}
+                if name == "C3" and cpu_c3 is not None:
+                    blk["cpu_baseline"] = cpu_c3
                 if r["kern"] is not None:
                     blk.update(roofline_blocks(name, r, args))
                 for e in r["engines"]:
@@ -534,7 +588,7 @@ def main():
             except Exception as ex:
                 out["also_measured"]["C3"]["end_to_end"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

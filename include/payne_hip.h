@@ -432,6 +432,11 @@ int payne_sampler_counters(const payne_sampler* s, long long out[2]);
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 
+/* The kernel (with its template arguments) the context's last batch call launched for one kind -- 0 output dense layer,
+ * 1 post kernel, 2 sed kernel, 3 hidden dense layers (the last launch of that kind in the call) --, "" if none yet: which
+ * code path a net of a given depth / a spectrum of a given length takes.  Test and measurement aid, no reference counterpart. */
+const char* payne_last_kernel(const payne_ctx* ctx, int kind);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around every kernel
  * the batch calls enqueue (measurement aid for bench.py; no reference counterpart).
  * payne_profile(ctx, 1) clears the totals and starts recording, (ctx, 0) stops.

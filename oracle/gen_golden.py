@@ -528,8 +528,49 @@ def g13_smoothspec_branches():
     save("g13_smoothspec", **out)
 
 
+# ------------------------------------------------------------------ G14
+def g14_torchnets_300():
+    """The reference's DEFAULT network at real size (FitPayne: NNtype='LinNet', fitstar.py:81): LinNet D -> 300 x5 -> Npix, five
+    sigmoids (train/NNmodels.py:140-168), and SMLP D -> 300 x3 -> Npix, LeakyReLU (:92-137), both evaluated by torch in fp32
+    (predict/predictspec.py:61-74), on the C2 shape: 4096 model pixels, 3600 observed pixels.  Frozen: predictspec for four
+    label vectors (fp32, as the reference returns it), and lnlikefn for 128 (LinNet) / 32 (SMLP) draws of the demo priors."""
+    cfg = synth.CONFIGS["C2"]
+    labels = np.array([[5770.0, 4.44, 0.0, 0.0], [4100.0, 4.9, -0.08, 0.07], [7900.0, 4.05, 0.09, -0.1], [6250.0, 5.3, 0.03, 0.02]])
+    T = synth.TRUTH
+    for kind, ndraw, seed in (("LinNet", 128, 21), ("SMLP", 32, 22)):
+        net = synth.make_torch_net(kind, npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=(300, 300, 300), seed=seed)
+        path = '/g14/%s300.h5' % kind
+        rs.register_torchnet(path, net)
+        PP = predictspec.PayneSpecPredict(nnpath=path, NNtype=kind)
+        raw = np.array([PP.predictspec(list(l)) for l in labels])
+        assert raw.dtype == np.float32
+        obs = synth.obs_grid(net["wavelength"], cfg["nobs"])
+        _, clean = PP.getspec(Teff=T["Teff"], logg=T["logg"], feh=T["feh"], afe=T["afe"], rad_vel=T["vrad"],
+                              rot_vel=T["vrot"], vmic=np.nan, inst_R=2.355 * T["inst_R"], outwave=obs)
+        flux = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
+        eflux = np.full(len(obs), 0.01)
+        fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': flux, 'obs_eflux_fit': eflux,
+                   'specANNpath': path, 'NNtype': kind, 'fixedpars': {}}
+        fitpars = fitpars_for(SPEC_PARS)
+        runbools = [True, False, False, False, False]
+        L = likelihood(fitargs, fitpars, runbools)
+        P = prior(fitargs, synth.demo_priordict(), fitpars, runbools)
+        u = np.random.default_rng(14).uniform(size=(ndraw, 7))
+        theta = np.array([P.priortrans(ui) for ui in u])
+        with np.errstate(all="ignore"):
+            lnl = np.array([L.lnlikefn(t) for t in theta])
+        # getspec on the observed grid for the first four draws (fp64, as getspec returns it)
+        spec = []
+        for t in theta[:4]:
+            with np.errstate(all="ignore"):
+                spec.append(PP.getspec(Teff=t[0], logg=t[1], feh=t[2], afe=t[3], rad_vel=t[4], rot_vel=t[5], vmic=np.nan,
+                                       inst_R=2.355 * t[6], outwave=obs)[1])
+        save("g14_%s300" % kind.lower(), seed=np.array(seed), labels=labels, raw=raw, u=u, theta=theta, lnlike=lnl,
+             getspec4=np.array(spec), obs_wave=obs, obs_flux=flux, obs_eflux=eflux)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows, "g13": g13_smoothspec_branches}[k]()
+         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows, "g13": g13_smoothspec_branches, "g14": g14_torchnets_300}[k]()

@@ -71,3 +71,56 @@ def test_timeout_and_environment():
     t0 = time.monotonic()
     rc = launch_ranks(2, [sys.executable, "-c", "import time; time.sleep(60)"], timeout_s=1.0)
     assert rc == 124 and time.monotonic() - t0 < 20
+
+
+DRIVER = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, sys.argv[1])
+    from thepayne_amd.launch import launch_ranks
+    child = "import os, sys, time; open(sys.argv[1] + '/pid_%s' % os.environ['RANK'], 'w').write(str(os.getpid())); time.sleep(300)"
+    sys.exit(launch_ranks(2, [sys.executable, "-c", child, sys.argv[2]], timeout_s=600))
+''')
+
+
+def test_a_terminated_parent_leaves_no_ranks_behind(tmp_path):
+    """SIGTERM to the process that called launch_ranks (a cancelled job, a driver's timeout): the ranks are ended with it."""
+    import signal
+    import subprocess
+    script = tmp_path / "driver.py"
+    script.write_text(DRIVER)
+    parent = subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)])
+    t0 = time.monotonic()
+    while not all((tmp_path / ("pid_%d" % r)).exists() and (tmp_path / ("pid_%d" % r)).read_text() for r in range(2)):
+        assert time.monotonic() - t0 < 60 and parent.poll() is None
+        time.sleep(0.05)
+    pids = [int((tmp_path / ("pid_%d" % r)).read_text()) for r in range(2)]
+    parent.send_signal(signal.SIGTERM)
+    parent.wait(timeout=30)
+    assert parent.returncode != 0
+
+    def alive(pid):
+        try:
+            with open("/proc/%d/stat" % pid) as fh:
+                return fh.read().split(")")[-1].split()[0] != "Z"
+        except OSError:
+            return False
+    t0 = time.monotonic()
+    while any(alive(p) for p in pids) and time.monotonic() - t0 < 10:
+        time.sleep(0.05)
+    assert not any(alive(p) for p in pids), pids
+
+
+def test_every_collective_of_the_multi_gpu_paths_over_gloo(tmp_path):
+    """tools/collectives_check.py (what tests/test_rccl_world1_gpu.py runs over RCCL on the GPU box): a forced group of one rank,
+    and two ranks, give the same tables."""
+    import numpy as np
+    check = os.path.join(ROOT, "tools", "collectives_check.py")
+    got = {}
+    for n in (1, 2):
+        out = str(tmp_path / ("g%d.npz" % n))
+        with open(tmp_path / ("g%d.log" % n), "w") as fh:
+            assert launch_ranks(n, [sys.executable, check, "--backend", "gloo", "--out", out], rank0_stdout=fh, timeout_s=300) == 0
+        got[n] = np.load(out)
+    for k in ("table", "kept", "once"):
+        assert np.array_equal(got[1][k], got[2][k]), k
+    assert int(got[1]["world"]) == 1 and int(got[2]["world"]) == 2

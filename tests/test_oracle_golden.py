@@ -31,6 +31,27 @@ def test_g1_torch_nets(golden, kind):
     np.testing.assert_allclose(got, g[kind.lower()], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("kind,seed", [("LinNet", 21), ("SMLP", 22)])
+def test_g14_torch_nets_at_full_width(golden, kind, seed):
+    """The reference's default network at real size (LinNet 5 x 300, fitstar.py:81; SMLP 3 x 300) on the C2 shape: the reference
+    runs these in torch fp32, the restatement in numpy fp32 -- the two differ by the order of the 300-term sums: one fp32 ulp."""
+    g = golden("g14_%s300" % kind.lower())
+    cfg = synth.CONFIGS["C2"]
+    net = synth.make_torch_net(kind, npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=(300, 300, 300), seed=seed)
+    got = np.array([O.torchnet_forward(net, l) for l in g["labels"]])
+    assert got.dtype == np.float32 and g["raw"].dtype == np.float32
+    np.testing.assert_allclose(got, g["raw"], rtol=0, atol=4e-7)
+    L = O.OracleLikelihood(net, g["obs_wave"], g["obs_flux"], g["obs_eflux"], SPEC_PARS)
+    th = g["theta"][:24]
+    with np.errstate(all="ignore"):
+        lnl = np.array([L.lnlikefn(t) for t in th])
+    ref = g["lnlike"][:24]
+    assert np.all(np.abs(lnl - ref) <= 2e-6 * np.abs(ref) + 5e-3)
+    _, f = O.getspec(net, Teff=th[0, 0], logg=th[0, 1], feh=th[0, 2], afe=th[0, 3], rad_vel=th[0, 4], rot_vel=th[0, 5],
+                     vmic=np.nan, inst_R=2.355 * th[0, 6], outwave=g["obs_wave"])
+    np.testing.assert_allclose(f, g["getspec4"][0], rtol=0, atol=4e-7)
+
+
 def test_g2_getspec_stages_and_masks(golden):
     g = golden("g2_getspec")
     net = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)

@@ -1,0 +1,47 @@
+"""The RCCL code of the multi-GPU paths, run once on the driver's one-GPU box: a process group of ONE rank over backend "nccl"
+(= RCCL on ROCm) with device tensors.  No 8-GPU node is available to this build, so before this test the "nccl" branches of
+thepayne_amd/dist.py and bench.py had never executed; a world of one cannot show scaling, but it shows that librccl loads and that
+init_process_group(device_id=...), all_gather (fp64 rows), all_gather_into_tensor, all_reduce(MAX), barrier and
+destroy_process_group work on this image -- the first 8-GPU run then cannot die on an API error.  Every rank is a FRESH child
+started by thepayne_amd.launch.launch_ranks (no process that has touched a GPU is re-executed); a failed child fails the test."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from thepayne_amd.launch import launch_ranks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "tools", "collectives_check.py")
+
+
+def test_every_collective_over_rccl_at_world_size_one_equals_gloo(tmp_path):
+    outs = {}
+    for backend, n in (("nccl", 1), ("gloo", 1), ("gloo", 2)):
+        out = str(tmp_path / ("%s_%d.npz" % (backend, n)))
+        log = tmp_path / ("%s_%d.log" % (backend, n))
+        with open(log, "w") as fh:
+            rc = launch_ranks(n, [sys.executable, CHECK, "--backend", backend, "--out", out], rank0_stdout=fh, timeout_s=600)
+        assert rc == 0, (backend, n, rc, log.read_text())
+        assert "collectives ok: backend %s, world %d" % (backend, n) in log.read_text()
+        outs[(backend, n)] = np.load(out)
+    r, g1, g2 = outs[("nccl", 1)], outs[("gloo", 1)], outs[("gloo", 2)]
+    assert str(r["device"]).startswith("cuda") and str(g1["device"]) == "cpu"
+    for k in ("table", "kept", "once"):                         # the same table / likelihoods whatever carried them, however many ranks
+        assert np.array_equal(r[k], g1[k]) and np.array_equal(r[k], g2[k]), k
+    assert np.array_equal(r["bench"], g1["bench"]) and float(r["tmax"][0]) == 1.0
+
+
+def test_bench_line_through_a_one_rank_rccl_group(tmp_path):
+    """bench.py's own collectives (barrier, MAX of the ranks' times, the summary gather) through RCCL at world size 1: the line says so."""
+    out = tmp_path / "bench.json"
+    with open(out, "w") as fh:
+        rc = launch_ranks(1, [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "5", "--warmup", "2", "--repeats", "3",
+                              "--no-cpu-baseline", "--no-e2e", "--no-also"], rank0_stdout=fh, timeout_s=900)
+    assert rc == 0, out.read_text()
+    line = json.loads(out.read_text().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_world"] == 1 and line["collective_backend"] == "nccl"
+    assert line["value"] > 1e6 and len(line["per_rank_evals_per_s"]) == 1

@@ -109,6 +109,62 @@ def test_native_bookkeeping_matches_python_loop():
     assert abs(rn.logz[-1] - (0.5 * nd * np.log(2 * np.pi) + nd * np.log(0.05))) < 5 * rn.logzerr[-1] + 0.3
 
 
+def test_native_and_python_records_from_an_empty_evidence_with_points_at_minus_infinity():
+    """The regime the evidence guards exist for: ln Z = -1e300 at the start and a third of the first live points at lnL = -inf
+    (NaN likelihoods, a prior box wider than the model).  Native and Python bookkeeping give the same records -- delta_logz = inf
+    while nothing finite has accumulated, finite and equal to a few ulp afterwards."""
+    from thepayne_amd.build import build_lib
+    build_lib()
+    nd = 3
+
+    def ll(V):
+        out = -0.5 * np.sum(((V - 0.5) / 0.1) ** 2, axis=1)
+        out[V[:, 0] < 0.33] = -np.inf
+        return out
+
+    runs = []
+    for native in (True, False):
+        S = NestedSampler(ll, lambda U: U, nd, nlive=48, bound='single', sample='rwalk', walks=8, batched=True,
+                          queue_size=48, rstate=np.random.default_rng(11), native=native)
+        S._native_bound = False
+        assert S.logz == -1e300 and np.isneginf(S.live_logl).sum() >= 8
+        runs.append(list(S.sample(dlogz=0.1, maxiter=260)))
+    tn, tp = runs
+    assert len(tn) == len(tp) == 260
+    n_inf = 0
+    for a, b in zip(tn, tp):
+        assert a[0] == b[0] and a[9] == b[9] and np.array_equal(a[1], b[1])
+        assert a[3] == b[3] or (np.isneginf(a[3]) and np.isneginf(b[3]))        # loglstar of the dead point
+        for i in (4, 5, 6, 7, 8, 14):
+            x, y = a[i], b[i]
+            if np.isinf(x) or np.isinf(y):
+                assert x == y, (i, x, y)
+            else:
+                assert abs(x - y) <= 1e-11 * max(1.0, abs(x)), (i, x, y)
+        n_inf += int(np.isinf(a[14]))
+    assert n_inf >= 8 and np.isfinite(tn[-1][14]) and np.isfinite(tn[-1][6])   # the -inf points die first, then the evidence is finite
+
+
+def test_a_bound_fitted_ahead_and_dropped_leaves_the_decomposition_schedule_alone():
+    """_prefetch_bound fits the next bound while the GPU walks; when that fit is not used (the update was not due, or another
+    queue came first) the schedule of decomposition attempts must be the serial run's: fitting has no side effects, adopting has."""
+    def ll(V):
+        return -0.5 * np.sum(((V - 0.5) / 0.1) ** 2, axis=1)
+    S = NestedSampler(ll, lambda U: U, 3, nlive=64, bound='multi', sample='rwalk', walks=5, batched=True,
+                      rstate=np.random.default_rng(3))
+    S._update_bound()
+    w0 = S._split_wait
+    for _ in range(3):
+        S._fit_bound()                         # made ahead, never adopted
+        S._bound_next = S._fit_bound() + (S._cycle - 1,)     # a prefetch for another cycle: dropped by _update_bound
+    assert S._split_wait == w0
+    S._update_bound()
+    assert S._bound_next is None and S._split_wait == (w0 - 1 if w0 > 1 else S._split_wait)
+    ells, stack, split, wait = S._fit_bound()
+    S._adopt_bound(ells, stack, split, wait)
+    assert S._split_wait == wait
+
+
 class _QueueProposer(object):
     """A host stand-in for DeviceProposer's queue calls (rwalk_queue / _begin / _end): K random-walk chains from random live
     points, isotropic steps (the bound is ignored, so a queue depends on the live set, the threshold, the scale and the seed only)."""

@@ -1262,18 +1262,23 @@ __global__ void __launch_bounds__(512) payne_dense_fused_kernel(DenseParams ph, 
     if (pa.out && cand < ph.B) prep_candidate(pa.T, ph.theta + (size_t)cand * ph.ld_theta, pa.instr_factor, pa.out[cand]);
   }
   // ---- wait for this tile's 64 rows of activations
+  // (a spin that runs out must not pass silently: the tile would be computed from activations nobody published.  The whole
+  //  tile is then written as NaN -- every likelihood of these 64 candidates comes back NaN -- and the flag is set for the host)
+  __shared__ int fuse_timed_out;
   if (tid == 0) {
-    int spins = 0;
+    int spins = 0, expired = 0;
     const unsigned long long want = fs.done_target[mt];
     while (__hip_atomic_load(fs.done + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > kFuseSpinMax) { *fs.timeout = 1; break; }
+      if (++spins > kFuseSpinMax) { *fs.timeout = 1; expired = 1; break; }
     }
+    fuse_timed_out = expired;
     HK_STAMP(4);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  const float poison = fuse_timed_out ? __builtin_nanf("") : 0.f;
   HK_STAMP(5);
   // ---- the output tile (payne_dense_dma3_kernel<10, 4, true> from here on)
   auto wait_landed = [&](int younger) {
@@ -1358,7 +1363,7 @@ __global__ void __launch_bounds__(512) payne_dense_fused_kernel(DenseParams ph, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);
+      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act) + poison, &p.Y[(size_t)row * p.ldy + col]);
     }
   }
   HK_STAMP(15);

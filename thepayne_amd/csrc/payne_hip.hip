@@ -126,6 +126,7 @@ struct payne_ctx {
   size_t prof_used = 0;
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
+  const char* last_kernel[4] = {"", "", "", ""};   // what the last call launched, per kind (payne_last_kernel)
 };
 
 // RAII bracket of one timed launch.  The event pair is handed to the launch itself (hipExtLaunchKernelGGL:
@@ -135,8 +136,8 @@ struct payne_ctx {
 struct ProfScope;
 static thread_local ProfScope* g_prof_scope = nullptr;
 struct ProfScope {
-  payne_ctx* c; hipStream_t s; payne_ctx::ProfRec* r = nullptr; bool used = false; ProfScope* outer = nullptr;
-  ProfScope(payne_ctx* c_, hipStream_t s_, int kind) : c(c_), s(s_) {
+  payne_ctx* c; hipStream_t s; payne_ctx::ProfRec* r = nullptr; bool used = false; ProfScope* outer = nullptr; int kind;
+  ProfScope(payne_ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_) {
     outer = g_prof_scope; g_prof_scope = this;
     if (!c->prof) return;
     if (c->prof_used == c->prof_pool.size()) {
@@ -156,6 +157,7 @@ struct ProfScope {
 #define PAYNE_LAUNCH(kernel, grid, block, lds, stream, ...)                                               \
   do {                                                                                                    \
     ProfScope* ps_ = g_prof_scope;                                                                        \
+    if (ps_) ps_->c->last_kernel[ps_->kind] = #kernel;                                                    \
     if (ps_ && ps_->r && !ps_->used) {                                                                    \
       ps_->used = true;                                                                                   \
       hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, ps_->r->e0, ps_->r->e1, 0, __VA_ARGS__); \
@@ -245,6 +247,10 @@ extern "C" const char* payne_kernel_name(int which) {
     case 2: return "payne_sed_kernel";
     default: return "";
   }
+}
+
+extern "C" const char* payne_last_kernel(const payne_ctx* c, int kind) {
+  return (c && kind >= 0 && kind < 4) ? c->last_kernel[kind] : "";
 }
 
 extern "C" void payne_ctx_destroy(payne_ctx* c) {
@@ -927,6 +933,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
       PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
       PAYNE_LAUNCH(lean ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+      c->last_kernel[1] = post_kernel_label((c->opts.variant & PAYNE_V_POST_GENERIC) ? 0 : c->T.n1, c->post_tw_lds, lean && c->lean_available);
     }
   }
   hipError_t e = hipGetLastError();
@@ -1308,6 +1315,11 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
   int rc = sampler_check(s, live_u, K, live_v);
   if (rc) return rc;
   payne_ctx* c = s->ctx;
+  if (s->queue_open) {
+    // a queue begun and never collected (an abandoned generator, a caller of _begin that skipped _end): its transfer DOWN into
+    // q_host may still be pending on its stream and would land on top of the start points written below -- wait for it first
+    HIPCHK(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(s->queue_stream)));
+  }
   s->queue_open = false;
   if (!live_logl || !axes_unit || nlive <= 0 || walks <= 0)
     return fail(c, PAYNE_E_INVALID, "bad payne_ns_rwalk_queue arguments");

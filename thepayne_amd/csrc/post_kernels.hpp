@@ -597,6 +597,17 @@ PAYNE_POST_FULL_B_LIST(PAYNE_POST_EXTERN)
 #endif
 
 typedef void (*post_kernel_fn)(const PostTables, PostArgs);
+// the instantiation pick_post_kernel returns, by name (payne_last_kernel)
+static const char* post_kernel_label(int n1, bool tw_lds, bool lean) {
+  if (lean) {
+    if (tw_lds && n1 == 4096) return "payne_post_kernel<12, true, true>";
+    if (tw_lds && n1 == 2048) return "payne_post_kernel<11, true, true>";
+    if (tw_lds && n1 == 1024) return "payne_post_kernel<10, true, true>";
+    if (!tw_lds && n1 == 8192) return "payne_post_kernel<13, false, true>";
+  }
+  if (tw_lds) return n1 == 1024 ? "payne_post_kernel<10, true>" : n1 == 2048 ? "payne_post_kernel<11, true>" : n1 == 4096 ? "payne_post_kernel<12, true>" : "payne_post_kernel<0, true>";
+  return n1 == 8192 ? "payne_post_kernel<13, false>" : "payne_post_kernel<0, false>";
+}
 // compile-time FFT geometry for the common spectrum lengths, runtime geometry otherwise
 static post_kernel_fn pick_post_kernel(int n1, bool tw_lds, bool lean = false) {
   if (lean) {                                   // likelihood-only builds of the LDS-twiddle sizes that matter

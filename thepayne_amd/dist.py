@@ -14,15 +14,24 @@ import numpy as np
 __all__ = ["init_from_env", "shard", "gather_summaries", "fit_stars", "sharded_lnlike", "ShardedBatch", "finalize"]
 
 
-def init_from_env(backend=None):
+def _group_up():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from the torchrun environment.  Returns
-    (rank, world, local_rank); a no-op single-process setup when WORLD_SIZE is unset/1."""
+    (rank, world, local_rank); a no-op single-process setup when WORLD_SIZE is unset/1 -- unless `force` (or
+    PAYNE_DIST_FORCE=1) asks for a process group of ONE rank: every collective below then runs through the backend
+    (RCCL on a GPU) instead of being skipped, which is how a one-GPU box exercises the code an 8-GPU node will run."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("PAYNE_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -59,7 +68,7 @@ def gather_summaries(local, n_total, rank, world, length):
     out = np.full((n_total, length), np.nan)
     for i, s in local.items():
         out[i] = s
-    if world == 1:
+    if world == 1 and not _group_up():
         return out
     per = (n_total + world - 1) // world
     use_cuda = dist.get_backend() == "nccl"
@@ -96,7 +105,7 @@ def sharded_lnlike(lnlike_fn, theta, rank, world):
     import torch.distributed as dist
     theta = np.asarray(theta) if not hasattr(theta, "shape") else theta
     B = theta.shape[0]
-    if world == 1:
+    if world == 1 and not _group_up():
         out = lnlike_fn(theta)
         return out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out, dtype=np.float64)
     per = (B + world - 1) // world
@@ -132,7 +141,7 @@ class ShardedBatch(object):
         import torch.distributed as dist
         if self.hi > self.lo:
             fn(self.lo, self.hi, self.mine[:self.hi - self.lo])
-        if self.world > 1:
+        if self.world > 1 or _group_up():
             dist.all_gather_into_tensor(self.full, self.mine)
         else:
             self.full.copy_(self.mine)

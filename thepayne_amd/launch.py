@@ -7,6 +7,7 @@ collective for ever) and becomes the parent's exit code.  No process that has in
 another program (os.exec*): ranks are children, started before any GPU call.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -38,12 +39,6 @@ def launch_ranks(n, cmd, prepare=None, poll_s=0.05, timeout_s=None, rank0_stdout
         prepare()
     port = free_port()
     procs = []
-    for r in range(n):
-        procs.append(subprocess.Popen(list(cmd), env=rank_env(r, n, port),
-                                      stdout=(rank0_stdout if r == 0 else subprocess.DEVNULL)))
-    rc = 0
-    pending = list(procs)
-    t0 = time.monotonic()
 
     def end(ps):
         for q in ps:
@@ -57,23 +52,43 @@ def launch_ranks(n, cmd, prepare=None, poll_s=0.05, timeout_s=None, rank0_stdout
                 q.kill()
                 q.wait()
 
-    while pending:
-        for p in list(pending):
-            code = p.poll()
-            if code is None:
-                continue
-            pending.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                end(pending)                 # a failed rank leaves the others waiting in a collective: end them
-                pending = []
-                break
-        if pending and timeout_s is not None and time.monotonic() - t0 > timeout_s:
-            end(pending)
-            return 124
-        if pending:
-            time.sleep(poll_s)
-    return rc
+    # A parent that is interrupted, terminated or hit by an exception must not leave N GPU ranks behind (they hold their
+    # devices and may wait in a collective for ever): SIGTERM becomes an exception here, and `finally` ends whoever still runs.
+    def on_term(signum, frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                       # not the main thread: no handler, the finally below still covers exceptions
+        pass
+    try:
+        for r in range(n):
+            procs.append(subprocess.Popen(list(cmd), env=rank_env(r, n, port),
+                                          stdout=(rank0_stdout if r == 0 else subprocess.DEVNULL)))
+        rc = 0
+        pending = list(procs)
+        t0 = time.monotonic()
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    end(pending)                 # a failed rank leaves the others waiting in a collective: end them
+                    pending = []
+                    break
+            if pending and timeout_s is not None and time.monotonic() - t0 > timeout_s:
+                end(pending)
+                return 124
+            if pending:
+                time.sleep(poll_s)
+        return rc
+    finally:
+        end([q for q in procs if q.poll() is None])
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
 
 
 if __name__ == "__main__":          # python -m thepayne_amd.launch N prog args...

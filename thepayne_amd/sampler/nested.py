@@ -222,14 +222,13 @@ class NestedSampler(object):
         if self.bound == 'none' and self.method == 'unif':
             self._axes = None
             return
-        if self._bound_next is not None and self._bound_next[3] == self._cycle:    # fitted while the GPU walked this cycle
-            ells, stack, split, _ = self._bound_next
+        if self._bound_next is not None and self._bound_next[4] == self._cycle:    # fitted while the GPU walked this cycle
+            ells, stack, split, wait, _ = self._bound_next
             self._bound_next = None
-            self._adopt_bound(ells, stack, split)
+            self._adopt_bound(ells, stack, split, wait)
             return
-        self._bound_next = None
-        ells, stack, split = self._fit_bound()
-        self._adopt_bound(ells, stack, split)
+        self._bound_next = None                # (a fit made ahead and not used leaves no trace: the decomposition schedule is the serial run's)
+        self._adopt_bound(*self._fit_bound())
 
     def _prefetch_bound(self):
         """The fit of the next bound update, made on the host while the GPU walks (see overlap_bound) -- only when that update is
@@ -241,10 +240,11 @@ class NestedSampler(object):
         u = self.live_u
         # the decomposition is tried at every update while it finds several ellipsoids, at every fourth one
         # while the live points keep forming a single cloud
-        split = False
+        # (no side effects here: the schedule's counter moves when a fit is ADOPTED -- a fit made ahead by _prefetch_bound may be dropped)
+        split, wait = False, self._split_wait
         if self.bound == 'multi':
-            self._split_wait -= 1
-            split = self._split_wait <= 0
+            wait -= 1
+            split = wait <= 0
         if self._native_bound:             # C++ (payne_ns_bound): same arithmetic as _Ell / _split_ellipsoids
             nd, E = self.ndim, MAX_ELL if split else 1
             ctr, lv = np.empty((E, nd)), np.empty(E)
@@ -261,10 +261,11 @@ class NestedSampler(object):
             ells = _split_ellipsoids(u, whole, self.enlarge, [MAX_ELL]) if split else [whole]
             stack = tuple(np.stack([getattr(e, k) for e in ells]) for k in ("ctr", "axes_unit", "ainv"))
         if split:
-            self._split_wait = 1 if len(ells) > 1 else 4
-        return ells, stack, split
+            wait = 1 if len(ells) > 1 else 4
+        return ells, stack, split, wait
 
-    def _adopt_bound(self, ells, stack, split):
+    def _adopt_bound(self, ells, stack, split, wait):
+        self._split_wait = wait
         self._ell_stack = stack
         self._ax_arg = stack[1] if len(stack[1]) > 1 else stack[1][0]      # (one object per bound: the proposer remembers its address)
         self._ells = ells                  # (an update without a split attempt always follows a single-cloud result)
@@ -602,7 +603,10 @@ class NestedSampler(object):
         return rec, stop
 
     def _consume_py(self, rec, dlogz, max_emit, logl_max, cap):
-        """The loop of payne_ns_consume in Python (thepayne_amd/csrc/ns_core.hpp), statement for statement."""
+        """The loop of payne_ns_consume (thepayne_amd/csrc/ns_core.hpp) in Python: the same recurrences, guards and records.  The
+        native loop shares its exponentials between logaddexp, H's weights and the two weight terms (seven libm calls per dead
+        point instead of nine), so evidence values agree to a few ulp, not to the bit; ln Z at or below -1e299 -- nothing
+        finite accumulated yet, e.g. live points at -inf -- records delta_logz = inf in both."""
         n = self.nlive
         dlv = math.log((n + 1.0) / n)
         logdfac = math.log(0.5 * math.expm1(dlv))
@@ -644,7 +648,7 @@ class NestedSampler(object):
             self.live_u[worst], self.live_v[worst] = self._qU[q], self._qV[q]
             self.live_logl[worst], self.live_it[worst] = ql[q], self.it
             self._qpos += 1
-            rec["delta_logz"][m] = lae(self.logz, float(self.live_logl.max()) + self.logvol) - self.logz
+            rec["delta_logz"][m] = (lae(self.logz, float(self.live_logl.max()) + self.logvol) - self.logz) if self.logz > -1e299 else np.inf
             self.it += 1
             m += 1
         return m, stop

@@ -17,6 +17,9 @@ CONFIGS = {
     # observed magnitudes 5.0 +- 0.05, the `photscale` parametrisation: log(A) U[-3, 7], Av U[0, 1]
     "C3": dict(npix=4096, lam0=5150.0, R=32000.0, nobs=3600, batch=512, phot=True),
     "C5": dict(npix=65536, lam0=4000.0, R=100000.0, nobs=60000, batch=2048),
+    # not a BASELINE config: spectra between the LDS-resident kernel (<= 16 384 points) and C5 -- an R ~ 60k grid of 32 768 pixels
+    # (4500-4861 AA), 30 000 observed pixels, 1024 candidates (the reference's own demo spectrum has 25 600 pixels, demo/runPayne.py:43-50)
+    "C32k": dict(npix=32768, lam0=4500.0, R=60000.0, nobs=30000, batch=1024),
     "tiny": dict(npix=256, lam0=5150.0, R=32000.0, nobs=200, batch=16),
     "small": dict(npix=1024, lam0=5150.0, R=32000.0, nobs=900, batch=32),
 }
