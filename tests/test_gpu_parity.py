@@ -338,9 +338,12 @@ def test_abi_error_paths(Engine):
 
 @pytest.mark.parametrize("variant", [0, 256, 32], ids=["four_step", "four_step_fused", "plain_passes"])
 def test_spectra_larger_than_lds_vs_oracle(Engine, variant):
-    """n1 > 16384 takes the global-workspace kernel (persistent workgroups): a 40 000-pixel net and the
-    65 536-pixel C5 grid (R ~ 100k), a few candidates each (the oracle needs ~0.1 s per evaluation)."""
-    for npix, nobs, lam0, R, B in ((40000, 30000, 5150.0, 32000.0, 3), (65536, 60000, 4000.0, 100000.0, 5)):
+    """n1 > 16384 takes the kernels for spectra larger than LDS (persistent workgroups): a 40 000-pixel net and the 65 536-pixel
+    C5 grid (R ~ 100k); the reference's own demo length, 25 600 pixels (demo/runPayne.py:43-50: n1 = 32 768, resampling maps that
+    are not the identity) and a 32 768-pixel R ~ 60k grid (payne_post_chip2_kernel: two candidates at a time, odd batches, a batch
+    walked in chunks); a few candidates each (the oracle needs ~0.1 s per evaluation)."""
+    for npix, nobs, lam0, R, B in ((40000, 30000, 5150.0, 32000.0, 3), (65536, 60000, 4000.0, 100000.0, 5),
+                                   (25600, 20000, 5150.0, 32000.0, 5), (32768, 30000, 4500.0, 60000.0, 5)):
         raw = synth.make_yst_net(npix=npix, lam0=lam0, R_fwhm=R, H=16, seed=31, line_depth=0.1)
         obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.0005, relative=True)
         th7 = synth.draw_candidates(B, seed=npix)
@@ -424,6 +427,50 @@ def test_c5_at_size(Engine):
     # same answers in reverse order (grid-stride walk of the batch) and on a second call
     assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th[::-1].copy()).cpu().numpy()[::-1]), np.nan_to_num(lnl))
     assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th).cpu().numpy()), np.nan_to_num(lnl))
+
+
+def test_c32k_at_size(Engine):
+    """Spectra between the LDS-resident kernel and C5 at a real shape and batch: 32 768 pixels (R ~ 60k), H = 300, 30 000 observed
+    pixels, 1024 candidates = 512 pairs over payne_post_chip2_kernel's persistent workgroups.  Rows against the oracle; every row
+    against chi^2 recomputed on the host from the predicted spectra; pairs whose two candidates take DIFFERENT paths (no rotation,
+    no instrumental smoothing, Inst_R above the network's resolution) beside pairs that take the usual one; order independence."""
+    cfg = synth.CONFIGS["C32k"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
+    B = cfg["batch"]
+    th7 = synth.draw_candidates(B, seed=77)
+    th7[:, 6] = np.linspace(0.55, 0.9, B) * cfg["R"]
+    th7[6, 5] = 0.0                                                    # no rotation: its pair (6, 7) goes candidate by candidate
+    th7[11, 6] = np.nan                                                # Inst_R absent: plain interpolation (ystpred.py:271-272)
+    th7[21, 6] = 1.2 * raw["resolution"] / 2.355                       # above the ANN's own resolution: NaN by contract
+    th = theta_full(th7)
+    rows = [list(th[k, :8]) for k in (0, 1, 6)]
+    clean = np.array([O.genspec(raw, r, outwave=obs)[1] for r in rows])
+    flux = clean[0] + np.random.default_rng(3).normal(0, 0.01, len(obs))
+    eflux = np.full(len(obs), 0.01)
+    eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=B)
+    lnl = eng.lnlike_batch(th).cpu().numpy()
+    assert eng.kernels_used()["post"] == "payne_post_chip2_kernel"
+    assert np.isnan(lnl[21]) and np.isfinite(np.delete(lnl, 21)).all()
+    L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
+    for k in (0, 1, 6, 7, 10, 11, 20, 511, 512, 1022, 1023):
+        ref = L.lnlikefn(th7[k])
+        assert abs(lnl[k] - ref) <= lnl_tol(np.array([ref]))[0], (k, lnl[k], ref)
+    spec = eng.predict_batch(th[[0, 1, 6]], stage=2, fwhm_R=True).cpu().numpy()
+    assert np.nanmax(np.abs(spec - clean)) <= FLUX_TOL
+    ok = np.isfinite(lnl)
+    for s in range(0, B, 64):
+        sp = eng.predict_batch(th[s:s + 64], stage=3, fwhm_R=True).cpu().numpy().astype(np.float64)
+        chi = -0.5 * (((sp - flux) / eflux) ** 2).sum(axis=1)
+        sel = ok[s:s + 64]
+        assert np.all(np.abs(chi[sel] - lnl[s:s + 64][sel]) <= 2e-5 * np.abs(lnl[s:s + 64][sel]) + 5e-3)
+    # the same answers in reverse order (other partners, other workgroups), for an odd batch, and from the workspace kernel
+    assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th[::-1].copy()).cpu().numpy()[::-1]), np.nan_to_num(lnl))
+    assert np.array_equal(np.nan_to_num(eng.lnlike_batch(th[:333]).cpu().numpy()), np.nan_to_num(lnl[:333]))
+    ws = Engine(_net(raw), obs=(obs, flux, eflux), b_max=64, variant=65536)
+    l2 = ws.lnlike_batch(th[:64]).cpu().numpy()
+    assert ws.kernels_used()["post"] == "payne_post_big_kernel"
+    assert np.all(np.abs(l2 - lnl[:64])[ok[:64]] <= lnl_tol(lnl[:64][ok[:64]]))
 
 
 @pytest.mark.parametrize("variant", [0, 8192])

@@ -42,6 +42,8 @@ def test_bench_line_through_a_one_rank_rccl_group(tmp_path):
         rc = launch_ranks(1, [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "5", "--warmup", "2", "--repeats", "3",
                               "--no-cpu-baseline", "--no-e2e", "--no-also"], rank0_stdout=fh, timeout_s=900)
     assert rc == 0, out.read_text()
-    line = json.loads(out.read_text().strip().splitlines()[-1])
+    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.read_text()[-3000:]             # ONE JSON line from rank 0 (RCCL may add lines of its own)
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["rccl_world"] == 1 and line["collective_backend"] == "nccl"
     assert line["value"] > 1e6 and len(line["per_rank_evals_per_s"]) == 1

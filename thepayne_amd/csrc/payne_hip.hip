@@ -86,6 +86,7 @@ struct payne_ctx {
   int big_grid = 0;
   bool big_tiled = false;             // ... with the four-step transform (LDS tile attribute set at create)
   bool big_chip = false;              // ... or with the convolution stages on the compute unit (65 536 points: payne_post_chip_kernel)
+  bool big_chip2 = false;             // ... 32 768 points, two candidates at a time (payne_post_chip2_kernel)
   // optional continuum network (payne_ctx_set_continuum; ystpred.py:81-85, 191-209)
   bool has_cont = false;
   int cn_layers = 0, cn_npix = 0, cn_ld_hid = 0;
@@ -361,7 +362,14 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if ((opts->variant & PAYNE_V_DENSE_FUSED) && (rc = dev_alloc(c, (size_t)96, &c->fuse_cnt, c->owned))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
-      if ((rc = dev_alloc(c, (size_t)c->big_grid * 2 * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
+      // 32 768-point spectra on a geometric grid: the on-chip stages for two candidates at a time (four buffers per workgroup)
+      c->big_chip2 = T.n1 == kChip2N1 && c->H.geo && !(opts->variant & (PAYNE_V_BIG_PLAIN | PAYNE_V_BIG_FUSED | PAYNE_V_BIG_WORKSPACE));
+      if ((rc = dev_alloc(c, (size_t)c->big_grid * (c->big_chip2 ? 4 : 2) * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
+      if (c->big_chip2) {
+        he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_chip2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kChipLdsBytes);
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute(chip2): ") + hipGetErrorString(he)));
+      }
       c->big_tiled = !(opts->variant & PAYNE_V_BIG_PLAIN);
       // 65 536-point spectra on a geometric grid: the convolution stages stay on the compute unit (payne_post_chip_kernel)
       c->big_chip = T.n1 == kChipN1 && c->H.geo && !(opts->variant & (PAYNE_V_BIG_PLAIN | PAYNE_V_BIG_FUSED | PAYNE_V_BIG_WORKSPACE));
@@ -926,6 +934,9 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
     if (c->big_ws && c->big_chip) {
       const int grid = B < c->big_grid ? B : c->big_grid;
       PAYNE_LAUNCH(payne_post_chip_kernel, dim3(grid), dim3(kChipThreads), kChipLdsBytes, s, c->T, a, c->big_ws, B);
+    } else if (c->big_ws && c->big_chip2) {
+      const int pairs = (B + 1) / 2, grid = pairs < c->big_grid ? pairs : c->big_grid;
+      PAYNE_LAUNCH(payne_post_chip2_kernel, dim3(grid), dim3(kChipThreads), kChipLdsBytes, s, c->T, a, c->big_ws, B);
     } else if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
       const int tiled = (c->big_tiled ? 1 : 0) | ((c->opts.variant & PAYNE_V_BIG_FUSED) ? 2 : 0);

@@ -6,6 +6,7 @@
 #include "select.hpp"
 #include "sampler_core.hpp"
 #include "post_onchip.hpp"
+#include "post_onchip2.hpp"
 
 // ============================================================================
 // per-candidate spectrum pipeline
@@ -331,6 +332,118 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const Pos
     if (a.stamps && threadIdx.x == 0) ex.stamps[0] = (unsigned long long)ex.nst;
 #endif
     __syncthreads();
+  }
+#endif
+}
+#endif
+
+// 32 768-point spectra (16 384 < n1 <= 32 768: e.g. the reference's own 25 600-pixel demo spectrum, demo/runPayne.py:43-50, any
+// R ~ 50-80k fit): the same on-chip stages, TWO candidates at a time (post_onchip2.hpp).  A workgroup walks the batch in pairs; a
+// pair whose candidates both take the usual path -- rotation, instrumental smoothing, a 32 768-point instrumental window, records
+// made ahead -- runs both convolution stages of both candidates on the compute unit (five transfers of each spectrum, as at
+// 65 536 points); anything else (a candidate without rotation, a shorter window, spectrum output stages 0 / 1) goes candidate by
+// candidate through payne_post_big_kernel's phases with the runtime-geometry transform.
+constexpr size_t kChip2WsFloatsPerGroup(int n1) { return (size_t)4 * n1; }      // two buffers per candidate
+#ifndef PAYNE_TU_CHIP2
+__global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const PostTables T, PostArgs a, float* ws, int B);
+#else
+__global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const PostTables T, PostArgs a, float* ws, int B) {
+#ifdef __HIP_DEVICE_COMPILE__
+  __shared__ double red[kChipThreads + kChipThreads / 2 + 2];
+  __shared__ CandState S2[2];
+  __shared__ ChipResample R2[2];
+  extern __shared__ __attribute__((aligned(16))) unsigned char chip_sm[];
+  float* base = ws + (size_t)blockIdx.x * 4 * T.n1;
+  float* buf[2][2] = {{base, base + T.n1}, {base + 2 * (size_t)T.n1, base + 3 * (size_t)T.n1}};
+  DevExecT<false, false> ex;                                   // (the phases around the stages: global-workspace executor)
+  const ChipLds L = chip_lds(chip_sm);
+  chip2_fill_tables(L, T.tw, (int)threadIdx.x);
+  __syncthreads();
+  double* chi2 = red + scratch_doubles(kChipThreads) - 1;
+  const int tid = (int)threadIdx.x;
+  const int stage = a.out_stage;
+  for (int p = blockIdx.x; 2 * p < B; p += gridDim.x) {
+    const int bb[2] = {2 * p, (2 * p + 1 < B) ? 2 * p + 1 : 2 * p};      // (an odd batch: the last candidate twice, written once)
+    const int ncand = bb[1] != bb[0] ? 2 : 1;
+    bool pair = a.prep != nullptr && T.geo && T.nobs > 0 && (stage == -1 || stage == 2 || stage == 3) && (a.out != nullptr || T.obs_f1 != nullptr);
+    if (pair) {
+      // both records into LDS (a dword copy by the first two waves)
+      const unsigned* s0 = reinterpret_cast<const unsigned*>(a.prep + bb[0]);
+      const unsigned* s1 = reinterpret_cast<const unsigned*>(a.prep + bb[1]);
+      unsigned* d0 = reinterpret_cast<unsigned*>(&S2[0]);
+      unsigned* d1 = reinterpret_cast<unsigned*>(&S2[1]);
+      for (int i = tid; i < kPrepDwords; i += kChipThreads) { d0[i] = s0[i]; d1[i] = s1[i]; }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        pair = pair && S2[c].do_rot && S2[c].do_smooth && S2[c].w_ready && !S2[c].W.bad && S2[c].W.n2 == kChip2N1;
+    }
+    if (!pair) {
+      __syncthreads();
+      for (int c = 0; c < ncand; ++c) {
+        const int b = bb[c];
+        run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw,
+                                       buf[0][0], buf[0][1], S2[0], red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, stage, chi2,
+                                       a.prep ? a.prep + b : nullptr);
+        if (tid == 0 && a.lnl && stage < 0) {
+          double x2 = *chi2;
+          if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+          a.lnl[b] = -0.5 * x2;
+        }
+        __syncthreads();
+      }
+      continue;
+    }
+    const float* raw[2] = {a.raw + (size_t)bb[0] * a.ld_raw, a.raw + (size_t)bb[1] * a.ld_raw};
+    // ---- rotation stage of both candidates (ystpred.py:211-224, smoothing.py:293-336): the raw rows in (NaN -> 0), the edge rule out
+    TaperArgs ta[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      ta[c] = TaperArgs{};
+      ta[c].vs_tab = T.vs_tab; ta[c].vs_tab_n = T.vs_tab_n;
+      ta[c].vs_c = S2[c].vs_a * T.vs_val;
+      ta[c].vs_c64 = ta[c].vs_c * (1.0 / kVsTabStep);
+    }
+    const bool ident = T.rot_identity != 0;
+    Chip2Io io;
+    if (ident) { io.in[0] = raw[0]; io.in[1] = raw[1]; }
+    else {                                                   // resample_wave onto the pow-2 log grid first (static maps)
+      for (int c = 0; c < 2; ++c) ex.par([&](int t, int n) { phase_rot_resample(t, n, T, raw[c], buf[c][1]); });
+      io.in[0] = buf[0][1]; io.in[1] = buf[1][1];
+    }
+    io.out[0] = buf[0][1]; io.out[1] = buf[1][1];
+    chip2_conv<true>(L, io, ta[0], ta[1], ident, ident, tid, nullptr);
+    float* spec[2] = {buf[0][1], buf[1][1]};
+    if (!ident) {                                            // back onto the model grid (NaN outside), then the edge rule
+      for (int c = 0; c < 2; ++c) ex.par([&](int t, int n) { phase_rot_back(t, n, T, buf[c][1], buf[c][0]); });
+      spec[0] = buf[0][0]; spec[1] = buf[1][0];
+      ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec[0]); phase_rot_edges(t, T.npix, spec[1]); });
+    }
+    // ---- instrumental stage: each candidate's own window (mask, Doppler shift, pow-2 log grid), gathered while loading
+    if (tid < 2) {
+      const Window& W = S2[tid].W;
+      R2[tid].rsA = W.rsA; R2[tid].rsBm = W.rsB + kPosMagic; R2[tid].hs = W.hs_ann; R2[tid].i0 = W.i0; R2[tid].i1 = W.i1;
+    }
+    __syncthreads();
+    ta[0].g_c2 = S2[0].W.g_c2; ta[1].g_c2 = S2[1].W.g_c2;
+    float* conv[2] = {spec[0] == buf[0][1] ? buf[0][0] : buf[0][1], spec[1] == buf[1][1] ? buf[1][0] : buf[1][1]};
+    io.in[0] = spec[0]; io.in[1] = spec[1]; io.out[0] = conv[0]; io.out[1] = conv[1];
+    chip2_conv<false>(L, io, ta[0], ta[1], false, false, tid, R2);
+    // ---- observed grid, blaze, chi^2: candidate by candidate
+    for (int c = 0; c < ncand; ++c) {
+      const int b = bb[c];
+      float* outp = a.out ? a.out + (size_t)b * a.ld_out : nullptr;
+      const Window W = S2[c].W;
+      ex.par([&](int t, int n) { store_partial(t, phase_obs<16>(t, n, T, S2[c], W, conv[c], outp, stage), red); });
+      if (tid == 0 && a.lnl && stage < 0) {
+        double x2 = 0.0;
+        const int ns = n_slots(kChipThreads);
+        for (int i = 0; i < ns; ++i) x2 += red[i];
+        if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
+        a.lnl[b] = -0.5 * x2;
+      }
+      __syncthreads();
+    }
   }
 #endif
 }
