@@ -112,6 +112,32 @@ __device__ __forceinline__ void pk_cmul2(pk2& a, pk2 wa, pk2& b, pk2 wb) {
       "v_pk_fma_f32 %1, %1, %5, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
       : "+v"(a), "+v"(b), "=&v"(t), "=&v"(s) : "v"(wa), "v"(wb));
 }
+// nan_to_num(nan = 1.0) of eight shifted fluxes (NaN -> 0, smoothing.py:138).  The compiler's form of one -- v_cmp_o into vcc, the
+// two wait states a vector read of a freshly written condition register needs (s_nop 1), v_cndmask -- costs a wave 20 ticks, four
+// instructions' worth (tools/exp/nop_rate.hip).  Eight comparisons into eight scalar register pairs, then eight selects: two
+// instructions a value, the wait states covered by the comparisons in between.
+__device__ __forceinline__ void nan_scrub8(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float& a6, float& a7) {
+  unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+  asm("v_cmp_o_f32 %8, %0, %0\n\t" "v_cmp_o_f32 %9, %1, %1\n\t" "v_cmp_o_f32 %10, %2, %2\n\t" "v_cmp_o_f32 %11, %3, %3\n\t"
+      "v_cmp_o_f32 %12, %4, %4\n\t" "v_cmp_o_f32 %13, %5, %5\n\t" "v_cmp_o_f32 %14, %6, %6\n\t" "v_cmp_o_f32 %15, %7, %7\n\t"
+      "v_cndmask_b32 %0, 0, %0, %8\n\t" "v_cndmask_b32 %1, 0, %1, %9\n\t" "v_cndmask_b32 %2, 0, %2, %10\n\t" "v_cndmask_b32 %3, 0, %3, %11\n\t"
+      "v_cndmask_b32 %4, 0, %4, %12\n\t" "v_cndmask_b32 %5, 0, %5, %13\n\t" "v_cndmask_b32 %6, 0, %6, %14\n\t" "v_cndmask_b32 %7, 0, %7, %15"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+        "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7));
+}
+// (a, b) *= (wa la, wb lb): the two table products and the two data products in ONE statement (wa, wb come back as the products)
+__device__ __forceinline__ void pk_cmul2x2(pk2& a, pk2& b, pk2& wa, pk2 la, pk2& wb, pk2 lb) {
+  pk2 t, s;
+  asm("v_pk_mul_f32 %4, %2, %6 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %5, %3, %7 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %2, %2, %6, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+      "v_pk_fma_f32 %3, %3, %7, %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+      "v_pk_mul_f32 %4, %0, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %5, %1, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %0, %2, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+      "v_pk_fma_f32 %1, %1, %3, %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+      : "+v"(a), "+v"(b), "+v"(wa), "+v"(wb), "=&v"(t), "=&v"(s) : "v"(la), "v"(lb));
+}
 // a (c - i s) with the constant pair cs = (c, s) in scalar registers: (a.x c + a.y s, a.y c - a.x s)
 __device__ __forceinline__ pk2 pk_cmul_k(pk2 a, pk2 cs) {
   pk2 t, r;
@@ -242,24 +268,43 @@ __device__ __forceinline__ void pk_dft4(pk2& a0, pk2& a1, pk2& a2, pk2& a3) {
       "v_pk_add_f32 %2, %4, %5 neg_lo:[0,1] neg_hi:[0,1]"                               // a2 = t0 - t2
       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t2));
 }
+// ONE statement (26 instructions): between two dependent statements the compiler puts an `s_nop` -- it cannot see that the first one
+// writes whole registers --, and an s_nop costs a wave 3.7 of the ~5 ticks a vector instruction costs it (tools/exp/nop_rate.hip);
+// the two half-transforms are interleaved instruction by instruction so that nothing sits next to what it depends on (a dependent
+// neighbour waits 3.3 ticks more).
 __device__ __forceinline__ void pk_dft8(pk2* u) {
   pk2 e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
-  pk_dft4(e0, e1, e2, e3); pk_dft4(o0, o1, o2, o3);
   const pk2 hh = {0.70710678118654752f, 0.70710678118654752f};
-  pk2 tA, tB;
-  asm("v_pk_add_f32 %6, %4, %4 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // s1 = o1 (1 - i)
-      "v_pk_add_f32 %7, %5, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // s3 = o3 (1 + i)
-      "v_pk_fma_f32 %4, %6, %10, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"                // u5 = e1 - h s1    (in o1's place)
-      "v_pk_fma_f32 %1, %6, %10, %1\n\t"                                              // u1 = e1 + h s1
-      "v_pk_fma_f32 %5, %7, %10, %3\n\t"                                              // u7 = e3 + h s3    (in o3's place)
-      "v_pk_fma_f32 %3, %7, %10, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"                // u3 = e3 - h s3
-      "v_pk_add_f32 %6, %0, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // u4 = e0 - o0
-      "v_pk_add_f32 %0, %0, %8\n\t"                                                   // u0 = e0 + o0
-      "v_pk_add_f32 %7, %2, %9 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // u6 = e2 + i o2
-      "v_pk_add_f32 %2, %2, %9 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"               // u2 = e2 - i o2
-      : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o1), "+v"(o3), "=&v"(tA), "=&v"(tB)
-      : "v"(o0), "v"(o2), "s"(hh));
-  u[0] = e0; u[1] = e1; u[2] = e2; u[3] = e3; u[4] = tA; u[5] = o1; u[6] = tB; u[7] = o3;
+  pk2 tA, tB, tC, tD;
+  asm("v_pk_add_f32 %8, %0, %2\n\t"                                                   // TE0 = e0 + e2
+      "v_pk_add_f32 %10, %4, %6\n\t"                                                  // TO0 = o0 + o2
+      "v_pk_add_f32 %9, %1, %3\n\t"                                                   // TE2 = e1 + e3
+      "v_pk_add_f32 %11, %5, %7\n\t"                                                  // TO2 = o1 + o3
+      "v_pk_add_f32 %2, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // e2 := e0 - e2
+      "v_pk_add_f32 %6, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // o2 := o0 - o2
+      "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // e3 := e1 - e3
+      "v_pk_add_f32 %7, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // o3 := o1 - o3
+      "v_pk_add_f32 %0, %8, %9\n\t"                                                   // E0 = TE0 + TE2
+      "v_pk_add_f32 %4, %10, %11\n\t"                                                 // O0 = TO0 + TO2
+      "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // E1 = e2 - i e3
+      "v_pk_add_f32 %5, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // O1 = o2 - i o3
+      "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // E3 = e2 + i e3
+      "v_pk_add_f32 %7, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // O3 = o2 + i o3
+      "v_pk_add_f32 %2, %8, %9 neg_lo:[0,1] neg_hi:[0,1]\n\t"                         // E2 = TE0 - TE2
+      "v_pk_add_f32 %6, %10, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"                       // O2 = TO0 - TO2
+      "v_pk_add_f32 %8, %5, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // s1 = O1 (1 - i)
+      "v_pk_add_f32 %9, %7, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"         // s3 = O3 (1 + i)
+      "v_pk_add_f32 %10, %0, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"                        // u4 = E0 - O0
+      "v_pk_add_f32 %0, %0, %4\n\t"                                                   // u0 = E0 + O0
+      "v_pk_fma_f32 %5, %8, %12, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"                // u5 = E1 - h s1    (in O1's place)
+      "v_pk_fma_f32 %1, %8, %12, %1\n\t"                                              // u1 = E1 + h s1
+      "v_pk_add_f32 %11, %2, %6 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"        // u6 = E2 + i O2
+      "v_pk_add_f32 %2, %2, %6 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"         // u2 = E2 - i O2
+      "v_pk_fma_f32 %7, %9, %12, %3\n\t"                                              // u7 = E3 + h s3    (in O3's place)
+      "v_pk_fma_f32 %3, %9, %12, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]"                       // u3 = E3 - h s3
+      : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "=&v"(tA), "=&v"(tB), "=&v"(tC), "=&v"(tD)
+      : "s"(hh));
+  u[0] = e0; u[1] = e1; u[2] = e2; u[3] = e3; u[4] = tC; u[5] = o1; u[6] = tD; u[7] = o3;
 }
 __device__ __forceinline__ void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
   pk2 p0 = to_pk(a0), p1 = to_pk(a1), p2 = to_pk(a2), p3 = to_pk(a3);

@@ -283,7 +283,7 @@ PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool&
   if constexpr (ex_chip<Ex>::value) {
     if (rs) {                                                // the instrumental stage: its load resamples `src0` itself
       __shared__ ChipResample R;                             // (handed to the out-of-line stage through LDS)
-      if (threadIdx.x == 0) { R.rsA = rs->rsA; R.rsBm = rs->rsB + kPosMagic; R.hs = rs->hs_ann; R.i0 = rs->i0; R.i1 = rs->i1; }
+      if (threadIdx.x == 0) R = chip_resample_of(*rs);
       __syncthreads();
       chip_conv<VSINI>(ex.L, src0, work, ta, false, edge, (int)threadIdx.x, &R);
     } else {
@@ -420,10 +420,7 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const Po
       ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec[0]); phase_rot_edges(t, T.npix, spec[1]); });
     }
     // ---- instrumental stage: each candidate's own window (mask, Doppler shift, pow-2 log grid), gathered while loading
-    if (tid < 2) {
-      const Window& W = S2[tid].W;
-      R2[tid].rsA = W.rsA; R2[tid].rsBm = W.rsB + kPosMagic; R2[tid].hs = W.hs_ann; R2[tid].i0 = W.i0; R2[tid].i1 = W.i1;
-    }
+    if (tid < 2) R2[tid] = chip_resample_of(S2[tid].W);
     __syncthreads();
     ta[0].g_c2 = S2[0].W.g_c2; ta[1].g_c2 = S2[1].W.g_c2;
     float* conv[2] = {spec[0] == buf[0][1] ? buf[0][0] : buf[0][1], spec[1] == buf[1][1] ? buf[1][0] : buf[1][1]};

@@ -224,15 +224,20 @@ __device__ __forceinline__ void chip_mul2(c32& a, c32 wa, c32& b, c32 wb) {
   pk_cmul2(pa, to_pk(wa), pb, to_pk(wb));
   a = un_pk(pa); b = un_pk(pb);
 }
+// (a, b) *= (wa la, wb lb) -- a two-table twiddle and its application as one statement (pk_cmul2x2)
+__device__ __forceinline__ void chip_mul2x2(c32& a, c32& b, c32 wa, c32 la, c32 wb, c32 lb) {
+  pk2 pa = to_pk(a), pb = to_pk(b), pwa = to_pk(wa), pwb = to_pk(wb);
+  pk_cmul2x2(pa, pb, pwa, to_pk(la), pwb, to_pk(lb));
+  a = un_pk(pa); b = un_pk(pb);
+}
 template <bool PERM>
 __device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_32768^(t k1) = W_65536^(2 t k1)
   const int vt = chip_fresh(vt_);
 #pragma unroll
   for (int k1 = 1; k1 < 31; k1 += 2) {
     const int e0 = (2 * vt * k1) & 65535, e1 = (2 * vt * (k1 + 1)) & 65535;
-    c32 w0 = ldc(L.w1024, (e0 >> 6) & 1023), w1 = ldc(L.w1024, (e1 >> 6) & 1023);
-    chip_mul2(w0, ldc(L.wfine, e0 & 63), w1, ldc(L.wfine, e1 & 63));
-    chip_mul2(u[chip_pos(PERM, k1)], w0, u[chip_pos(PERM, k1 + 1)], w1);
+    chip_mul2x2(u[chip_pos(PERM, k1)], u[chip_pos(PERM, k1 + 1)], ldc(L.w1024, (e0 >> 6) & 1023), ldc(L.wfine, e0 & 63),
+                ldc(L.w1024, (e1 >> 6) & 1023), ldc(L.wfine, e1 & 63));
     if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);        // four twiddles (eight table reads) in flight at a time
   }
   u[chip_pos(PERM, 31)] = cmul(u[chip_pos(PERM, 31)], chip_w65536(L, (2 * vt * 31) & 65535));
@@ -363,26 +368,50 @@ __device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 
 // R_resample_loop of post_core.hpp, geometric grids): with `rs` the stage's load gathers and interpolates its points itself
 // (positions by one fp64 fma each, as there) instead of reading a resampled copy a phase of its own wrote -- two transfers of
 // the spectrum and one phase fewer.
-struct ChipResample { double rsA, rsBm; float hs; int i0, i1; };
-__device__ __forceinline__ void chip_gather(const float* __restrict__ spec, const ChipResample& R, int vt, c32 (&u)[32]) {
+// tlo / thi: the positions (+ kPosMagic) of the window's first pixel and of "just below its last" -- a position clamped to
+// [tlo, thi] has its integer part in [i0, i1 - 2] and its fraction in [0, 1): what magic_locate's integer clamps and exponent
+// test produce, for two instructions instead of a dozen (positions of a valid window are finite: a window that is not is `bad`)
+struct ChipResample { double rsA, rsBm, tlo, thi; float hs; int i0, i1; };
+__device__ __forceinline__ ChipResample chip_resample_of(const Window& W) {
+  ChipResample R;
+  R.rsA = W.rsA; R.rsBm = W.rsB + kPosMagic; R.hs = W.hs_ann; R.i0 = W.i0; R.i1 = W.i1;
+  R.tlo = kPosMagic + (double)W.i0;
+  R.thi = kPosMagic + (double)(W.i1 - 1) - 2.3283064365386963e-10;       // one position ulp (2^-32) below the last pixel
+  return R;
+}
+// STRIDE: complex points between two registers of a virtual thread (1024: one 65 536-point spectrum; 512: one of two 32 768-point ones)
+template <int STRIDE>
+__device__ __forceinline__ void chip_gather_t(const float* __restrict__ spec, const ChipResample& R, int vt, c32 (&u)[32]) {
+  const double step = (double)(2 * STRIDE) * R.rsA;                 // real points 2 n and 2 n + 1 of n = vt + STRIDE a
+  double te = fma((double)(2 * vt), R.rsA, R.rsBm), to = fma((double)(2 * vt + 1), R.rsA, R.rsBm);
 #pragma unroll
   for (int a0 = 0; a0 < 32; a0 += 4) {                              // four complex points (sixteen gathers) at a time
     float va[8], vb[8], vw[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int j = 2 * (vt + 1024 * (a0 + (q >> 1))) + (q & 1);
-      int k; float ww;
-      magic_locate(fma((double)j, R.rsA, R.rsBm), R.i0, R.i1, R.hs, k, ww);
-      va[q] = spec[k]; vb[q] = spec[k + 1]; vw[q] = ww;
+      double& t = (q & 1) ? to : te;
+      union { double d; unsigned long long u; } cv;
+      cv.d = fmin(fmax(t, R.tlo), R.thi);
+      t += step;                                                    // (thirty-two roundings of 2^-33 pixel: nothing)
+      const int k = (int)((unsigned)(cv.u >> 32) & 0x7FFFFu);
+      const float f = (float)(unsigned)cv.u * 2.3283064365386963e-10f;
+      vw[q] = f * (1.0f + R.hs * (f - 1.0f));
+      va[q] = spec[k]; vb[q] = spec[k + 1];
     }
+    nan_scrub8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);      // nan_to_num, smoothing.py:138
+    nan_scrub8(vb[0], vb[1], vb[2], vb[3], vb[4], vb[5], vb[6], vb[7]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float a0_ = nan_to_zero(va[2 * q]), b0_ = nan_to_zero(vb[2 * q]), a1_ = nan_to_zero(va[2 * q + 1]), b1_ = nan_to_zero(vb[2 * q + 1]);
-      u[a0 + q] = {a0_ + (b0_ - a0_) * vw[2 * q], a1_ + (b1_ - a1_) * vw[2 * q + 1]};    // nan_to_num, smoothing.py:138
+      u[a0 + q] = {va[2 * q] + (vb[2 * q] - va[2 * q]) * vw[2 * q], va[2 * q + 1] + (vb[2 * q + 1] - va[2 * q + 1]) * vw[2 * q + 1]};
       f2v t; t.x = u[a0 + q].x; t.y = u[a0 + q].y; asm volatile("" : "+v"(t)); u[a0 + q] = {t.x, t.y};
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+// NaN -> 0 on all sixty-four values of a virtual thread's share
+__device__ __forceinline__ void chip_scrub(c32 (&u)[32]) {
+#pragma unroll
+  for (int a = 0; a < 32; a += 4) nan_scrub8(u[a].x, u[a].y, u[a + 1].x, u[a + 1].y, u[a + 2].x, u[a + 2].y, u[a + 3].x, u[a + 3].y);
 }
 template <bool VSINI>
 __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* __restrict__ in, float* __restrict__ out, const TaperArgs ta,
@@ -394,8 +423,8 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
   c32 u0[32], u1[32];
   if (rs) {
     const ChipResample R = *rs;
-    chip_gather(in, R, vt0, u0);
-    chip_gather(in, R, vt0 + 32, u1);
+    chip_gather_t<1024>(in, R, vt0, u0);
+    chip_gather_t<1024>(in, R, vt0 + 32, u1);
   } else {
   // (uniform base + the thread's 32-bit offset: the 64 addresses live in scalar registers, not in 128 vector ones)
 #pragma unroll
@@ -406,13 +435,7 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
     u0[a] = {v.x, v.y}; u1[a] = {w.x, w.y};
   }
   }
-  if (scrub && !rs) {
-#pragma unroll
-    for (int a = 0; a < 32; ++a) {
-      u0[a] = {nan_to_zero(u0[a].x), nan_to_zero(u0[a].y)};
-      u1[a] = {nan_to_zero(u1[a].x), nan_to_zero(u1[a].y)};
-    }
-  }
+  if (scrub && !rs) { chip_scrub(u0); chip_scrub(u1); }
   chip_pin(u0); chip_pin(u1);
   chip_fft_fwd(L, u0, u1, vt0);
   chip_taper<VSINI>(L, u0, u1, vt0, ta);

@@ -104,9 +104,8 @@ __device__ __forceinline__ void chip2_tw1(const ChipLds& L, c32 (&u)[32], int vt
 #pragma unroll
   for (int k1 = 1; k1 < 31; k1 += 2) {
     const int e0 = (t2 * k1) & 32767, e1 = (t2 * (k1 + 1)) & 32767;
-    c32 w0 = ldc(L.w1024, (e0 >> 5) & 1023), w1 = ldc(L.w1024, (e1 >> 5) & 1023);
-    chip_mul2(w0, ldc(L.wfine, e0 & 31), w1, ldc(L.wfine, e1 & 31));
-    chip_mul2(u[chip_pos(PERM, k1)], w0, u[chip_pos(PERM, k1 + 1)], w1);
+    chip_mul2x2(u[chip_pos(PERM, k1)], u[chip_pos(PERM, k1 + 1)], ldc(L.w1024, (e0 >> 5) & 1023), ldc(L.wfine, e0 & 31),
+                ldc(L.w1024, (e1 >> 5) & 1023), ldc(L.wfine, e1 & 31));
     if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   u[chip_pos(PERM, 31)] = cmul(u[chip_pos(PERM, 31)], chip2_w32768(L, (t2 * 31) & 32767));
@@ -221,28 +220,6 @@ __device__ __forceinline__ void chip2_taper(const ChipLds& L, c32 (&u0)[32], c32
   __syncthreads();
 }
 
-// the instrumental stage's own input: candidate c's masked, Doppler-shifted spectrum resampled onto its pow-2 log grid while loading
-__device__ __forceinline__ void chip2_gather(const float* __restrict__ spec, const ChipResample& R, int tp, c32 (&u)[32]) {
-#pragma unroll
-  for (int a0 = 0; a0 < 32; a0 += 4) {
-    float va[8], vb[8], vw[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = 2 * (tp + 512 * (a0 + (q >> 1))) + (q & 1);
-      int k; float ww;
-      magic_locate(fma((double)j, R.rsA, R.rsBm), R.i0, R.i1, R.hs, k, ww);
-      va[q] = spec[k]; vb[q] = spec[k + 1]; vw[q] = ww;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float a0_ = nan_to_zero(va[2 * q]), b0_ = nan_to_zero(vb[2 * q]), a1_ = nan_to_zero(va[2 * q + 1]), b1_ = nan_to_zero(vb[2 * q + 1]);
-      u[a0 + q] = {a0_ + (b0_ - a0_) * vw[2 * q], a1_ + (b1_ - a1_) * vw[2 * q + 1]};
-      f2v t; t.x = u[a0 + q].x; t.y = u[a0 + q].y; asm volatile("" : "+v"(t)); u[a0 + q] = {t.x, t.y};
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 struct Chip2Io { const float* in[2]; float* out[2]; };
 // One stage of BOTH candidates: input (real, global) -> registers -> convolution -> output (real, global).  rs: the two resampling
 // windows (LDS) when the stage gathers its own input, else null.
@@ -259,8 +236,8 @@ __device__ __attribute__((noinline)) void chip2_conv(const ChipLds L, const Chip
   c32 u0[32], u1[32];
   if (rs) {
     const ChipResample R = rs[c];
-    chip2_gather(in, R, tp0, u0);
-    chip2_gather(in, R, tp0 + 32, u1);
+    chip_gather_t<512>(in, R, tp0, u0);                             // (candidate c's masked, Doppler-shifted spectrum onto its pow-2 log grid)
+    chip_gather_t<512>(in, R, tp0 + 32, u1);
   } else {
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
@@ -270,13 +247,7 @@ __device__ __attribute__((noinline)) void chip2_conv(const ChipLds L, const Chip
       u0[a] = {v.x, v.y}; u1[a] = {w.x, w.y};
     }
   }
-  if (scrub && !rs) {
-#pragma unroll
-    for (int a = 0; a < 32; ++a) {
-      u0[a] = {nan_to_zero(u0[a].x), nan_to_zero(u0[a].y)};
-      u1[a] = {nan_to_zero(u1[a].x), nan_to_zero(u1[a].y)};
-    }
-  }
+  if (scrub && !rs) { chip_scrub(u0); chip_scrub(u1); }
   chip_pin(u0); chip_pin(u1);
   chip2_fft_fwd(L, u0, u1, vt0);
   chip2_taper<VSINI>(L, u0, u1, vt0, ta0, ta1);
