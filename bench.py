@@ -364,7 +364,7 @@ def roofline_blocks(cfg_name, res, args):
     big = n1 > 16384
     if big and dom == "post":
         # Spectra larger than LDS.  What binds the kernel depends on its form: payne_post_chip_kernel / payne_post_chip32_kernel keep
-        # a convolution stage on the compute unit (5 transfers of the spectrum) and are bound by VECTOR ISSUE ->
+        # a convolution stage on the compute unit (5 transfers of the spectrum) and are bound by the SIMDs' vector throughput ->
         # `frac` is the algorithmic FLOP rate against the fp32 vector peak; payne_post_big_kernel streams the spectrum through a
         # global workspace 25 times and is HBM/L2-bound -> `frac` is SURVEY 8(d)'s modelled streaming bytes over the measured time.
         # Both figures and the counter rate are printed for either kernel.
@@ -594,7 +594,7 @@ def main():
 
 def eng_round_trips(n1, variant=0):
     """Transfers of the spectrum (4 n1 bytes each, a read or a write) per evaluation.  payne_post_chip_kernel (65 536 points,
-    DESIGN.md 3.4b): the raw row in (1), the rotation stage's result out (1), the instrumental stage's gather of it (1), its
+    DESIGN.md 3.4): the raw row in (1), the rotation stage's result out (1), the instrumental stage's gather of it (1), its
     result out (1), the observed grid's gather (1) = 5.  payne_post_big_kernel (other lengths above 16 384, or
     PAYNE_V_BIG_WORKSPACE): the row in and its copy out (2), per convolution stage the forward and the inverse transform at 2
     transfers per pass (the four-step form has 2 passes, the plain form one per radix-8 pass) + the taper pass (2), the resampling

@@ -200,7 +200,7 @@ def test_three_bf16_parts_hold_an_fp32_value_exactly():
 
 def test_likelihood_post_kernels_keep_two_workgroups_per_cu(tmp_path):
     """The likelihood-only post kernels of the LDS-resident sizes must stay at <= 128 vector registers: at 129 the hardware runs ONE
-    512-thread workgroup per compute unit instead of two and the C2 step loses 6 us (it happened three times while
+    512-thread workgroup per compute unit instead of two and the C2 step loses 6 us (NOTES.md 3.3d; it happened three times while
     unrelated code moved).  Read off the compiler's own resource summary of the unit that holds them."""
     import re
     import subprocess

@@ -2,24 +2,33 @@
 #pragma once
 #include "sampler_core.hpp"
 
-// transform only (mode 0) or transform + ln-prior + theta row (mode 1)
-__global__ void payne_prior_kernel(SamplerDev sd, const double* u, int K, double* v, double* lnprior, double* rows, int mode) {
+// transform only (mode 0) or transform + ln-prior + theta row (mode 1).
+// (No private arrays and no reference to the by-value argument handed to an out-of-line function: the first version kept the
+//  transformed point in a `double vv[PAYNE_MAX_DIM]` indexed by the loop counter and passed `sd.dims[d]` / `sd.adv` by reference to
+//  helpers the compiler did not inline -- the whole 4 KB argument struct was copied to scratch memory, 4 400 bytes and 319 spilled
+//  registers per thread.  The point is read back from `v`, which this thread has just written; the helpers are inlined.)
+__global__ void __launch_bounds__(128) __attribute__((flatten)) payne_prior_kernel(SamplerDev sd, const double* u, int K, double* v, double* lnprior, double* rows, int mode) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= K) return;
-  double vv[PAYNE_MAX_DIM];
+  double* __restrict__ vc = v + (size_t)c * sd.ndim;
   double lp = 0.0;
   for (int d = 0; d < sd.ndim; ++d) {
-    vv[d] = prior_ppf(sd.dims[d], sd.q0[d], sd.q1[d], u[(size_t)c * sd.ndim + d], sd.adv);
-    v[(size_t)c * sd.ndim + d] = vv[d];
-    lp += prior_ln(sd.dims[d], vv[d]);
+    const payne_prior_dim dim = sd.dims[d];
+    const double vd = prior_ppf(dim, sd.q0[d], sd.q1[d], u[(size_t)c * sd.ndim + d], sd.adv);
+    vc[d] = vd;
+    lp += prior_ln(dim, vd);
   }
   if (adv_any(sd.adv)) {
     const payne_adv_priors& a = sd.adv;
-    const double add = adv_lnprior(a, a.dim_logg >= 0 ? vv[a.dim_logg] : a.val_logg, a.dim_logr >= 0 ? vv[a.dim_logr] : a.val_logr,
-                                   a.dim_vrot >= 0 ? vv[a.dim_vrot] : a.val_vrot, a.plx_dim >= 0 ? vv[a.plx_dim] : 1.0);
+    const double add = adv_lnprior(a, a.dim_logg >= 0 ? vc[a.dim_logg] : a.val_logg, a.dim_logr >= 0 ? vc[a.dim_logr] : a.val_logr,
+                                   a.dim_vrot >= 0 ? vc[a.dim_vrot] : a.val_vrot, a.plx_dim >= 0 ? vc[a.plx_dim] : 1.0);
     lp = (lp == -INFINITY || add == -INFINITY) ? -INFINITY : lp + add;
   }
-  if (mode) { lnprior[c] = lp; write_theta_row(sd, vv, rows + (size_t)c * sd.ncols); }
+  if (mode) {
+    lnprior[c] = lp;
+    double* row = rows + (size_t)c * sd.ncols;                    // the theta row by column (col_src / col_val: resolved at sampler creation)
+    for (int q = 0; q < sd.ncols; ++q) { const int src = sd.col_src[q]; row[q] = src >= 0 ? vc[src] : sd.col_val[q]; }
+  }
 }
 // the per-dimension constants of the transforms, by the device's own normcdf / expm1 / log (sampler creation)
 __global__ void payne_prior_cache_kernel(SamplerDev sd, double* q) {
