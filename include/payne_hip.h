@@ -166,6 +166,11 @@ int payne_ctx_set_continuum(payne_ctx* ctx, const payne_model_desc* cont);
  * (np.interp clamps).  NULL removes it; payne_ctx_set_obs removes it too.  Any spectrum length; the FFT length the
  * reference derives from the vector (smoothing.py:533-538) must not exceed the model's own (pow2ceil(npix)): NaN then. */
 int payne_ctx_set_lsf(payne_ctx* ctx, const double* lsf, int n);
+/* The same with the dispersion vector given on wavelengths of its own (HOST fp64 [n], strictly increasing) instead of on the
+ * bound observed grid: smoothspec(wave, spec, resolution=<vector on wave>, outwave=<another grid>, smoothtype='lsf')
+ * (Payne/utils/smoothing.py:125-151: the vector is a function of the INPUT wavelengths there; getspec interpolates it from the
+ * output grid, ystpred.py:255-259).  The dispersion at a model pixel is np.interp of the vector (clamped outside). */
+int payne_ctx_set_lsf_on(payne_ctx* ctx, const double* lsf_wave, const double* lsf, int n);
 
 void payne_ctx_destroy(payne_ctx* ctx);
 
@@ -205,7 +210,10 @@ int payne_predict_batch(payne_ctx* ctx, const double* theta, int B, int stage, u
 /* The broadening stages on caller-supplied spectra: PayneSpecPredict.smoothspec (Payne/predict/ystpred.py:279-281 ->
  * Payne/utils/smoothing.py:19-169, the 'vsini' / 'vel' / 'R' / 'lsf' FFT branches).  spectra: device fp32
  * [B][ld_spec], full flux on the context's model wavelength grid; theta, stage (1..3), flags and out as for
- * payne_predict_batch -- the ANN forward pass is simply replaced by `spectra`. */
+ * payne_predict_batch -- the ANN forward pass is simply replaced by `spectra`.  Stage 4 (PAYNE_SMOOTH_VSINI_TO_OBS):
+ * rotational broadening only, interpolated from the stage's own resampled grid onto the bound observed grid with NaN outside
+ * (smoothspec(smoothtype='vsini', outwave=...), smoothing.py:293-312); out is [B][nobs]. */
+#define PAYNE_SMOOTH_VSINI_TO_OBS 4
 int payne_smooth_batch(payne_ctx* ctx, const float* spectra, int ld_spec, const double* theta, int B, int stage,
                        unsigned flags, float* out, int ld_out, void* stream);
 

@@ -569,8 +569,36 @@ def g14_torchnets_300():
              getspec4=np.array(spec), obs_wave=obs, obs_flux=flux, obs_eflux=eflux)
 
 
+# ------------------------------------------------------------------ G15
+def g15_smoothspec_fft_corners():
+    """smoothspec's FFT branches with the argument combinations the sampler's path never uses (Payne/utils/smoothing.py:19-169):
+    'vsini' onto another grid and with inres; min_wave_smooth / max_wave_smooth (outwave=None: the input restricted, the result back
+    on all of wave); 'lsf' with the vector on the input grid and another output grid.  Same 700-pixel spectrum as g13."""
+    from Payne.utils.smoothing import smoothspec
+    rng = np.random.default_rng(13)
+    wave = 5150.0 * (1.0 + 1.0 / 70000.0) ** np.arange(700)
+    spec = 1.0 - 0.3 * np.exp(-0.5 * ((wave - 5175.0) / 0.15) ** 2) - 0.2 * np.exp(-0.5 * ((wave - 5190.0) / 0.4) ** 2) \
+        + 0.01 * rng.normal(size=700)
+    spec[[100, 431]] = np.nan
+    outwave = np.linspace(5160.0, 5195.0, 300)
+    lsf_on_wave = 0.12 * (1.0 + 0.4 * (wave - wave.mean()) / (wave.max() - wave.min()))
+    lim = dict(min_wave_smooth=5162.0, max_wave_smooth=5193.0)
+    out = dict(wave=wave, spec=spec, outwave=outwave, lsf_on_wave=lsf_on_wave, limits=np.array([lim['min_wave_smooth'], lim['max_wave_smooth']]))
+    with np.errstate(all="ignore"):
+        out["vsini_out"] = smoothspec(wave, spec, 12.0, outwave=outwave, smoothtype='vsini')
+        out["vsini_out_inres"] = smoothspec(wave, spec, 12.0, outwave=outwave, smoothtype='vsini', inres=5.0)
+        out["vsini_native_inres"] = smoothspec(wave, spec, 12.0, smoothtype='vsini', inres=5.0)
+        out["vsini_limits"] = smoothspec(wave, spec, 12.0, smoothtype='vsini', **lim)
+        out["vel_limits"] = smoothspec(wave, spec, 8.0, smoothtype='vel', **lim)
+        out["vel_limits_inres"] = smoothspec(wave, spec, 8.0, smoothtype='vel', inres=3.0, **lim)
+        out["R_limits"] = smoothspec(wave, spec, 30000.0, smoothtype='R', inres=90000.0, **lim)
+        out["lsf_out"] = smoothspec(wave, spec, lsf_on_wave, outwave=outwave, smoothtype='lsf')
+        out["lsf_limits"] = smoothspec(wave, spec, lsf_on_wave, smoothtype='lsf', **lim)
+    save("g15_smoothspec_fft", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for k in which:
         {"g1": g1_ann, "g2": g2_getspec, "g4": g4_lnlike, "g5": g5_sed, "g6": g6_prior, "g7": g7_misc,
-         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows, "g13": g13_smoothspec_branches, "g14": g14_torchnets_300}[k]()
+         "g8": g8_continuum, "g9": g9_lsf, "g10": g10_advanced_priors, "g11": g11_native_grid, "g12": g12_long_rows, "g13": g13_smoothspec_branches, "g14": g14_torchnets_300, "g15": g15_smoothspec_fft_corners}[k]()

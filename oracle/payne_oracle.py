@@ -10,7 +10,7 @@ __all__ = [
     "CKMS", "SIGMA_TO_FWHM", "C_KMS_DOPPLER",
     "leaky_relu", "yst_encode", "yst_forward", "torchnet_forward", "ann_forward",
     "mask_range", "resample_pow2", "taper_vsini", "taper_gauss", "fft_convolve",
-    "smooth_vsini", "smooth_R", "smooth_lsf", "smoothspec_offpath", "getspec", "polycalc", "genspec",
+    "smooth_vsini", "smooth_R", "smooth_lsf", "smoothspec_offpath", "smoothspec_fft", "getspec", "polycalc", "genspec",
     "chi2_spec", "chi2_spec_loop", "fastann_forward", "highav_offset", "sed_mags",
     "genphot", "genphot_scaled", "OracleLikelihood", "lnprobfn",
 ]
@@ -239,6 +239,48 @@ def smoothspec_offpath(wave, spec, resolution, outwave=None, smoothtype='vel', f
         with np.errstate(all="ignore"):
             flux[i] = _trapz(f * _s, x) / _trapz(f, x)
     return flux
+
+
+def smoothspec_fft(wave, spec, resolution, outwave=None, smoothtype='vel', inres=None, min_wave_smooth=0, max_wave_smooth=np.inf):
+    """``smoothspec`` with ``fftsmooth=True`` for smoothtype 'vel' / 'R' / 'vsini' / 'lsf' in general (Payne/utils/smoothing.py:19-169):
+    any ``outwave``, ``inres``, and -- with ``outwave=None`` -- the input restricted by ``min_wave_smooth`` / ``max_wave_smooth`` with the
+    result back on all of ``wave`` (:131-141).  smooth_vel_fft :252-291, smooth_vsini_fft :293-312, smooth_lsf_fft :482-586."""
+    wave, spec = np.asarray(wave, dtype=np.float64), np.asarray(spec, dtype=np.float64)
+    if smoothtype in ('vel', 'vsini'):
+        sigma, width, linear = float(resolution), CKMS / float(resolution), False
+        inres_v = 0.0 if inres is None else float(inres)
+    elif smoothtype == 'R':
+        sigma, width, linear = CKMS / float(resolution), float(resolution), False
+        inres_v = 0.0 if inres is None else CKMS / float(inres)             # :110-115
+    elif smoothtype == 'lsf':
+        sigma, width, linear = np.asarray(resolution, dtype=np.float64), 100, True
+    else:
+        raise ValueError(smoothtype)
+    if outwave is not None:                                                 # mask_wave, :631-647
+        outwave = np.asarray(outwave, dtype=np.float64)
+        wlim = np.array([outwave.min(), outwave.max()])
+    else:
+        wlim = np.squeeze(np.array([min_wave_smooth, max_wave_smooth])).astype(np.float64)
+    wlim = wlim + 20.0 * width * np.array([-1, 1]) if linear else wlim * (1 + 20.0 / width * np.array([-1, 1]))
+    mask = (wave > wlim[0]) & (wave < wlim[1])
+    w, s = wave[mask], np.nan_to_num(spec[mask], nan=1.0)
+    if outwave is None:
+        outwave = wave
+    if smoothtype == 'lsf':                                                 # :143-147, 482-586 (the vector on the INPUT grid, masked with it)
+        sig = sigma[mask]
+        dw = np.gradient(w)
+        cdf = np.cumsum(dw / sig)
+        cdf /= cdf.max()
+        x_per_sigma = np.nanmedian(np.gradient(cdf) / (dw / sig))
+        nx = int(2 ** np.ceil(np.log2(2 / x_per_sigma)))
+        lam = np.interp(np.linspace(0, 1, nx), cdf, w)
+        conv = fft_convolve(np.interp(lam, w, s), taper_gauss(nx, 1.0 / nx, x_per_sigma))
+        return np.interp(outwave, lam, conv)
+    with np.errstate(invalid="ignore"):
+        sig = np.sqrt(sigma ** 2 - inres_v ** 2)
+    wr, sr = resample_pow2(w, s)
+    taper = taper_vsini(len(sr), _grid_dv(wr), sig) if smoothtype == 'vsini' else taper_gauss(len(sr), _grid_dv(wr), sig)
+    return np.interp(outwave, wr, fft_convolve(sr, taper), left=np.nan, right=np.nan)
 
 
 def smooth_lsf(wave, spec, disparr, outwave, pix_per_sigma=2):

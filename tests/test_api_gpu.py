@@ -477,6 +477,30 @@ def test_smoothspec_branches_off_the_sampler_path(tmp_path, golden):
     assert np.nanmax(np.abs(a - b)) < 1e-6
 
 
+def test_smoothspec_fft_branches_with_any_arguments(tmp_path, golden):
+    """The argument combinations of smoothspec's FFT branches that the sampler's path never uses and rounds 1-3 refused: 'vsini' onto
+    another grid and with inres (payne_smooth_batch stage 4: the rotation stage's result interpolated from its own resampled grid),
+    min_wave_smooth / max_wave_smooth (the input restricted, the result back on all of wave, NaN outside), an LSF vector given on
+    the INPUT grid with another output grid (payne_ctx_set_lsf_on) -- against vectors frozen from the reference's smoothspec (g15)."""
+    from thepayne_amd.predict.ystpred import PayneSpecPredict
+    from Payne.utils.smoothing import smoothspec
+    from test_oracle_golden import g15_calls
+    g = golden("g15_smoothspec_fft")
+    raw = synth.make_yst_net(npix=256, H=16, seed=3)
+    PP = PayneSpecPredict(nnpath=_save_yst(tmp_path, raw), NNtype='YST1')
+    for key, kw in g15_calls(g).items():
+        kw = dict(kw)
+        res = kw.pop("resolution")
+        ref = g[key]
+        for fn in (lambda: PP.smoothspec(g["wave"], g["spec"], res, **kw), lambda: smoothspec(g["wave"], g["spec"], res, **kw)):
+            got = fn()
+            assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref)), (key, int(np.isnan(got).sum()), int(np.isnan(ref).sum()))
+            tol = 2e-6 if key.startswith("lsf") else 1e-6                # (the LSF branch's stated allowance, as in test_fuzz_gpu)
+            assert np.nanmax(np.abs(got - ref)) < tol, (key, np.nanmax(np.abs(got - ref)))
+    with pytest.raises(ValueError):                                # limits that keep fewer than 8 input pixels
+        PP.smoothspec(g["wave"], g["spec"], 1e6, smoothtype='R', min_wave_smooth=5170.0, max_wave_smooth=5170.2)   # (~5 pixels kept)
+
+
 def test_two_documented_deviations_from_the_reference(tmp_path):
     """Where this build does NOT do what the reference does, each pinned by name:
     (1) an output grid that misses the Doppler-shifted model entirely: the reference's mask is empty and numpy raises

@@ -259,3 +259,32 @@ def test_g13_smoothspec_branches_off_the_path(golden):
         ref = g[key]
         assert np.array_equal(np.isnan(got), np.isnan(ref)), key
         np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12, equal_nan=True, err_msg=key)
+
+
+def g15_calls(g):
+    """The nine calls of gen_golden.g15_smoothspec_fft_corners: key -> keyword arguments of smoothspec(wave, spec, resolution, ...)."""
+    ow, lsf = g["outwave"], g["lsf_on_wave"]
+    lim = dict(min_wave_smooth=float(g["limits"][0]), max_wave_smooth=float(g["limits"][1]))
+    return {"vsini_out": dict(resolution=12.0, outwave=ow, smoothtype='vsini'),
+            "vsini_out_inres": dict(resolution=12.0, outwave=ow, smoothtype='vsini', inres=5.0),
+            "vsini_native_inres": dict(resolution=12.0, smoothtype='vsini', inres=5.0),
+            "vsini_limits": dict(resolution=12.0, smoothtype='vsini', **lim),
+            "vel_limits": dict(resolution=8.0, smoothtype='vel', **lim),
+            "vel_limits_inres": dict(resolution=8.0, smoothtype='vel', inres=3.0, **lim),
+            "R_limits": dict(resolution=30000.0, smoothtype='R', inres=90000.0, **lim),
+            "lsf_out": dict(resolution=lsf, outwave=ow, smoothtype='lsf'),
+            "lsf_limits": dict(resolution=lsf, smoothtype='lsf', **lim)}
+
+
+def test_g15_smoothspec_fft_branches_in_general(golden):
+    """smoothspec's FFT branches with the argument combinations off the sampler's path ('vsini' onto another grid / with inres,
+    min / max_wave_smooth, an LSF vector on the input grid with another output grid): the restatement against the reference."""
+    g = golden("g15_smoothspec_fft")
+    n_nan = 0
+    for key, kw in g15_calls(g).items():
+        with np.errstate(all="ignore"):
+            got = O.smoothspec_fft(g["wave"], g["spec"], **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(g[key])), key
+        np.testing.assert_allclose(got, g[key], rtol=0, atol=1e-12, equal_nan=True)
+        n_nan += int(np.isnan(g[key]).sum())
+    assert n_nan > 500                                            # the limited calls really leave NaN outside the kept range

@@ -20,7 +20,7 @@ V_OUT_GENERIC, V_POST_GENERIC, V_TW_GLOBAL, V_POST_FULL, V_NO_PREP, V_BIG_PLAIN,
 V_OUT_SMALL_TILES = 16384
 V_NO_WALK_SPEC = 131072
 
-SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_destroy", "payne_last_error",
+SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_set_lsf_on", "payne_ctx_destroy", "payne_last_error",
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name", "payne_last_kernel",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
@@ -127,6 +127,8 @@ def load(path=None):
     lib.payne_ctx_set_obs.restype = C.c_int
     lib.payne_ctx_set_continuum.argtypes = [ctxp, C.POINTER(ModelDesc)]
     lib.payne_ctx_set_continuum.restype = C.c_int
+    lib.payne_ctx_set_lsf_on.argtypes = [ctxp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    lib.payne_ctx_set_lsf_on.restype = C.c_int
     lib.payne_ctx_set_lsf.argtypes = [ctxp, C.POINTER(C.c_double), C.c_int]
     lib.payne_ctx_set_lsf.restype = C.c_int
     lib.payne_smooth_batch.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int,

@@ -101,7 +101,9 @@ struct payne_ctx {
   // optional LSF vector (payne_ctx_set_lsf): dispersion in AA per bound observed pixel; replaces Inst_R
   bool has_lsf = false;
   const double* d_obs_wave = nullptr;   // [nobs] (obs_owned)
-  const double* lsf = nullptr;          // [nobs]
+  const double* lsf = nullptr;          // [n_lsf] dispersions ...
+  const double* lsf_wave = nullptr;     // ... at these wavelengths (the observed grid itself for payne_ctx_set_lsf)
+  int n_lsf = 0;
   float* lsf_spec = nullptr;            // [lsf_chunk][npix] spectra after vsini, shifted
   double* lsf_ws = nullptr;             // [lsf_chunk][2 npix + n1]
   float* lsf_fws = nullptr;             // global form: [lsf_chunk][2 fft_buf_floats(n1)] FFT buffers
@@ -526,7 +528,7 @@ extern "C" int payne_ctx_set_continuum(payne_ctx* c, const payne_model_desc* con
 // LSF vector for the instrumental broadening: `lsf[n]` = Gaussian dispersion (AA) at each pixel of the bound
 // observed grid (getspec(inst_R=array, outwave=...), ystpred.py:248-269).  While set, theta's Inst_R column
 // is ignored.  NULL removes it; re-binding the observed grid removes it too.
-extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) {
+static int set_lsf_impl(payne_ctx* c, const double* lsf_wave, const double* lsf, int n) {
   if (!c) return PAYNE_E_INVALID;
   if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
   int prev = 0;
@@ -539,12 +541,22 @@ extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) {
   auto done = [&](int rc) { if (prev != c->device) (void)hipSetDevice(prev); return rc; };
   if (!lsf) return done(PAYNE_OK);
   if (!c->obs_bound) return done(fail(c, PAYNE_E_INVALID, "bind the observed grid before its LSF vector"));
-  if (n != c->T.nobs) return done(fail(c, PAYNE_E_INVALID, "the LSF vector must have one entry per observed pixel"));
+  if (!lsf_wave && n != c->T.nobs) return done(fail(c, PAYNE_E_INVALID, "the LSF vector must have one entry per observed pixel"));
+  if (lsf_wave && n < 2) return done(fail(c, PAYNE_E_INVALID, "an LSF vector on its own wavelengths needs at least two entries"));
   for (int i = 0; i < n; ++i)
     if (!(lsf[i] > 0.0)) return done(fail(c, PAYNE_E_INVALID, "LSF dispersions must be positive"));
+  if (lsf_wave)
+    for (int i = 1; i < n; ++i)
+      if (!(lsf_wave[i] > lsf_wave[i - 1])) return done(fail(c, PAYNE_E_INVALID, "the LSF vector's wavelengths must be strictly increasing"));
   std::vector<double> v(lsf, lsf + n);
   int rc;
   if ((rc = upload(c, v, &c->lsf, c->lsf_owned))) return done(rc);
+  c->n_lsf = n;
+  c->lsf_wave = c->d_obs_wave;
+  if (lsf_wave) {
+    std::vector<double> w(lsf_wave, lsf_wave + n);
+    if ((rc = upload(c, w, &c->lsf_wave, c->lsf_owned))) return done(rc);
+  }
   c->lsf_global = c->T.n1 > 8192 || (c->opts.variant & PAYNE_V_LSF_GLOBAL);
   c->lsf_chunk = c->lsf_global ? std::min(c->opts.b_max, 256) : c->opts.b_max;
   if ((rc = dev_alloc(c, (size_t)c->lsf_chunk * c->T.npix, &c->lsf_spec, c->lsf_owned, false))) return done(rc);
@@ -558,6 +570,11 @@ extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) {
   }
   c->has_lsf = true;
   return done(PAYNE_OK);
+}
+extern "C" int payne_ctx_set_lsf(payne_ctx* c, const double* lsf, int n) { return set_lsf_impl(c, nullptr, lsf, n); }
+extern "C" int payne_ctx_set_lsf_on(payne_ctx* c, const double* lsf_wave, const double* lsf, int n) {
+  if (c && lsf && !lsf_wave) return fail(c, PAYNE_E_INVALID, "lsf_wave is NULL");
+  return set_lsf_impl(c, lsf_wave, lsf, n);
 }
 
 // ---- launches --------------------------------------------------------------
@@ -970,7 +987,7 @@ static int run_post_lsf(payne_ctx* c, const double* theta, int B, int stage, flo
     if (rc) return rc;
     LsfArgs a{};
     a.theta = th; a.ld_theta = c->ncols; a.spec = c->lsf_spec; a.ld_spec = c->T.npix;
-    a.obs_wave = c->d_obs_wave; a.lsf = c->lsf;
+    a.obs_wave = c->d_obs_wave; a.lsf = c->lsf; a.lsf_wave = c->lsf_wave; a.n_lsf = c->n_lsf;
     a.ws = c->lsf_ws; a.ws_stride = 2 * (size_t)c->T.npix + c->T.n1;
     a.fws = c->lsf_fws; a.fws_stride = 2 * (size_t)fft_buf_floats(c->T.n1);
     a.out = out ? out + (size_t)off * ld_out : nullptr; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl ? lnl + off : nullptr;
@@ -1054,7 +1071,8 @@ extern "C" int payne_smooth_batch(payne_ctx* c, const float* spectra, int ld_spe
   if (rc) return rc;
   if (!spectra) return fail(c, PAYNE_E_INVALID, "spectra is NULL");
   if (!c->has_model) return fail(c, PAYNE_E_INVALID, "context has no spectral model");
-  if (stage < 1 || stage > 3) return fail(c, PAYNE_E_INVALID, "stage must be 1..3");
+  if (stage < 1 || stage > 4) return fail(c, PAYNE_E_INVALID, "stage must be 1..4");
+  if (stage == PAYNE_SMOOTH_VSINI_TO_OBS && c->has_lsf) return fail(c, PAYNE_E_INVALID, "stage 4 with an LSF vector bound");
   if (ld_spec < c->T.npix) return fail(c, PAYNE_E_INVALID, "ld_spec too small");
   if (stage >= 2 && !c->obs_bound) return fail(c, PAYNE_E_INVALID, "no observed grid bound");
   if (ld_out < (stage >= 2 ? c->T.nobs : c->T.npix)) return fail(c, PAYNE_E_INVALID, "ld_out too small");
@@ -1063,7 +1081,9 @@ extern "C" int payne_smooth_batch(payne_ctx* c, const float* spectra, int ld_spe
   hipLaunchKernelGGL(payne_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spectra, ld_spec, c->raw, c->T.npix, B);
   c->prep_valid = false;                                   // no dense launch wrote records for these rows
   // stage 1 here is smoothspec('vsini') itself: getspec's edge rule (ystpred.py:223-224) is not part of it
-  return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage == 1 ? 6 : stage, out, ld_out, nullptr, false, s);
+  // stage 4: ... interpolated from the stage's own resampled grid onto the bound observed grid (smoothspec('vsini', outwave=...))
+  return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage == 1 ? 6 : (stage == PAYNE_SMOOTH_VSINI_TO_OBS ? 7 : stage), out, ld_out,
+                  nullptr, false, s);
 }
 
 extern "C" int payne_sed_batch(payne_ctx* c, const double* pars, int B, double* mags, void* stream) {

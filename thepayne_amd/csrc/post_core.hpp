@@ -1514,10 +1514,12 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
+// force_grid: `conv` lives on the uniform log grid W describes whatever S.do_smooth says (the rotation stage's own resampled grid:
+// smoothspec('vsini', outwave=...), smoothing.py:293-312)
 template <int OU = 16>
 PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
-                          const float* __restrict__ conv, float* __restrict__ out, int out_stage) {
-  const bool cheb = T.npoly > 0, hasf = T.obs_f1 != nullptr, smooth = S.do_smooth != 0;
+                          const float* __restrict__ conv, float* __restrict__ out, int out_stage, bool force_grid = false) {
+  const bool cheb = T.npoly > 0 && !force_grid, hasf = T.obs_f1 != nullptr, smooth = S.do_smooth != 0 || force_grid;
   if (!out && !hasf) return 0.0;                         // nothing to produce
   if (smooth && W.bad) {                                 // window too small: every pixel NaN
     if (out) for (int i = tid; i < T.nobs; i += nthr) out[i] = nanf_();

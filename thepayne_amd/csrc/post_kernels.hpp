@@ -460,7 +460,8 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const Po
 struct LsfArgs {
   const double* theta; int ld_theta;
   const float* spec; int ld_spec;        // [B][npix] after vsini, shifted
-  const double* obs_wave; const double* lsf; // [nobs]
+  const double* obs_wave;                // [nobs]
+  const double* lsf_wave; const double* lsf; int n_lsf;   // the dispersion vector and its abscissa ([n_lsf]; getspec: the observed grid itself)
   double* ws; size_t ws_stride;          // per candidate: a[npix] | cdf[npix] | lam[n1]
   float* fws; size_t fws_stride;         // GLOBAL form: per candidate the two FFT buffers (2 x fft_buf_floats(n1) floats)
   float* out; int ld_out; int out_stage; // 2 / 3 / -1
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(256) payne_lsf_kernel(const PostTables T, LsfA
   if (!bad) {
     // ---- sigma_i (disparr = np.interp(modwave, outwave, inst_R)), r_i = gradient(w)_i / sigma_i
     for (int i = tid; i < n; i += 256) {
-      const double sig = interp_np(W(i), a.obs_wave, a.lsf, nobs);
+      const double sig = interp_np(W(i), a.lsf_wave, a.lsf, a.n_lsf);
       const double dw = (i == 0) ? (W(1) - W(0)) : ((i == n - 1) ? (W(n - 1) - W(n - 2)) : (W(i + 1) - W(i - 1)) / 2.0);
       wsA[i] = dw / sig;
     }

@@ -194,6 +194,7 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
 }
 
 // out_stage: -1 chi^2 only | 0 raw ANN | 1 after vsini | 2 getspec on obs grid | 3 genspec (x blaze) | 5 after vsini, shifted | 6 after vsini, without the spec[0]=spec[1] edge rule
+//            | 7 after vsini, interpolated from the stage's own resampled grid onto the OBSERVED grid (NaN outside): smoothspec('vsini', outwave=...)
 // `early`: called by every thread in the first phase once ALL of the phase's global loads have been requested (the row, the
 // record, theta) and before any of them is waited for -- the caller's own start-up traffic (the LDS kernel's twiddle table and
 // photometric terms, requested before this function) is committed there, so its round trip and the row's are ONE round trip.
@@ -243,8 +244,15 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
     // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
     // transform's last pass can apply the edge rule itself
-    bool edge = T.rot_identity != 0 && out_stage != 6;   // 6 = smoothspec('vsini') itself: no edge rule
+    bool edge = T.rot_identity != 0 && out_stage != 6 && out_stage != 7;   // 6, 7 = smoothspec('vsini') itself: no edge rule
     float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge, fused_row ? raw : nullptr);
+    if (out_stage == 7) {
+      // np.interp(outwave, w_resampled, conv, left = right = NaN) (smoothing.py:308-311): the resampled grid is resample_wave of the
+      // WHOLE model grid -- the window of "no mask, no shift"
+      const Window Wv = window_from_counts(T, 0.0, 0.0, 0, T.npix);
+      ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, Wv, conv, out, 2, true), red); });
+      return;
+    }
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
     else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = out_stage != 6; }
@@ -255,6 +263,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
       edges_pending = false;
     }
+  }
+  if (out_stage == 7) {                                       // (no rotation: the reference's taper is 0 / 0 there -- NaN everywhere)
+    ex.par([&](int t, int n) { for (int i = t; i < T.nobs; i += n) out[i] = nanf_(); });
+    return;
   }
   if (out_stage == 1 || out_stage == 5 || out_stage == 6) {   // 5: still shifted by -1 (input of the LSF kernel); 6: no edge rule
     const float base = out_stage == 5 ? 0.f : kBase;

@@ -186,7 +186,7 @@ class PayneEngine(object):
         t = self._theta(theta, self.ncols)
         B = t.shape[0]
         sp = self.torch.as_tensor(np.ascontiguousarray(spectra, dtype=np.float32)).to(self.device).reshape(B, self.npix)
-        n_out = self.npix if stage < 2 else self.nobs
+        n_out = self.npix if stage < 2 else self.nobs          # (stage 4: rotational broadening onto the observed grid)
         out = self.torch.empty((B, n_out), dtype=self.torch.float32, device=self.device)
         for s in range(0, B, self.b_max):
             n = min(self.b_max, B - s)
@@ -196,11 +196,17 @@ class PayneEngine(object):
                 self._err(rc, "payne_smooth_batch")
         return out
 
-    def set_lsf(self, lsf):
-        """Bind an LSF vector (dispersion per pixel of the bound observed grid) or, with None, remove it
-        (payne_ctx_set_lsf).  While set, theta's Inst_R column is ignored."""
+    def set_lsf(self, lsf, wave=None):
+        """Bind an LSF vector (dispersion per pixel of the bound observed grid, or -- with `wave` -- at wavelengths of its
+        own: payne_ctx_set_lsf_on) or, with None, remove it (payne_ctx_set_lsf).  While set, theta's Inst_R column is ignored."""
         if lsf is None:
             rc = self.lib.payne_ctx_set_lsf(self._ctx, None, 0)
+        elif wave is not None:
+            a = np.ascontiguousarray(lsf, dtype=np.float64)
+            w = np.ascontiguousarray(wave, dtype=np.float64)
+            if len(a) != len(w):
+                raise ValueError("the LSF vector and its wavelengths differ in length")
+            rc = self.lib.payne_ctx_set_lsf_on(self._ctx, w.ctypes.data_as(C.POINTER(C.c_double)), a.ctypes.data_as(C.POINTER(C.c_double)), len(a))
         else:
             a = np.ascontiguousarray(lsf, dtype=np.float64)
             rc = self.lib.payne_ctx_set_lsf(self._ctx, a.ctypes.data_as(C.POINTER(C.c_double)), len(a))

@@ -193,17 +193,38 @@ class PayneSpecPredict(object):
             raise NotImplementedError("smoothtype=%r (the reference knows 'vel', 'vsini', 'R', 'lambda', 'lsf')" % (smoothtype,))
         if smoothtype == 'lambda' or (not kwargs.get('fftsmooth', True) and smoothtype != 'vsini'):
             return self._smoothspec_direct(wave, spec, sigma, outwave, smoothtype, dict(kwargs))
-        if kwargs.get('min_wave_smooth', 0) != 0 or kwargs.get('max_wave_smooth', np.inf) != np.inf:
-            raise NotImplementedError("min_wave_smooth / max_wave_smooth with the FFT branches are not built")
         wave = np.ascontiguousarray(wave, dtype=np.float64)
         spec = np.asarray(spec, dtype=np.float64)
         ckms = 2.998e5                                                       # smoothing.py:16
         inres = kwargs.get('inres', None)
         r_in = np.inf
+        # What smoothspec does before it calls the smoothing function is argument preparation and stays here (as in
+        # _smoothspec_direct): with outwave=None, min_wave_smooth / max_wave_smooth restrict the INPUT (mask_wave, smoothing.py:131-135,
+        # 631-647) and the result comes back on all of `wave` (:140-141), NaN outside the kept range.
+        wlo, whi = kwargs.get('min_wave_smooth', 0), kwargs.get('max_wave_smooth', np.inf)
+        limited = outwave is None and (wlo != 0 or whi != np.inf)
+        ow = None if outwave is None else np.ascontiguousarray(outwave, dtype=np.float64)
+
+        def masked(width, linear, by_out):
+            """wave / spec inside mask_wave's limits: from outwave (by_out) or from min / max_wave_smooth."""
+            wlim = np.array([ow.min(), ow.max()]) if by_out else np.squeeze(np.array([wlo, whi])).astype(np.float64)
+            wlim = wlim + 20.0 * float(width) * np.array([-1, 1]) if linear else wlim * (1 + 20.0 / width * np.array([-1, 1]))
+            m = (wave > wlim[0]) & (wave < wlim[1])
+            if m.sum() < 8:
+                raise ValueError("fewer than 8 input pixels inside the smoothing limits")
+            return m
+        lsf_wave = None
         if smoothtype == 'vsini':
-            if outwave is not None or (inres not in (None, 0, 0.0)):
-                raise NotImplementedError("smoothtype='vsini' is built for outwave=None, inres=0 (as getspec calls it)")
-            th_R, th_rot, stage = np.nan, float(sigma), 1
+            sig = float(sigma)
+            sig_eff = float(np.sqrt(sig ** 2 - float(inres or 0.0) ** 2))       # smooth_vsini_fft, smoothing.py:296-297 (NaN if negative)
+            if ow is None and not limited:
+                th_R, th_rot, stage = np.nan, sig_eff, 1                       # onto the model grid itself (what getspec calls)
+            else:
+                # onto another grid: the result is interpolated from the stage's own resampled grid (:308-311), after mask_wave
+                m = masked(ckms / sig, False, ow is not None)
+                grid_out = wave if ow is None else ow
+                wave, spec = np.ascontiguousarray(wave[m]), spec[m]
+                th_R, th_rot, stage = np.nan, sig_eff, 4
         elif smoothtype in ('vel', 'R'):
             if smoothtype == 'vel':                                          # sigma in km/s -> R_sigma; inres in km/s
                 th_R = ckms / float(sigma)
@@ -212,23 +233,35 @@ class PayneSpecPredict(object):
                 th_R = float(sigma)
                 r_in = float(inres) if inres is not None else np.inf
             th_rot, stage = 0.0, 2
+            grid_out = wave if ow is None else ow
+            if limited:
+                m = masked(th_R, False, False)
+                wave, spec = np.ascontiguousarray(wave[m]), spec[m]
         elif smoothtype == 'lsf':
-            if outwave is not None and not np.array_equal(np.asarray(outwave, dtype=np.float64), wave):
-                raise NotImplementedError("smoothtype='lsf' is built for outwave=None or outwave=wave")
             th_R, th_rot, stage = np.nan, 0.0, 2
+            lsf_vec = np.atleast_1d(np.asarray(sigma, dtype=np.float64))
+            grid_out = wave if ow is None else ow
+            if limited:
+                m = masked(100, True, False)
+                wave, spec, lsf_vec = np.ascontiguousarray(wave[m]), spec[m], lsf_vec[m]
+            if limited or (ow is not None and not np.array_equal(ow, wave)):
+                lsf_wave = wave                                              # the vector is a function of the INPUT wavelengths (smoothing.py:145-147)
         else:
             raise NotImplementedError("smoothtype=%r is not built (have 'vsini', 'vel', 'R', 'lsf')" % (smoothtype,))
         eng = self._smooth_engine(wave, r_in)
-        if stage == 2:
-            grid = wave if outwave is None else np.ascontiguousarray(outwave, dtype=np.float64)
-            eng.set_obs(grid)
+        if stage >= 2:
+            eng.set_obs(np.ascontiguousarray(grid_out))
         th = np.full((1, eng.ncols), np.nan)
         th[0, :8] = [5000.0, 4.0, 0.0, 0.0, 0.0, th_rot, np.nan, th_R]
         if smoothtype == 'lsf':
-            eng.set_lsf(np.atleast_1d(np.asarray(sigma, dtype=np.float64)))
+            eng.set_lsf(lsf_vec, wave=lsf_wave)
         out = eng.smooth_batch(spec[None, :], th, stage=stage).cpu().numpy()[0].astype(np.float64)
-        if outwave is None and smoothtype in ('vel', 'R'):
-            out = native_grid_edges(wave, out)
+        if smoothtype in ('vel', 'R', 'vsini') and stage >= 2:
+            # np.interp(outwave, exp(linspace(ln wmin, ln wmax, n)), conv, left = right = NaN): an output pixel that coincides with an
+            # end of the (kept) input grid is NaN whenever exp(log(w)) rounds to the inside of w; the kernel works in ln(lambda) and
+            # cannot see that rounding -- the same numpy expressions decide here (everything further out is NaN already)
+            lo, hi = np.exp(np.log(wave.min())), np.exp(np.log(wave.max()))
+            out[(grid_out < lo) | (grid_out > hi)] = np.nan
         return out
 
     def _smoothspec_direct(self, wave, spec, resolution, outwave, smoothtype, kw):
