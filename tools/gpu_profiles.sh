@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench command: kernel stats, HBM counters (FETCH_SIZE, WRITE_SIZE: separate passes) and one SQ
 # pass; the summaries land in gpurun_out/ under the names profiles/ uses (copy them there: gpurun_out/ is scratch).
-#   bash tools/gpu_profiles.sh [round-tag r3] [config C2|C3|C5]
-TAG=${1:-r3}; CFG=${2:-C2}
+#   bash tools/gpu_profiles.sh [round-tag r4] [config C2|C3|C5|C32k|LinNet300]
+TAG=${1:-r4}; CFG=${2:-C2}
 cfg=$(echo $CFG | tr A-Z a-z)
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 REPO=$PWD
 STEPS=200; PSTEPS=20
-if [ $CFG = C5 ]; then STEPS=5; PSTEPS=3; fi
+if [ $CFG = C5 ] || [ $CFG = C32k ]; then STEPS=5; PSTEPS=3; fi
 EXTRA=""; if [ $CFG != C2 ]; then EXTRA="--no-cpu-baseline"; fi
 python bench.py --config $CFG --steps $STEPS --warmup 5 $EXTRA > $OUT/${TAG}_${cfg}_bench.json 2> $OUT/${TAG}_${cfg}_bench.err; tail -c 400 $OUT/${TAG}_${cfg}_bench.json
 cd /tmp && export TMPDIR=/tmp
