@@ -48,7 +48,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   PostTables T;
   std::memset(&T, 0, sizeof(T));
   fill_model_scalars(H, T);
-  T.nobs = nobs; T.vs_tab = H.vs_tab32.data();
+  T.nobs = nobs; T.vs_tab = H.vs_tab32.data() + 1;
   T.lnlam = H.lnlam.data(); T.lam = H.lam.data(); T.tw = H.tw.data(); T.twf = H.twf.data();
   T.rs1_idx = H.rs1_idx.data(); T.rs1_frac = H.rs1_frac.data();
   T.bk1_idx = H.bk1_idx.data(); T.bk1_frac = H.bk1_frac.data();

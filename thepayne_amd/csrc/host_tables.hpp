@@ -34,7 +34,7 @@ struct HostTables {
 inline void fill_model_scalars(const HostTables& H, PostTables& T) {
   T.npix = H.npix; T.n1 = H.n1; T.nmax = H.nmax; T.vs_val = H.vs_val;
   T.geo_inv_dln = H.geo_inv_dln; T.geo = H.geo; T.ln0 = H.ln0; T.dln = H.dln; T.ln_last = H.ln_last;
-  T.vs_tab_n = (int)H.vs_tab32.size();
+  T.vs_tab_n = (int)H.vs_tab32.size() - 1;      // (without the leading mirror entry)
   T.twf_n = (int)H.twf.size();
   T.rot_identity = H.rot_identity;
   T.inv_lam0 = H.lam.empty() ? 0.f : (float)(1.0 / H.lam[0]);
@@ -96,7 +96,10 @@ inline int build_model_tables(const double* wave, int npix, HostTables& H) {
       H.vs_tab[i] = vsini_sb_exact(u);
     }
   }
-  H.vs_tab32.assign(H.vs_tab.begin(), H.vs_tab.end());
+  // what the kernel interpolates: fp32, with ONE LEADING entry sb(-h) = sb(h) so that the four values around any position are
+  // contiguous (PostTables::vs_tab points at the entry of u = 0, i.e. at vs_tab32[1])
+  H.vs_tab32.assign(1, (float)H.vs_tab[1]);
+  H.vs_tab32.insert(H.vs_tab32.end(), H.vs_tab.begin(), H.vs_tab.end());
   // vsini grid: w = exp(linspace(ln wmin, ln wmax, n1))
   std::vector<double> lnw, w(H.n1);
   linspace(std::log(wave[0]), std::log(wave[npix - 1]), H.n1, lnw);

@@ -344,6 +344,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     fill_model_scalars(c->H, T);
     T.r_ann = model->resolution; T.npoly = opts->npoly;
     if ((rc = upload(c, c->H.vs_tab32, &T.vs_tab, c->owned))) return bail(rc);
+    T.vs_tab += 1;                                           // (the table's entry of u = 0: one mirror entry sits in front of it)
     if ((rc = dev_alloc(c, 1, &c->d_T, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lnlam, &T.lnlam, c->owned))) return bail(rc);
     if ((rc = upload(c, c->H.lam, &T.lam, c->owned))) return bail(rc);

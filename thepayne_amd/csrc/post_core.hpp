@@ -45,6 +45,7 @@ constexpr double kPi = 3.141592653589793;
 constexpr float kBase = 1.0f;                // the flux shift
 constexpr double kVsTabStep = 1.0 / 64.0;    // vsini taper table spacing in u
 constexpr double kVsTabMax = 256.0;
+constexpr double kPosMagic = 1572864.0;      // 1.5 * 2^20: a position t in [0, 2^19) added to it has ulp 2^-32 (magic_locate, vsini_tab_pos)
 // Threads of the per-candidate workgroup, and how many of them own a butterfly in the radix-8 passes.
 // One wave issues a vector instruction every ~5 cycles whatever its kind (tools/exp/pk_rate.hip) while a SIMD
 // keeps four waves going at that rate each, so the per-pixel phases (tapers, resampling, observed grid) are
@@ -690,18 +691,40 @@ PAYNE_HD_COLD double vsini_sb_exact(double ub) {
 // Branch-free (loads from a clamped index): a guarded load costs a branch and a wait and
 // serialises the caller's unrolled evaluations.  `far` reports bins beyond the table (or a
 // NaN argument); the caller re-evaluates those with vsini_sb_exact.
-PAYNE_HD float vsini_taper_fast(const float* __restrict__ tab, int tab_n, double vs_c64, int k, bool& far) {
-  const double t = (double)k * vs_c64;                   // u / kVsTabStep
-  const bool in = t < (double)(tab_n - 3);               // false for NaN
+// (tab[-1] exists and equals tab[1] -- sb is even --: the four values are ONE 16-byte access at tab + i - 1, no select on i = 0.)
+// The table position is split like the pixel positions (magic_locate): t + kPosMagic has the integer part in its high dword and the
+// fraction, in units of 2^-32, in its low dword -- an fma, a mask and one conversion where floor / convert / subtract / convert cost
+// four fp64-rate instructions per bin, a quarter of the on-chip rotation stage's vector instructions with the rest of this function.
+typedef float tap2 __attribute__((vector_size(8)));      // two bins side by side: the pair (k, M - k) is always evaluated together
+struct TapPos { int i; float f; };
+PAYNE_HD TapPos vsini_tab_pos(int tab_n, double vs_c64, int k, bool& far) {
+  const double tm = fma((double)k, vs_c64, kPosMagic);   // u / kVsTabStep (+ magic); 0 <= t < 2^19
+  const bool in = tm < kPosMagic + (double)(tab_n - 3);  // false for NaN
   far = far || !in;
-  int i = in ? (int)t : 0;
-  i = i < 0 ? 0 : i;
-  const float f = in ? (float)(t - (double)i) : 0.f;
-  const float ym = tab[i > 0 ? i - 1 : 1], y0 = tab[i], y1 = tab[i + 1], y2 = tab[i + 2];
-  const float fm1 = f - 1.0f, fm2 = f - 2.0f, fp1 = f + 1.0f;
-  const float v = (-f * fm1 * fm2 * (1.0f / 6.0f)) * ym + (fp1 * fm1 * fm2 * 0.5f) * y0 + (-fp1 * f * fm2 * 0.5f) * y1 +
-                  (fp1 * f * fm1 * (1.0f / 6.0f)) * y2;
-  return k == 0 ? 1.0f : v;
+  union { double d; unsigned long long u; } cv;
+  cv.d = in ? tm : kPosMagic;
+  TapPos p;
+  p.i = (int)((unsigned)(cv.u >> 32) & 0x7FFFFu);
+  p.f = (float)(unsigned)cv.u * 2.3283064365386963e-10f;  // 2^-32
+  return p;
+}
+// 4-point Lagrange weights of two bins at once (packed fp32 on the GPU)
+PAYNE_HD void vsini_taper_fast2(const float* __restrict__ tab, int tab_n, double vs_c64, int ka, int kb, bool& far, float& ta_, float& tb_) {
+  const TapPos pa = vsini_tab_pos(tab_n, vs_c64, ka, far), pb = vsini_tab_pos(tab_n, vs_c64, kb, far);
+  const float* __restrict__ qa = tab + pa.i - 1;
+  const float* __restrict__ qb = tab + pb.i - 1;
+  const tap2 ym = {qa[0], qb[0]}, y0 = {qa[1], qb[1]}, y1 = {qa[2], qb[2]}, y2 = {qa[3], qb[3]};
+  const tap2 f = {pa.f, pb.f};
+  const tap2 fm1 = f - 1.0f, fm2 = f - 2.0f, fp1 = f + 1.0f;
+  const tap2 a = f * fm1, b = fp1 * fm2;                  // f (f - 1), (f + 1)(f - 2)
+  const tap2 v = (a * fm2 * (-1.0f / 6.0f)) * ym + (b * fm1 * 0.5f) * y0 + (b * f * (-0.5f)) * y1 + (a * fp1 * (1.0f / 6.0f)) * y2;
+  ta_ = ka == 0 ? 1.0f : v[0];
+  tb_ = kb == 0 ? 1.0f : v[1];
+}
+PAYNE_HD float vsini_taper_fast(const float* __restrict__ tab, int tab_n, double vs_c64, int k, bool& far) {
+  float a, b;
+  vsini_taper_fast2(tab, tab_n, vs_c64, k, k, far, a, b);
+  return a;
 }
 // smoothing.py:598-599: exp(-2 pi^2 sigma^2 ss^2), ss = k/(n dv), as exp2(c2 k^2)
 PAYNE_HD float gauss_taper(float g_c2, int k) {
@@ -719,6 +742,11 @@ struct TaperArgs {
 };
 template <bool VSINI> PAYNE_HD float taper_at(const TaperArgs& a, int k, bool& far) {
   return VSINI ? vsini_taper_fast(a.vs_tab, a.vs_tab_n, a.vs_c64, k, far) : gauss_taper(a.g_c2, k);
+}
+// the two bins of a conjugate pair
+template <bool VSINI> PAYNE_HD void taper_at2(const TaperArgs& a, int ka, int kb, bool& far, float& ta_, float& tb_) {
+  if (VSINI) vsini_taper_fast2(a.vs_tab, a.vs_tab_n, a.vs_c64, ka, kb, far, ta_, tb_);
+  else { ta_ = gauss_taper(a.g_c2, ka); tb_ = gauss_taper(a.g_c2, kb); }
 }
 // exact re-evaluation of a bin the table does not cover (rare: u >= 256 or NaN)
 PAYNE_HD float taper_far(const TaperArgs& a, int k, float fast) {
@@ -799,8 +827,7 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, ZP Z, int M, TP tw, int tw_ste
       const bool pair = k0 <= npair;
       const int k = pair ? k0 : npair;
       zk[q] = ld1(Z, k); zm[q] = ld1(Z, M - k); w[q] = ld1(tw, k * tw_step);
-      tk[q] = taper_at<VSINI>(ta, pair ? k : M / 2, far);
-      tm[q] = taper_at<VSINI>(ta, pair ? M - k : M, far);
+      taper_at2<VSINI>(ta, pair ? k : M / 2, pair ? M - k : M, far, tk[q], tm[q]);
     }
     if (VSINI && far) {
 #pragma unroll
@@ -857,6 +884,11 @@ PAYNE_HD void rfft_taper_phase(int tid, int nthr, ZP Z, int M, TP tw, int tw_ste
   }
 }
 
+template <bool VSINI> PAYNE_HD void taper_full2(const TaperArgs& ta, int ka, int kb, float& ta_, float& tb_) {
+  bool far = false;
+  taper_at2<VSINI>(ta, ka, kb, far, ta_, tb_);
+  if (VSINI && far) { ta_ = taper_far(ta, ka, ta_); tb_ = taper_far(ta, kb, tb_); }
+}
 template <bool VSINI> PAYNE_HD float taper_full(const TaperArgs& ta, int k) {
   bool far = false;
   float t = taper_at<VSINI>(ta, k, far);
@@ -981,7 +1013,6 @@ PAYNE_HD void search_locate(const PostTables& T, int lo, int hi, double v, int& 
 // the fraction in units of 2^-32, bits 0..18 of the high dword the integer part, and the
 // exponent field is the constant 0x413.  Position resolution 2.3e-10 pixel (single rounding).
 // Anything else in the exponent field (NaN, negative, huge) gives a NaN weight.
-constexpr double kPosMagic = 1572864.0;
 PAYNE_HD void magic_locate(double tm, int lo, int hi, float hs, int& k, float& w) {
   union { double d; unsigned long long u; } cv;
   cv.d = tm;

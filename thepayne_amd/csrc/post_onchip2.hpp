@@ -170,7 +170,8 @@ __device__ __forceinline__ void chip2_taper_pairs(const ChipLds& L, c32 (&u)[32]
   for (int r = 0; r < 16; ++r) {
     const int k0 = P.low + 512 * r;
     const int k = (k0 == 0) ? 1 : k0;
-    const float tk = taper_full<VSINI>(ta, k), tm = taper_full<VSINI>(ta, M - k);
+    float tk, tm;
+    taper_full2<VSINI>(ta, k, M - k, tk, tm);
     const c32 w = chip2_w32768(L, k);                               // exp(-2 pi i k / 2M), 2M = 32768
     c32 yk, ym;
     c32& ua = u[chip_pos(true, r)];

@@ -32,18 +32,28 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
     """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
     bookkeeping included).  Returns {mode: {...}}.  config 'C3' = C2 + photometry in seven filters (joint fit, photscale).
     `seed`: the sampler's random stream; `dlogz`: stopping threshold (tiny: the run ends at `maxcall`)."""
-    cfg = synth.CONFIGS[config]
+    cfg = synth.CONFIGS["C2" if config == "LinNet300" else config]
     joint = bool(cfg.get("phot"))
-    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0, line_depth=0.3)
-    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
     tmp = tempfile.mkdtemp()
-    path = os.path.join(tmp, "yst.npz")
-    nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
+    nntype = 'YST1'
+    if config == "LinNet300":                 # FitPayne's default network (fitstar.py:81) at full width, in the reference's file layout
+        nntype = 'LinNet'
+        raw = synth.make_torch_net("LinNet", npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=(300, 300, 300), seed=21)
+        path = os.path.join(tmp, "linnet.npz")
+        d = {("model/" + k if k.startswith("lin") else k): v for k, v in raw.items() if k != "kind"}
+        d["wavelengths"] = d.pop("wavelength")
+        d["resolution"] = np.array([d["resolution"]])
+        nnio.save_npz(path, d)
+    else:
+        raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0, line_depth=0.3)
+        path = os.path.join(tmp, "yst.npz")
+        nnio.save_npz(path, {k: (np.array([v]) if k == "resolution" else v) for k, v in raw.items() if k != "kind"})
+    obs = synth.obs_grid(raw["wavelength"], cfg["nobs"])
     free = SPEC + (['log(A)', 'Av'] if joint else [])
     fitpars = [list(ALL), {p: p in free for p in ALL}]
     rb = [True, joint, False, joint, False]                 # spec, phot, modpoly, photscale, carbon
     fitargs = {'obs_wave_fit': obs, 'obs_flux_fit': np.ones(len(obs)), 'obs_eflux_fit': np.full(len(obs), 0.01),
-               'specANNpath': path, 'NNtype': 'YST1', 'fixedpars': {}}
+               'specANNpath': path, 'NNtype': nntype, 'fixedpars': {}}
     if joint:
         phot = synth.make_phot_nets()
         fitargs.update({'photANNpath': phot, 'obs_phot': synth.c3_obs_phot(phot["filters"])})
