@@ -1423,6 +1423,11 @@ PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const Cand
                               const float* __restrict__ spec, float* __restrict__ work) {
   // RU: a whole thread-share of gathers in flight
   const double rsBm = W.rsB + kPosMagic, rsD = (double)nthr * W.rsA;
+  // GEO: the POSITION is clamped to [first pixel, one position ulp below the last] -- its integer part is then in [i0, i1 - 2] and its
+  // fraction in [0, 1): what magic_locate's integer clamps, fraction selects and exponent test produce, for two instructions instead
+  // of three round trips through a condition register (20 ticks each for a wave: tools/exp/nop_rate.hip).  Positions of a window that
+  // is not `bad` are finite.
+  const double tlo = kPosMagic + (double)W.i0, thi = kPosMagic + (double)(W.i1 - 1) - 2.3283064365386963e-10;
   for (int base = tid; base < W.n2; base += RU * nthr) {
     float a[RU], b[RU], w[RU];
     const double tm0 = fma((double)base, W.rsA, rsBm);   // point base + q nthr sits at tm0 + q rsD
@@ -1430,7 +1435,13 @@ PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const Cand
     for (int q = 0; q < RU; ++q) {
       const int j0 = base + q * nthr, j = j0 < W.n2 ? j0 : W.n2 - 1;
       int k; float ww;
-      if (GEO) magic_locate(fma((double)q, rsD, tm0), W.i0, W.i1, W.hs_ann, k, ww);   // (k is clamped: j0 >= n2 is harmless)
+      if (GEO) {                                         // (clamped: j0 >= n2 is harmless)
+        union { double d; unsigned long long u; } cv;
+        cv.d = fmin(fmax(fma((double)q, rsD, tm0), tlo), thi);
+        k = (int)((unsigned)(cv.u >> 32) & 0x7FFFFu);
+        const float f = (float)(unsigned)cv.u * 2.3283064365386963e-10f;      // 2^-32
+        ww = f * (1.0f + W.hs_ann * (f - 1.0f));
+      }
       else {
         const double lw = (j == W.n2 - 1) ? W.lnmax : ((double)j * W.step + W.lnmin);
         search_locate(T, W.i0, W.i1, lw - S.dop, k, ww);
