@@ -223,6 +223,32 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
         assert np.all(np.abs(l2 - ref) <= lnl_tol(ref)), (v, np.abs(l2 - ref).max())
 
 
+@pytest.mark.parametrize("kind,H,npix,nobs,B", [("LinNet", (50, 37, 96), 1000, 700, 19), ("LinNet", (128, 128, 128), 2048, 1800, 40),
+                                                ("SMLP", (300, 300, 300), 3000, 2500, 33), ("SMLP", (33, 65, 17), 512, 400, 7)])
+def test_torch_nets_of_any_shape_vs_oracle(Engine, kind, H, npix, nobs, B):
+    """LinNet / SMLP with hidden widths that differ from layer to layer (the register-staged dense kernel, no bf16 planes), that are
+    not multiples of the tiles, and equal (the matrix-core path), spectra that are not powers of two, odd batches: network output
+    and likelihood against the numpy-fp32 restatement of the reference's torch forward pass."""
+    raw = synth.make_torch_net(kind, npix=npix, H=H, seed=5)
+    obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.06 * (raw["wavelength"][-1] - raw["wavelength"][0]))
+    th7 = synth.draw_candidates(B, seed=npix + H[0])
+    flux0 = O.genspec(raw, list(theta_full(th7[:1])[0, :8]), outwave=obs)[1]
+    flux = flux0 + np.random.default_rng(3).normal(0, 0.01, nobs)
+    eflux = np.full(nobs, 0.01)
+    eng = Engine(_net(raw, kind), obs=(obs, flux, eflux), b_max=16)
+    th = theta_full(th7)
+    s0 = eng.predict_batch(th, stage=0).cpu().numpy()
+    ref0 = np.array([O.torchnet_forward(raw, t[:4]) for t in th7])
+    assert np.abs(s0 - ref0).max() <= TORCH_FP32_FLUX_TOL, np.abs(s0 - ref0).max()
+    L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
+    with np.errstate(all="ignore"):
+        ref = np.array([L.lnlikefn(t) for t in th7])
+    lnl = eng.lnlike_batch(th).cpu().numpy()
+    assert np.array_equal(np.isnan(lnl), np.isnan(ref))
+    ok = np.isfinite(ref)
+    assert ok.sum() >= B - 2 and np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok])), np.abs(lnl[ok] - ref[ok]).max()
+
+
 def test_lnlike_modpoly_against_reference_golden(Engine, golden):
     g = golden("g4_lnlike_modpoly")
     cfg = synth.CONFIGS["small"]
