@@ -364,8 +364,8 @@ def roofline_blocks(cfg_name, res, args):
     big = n1 > 16384
     if big and dom == "post":
         # Spectra larger than LDS.  What binds the kernel depends on its form: payne_post_chip_kernel / payne_post_chip32_kernel keep
-        # a convolution stage on the compute unit (5 transfers of the spectrum) and are bound by the SIMDs' vector throughput ->
-        # `frac` is the algorithmic FLOP rate against the fp32 vector peak; payne_post_big_kernel streams the spectrum through a
+        # a convolution stage on the compute unit (5 transfers of the spectrum): their arithmetic / LDS phases and their memory phases
+        # alternate on a CU -> `frac` is the algorithmic FLOP rate against the fp32 vector peak; payne_post_big_kernel streams the spectrum through a
         # global workspace 25 times and is HBM/L2-bound -> `frac` is SURVEY 8(d)'s modelled streaming bytes over the measured time.
         # Both figures and the counter rate are printed for either kernel.
         transfers = eng_round_trips(n1, args.variant)
@@ -389,9 +389,12 @@ def roofline_blocks(cfg_name, res, args):
         if chip:
             out["roofline"] = dict({"bound": "fp32-vector", "kernel": kname, "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                                     "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                                    "note": "stages on the compute unit: bound by vector issue, not by bytes (the counters' HBM rate is "
-                                            "`hbm_frac_counters`; `modelled_hbm_frac` prices SURVEY 8(d)'s eight streaming passes, which this "
-                                            "kernel does not make)"}, **extra)
+                                    "note": "convolution stages on the compute unit (5 transfers of the spectrum instead of 25).  By ablation "
+                                            "(tools/exp/chip_ablate.py, NOTES R4.12) 41 % of the kernel is the stages' arithmetic and LDS exchanges, "
+                                            "59 % their loads / stores / gather and the observed-grid loop at ~20 B/clk/CU (the L2-to-CU port's "
+                                            "ceiling); one workgroup per CU: the two alternate, never overlap.  `frac` = algorithmic FLOPs over the "
+                                            "fp32 vector peak; `hbm_frac_counters` = counters' bytes over the HBM peak; `modelled_hbm_frac` prices "
+                                            "SURVEY 8(d)'s eight streaming passes, which this kernel does not make"}, **extra)
         else:
             out["roofline"] = dict({"bound": "hbm", "kernel": kname or "payne_post_big_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
                                     "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}, **extra)
