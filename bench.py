@@ -596,14 +596,14 @@ def main():
 
 
 def eng_round_trips(n1, variant=0):
-    """Transfers of the spectrum (4 n1 bytes each, a read or a write) per evaluation.  payne_post_chip_kernel (65 536 points,
-    DESIGN.md 3.4): the raw row in (1), the rotation stage's result out (1), the instrumental stage's gather of it (1), its
+    """Transfers of the spectrum (4 n1 bytes each, a read or a write) per evaluation.  payne_post_chip_kernel (65 536 points) and
+    payne_post_chip2_kernel (32 768 points): the raw row in (1), the rotation stage's result out (1), the instrumental stage's gather of it (1), its
     result out (1), the observed grid's gather (1) = 5.  payne_post_big_kernel (other lengths above 16 384, or
     PAYNE_V_BIG_WORKSPACE): the row in and its copy out (2), per convolution stage the forward and the inverse transform at 2
     transfers per pass (the four-step form has 2 passes, the plain form one per radix-8 pass) + the taper pass (2), the resampling
     pass between the stages (2) and the closing interpolation read (1)."""
     import numpy as np
-    if n1 == 65536 and not (variant & (32 | 256 | 65536)):
+    if n1 in (65536, 32768) and not (variant & (32 | 256 | 65536)):      # payne_post_chip_kernel / payne_post_chip2_kernel
         return 5
     M = n1 // 2
     tiled = (M % 512 == 0) and (M // 512 in (32, 64, 128)) and not (variant & 32)
