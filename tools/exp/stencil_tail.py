@@ -1,3 +1,8 @@
+"""The instrumental stage as a compact stencil (Next 1): the exact circular kernel g = irfft(taper) of the reference's
+Gaussian taper exp(-2 pi^2 sigma^2 ss^2) (Payne/utils/smoothing.py:598-601) on N = 4096 points, the l1 mass of its tails beyond W taps
+and the error a truncated stencil makes on a white 0.03-rms spectrum -- for the widths C2's prior produces (0.35 .. 2.5 resampled
+pixels; 1.5 at the truth).  CPU only.  Result (NOTES R4.1): the taper is not small at the Nyquist frequency for these widths, the kernel
+carries an alternating 1/j^2 tail, and a stencil exact to 1e-8 exists only above ~1.9 pixels (11 % of the prior, none of the posterior)."""
 import numpy as np
 N=4096
 def kern(sig_px):
