@@ -255,9 +255,12 @@ def alg_work(d):
     D, H, N, B, F, HP = d["D"], d["H"], d["N"], d["B"], d["F"], d["HP"]
     nhh = d.get("n_hh", 1)                    # H x H layers: 1 (YST1), 4 (LinNet), 2 (SMLP)
     L2N = np.log2(N)
-    fl_post = 2 * 2 * 2.5 * N * L2N + 60.0 * N
+    fl_post_alg = 2 * 2 * 2.5 * N * L2N + 60.0 * N          # the algorithm: two convolution stages, two transforms each
+    # what the post kernel itself executes: three transforms when the output layer hands over rows already transformed (its
+    # weights carry the first stage's forward transform at no extra product: payne_last_kernel kind 4 == "frequency")
+    fl_post = d.get("post_transforms", 4) * 2.5 * N * L2N + 60.0 * N
     fl_sed = F * 2.0 * (6 * HP + HP * HP + HP)
-    flops_eval = 2.0 * (D * H + nhh * H * H + H * N) + fl_post + fl_sed
+    flops_eval = 2.0 * (D * H + nhh * H * H + H * N) + fl_post_alg + fl_sed
     bytes_batch = 4.0 * (D * H + H + nhh * (H * H + H) + H * N + N) + 8.0 * N + 16.0 * d["nobs"] + B * (8.0 * 12 + 4) \
         + 4.0 * F * (6 * HP + HP + HP * HP + HP + HP + 1)
     return dict(flops_eval=flops_eval, bytes_batch=bytes_batch, flops_post=fl_post, flops_sed=fl_sed,
@@ -349,6 +352,8 @@ def roofline_blocks(cfg_name, res, args):
     """roofline / mfma_kernel / kernels_us / whole_step / hbm blocks of one configuration's run."""
     d, kern = res["dims"], res["kern"]
     B, H, N, n1 = d["B"], d["H"], d["N"], d["n1"]
+    rows = res["engines"][0].kernels_used().get("rows", "pixels") if res.get("engines") else "pixels"
+    d = dict(d, post_transforms=3 if rows == "frequency" else 4)
     W = alg_work(d)
     ms_per_step = 1e3 * res["dt"] / res["steps"]
     out = {}
@@ -406,7 +411,9 @@ def roofline_blocks(cfg_name, res, args):
                            "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                            "traffic": traffic[dom], "traffic_source": tsrc,
                            "alg_flops_per_launch": flops[dom], "avg_us_per_launch": per[dom]}
+        out["rows_handed_to_post_kernel"] = rows
         if dom == "post":
+            out["roofline"]["transforms_in_kernel"] = d["post_transforms"]
             out["roofline"]["note"] = ("FFT / interpolation pipeline in LDS: no MFMA instructions; priced against the "
                                        "packed-fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s). The MFMA kernel of "
                                        "the step is under `mfma_kernel`.")

@@ -134,6 +134,9 @@ typedef struct payne_opts {
 #define PAYNE_V_NO_WALK_SPEC 131072u /* the sampler's next proposal drawn at the post kernel's tail, after the likelihood it waits for (what fits
                                      * with more than 16 sampled dimensions or 32 theta columns use), instead of made ahead for both outcomes by
                                      * idle workgroups of the hidden-layer launch */
+#define PAYNE_V_ROWS_PIXEL 262144u /* the output layer writes pixels and the post kernel transforms them itself (what runs with a continuum
+                                    * network, with vsini maps that are not the identity, and for spectra other than 1k/2k/4k/8k);
+                                    * default where it applies: the output layer's weights carry the first stage's forward transform */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;
@@ -442,7 +445,9 @@ const char* payne_kernel_name(int which);
 
 /* The kernel (with its template arguments) the context's last batch call launched for one kind -- 0 output dense layer,
  * 1 post kernel, 2 sed kernel, 3 hidden dense layers (the last launch of that kind in the call) --, "" if none yet: which
- * code path a net of a given depth / a spectrum of a given length takes.  Test and measurement aid, no reference counterpart. */
+ * code path a net of a given depth / a spectrum of a given length takes.  kind 4: "frequency" when the output layer handed the
+ * post kernel rows already transformed (its weights restated once at payne_ctx_create: 1k/2k/4k/8k spectra on a geometric grid,
+ * no continuum network, not PAYNE_V_ROWS_PIXEL), "pixels" otherwise.  Test and measurement aid, no reference counterpart. */
 const char* payne_last_kernel(const payne_ctx* ctx, int kind);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every kernel

@@ -28,7 +28,10 @@ def _net(raw, kind="YST1"):
 # every kernel variant that ships (payne_opts.variant, include/payne_hip.h): the defaults, and the code paths that
 # differently shaped nets / spectra take, forced onto the C2 problem
 VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
-            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048, "dense_fused": 32768}
+            "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048, "dense_fused": 32768,
+            "rows_pixel": 262144, "rows_pixel+post_full": 262144 | 8, "rows_pixel+no_prep": 262144 | 16, "rows_pixel+dense_fused": 262144 | 32768}
+# ... of which these hand the post kernel rows in the frequency domain (the output layer's weights restated: payne_hip.h, payne_last_kernel kind 4)
+FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "dense_fused"}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -40,6 +43,7 @@ def test_lnlike_c2_against_reference_golden(Engine, golden, variant):
     lnl = eng.lnlike_batch(theta_full(g["theta"])).cpu().numpy()
     err = np.abs(lnl - g["lnlike"])
     assert np.all(err <= lnl_tol(g["lnlike"])), (err.max(), np.argmax(err))
+    assert eng.kernels_used()["rows"] == ("frequency" if variant in FREQ_ROWS else "pixels"), (variant, eng.kernels_used())
     # determinism + independence of batch position
     lnl2 = eng.lnlike_batch(theta_full(g["theta"][::-1].copy())).cpu().numpy()[::-1]
     assert np.array_equal(lnl, lnl2)
@@ -148,10 +152,15 @@ def test_dense_layers_on_odd_shapes(Engine, H, npix, B, D):
         assert np.abs(got - ref).max() <= FLUX_TOL, (variant, np.abs(got - ref).max())
 
 
-def test_predict_stages_against_reference_golden(Engine, golden):
+@pytest.mark.parametrize("domain", ["frequency", "pixels"])
+def test_predict_stages_against_reference_golden(Engine, golden, domain):
+    """predictspec, the spectrum after rotation (Vrot = 0 and values from 1e-3 to 50 km/s) and getspec on the
+    observed grid against the reference's own outputs -- with the output layer handing over transformed rows (default here: 1024
+    pixels on a geometric grid) and pixel rows (PAYNE_V_ROWS_PIXEL: what every other shape runs)."""
+    from thepayne_amd import _lib
     g = golden("g2_getspec")
     raw = synth.make_yst_net(npix=1024, H=64, seed=5, line_depth=0.3)
-    eng = Engine(_net(raw), obs=(g["obs_wave"],), b_max=64)
+    eng = Engine(_net(raw), obs=(g["obs_wave"],), b_max=64, variant=0 if domain == "frequency" else _lib.V_ROWS_PIXEL)
     lab = g["labels"]
     rows = g["theta_rows"]
     th = np.full((len(rows), eng.ncols), np.nan)
@@ -159,10 +168,12 @@ def test_predict_stages_against_reference_golden(Engine, golden):
     th[:, 4], th[:, 5], th[:, 7] = rows[:, 0], rows[:, 1], rows[:, 2]
     s0 = eng.predict_batch(th[:1], stage=0).cpu().numpy()[0]
     assert np.abs(s0 - g["raw"]).max() <= FLUX_TOL
+    assert eng.kernels_used()["rows"] == "pixels"           # (the network's own output is always asked for in pixels)
     for v, ref in zip(g["vrot_values"], g["after_rot"]):
         t = th[:1].copy(); t[0, 5] = v
         s1 = eng.predict_batch(t, stage=1).cpu().numpy()[0]
         assert np.abs(s1 - ref).max() <= FLUX_TOL, v
+    assert eng.kernels_used()["rows"] == domain
     s2 = eng.predict_batch(th, stage=2, fwhm_R=True).cpu().numpy()
     assert np.array_equal(np.isnan(s2), np.isnan(g["final"]))
     assert np.nanmax(np.abs(s2 - g["final"])) <= FLUX_TOL
@@ -318,16 +329,21 @@ def test_lnlike_vs_oracle_shapes(Engine, npix, nobs, H, B):
     assert ok.sum() >= B - 2 and np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok]))
 
 
-def test_nan_and_branch_semantics_vs_oracle(Engine):
+@pytest.mark.parametrize("rows", ["default", "pixels"])
+def test_nan_and_branch_semantics_vs_oracle(Engine, rows):
     """Inst_R NaN/<=0 -> plain interpolation; Inst_R above the ANN's R -> NaN lnL;
-    Vrot = 0 / Vrad = 0 skip their stages; obs outside the model range -> NaN."""
+    Vrot = 0 / Vrad = 0 skip their stages; obs outside the model range -> NaN; a NaN label (the network's whole output NaN):
+    a flat spectrum out of whichever stage scrubs first (smoothing.py:285 nan_to_num), NaN when none runs."""
+    from thepayne_amd import _lib
     raw, obs, flux, eflux = yst_problem("small", H=64)
-    eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=16)
+    eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=16, variant=0 if rows == "default" else _lib.V_ROWS_PIXEL)
     base = synth.draw_candidates(1, seed=5)[0]
     cases = []
-    for vrad, vrot, R in [(0.0, 0.0, 28000.0), (12.0, 0.0, np.nan), (0.0, 4.0, -1.0), (10.0, 2.0, 40000.0),
-                          (300.0, 1.0, 28000.0), (-300.0, 0.0, np.nan)]:
+    for vrad, vrot, R, teff in [(0.0, 0.0, 28000.0, None), (12.0, 0.0, np.nan, None), (0.0, 4.0, -1.0, None), (10.0, 2.0, 40000.0, None),
+                                (300.0, 1.0, 28000.0, None), (-300.0, 0.0, np.nan, None),
+                                (5.0, 3.0, 28000.0, np.nan), (5.0, 0.0, 28000.0, np.nan), (5.0, 0.0, np.nan, np.nan), (0.0, 2.0, np.nan, np.nan)]:
         t = base.copy(); t[4], t[5], t[6] = vrad, vrot, R
+        if teff is not None: t[0] = teff
         cases.append(t)
     cases = np.array(cases)
     L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)

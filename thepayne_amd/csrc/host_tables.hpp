@@ -60,6 +60,46 @@ inline void interp_map(double x, const std::vector<double>& xp, bool nan_outside
   frac = (float)((x - xp[k]) / (xp[k + 1] - xp[k]));
 }
 
+// What the post kernel's first convolution stage holds between its forward transform and the taper, for a real vector v of n points:
+// Z[k] = sum_m (v[2m] + i v[2m+1]) exp(-2 pi i m k / (n/2)), k < n/2, written (re, im) interleaved -- n doubles.  The map v -> Z is
+// linear and the same for every candidate, so a network whose output layer is linear can carry it in its weights (freq_rows below).
+inline void packed_half_transform(const double* v, int n, double* out) {
+  const int M = n / 2;
+  std::vector<double> re(M), im(M);
+  int lg = 0;
+  while ((1 << lg) < M) ++lg;
+  for (int m = 0; m < M; ++m) {
+    int r = 0;
+    for (int b = 0; b < lg; ++b) r |= ((m >> b) & 1) << (lg - 1 - b);
+    re[r] = v[2 * m]; im[r] = v[2 * m + 1];
+  }
+  const double pi = 3.14159265358979323846264338327950288;
+  for (int len = 2; len <= M; len <<= 1) {
+    const int h = len / 2;
+    for (int j = 0; j < h; ++j) {
+      const double a = -2.0 * pi * (double)j / (double)len, wr = std::cos(a), wi = std::sin(a);
+      for (int s = j; s < M; s += len) {
+        const double xr = re[s + h] * wr - im[s + h] * wi, xi = re[s + h] * wi + im[s + h] * wr;
+        re[s + h] = re[s] - xr; im[s + h] = im[s] - xi;
+        re[s] += xr; im[s] += xi;
+      }
+    }
+  }
+  for (int k = 0; k < M; ++k) { out[2 * k] = re[k]; out[2 * k + 1] = im[k]; }
+}
+// The output layer of a network (W [n][K] row-major, bias [n], spectrum = W a + bias + shift) restated for rows handed over as
+// packed_half_transform of the spectrum: Wz [n][K], bz [n].
+inline void freq_rows(const float* W, const float* bias, double shift, int n, int K, std::vector<float>& Wz, std::vector<float>& bz) {
+  Wz.assign((size_t)n * K, 0.f); bz.assign((size_t)n, 0.f);
+  std::vector<double> v(n), z(n);
+  for (int h = 0; h <= K; ++h) {
+    for (int i = 0; i < n; ++i) v[i] = h < K ? (double)W[(size_t)i * K + h] : (double)bias[i] + shift;
+    packed_half_transform(v.data(), n, z.data());
+    if (h < K) for (int i = 0; i < n; ++i) Wz[(size_t)i * K + h] = (float)z[i];
+    else for (int i = 0; i < n; ++i) bz[i] = (float)z[i];
+  }
+}
+
 // returns 0 on success, <0 if the wavelength grid is unusable
 inline int build_model_tables(const double* wave, int npix, HostTables& H) {
   if (npix < 16) return -1;

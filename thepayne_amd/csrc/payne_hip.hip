@@ -72,6 +72,9 @@ struct payne_ctx {
   // 3 x bf16 planes for payne_dense_dma3_kernel: the output layer's weights [3][N][w_out_kp], the last hidden layer's output
   // [3][b_max][ld_hid] (written by the hidden-layer kernel's epilogue; zero beyond the hidden width)
   unsigned short* w_out_p3 = nullptr; unsigned short* hid_p3 = nullptr;
+  // the same output layer restated for rows in the frequency domain (host_tables.hpp freq_rows): what the likelihood and the
+  // predictions past stage 0 run when the post kernel can start from the transform (freq_ok); raw_freq: the rows now in c->raw
+  unsigned short* w_out_p3z = nullptr; const float* bias_z = nullptr; bool freq_ok = false, raw_freq = false;
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
@@ -253,6 +256,7 @@ extern "C" const char* payne_kernel_name(int which) {
 }
 
 extern "C" const char* payne_last_kernel(const payne_ctx* c, int kind) {
+  if (c && kind == 4) return c->raw_freq ? "frequency" : "pixels";        // what the output layer handed to the post kernel
   return (c && kind >= 0 && kind < 4) ? c->last_kernel[kind] : "";
 }
 
@@ -404,6 +408,37 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(c->post_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->post_lds);
     if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)));
+    // The first convolution stage's forward transform is linear and the same for every candidate: with identity vsini maps and a
+    // compile-time geometry the output layer writes the rows already transformed (weights = the transform of each hidden unit's
+    // pixel vector, computed here once in fp64), and the post kernel starts at the taper.
+    {
+      const bool fixed = geom_n1 != 0 && ((c->post_tw_lds && (T.n1 == 1024 || T.n1 == 2048 || T.n1 == 4096)) || (!c->post_tw_lds && T.n1 == 8192));
+      if (fixed && T.rot_identity && T.n1 == model->npix && c->w_out_p3 && c->hid_p3 && !(opts->variant & PAYNE_V_ROWS_PIXEL)) {
+        const payne_layer& L = model->layers[model->n_layers - 1];
+        const int K = L.n_in, Kp = c->w_out_kp, n = L.n_out;
+        std::vector<float> W((size_t)n * K), b((size_t)n), Wz, bz;
+        he = hipMemcpy(W.data(), L.w, W.size() * 4, hipMemcpyDeviceToHost);
+        if (he == hipSuccess) he = hipMemcpy(b.data(), L.b, b.size() * 4, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(output layer): ") + hipGetErrorString(he)));
+        freq_rows(W.data(), b.data(), -(double)kBase, n, K, Wz, bz);   // (rows are kept shifted by -1, as the pixel rows are)
+        std::vector<float> Wp((size_t)n * Kp, 0.f);
+        for (int i = 0; i < n; ++i) std::copy(Wz.begin() + (size_t)i * K, Wz.begin() + (size_t)(i + 1) * K, Wp.begin() + (size_t)i * Kp);
+        const float* d_wp = nullptr;
+        std::vector<void*> tmp;
+        if ((rc = upload(c, Wp, &d_wp, tmp))) return bail(rc);
+        const size_t nw = (size_t)n * Kp;
+        rc = dev_alloc(c, 3 * nw, &c->w_out_p3z, c->owned);
+        if (!rc) {
+          hipLaunchKernelGGL(payne_split3_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, nullptr, d_wp, nw, c->w_out_p3z, nw);
+          he = hipDeviceSynchronize();
+        }
+        for (void* q : tmp) (void)hipFree(q);
+        if (rc) return bail(rc);
+        if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("weight split: ") + hipGetErrorString(he)));
+        if ((rc = upload(c, bz, &c->bias_z, c->owned))) return bail(rc);
+        c->freq_ok = true;
+      }
+    }
     c->has_model = true;
     if ((rc = bind_obs(c, obs))) return bail(rc);
   }
@@ -649,10 +684,11 @@ static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
 static bool out_dma3_ok(const payne_ctx* c, int, int) {
   return c->w_out_p3 && c->hid_p3 && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & (PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64));
 }
-static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s) {
+static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool freq) {
   p.k_real = p.K;
   p.K = c->w_out_kp;
-  p.Wp = c->w_out_p3; p.plane_w = (size_t)p.N * c->w_out_kp;
+  p.Wp = freq ? c->w_out_p3z : c->w_out_p3; p.plane_w = (size_t)p.N * c->w_out_kp;
+  if (freq) { p.bias = c->bias_z; p.bias_shift = 0.f; }
   p.Xp = c->hid_p3; p.plane_x = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
   p.grid_m = (p.B + 63) / 64;
   p.grid_n = (p.N + 127) / 128;
@@ -717,6 +753,7 @@ struct NetRef {
   const payne_layer* layers; int n_layers; int n_labels; const double* xmin; const double* xden;
   float* const* hid; int ld_hid; float* out; int ld_out; float out_shift;
   bool spectral;                      // the spectral net owns the DMA / bf16x3 operand copies and the prep records
+  bool freq = false;                  // spectral net: rows written in the frequency domain (c->w_out_p3z)
 };
 // `sed`: a joint likelihood's photometric nets ride in the first hidden-layer launch (sed_tile); *sed is cleared when they did.
 static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, double instr_factor, hipStream_t s, bool* sed = nullptr) {
@@ -736,7 +773,8 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     po.K = L2.n_in; po.bias = L2.b; po.N = L2.n_out; po.B = B; po.act = L2.act; po.bias_shift = N.out_shift;
     po.Y = N.out; po.ldy = N.ld_out;
     po.k_real = po.K; po.K = c->w_out_kp;
-    po.Wp = c->w_out_p3; po.plane_w = (size_t)po.N * c->w_out_kp;
+    po.Wp = N.freq ? c->w_out_p3z : c->w_out_p3; po.plane_w = (size_t)po.N * c->w_out_kp;
+    if (N.freq) { po.bias = c->bias_z; po.bias_shift = 0.f; }
     po.Xp = c->hid_p3; po.plane_x = (size_t)c->opts.b_max * c->ld_hid; po.ldp = c->ld_hid;
     po.grid_m = (B + 63) / 64; po.grid_n = (po.N + 127) / 128;
     const int grid = po.grid_m * po.grid_n;
@@ -800,7 +838,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last) launch_hidden<false>(p, pa, s);
-      else if (use3) launch_out_dma3(c, p, s);
+      else if (use3) launch_out_dma3(c, p, s, N.freq);
       else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) {
         if ((c->w_out_kp % 64) == 0 && (c->opts.variant & PAYNE_V_OUT_BK64)) launch_out_dma<64>(c, p, s);
         else launch_out_dma<32>(c, p, s);
@@ -887,9 +925,14 @@ __global__ void __launch_bounds__(256) payne_cont_kernel(const float* __restrict
 
 // `instr_factor`: what Inst_R is multiplied by (2.355 in the likelihood / genspec, 1 in getspec): the
 // first-layer launch also writes the post kernel's per-candidate records (c->prep) for that factor.
-static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s, bool with_cont = true, bool* sed = nullptr) {
+// `pixels`: the caller reads the rows themselves (stage 0); otherwise they may be handed to the post kernel already transformed.
+static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor, hipStream_t s, bool with_cont = true, bool* sed = nullptr,
+                   bool pixels = false) {
   c->prep_valid = false;
   NetRef N{c->layers, c->n_layers, c->n_labels, c->xmin, c->xden, c->hid, c->ld_hid, c->raw, c->T.npix, kBase, true};
+  // (the continuum multiplies pixel by pixel; out_dma3_ok: the launch that reads the restated weights is the one that runs)
+  N.freq = c->freq_ok && !pixels && !(c->has_cont && with_cont) && out_dma3_ok(c, B, c->T.npix);
+  c->raw_freq = N.freq; c->T.raw_freq = N.freq ? 1 : 0;
   int rc = run_net(c, N, theta, B, instr_factor, s, sed);
   if (rc || !c->has_cont || !with_cont) return rc;
   NetRef C{c->clayers, c->cn_layers, c->n_labels, c->cxmin, c->cxden, c->chid, c->cn_ld_hid, c->cont_raw, c->cn_npix, 0.f, false};
@@ -1054,7 +1097,7 @@ extern "C" int payne_predict_batch(payne_ctx* c, const double* theta, int B, int
   }
   if (stage >= 2 && !c->obs_bound) return fail(c, PAYNE_E_INVALID, "no observed grid bound");
   if (ld_out < (stage >= 2 ? c->T.nobs : c->T.npix)) return fail(c, PAYNE_E_INVALID, "ld_out too small");
-  if ((rc = run_ann(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, s, stage != 0))) return rc;   // stage 0 = predictspec: no continuum
+  if ((rc = run_ann(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, s, stage != 0, nullptr, stage == 0))) return rc;   // stage 0 = predictspec: no continuum
   return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage, out, ld_out, nullptr, false, s);
 }
 
@@ -1081,6 +1124,7 @@ extern "C" int payne_smooth_batch(payne_ctx* c, const float* spectra, int ld_spe
   const size_t n = (size_t)B * c->T.npix;
   hipLaunchKernelGGL(payne_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spectra, ld_spec, c->raw, c->T.npix, B);
   c->prep_valid = false;                                   // no dense launch wrote records for these rows
+  c->raw_freq = false; c->T.raw_freq = 0;                  // ... and they are pixels
   // stage 1 here is smoothspec('vsini') itself: getspec's edge rule (ystpred.py:223-224) is not part of it
   // stage 4: ... interpolated from the stage's own resampled grid onto the bound observed grid (smoothspec('vsini', outwave=...))
   return run_post(c, theta, B, (flags & PAYNE_F_FWHM_R) ? 2.355 : 1.0, stage == 1 ? 6 : (stage == PAYNE_SMOOTH_VSINI_TO_OBS ? 7 : stage), out, ld_out,

@@ -211,6 +211,8 @@ struct PostTables {
   int vs_tab_n;
   int rot_identity;    // the vsini resampling maps are the identity (to fp32): skip them
   float inv_lam0, inv_dln32;  // 1/lam[0], 1/dln in fp32: the +-31-pixel position guess of the mask probe
+  int raw_freq;        // this launch's rows are packed_half_transform (host_tables.hpp) of the spectra: the output layer carried the
+                       // first stage's forward transform in its weights (identity vsini maps, compile-time geometry only)
 };
 
 // Per-candidate scalars from theta, shared by the workgroup (lives in LDS).

@@ -160,7 +160,8 @@ PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool&
 // `rs` (chip executors only): the stage's input is `src0` resampled through this window (the resampling phase was skipped).
 template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
-                            const TaperArgs& ta, bool& edge, const float* src0 = nullptr, const Window* rs = nullptr) {
+                            const TaperArgs& ta, bool& edge, const float* src0 = nullptr, const Window* rs = nullptr,
+                            bool have_z = false) {   // have_z: `work` already holds the forward transform (T.raw_freq rows)
   const int M = n / 2;
   if constexpr (ex_chip<Ex>::value) {
     if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0, rs);
@@ -168,7 +169,7 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
-      c32* z = (PAYNE_EXP_SKIP & 1) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
+      c32* z = ((PAYNE_EXP_SKIP & 1) || have_z) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
       constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
       if (!(PAYNE_EXP_SKIP & 2)) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
@@ -207,6 +208,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   // executors it is made AFTER the row has been requested (a global load and its wait ahead of that request was a round trip
   // of its own at the start of every workgroup); only the fused four-step form needs it before.
   const bool maybe_direct = (out_stage != 0) && T.rot_identity;
+  // rows handed over in the frequency domain (the output layer carried the forward transform): every candidate starts at the
+  // taper -- one that does not rotate with the taper of u = 0, which is 1 in every bin (and without the NaN scrub of the
+  // rotating branch: a row is all NaN or not at all, and a NaN row stays NaN through the transform back)
+  const bool freq = LOG2N > 0 && T.raw_freq != 0;
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
   constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : (NT >= 1024 ? 8 : 16);   // (1024 threads: 128 registers each)
   // global-workspace executor with the four-step transform: the first pass of the vsini transform reads the row itself
@@ -226,7 +231,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (prep) phase_take_prep_commit(t, pr, S);
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
-    if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
+    if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, (direct || freq) ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -236,17 +241,17 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   }
   const bool rot = S.do_rot != 0, smooth = S.do_smooth != 0;
   bool edges_pending = false;
-  if (rot) {
-    if (!direct) ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
+  if (rot || freq) {
+    if (!direct && !freq) ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
     TaperArgs ta{};
     ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
-    ta.vs_c = S.vs_a * T.vs_val;                       // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)
+    ta.vs_c = rot ? S.vs_a * T.vs_val : 0.0;           // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)
     ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
     // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
     // transform's last pass can apply the edge rule itself
-    bool edge = T.rot_identity != 0 && out_stage != 6 && out_stage != 7;   // 6, 7 = smoothspec('vsini') itself: no edge rule
-    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge, fused_row ? raw : nullptr);
-    if (out_stage == 7) {
+    bool edge = rot && T.rot_identity != 0 && out_stage != 6 && out_stage != 7;   // 6, 7 = smoothspec('vsini') itself: no edge rule
+    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge, fused_row ? raw : nullptr, nullptr, freq);
+    if (rot && out_stage == 7) {
       // np.interp(outwave, w_resampled, conv, left = right = NaN) (smoothing.py:308-311): the resampled grid is resample_wave of the
       // WHOLE model grid -- the window of "no mask, no shift"
       const Window Wv = window_from_counts(T, 0.0, 0.0, 0, T.npix);
@@ -255,7 +260,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     }
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
-    else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = out_stage != 6; }
+    else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = rot && out_stage != 6; }
     spec = dst;
     work = conv;
     edges_pending = edge;

@@ -304,8 +304,9 @@ class PayneEngine(object):
         return out
 
     def kernels_used(self):
-        """{'out' | 'post' | 'sed' | 'hidden': kernel name} as launched by the last batch call (payne_last_kernel)."""
-        return {name: self.lib.payne_last_kernel(self._ctx, k).decode().strip("()") for k, name in enumerate(("out", "post", "sed", "hidden"))}
+        """{'out' | 'post' | 'sed' | 'hidden': kernel name, 'rows': 'frequency' | 'pixels'} as launched by the last batch call
+        (payne_last_kernel)."""
+        return {name: self.lib.payne_last_kernel(self._ctx, k).decode().strip("()") for k, name in enumerate(("out", "post", "sed", "hidden", "rows"))}
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
