@@ -58,16 +58,18 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
   T.npoly = npoly;
   if (force_general == 1 || force_general == 2) { T.geo = 0; T.rot_identity = 0; }    // (3: runtime geometry on the geometric grid)
-  // 4: the rows handed over the way the restated output layer writes them (freq_rows): their half transform, rounded to fp32
+  // 4: the rows handed over the way the restated output layer writes them (freq_rows): their half transform in pair layout,
+  // rounded to fp32
   std::vector<float> zrows;
   if (force_general == 4) {
     if (!T.rot_identity || H.n1 != npix) return -78;
     zrows.resize((size_t)B * npix);
-    std::vector<double> v(npix), z(npix);
+    std::vector<double> v(npix), z(npix), zp(npix);
     for (int c = 0; c < B; ++c) {
       for (int i = 0; i < npix; ++i) v[i] = (double)raw_m1[(size_t)c * npix + i];
       packed_half_transform(v.data(), npix, z.data());
-      for (int i = 0; i < npix; ++i) zrows[(size_t)c * npix + i] = (float)z[i];
+      pair_layout(z.data(), npix, zp.data());
+      for (int i = 0; i < npix; ++i) zrows[(size_t)c * npix + i] = (float)zp[i];
     }
     raw_m1 = zrows.data();
     T.raw_freq = 1;

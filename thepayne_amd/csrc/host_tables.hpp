@@ -87,14 +87,25 @@ inline void packed_half_transform(const double* v, int n, double* out) {
   }
   for (int k = 0; k < M; ++k) { out[2 * k] = re[k]; out[2 * k + 1] = im[k]; }
 }
+// ... in the order the post kernel reads it (post_core.hpp slots_issue): the conjugate pair (Z[j], Z[M - j]) side by side in slot j
+// (four floats), j = 1 .. M/2 - 1; slot 0 = (Z[0], Z[M/2]).  M = n/2.
+inline void pair_layout(const double* z, int n, double* out) {
+  const int M = n / 2;
+  out[0] = z[0]; out[1] = z[1]; out[2] = z[M]; out[3] = z[M + 1];
+  for (int j = 1; j < M / 2; ++j) {
+    out[4 * j] = z[2 * j]; out[4 * j + 1] = z[2 * j + 1];
+    out[4 * j + 2] = z[2 * (M - j)]; out[4 * j + 3] = z[2 * (M - j) + 1];
+  }
+}
 // The output layer of a network (W [n][K] row-major, bias [n], spectrum = W a + bias + shift) restated for rows handed over as
-// packed_half_transform of the spectrum: Wz [n][K], bz [n].
+// the half transform of the spectrum in pair layout: Wz [n][K], bz [n].
 inline void freq_rows(const float* W, const float* bias, double shift, int n, int K, std::vector<float>& Wz, std::vector<float>& bz) {
   Wz.assign((size_t)n * K, 0.f); bz.assign((size_t)n, 0.f);
-  std::vector<double> v(n), z(n);
+  std::vector<double> v(n), z(n), zn(n);
   for (int h = 0; h <= K; ++h) {
     for (int i = 0; i < n; ++i) v[i] = h < K ? (double)W[(size_t)i * K + h] : (double)bias[i] + shift;
-    packed_half_transform(v.data(), n, z.data());
+    packed_half_transform(v.data(), n, zn.data());
+    pair_layout(zn.data(), n, z.data());
     if (h < K) for (int i = 0; i < n; ++i) Wz[(size_t)i * K + h] = (float)z[i];
     else for (int i = 0; i < n; ++i) bz[i] = (float)z[i];
   }

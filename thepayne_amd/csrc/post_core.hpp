@@ -211,8 +211,8 @@ struct PostTables {
   int vs_tab_n;
   int rot_identity;    // the vsini resampling maps are the identity (to fp32): skip them
   float inv_lam0, inv_dln32;  // 1/lam[0], 1/dln in fp32: the +-31-pixel position guess of the mask probe
-  int raw_freq;        // this launch's rows are packed_half_transform (host_tables.hpp) of the spectra: the output layer carried the
-                       // first stage's forward transform in its weights (identity vsini maps, compile-time geometry only)
+  int raw_freq;        // this launch's rows are the half transform of the spectra in pair layout (host_tables.hpp freq_rows): the output
+                       // layer carried the first stage's forward transform in its weights (identity vsini maps, compile-time geometry)
 };
 
 // Per-candidate scalars from theta, shared by the workgroup (lives in LDS).
@@ -896,6 +896,74 @@ template <bool VSINI> PAYNE_HD float taper_full(const TaperArgs& ta, int k) {
   float t = taper_at<VSINI>(ta, k, far);
   if (VSINI && far) t = taper_far(ta, k, t);
   return t;
+}
+
+// ---------------------------------------------------------------------------
+// Rows handed over in the frequency domain (PostTables::raw_freq) come in PAIR layout: slot j (16 bytes) = (Z[j], Z[M - j]) for
+// j = 1 .. M/2 - 1, slot 0 = (Z[0], Z[M/2]) (host_tables.hpp freq_rows).  The conjugate pair the middle step combines arrives in
+// ONE load, and the step is done on the way from global memory to LDS: no commit of the row, no barrier, no phase of its own.
+// taper_slot: the two factors of a slot with the normalisation rfft_taper_phase applies (slot 0: taper(M/2)/M and taper(M)); they
+// depend on theta[5] alone.  (Made ahead by riders of the hidden-layer launch they cost that launch 1.6 us and saved this kernel
+// 0.3: NOTES R4.14.)
+PAYNE_HD TaperArgs vsini_taper_args(const PostTables& T, double vrot) {
+  TaperArgs ta{};
+  ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
+  // u_k = 2 pi sigma k/(n dv) (smoothing.py:612-614, :297); a candidate that does not rotate: u = 0, the taper is 1 in every bin
+  ta.vs_c = (vrot != 0.0) ? (2.0 * kPi * sqrt(vrot * vrot - 0.0)) * T.vs_val : 0.0;
+  ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
+  return ta;
+}
+PAYNE_HD void taper_slot(const TaperArgs& ta, int M, int j, float& a, float& b) {
+  const float invM = 1.0f / (float)M, g = 0.25f * invM;
+  float ta_, tb_;
+  taper_full2<true>(ta, j ? j : M / 2, j ? M - j : M, ta_, tb_);
+  if (j) { a = ta_ * g; b = tb_ * g; }
+  else { a = ta_ * invM; b = tb_; }
+}
+template <int SU> struct SlotRegs { float z[SU][4]; c32 w[SU]; float t[SU][2]; };
+// `w`: exp(-2 pi i j/2M), j < M/2, in GLOBAL memory (the kernel's LDS copy of the table is still on its way in this phase)
+template <int SU>
+PAYNE_HD void slots_issue(int tid, int nthr, int M, const float* __restrict__ row, const c32* __restrict__ w, SlotRegs<SU>& R) {
+  const int ns = M / 2;
+#pragma unroll
+  for (int q = 0; q < SU; ++q) {                     // clamped index: unconditional loads
+    const int j0 = tid + q * nthr, j = j0 < ns ? j0 : ns - 1;
+#ifdef __HIP_DEVICE_COMPILE__
+    R.z[q][0] = __builtin_nontemporal_load(&row[4 * j]); R.z[q][1] = __builtin_nontemporal_load(&row[4 * j + 1]);
+    R.z[q][2] = __builtin_nontemporal_load(&row[4 * j + 2]); R.z[q][3] = __builtin_nontemporal_load(&row[4 * j + 3]);
+#else
+    R.z[q][0] = row[4 * j]; R.z[q][1] = row[4 * j + 1]; R.z[q][2] = row[4 * j + 2]; R.z[q][3] = row[4 * j + 3];
+#endif
+    R.w[q] = w[j];
+  }
+}
+// `scrub`: NaN -> 0 first (the rotating branch's nan_to_num; a row is all NaN or not at all)
+template <int SU, class YP>
+PAYNE_HD void slots_commit(int tid, int nthr, int M, SlotRegs<SU>& R, YP Y, const TaperArgs& ta, bool scrub) {
+  const int ns = M / 2;
+  const float invM = 1.0f / (float)M;
+#pragma unroll
+  for (int q = 0; q < SU; ++q) {                     // (all the table loads before any of the pairs)
+    const int j0 = tid + q * nthr, j = j0 < ns ? j0 : ns - 1;
+    taper_slot(ta, M, j, R.t[q][0], R.t[q][1]);
+  }
+#pragma unroll
+  for (int q = 0; q < SU; ++q) {
+    const int j = tid + q * nthr;
+    if (j >= ns) break;
+    c32 zk{R.z[q][0], R.z[q][1]}, zm{R.z[q][2], R.z[q][3]};
+    if (scrub) { zk.x = nan_to_zero(zk.x); zk.y = nan_to_zero(zk.y); zm.x = nan_to_zero(zm.x); zm.y = nan_to_zero(zm.y); }
+    if (j) {
+      c32 yk, ymk;
+      taper_pair(zk, zm, R.w[q], R.t[q][0], R.t[q][1], yk, ymk);
+      st1(Y, j, yk);
+      st1(Y, M - j, ymk);
+    } else {                                         // the two self-conjugate bins (see rfft_taper_phase)
+      const float x0 = zk.x + zk.y, xm = R.t[q][1] * (zk.x - zk.y);
+      st1(Y, 0, c32{0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM});
+      st1(Y, M / 2, cscale(cconj(zm), R.t[q][0]));
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

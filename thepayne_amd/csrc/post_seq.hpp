@@ -161,7 +161,7 @@ PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool&
 template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
                             const TaperArgs& ta, bool& edge, const float* src0 = nullptr, const Window* rs = nullptr,
-                            bool have_z = false) {   // have_z: `work` already holds the forward transform (T.raw_freq rows)
+                            bool have_y = false) {   // have_y: `work` already holds the tapered transform (T.raw_freq rows: slots_commit)
   const int M = n / 2;
   if constexpr (ex_chip<Ex>::value) {
     if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0, rs);
@@ -169,9 +169,9 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
-      c32* z = ((PAYNE_EXP_SKIP & 1) || have_z) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
+      c32* z = ((PAYNE_EXP_SKIP & 1) || have_y) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
       constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
-      if (!(PAYNE_EXP_SKIP & 2)) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
+      if (!(PAYNE_EXP_SKIP & 2) && !have_y) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
       float* res = (PAYNE_EXP_SKIP & 4) ? (float*)z : (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
       edge = false;
@@ -209,9 +209,12 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   // of its own at the start of every workgroup); only the fused four-step form needs it before.
   const bool maybe_direct = (out_stage != 0) && T.rot_identity;
   // rows handed over in the frequency domain (the output layer carried the forward transform): every candidate starts at the
-  // taper -- one that does not rotate with the taper of u = 0, which is 1 in every bin (and without the NaN scrub of the
-  // rotating branch: a row is all NaN or not at all, and a NaN row stays NaN through the transform back)
+  // taper, applied on the way from global memory to LDS (slots_issue / slots_commit) -- one that does not rotate with the taper
+  // of u = 0, which is 1 in every bin (and without the NaN scrub of the rotating branch: a row is all NaN or not at all, and a
+  // NaN row stays NaN through the transform back)
   const bool freq = LOG2N > 0 && T.raw_freq != 0;
+  constexpr int MFq = LOG2N > 0 ? (1 << LOG2N) / 2 : 4;
+  constexpr int SU = (MFq / 2 + NT - 1) / NT;          // slots per thread (2 at 4096 points on 512 threads)
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
   constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : (NT >= 1024 ? 8 : 16);   // (1024 threads: 128 registers each)
   // global-workspace executor with the four-step transform: the first pass of the vsini transform reads the row itself
@@ -221,7 +224,9 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   const bool fused_row = may_fuse && direct;
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
-    if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
+    SlotRegs<SU> slots;
+    if (freq) slots_issue<SU>(t, NT, MFq, raw, T.twf + plan_total(MFq), slots);
+    else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     PrepRegs pr;
     if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
     double th5 = 0.0;
@@ -231,7 +236,8 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (prep) phase_take_prep_commit(t, pr, S);
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
-    if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, (direct || freq) ? bufB : bufA, direct);
+    if (freq) slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
+    else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -245,7 +251,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (!direct && !freq) ex.par([&](int t, int n) { phase_rot_resample(t, n, T, spec, work); });
     TaperArgs ta{};
     ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
-    ta.vs_c = rot ? S.vs_a * T.vs_val : 0.0;           // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)
+    ta.vs_c = rot ? S.vs_a * T.vs_val : 0.0;           // u_k = 2 pi sigma k/(n dv)   (smoothing.py:612-614)   [freq: applied already]
     ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
     // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
     // transform's last pass can apply the edge rule itself

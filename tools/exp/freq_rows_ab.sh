@@ -1,6 +1,6 @@
 #!/bin/bash
 # The output layer carrying the first stage's forward transform (default) against pixel rows (--variant 262144), interleaved.
-#   bash tools/exp/freq_rows_ab.sh [C2|C3] [repeats]
+#   bash tools/exp/freq_rows_ab.sh [C2|C3|LinNet300] [repeats]
 CFG=${1:-C2}; REP=${2:-3}
 one() {
   python bench.py --config $CFG --steps 300 --warmup 30 --variant $2 --no-cpu-baseline --no-e2e --no-also 2>/dev/null | python -c "
