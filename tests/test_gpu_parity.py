@@ -392,6 +392,7 @@ def test_spectra_larger_than_lds_vs_oracle(Engine, variant):
         obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.0005, relative=True)
         th7 = synth.draw_candidates(B, seed=npix)
         th7[:, 6] = np.linspace(0.6, 0.85, B) * R                  # instrument R below the ANN's own
+        th7[1, 5] = 0.0                                            # one candidate that does not rotate
         rows = [list(theta_full(t)[0, :8]) for t in th7]
         ref_flux = np.array([O.genspec(raw, r, outwave=obs)[1] for r in rows])
         flux = ref_flux[0] + np.random.default_rng(1).normal(0, 0.01, nobs)
@@ -404,6 +405,8 @@ def test_spectra_larger_than_lds_vs_oracle(Engine, variant):
         ref = np.array([L.lnlikefn(t) for t in th7])
         lnl = eng.lnlike_batch(theta_full(th7)).cpu().numpy()
         assert np.all(np.abs(lnl - ref) <= lnl_tol(ref)), (npix, np.abs(lnl - ref).max())
+        # the on-chip stages of the 65 536- and 32 768-point geometric grids take the row as its transform (the output layer's weights restated)
+        assert eng.kernels_used()["rows"] == ("frequency" if (npix in (65536, 32768) and variant == 0) else "pixels"), (npix, eng.kernels_used())
         s1 = eng.predict_batch(theta_full(th7[:1]), stage=1).cpu().numpy()[0]
         r1 = O.getspec(raw, Teff=th7[0, 0], logg=th7[0, 1], feh=th7[0, 2], afe=th7[0, 3], rot_vel=th7[0, 5])[1]
         assert np.abs(s1 - r1).max() <= FLUX_TOL

@@ -97,15 +97,43 @@ inline void pair_layout(const double* z, int n, double* out) {
     out[4 * j + 2] = z[2 * (M - j)]; out[4 * j + 3] = z[2 * (M - j) + 1];
   }
 }
+// ... and in the order the on-chip stage of a 65 536-point spectrum holds it (post_onchip.hpp chip_taper_pairs): virtual thread
+// vt = 32 h + l (1024 of them) combines the pairs k = low + 1024 r, r < 16, low = h + 32 l; slot r * 1024 + vt = (Z[k], Z[M - k]),
+// slot 0 = (Z[0], Z[M/2]).  Consecutive lanes read consecutive 16-byte slots.
+inline void chip_layout(const double* z, int n, double* out) {
+  const int M = n / 2;                                       // 32768
+  for (int r = 0; r < 16; ++r)
+    for (int vt = 0; vt < 1024; ++vt) {
+      const int low = (vt >> 5) + 32 * (vt & 31), k = low + 1024 * r, kb = (k == 0) ? M / 2 : M - k;
+      double* o = out + 4 * ((size_t)r * 1024 + vt);
+      o[0] = z[2 * k]; o[1] = z[2 * k + 1]; o[2] = z[2 * kb]; o[3] = z[2 * kb + 1];
+    }
+}
+// ... and of a 32 768-point spectrum of the two-candidates-at-a-time stage (post_onchip2.hpp chip2_taper_pairs): after its third
+// radix stage the virtual thread (h, l) of candidate c = bit 2 of l holds k = low + 512 r, low = h + 32 k2a, k2a = 4 (l >> 3) + (l & 3);
+// slot r * 512 + 16 h + k2a of the candidate's row = (Z[k], Z[M - k]), slot 0 = (Z[0], Z[M/2]).
+inline void chip2_layout(const double* z, int n, double* out) {
+  const int M = n / 2;                                       // 16384
+  for (int r = 0; r < 16; ++r)
+    for (int h = 0; h < 32; ++h)
+      for (int k2a = 0; k2a < 16; ++k2a) {
+        const int low = h + 32 * k2a, k = low + 512 * r, kb = (k == 0) ? M / 2 : M - k;
+        double* o = out + 4 * ((size_t)r * 512 + 16 * h + k2a);
+        o[0] = z[2 * k]; o[1] = z[2 * k + 1]; o[2] = z[2 * kb]; o[3] = z[2 * kb + 1];
+      }
+}
 // The output layer of a network (W [n][K] row-major, bias [n], spectrum = W a + bias + shift) restated for rows handed over as
-// the half transform of the spectrum in pair layout: Wz [n][K], bz [n].
-inline void freq_rows(const float* W, const float* bias, double shift, int n, int K, std::vector<float>& Wz, std::vector<float>& bz) {
+// the half transform of the spectrum: layout 0 pair_layout, 1 chip_layout (n = 65536), 2 chip2_layout (n = 32768).  Wz [n][K], bz [n].
+inline void freq_rows(const float* W, const float* bias, double shift, int n, int K, std::vector<float>& Wz, std::vector<float>& bz,
+                      int layout = 0) {
   Wz.assign((size_t)n * K, 0.f); bz.assign((size_t)n, 0.f);
   std::vector<double> v(n), z(n), zn(n);
   for (int h = 0; h <= K; ++h) {
     for (int i = 0; i < n; ++i) v[i] = h < K ? (double)W[(size_t)i * K + h] : (double)bias[i] + shift;
     packed_half_transform(v.data(), n, zn.data());
-    pair_layout(zn.data(), n, z.data());
+    if (layout == 1) chip_layout(zn.data(), n, z.data());
+    else if (layout == 2) chip2_layout(zn.data(), n, z.data());
+    else pair_layout(zn.data(), n, z.data());
     if (h < K) for (int i = 0; i < n; ++i) Wz[(size_t)i * K + h] = (float)z[i];
     else for (int i = 0; i < n; ++i) bz[i] = (float)z[i];
   }

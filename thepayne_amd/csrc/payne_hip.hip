@@ -413,14 +413,15 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     // pixel vector, computed here once in fp64), and the post kernel starts at the taper.
     {
       const bool fixed = geom_n1 != 0 && ((c->post_tw_lds && (T.n1 == 1024 || T.n1 == 2048 || T.n1 == 4096)) || (!c->post_tw_lds && T.n1 == 8192));
-      if (fixed && T.rot_identity && T.n1 == model->npix && c->w_out_p3 && c->hid_p3 && !(opts->variant & PAYNE_V_ROWS_PIXEL)) {
+      // (65 536 / 32 768 points with the stages on the compute unit: the rows in the order those kernels' registers hold the transform)
+      if ((fixed || c->big_chip || c->big_chip2) && T.rot_identity && T.n1 == model->npix && c->w_out_p3 && c->hid_p3 && !(opts->variant & PAYNE_V_ROWS_PIXEL)) {
         const payne_layer& L = model->layers[model->n_layers - 1];
         const int K = L.n_in, Kp = c->w_out_kp, n = L.n_out;
         std::vector<float> W((size_t)n * K), b((size_t)n), Wz, bz;
         he = hipMemcpy(W.data(), L.w, W.size() * 4, hipMemcpyDeviceToHost);
         if (he == hipSuccess) he = hipMemcpy(b.data(), L.b, b.size() * 4, hipMemcpyDeviceToHost);
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(output layer): ") + hipGetErrorString(he)));
-        freq_rows(W.data(), b.data(), -(double)kBase, n, K, Wz, bz);   // (rows are kept shifted by -1, as the pixel rows are)
+        freq_rows(W.data(), b.data(), -(double)kBase, n, K, Wz, bz, c->big_chip ? 1 : (c->big_chip2 ? 2 : 0));   // (rows are kept shifted by -1, as the pixel rows are)
         std::vector<float> Wp((size_t)n * Kp, 0.f);
         for (int i = 0; i < n; ++i) std::copy(Wz.begin() + (size_t)i * K, Wz.begin() + (size_t)(i + 1) * K, Wp.begin() + (size_t)i * Kp);
         const float* d_wp = nullptr;

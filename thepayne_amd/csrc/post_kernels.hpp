@@ -279,15 +279,15 @@ namespace payne { template <> struct ex_chip<ChipExec> { static constexpr bool v
 #ifdef __HIP_DEVICE_COMPILE__
 namespace payne {
 template <bool VSINI, class Ex>
-PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0, const Window* rs) {
+PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0, const Window* rs, bool zin, bool scrub) {
   if constexpr (ex_chip<Ex>::value) {
     if (rs) {                                                // the instrumental stage: its load resamples `src0` itself
       __shared__ ChipResample R;                             // (handed to the out-of-line stage through LDS)
       if (threadIdx.x == 0) R = chip_resample_of(*rs);
       __syncthreads();
-      chip_conv<VSINI>(ex.L, src0, work, ta, false, edge, (int)threadIdx.x, &R);
+      chip_conv<VSINI>(ex.L, src0, work, ta, false, edge, (int)threadIdx.x, &R, false);
     } else {
-      chip_conv<VSINI>(ex.L, src0 ? src0 : work, work, ta, src0 != nullptr, edge, (int)threadIdx.x, nullptr);
+      chip_conv<VSINI>(ex.L, src0 ? src0 : work, work, ta, src0 != nullptr && scrub, edge, (int)threadIdx.x, nullptr, zin && src0 != nullptr);
     }
     ex.mark(0);
     edge = false;
@@ -380,9 +380,20 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const Po
     }
     if (!pair) {
       __syncthreads();
+      const float* rowp[2] = {a.raw + (size_t)bb[0] * a.ld_raw, a.raw + (size_t)bb[1] * a.ld_raw};
+      if (T.raw_freq) {
+        // rows handed over transformed: back to pixels first (the taper of u = 0 is 1 in every bin; no scrub: a NaN row stays NaN),
+        // into the second candidate's buffers, which the candidate-by-candidate phases below do not use
+        TaperArgs id{};
+        id.vs_tab = T.vs_tab; id.vs_tab_n = T.vs_tab_n;
+        Chip2Io io;
+        io.in[0] = rowp[0]; io.in[1] = rowp[1]; io.out[0] = buf[1][0]; io.out[1] = buf[1][1];
+        chip2_conv<true>(L, io, id, id, false, false, tid, nullptr, true);
+        rowp[0] = buf[1][0]; rowp[1] = buf[1][1];
+      }
       for (int c = 0; c < ncand; ++c) {
         const int b = bb[c];
-        run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw,
+        run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, rowp[c],
                                        buf[0][0], buf[0][1], S2[0], red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, stage, chi2,
                                        a.prep ? a.prep + b : nullptr);
         if (tid == 0 && a.lnl && stage < 0) {
@@ -412,7 +423,7 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const Po
       io.in[0] = buf[0][1]; io.in[1] = buf[1][1];
     }
     io.out[0] = buf[0][1]; io.out[1] = buf[1][1];
-    chip2_conv<true>(L, io, ta[0], ta[1], ident, ident, tid, nullptr);
+    chip2_conv<true>(L, io, ta[0], ta[1], ident, ident, tid, nullptr, ident && T.raw_freq != 0);
     float* spec[2] = {buf[0][1], buf[1][1]};
     if (!ident) {                                            // back onto the model grid (NaN outside), then the edge rule
       for (int c = 0; c < 2; ++c) ex.par([&](int t, int n) { phase_rot_back(t, n, T, buf[c][1], buf[c][0]); });
@@ -425,7 +436,7 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const Po
     ta[0].g_c2 = S2[0].W.g_c2; ta[1].g_c2 = S2[1].W.g_c2;
     float* conv[2] = {spec[0] == buf[0][1] ? buf[0][0] : buf[0][1], spec[1] == buf[1][1] ? buf[1][0] : buf[1][1]};
     io.in[0] = spec[0]; io.in[1] = spec[1]; io.out[0] = conv[0]; io.out[1] = conv[1];
-    chip2_conv<false>(L, io, ta[0], ta[1], false, false, tid, R2);
+    chip2_conv<false>(L, io, ta[0], ta[1], false, false, tid, R2, false);
     // ---- observed grid, blaze, chi^2: candidate by candidate
     for (int c = 0; c < ncand; ++c) {
       const int b = bb[c];

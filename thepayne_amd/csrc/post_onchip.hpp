@@ -303,19 +303,23 @@ __device__ __forceinline__ void chip_taper_send1(const ChipLds& L, const c32 (&u
 #pragma unroll
   for (int j = 0; j < 16; ++j) stc(L.xch, j * 1024 + vt, u[chip_pos(true, 16 + j)]);
 }
-template <bool VSINI>
+// HAVE: the partner's values already sit in registers 16 + r (a row handed over transformed, host_tables.hpp chip_layout:
+// register 16 of thread 0 is Z[M/2])
+template <bool VSINI, bool HAVE = false>
 __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32], int vt, const TaperArgs& ta) {
   constexpr int M = kChipM;
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const ChipPair P = chip_pair(vt);
   // (the registers are in the permuted layout the forward transform leaves: logical r at chip_pos(true, r))
   const c32 z0 = u[chip_pos(true, 0)];                             // thread 0: Z[0] (holds the real bins X[0] and X[M])
-  const c32 zh = ldc(L.xch, vt);                                   // thread 0: Z[M/2] (its register 16, slot 0)
+  const c32 zh = HAVE ? u[chip_pos(true, 16)] : ldc(L.xch, vt);    // thread 0: Z[M/2] (its register 16, slot 0)
+  if constexpr (!HAVE) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int slot = 15 - r + P.sh;                                      // the partner's register 31 - r (thread 0: 32 - r)
     slot = slot > 15 ? 15 : slot;                                  // (thread 0, r = 0: not a pair, the value is not used)
     u[chip_pos(true, 16 + r)] = ldc(L.xch, slot * 1024 + P.pt);
+  }
   }
   // the pairs (k, M - k), k = low + 1024 r, r < 16: taper and real-FFT split / merge
 #pragma unroll
@@ -364,6 +368,16 @@ __device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 
   __syncthreads();
   chip_taper_pairs<VSINI>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI>(L, u1, t1, ta); chip_pin(u1);
   __syncthreads();
+  chip_taper_send2(L, u0, tid); chip_taper_send2(L, u1, t1);
+  __syncthreads();
+  chip_taper_recv2(L, u0, tid); chip_pin(u0); chip_taper_recv2(L, u1, t1); chip_pin(u1);
+  __syncthreads();
+}
+// ... of a row that arrived as its transform with every pair side by side: no first round
+template <bool VSINI>
+__device__ __forceinline__ void chip_taper_have(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid, const TaperArgs& ta) {
+  const int t1 = tid + 32;
+  chip_taper_pairs<VSINI, true>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI, true>(L, u1, t1, ta); chip_pin(u1);
   chip_taper_send2(L, u0, tid); chip_taper_send2(L, u1, t1);
   __syncthreads();
   chip_taper_recv2(L, u0, tid); chip_pin(u0); chip_taper_recv2(L, u1, t1); chip_pin(u1);
@@ -426,12 +440,29 @@ __device__ __forceinline__ void chip_scrub(c32 (&u)[32]) {
 }
 template <bool VSINI>
 __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* __restrict__ in, float* __restrict__ out, const TaperArgs ta,
-                                                    bool scrub, bool edge, int tid, const ChipResample* rs) {
+                                                    bool scrub, bool edge, int tid, const ChipResample* rs, bool zin) {
   typedef float f2g __attribute__((ext_vector_type(2)));
   const PAYNE_AS_GLOBAL f2g* g = (const PAYNE_AS_GLOBAL f2g*)in;
   // the thread's two virtual threads: vt0 = (h = 2 i, l), vt1 = (h = 2 i + 1, l), i = tid / 32, l = tid % 32
   const int vt0 = 64 * (tid >> 5) + (tid & 31);
   c32 u0[32], u1[32];
+  if (zin) {
+    // the row is the TRANSFORM of the spectrum (the output layer's weights carried it), in the order the taper wants it
+    // (chip_layout): slot r * 1024 + vt = (Z[k], Z[M - k]), k = low + 1024 r -- no forward transform, no first exchange round
+    typedef float f4g __attribute__((ext_vector_type(4)));
+    const PAYNE_AS_GLOBAL f4g* g4 = (const PAYNE_AS_GLOBAL f4g*)in;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const PAYNE_AS_GLOBAL f4g* ga = g4 + 1024 * r;
+      const PAYNE_AS_GLOBAL f4g* gb = g4 + 1024 * r + 32;
+      const f4g v = ga[vt0], w = gb[vt0];
+      u0[chip_pos(true, r)] = {v.x, v.y}; u0[chip_pos(true, 16 + r)] = {v.z, v.w};
+      u1[chip_pos(true, r)] = {w.x, w.y}; u1[chip_pos(true, 16 + r)] = {w.z, w.w};
+    }
+    if (scrub) { chip_scrub(u0); chip_scrub(u1); }
+    chip_pin(u0); chip_pin(u1);
+    chip_taper_have<VSINI>(L, u0, u1, vt0, ta);
+  } else {
   if (rs) {
     const ChipResample R = *rs;
     chip_gather_t<1024>(in, R, vt0, u0);
@@ -450,6 +481,7 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
   chip_pin(u0); chip_pin(u1);
   chip_fft_fwd(L, u0, u1, vt0);
   chip_taper<VSINI>(L, u0, u1, vt0, ta);
+  }
   chip_fft_back(L, u0, u1, vt0);
   chip_pin(u0); chip_pin(u1);
   PAYNE_AS_GLOBAL f2g* o = (PAYNE_AS_GLOBAL f2g*)out;

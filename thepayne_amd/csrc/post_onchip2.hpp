@@ -157,18 +157,21 @@ __device__ __forceinline__ ChipPair chip2_pair(int vt_) {
   p.sh = p.t0 ? 1 : 0;
   return p;
 }
-template <bool VSINI>
+// HAVE: the partner's values already sit in registers 16 + r (a row handed over transformed: host_tables.hpp chip2_layout)
+template <bool VSINI, bool HAVE = false>
 __device__ __forceinline__ void chip2_taper_pairs(const ChipLds& L, c32 (&u)[32], int vt, const TaperArgs& ta) {
   constexpr int M = kChip2M;
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
   const ChipPair P = chip2_pair(vt);
   const c32 z0 = u[chip_pos(true, 0)];
-  const c32 zh = ldc(L.xch, chip_fresh(vt));
+  const c32 zh = HAVE ? u[chip_pos(true, 16)] : ldc(L.xch, chip_fresh(vt));
+  if constexpr (!HAVE) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int slot = 15 - r + P.sh;
     slot = slot > 15 ? 15 : slot;
     u[chip_pos(true, 16 + r)] = ldc(L.xch, slot * 1024 + P.pt);
+  }
   }
 #pragma unroll
   for (int r = 0; r < ((PAYNE_EXP_CHIP & 8) ? 0 : 16); ++r) {
@@ -205,11 +208,13 @@ __device__ __forceinline__ void chip2_taper_recv2(const ChipLds& L, c32 (&u)[32]
 }
 // (after S3 the candidate of a virtual thread is bit 2 of l -- NOT the half of the workgroup it started in: the taper's arguments
 //  are chosen per virtual thread here, by lane)
-template <bool VSINI>
+template <bool VSINI, bool HAVE = false>
 __device__ __forceinline__ void chip2_taper(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0, const TaperArgs& ta0, const TaperArgs& ta1) {
   const int vt1 = vt0 + 32;
-  chip_taper_send1(L, u0, vt0); chip_taper_send1(L, u1, vt1);
-  __syncthreads();
+  if constexpr (!HAVE) {
+    chip_taper_send1(L, u0, vt0); chip_taper_send1(L, u1, vt1);
+    __syncthreads();
+  }
   // both virtual threads of a thread have the same l, hence the same candidate; what differs between the candidates' tapers are
   // three scalars (the table is the context's)
   const bool second = ((chip_fresh(vt0) >> 2) & 1) != 0;
@@ -217,8 +222,8 @@ __device__ __forceinline__ void chip2_taper(const ChipLds& L, c32 (&u0)[32], c32
   ta.vs_c64 = second ? ta1.vs_c64 : ta0.vs_c64;
   ta.vs_c = second ? ta1.vs_c : ta0.vs_c;
   ta.g_c2 = second ? ta1.g_c2 : ta0.g_c2;
-  chip2_taper_pairs<VSINI>(L, u0, vt0, ta); chip_pin(u0); chip2_taper_pairs<VSINI>(L, u1, vt1, ta); chip_pin(u1);
-  __syncthreads();
+  chip2_taper_pairs<VSINI, HAVE>(L, u0, vt0, ta); chip_pin(u0); chip2_taper_pairs<VSINI, HAVE>(L, u1, vt1, ta); chip_pin(u1);
+  if constexpr (!HAVE) __syncthreads();                            // (round 1's slots are read no more)
   chip_taper_send2(L, u0, vt0); chip_taper_send2(L, u1, vt1);
   __syncthreads();
   chip2_taper_recv2(L, u0, vt0); chip_pin(u0); chip2_taper_recv2(L, u1, vt1); chip_pin(u1);
@@ -230,7 +235,7 @@ struct Chip2Io { const float* in[2]; float* out[2]; };
 // windows (LDS) when the stage gathers its own input, else null.
 template <bool VSINI>
 __device__ __attribute__((noinline)) void chip2_conv(const ChipLds L, const Chip2Io io, const TaperArgs ta0, const TaperArgs ta1,
-                                                     bool scrub, bool edge, int tid, const ChipResample* rs) {
+                                                     bool scrub, bool edge, int tid, const ChipResample* rs, bool zin) {
   typedef float f2g __attribute__((ext_vector_type(2)));
   const int c = __builtin_amdgcn_readfirstlane(tid >> 8);           // this wave's candidate while the data is in "time" order
   const float* in = c ? io.in[1] : io.in[0];
@@ -239,6 +244,22 @@ __device__ __attribute__((noinline)) void chip2_conv(const ChipLds L, const Chip
   const int vt0 = 64 * (tid >> 5) + (tid & 31);
   const int tp0 = vt0 & 511;                                        // t' of the first virtual thread (the second: + 32)
   c32 u0[32], u1[32];
+  if (zin) {
+    // the rows are the TRANSFORMS of the two spectra in the order the taper wants them (chip2_layout): in the spectrum the
+    // candidate of a virtual thread is bit 2 of its lane digit -- each lane reads its own candidate's row
+    typedef float f4g __attribute__((ext_vector_type(4)));
+    const int lz = vt0 & 31, k2a = 4 * (lz >> 3) + (lz & 3), s0 = 16 * (vt0 >> 5) + k2a;
+    const PAYNE_AS_GLOBAL f4g* gz = (const PAYNE_AS_GLOBAL f4g*)(((lz >> 2) & 1) ? io.in[1] : io.in[0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const f4g v = gz[512 * r + s0], w = gz[512 * r + s0 + 16];
+      u0[chip_pos(true, r)] = {v.x, v.y}; u0[chip_pos(true, 16 + r)] = {v.z, v.w};
+      u1[chip_pos(true, r)] = {w.x, w.y}; u1[chip_pos(true, 16 + r)] = {w.z, w.w};
+    }
+    if (scrub) { chip_scrub(u0); chip_scrub(u1); }
+    chip_pin(u0); chip_pin(u1);
+    chip2_taper<VSINI, true>(L, u0, u1, vt0, ta0, ta1);
+  } else {
   if (rs) {
     const ChipResample R = rs[c];
     chip_gather_t<512>(in, R, tp0, u0);                             // (candidate c's masked, Doppler-shifted spectrum onto its pow-2 log grid)
@@ -256,6 +277,7 @@ __device__ __attribute__((noinline)) void chip2_conv(const ChipLds L, const Chip
   chip_pin(u0); chip_pin(u1);
   chip2_fft_fwd(L, u0, u1, vt0);
   chip2_taper<VSINI>(L, u0, u1, vt0, ta0, ta1);
+  }
   chip2_fft_back(L, u0, u1, vt0);
   chip_pin(u0); chip_pin(u1);
   PAYNE_AS_GLOBAL f2g* o = (PAYNE_AS_GLOBAL f2g*)out;

@@ -151,7 +151,7 @@ PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsign
 constexpr int kChipN1 = 65536;
 template <class Ex> struct ex_chip { static constexpr bool value = false; };
 template <bool VSINI, class Ex>
-PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0, const Window* rs);
+PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool& edge, const float* src0, const Window* rs, bool zin, bool scrub);
 
 // One real FFT-convolution stage of n points sitting in `work` (other buffer: `other`).
 // `twf`: pass-ordered table of the fixed geometry (LDS or global); T.tw: plain full circle.
@@ -161,10 +161,11 @@ PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool&
 template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
                             const TaperArgs& ta, bool& edge, const float* src0 = nullptr, const Window* rs = nullptr,
-                            bool have_y = false) {   // have_y: `work` already holds the tapered transform (T.raw_freq rows: slots_commit)
+                            bool have_y = false,     // have_y: `work` already holds the tapered transform (T.raw_freq rows: slots_commit)
+                            bool zin = false, bool scrub = true) {   // chip executors: src0 is the row's transform (chip_layout); NaN -> 0 on the way in
   const int M = n / 2;
   if constexpr (ex_chip<Ex>::value) {
-    if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0, rs);
+    if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0, rs, zin, scrub);
   }
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
@@ -212,7 +213,9 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   // taper, applied on the way from global memory to LDS (slots_issue / slots_commit) -- one that does not rotate with the taper
   // of u = 0, which is 1 in every bin (and without the NaN scrub of the rotating branch: a row is all NaN or not at all, and a
   // NaN row stays NaN through the transform back)
-  const bool freq = LOG2N > 0 && T.raw_freq != 0;
+  // (the on-chip stage of a 65 536-point spectrum takes the transformed row straight into its registers: chip_conv)
+  const bool freq_chip = ex_chip<Ex>::value && T.n1 == kChipN1 && T.raw_freq != 0;
+  const bool freq = (LOG2N > 0 && T.raw_freq != 0) || freq_chip;
   constexpr int MFq = LOG2N > 0 ? (1 << LOG2N) / 2 : 4;
   constexpr int SU = (MFq / 2 + NT - 1) / NT;          // slots per thread (2 at 4096 points on 512 threads)
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
@@ -221,11 +224,11 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   const bool may_fuse = maybe_direct && row_vectorised(T.npix, raw) &&
                         ((ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2)) || (ex_chip<Ex>::value && T.n1 == kChipN1));
   bool direct = may_fuse ? (th[5] != 0.0) : false;
-  const bool fused_row = may_fuse && direct;
+  const bool fused_row = may_fuse && (direct || freq_chip);
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
     SlotRegs<SU> slots;
-    if (freq) slots_issue<SU>(t, NT, MFq, raw, T.twf + plan_total(MFq), slots);
+    if (freq && !freq_chip) slots_issue<SU>(t, NT, MFq, raw, T.twf + plan_total(MFq), slots);
     else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     PrepRegs pr;
     if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
@@ -236,7 +239,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (prep) phase_take_prep_commit(t, pr, S);
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
-    if (freq) slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
+    if (freq && !freq_chip) slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
     else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
@@ -256,7 +259,8 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     // identity maps: the convolved buffer IS the spectrum on the ANN grid (npix == n1), and the
     // transform's last pass can apply the edge rule itself
     bool edge = rot && T.rot_identity != 0 && out_stage != 6 && out_stage != 7;   // 6, 7 = smoothspec('vsini') itself: no edge rule
-    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge, fused_row ? raw : nullptr, nullptr, freq);
+    float* conv = conv_stage<LOG2N, NT, true>(ex, T, twf, work, spec, T.n1, ta, edge, fused_row ? raw : nullptr, nullptr, freq && !freq_chip,
+                                              freq_chip, direct);
     if (rot && out_stage == 7) {
       // np.interp(outwave, w_resampled, conv, left = right = NaN) (smoothing.py:308-311): the resampled grid is resample_wave of the
       // WHOLE model grid -- the window of "no mask, no shift"
