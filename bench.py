@@ -263,7 +263,7 @@ def alg_work(d):
     flops_eval = 2.0 * (D * H + nhh * H * H + H * N) + fl_post_alg + fl_sed
     bytes_batch = 4.0 * (D * H + H + nhh * (H * H + H) + H * N + N) + 8.0 * N + 16.0 * d["nobs"] + B * (8.0 * 12 + 4) \
         + 4.0 * F * (6 * HP + HP + HP * HP + HP + HP + 1)
-    return dict(flops_eval=flops_eval, bytes_batch=bytes_batch, flops_post=fl_post, flops_sed=fl_sed,
+    return dict(flops_eval=flops_eval, bytes_batch=bytes_batch, flops_post=fl_post, flops_post_alg=fl_post_alg, flops_sed=fl_sed,
                 flops_out=2.0 * H * N)
 
 
@@ -414,6 +414,13 @@ def roofline_blocks(cfg_name, res, args):
         out["rows_handed_to_post_kernel"] = rows
         if dom == "post":
             out["roofline"]["transforms_in_kernel"] = d["post_transforms"]
+            if d["post_transforms"] != 4:
+                # SURVEY 8(d)'s own figure for everything after the network (four transforms), over the same launch time: the
+                # transform the output layer's weights carry is done, at no product of its own
+                a8 = B * W["flops_post_alg"] / (max(per[dom], 1e-9) * 1e-6) / 1e12
+                out["roofline"]["survey_8d"] = {"alg_flops_per_launch": B * W["flops_post_alg"], "achieved": a8, "frac": a8 / PEAK_FP32_TFLOPS,
+                                                "what": "`achieved` / `frac` above count the three transforms this kernel executes; these count "
+                                                        "the four of the algorithm it completes"}
             out["roofline"]["note"] = ("FFT / interpolation pipeline in LDS: no MFMA instructions; priced against the "
                                        "packed-fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s). The MFMA kernel of "
                                        "the step is under `mfma_kernel`.")
