@@ -406,7 +406,7 @@ __device__ __forceinline__ ChipResample chip_resample_of(const Window& W) {
 }
 // STRIDE: complex points between two registers of a virtual thread (1024: one 65 536-point spectrum; 512: one of two 32 768-point ones)
 template <int STRIDE>
-__device__ __forceinline__ void chip_gather_t(const float* __restrict__ spec, const ChipResample& R, int vt, c32 (&u)[32]) {
+__device__ __forceinline__ void chip_gather_t(const float* spec, const ChipResample& R, int vt, c32 (&u)[32]) {
   const double step = (double)(2 * STRIDE) * R.rsA;                 // real points 2 n and 2 n + 1 of n = vt + STRIDE a
   double te = fma((double)(2 * vt), R.rsA, R.rsBm), to = fma((double)(2 * vt + 1), R.rsA, R.rsBm);
 #pragma unroll
@@ -439,7 +439,7 @@ __device__ __forceinline__ void chip_scrub(c32 (&u)[32]) {
   for (int a = 0; a < 32; a += 4) nan_scrub8(u[a].x, u[a].y, u[a + 1].x, u[a + 1].y, u[a + 2].x, u[a + 2].y, u[a + 3].x, u[a + 3].y);
 }
 template <bool VSINI>
-__device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* __restrict__ in, float* __restrict__ out, const TaperArgs ta,
+__device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* in, float* out, const TaperArgs ta,   // (in == out is allowed)
                                                     bool scrub, bool edge, int tid, const ChipResample* rs, bool zin) {
   typedef float f2g __attribute__((ext_vector_type(2)));
   const PAYNE_AS_GLOBAL f2g* g = (const PAYNE_AS_GLOBAL f2g*)in;

@@ -312,7 +312,9 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
       bool no_edge = false;
-      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, work, spec, W.n2, ta, no_edge, gather ? spec : nullptr, gather ? &W : nullptr);
+      // (a stage that gathers its input itself has all of it in registers before it stores anything: its output goes where its
+      //  input was -- one 256 KB buffer per workgroup in flight instead of two, 67 MB for the 256 workgroups of a C5 launch)
+      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, gather ? spec : work, spec, W.n2, ta, no_edge, gather ? spec : nullptr, gather ? &W : nullptr);
     }
   }
   if (!(PAYNE_EXP_SKIP & 16)) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
