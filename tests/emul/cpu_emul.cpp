@@ -36,6 +36,16 @@ static void run_one(HostExec& ex, const PostTables& T, const double* th, double 
   run_candidate<LOG2N, kPostThreads>(ex, T, T.twf, th, factor, raw, a, b, S, red, out, stage, x2, prep);
 }
 
+// The output layer restated for rows in the frequency domain (host_tables.hpp freq_rows: what payne_ctx_create uploads), for the CPU
+// test that checks it against numpy's FFT.  layout: 0 pair_layout, 1 chip_layout (n = 65536), 2 chip2_layout (n = 32768).
+extern "C" int payne_emul_freq_rows(const float* W, const float* bias, double shift, int n, int K, int layout, float* Wz, float* bz) {
+  std::vector<float> wz, b;
+  freq_rows(W, bias, shift, n, K, wz, b, layout);
+  std::memcpy(Wz, wz.data(), wz.size() * sizeof(float));
+  std::memcpy(bz, b.data(), b.size() * sizeof(float));
+  return 0;
+}
+
 extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const double* obs_wave,
                                const double* obs_flux, const double* obs_eflux, int nobs, int npoly,
                                const double* theta, int ncols, int B, double instr_factor,

@@ -43,6 +43,7 @@ def emul():
         assert rc == 0, rc        # -77/-78: the setup-time mask probe disagrees with the full mask count
         return out, chi2, info
     run.fast_windows = lib.payne_emul_fast_windows
+    run.lib = lib
     return run
 
 
@@ -206,3 +207,43 @@ def test_four_step_transform_reads_the_row_itself_on_a_geometric_grid(emul):
     with np.errstate(all="ignore"):
         _, ref = O.getspec(net, Teff=5600.0, logg=4.3, feh=-0.2, afe=0.1, rad_vel=12.0, rot_vel=6.0, inst_R=60000.0, outwave=obs)
     assert np.array_equal(np.isnan(fused[0]), np.isnan(ref)) and np.nanmax(np.abs(fused[0] - ref)) <= 1e-6
+
+
+@pytest.mark.parametrize("n,layout", [(1024, 0), (4096, 0), (65536, 1), (32768, 2)])
+def test_output_layer_restated_for_rows_in_the_frequency_domain(emul, n, layout):
+    """host_tables.hpp freq_rows (what payne_ctx_create uploads beside the pixel weights): every hidden unit's pixel vector and the
+    bias - 1 as the half-length complex transform Z = FFT_M(v[2m] + i v[2m+1]) (numpy's sign convention), bins placed where the post
+    kernels read them: pair layout (slot j = Z[j], Z[M-j]; slot 0 = Z[0], Z[M/2]) for the LDS kernel, the register order of the
+    on-chip stages for 65 536 / 32 768 points.  Linearity is then the whole argument: W_z a + b_z is the transform of W a + b - 1."""
+    rng = np.random.default_rng(n)
+    K, M = 5, n // 2
+    W = rng.normal(0, 0.05, (n, K)).astype(np.float32)
+    b = (1.0 + rng.normal(0, 0.02, n)).astype(np.float32)
+    Wz, bz = np.zeros((n, K), np.float32), np.zeros(n, np.float32)
+    assert emul.lib.payne_emul_freq_rows(W.ctypes.data_as(fp), b.ctypes.data_as(fp), ctypes.c_double(-1.0), n, K, layout,
+                                         Wz.ctypes.data_as(fp), bz.ctypes.data_as(fp)) == 0
+    # the bin k of every slot, and its partner
+    if layout == 0:
+        k = np.arange(M // 2)
+    elif layout == 1:                                            # virtual thread vt = 32 h + l combines k = h + 32 l + 1024 r
+        r, vt = np.divmod(np.arange(16 * 1024), 1024)
+        k = (vt >> 5) + 32 * (vt & 31) + 1024 * r
+    else:                                                        # slot r * 512 + 16 h + k2a holds k = h + 32 k2a + 512 r
+        r, q = np.divmod(np.arange(16 * 512), 512)
+        h, k2a = np.divmod(q, 16)
+        k = h + 32 * k2a + 512 * r
+    kb = np.where(k == 0, M // 2, M - k)
+    seen = np.zeros(M, int)
+    np.add.at(seen, k, 1); np.add.at(seen, kb, 1)
+    assert (seen == 1).all()                                     # every bin of the transform exactly once
+
+    def place(v):
+        Z = np.fft.fft(v[0::2].astype(np.float64) + 1j * v[1::2].astype(np.float64))
+        out = np.empty(n)
+        out[0::4], out[1::4], out[2::4], out[3::4] = Z[k].real, Z[k].imag, Z[kb].real, Z[kb].imag
+        return out
+    for col in range(K):
+        ref = place(W[:, col])
+        assert np.abs(Wz[:, col] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    ref = place(b.astype(np.float64) - 1.0)
+    assert np.abs(bz - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
