@@ -137,6 +137,8 @@ typedef struct payne_opts {
 #define PAYNE_V_ROWS_PIXEL 262144u /* the output layer writes pixels and the post kernel transforms them itself (what runs with a continuum
                                     * network, with vsini maps that are not the identity, and for spectra other than 1k/2k/4k/8k);
                                     * default where it applies: the output layer's weights carry the first stage's forward transform */
+#define PAYNE_V_QUEUE_MEMCPY 1048576u /* the sampler's proposal queue moved by hipMemcpyAsync and collected by hipStreamSynchronize (default: copy
+                                       * kernels on mapped host memory, completion read from a word the last of them writes there) */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

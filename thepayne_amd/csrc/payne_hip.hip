@@ -18,6 +18,7 @@
 //                       photANN.fastANN + highAv + the magnitude formulae of predictsed.py.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1153,6 +1154,11 @@ struct payne_sampler {
   double* spec = nullptr;                 // [k_max][2][kSpecStride] the next step's proposals made ahead (null: more dimensions / columns than a record holds)
   // staging of payne_ns_rwalk_queue: chains (u | v | lnprob) and counters (nacc | ncall | nredraw), device + pinned host
   double *q_dev = nullptr, *q_host = nullptr;
+  // the queue's transfers as KERNELS on mapped host memory (q_host_dev: the device's address of q_host) and its completion as a word
+  // the last of them writes into it (q_flag, behind the staging block; q_seq: the value the queue in flight will write) -- the
+  // host reads that word instead of synchronising the stream: hipMemcpyAsync's own enqueue (17 us) and the wake-up out of
+  // hipStreamSynchronize were most of the GPU's idle time between two queues (NOTES R4.16).  Null: PAYNE_V_QUEUE_MEMCPY.
+  double* q_host_dev = nullptr; volatile unsigned long long* q_flag = nullptr; unsigned long long* q_flag_dev = nullptr; unsigned long long q_seq = 0;
   std::vector<int> pk_src, pk_heap;       // payne_ns_rwalk_queue_turn: the live set its peek predicts, by index (payne_ns::peek_index)
   std::vector<double> pk_l;
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
@@ -1252,9 +1258,18 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     for (int i = 0; i < PAYNE_MAX_DIM; ++i) { s->sd.q0[i] = qh[i]; s->sd.q1[i] = qh[PAYNE_MAX_DIM + i]; }
   }
   (void)hipMemset(s->inside, 0, K * 4);
-  if (hipHostMalloc((void**)&s->q_host, q_doubles(K, nd) * 8, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&s->q_host, (q_doubles(K, nd) + 8) * 8, hipHostMallocMapped) != hipSuccess) {
     payne_sampler_destroy(s);
     return fail(c, PAYNE_E_HIP, "hipHostMalloc(sampler staging)");
+  }
+  if (!(c->opts.variant & PAYNE_V_QUEUE_MEMCPY)) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, s->q_host, 0) == hipSuccess && dp) {
+      s->q_host_dev = static_cast<double*>(dp);
+      s->q_flag = reinterpret_cast<volatile unsigned long long*>(s->q_host + q_doubles(K, nd));
+      s->q_flag_dev = reinterpret_cast<unsigned long long*>(s->q_host_dev + q_doubles(K, nd));
+      *s->q_flag = 0ull;
+    }
   }
   *out = s;
   return PAYNE_OK;
@@ -1375,6 +1390,18 @@ extern "C" int payne_rwalk_batch(payne_sampler* s, double* u, double* v, double*
 // _end waits for the stream and selects the chains that moved.  payne_ns_rwalk_queue is the two back to back.
 // `src` (payne_ns_rwalk_queue_turn): live slot i holds row src[i] of (qu, qv) with lnprob lg[i] when src[i] >= 0 -- the live set a
 // queue's consumption will leave, by index (payne_ns::peek_index), never copied
+// The queue's staging block up (from mapped host memory) and down (into it; ONE workgroup, which then publishes the queue's
+// sequence number behind the block with system scope -- what payne_ns_rwalk_queue_end waits for).
+__global__ void __launch_bounds__(256) payne_stage_in_kernel(double* __restrict__ dst, const double* __restrict__ src_host, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src_host[i];
+}
+__global__ void __launch_bounds__(1024) payne_stage_out_kernel(double* __restrict__ dst_host, const double* __restrict__ src, size_t n,
+                                                               unsigned long long* flag, unsigned long long seq) {
+  for (size_t i = threadIdx.x; i < n; i += 1024) dst_host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 static int queue_begin_core(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
                             int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
                             double scale, double loglstar, int walks, unsigned long long seed, void* stream,
@@ -1434,7 +1461,12 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
     std::memcpy(hax + n_ax, ctr, (size_t)n_ell * nd * 8);
     std::memcpy(hax + n_ax + (size_t)n_ell * nd, ainv, n_ax * 8);
   }
-  HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, (nq_d + n_cnt + n_ax + n_as) * 8, hipMemcpyHostToDevice, st));
+  if (s->q_host_dev) {
+    const size_t n_up = nq_d + n_cnt + n_ax + n_as;
+    hipLaunchKernelGGL(payne_stage_in_kernel, dim3((unsigned)((n_up + 1023) / 1024)), dim3(256), 0, st, s->q_dev, s->q_host_dev, n_up);
+  } else {
+    HIPCHK(c, hipMemcpyAsync(s->q_dev, s->q_host, (nq_d + n_cnt + n_ax + n_as) * 8, hipMemcpyHostToDevice, st));
+  }
   double* du = s->q_dev;
   double* dv = du + (size_t)K * nd;
   double* dl = dv + (size_t)K * nd;
@@ -1447,7 +1479,14 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
   if (n_ell > 1) { s->walk.as_ctr = dax + n_ax; s->walk.as_ainv = dax + n_ax + (size_t)n_ell * nd; s->walk.ell_out = dell; s->walk.n_ell = n_ell; }
   for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, (nq_d + n_cnt) * 8, hipMemcpyDeviceToHost, st));
+  if (s->q_host_dev) {
+    ++s->q_seq;
+    hipLaunchKernelGGL(payne_stage_out_kernel, dim3(1), dim3(1024), 0, st, s->q_host_dev, s->q_dev, nq_d + n_cnt, s->q_flag_dev, s->q_seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("queue staging launch: ") + hipGetErrorString(e));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(s->q_host, s->q_dev, (nq_d + n_cnt) * 8, hipMemcpyDeviceToHost, st));
+  }
   s->queue_open = true; s->queue_K = K; s->queue_stream = stream;
   return PAYNE_OK;
 }
@@ -1462,7 +1501,18 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   const double* hu = s->q_host;
   const double* hv = hu + (size_t)K * nd;
   const double* hl = hv + (size_t)K * nd;
-  HIPCHK(c, hipStreamSynchronize(st));
+  if (s->q_flag) {
+    // the word the queue's last kernel writes behind its results (every kernel before it on the stream has completed by then);
+    // a queue that does not report within 10 s is handed to hipStreamSynchronize, which returns the fault if there was one
+    const unsigned long long want = s->q_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(const_cast<const unsigned long long*>(s->q_flag), __ATOMIC_ACQUIRE) != want) {
+      if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { HIPCHK(c, hipStreamSynchronize(st)); break; }
+    }
+  } else {
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
   // ---- the chains that moved are the queue; a chain that never moved is a copy of a live point
   long long acc = 0, calls = 0, redraw = 0, idle_calls = 0;
   int m = 0;
