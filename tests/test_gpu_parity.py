@@ -602,3 +602,36 @@ def test_fused_dense_launch_hands_fresh_activations_over_every_step(Engine):
     for Bs in (64, 128, 448, 100):
         th = theta_full(synth.draw_candidates(Bs, seed=77))
         assert np.array_equal(np.nan_to_num(ref.lnlike_batch(th).cpu().numpy()), np.nan_to_num(fus.lnlike_batch(th).cpu().numpy()))
+
+
+def test_row_domains_switch_within_one_context(Engine):
+    """One context, calls in turn that hand the post kernel rows in the frequency domain (likelihood, getspec), in pixels
+    (predictspec; spectra supplied by the caller; everything while a continuum network is bound) and back: every call gives what a
+    fresh context gives for it, and payne_last_kernel(kind 4) names the domain each one ran in."""
+    from thepayne_amd import nnio
+    raw, obs, flux, eflux = yst_problem("small", H=64)
+    th = theta_full(synth.draw_candidates(12, seed=77))
+    th[3, 5] = 0.0                                                  # one candidate that does not rotate
+
+    def fresh():
+        return Engine(_net(raw), obs=(obs, flux, eflux), b_max=16)
+    ref_l = fresh().lnlike_batch(th).cpu().numpy()
+    ref_2 = fresh().predict_batch(th, stage=2, fwhm_R=True).cpu().numpy()
+    ref_0 = fresh().predict_batch(th, stage=0).cpu().numpy()
+    sp = ref_0.astype(np.float32)
+    ref_s = fresh().smooth_batch(sp, th, stage=2, fwhm_R=True).cpu().numpy()
+    eng = fresh()
+    for _ in range(2):
+        assert np.array_equal(eng.lnlike_batch(th).cpu().numpy(), ref_l, equal_nan=True) and eng.kernels_used()["rows"] == "frequency"
+        assert np.array_equal(eng.predict_batch(th, stage=0).cpu().numpy(), ref_0) and eng.kernels_used()["rows"] == "pixels"
+        assert np.array_equal(eng.predict_batch(th, stage=2, fwhm_R=True).cpu().numpy(), ref_2, equal_nan=True) and eng.kernels_used()["rows"] == "frequency"
+        assert np.array_equal(eng.smooth_batch(sp, th, stage=2, fwhm_R=True).cpu().numpy(), ref_s, equal_nan=True) and eng.kernels_used()["rows"] == "pixels"
+    # the same spectra through the network (frequency rows) and handed over as pixels (its own predictspec output): the same getspec
+    assert np.nanmax(np.abs(ref_s - ref_2)) <= FLUX_TOL
+    # a continuum network multiplies pixel by pixel: pixel rows while it is bound, frequency rows again once it is removed
+    cnet = nnio.normalize_spec_net(synth.make_cont_net(npix=300, lam_lo=raw["wavelength"][0] - 2.0, lam_hi=raw["wavelength"][-1] + 2.0, H=16), "YST1")
+    eng.set_continuum(cnet)
+    with_c = eng.lnlike_batch(th).cpu().numpy()
+    assert eng.kernels_used()["rows"] == "pixels" and not np.array_equal(with_c, ref_l, equal_nan=True)
+    eng.set_continuum(None)
+    assert np.array_equal(eng.lnlike_batch(th).cpu().numpy(), ref_l, equal_nan=True) and eng.kernels_used()["rows"] == "frequency"
