@@ -442,6 +442,25 @@ int payne_ns_rwalk_queue_turn(payne_sampler* s, double* qu, double* qv, double* 
  * has no likelihood-only kernel).  Measurement / test aid, no reference counterpart. */
 int payne_sampler_counters(const payne_sampler* s, long long out[2]);
 
+/* The proposal queue's TURN on the device.  payne_ns_rwalk_queue_turn collects a queue, adapts the scale, predicts the live set and
+ * launches the next queue from the host -- the GPU idles meanwhile (~100 us of a 1 ms cycle at C2).  Here the live set lives on the
+ * device: one workgroup merges the finished queue's proposals into it (the nlive largest of live points and proposals: what consuming
+ * them in order leaves, thresholds only rise), adapts the scale by dynesty's rule, takes the new threshold and draws every chain's
+ * start point, and the next queue is ENQUEUED before the current one has finished.  The host consumes each queue (payne_ns_consume) for
+ * the evidence in its own time; its live SET is the device's, its slot order is not (start points differ from the host-turn loop's:
+ * the same sampler statistically, not to the bit).  dynesty has no counterpart (one proposal at a time).
+ *   _init    uploads the live set and the scale / threshold to start from (no queue may be in flight);
+ *   _launch  enqueues [new bound, if one is given] + turn (merge = 0: start from the uploaded set as it is) + walks + 1 steps + the
+ *            results' transfer; at most two queues in flight; axes_unit = NULL keeps the bound already on the device;
+ *   _collect waits for the OLDEST queue in flight and returns it as payne_ns_rwalk_queue_end does, with the scale and threshold
+ *            it ran under in dyn_used[2]. */
+int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl, int nlive,
+                            double scale, double loglstar);
+int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                              int walks, unsigned long long seed, int merge, void* stream);
+int payne_ns_queue_dev_collect(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats,
+                               double* dyn_used);
+
 /* Kernel family names (for profiler filters): 0 dense layer, 1 post, 2 sed. */
 const char* payne_kernel_name(int which);
 

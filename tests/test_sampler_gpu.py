@@ -588,3 +588,85 @@ def test_device_advanced_priors(tmp_path, photscale):
     hw = lnprob_batch(Vw[moved], L, P)
     assert np.all(np.abs(lw[moved] - hw) <= 1e-9 * np.abs(hw) + 1e-8) and np.all(lw[moved] > lstar)
     prop.close()
+
+
+def test_queue_turn_on_the_device(tmp_path):
+    """payne_ns_queue_dev_*: the live set on the device, queues enqueued one ahead, the turn between two of them made by one
+    workgroup.  Against a numpy model of the same rule, queue after queue: every returned proposal beats the threshold its queue ran
+    under and carries the lnprob the host path computes; that threshold is the lnprob of the last point that died when the queues
+    before it were consumed in order (dynesty's loop, replayed here: a proposal replaces the worst live point if it beats it); the
+    scale follows dynesty's adaptation of the queue's own counters."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    L, P, _ = _fit_objects(tmp_path, photscale=True)
+    prop = _proposer(L, P, k_max=64)
+    rng = np.random.default_rng(5)
+    nd, nlive, K, walks = L.ndim, 96, 64, 6
+    live_u = np.ascontiguousarray(rng.uniform(0.35, 0.65, size=(nlive, nd)))
+    live_v, ll = prop.lnprob_u(live_u)
+    ll = np.where(np.isnan(ll), -np.inf, ll)
+    lstar0 = float(ll.min())
+    axes = 0.02 * np.eye(nd)
+    scale = 1.0
+    prop.queue_dev_init(live_u, live_v, ll, scale, lstar0)
+    seeds = [int(s) for s in rng.integers(0, 2 ** 62, size=6)]
+    prop.queue_dev_launch(K, axes, None, None, walks, seeds[0], merge=False)
+    prop.queue_dev_launch(K, axes, None, None, walks, seeds[1], merge=True)
+    model_l = ll.copy()                                       # the host's replay: consume every queue in order
+    qbuf = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+    lstar, seen_accept = lstar0, 0
+    for q in range(len(seeds)):
+        nq, acc, calls, redrawn, idle, sc_used, ls_used = prop.queue_dev_collect(qbuf)
+        qU, qV, ql = qbuf[0][:nq].copy(), qbuf[1][:nq].copy(), qbuf[2][:nq].copy()
+        assert ls_used == lstar, (q, ls_used, lstar)          # the threshold this queue ran under = what the replay left
+        assert abs(sc_used - scale) <= 1e-12 * scale
+        assert calls == K * walks and np.all(ql > ls_used) and np.all((qU > 0) & (qU < 1))
+        host = lnprob_batch(qV, L, P)
+        assert np.all(np.abs(ql - host) <= 1e-9 * np.abs(host) + 1e-9)
+        frac = acc / max(1, calls + redrawn)
+        scale = min(max(scale * np.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)
+        for l in ql:                                          # dynesty's loop: a proposal replaces the worst live point if it beats it
+            w = int(np.argmin(model_l))
+            if l > model_l[w]:
+                lstar = float(model_l[w])                     # (the threshold: the lnprob of the point that just died)
+                model_l[w] = l; seen_accept += 1
+        if q + 2 < len(seeds):
+            prop.queue_dev_launch(K, axes, None, None, walks, seeds[q + 2], merge=True)
+    assert seen_accept > nlive // 4 and lstar > lstar0
+    prop.close()
+
+
+def test_sampling_loop_with_the_turn_on_the_device(tmp_path):
+    """pipeline='device' (the live set on the device, queues enqueued one ahead, payne_ns_turn_kernel between them) against the
+    serial loop: a stop in mid-queue drains what is in flight and leaves the proposer usable, a second call starts again from the
+    host's live set, dead points come out in order, and both loops integrate the same evidence.  The device's threshold is checked
+    against the host's every queue (a mismatch would re-upload the live set: none here)."""
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    from thepayne_amd.sampler import NestedSampler
+    L, P, _ = _fit_objects(tmp_path, photscale=True)
+    out = []
+    for pipeline in ('device', False):
+        prop = _proposer(L, P, k_max=64)
+        S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=64, bound='multi', sample='rwalk',
+                          walks=10, batched=True, queue_size=64, rstate=np.random.default_rng(9), proposer=prop, pipeline=pipeline)
+        assert S._dev_turn == (pipeline == 'device') and not S.pipeline
+        n1 = sum(len(r["logl"]) for r in S.sample_chunks(maxiter=150, dlogz=1e-9))
+        assert n1 == 150 and S._dev_inflight == 0 and not S._dev_sync
+        U = np.random.default_rng(1).uniform(0.3, 0.7, size=(8, L.ndim))
+        V, lp = prop.lnprob_u(U)                                         # the proposer between two calls of the loop
+        assert np.all(np.abs(lp - lnprob_batch(V, L, P)) <= 1e-9 * np.abs(lp) + 1e-9)
+        for _ in S.sample_chunks(dlogz=0.5, maxcall=300000):
+            pass
+        for _ in S.add_live_points():
+            pass
+        r = S.results
+        assert np.all(np.diff(r.logl[:-64]) >= 0) and np.all(np.diff(r.logz) >= -1e-12)
+        # every dead point's lnprob is what the host path computes for its coordinates
+        pick = np.random.default_rng(2).choice(len(r.logl) - 64, size=32, replace=False)
+        host = lnprob_batch(np.ascontiguousarray(r.samples[pick]), L, P)
+        assert np.all(np.abs(r.logl[pick] - host) <= 1e-9 * np.abs(host) + 1e-9)
+        out.append((r, S.ncall, S._dev_desync))
+        prop.close()
+    (ra, na, desync), (rb, nb, _) = out
+    assert desync == 0
+    assert abs(ra.logz[-1] - rb.logz[-1]) < 4 * np.hypot(ra.logzerr[-1], rb.logzerr[-1]) + 0.2
+    assert 0.5 < na / nb < 2.0

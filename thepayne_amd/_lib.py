@@ -26,7 +26,8 @@ SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name", "payne_last_kernel",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
-           "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_sampler_counters", "payne_ns_rwalk_queue", "payne_ns_rwalk_queue_begin", "payne_ns_rwalk_queue_end", "payne_ns_rwalk_queue_turn", "payne_ns_consume", "payne_ns_peek", "payne_ns_bound", "payne_format_rows"]
+           "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_sampler_counters", "payne_ns_rwalk_queue", "payne_ns_rwalk_queue_begin", "payne_ns_rwalk_queue_end", "payne_ns_rwalk_queue_turn", "payne_ns_consume", "payne_ns_peek", "payne_ns_bound", "payne_format_rows",
+           "payne_ns_queue_dev_init", "payne_ns_queue_dev_launch", "payne_ns_queue_dev_collect"]
 
 PAYNE_MAX_DIM, PAYNE_MAX_FIXED = 24, 16
 PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_TGAUSSIAN, PRIOR_EXP, PRIOR_TEXP, PRIOR_LOGUNIFORM, PRIOR_TABLE = range(7)
@@ -187,6 +188,12 @@ def load(path=None):
                                               C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_ulonglong,
                                               C.POINTER(C.c_int)]
     lib.payne_ns_rwalk_queue_turn.restype = C.c_int
+    lib.payne_ns_queue_dev_init.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    lib.payne_ns_queue_dev_init.restype = C.c_int
+    lib.payne_ns_queue_dev_launch.argtypes = [ctxp, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_ulonglong, C.c_int, C.c_void_p]
+    lib.payne_ns_queue_dev_launch.restype = C.c_int
+    lib.payne_ns_queue_dev_collect.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    lib.payne_ns_queue_dev_collect.restype = C.c_int
     lib.payne_sampler_counters.argtypes = [ctxp, C.POINTER(C.c_longlong)]
     lib.payne_sampler_counters.restype = C.c_int
     lib.payne_rwalk_step.argtypes = [ctxp, C.c_int]

@@ -1159,6 +1159,17 @@ struct payne_sampler {
   // host reads that word instead of synchronising the stream: hipMemcpyAsync's own enqueue (17 us) and the wake-up out of
   // hipStreamSynchronize were most of the GPU's idle time between two queues (NOTES R4.16).  Null: PAYNE_V_QUEUE_MEMCPY.
   double* q_host_dev = nullptr; volatile unsigned long long* q_flag = nullptr; unsigned long long* q_flag_dev = nullptr; unsigned long long q_seq = 0;
+  unsigned* q_arrivals = nullptr;         // device word: workgroups of the results' transfer that have finished (wraps to zero)
+  // The queue's TURN on the device (payne_ns_queue_dev_*): the live set lives there (two copies, written in turn), the turn kernel
+  // merges a queue's proposals into it, adapts the scale, raises the threshold and draws the next start points -- the next queue
+  // is ENQUEUED before the current one has finished, and the GPU goes from one to the other without the host (NOTES R4.18).
+  double *lv_u[2] = {nullptr, nullptr}, *lv_v[2] = {nullptr, nullptr}, *lv_l[2] = {nullptr, nullptr};
+  int lv_n = 0, lv_cur = 0;
+  double* dyn = nullptr;                  // device: {scale, loglstar}
+  double* dq_host[2] = {nullptr, nullptr}; double* dq_host_dev[2] = {nullptr, nullptr};      // two mapped result blocks (+ flag word each)
+  unsigned long long dq_seq[2] = {0, 0};
+  double* dax_host[2] = {nullptr, nullptr}; double* dax_host_dev[2] = {nullptr, nullptr};    // two mapped blocks for the bound
+  int dq_launched = 0, dq_collected = 0, dq_K = 0, dq_n_ell = 0, dax_n = 0;
   std::vector<int> pk_src, pk_heap;       // payne_ns_rwalk_queue_turn: the live set its peek predicts, by index (payne_ns::peek_index)
   std::vector<double> pk_l;
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
@@ -1183,6 +1194,7 @@ extern "C" void payne_sampler_destroy(payne_sampler* s) {
   (void)hipSetDevice(s->ctx->device);
   for (void* p : s->owned) (void)hipFree(p);
   if (s->q_host) (void)hipHostFree(s->q_host);
+  for (int b = 0; b < 2; ++b) { if (s->dq_host[b]) (void)hipHostFree(s->dq_host[b]); if (s->dax_host[b]) (void)hipHostFree(s->dax_host[b]); }
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -1269,6 +1281,8 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
       s->q_flag = reinterpret_cast<volatile unsigned long long*>(s->q_host + q_doubles(K, nd));
       s->q_flag_dev = reinterpret_cast<unsigned long long*>(s->q_host_dev + q_doubles(K, nd));
       *s->q_flag = 0ull;
+      void* ap = nullptr;
+      if (hipMalloc(&ap, 8) == hipSuccess && hipMemset(ap, 0, 8) == hipSuccess) { s->owned.push_back(ap); s->q_arrivals = static_cast<unsigned*>(ap); }
     }
   }
   *out = s;
@@ -1320,7 +1334,7 @@ static void rwalk_begin_impl(payne_sampler* s, double* u, double* v, double* lnp
   s->walk = WalkState{u, v, lnprob, nacc, ncall, s->u_prop, s->v_prop, s->lnprior, s->inside, s->rows, axes_dev,
                       ell_dev, nredraw, scale, loglstar, seed, K,
                       s->sd.ndim, s->sd.ncols, (s->sd.adv.imf || s->sd.adv.vrot || s->sd.adv.plx_dim >= 0) ? 1 : 0, s->spec,
-                      nullptr, nullptr, nullptr, 0};
+                      nullptr, nullptr, nullptr, 0, nullptr};
   s->tail_done = false;
 }
 extern "C" int payne_rwalk_begin_ell(payne_sampler* s, double* u, double* v, double* lnprob, int K, const double* axes,
@@ -1396,11 +1410,146 @@ __global__ void __launch_bounds__(256) payne_stage_in_kernel(double* __restrict_
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src_host[i];
 }
 __global__ void __launch_bounds__(1024) payne_stage_out_kernel(double* __restrict__ dst_host, const double* __restrict__ src, size_t n,
-                                                               unsigned long long* flag, unsigned long long seq) {
-  for (size_t i = threadIdx.x; i < n; i += 1024) dst_host[i] = src[i];
+                                                               unsigned long long* flag, unsigned long long seq,
+                                                               const double* __restrict__ src2 = nullptr, int n2 = 0,
+                                                               unsigned* arrivals = nullptr) {
+  // (several workgroups when `arrivals` is given: the last one to arrive publishes -- atomicInc wraps the count back to zero)
+  for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) dst_host[i] = src[i];
+  if (blockIdx.x == 0 && src2 && (int)threadIdx.x < n2) dst_host[n + threadIdx.x] = src2[threadIdx.x];   // (the device's scale and threshold behind the block)
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    bool last = true;
+    if (arrivals && gridDim.x > 1) last = atomicInc(arrivals, gridDim.x - 1) == gridDim.x - 1;
+    if (last) { __threadfence_system(); __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
+}
+
+// ---- the queue's turn on the device ------------------------------------------------------------------------------------
+// What payne_ns_rwalk_queue_turn does on the host between two queues, as ONE workgroup: the chains that moved are the proposals;
+// consuming them in order (each replaces the worst live point if it beats it) leaves the nlive LARGEST of live points and proposals
+// -- thresholds only rise, so a proposal in that set beat every threshold it met, and one outside it died or never got in --: a sort
+// by (lnprob descending, live points before proposals on ties: the test is strict).  Then the scale adaptation dynesty-style from
+// the queue's counters, the new threshold (the largest lnprob left outside the set: the last point to die), and every chain's start point, uniform among the new live
+// points (the host's splitmix of the seed).  The host replays the same queue for the evidence in its own time; its live SET is the
+// same, its slot order is not (nothing on the device depends on it).
+struct TurnArgs {
+  const double *lu, *lv, *ll; double *ou, *ov, *ol;    // live set in / out (the same arrays when merge == 0)
+  int nlive, nd, K, merge, n2;                         // n2: power of two >= nlive + K (<= 2048)
+  double *cu, *cv, *cl; int *na, *nc, *nr;             // chains: the finished queue's results in, the next queue's start points out
+  double* dyn;                                         // {scale, loglstar}
+  double scale0, lstar0;                               // merge == 0: what to start from
+  unsigned long long seed;
+};
+__global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
+  __shared__ double key[2048];
+  __shared__ int id[2048];
+  __shared__ long long cnt[3];
+  const int tid = threadIdx.x, nl = a.nlive, nd = a.nd, K = a.K;
+  double scale = a.scale0, lstar = a.lstar0;
+  if (a.merge) {
+    if (tid < 3) cnt[tid] = 0;
+    for (int e = tid; e < a.n2; e += 1024) {
+      double v = -INFINITY; int who = (1 << 30) + e;
+      if (e < nl) { const double l = a.ll[e]; v = (l != l) ? -INFINITY : l; who = e; }
+      else if (e < nl + K) {
+        const int k = e - nl;
+        if (a.na[k] > 0) { const double l = a.cl[k]; v = (l != l) ? -INFINITY : l; who = e; }
+      }
+      key[e] = v; id[e] = who;
+    }
+    __syncthreads();
+    int s0 = 0, s1 = 0, s2 = 0;                               // (per wave first: a thousand atomics on three LDS words were 25 us of this kernel)
+    for (int k = tid; k < K; k += 1024) { s0 += a.na[k]; s1 += a.nc[k]; s2 += a.nr[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+    if ((tid & 63) == 0 && (s0 | s1 | s2)) {
+      atomicAdd((unsigned long long*)&cnt[0], (unsigned long long)s0); atomicAdd((unsigned long long*)&cnt[1], (unsigned long long)s1);
+      atomicAdd((unsigned long long*)&cnt[2], (unsigned long long)s2);
+    }
+    // bitonic sort, "before" = larger lnprob, then smaller id
+    if (a.n2 <= 1024) {
+      // one element per thread, in registers: the exchanges at distances below 64 are wave shuffles (45 of the 55 stages of 1024
+      // elements), the others go through LDS -- every stage as an LDS pass with its barrier made this kernel 38 us
+      __syncthreads();
+      const int i = tid;
+      double kv = i < a.n2 ? key[i] : -INFINITY;
+      int iv = i < a.n2 ? id[i] : 0x7fffffff;
+      for (int kk = 2; kk <= a.n2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+          double kp; int ip;
+          if (j < 64) {
+            kp = __shfl_xor(kv, j); ip = __shfl_xor(iv, j);
+          } else {
+            __syncthreads();
+            if (i < a.n2) { key[i] = kv; id[i] = iv; }
+            __syncthreads();
+            kp = i < a.n2 ? key[i ^ j] : kv; ip = i < a.n2 ? id[i ^ j] : iv;
+          }
+          const bool mine_first = (kv > kp) || (kv == kp && iv < ip);
+          const bool want_first = (((i & j) == 0) == ((i & kk) == 0));      // the lower place of an ascending run, the upper of a descending one
+          if (mine_first != want_first) { kv = kp; iv = ip; }
+        }
+      __syncthreads();
+      if (i < a.n2) { key[i] = kv; id[i] = iv; }
+    } else {
+    for (int kk = 2; kk <= a.n2; kk <<= 1)
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        __syncthreads();
+        for (int i = tid; i < a.n2; i += 1024) {
+          const int p = i ^ j;
+          if (p > i) {
+            const double ki = key[i], kp = key[p]; const int ii = id[i], ip = id[p];
+            const bool i_first = (ki > kp) || (ki == kp && ii < ip);
+            const bool up = (i & kk) == 0;                   // this run sorts "first things first"
+            if (i_first != up) { key[i] = kp; key[p] = ki; id[i] = ip; id[p] = ii; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // the threshold the next queue walks under is the lnprob of the LAST point that dies (dynesty's loglstar; payne_ns::peek_index):
+    // every element outside the new set died or was turned away at a threshold no higher, so that is the largest of them --
+    // unless no proposal got in, and nothing died
+    int got_in = 0;
+    for (int r = tid; r < nl; r += 1024) got_in |= (id[r] >= nl) ? 1 : 0;
+    got_in = __syncthreads_or(got_in);
+    lstar = got_in ? key[nl] : a.dyn[1];
+    const long long denom = cnt[1] + cnt[2] > 1 ? cnt[1] + cnt[2] : 1;
+    const double frac = (double)cnt[0] / (double)denom;     // a redrawn (out-of-cube) proposal counts as a rejection
+    scale = a.dyn[0] * exp((frac - 0.5) / nd / 0.5);
+    scale = scale > 1e-4 ? scale : 1e-4; scale = scale < 4.0 ? scale : 4.0;
+    // the new live set, row r = the r-th best
+    for (int e = tid; e < nl * nd; e += 1024) {
+      const int r = e / nd, d = e - r * nd, who = id[r];
+      const bool live = who < nl;
+      const size_t src = (size_t)(live ? who : who - nl) * nd + d;
+      a.ou[e] = live ? a.lu[src] : a.cu[src];
+      a.ov[e] = live ? a.lv[src] : a.cv[src];
+    }
+    for (int r = tid; r < nl; r += 1024) a.ol[r] = key[r];
+    __threadfence();
+    __syncthreads();                                         // (the chains' rows are overwritten below)
+  }
+  if (tid == 0) { a.dyn[0] = scale; a.dyn[1] = lstar; }
+  // start points: uniform among the live points (queue_begin_core's draw)
+  auto mix = [](unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+  };
+  __syncthreads();
+  for (int k = tid; k < K; k += 1024) {                       // (K <= 1024; the slot of every chain once, through the sort's LDS)
+    const int i = (int)(mix(a.seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull)) % (unsigned long long)nl);
+    id[k] = i;
+    a.cl[k] = a.ol[i];
+    a.na[k] = 0; a.nc[k] = 0; a.nr[k] = 0;
+  }
+  __syncthreads();
+  for (int e = tid; e < K * nd; e += 1024) {
+    const int k = e / nd, d = e - k * nd, i = id[k];
+    a.cu[e] = a.ou[(size_t)i * nd + d];
+    a.cv[e] = a.ov[(size_t)i * nd + d];
+  }
 }
 static int queue_begin_core(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
                             int nlive, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
@@ -1481,7 +1630,8 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
   if (rc) return rc;
   if (s->q_host_dev) {
     ++s->q_seq;
-    hipLaunchKernelGGL(payne_stage_out_kernel, dim3(1), dim3(1024), 0, st, s->q_host_dev, s->q_dev, nq_d + n_cnt, s->q_flag_dev, s->q_seq);
+    hipLaunchKernelGGL(payne_stage_out_kernel, dim3(s->q_arrivals ? 8 : 1), dim3(1024), 0, st, s->q_host_dev, s->q_dev, nq_d + n_cnt, s->q_flag_dev, s->q_seq,
+                       (const double*)nullptr, 0, s->q_arrivals);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("queue staging launch: ") + hipGetErrorString(e));
   } else {
@@ -1490,6 +1640,7 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
   s->queue_open = true; s->queue_K = K; s->queue_stream = stream;
   return PAYNE_OK;
 }
+static void queue_extract(const double* hu, int K, int nd, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats);
 extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats) {
   if (!s) return PAYNE_E_INVALID;
   payne_ctx* c = s->ctx;
@@ -1499,8 +1650,6 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   const int K = s->queue_K, nd = s->sd.ndim;
   hipStream_t st = reinterpret_cast<hipStream_t>(s->queue_stream);
   const double* hu = s->q_host;
-  const double* hv = hu + (size_t)K * nd;
-  const double* hl = hv + (size_t)K * nd;
   if (s->q_flag) {
     // the word the queue's last kernel writes behind its results (every kernel before it on the stream has completed by then);
     // a queue that does not report within 10 s is handed to hipStreamSynchronize, which returns the fault if there was one
@@ -1513,7 +1662,13 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   } else {
     HIPCHK(c, hipStreamSynchronize(st));
   }
-  // ---- the chains that moved are the queue; a chain that never moved is a copy of a live point
+  queue_extract(hu, K, nd, qu, qv, ql, qnc, nq, stats);
+  return PAYNE_OK;
+}
+// ---- the chains that moved are the queue; a chain that never moved is a copy of a live point
+static void queue_extract(const double* hu, int K, int nd, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats) {
+  const double* hv = hu + (size_t)K * nd;
+  const double* hl = hv + (size_t)K * nd;
   long long acc = 0, calls = 0, redraw = 0, idle_calls = 0;
   int m = 0;
   const int *na = reinterpret_cast<const int*>(hl + K), *nc = na + K, *nr = nc + K;
@@ -1535,6 +1690,150 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   }
   *nq = m;
   stats[0] = acc; stats[1] = calls; stats[2] = redraw; stats[3] = idle_calls;
+}
+
+// ---- the queue's turn on the device: host entry points (header: payne_ns_queue_dev_*) ------------------------------------------
+static bool wait_word(volatile unsigned long long* w, unsigned long long want, double seconds) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(const_cast<const unsigned long long*>(w), __ATOMIC_ACQUIRE) != want)
+    if ((++spins & 0xFFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+  return true;
+}
+extern "C" int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl, int nlive,
+                                       double scale, double loglstar) {
+  if (!s) return PAYNE_E_INVALID;
+  payne_ctx* c = s->ctx;
+  if (!live_u || !live_v || !live_logl || nlive <= 0) return fail(c, PAYNE_E_INVALID, "bad payne_ns_queue_dev_init arguments");
+  if (!s->q_host_dev) return fail(c, PAYNE_E_UNSUPPORTED, "the device-side turn needs the mapped staging block (not PAYNE_V_QUEUE_MEMCPY)");
+  if (s->dq_launched != s->dq_collected) return fail(c, PAYNE_E_INVALID, "payne_ns_queue_dev_init with queues in flight");
+  const int nd = s->sd.ndim, K = s->k_max;
+  if (nlive + K > 2048) return fail(c, PAYNE_E_UNSUPPORTED, "nlive + queue size > 2048");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (prev != c->device) HIPCHK(c, hipSetDevice(c->device));
+  if (nlive != s->lv_n) {
+    for (int b = 0; b < 2; ++b) {
+      void* p = nullptr;
+      HIPCHK(c, hipMalloc(&p, (size_t)nlive * nd * 8)); s->owned.push_back(p); s->lv_u[b] = static_cast<double*>(p);
+      HIPCHK(c, hipMalloc(&p, (size_t)nlive * nd * 8)); s->owned.push_back(p); s->lv_v[b] = static_cast<double*>(p);
+      HIPCHK(c, hipMalloc(&p, (size_t)nlive * 8)); s->owned.push_back(p); s->lv_l[b] = static_cast<double*>(p);
+    }
+    s->lv_n = nlive;
+  }
+  if (!s->dyn) { void* p = nullptr; HIPCHK(c, hipMalloc(&p, 4 * 8)); s->owned.push_back(p); s->dyn = static_cast<double*>(p); }
+  const size_t nblk = q_doubles(K, nd) + 16;
+  for (int b = 0; b < 2; ++b) {
+    if (!s->dq_host[b]) {
+      HIPCHK(c, hipHostMalloc((void**)&s->dq_host[b], nblk * 8, hipHostMallocMapped));
+      void* dp = nullptr;
+      HIPCHK(c, hipHostGetDevicePointer(&dp, s->dq_host[b], 0));
+      s->dq_host_dev[b] = static_cast<double*>(dp);
+      s->dax_n = (int)((size_t)PAYNE_MAX_ELL * (2 * nd * nd + nd));
+      HIPCHK(c, hipHostMalloc((void**)&s->dax_host[b], (size_t)s->dax_n * 8, hipHostMallocMapped));
+      HIPCHK(c, hipHostGetDevicePointer(&dp, s->dax_host[b], 0));
+      s->dax_host_dev[b] = static_cast<double*>(dp);
+    }
+    reinterpret_cast<volatile unsigned long long*>(s->dq_host[b] + q_doubles(K, nd) + 8)[0] = 0ull;
+    s->dq_seq[b] = 0;
+  }
+  HIPCHK(c, hipMemcpy(s->lv_u[0], live_u, (size_t)nlive * nd * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(s->lv_v[0], live_v, (size_t)nlive * nd * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(s->lv_l[0], live_logl, (size_t)nlive * 8, hipMemcpyHostToDevice));
+  const double d2[4] = {scale, loglstar, 0.0, 0.0};
+  HIPCHK(c, hipMemcpy(s->dyn, d2, sizeof(d2), hipMemcpyHostToDevice));
+  s->lv_cur = 0; s->dq_launched = 0; s->dq_collected = 0; s->dq_n_ell = 0;
+  return PAYNE_OK;
+}
+extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
+                                         int walks, unsigned long long seed, int merge, void* stream) {
+  if (!s) return PAYNE_E_INVALID;
+  payne_ctx* c = s->ctx;
+  if (s->lv_n <= 0 || !s->dyn) return fail(c, PAYNE_E_INVALID, "payne_ns_queue_dev_launch before payne_ns_queue_dev_init");
+  if (K <= 0 || K > s->k_max || walks <= 0) return fail(c, PAYNE_E_INVALID, "bad payne_ns_queue_dev_launch arguments");
+  if (s->dq_launched - s->dq_collected >= 2) return fail(c, PAYNE_E_INVALID, "two queues already in flight");
+  if (s->dq_launched != s->dq_collected && K != s->dq_K) return fail(c, PAYNE_E_INVALID, "queue size changed with a queue in flight");
+  if (s->queue_open) return fail(c, PAYNE_E_INVALID, "a host-turn queue is in flight");
+  if (axes_unit) {
+    if (n_ell < 1 || n_ell > PAYNE_MAX_ELL || (n_ell > 1 && (!ctr || !ainv))) return fail(c, PAYNE_E_INVALID, "bad ellipsoid list");
+  } else {
+    n_ell = s->dq_n_ell;
+    if (n_ell < 1) return fail(c, PAYNE_E_INVALID, "no bound on the device yet");
+  }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (prev != c->device) HIPCHK(c, hipSetDevice(c->device));
+  const int nd = s->sd.ndim, nl = s->lv_n, b = s->dq_launched & 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t nq_d = (size_t)K * (2 * nd + 1), n_cnt = ((size_t)3 * K + 1) / 2, n_ax = (size_t)n_ell * nd * nd;
+  const size_t n_as = n_ell > 1 ? (size_t)n_ell * nd + n_ax : 0;
+  double* du = s->q_dev;
+  double* dv = du + (size_t)K * nd;
+  double* dl = dv + (size_t)K * nd;
+  int* dna = reinterpret_cast<int*>(dl + K);
+  int* dnc = dna + K;
+  int* dnr = dnc + K;
+  double* dax = dl + K + n_cnt;
+  int* dell = n_ell > 1 ? reinterpret_cast<int*>(dax + n_ax + n_as) : nullptr;
+  if (axes_unit) {                                          // a new bound: up through its own mapped block (two, used in turn)
+    double* hax = s->dax_host[b];
+    std::memcpy(hax, axes_unit, n_ax * 8);
+    if (n_ell > 1) {
+      std::memcpy(hax + n_ax, ctr, (size_t)n_ell * nd * 8);
+      std::memcpy(hax + n_ax + (size_t)n_ell * nd, ainv, n_ax * 8);
+    }
+    hipLaunchKernelGGL(payne_stage_in_kernel, dim3((unsigned)((n_ax + n_as + 1023) / 1024)), dim3(256), 0, st, dax, s->dax_host_dev[b], n_ax + n_as);
+    s->dq_n_ell = n_ell;
+  }
+  TurnArgs ta{};
+  const int cur = s->lv_cur, nxt = merge ? cur ^ 1 : cur;
+  ta.lu = s->lv_u[cur]; ta.lv = s->lv_v[cur]; ta.ll = s->lv_l[cur];
+  ta.ou = s->lv_u[nxt]; ta.ov = s->lv_v[nxt]; ta.ol = s->lv_l[nxt];
+  ta.nlive = nl; ta.nd = nd; ta.K = K; ta.merge = merge ? 1 : 0;
+  int n2 = 2;
+  while (n2 < nl + K) n2 <<= 1;
+  ta.n2 = n2;
+  ta.cu = du; ta.cv = dv; ta.cl = dl; ta.na = dna; ta.nc = dnc; ta.nr = dnr;
+  ta.dyn = s->dyn; ta.scale0 = 0.0; ta.lstar0 = 0.0; ta.seed = seed;
+  if (!merge) {                                             // the values payne_ns_queue_dev_init left stay
+    double d2[2];
+    HIPCHK(c, hipMemcpy(d2, s->dyn, sizeof(d2), hipMemcpyDeviceToHost));
+    ta.scale0 = d2[0]; ta.lstar0 = d2[1];
+  }
+  hipLaunchKernelGGL(payne_ns_turn_kernel, dim3(1), dim3(1024), 0, st, ta);
+  s->lv_cur = nxt;
+  rwalk_begin_impl(s, du, dv, dl, K, dax, dell, 0.0, 0.0, walks, seed, dna, dnc, dnr, stream);
+  s->walk.dyn = s->dyn;
+  if (n_ell > 1) { s->walk.as_ctr = dax + n_ax; s->walk.as_ainv = dax + n_ax + (size_t)n_ell * nd; s->walk.ell_out = dell; s->walk.n_ell = n_ell; }
+  int rc = PAYNE_OK;
+  for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
+  if (rc) return rc;
+  ++s->dq_seq[b];
+  hipLaunchKernelGGL(payne_stage_out_kernel, dim3(s->q_arrivals ? 8 : 1), dim3(1024), 0, st, s->dq_host_dev[b], s->q_dev, nq_d + n_cnt,
+                     reinterpret_cast<unsigned long long*>(s->dq_host_dev[b] + q_doubles(s->k_max, nd) + 8), s->dq_seq[b], s->dyn, 2, s->q_arrivals);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("device-turn launch: ") + hipGetErrorString(e));
+  ++s->dq_launched; s->dq_K = K; s->queue_stream = stream;
+  return PAYNE_OK;
+}
+extern "C" int payne_ns_queue_dev_collect(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats,
+                                          double* dyn_used) {
+  if (!s) return PAYNE_E_INVALID;
+  payne_ctx* c = s->ctx;
+  if (s->dq_collected >= s->dq_launched) return fail(c, PAYNE_E_INVALID, "payne_ns_queue_dev_collect without a queue in flight");
+  if (!qu || !qv || !ql || !qnc || !nq || !stats) return fail(c, PAYNE_E_INVALID, "bad payne_ns_queue_dev_collect arguments");
+  const int b = s->dq_collected & 1, K = s->dq_K, nd = s->sd.ndim;
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->dq_host[b] + q_doubles(s->k_max, nd) + 8);
+  if (!wait_word(flag, s->dq_seq[b], 10.0)) {
+    HIPCHK(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(s->queue_stream)));
+    if (*flag != s->dq_seq[b]) return fail(c, PAYNE_E_HIP, "the queue's completion word never arrived");
+  }
+  queue_extract(s->dq_host[b], K, nd, qu, qv, ql, qnc, nq, stats);
+  if (dyn_used) {
+    const size_t nq_d = (size_t)K * (2 * nd + 1), n_cnt = ((size_t)3 * K + 1) / 2;
+    dyn_used[0] = s->dq_host[b][nq_d + n_cnt]; dyn_used[1] = s->dq_host[b][nq_d + n_cnt + 1];
+  }
+  ++s->dq_collected;
   return PAYNE_OK;
 }
 // One turn of the sampler's pipelined loop in ONE call: collect the queue in flight (_end), adapt the step scale to its acceptance

@@ -156,7 +156,12 @@ struct WalkState {
   // the queue call (payne_ns_rwalk_queue_begin): the walk's first step also finds the ellipsoid each chain steps in -- one that holds
   // its start point (a random one of those), else the nearest -- and writes it to ell_out; null: `ell` came from the host
   const double* as_ctr; const double* as_ainv; int* ell_out; int n_ell;
+  // the queue launched WITHOUT the host in between (payne_ns_queue_dev_launch): scale and loglstar are not known when the
+  // launch is made -- payne_ns_turn_kernel writes them here, {scale, loglstar}; null: the two fields above hold them
+  const double* dyn;
 };
+__device__ __forceinline__ double walk_scale(const WalkState& W) { return W.dyn ? W.dyn[0] : W.scale; }
+__device__ __forceinline__ double walk_lstar(const WalkState& W) { return W.dyn ? W.dyn[1] : W.loglstar; }
 // device-resident copy for the post kernel's tail (payne_post_kernel<.., LEAN>: PostArgs::tail)
 struct WalkTail { SamplerDev sd; WalkState w; };
 
@@ -228,7 +233,7 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   double* const u_prop = W.u_prop; double* const v_prop = W.v_prop; double* const lnprior_prop = W.lnprior_prop;
   int* const inside = W.inside; double* const rows = W.rows;
   const double* const axes = W.axes; int* const nredraw = W.nredraw;
-  const double scale = W.scale, loglstar = W.loglstar;
+  const double scale = walk_scale(W), loglstar = walk_lstar(W);
   const unsigned long long seed = W.seed;
   const int nd = L.nd;
   const bool act = lane < nd;
@@ -400,6 +405,7 @@ __device__ __forceinline__ void rwalk_spec_wave(const SamplerDev& sd, const Walk
   const int dl = act ? l : 0;
   const size_t off = (size_t)c * nd + dl;
   const double uc = (o ? W.u_prop : W.u)[off], vc = (o ? W.v_prop : W.v)[off];
+  const double wscale = walk_scale(W);
   const int my_ell = W.ell ? W.ell[c] : 0;
   const payne_prior_dim dim = sd.dims[dl];
   const double q0 = sd.q0[dl], q1 = sd.q1[dl];
@@ -441,8 +447,8 @@ __device__ __forceinline__ void rwalk_spec_wave(const SamplerDev& sd, const Walk
       const float ze = __shfl(z, cb + g * NP + (k & (NP - 1)));
       sdot = (k < nd) ? fma(ax16[k], (double)ze, sdot) : sdot;
     }
-    const double upgA = ucgA + (W.scale * (double)rad) * sdot;
-    const double upgB = ucgB + (W.scale * (double)rad) * sdot;
+    const double upgA = ucgA + (wscale * (double)rad) * sdot;
+    const double upgB = ucgB + (wscale * (double)rad) * sdot;
     const unsigned gmA = (unsigned)(__ballot(actg && !((upgA > 0.0) && (upgA < 1.0))) >> cb);
     const unsigned gmB = (unsigned)(__ballot(actg && !((upgB > 0.0) && (upgB < 1.0))) >> cb);
     int fA = -1, fB = -1;

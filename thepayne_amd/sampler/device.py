@@ -275,6 +275,46 @@ class DeviceProposer(object):
             self.eng._err(rc, "payne_ns_rwalk_queue_turn")
         return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]), sc.value, ls.value, m.value
 
+    # ---- the queue's turn on the device (payne_ns_queue_dev_*): the live set lives there, queues follow each other without the host
+    def queue_dev_init(self, live_u, live_v, live_logl, scale, loglstar):
+        """Upload the live set and the scale / threshold the first queue starts from (no queue may be in flight)."""
+        u = np.ascontiguousarray(live_u, dtype=np.float64)
+        v = np.ascontiguousarray(live_v, dtype=np.float64)
+        l = np.ascontiguousarray(np.where(np.isnan(live_logl), -np.inf, live_logl), dtype=np.float64)
+        rc = self.lib.payne_ns_queue_dev_init(self._handle, u.ctypes.data, v.ctypes.data, l.ctypes.data, len(l), float(scale), float(loglstar))
+        if rc != 0:
+            self.eng._err(rc, "payne_ns_queue_dev_init")
+        self._qb_dev = None
+
+    def queue_dev_launch(self, K, axes_unit, ctr, ainv, walks, seed, merge=True):
+        """Enqueue one queue behind whatever is in flight: [the bound, when it is not the one already on the device] + the turn
+        (merge: the queue before this one into the live set) + the walk + its results' transfer."""
+        if K > self.k_max:
+            raise ValueError("K > k_max")
+        key = (id(axes_unit), id(ctr), id(ainv))
+        if getattr(self, "_qb_dev", None) == key:
+            axp, n_ell, cp, ap = None, 0, None, None                     # (the bound on the device is this one)
+        else:
+            axp, n_ell, cp, ap, keep = self._queue_bound(axes_unit, ctr, ainv)
+        rc = self.lib.payne_ns_queue_dev_launch(self._handle, int(K), axp, n_ell, cp, ap, int(walks), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                1 if merge else 0, self._stream())
+        if rc != 0:
+            self.eng._err(rc, "payne_ns_queue_dev_launch")
+        self._qb_dev = key
+
+    def queue_dev_collect(self, qbuf):
+        """The oldest queue in flight, as rwalk_queue_end returns it, + the scale and threshold it ran under."""
+        qU, qV, ql, qnc = qbuf
+        nq = C.c_int(0)
+        stats = self._qstats
+        if getattr(self, "_dyn_used", None) is None:
+            self._dyn_used = np.zeros(2)
+        rc = self.lib.payne_ns_queue_dev_collect(self._handle, qU.ctypes.data, qV.ctypes.data, ql.ctypes.data, qnc.ctypes.data,
+                                                 C.byref(nq), stats.ctypes.data, self._dyn_used.ctypes.data)
+        if rc != 0:
+            self.eng._err(rc, "payne_ns_queue_dev_collect")
+        return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]), float(self._dyn_used[0]), float(self._dyn_used[1])
+
     # the same in three parts (MultiPopProposer interleaves the steps of several populations)
     def rwalk_begin(self, U, V, lnprob, axes, scale, loglstar, walks, seed, stream=None, ell=None):
         K, nd = len(U), self.ndim

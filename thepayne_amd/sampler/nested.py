@@ -191,6 +191,18 @@ class NestedSampler(object):
         # records.  The queue is the one a launch after the consumption would have made, except for the bound it steps in (one
         # consumed queue older: the proposal metric only, as under overlap_bound).  A queue launched ahead is dropped when the
         # consumption ended elsewhere (a stop condition, maxiter).  Default: on when the proposer can run the queue in two parts.
+        # pipeline='device': the turn between two queues is made ON the device (payne_ns_queue_dev_*: the live set lives there, one
+        # workgroup merges a queue's proposals into it, adapts the scale, raises the threshold and draws the next start points),
+        # and the next queue is enqueued BEFORE the current one has finished -- the GPU goes from queue to queue without waiting for
+        # the host, which consumes each queue for the evidence meanwhile.  The host's live SET stays the device's (checked every
+        # queue through the threshold; a mismatch -- ties -- re-uploads it); start points are drawn from the device's ordering of
+        # it, so a run is the host-turn run statistically, not to the bit.
+        self._dev_turn = isinstance(pipeline, str) and pipeline == 'device'
+        if self._dev_turn:
+            if not (sample == 'rwalk' and hasattr(proposer, "queue_dev_launch") and native):
+                raise ValueError("pipeline='device' needs sample='rwalk', native bookkeeping and a proposer with queue_dev_launch")
+            pipeline = False
+        self._dev_sync, self._dev_inflight, self._dev_desync = False, 0, 0
         self.pipeline = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native) if pipeline is None else bool(pipeline)
         if self.pipeline and not (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native):
             raise ValueError("pipeline=True needs sample='rwalk', native bookkeeping and a proposer with rwalk_queue_begin / _end")
@@ -324,6 +336,8 @@ class NestedSampler(object):
             return
         self._cycle += 1
         self._last_m, self._m_acc = self._m_acc, 0
+        if self.method == 'rwalk' and self._dev_turn:
+            return self._fill_queue_dev()
         if self.method == 'rwalk' and hasattr(self.proposer, "rwalk_queue"):
             # the whole queue in one native call: start points, ellipsoid assignment, transfers, walk, selection
             # (two host buffers in turn: the queue launched ahead is collected while the one before may still hold proposals)
@@ -411,6 +425,51 @@ class NestedSampler(object):
         self._pending_nc += int(ncalls[~moved].sum())
         self._set_queue(U[moved], V[moved], ll[moved], np.maximum(1, ncalls[moved]))
 
+    def _fill_queue_dev(self, again=True):
+        """pipeline='device': keep one queue enqueued behind the one being collected; the device makes the turn between them."""
+        K, nd, prop = self.queue_size, self.ndim, self.proposer
+        self._qbufs.reverse()
+        if self._qbufs[0] is None or len(self._qbufs[0][2]) < K:
+            self._qbufs[0] = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+        self._qbuf = self._qbufs[0]
+        ctr, au, ai = self._ell_stack
+        if not self._dev_sync:                     # the first queue of a loop (or after a mismatch): from the host's live set
+            prop.queue_dev_init(self.live_u, self.live_v, self.live_logl, self.scale, self.loglstar)
+            prop.queue_dev_launch(K, self._ax_arg, ctr, ai, self.walks, self._queue_seed(), merge=False)
+            self._dev_sync, self._dev_inflight = True, 1
+        while self._dev_inflight < 2:              # (the bound it steps in: the one the host holds now -- a new one goes up with it)
+            prop.queue_dev_launch(K, self._ax_arg, ctr, ai, self.walks, self._queue_seed(), merge=True)
+            self._dev_inflight += 1
+        nq, acc, calls, redrawn, idle, sc_used, ls_used = prop.queue_dev_collect(self._qbuf)
+        self._dev_inflight -= 1
+        if ls_used != self.loglstar:
+            # the device's live set is not the host's (equal lnprob values broke a tie the other way; a loop that stopped in
+            # mid-queue): collect what is in flight, start again from the host's set
+            self._dev_desync += 1
+            self._dev_drain()
+            if not again:
+                raise RuntimeError("the device's threshold (%r) is not the host's (%r)" % (ls_used, self.loglstar))
+            self._qbufs.reverse()
+            return self._fill_queue_dev(again=False)
+        self.ncall += calls
+        frac = acc / max(1, calls + redrawn)
+        self.scale = min(max(sc_used * math.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)     # (what the device's turn computed too)
+        self._pending_nc += idle
+        qU, qV, ql, qnc = self._qbuf
+        self._q_assign(qU[:nq], qV[:nq], ql[:nq], qnc[:nq])
+
+    def _dev_drain(self):
+        """Collect and discard the queues still in flight; the device's live set no longer counts."""
+        K, nd = self.queue_size, self.ndim
+        scratch = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+        while self._dev_inflight > 0:
+            try:
+                self.proposer.queue_dev_collect(scratch)
+            except Exception:                      # (a proposer closed before an abandoned generator was finalised)
+                pass
+            self._dev_inflight -= 1
+        self._dev_sync = False
+
     def _launch_ahead(self):
         """The next queue, launched from the state the consumption of the current one will leave (payne_ns_peek)."""
         K, nd, n = self.queue_size, self.ndim, self.nlive
@@ -437,6 +496,8 @@ class NestedSampler(object):
 
     def _drop_ahead(self):
         """Collect and discard a queue still in flight (the sampling loop ended before it was needed)."""
+        if self._dev_turn and (self._dev_inflight or self._dev_sync):
+            self._dev_drain()
         if self._ahead is not None:
             self._seed_again, self._ahead = self._ahead["seed"], None
             self._qbufs.reverse()

@@ -4,7 +4,7 @@
 CFG=${1:-C2}
 OUT=$PWD/gpurun_out; REPO=$PWD; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/turn_tl -o s -- python3 $REPO/tools/sampler_bench.py --config $CFG --maxcall 400000 --modes device_chunks > $OUT/turn_tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/turn_tl -o s -- python3 $REPO/tools/sampler_bench.py --config $CFG --maxcall 400000 --modes ${2:-device_chunks} --dlogz 1e-9 > $OUT/turn_tl.log 2>&1
 cd $REPO
 python3 - <<PY
 import csv, glob

@@ -73,6 +73,9 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
         if mode.endswith("_serial"):                        # "device_chunks_serial": every queue launched after the one before is consumed
             kw["pipeline"] = False
             mode_ = mode[:-len("_serial")]
+        elif mode.endswith("_devturn"):                     # "device_chunks_devturn": the turn between two queues made on the device
+            kw["pipeline"] = 'device'
+            mode_ = mode[:-len("_devturn")]
         else:
             mode_ = mode
         if mode.startswith("device2"):                      # two chain populations in flight
@@ -96,7 +99,8 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
                 pass
         dt = time.perf_counter() - t0
         out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 4),
-                     "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale), "max_ellipsoids": nell}
+                     "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale), "max_ellipsoids": nell,
+                     **({"resyncs": int(S._dev_desync)} if getattr(S, "_dev_turn", False) else {})}
         if verbose:
             print(mode, json.dumps(out[mode]), flush=True)
         if proposer is not None:
@@ -114,8 +118,9 @@ def main():
     ap.add_argument("--modes", default="host,device,device_chunks,device2_chunks")
     ap.add_argument("--bound", default="multi")
     ap.add_argument("--variant", type=int, default=0, help="payne_opts.variant (PAYNE_V_* bits)")
+    ap.add_argument("--dlogz", type=float, default=0.01, help="stopping threshold (tiny: the run ends at --maxcall)")
     a = ap.parse_args()
-    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True, bound=a.bound, variant=a.variant)
+    out = run(a.config, a.maxcall, a.nlive, a.walks, tuple(a.modes.split(",")), verbose=True, bound=a.bound, variant=a.variant, dlogz=a.dlogz)
     print(json.dumps({"sampler_bench": out, "config": a.config, "nlive": a.nlive, "walks": a.walks}))
 
 
