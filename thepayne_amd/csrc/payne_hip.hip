@@ -1169,7 +1169,7 @@ struct payne_sampler {
   double* dq_host[2] = {nullptr, nullptr}; double* dq_host_dev[2] = {nullptr, nullptr};      // two mapped result blocks (+ flag word each)
   unsigned long long dq_seq[2] = {0, 0};
   double* dax_host[2] = {nullptr, nullptr}; double* dax_host_dev[2] = {nullptr, nullptr};    // two mapped blocks for the bound
-  int dq_launched = 0, dq_collected = 0, dq_K = 0, dq_n_ell = 0, dax_n = 0;
+  int dq_launched = 0, dq_collected = 0, dq_exported = 0, dq_K = 0, dq_n_ell = 0, dax_n = 0;   // (exported: queues whose results' transfer is enqueued)
   std::vector<int> pk_src, pk_heap;       // payne_ns_rwalk_queue_turn: the live set its peek predicts, by index (payne_ns::peek_index)
   std::vector<double> pk_l;
   WalkTail* tail_dev = nullptr;           // the walk in progress as the post kernel's tail reads it (written by the launch that opens the walk)
@@ -1440,6 +1440,9 @@ struct TurnArgs {
   double* dyn;                                         // {scale, loglstar}
   double scale0, lstar0;                               // merge == 0: what to start from
   unsigned long long seed;
+  // the finished queue's results on their way to the host from HERE (its own transfer kernel was 9 us between two queues): the
+  // stores are issued first and drain under the sort; the completion word follows the kernel's last statement
+  double* exp_dst; int exp_n; unsigned long long* exp_flag; unsigned long long exp_seq;
 };
 __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
   __shared__ double key[2048];
@@ -1447,6 +1450,10 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
   __shared__ long long cnt[3];
   const int tid = threadIdx.x, nl = a.nlive, nd = a.nd, K = a.K;
   double scale = a.scale0, lstar = a.lstar0;
+  if (a.exp_dst) {                                           // chains | counters (contiguous from a.cu), then the scale and threshold they ran under
+    for (int e = tid; e < a.exp_n; e += 1024) a.exp_dst[e] = a.cu[e];
+    if (tid < 2) a.exp_dst[a.exp_n + tid] = a.dyn[tid];
+  }
   if (a.merge) {
     if (tid < 3) cnt[tid] = 0;
     for (int e = tid; e < a.n2; e += 1024) {
@@ -1528,9 +1535,9 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
       a.ov[e] = live ? a.lv[src] : a.cv[src];
     }
     for (int r = tid; r < nl; r += 1024) a.ol[r] = key[r];
-    __threadfence();
-    __syncthreads();                                         // (the chains' rows are overwritten below)
+    __syncthreads();                                         // (the chains' rows are overwritten below; the new set is read back by this workgroup only)
   }
+  __syncthreads();                                           // (the export above has read the old values)
   if (tid == 0) { a.dyn[0] = scale; a.dyn[1] = lstar; }
   // start points: uniform among the live points (queue_begin_core's draw)
   auto mix = [](unsigned long long x) {
@@ -1549,6 +1556,11 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
     const int k = e / nd, d = e - k * nd, i = id[k];
     a.cu[e] = a.ou[(size_t)i * nd + d];
     a.cv[e] = a.ov[(size_t)i * nd + d];
+  }
+  if (a.exp_dst) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.exp_flag, a.exp_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 static int queue_begin_core(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl,
@@ -1742,7 +1754,7 @@ extern "C" int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, c
   HIPCHK(c, hipMemcpy(s->lv_l[0], live_logl, (size_t)nlive * 8, hipMemcpyHostToDevice));
   const double d2[4] = {scale, loglstar, 0.0, 0.0};
   HIPCHK(c, hipMemcpy(s->dyn, d2, sizeof(d2), hipMemcpyHostToDevice));
-  s->lv_cur = 0; s->dq_launched = 0; s->dq_collected = 0; s->dq_n_ell = 0;
+  s->lv_cur = 0; s->dq_launched = 0; s->dq_collected = 0; s->dq_exported = 0; s->dq_n_ell = 0;
   return PAYNE_OK;
 }
 extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
@@ -1795,6 +1807,13 @@ extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* 
   ta.n2 = n2;
   ta.cu = du; ta.cv = dv; ta.cl = dl; ta.na = dna; ta.nc = dnc; ta.nr = dnr;
   ta.dyn = s->dyn; ta.scale0 = 0.0; ta.lstar0 = 0.0; ta.seed = seed;
+  if (s->dq_launched > s->dq_exported) {                    // the queue before this one: its results leave with this turn
+    const int pb = s->dq_exported & 1;
+    ta.exp_dst = s->dq_host_dev[pb]; ta.exp_n = (int)(nq_d + n_cnt);
+    ta.exp_flag = reinterpret_cast<unsigned long long*>(s->dq_host_dev[pb] + q_doubles(s->k_max, nd) + 8);
+    ta.exp_seq = ++s->dq_seq[pb];
+    ++s->dq_exported;
+  }
   if (!merge) {                                             // the values payne_ns_queue_dev_init left stay
     double d2[2];
     HIPCHK(c, hipMemcpy(d2, s->dyn, sizeof(d2), hipMemcpyDeviceToHost));
@@ -1808,9 +1827,7 @@ extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* 
   int rc = PAYNE_OK;
   for (int w = 0; !rc && w <= walks; ++w) rc = payne_rwalk_step(s, w);
   if (rc) return rc;
-  ++s->dq_seq[b];
-  hipLaunchKernelGGL(payne_stage_out_kernel, dim3(s->q_arrivals ? 8 : 1), dim3(1024), 0, st, s->dq_host_dev[b], s->q_dev, nq_d + n_cnt,
-                     reinterpret_cast<unsigned long long*>(s->dq_host_dev[b] + q_doubles(s->k_max, nd) + 8), s->dq_seq[b], s->dyn, 2, s->q_arrivals);
+  // (its results: with the NEXT queue's turn, or by payne_ns_queue_dev_collect when none has been launched by then)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("device-turn launch: ") + hipGetErrorString(e));
   ++s->dq_launched; s->dq_K = K; s->queue_stream = stream;
@@ -1823,6 +1840,14 @@ extern "C" int payne_ns_queue_dev_collect(payne_sampler* s, double* qu, double* 
   if (s->dq_collected >= s->dq_launched) return fail(c, PAYNE_E_INVALID, "payne_ns_queue_dev_collect without a queue in flight");
   if (!qu || !qv || !ql || !qnc || !nq || !stats) return fail(c, PAYNE_E_INVALID, "bad payne_ns_queue_dev_collect arguments");
   const int b = s->dq_collected & 1, K = s->dq_K, nd = s->sd.ndim;
+  if (s->dq_exported <= s->dq_collected) {                  // the newest queue, no turn behind it: a transfer of its own
+    const size_t nq_d = (size_t)K * (2 * nd + 1), n_cnt = ((size_t)3 * K + 1) / 2;
+    ++s->dq_seq[b];
+    hipLaunchKernelGGL(payne_stage_out_kernel, dim3(s->q_arrivals ? 8 : 1), dim3(1024), 0, reinterpret_cast<hipStream_t>(s->queue_stream),
+                       s->dq_host_dev[b], s->q_dev, nq_d + n_cnt,
+                       reinterpret_cast<unsigned long long*>(s->dq_host_dev[b] + q_doubles(s->k_max, nd) + 8), s->dq_seq[b], s->dyn, 2, s->q_arrivals);
+    ++s->dq_exported;
+  }
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->dq_host[b] + q_doubles(s->k_max, nd) + 8);
   if (!wait_word(flag, s->dq_seq[b], 10.0)) {
     HIPCHK(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(s->queue_stream)));
