@@ -3,7 +3,7 @@
 CFG=${1:-C2}
 OUT=$PWD/gpurun_out; REPO=$PWD; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/sampler_gaps -o s -- python3 $REPO/tools/sampler_bench.py --config $CFG --maxcall 400000 --modes device_chunks > $OUT/sampler_gaps.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/sampler_gaps -o s -- python3 $REPO/tools/sampler_bench.py --config $CFG --maxcall 400000 --modes device_chunks --variant ${2:-0} > $OUT/sampler_gaps.log 2>&1
 cd $REPO
 python3 - <<PY
 import csv, glob, collections
