@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--phot", action="store_true", help="joint fit with seven synthetic broad-band magnitudes")
     ap.add_argument("--dynamic", action="store_true", help="samplertype 'Dynamic' instead of 'Static'")
+    ap.add_argument("--device-turn", action="store_true",
+                    help="sampler['pipeline'] = 'device': the live set on the GPU, the turn between two proposal queues made there (static sampler)")
     ap.add_argument("--npix", type=int, default=4096)
     ap.add_argument("--npoints", type=int, default=125)
     ap.add_argument("--out", default="demo_sun.dat")
@@ -72,6 +74,8 @@ def main():
     inputdict['sampler'] = {'samplertype': 'Dynamic' if a.dynamic else 'Static', 'samplerbounds': 'multi',
                             'samplemethod': 'rwalk', 'npoints': a.npoints, 'flushnum': 100,
                             'delta_logz_final': 0.1, 'bootstrap': 0, 'walks': 25, 'maxbatch': 4}
+    if a.device_turn and not a.dynamic:
+        inputdict['sampler']['pipeline'] = 'device'
     inputdict['priordict'] = synth.demo_priordict()
     inputdict['priordict']['Teff'] = {'pv_uniform': [5000.0, 6500.0]}
     if a.phot:
