@@ -81,7 +81,7 @@ def test_sed_predictors():
                        S.sed(logt=3.7, logg=4.0, feh=0, afe=0, av=0.2, rv=3.1, logA=1.0))
 
 
-def _fit_objects(tmp_path, photscale=True, modpoly=False, variant=0):
+def _fit_objects(tmp_path, photscale=True, modpoly=False, variant=0, b_max=64):
     from thepayne_amd.fitting.likelihood import likelihood
     from thepayne_amd.fitting.prior import prior
     raw, obs, flux, eflux = yst_problem("small", H=64)
@@ -101,7 +101,7 @@ def _fit_objects(tmp_path, photscale=True, modpoly=False, variant=0):
     pd['Dist'] = {'pv_uniform': [10.0, 1000.0]}
     if modpoly:
         pd['blaze_coeff'] = [[0.0, 0.05], [0.0, 0.02], [0.0, 0.01]]
-    L = likelihood(fitargs, fitpars, runbools, b_max=64, variant=variant)
+    L = likelihood(fitargs, fitpars, runbools, b_max=b_max, variant=variant)
     P = prior(fitargs, pd, fitpars, runbools)
     OL = O.OracleLikelihood(raw, obs, flux, eflux, L.fitpars_i, phot=dict(phot, hiav=None), obs_phot=obs_phot,
                             photscale=photscale, modpoly=modpoly)

@@ -590,17 +590,18 @@ def test_device_advanced_priors(tmp_path, photscale):
     prop.close()
 
 
-def test_queue_turn_on_the_device(tmp_path):
+@pytest.mark.parametrize("nlive,K", [(96, 64), (125, 125), (700, 600)])     # the last: 2048 sort slots (two elements per thread, through LDS)
+def test_queue_turn_on_the_device(tmp_path, nlive, K):
     """payne_ns_queue_dev_*: the live set on the device, queues enqueued one ahead, the turn between two of them made by one
     workgroup.  Against a numpy model of the same rule, queue after queue: every returned proposal beats the threshold its queue ran
     under and carries the lnprob the host path computes; that threshold is the lnprob of the last point that died when the queues
     before it were consumed in order (dynesty's loop, replayed here: a proposal replaces the worst live point if it beats it); the
     scale follows dynesty's adaptation of the queue's own counters."""
     from thepayne_amd.fitting.fitstar import lnprob_batch
-    L, P, _ = _fit_objects(tmp_path, photscale=True)
-    prop = _proposer(L, P, k_max=64)
+    L, P, _ = _fit_objects(tmp_path, photscale=True, b_max=max(64, K))
+    prop = _proposer(L, P, k_max=K)
     rng = np.random.default_rng(5)
-    nd, nlive, K, walks = L.ndim, 96, 64, 6
+    nd, walks = L.ndim, 6
     live_u = np.ascontiguousarray(rng.uniform(0.35, 0.65, size=(nlive, nd)))
     live_v, ll = prop.lnprob_u(live_u)
     ll = np.where(np.isnan(ll), -np.inf, ll)
