@@ -178,13 +178,15 @@ def pmc_file(cfg_name):
     return None, {"source_hash": h}
 
 
-def pmc_bytes(path, key):
+def pmc_bytes(path, keys):
     """2 x FETCH_SIZE + WRITE_SIZE (KB, separate passes; FETCH doubled as MI355X_MICROARCH.md prescribes for
-    16-B/lane streaming reads on gfx950) per launch of the kernels whose name contains `key`."""
+    16-B/lane streaming reads on gfx950) per launch of the kernels whose name contains one of `keys` (the one launched most
+    often: a context's one-off launches -- e.g. the single payne_dense_dma3 launch of a C5 context's set-up beside the
+    payne_dense_big3_kernel of every step -- do not count)."""
     import csv
     tot, seen = {}, {}
     for r in csv.DictReader(open(path)):
-        if key in r["kernel"] and int(r["launches"]) >= seen.get(r["counter"], 0):     # the steady-state variant
+        if any(k in r["kernel"] for k in keys) and int(r["launches"]) >= seen.get(r["counter"], 0):     # the steady-state variant
             tot[r["counter"]] = float(r["mean_value_per_launch_KB_raw"])
             seen[r["counter"]] = int(r["launches"])
     if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
@@ -192,8 +194,8 @@ def pmc_bytes(path, key):
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
-KERNEL_KEYS = {"dense_out": "payne_dense_dma", "post": "payne_post", "dense_hidden": "payne_dense_hidden_kernel",
-               "sed": "payne_sed"}
+KERNEL_KEYS = {"dense_out": ("payne_dense_dma", "payne_dense_big3"), "post": ("payne_post",), "dense_hidden": ("payne_dense_hidden_kernel",),
+               "sed": ("payne_sed",)}
 METRIC_C2 = "likelihood-evals/sec (4k-pixel ANN, 512 live points)"
 
 
@@ -311,22 +313,35 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
         step(i)
     # `repeats` blocks of EXACTLY `steps` steps, each between barrier + synchronize on both sides, each block's time the MAX over
     # ranks; the median block is the result (the first block after a warm-up of five steps rides a clock ramp: min / max say so)
-    blocks, blocks_local = [], []
+    # Each block is timed twice: by a HIP event pair on the launch stream around its `steps` steps (what the device
+    # spent on them -- `value`), and by the host clock between the two barriers (`ms_per_step_wall`: + the synchronize / barrier
+    # edges of a block, ~55 us whatever its length, i.e. 2.8 us per step of a 20-step block and 0.3 of a 200-step one).
+    # Batches in flight on several streams have no single launch stream: their blocks are timed by the host clock alone.
+    use_events = (S == 1)
+    blocks, blocks_local, blocks_wall = [], [], []
     for _ in range(max(1, repeats)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
+        if use_events:
+            ev0.record(sts[0])
         for i in range(steps):
             step(i)
+        if use_events:
+            ev1.record(sts[0])
         barrier()
-        dl = time.perf_counter() - t0
-        tmax = torch.tensor([dl], dtype=torch.float64, device=theta.device)
+        dw = time.perf_counter() - t0
+        dl = 1e-3 * ev0.elapsed_time(ev1) if use_events else dw
+        tmax = torch.tensor([dl, dw], dtype=torch.float64, device=theta.device)
         if world > 1 or grouped:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        blocks.append(float(tmax.item()))
+        blocks.append(float(tmax[0].item()))
+        blocks_wall.append(float(tmax[1].item()))
         blocks_local.append(dl)
     order = sorted(range(len(blocks)), key=lambda j: blocks[j])
     mid = order[len(order) // 2]
     dt, dt_local = blocks[mid], blocks_local[mid]
+    dt_wall = sorted(blocks_wall)[len(blocks_wall) // 2]
     if shard and world > 1:
         lnl = sb.result()
     for l_ in lnls[1:]:                  # every in-flight batch evaluated the same candidates: same answers
@@ -343,7 +358,7 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
         torch.cuda.synchronize()
         kern = eng.profile_read()
         eng.profile(False)
-    res = dict(P, dt=dt, dt_local=dt_local, blocks=blocks, steps=steps, warmup=warmup, B=B, S=S, kern=kern, lnl=lnl, shard=bool(shard and world > 1),
+    res = dict(P, dt=dt, dt_local=dt_local, dt_wall=dt_wall, timed_by=("hip-events" if use_events else "host-clock"), blocks=blocks, steps=steps, warmup=warmup, B=B, S=S, kern=kern, lnl=lnl, shard=bool(shard and world > 1),
                evals=(B * steps if shard else world * B * steps))
     return res
 
@@ -525,7 +540,9 @@ def main():
     grouped = world > 1 or args.force_dist
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
+        if "MASTER_PORT" not in os.environ:
+            from thepayne_amd.launch import free_port
+            os.environ["MASTER_PORT"] = str(free_port()) if world == 1 else "29512"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     res = run_config(args.config, args, args.steps, args.warmup, rank, world, local_rank, B=args.batch,
@@ -555,7 +572,12 @@ def main():
         "ms_per_step": 1e3 * res["dt"] / args.steps,
         "repeats": len(res["blocks"]), "ms_per_step_min": 1e3 * min(res["blocks"]) / args.steps,
         "ms_per_step_max": 1e3 * max(res["blocks"]) / args.steps,
-        "timing": "median of `repeats` blocks of `steps` steps, each block between barrier + synchronize, MAX over ranks",
+        "ms_per_step_wall": 1e3 * res["dt_wall"] / args.steps,
+        "timing": ("median of `repeats` blocks of `steps` steps, MAX over ranks; every block sits between barrier + synchronize on both "
+                   "sides and is timed by a HIP event pair on the launch stream around its steps (`value`, `ms_per_step`) and by the host "
+                   "clock between the barriers (`ms_per_step_wall`: + ~55 us of synchronize / barrier edges per block)")
+                  if res["timed_by"] == "hip-events" else
+                  "median of `repeats` blocks of `steps` steps, each block between barrier + synchronize (host clock), MAX over ranks",
         "higher_is_better": True, "scaling": "strong" if res["shard"] else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_text(args.config, d),
@@ -585,12 +607,15 @@ def main():
     if world == 1 and not args.no_also and args.config == "C2" and not args.batch and args.streams == 1:
         # the configurations the headline does not show: short runs, same code path, own kernel times and roofline blocks
         also = {}
-        for name, (k, w, rep) in (("C3", (args.steps, args.warmup, args.repeats)), ("LinNet300", (args.steps, args.warmup, min(args.repeats, 5))),
+        # C2r: C2 on a model grid that is NOT a power of two long (3600 pixels of the same lambda_0 and R, 3200 observed pixels):
+        # what a trained Payne network looks like (Payne/utils/readc3k.py:441-447 builds the grid from a range and a resolution)
+        for name, (k, w, rep) in (("C3", (args.steps, args.warmup, args.repeats)), ("C2r", (args.steps, args.warmup, min(args.repeats, 5))),
+                                  ("LinNet300", (args.steps, args.warmup, min(args.repeats, 5))),
                                   ("C32k", (5, 2, 3)), ("C5", (3, 1, 3))):   # (C3 as long as the headline: a step is 0.04 ms)
             try:
                 r = run_config(name, args, k, w, 0, 1, local_rank, repeats=rep)
                 blk = {"value": r["evals"] / r["dt"], "unit": "likelihood-evals/s", "steps": k, "warmup": w, "repeats": rep,
-                       "ms_per_step": 1e3 * r["dt"] / k, "ms_per_step_min": 1e3 * min(r["blocks"]) / k,
+                       "ms_per_step": 1e3 * r["dt"] / k, "ms_per_step_wall": 1e3 * r["dt_wall"] / k, "ms_per_step_min": 1e3 * min(r["blocks"]) / k,
                        "ms_per_step_max": 1e3 * max(r["blocks"]) / k, "workload": workload_text(name, r["dims"]),
                        "kernels": r["engines"][0].kernels_used()}
                 if name == "C3" and cpu_c3 is not None:

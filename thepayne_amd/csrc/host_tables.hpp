@@ -260,9 +260,12 @@ inline int build_obs_tables(const double* wave, const double* flux, const double
     }
   }
   H.obs_wave.assign(wave, wave + nobs);
-  H.obs_rec.resize(nobs);
+  // padded to a multiple of kObsPad records with copies of the last pixel that weigh nothing (1/sigma^2 = 0): the likelihood-only
+  // loop (post_core.hpp obs_loop_fast) then runs whole blocks of pixels without an index clamp or a validity test per pixel
+  H.obs_rec.resize(((size_t)nobs + kObsPad - 1) / kObsPad * kObsPad);
   for (int i = 0; i < nobs; ++i)
     H.obs_rec[i] = ObsRec{H.lnobs[i], H.has_flux ? H.obs_f1[i] : 0.f, H.has_flux ? H.obs_ivar[i] : 0.f};
+  for (size_t i = (size_t)nobs; i < H.obs_rec.size(); ++i) H.obs_rec[i] = ObsRec{H.lnobs[nobs - 1], 0.f, 0.f};
   return 0;
 }
 

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/payne_hip.h"
@@ -1515,9 +1516,11 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
       }
     }
     __syncthreads();
-    // the threshold the next queue walks under is the lnprob of the LAST point that dies (dynesty's loglstar; payne_ns::peek_index):
-    // every element outside the new set died or was turned away at a threshold no higher, so that is the largest of them --
-    // unless no proposal got in, and nothing died
+    // the threshold the next queue walks under: the largest lnprob left outside the new set.  That is the lnprob D of the last point
+    // to die (dynesty's loglstar; payne_ns::peek_index) OR a proposal that was turned away after the last replacement, which lies
+    // between D and the new live minimum M -- any threshold in [D, M) is valid to walk under (a proposal is tested again, against the
+    // worst live point of its iteration, when the host consumes it), and the host accepts exactly that window (nested.py
+    // _fill_queue_dev).  If no proposal got in, nothing died and the old threshold stays.
     int got_in = 0;
     for (int r = tid; r < nl; r += 1024) got_in |= (id[r] >= nl) ? 1 : 0;
     got_in = __syncthreads_or(got_in);
@@ -1653,6 +1656,22 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
   return PAYNE_OK;
 }
 static void queue_extract(const double* hu, int K, int nd, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats);
+static bool wait_word(volatile unsigned long long* w, unsigned long long want, double seconds) {
+  // spin for the first millisecond (a C2 queue is ~1 ms: the word is usually there), then give the core away between looks -- a
+  // queue of 65 536-pixel spectra takes seconds, which one host core used to burn
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  bool polite = false;
+  while (__atomic_load_n(const_cast<const unsigned long long*>(w), __ATOMIC_ACQUIRE) != want) {
+    if (polite) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (polite || (++spins & 0x3FFu) == 0) {
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dt > seconds) return false;
+      polite = dt > 1e-3;
+    }
+  }
+  return true;
+}
 extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats) {
   if (!s) return PAYNE_E_INVALID;
   payne_ctx* c = s->ctx;
@@ -1665,12 +1684,7 @@ extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv
   if (s->q_flag) {
     // the word the queue's last kernel writes behind its results (every kernel before it on the stream has completed by then);
     // a queue that does not report within 10 s is handed to hipStreamSynchronize, which returns the fault if there was one
-    const unsigned long long want = s->q_seq;
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (__atomic_load_n(const_cast<const unsigned long long*>(s->q_flag), __ATOMIC_ACQUIRE) != want) {
-      if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { HIPCHK(c, hipStreamSynchronize(st)); break; }
-    }
+    if (!wait_word(s->q_flag, s->q_seq, 10.0)) HIPCHK(c, hipStreamSynchronize(st));
   } else {
     HIPCHK(c, hipStreamSynchronize(st));
   }
@@ -1705,13 +1719,6 @@ static void queue_extract(const double* hu, int K, int nd, double* qu, double* q
 }
 
 // ---- the queue's turn on the device: host entry points (header: payne_ns_queue_dev_*) ------------------------------------------
-static bool wait_word(volatile unsigned long long* w, unsigned long long want, double seconds) {
-  const auto t0 = std::chrono::steady_clock::now();
-  unsigned spins = 0;
-  while (__atomic_load_n(const_cast<const unsigned long long*>(w), __ATOMIC_ACQUIRE) != want)
-    if ((++spins & 0xFFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
-  return true;
-}
 extern "C" int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, const double* live_v, const double* live_logl, int nlive,
                                        double scale, double loglstar) {
   if (!s) return PAYNE_E_INVALID;

@@ -46,6 +46,8 @@ constexpr float kBase = 1.0f;                // the flux shift
 constexpr double kVsTabStep = 1.0 / 64.0;    // vsini taper table spacing in u
 constexpr double kVsTabMax = 256.0;
 constexpr double kPosMagic = 1572864.0;      // 1.5 * 2^20: a position t in [0, 2^19) added to it has ulp 2^-32 (magic_locate, vsini_tab_pos)
+constexpr unsigned kPosMagicHi = 0x41380000u; // its high dword: the high dword of t + kPosMagic is kPosMagicHi + floor(t) for 0 <= t < 2^19
+constexpr int kObsPad = 8192;                // PostTables::obs_rec holds a multiple of this many records (host_tables.hpp build_obs_tables)
 // Threads of the per-candidate workgroup, and how many of them own a butterfly in the radix-8 passes.
 // One wave issues a vector instruction every ~5 cycles whatever its kind (tools/exp/pk_rate.hip) while a SIMD
 // keeps four waves going at that rate each, so the per-pixel phases (tapers, resampling, observed grid) are
@@ -250,6 +252,14 @@ constexpr int kSlotShift = 6;        // one partial per wave (ballot / shuffle r
 constexpr int kSlotShift = 0;        // host emulation: one partial per thread
 #endif
 PAYNE_HD int n_slots(int nthr) { return nthr >> kSlotShift; }
+// did some thread of the wave see it?  (host emulation: a "wave" is one thread)
+PAYNE_HD bool wave_any(bool p) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __ballot(p) != 0ull;
+#else
+  return p;
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // FFT: Stockham radix-2/4/8 passes on M complex points held in LDS.
@@ -909,7 +919,9 @@ PAYNE_HD TaperArgs vsini_taper_args(const PostTables& T, double vrot) {
   TaperArgs ta{};
   ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
   // u_k = 2 pi sigma k/(n dv) (smoothing.py:612-614, :297); a candidate that does not rotate: u = 0, the taper is 1 in every bin
-  ta.vs_c = (vrot != 0.0) ? (2.0 * kPi * sqrt(vrot * vrot - 0.0)) * T.vs_val : 0.0;
+  // (sqrt(vrot^2 - 0) of smoothing.py:297 IS |vrot|: a correctly rounded square root of a correctly rounded square gives the
+  //  magnitude back exactly; the fp64 square root is a twenty-instruction Newton chain in front of every workgroup's table look-ups)
+  ta.vs_c = (vrot != 0.0) ? (2.0 * kPi * fabs(vrot)) * T.vs_val : 0.0;
   ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
   return ta;
 }
@@ -938,21 +950,64 @@ PAYNE_HD void slots_issue(int tid, int nthr, int M, const float* __restrict__ ro
   }
 }
 // `scrub`: NaN -> 0 first (the rotating branch's nan_to_num; a row is all NaN or not at all)
+// The tapers of a thread's SU slots when every bin is inside the table (the caller has checked the thread's LARGEST bin, M - tid,
+// or M for thread 0: the table position grows with the bin): no per-bin range test, no selects, the position of bin M - j from
+// the position of bin j by one subtraction and that of the next slot by one addition (positions carry 2^-32 of a table step;
+// three roundings instead of one move them by < 1e-9 step).
+template <int SU>
+PAYNE_HD void taper_slots_fast(const TaperArgs& ta, int tid, int nthr, int M, SlotRegs<SU>& R) {
+  const int ns = M / 2;
+  const float invM = 1.0f / (float)M, g = 0.25f * invM;
+  const double tmM = fma((double)M, ta.vs_c64, 2.0 * kPosMagic), dq = (double)nthr * ta.vs_c64;
+  double tma = fma((double)(tid ? tid : M / 2), ta.vs_c64, kPosMagic);     // slot 0: bins M/2 and M
+#pragma unroll
+  for (int q = 0; q < SU; ++q) {
+    const int j0 = tid + q * nthr;
+    union { double d; unsigned long long u; } ca, cb;
+    ca.d = (j0 < ns) ? tma : fma((double)(ns - 1), ta.vs_c64, kPosMagic);  // (a slot past the end: the last one again, never stored)
+    cb.d = tmM - ca.d;
+    if (q == 0 && tid == 0) cb.d = tmM - kPosMagic;                        // bin M itself
+    const float* __restrict__ qa = ta.vs_tab + (int)((unsigned)(ca.u >> 32) - kPosMagicHi) - 1;
+    const float* __restrict__ qb = ta.vs_tab + (int)((unsigned)(cb.u >> 32) - kPosMagicHi) - 1;
+    const tap2 ym = {qa[0], qb[0]}, y0 = {qa[1], qb[1]}, y1 = {qa[2], qb[2]}, y2 = {qa[3], qb[3]};
+    const tap2 f = {(float)(unsigned)ca.u * 2.3283064365386963e-10f, (float)(unsigned)cb.u * 2.3283064365386963e-10f};
+    const tap2 fm1 = f - 1.0f, fm2 = f - 2.0f, fp1 = f + 1.0f;
+    const tap2 a = f * fm1, b = fp1 * fm2;
+    const tap2 v = (a * fm2 * (-1.0f / 6.0f)) * ym + (b * fm1 * 0.5f) * y0 + (b * f * (-0.5f)) * y1 + (a * fp1 * (1.0f / 6.0f)) * y2;
+    const bool first = (q == 0 && tid == 0);
+    R.t[q][0] = v[0] * (first ? invM : g);
+    R.t[q][1] = first ? v[1] : v[1] * g;
+    tma = (q == 0 && tid == 0) ? fma((double)nthr, ta.vs_c64, kPosMagic) : tma + dq;
+  }
+}
+template <int SU>
+PAYNE_HD void slots_tapers(int tid, int nthr, int M, SlotRegs<SU>& R, const TaperArgs& ta) {
+  const int ns = M / 2;
+  // is the thread's largest bin (M - tid, M for thread 0) inside the table?  (false for a NaN rotation: the general look-up
+  // produces the NaN tapers)
+  const bool in_tab = fma((double)(M - tid), ta.vs_c64, kPosMagic) < kPosMagic + (double)(ta.vs_tab_n - 3);
+  if (!wave_any(!in_tab)) taper_slots_fast<SU>(ta, tid, nthr, M, R);
+  else {
+#pragma unroll
+    for (int q = 0; q < SU; ++q) {                   // (all the table loads before any of the pairs)
+      const int j0 = tid + q * nthr, j = j0 < ns ? j0 : ns - 1;
+      taper_slot(ta, M, j, R.t[q][0], R.t[q][1]);
+    }
+  }
+}
 template <int SU, class YP>
-PAYNE_HD void slots_commit(int tid, int nthr, int M, SlotRegs<SU>& R, YP Y, const TaperArgs& ta, bool scrub) {
+PAYNE_HD void slots_store(int tid, int nthr, int M, SlotRegs<SU>& R, YP Y, bool scrub) {
   const int ns = M / 2;
   const float invM = 1.0f / (float)M;
-#pragma unroll
-  for (int q = 0; q < SU; ++q) {                     // (all the table loads before any of the pairs)
-    const int j0 = tid + q * nthr, j = j0 < ns ? j0 : ns - 1;
-    taper_slot(ta, M, j, R.t[q][0], R.t[q][1]);
-  }
+  // nan_to_num of the rotating branch: a row in the frequency domain is NaN in every bin or in none (any NaN pixel of the spectrum
+  // reaches every bin of its transform), so the test is one value and the branch is the same for the whole workgroup
+  const bool rownan = scrub && wave_any(R.z[0][0] != R.z[0][0]);
 #pragma unroll
   for (int q = 0; q < SU; ++q) {
     const int j = tid + q * nthr;
     if (j >= ns) break;
     c32 zk{R.z[q][0], R.z[q][1]}, zm{R.z[q][2], R.z[q][3]};
-    if (scrub) { zk.x = nan_to_zero(zk.x); zk.y = nan_to_zero(zk.y); zm.x = nan_to_zero(zm.x); zm.y = nan_to_zero(zm.y); }
+    if (rownan) { zk = c32{0.f, 0.f}; zm = c32{0.f, 0.f}; }
     if (j) {
       c32 yk, ymk;
       taper_pair(zk, zm, R.w[q], R.t[q][0], R.t[q][1], yk, ymk);
@@ -964,6 +1019,11 @@ PAYNE_HD void slots_commit(int tid, int nthr, int M, SlotRegs<SU>& R, YP Y, cons
       st1(Y, M / 2, cscale(cconj(zm), R.t[q][0]));
     }
   }
+}
+template <int SU, class YP>
+PAYNE_HD void slots_commit(int tid, int nthr, int M, SlotRegs<SU>& R, YP Y, const TaperArgs& ta, bool scrub) {
+  slots_tapers<SU>(tid, nthr, M, R, ta);
+  slots_store<SU>(tid, nthr, M, R, Y, scrub);
 }
 
 // ---------------------------------------------------------------------------
@@ -1528,10 +1588,44 @@ PAYNE_HD void R_resample_loop(int tid, int nthr, const PostTables& T, const Cand
     }
   }
 }
+// The usual case of the loop above with half its instructions: geometric grid and a window of exactly RU x nthr points (every
+// thread owns RU of them: no bounds).  Only point 0 can round to a position below the first masked pixel and only point n2 - 1
+// above the last: the clamps sit on the first and the last row alone.  nan_to_num is not applied value by value: a NaN input shows
+// in the interpolated value, the function reports it and the caller runs the general loop instead (a NaN row; the NaN edges a
+// rotation stage with resampling maps leaves).  Weight f (1 + hs (f - 1)) from the integer fraction F = f 2^32 as F (c1 + c2 F).
+template <int RU>
+PAYNE_HD bool R_resample_fast(int tid, int nthr, const Window& W, const float* __restrict__ spec, float* __restrict__ work) {
+  const double rsBm = W.rsB + kPosMagic, rsD = (double)nthr * W.rsA;
+  const double tlo = kPosMagic + (double)W.i0, thi = kPosMagic + (double)(W.i1 - 1) - 2.3283064365386963e-10;
+  const float c1 = 2.3283064365386963e-10f * (1.0f - W.hs_ann), c2 = 5.421010862427522e-20f * W.hs_ann;
+  const double tm0 = fma((double)tid, W.rsA, rsBm);
+  float a[RU], b[RU], F[RU];
+#pragma unroll
+  for (int q = 0; q < RU; ++q) {
+    union { double d; unsigned long long u; } cv;
+    cv.d = fma((double)q, rsD, tm0);
+    if (q == 0) cv.d = fmax(cv.d, tlo);
+    if (q == RU - 1) cv.d = fmin(cv.d, thi);
+    const int k = (int)((unsigned)(cv.u >> 32) - kPosMagicHi);
+    F[q] = (float)(unsigned)cv.u;
+    a[q] = spec[k]; b[q] = spec[k + 1];
+  }
+  bool nan = false;
+#pragma unroll
+  for (int q = 0; q < RU; ++q) {
+    const float r = fmaf(b[q] - a[q], F[q] * fmaf(F[q], c2, c1), a[q]);
+    nan = nan || (r != r);
+    work[tid + q * nthr] = r;
+  }
+  return nan;
+}
 template <int RU = 16>
 PAYNE_HD void phase_R_resample(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
                                const float* __restrict__ spec, float* __restrict__ work) {
-  if (T.geo) R_resample_loop<true, RU>(tid, nthr, T, S, W, spec, work);
+  if (T.geo) {
+    if (W.n2 == RU * nthr && !wave_any(R_resample_fast<RU>(tid, nthr, W, spec, work))) return;
+    R_resample_loop<true, RU>(tid, nthr, T, S, W, spec, work);
+  }
   else R_resample_loop<false, RU>(tid, nthr, T, S, W, spec, work);
 }
 
@@ -1623,6 +1717,45 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
   return acc;
 }
 
+// The likelihood's usual case of obs_loop<0, false, true, false, OU> with a third of its instructions (profiles/r5_c2_valu_census.txt):
+// smoothed spectrum on the candidate's log grid, no blaze, chi^2 only, every pixel of the thread STRICTLY inside the window
+// (position t in [0, n2 - 1): the high dword of t + kPosMagic minus kPosMagicHi is then the left neighbour, one unsigned comparison
+// is the whole window test -- NaN, negative and too-large positions all fail it -- and no clamp, select or edge tolerance is
+// needed).  Whole blocks of the padded record table (kObsPad): no index clamp, no validity test; a padding record weighs nothing.
+// The interpolation weight f (1 + hs (f - 1)) is evaluated on the integer fraction F = f 2^32 as F (c1 + c2 F).
+// `bad` comes back true if some pixel failed the test: the caller then runs the general loop for this thread's pixels (on the
+// GPU: for the whole wave, a uniform branch) -- same result, the fast loop's value is dropped.
+template <int OU>
+PAYNE_HD float obs_loop_fast(int tid, int nthr, const PostTables& T, const Window& W, const float* __restrict__ conv, bool& bad) {
+  float acc = 0.f;
+  const double obBm = W.obB + kPosMagic;
+  const float c1 = 2.3283064365386963e-10f * (1.0f - W.hs_step), c2 = 5.421010862427522e-20f * W.hs_step;   // 2^-32 (1 - hs), 2^-64 hs
+  const unsigned kmax = (unsigned)(W.n2 - 2);
+  unsigned worst = 0u;
+  for (int base = tid; base < T.nobs; base += OU * nthr) {
+    float a[OU], b[OU], F[OU], of1[OU], iv[OU];
+#pragma unroll
+    for (int q = 0; q < OU; ++q) {
+      const ObsRec rec = T.obs_rec[(unsigned)(base + q * nthr)];   // one 16-byte load; the table is padded past nobs
+      of1[q] = rec.f1; iv[q] = rec.ivar;
+      union { double d; unsigned long long u; } cv;
+      cv.d = fma(rec.lnw, W.obA, obBm);
+      const unsigned kk = (unsigned)(cv.u >> 32) - kPosMagicHi;
+      worst = kk > worst ? kk : worst;
+      const unsigned k = kk < kmax ? kk : kmax;          // (a pixel that failed: any valid address)
+      F[q] = (float)(unsigned)cv.u;
+      a[q] = conv[k]; b[q] = conv[k + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < OU; ++q) {
+      const float w = F[q] * fmaf(F[q], c2, c1);
+      const float d = fmaf(b[q] - a[q], w, a[q]) - of1[q];
+      acc = fmaf(d * d, iv[q], acc);
+    }
+  }
+  bad = worst > kmax;
+  return acc;
+}
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
@@ -1649,19 +1782,55 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
        : (cheb ? obs_loop<MODE_, true, true, false, OUC>(tid, nthr, T, S, W, conv, out, out_stage)           \
                : obs_loop<MODE_, false, true, false, OU>(tid, nthr, T, S, W, conv, out, out_stage)))
   float acc;
-  if (smooth) acc = PAYNE_OBS(0);
-  else if (T.geo) acc = PAYNE_OBS(1);
-  else acc = PAYNE_OBS(2);
+  // chi^2 only, no blaze, smoothed spectrum: the short loop on whole blocks of the padded table (if the padding is not most of
+  // the work), the general one for a wave that met a pixel at or outside the window's ends
+  bool general = true;
+  if (smooth && !cheb && hasf && !out) {
+    const int blk = OU * nthr, npad = (T.nobs + blk - 1) / blk * blk;
+    if (4 * (npad - T.nobs) <= T.nobs && blk <= kObsPad) {
+      bool bad;
+      acc = obs_loop_fast<OU>(tid, nthr, T, W, conv, bad);
+      general = wave_any(bad);
+    }
+  }
+  if (general) {
+    if (smooth) acc = PAYNE_OBS(0);
+    else if (T.geo) acc = PAYNE_OBS(1);
+    else acc = PAYNE_OBS(2);
+  }
 #undef PAYNE_OBS
   return (double)acc;
 }
 
 // chi^2 partial of the thread -> one partial per slot in red[] (GPU: wave shuffle reduction)
+#ifdef __HIP_DEVICE_COMPILE__
+// Sum of a double over the wave, in lane 63: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the rows'
+// totals handed on (row_bcast 15, 31) -- data-parallel-primitive moves of the two halves and one fp64 add per level, 18 vector
+// instructions and no LDS crossbar (the shuffle form: six dependent ds_bpermute round trips of ~100 cycles each, 40 instructions,
+// at the very end of every workgroup's life).
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double x) {
+  union { double d; int i[2]; } a, b;
+  a.d = x;
+  b.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], CTRL, 0xf, 0xf, true);   // (bound_ctrl: a lane without a source reads 0)
+  b.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], CTRL, 0xf, 0xf, true);
+  return x + b.d;
+}
+__device__ __forceinline__ double wave_sum_to_last(double x) {
+  x = dpp_add_f64<0x111>(x);                             // row_shr:1
+  x = dpp_add_f64<0x112>(x);                             // row_shr:2
+  x = dpp_add_f64<0x114>(x);                             // row_shr:4
+  x = dpp_add_f64<0x118>(x);                             // row_shr:8   -> lane 15 of every row holds the row's sum
+  // (every row takes part in the last two levels: rows 0 and 2 collect sums nobody reads, lanes 31 and then 63 the right ones)
+  x = dpp_add_f64<0x142>(x);                             // row_bcast:15 -> lane 31 = rows 0 + 1, lane 63 = rows 2 + 3
+  x = dpp_add_f64<0x143>(x);                             // row_bcast:31 -> lane 63 holds the wave's sum
+  return x;
+}
+#endif
 PAYNE_HD void store_partial(int tid, double acc, double* red) {
 #ifdef __HIP_DEVICE_COMPILE__
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  acc = wave_sum_to_last(acc);
+  if ((tid & 63) == 63) red[tid >> 6] = acc;
 #else
   red[tid] = acc;
 #endif

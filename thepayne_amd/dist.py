@@ -31,7 +31,9 @@ def init_from_env(backend=None, force=False):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force = force or os.environ.get("PAYNE_DIST_FORCE", "0") == "1"
     if (world > 1 or force) and not dist.is_initialized():
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:        # (a forced group of one rank: any free port; torchrun sets it for real groups)
+            from .launch import free_port
+            os.environ["MASTER_PORT"] = str(free_port()) if world == 1 else "29511"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0

@@ -86,9 +86,21 @@ def launch_ranks(n, cmd, prepare=None, poll_s=0.05, timeout_s=None, rank0_stdout
                 time.sleep(poll_s)
         return rc
     finally:
+        # the clean-up itself must not be interrupted (a second SIGTERM / SIGINT while `end` waits would leave ranks alive):
+        # both signals are ignored until every rank is gone, then the previous handlers come back
+        old_int = None
+        try:
+            signal.signal(signal.SIGTERM, signal.SIG_IGN)
+            old_int = signal.signal(signal.SIGINT, signal.SIG_IGN)
+        except ValueError:
+            pass
         end([q for q in procs if q.poll() is None])
-        if old_term is not None:
-            signal.signal(signal.SIGTERM, old_term)
+        try:
+            if old_int is not None:
+                signal.signal(signal.SIGINT, old_int)
+            signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
+        except ValueError:
+            pass
 
 
 if __name__ == "__main__":          # python -m thepayne_amd.launch N prog args...

@@ -195,7 +195,7 @@ class NestedSampler(object):
         # workgroup merges a queue's proposals into it, adapts the scale, raises the threshold and draws the next start points),
         # and the next queue is enqueued BEFORE the current one has finished -- the GPU goes from queue to queue without waiting for
         # the host, which consumes each queue for the evidence meanwhile.  The host's live SET stays the device's (checked every
-        # queue through the threshold; a mismatch -- ties -- re-uploads it); start points are drawn from the device's ordering of
+        # queue: the device's threshold must lie in [the host's, the live minimum); outside that window the set is re-uploaded); start points are drawn from the device's ordering of
         # it, so a run is the host-turn run statistically, not to the bit.
         self._dev_turn = isinstance(pipeline, str) and pipeline == 'device'
         if self._dev_turn:
@@ -442,16 +442,23 @@ class NestedSampler(object):
             self._dev_inflight += 1
         nq, acc, calls, redrawn, idle, sc_used, ls_used = prop.queue_dev_collect(self._qbuf)
         self._dev_inflight -= 1
-        if ls_used != self.loglstar:
-            # the device's live set is not the host's (equal lnprob values broke a tie the other way; a loop that stopped in
-            # mid-queue): collect what is in flight, start again from the host's set
+        self.ncall += calls                        # (likelihood calls were made whether or not the queue is used)
+        # The threshold the device walked under is the largest lnprob left OUTSIDE its live set after the merge.  The host's own
+        # (the last point to die, D) can be lower: a proposal turned away after the last replacement lies between D and the live
+        # minimum M.  Every threshold in [D, M) is a valid one to walk under -- proposals are tested again, against the worst live
+        # point of their iteration, when they are consumed -- so that window is the test; outside it the two live SETS differ (a loop
+        # that stopped in mid-queue and went on; a tie across the set's boundary) and the device starts again from the host's.
+        # (Ties INSIDE the set -- the host drops the lower slot of two equal values, the device the higher id -- leave the same
+        # multiset of lnprob values on both sides and are not seen here; the points themselves then differ only in which of two
+        # equally likely positions stays, which no statistic of the run depends on.)
+        if not (self.loglstar <= ls_used < float(self.live_logl.min())) and ls_used != self.loglstar:
             self._dev_desync += 1
             self._dev_drain()
             if not again:
-                raise RuntimeError("the device's threshold (%r) is not the host's (%r)" % (ls_used, self.loglstar))
+                raise RuntimeError("the device's threshold (%r) is outside the host's window [%r, %r)"
+                                   % (ls_used, self.loglstar, float(self.live_logl.min())))
             self._qbufs.reverse()
             return self._fill_queue_dev(again=False)
-        self.ncall += calls
         frac = acc / max(1, calls + redrawn)
         self.scale = min(max(sc_used * math.exp((frac - 0.5) / nd / 0.5), 1e-4), 4.0)     # (what the device's turn computed too)
         self._pending_nc += idle
@@ -462,11 +469,10 @@ class NestedSampler(object):
         """Collect and discard the queues still in flight; the device's live set no longer counts."""
         K, nd = self.queue_size, self.ndim
         scratch = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
+        closed = not getattr(getattr(self.proposer, "_handle", None), "value", True)   # (closed before an abandoned generator was finalised)
         while self._dev_inflight > 0:
-            try:
-                self.proposer.queue_dev_collect(scratch)
-            except Exception:                      # (a proposer closed before an abandoned generator was finalised)
-                pass
+            if not closed:                         # any other failure is an error: the C side would still count the queue as in flight
+                self.ncall += self.proposer.queue_dev_collect(scratch)[2]
             self._dev_inflight -= 1
         self._dev_sync = False
 

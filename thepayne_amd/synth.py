@@ -16,6 +16,9 @@ CONFIGS = {
     # C3: C2 + photometry in 7 filters (Bessell_BVRI, 2MASS_JHKs), H = 64 sigmoid nets (make_phot_nets seed 1),
     # observed magnitudes 5.0 +- 0.05, the `photscale` parametrisation: log(A) U[-3, 7], Av U[0, 1]
     "C3": dict(npix=4096, lam0=5150.0, R=32000.0, nobs=3600, batch=512, phot=True),
+    # not a BASELINE config: C2's grid cut to a length that is not a power of two (what a trained network has: the reference builds
+    # its grid from a wavelength range and a resolution, Payne/utils/readc3k.py:441-447, and resamples to 2^k itself)
+    "C2r": dict(npix=3600, lam0=5150.0, R=32000.0, nobs=3200, batch=512),
     "C5": dict(npix=65536, lam0=4000.0, R=100000.0, nobs=60000, batch=2048),
     # not a BASELINE config: spectra between the LDS-resident kernel (<= 16 384 points) and C5 -- an R ~ 60k grid of 32 768 pixels
     # (4500-4861 AA), 30 000 observed pixels, 1024 candidates (the reference's own demo spectrum has 25 600 pixels, demo/runPayne.py:43-50)
