@@ -15,6 +15,7 @@ static int g_fast_windows = 0;   // candidates whose R-stage window came from th
 extern "C" int payne_emul_fast_windows() { return g_fast_windows; }
 
 struct HostExec {
+  static constexpr bool kTwLds = false;
   int nthr;
   template <class F> void par(F&& f) { for (int t = 0; t < nthr; ++t) f(t, nthr); }
   int nthreads() const { return nthr; }

@@ -1725,45 +1725,73 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
 // The interpolation weight f (1 + hs (f - 1)) is evaluated on the integer fraction F = f 2^32 as F (c1 + c2 F).
 // `bad` comes back true if some pixel failed the test: the caller then runs the general loop for this thread's pixels (on the
 // GPU: for the whole wave, a uniform branch) -- same result, the fast loop's value is dropped.
+struct ObsFastConsts { double obA, obBm; float c1, c2; unsigned kmax; };
+PAYNE_HD ObsFastConsts obs_fast_consts(const Window& W) {
+  ObsFastConsts c;
+  c.obA = W.obA; c.obBm = W.obB + kPosMagic;
+  c.c1 = 2.3283064365386963e-10f * (1.0f - W.hs_step); c.c2 = 5.421010862427522e-20f * W.hs_step;   // 2^-32 (1 - hs), 2^-64 hs
+  c.kmax = (unsigned)(W.n2 - 2);
+  return c;
+}
+// is the short loop worth taking for this grid and this block size?  (the padding must not be most of the work)
+PAYNE_HD bool obs_fast_ok(const PostTables& T, int blk) {
+  const int npad = (T.nobs + blk - 1) / blk * blk;
+  return 4 * (npad - T.nobs) <= T.nobs && blk <= kObsPad;
+}
+// the OU records of one block of the thread, requested (one 16-byte load each; the table is padded past nobs)
 template <int OU>
-PAYNE_HD float obs_loop_fast(int tid, int nthr, const PostTables& T, const Window& W, const float* __restrict__ conv, bool& bad) {
-  float acc = 0.f;
-  const double obBm = W.obB + kPosMagic;
-  const float c1 = 2.3283064365386963e-10f * (1.0f - W.hs_step), c2 = 5.421010862427522e-20f * W.hs_step;   // 2^-32 (1 - hs), 2^-64 hs
-  const unsigned kmax = (unsigned)(W.n2 - 2);
-  unsigned worst = 0u;
-  for (int base = tid; base < T.nobs; base += OU * nthr) {
-    float a[OU], b[OU], F[OU], of1[OU], iv[OU];
+PAYNE_HD void obs_fast_issue(int nthr, const PostTables& T, int base, ObsRec (&rec)[OU]) {
 #pragma unroll
-    for (int q = 0; q < OU; ++q) {
-      const ObsRec rec = T.obs_rec[(unsigned)(base + q * nthr)];   // one 16-byte load; the table is padded past nobs
-      of1[q] = rec.f1; iv[q] = rec.ivar;
-      union { double d; unsigned long long u; } cv;
-      cv.d = fma(rec.lnw, W.obA, obBm);
-      const unsigned kk = (unsigned)(cv.u >> 32) - kPosMagicHi;
-      worst = kk > worst ? kk : worst;
-      const unsigned k = kk < kmax ? kk : kmax;          // (a pixel that failed: any valid address)
-      F[q] = (float)(unsigned)cv.u;
-      a[q] = conv[k]; b[q] = conv[k + 1];
-    }
+  for (int q = 0; q < OU; ++q) rec[q] = T.obs_rec[(unsigned)(base + q * nthr)];
+}
+template <int OU>
+PAYNE_HD void obs_fast_block(const ObsRec (&rec)[OU], const ObsFastConsts& c, const float* __restrict__ conv, float& acc, unsigned& worst) {
+  float a[OU], b[OU], F[OU];
 #pragma unroll
-    for (int q = 0; q < OU; ++q) {
-      const float w = F[q] * fmaf(F[q], c2, c1);
-      const float d = fmaf(b[q] - a[q], w, a[q]) - of1[q];
-      acc = fmaf(d * d, iv[q], acc);
-    }
+  for (int q = 0; q < OU; ++q) {
+    union { double d; unsigned long long u; } cv;
+    cv.d = fma(rec[q].lnw, c.obA, c.obBm);
+    const unsigned kk = (unsigned)(cv.u >> 32) - kPosMagicHi;
+    worst = kk > worst ? kk : worst;
+    const unsigned k = kk < c.kmax ? kk : c.kmax;        // (a pixel that failed: any valid address)
+    F[q] = (float)(unsigned)cv.u;
+    a[q] = conv[k]; b[q] = conv[k + 1];
   }
-  bad = worst > kmax;
+#pragma unroll
+  for (int q = 0; q < OU; ++q) {
+    const float w = F[q] * fmaf(F[q], c.c2, c.c1);
+    const float d = fmaf(b[q] - a[q], w, a[q]) - rec[q].f1;
+    acc = fmaf(d * d, rec[q].ivar, acc);
+  }
+}
+// `first`: the records of the thread's first block, already requested by the caller (ahead of the transform that produces `conv`)
+template <int OU>
+PAYNE_HD float obs_loop_fast(int tid, int nthr, const PostTables& T, const Window& W, const float* __restrict__ conv, bool& bad,
+                             const ObsRec (*first)[OU] = nullptr) {
+  float acc = 0.f;
+  const ObsFastConsts c = obs_fast_consts(W);
+  unsigned worst = 0u;
+  int base = tid;
+  if (first && base < T.nobs) { obs_fast_block<OU>(*first, c, conv, acc, worst); base += OU * nthr; }
+  for (; base < T.nobs; base += OU * nthr) {
+    ObsRec rec[OU];
+    obs_fast_issue<OU>(nthr, T, base, rec);
+    obs_fast_block<OU>(rec, c, conv, acc, worst);
+  }
+  bad = worst > c.kmax;
   return acc;
 }
+
 // Final: interpolate onto the observed grid, blaze, chi^2 partial per thread.
 // `conv` = smoothed spectrum on the candidate's log grid (do_smooth) or the
 // (rotated) spectrum on the ANN grid (plain np.interp branch, ystpred.py:271-272).
 // force_grid: `conv` lives on the uniform log grid W describes whatever S.do_smooth says (the rotation stage's own resampled grid:
 // smoothspec('vsini', outwave=...), smoothing.py:293-312)
+// `first`: the thread's first block of records, requested ahead by the caller (only with obs_fast_ok and chi^2 alone: see run_candidate)
 template <int OU = 16>
 PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandState& S, const Window& W,
-                          const float* __restrict__ conv, float* __restrict__ out, int out_stage, bool force_grid = false) {
+                          const float* __restrict__ conv, float* __restrict__ out, int out_stage, bool force_grid = false,
+                          const ObsRec (*first)[OU] = nullptr) {
   const bool cheb = T.npoly > 0 && !force_grid, hasf = T.obs_f1 != nullptr, smooth = S.do_smooth != 0 || force_grid;
   if (!out && !hasf) return 0.0;                         // nothing to produce
   if (smooth && W.bad) {                                 // window too small: every pixel NaN
@@ -1785,13 +1813,10 @@ PAYNE_HD double phase_obs(int tid, int nthr, const PostTables& T, const CandStat
   // chi^2 only, no blaze, smoothed spectrum: the short loop on whole blocks of the padded table (if the padding is not most of
   // the work), the general one for a wave that met a pixel at or outside the window's ends
   bool general = true;
-  if (smooth && !cheb && hasf && !out) {
-    const int blk = OU * nthr, npad = (T.nobs + blk - 1) / blk * blk;
-    if (4 * (npad - T.nobs) <= T.nobs && blk <= kObsPad) {
-      bool bad;
-      acc = obs_loop_fast<OU>(tid, nthr, T, W, conv, bad);
-      general = wave_any(bad);
-    }
+  if (smooth && !cheb && hasf && !out && obs_fast_ok(T, OU * nthr)) {
+    bool bad;
+    acc = obs_loop_fast<OU>(tid, nthr, T, W, conv, bad, first);
+    general = wave_any(bad);
   }
   if (general) {
     if (smooth) acc = PAYNE_OBS(0);

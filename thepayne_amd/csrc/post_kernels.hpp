@@ -33,6 +33,7 @@ struct PostArgs {
 // BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
 template <bool BUF_LDS, bool TW_LDS>
 struct DevExecT {
+  static constexpr bool kTwLds = TW_LDS;                     // the twiddle table handed to run_candidate is the kernel's LDS copy
 #ifdef __HIP_DEVICE_COMPILE__
   static __device__ __forceinline__ auto buf(c32* p) {
     if constexpr (BUF_LDS) return (PAYNE_AS_LDS f2v*)p; else return (PAYNE_AS_GLOBAL f2v*)p;
@@ -128,6 +129,10 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   typedef float f2g __attribute__((ext_vector_type(2)));
   constexpr int NTW = LOG2N > 0 ? plan_table_len((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : 1, PER = (NTW + kPostThreads - 1) / kPostThreads;
   f2g tw_tmp[PER];
+  // rows handed over in the frequency domain: the first phase loads the split factors exp(-2 pi i j / 2M) slot by slot anyway
+  // (slots_issue) and puts them into the LDS table itself -- here they would be 8 KB more for every workgroup to pull through an
+  // L2 port that the kernel's first phase saturates (22 B/clk/CU: the row, the table and the records of two workgroups)
+  const int ntw_copy = (LOG2N > 0 && TW_LDS && T.raw_freq) ? plan_total((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : NTW;
   if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
     c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
     const f2g* __restrict__ g = reinterpret_cast<const f2g*>(T.twf);
@@ -138,7 +143,7 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int i0 = (int)threadIdx.x + q * kPostThreads;
-        tw_tmp[q] = g[i0 < NTW ? i0 : NTW - 1];
+        tw_tmp[q] = g[i0 < ntw_copy ? i0 : ntw_copy - 1];
       }
     } else {
       const int nt = T.twf_n;
@@ -167,10 +172,11 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
       //  -- the last one -- into that condition, behind the wait for the others: a second round trip)
 #pragma unroll
       for (int q = 0; q < PER; ++q) asm volatile("" : "+v"(tw_tmp[q]));
+      const int ncopy = T.raw_freq ? plan_total((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : NTW;
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int i0 = (int)threadIdx.x + q * kPostThreads;
-        if (i0 < NTW) tl[i0] = tw_tmp[q];
+        if (i0 < ncopy) tl[i0] = tw_tmp[q];
       }
     }
     if (a.mags != nullptr && a.n_filters <= 64 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + a.n_filters) {
@@ -270,6 +276,7 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
 // 512 threads, the stage's 32 768 complex points in registers, 128 KB of LDS as the transpose buffer.  The phases around the
 // two stages (mask window, resampling, observed grid, chi^2) are the global-workspace phases of payne_post_big_kernel; a
 // candidate whose instrumental window needs a shorter transform takes that kernel's runtime-geometry passes for that stage.
+namespace payne { template <bool TW> struct ex_lds_tail<DevExecT<true, TW>> { static constexpr bool value = true; }; }
 struct ChipExec : DevExecT<false, false> {
 #ifdef __HIP_DEVICE_COMPILE__
   ChipLds L;

@@ -146,6 +146,40 @@ PAYNE_SEQ_CALL c32* fft_fixed(Ex& ex, c32* src, c32* dst, const c32* twf, unsign
   return fft_fixed_passes<M, 1, NT>(ex, s, d, Ex::twid(twf), sign_last, edge) == s ? src : dst;
 }
 
+// Executors whose buffers are LDS say so through this trait: the LAST inverse transform of a likelihood evaluation and the
+// observed-grid loop behind it then run as ONE phase (inverse_and_obs below).
+template <class Ex> struct ex_lds_tail { static constexpr bool value = false; };
+#ifdef __HIP_DEVICE_COMPILE__
+// a barrier that waits for the wave's LDS traffic only: global loads stay in flight across it (__syncthreads() drains them)
+__device__ __forceinline__ void post_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int M, int P, int NT, class BP, class TP>
+__device__ __forceinline__ BP fft_fixed_passes_lds(int tid, BP src, BP dst, TP twf, unsigned sign_last) {
+  if constexpr (P >= M) {
+    return src;
+  } else {
+    constexpr int R = plan_radix(M, P);
+    constexpr bool last = (P * R >= M);
+    fft_pass_fixed<R, M, P, NT>(tid, src, dst, twf, last ? sign_last : 0u, false);
+    post_lds_barrier();
+    return fft_fixed_passes_lds<M, P * R, NT>(tid, dst, src, twf, sign_last);
+  }
+}
+// The tail of a likelihood evaluation as ONE phase: the records of the observed pixels (16 bytes a pixel, 58 KB per candidate at
+// C2 -- the phase that reads them is bound by those bytes at what an XCD's L2 hands a CU) are REQUESTED first and stay in flight
+// under the instrumental stage's whole inverse transform, whose passes are inlined here behind LDS-only barriers (a call, or
+// __syncthreads(), waits for every outstanding load); the loop then finds them in registers.  z: the tapered spectrum (Y of
+// rfft_taper_phase), zo: the other buffer.  Returns the thread's chi^2 partial.
+template <int M, int NT, int OU, class Ex>
+__device__ __forceinline__ double inverse_and_obs(int tid, const PostTables& T, const CandState& S, const Window& W, const c32* twf,
+                                                  c32* z, c32* zo) {
+  ObsRec rec[OU];
+  obs_fast_issue<OU>(NT, T, tid, rec);
+  auto r = fft_fixed_passes_lds<M, 1, NT>(tid, Ex::buf(z), Ex::buf(zo), Ex::twid(twf), 0x80000000u);
+  const float* conv = (r == Ex::buf(z)) ? (const float*)z : (const float*)zo;
+  return phase_obs<OU>(tid, NT, T, S, W, conv, nullptr, -1, false, &rec);
+}
+#endif
+
 // Executors that keep a 65 536-point stage on the compute unit (post_onchip.hpp: the spectrum in registers, LDS as the
 // transpose buffer) say so through this trait; their convolution stage is chip_conv_stage (post_kernels.hpp).
 constexpr int kChipN1 = 65536;
@@ -162,7 +196,8 @@ template <int LOG2N, int NT, bool VSINI, class Ex>
 PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* work, float* other, int n,
                             const TaperArgs& ta, bool& edge, const float* src0 = nullptr, const Window* rs = nullptr,
                             bool have_y = false,     // have_y: `work` already holds the tapered transform (T.raw_freq rows: slots_commit)
-                            bool zin = false, bool scrub = true) {   // chip executors: src0 is the row's transform (chip_layout); NaN -> 0 on the way in
+                            bool zin = false, bool scrub = true,     // chip executors: src0 is the row's transform (chip_layout); NaN -> 0 on the way in
+                            bool defer_inverse = false) {   // fixed geometry of exactly n points: leave the inverse transform to the caller (returns the tapered spectrum)
   const int M = n / 2;
   if constexpr (ex_chip<Ex>::value) {
     if (n == kChipN1) return chip_conv_stage<VSINI>(ex, work, ta, edge, src0, rs, zin, scrub);
@@ -174,6 +209,7 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
       constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
       if (!(PAYNE_EXP_SKIP & 2) && !have_y) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
+      if (defer_inverse) return (float*)z;
       float* res = (PAYNE_EXP_SKIP & 4) ? (float*)z : (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
       edge = false;
       return res;
@@ -239,7 +275,14 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (prep) phase_take_prep_commit(t, pr, S);
     else phase_setup(t, n, T, th, instr_factor, S);
     ex.mark(128);                                      // (diagnostic build: end of the instrument / mask-probe chain)
-    if (freq && !freq_chip) slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
+    if (freq && !freq_chip) {
+      if constexpr (Ex::kTwLds && LOG2N > 0) {         // the split factors this thread loaded for its slots complete the kernel's LDS table
+        auto tl = Ex::buf(const_cast<c32*>(twf) + plan_total(MFq));
+#pragma unroll
+        for (int q = 0; q < SU; ++q) { const int j = t + q * NT; if (j < MFq / 2) stc(tl, j, slots.w[q]); }
+      }
+      slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
+    }
     else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
@@ -290,6 +333,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   }
   const float* on_grid = spec;
   Window W{};
+  bool tail_done = false;
   if (smooth) {
     if (S.win_ready) {                                 // mask counts known since setup
       if (edges_pending) ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
@@ -314,10 +358,27 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       bool no_edge = false;
       // (a stage that gathers its input itself has all of it in registers before it stores anything: its output goes where its
       //  input was -- one 256 KB buffer per workgroup in flight instead of two, 67 MB for the 256 workgroups of a C5 launch)
-      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, gather ? spec : work, spec, W.n2, ta, no_edge, gather ? spec : nullptr, gather ? &W : nullptr);
+      // chi^2 alone from a window of the fixed geometry's own length, whole blocks of records: the inverse transform and the
+      // observed-grid loop as one phase, the records requested ahead of the transform (inverse_and_obs)
+      bool fused_tail = false;
+      if constexpr (ex_lds_tail<Ex>::value && LOG2N > 0 && UX <= 8) {    // (a thread's block of records stays in registers: 4 x UX of them)
+        fused_tail = !gather && out == nullptr && T.obs_f1 != nullptr && T.npoly == 0 && W.n2 == (1 << LOG2N) && obs_fast_ok(T, UX * NT);
+      }
+      on_grid = conv_stage<LOG2N, NT, false>(ex, T, twf, gather ? spec : work, spec, W.n2, ta, no_edge, gather ? spec : nullptr, gather ? &W : nullptr,
+                                             false, false, true, fused_tail);
+#ifdef __HIP_DEVICE_COMPILE__
+      if constexpr (ex_lds_tail<Ex>::value && LOG2N > 0 && UX <= 8) {
+        if (fused_tail) {
+          c32* z = (c32*)const_cast<float*>(on_grid);
+          c32* zo = (on_grid == work) ? (c32*)spec : (c32*)work;
+          ex.par([&](int t, int) { store_partial(t, inverse_and_obs<(1 << LOG2N) / 2, NT, UX, Ex>(t, T, S, W, twf, z, zo), red); });
+          tail_done = true;
+        }
+      }
+#endif
     }
   }
-  if (!(PAYNE_EXP_SKIP & 16)) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
+  if (!(PAYNE_EXP_SKIP & 16) && !tail_done) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
   // the sum of the per-wave partials: thread 0 alone, no closing barrier (it is also the only reader)
   ex.single([&](int n) {
     double s = 0.0;

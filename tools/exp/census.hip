@@ -9,6 +9,7 @@ using namespace payne;
 #include "../../thepayne_amd/csrc/sampler_core.hpp"
 
 struct DevEx {
+  static constexpr bool kTwLds = true;
   static __device__ __forceinline__ auto buf(c32* p) { return (PAYNE_AS_LDS f2v*)p; }
   static __device__ __forceinline__ auto twid(const c32* p) { return (const PAYNE_AS_LDS f2v*)p; }
   static __device__ __forceinline__ auto lds(c32* p) { return (PAYNE_AS_LDS f2v*)p; }

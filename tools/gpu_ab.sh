@@ -2,7 +2,7 @@
 # A/B of the running build against a kept library (thepayne_amd/build/old/libpayne_hip_head.so) in ONE box session, interleaved runs.
 #   bash tools/gpu_ab.sh [C2|C3|C5] [repeats]
 CFG=${1:-C2}; REP=${2:-3}
-OLD=$PWD/thepayne_amd/build/old/libpayne_hip_head.so
+OLD=${OLD:-$PWD/thepayne_amd/build/old/libpayne_hip_head.so}
 STEPS=300; WARM=30
 if [ $CFG = C5 ] || [ $CFG = C32k ]; then STEPS=5; WARM=2; fi
 one() {

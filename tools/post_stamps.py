@@ -64,6 +64,12 @@ for rep in range(3):
 n = int(st[0, 0])
 whole = st[:, ROW - 1].astype(np.int64) - st[:, 1].astype(np.int64)
 print("whole kernel per candidate (first stamp -> kernel end): median %d cycles" % np.median(whole))
+# the launch itself: how far apart the workgroups of one XCD (workgroup index mod 8) start and end.  (s_memtime is per XCD.)
+first, last = st[:, 1].astype(np.int64), st[:, ROW - 1].astype(np.int64)
+for x in range(8):
+    f, l = first[x::8], last[x::8]
+    print("  XCD %d: %3d workgroups, starts spread over %6d cycles, ends over %6d, first start -> last end %6d (a workgroup's life: median %d)"
+          % (x, len(f), f.max() - f.min(), l.max() - l.min(), l.max() - f.min(), np.median(l - f)))
 if os.environ.get("PAYNE_DIAG_SPARSE"):
     sys.exit(0)
 d = np.diff(st[:, 1:n + 1].astype(np.int64), axis=1)
