@@ -111,10 +111,7 @@ typedef struct payne_opts {
 #define PAYNE_V_TW_GLOBAL 4u     /* post kernel: twiddles read from L2 instead of LDS (what 8k spectra use) */
 #define PAYNE_V_POST_FULL 8u     /* likelihood through the full post kernel instead of its likelihood-only build */
 #define PAYNE_V_NO_PREP 16u      /* per-candidate records computed inside the post kernel (what 2-layer nets use) */
-#define PAYNE_V_BIG_PLAIN 32u    /* spectra > 16384 px: plain radix-8 passes instead of the four-step transform */
 #define PAYNE_V_SELECT_MEDIAN 64u /* continuum / LSF medians by radix selection (what rows too long for an LDS sort use) */
-#define PAYNE_V_BIG_FUSED 256u   /* spectra > 16384 px: the row read by the first transform pass, the taper applied while the inverse
-                                  * transform loads (19 instead of 25 transfers of the spectrum; measured 3 % slower: kept as the record) */
 #define PAYNE_V_NO_WALK_TAIL 512u /* the sampler's chain step as a launch of its own between two likelihood batches (what
                                   * contexts without a likelihood-only post kernel use) instead of at the post kernel's tail */
 #define PAYNE_V_OUT_BK64 1024u   /* output layer: 64-deep stages (half as many barrier steps) when the padded width allows */
@@ -126,9 +123,6 @@ typedef struct payne_opts {
                                     * hidden-layer launch */
 #define PAYNE_V_OUT_SMALL_TILES 16384u /* output layer with many tiles per CU (C5): 64 x 128 tiles, two workgroups per CU (what batches that
                                        * are not whole 128 x 256 tiles use) instead of persistent workgroups on 128 x 256 tiles */
-#define PAYNE_V_DENSE_FUSED 32768u /* hidden layers + output layer in ONE launch: output-layer workgroups take the hidden tiles on first
-                                    * (roles by ticket), publish them write-through and hand them over through agent-scope counters
-                                    * (3-layer nets of equal hidden width <= 320, batch a multiple of 64, one output tile per CU) */
 #define PAYNE_V_BIG_WORKSPACE 65536u /* 65 536-point spectra: both convolution stages through the global workspace (the four-step transform: what
                                       * other lengths above 16 384 use) instead of on the compute unit */
 #define PAYNE_V_NO_WALK_SPEC 131072u /* the sampler's next proposal drawn at the post kernel's tail, after the likelihood it waits for (what fits
@@ -137,8 +131,6 @@ typedef struct payne_opts {
 #define PAYNE_V_ROWS_PIXEL 262144u /* the output layer writes pixels and the post kernel transforms them itself (what runs with a continuum
                                     * network, with vsini maps that are not the identity, and for spectra other than 1k/2k/4k/8k);
                                     * default where it applies: the output layer's weights carry the first stage's forward transform */
-#define PAYNE_V_QUEUE_MEMCPY 1048576u /* the sampler's proposal queue moved by hipMemcpyAsync and collected by hipStreamSynchronize (default: copy
-                                       * kernels on mapped host memory, completion read from a word the last of them writes there) */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -23,8 +23,6 @@ struct HostExec {
   template <class F> void single(F&& f) { f(nthr); }
   c32* tile_ = nullptr;                                    // scratch of the four-step transform (null: plain passes)
   c32* tile() const { return tile_; }
-  bool fuse_ = true;
-  bool fuse() const { return fuse_; }
   static c32* buf(c32* p) { return p; }                    // address-space hooks of the device executor
   static const c32* twid(const c32* p) { return p; }
   static c32* lds(c32* p) { return p; }
@@ -68,7 +66,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
   T.npoly = npoly;
-  if (force_general == 1 || force_general == 2) { T.geo = 0; T.rot_identity = 0; }    // (3: runtime geometry on the geometric grid)
+  if (force_general == 1 || force_general == 2) { T.geo = 0; T.rot_identity = 0; }    // (3: the four-step transform on the geometric grid)
   // 4: the rows handed over the way the restated output layer writes them (freq_rows): their half transform in pair layout,
   // rounded to fp32
   std::vector<float> zrows;

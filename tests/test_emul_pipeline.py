@@ -195,18 +195,17 @@ def test_four_step_transform_of_the_big_kernel(emul, npix, nobs):
         assert np.nanmax(np.abs(tiled[i] - ref)) <= 1e-6
 
 
-def test_four_step_transform_reads_the_row_itself_on_a_geometric_grid(emul):
-    """The C5 shape (65 536 pixels on a geometric grid: the vsini resampling is the identity): the first pass of the vsini
-    transform reads the raw ANN row directly (NaN scrub included) and the inverse transforms combine the conjugate
-    pairs while they load -- no row copy, no separate taper pass; against the oracle."""
+def test_four_step_transform_on_a_geometric_grid(emul):
+    """The C5 shape (65 536 pixels on a geometric grid: the vsini resampling is the identity) through the four-step transform of
+    the global-workspace kernel (what payne_post_big_kernel runs under PAYNE_V_BIG_WORKSPACE); against the oracle."""
     npix, nobs = 65536, 3000
     net = synth.make_yst_net(npix=npix, lam0=4000.0, R_fwhm=100000.0, H=8, seed=3, line_depth=0.3)
     obs = synth.obs_grid(net["wavelength"], nobs, inset=0.0005, relative=True)
     th8 = np.array([[5600.0, 4.3, -0.2, 0.1, 12.0, 6.0, np.nan, 60000.0]])
-    fused, _, _ = emul(net, obs, None, None, th8, 2, factor=1.0, general=3, nthreads=512)
+    got, _, _ = emul(net, obs, None, None, th8, 2, factor=1.0, general=3, nthreads=512)
     with np.errstate(all="ignore"):
         _, ref = O.getspec(net, Teff=5600.0, logg=4.3, feh=-0.2, afe=0.1, rad_vel=12.0, rot_vel=6.0, inst_R=60000.0, outwave=obs)
-    assert np.array_equal(np.isnan(fused[0]), np.isnan(ref)) and np.nanmax(np.abs(fused[0] - ref)) <= 1e-6
+    assert np.array_equal(np.isnan(got[0]), np.isnan(ref)) and np.nanmax(np.abs(got[0] - ref)) <= 1e-6
 
 
 @pytest.mark.parametrize("n,layout", [(1024, 0), (4096, 0), (65536, 1), (32768, 2)])

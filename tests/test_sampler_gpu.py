@@ -535,16 +535,6 @@ def test_rwalk_queue_in_one_native_call(tmp_path):
                                                       0.05 * np.eye(nd), None, None, 1.0, -np.inf, walks, 9, again)
     assert calls4 == K * walks and red4 > K and np.all(again[0][:nq4] > 0)
     prop.close()
-    # the queue moved by hipMemcpyAsync and collected by hipStreamSynchronize (PAYNE_V_QUEUE_MEMCPY) instead of the copy kernels on
-    # mapped host memory and the completion word: the same queue to the bit
-    from thepayne_amd import _lib
-    L2, P2, _ = _fit_objects(tmp_path, photscale=True, variant=_lib.V_QUEUE_MEMCPY)
-    prop2 = _proposer(L2, P2, k_max=64)
-    other = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
-    r2 = prop2.rwalk_queue(live_u, live_v, ll, K, axes, ctr, ainv, 1.0, lstar, walks, 4242, other)
-    assert r2 == (nq, acc, calls, redrawn, idle)
-    assert np.array_equal(other[0][:nq], qU) and np.array_equal(other[1][:nq], qV) and np.array_equal(other[2][:nq], ql) and np.array_equal(other[3][:nq], qnc)
-    prop2.close()
 
 
 @pytest.mark.parametrize("photscale", [False, True])

@@ -16,11 +16,10 @@ F_FWHM_R = 1
 SMOOTH_VEL_DIRECT, SMOOTH_WAVE_DIRECT, SMOOTH_LSF_DIRECT, SMOOTH_WAVE_FFT, SMOOTH_INTERP = range(5)
 ABI_VERSION = 2
 E_INVALID, E_UNSUPPORTED, E_HIP, E_BATCH, E_SIGMA = -1, -2, -3, -4, -5
-V_OUT_GENERIC, V_POST_GENERIC, V_TW_GLOBAL, V_POST_FULL, V_NO_PREP, V_BIG_PLAIN, V_SELECT_MEDIAN, V_LSF_GLOBAL, V_BIG_FUSED, V_NO_WALK_TAIL, V_OUT_BK64, V_OUT_ROLLED, V_OUT_F32, V_SED_OWN_LAUNCH, V_DENSE_FUSED, V_BIG_WORKSPACE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 32768, 65536
+V_OUT_GENERIC, V_POST_GENERIC, V_TW_GLOBAL, V_POST_FULL, V_NO_PREP, V_SELECT_MEDIAN, V_LSF_GLOBAL, V_NO_WALK_TAIL, V_OUT_BK64, V_OUT_ROLLED, V_OUT_F32, V_SED_OWN_LAUNCH, V_BIG_WORKSPACE = 1, 2, 4, 8, 16, 64, 128, 512, 1024, 2048, 4096, 8192, 65536
 V_OUT_SMALL_TILES = 16384
 V_NO_WALK_SPEC = 131072
 V_ROWS_PIXEL = 262144
-V_QUEUE_MEMCPY = 1048576
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_set_lsf_on", "payne_ctx_destroy", "payne_last_error",
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name", "payne_last_kernel",

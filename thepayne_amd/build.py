@@ -119,7 +119,8 @@ def build_diag(verbose=False):
 
 def build_variant(tag, flags, verbose=False):
     """An experimental twin <variant_dir()>/libpayne_hip_<tag>.so built with extra compiler flags (tools/ only: timing
-    experiments such as -DPAYNE_EXP_SKIP=<phase mask>; never loaded by the product path, never built inside the package)."""
+    experiments, stamped twins such as ['-DPAYNE_STAMPS', '-DPAYNE_STAMPS_ENDS_ONLY']; never loaded by the product path, never built
+    inside the package)."""
     d = variant_dir()
     return _compile_link(os.path.join(d, "libpayne_hip_%s.so" % tag), extra=list(flags), tag="_" + tag, verbose=verbose, objdir=d)
 

@@ -396,17 +396,10 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
     // the diagnostic build, tools/post_stamps.py).  So: fragments of the next step, THEN the request.
     frags((it + 1) % DM_NS, an, bn);
     __builtin_amdgcn_sched_barrier(0);
-#if !(defined(PAYNE_EXP_GEMM) && (PAYNE_EXP_GEMM & 2))
     if (it + AHEAD < nk) issue((it + AHEAD) % DM_NS, (it + AHEAD) * BK);     // into the buffer whose fragments step it-1 consumed
-#endif
     __builtin_amdgcn_sched_barrier(0);
   };
   auto mfma_step = [&](const f32x4_t (&a)[BK / 8], const f32x4_t (&b)[BK / 8]) {
-#if defined(PAYNE_EXP_GEMM) && (PAYNE_EXP_GEMM & 1)
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) asm volatile("" :: "v"(a[kk]), "v"(b[kk]));
-    return;
-#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk].x, b[kk].x, acc, 0, 0, 0);
@@ -480,9 +473,6 @@ __global__ void __launch_bounds__(128 * WN) payne_dense_dma_kernel(DenseParams p
 // waves 0-3 move five, waves 4-7 four); 16-byte chunk c of tile row r sits at chunk c ^ ((r >> 2) & 3): the sixteen lanes of a
 // fragment read cover sixteen different bank groups.
 // ----------------------------------------------------------------------------
-#ifndef PAYNE_EXP_NT
-#define PAYNE_EXP_NT 0               // (timing experiments: 1 the output layer's stores ordinary, 2 the post kernel's row loads ordinary)
-#endif
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -657,11 +647,7 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#if PAYNE_EXP_NT & 1   /* timing experiment: ordinary stores */
-        if (row < p.B) p.Y[(size_t)row * p.ldy + col] = acc[r] + bv;
-#else
         if (row < p.B) __builtin_nontemporal_store(acc[r] + bv, &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
-#endif
       }
     } else {
 #pragma unroll
@@ -690,9 +676,6 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
 // (two lanes per row), 36 pieces: waves 0-3 move five, waves 4-7 four; the two 16-byte chunks of tile row r are swapped where
 // bit 4 of r is set: the sixteen lanes a ds_read_b128 serves together then cover sixteen different bank groups.
 // ----------------------------------------------------------------------------
-#ifndef PAYNE_EXP_B3
-#define PAYNE_EXP_B3 0              // (timing experiments, results WRONG by design: 1 no matrix instructions, 2 no requests after the first, 4 no stores)
-#endif
 constexpr int B3_TM = 128, B3_TN = 256, B3_NS = 4;
 constexpr int B3_A_PLANE = B3_TM * 32, B3_B_PLANE = B3_TN * 32;            // bytes per plane and stage
 constexpr int B3_STAGE = 3 * (B3_A_PLANE + B3_B_PLANE);
@@ -836,9 +819,7 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
       Frag f;
       frags(s & (B3_NS - 1), f);
       __builtin_amdgcn_sched_barrier(0);
-#if !(PAYNE_EXP_B3 & 2)
       request_next();                                      // into the buffer the step before consumed
-#endif
       if (it == 0) {                                       // the epilogue's bias (younger than the request: long landed by then)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -847,11 +828,7 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-#if !(PAYNE_EXP_B3 & 1)
       products(f);
-#else
-      asm volatile("" :: "v"(f.a[0][0]), "v"(f.b[1][2]), "v"(f.a[1][1]), "v"(f.b[0][0]));
-#endif
     }
     // C/D map of a 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -865,7 +842,7 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
           // (unconditional: the launch guarantees whole tiles -- B % 128 == 0, N % 256 == 0 --, so every wave issues exactly 64
           //  stores here, which is what the vmcnt(63) above counts on)
           const float v = acc[i][j][r] + bv[j];
-          if (!(PAYNE_EXP_B3 & 4) || v == 1.2345e30f) __builtin_nontemporal_store(act_none ? v : act_apply(v, p.act), &p.Y[(size_t)row * p.ldy + col]);
+          __builtin_nontemporal_store(act_none ? v : act_apply(v, p.act), &p.Y[(size_t)row * p.ldy + col]);
         }
       }
     since_stores = 0;
@@ -880,9 +857,6 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
 // 2x2 tiles each) and their partial tiles are summed through LDS.  With FUSE_L0 the A tile is
 // produced in place from theta (label encoding + first layer + activation).
 // ----------------------------------------------------------------------------
-#ifndef PAYNE_EXP_HK
-#define PAYNE_EXP_HK 0                // (timing experiments: 1 no first layer, 2 no matrix phase, 4 no weight-tile loads)
-#endif
 constexpr int HK_KC = 304;          // K chunk (a multiple of 16; with the pitch below two workgroups' tiles are 79.9 KB: two fit a CU)
 constexpr int HK_PITCH = 312;       // 8*odd floats: conflict-free ds_read_b128 for the 16-row x 4-offset lane map
 constexpr size_t HK_LDS_BYTES = (size_t)(2 * 32 * HK_PITCH + 32 * PAYNE_MAX_LABELS) * sizeof(float);
@@ -993,7 +967,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
       const int rr = (it / NKI) * 8 + (tid >> 5), k4 = (tid & 31) + 32 * (it % NKI);
       const int kcl = (4 * k4 < kn) ? kc + 4 * k4 : kc + kn - 4;
       const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
-      vb[it] = (PAYNE_EXP_HK & 4) ? z4 : *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * p.K + kcl);
+      vb[it] = *reinterpret_cast<const f32x4_t*>(p.W + (size_t)nr * p.K + kcl);
       if (!FUSE_L0) {
         const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1;
         va[it] = *reinterpret_cast<const f32x4_t*>(p.X + (size_t)mr * p.ldx + kcl);
@@ -1026,7 +1000,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
 #pragma unroll
         for (int tt = 0; tt < MAXT; ++tt) {
           const int tcol = wave + 4 * tt;
-          if (tcol < ntile && !(PAYNE_EXP_HK & 1)) {             // (wave-uniform)
+          if (tcol < ntile) {             // (wave-uniform)
             const bool live = (kc + 16 * tcol + r) < p.K0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1058,7 +1032,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
     __syncthreads();
     HK_STAMP(3);
     // ---- the four waves split the K steps of this chunk -------------------------------------
-    const int steps = (PAYNE_EXP_HK & 2) ? 0 : (kn16 >> 4);
+    const int steps = kn16 >> 4;
     for (int s = wave; s < steps; s += 4) {
       const int k = s * 16 + 4 * g;
       f32x4_t a[2], b[2];
@@ -1160,214 +1134,6 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
 }
 
 
-// ----------------------------------------------------------------------------
-// Hidden layers AND output layer in ONE launch (payne_opts.variant PAYNE_V_DENSE_FUSED; 3-layer nets of equal hidden width
-// <= 320, at most one output tile per compute unit: C2).  The grid is the output layer's (64 x 128 tiles, 512 threads, the
-// four-stage LDS-DMA ring of payne_dense_dma3_kernel); what the hidden-layer launch did is taken on by the same workgroups
-// first, by TICKET (an atomic counter read at entry: roles go to workgroups in the order they actually start, so a role's
-// owner is running by construction -- no assumption on dispatch order or placement, and a workgroup that starts late only
-// ever waits for work of workgroups that started before it):
-//   tickets 0 .. n_hid-1      one 32 x 32 tile of the last hidden layer each (hk_tile, bf16 planes stored write-through),
-//                             then an agent-scope add to the counter of the 64-row block the tile belongs to;
-//   the next n_prep tickets   the post kernel's per-candidate records (read by the NEXT launch: no hand-off);
-//   every workgroup           requests the first stage of its weight operand at entry (it depends on nothing), then its role,
-//                             then polls its row block's counter (one lane, bounded spin), agent-scope acquire, barrier, and
-//                             runs the output tile exactly as payne_dense_dma3_kernel<10, 4, true> does, the activation
-//                             planes arriving through LDS-DMA with the sc1 bit.
-// Counters are never reset: the host keeps their running totals (64-bit) and hands every launch its base and targets.
-// ----------------------------------------------------------------------------
-struct FuseSync {
-  unsigned long long* ticket;        // one counter
-  unsigned long long* done;          // [grid_m of the output layer] hidden tiles published per 64-row block
-  unsigned long long ticket_base;    // tickets handed out by every launch before this one
-  unsigned long long done_target[64];// per 64-row block: tiles published by every launch before this one + this launch's
-  int n_hid, n_prep;
-  int* timeout;                      // set to 1 by a workgroup whose spin ran out (diagnostic; results are then garbage)
-};
-constexpr int kFuseSpinMax = 1 << 21;
-template <int NL>
-__global__ void __launch_bounds__(512) payne_dense_fused_kernel(DenseParams ph, const PrepArgs pa, DenseParams p, const FuseSync fs) {
-  constexpr int NK = 10, D3_NS = 4, AHEAD = 3;
-  extern __shared__ __attribute__((aligned(16))) unsigned char d3_sm[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned long long* tkslot = reinterpret_cast<unsigned long long*>(d3_sm + (size_t)D3_NS * D3_STAGE - 16);
-  HK_STAMP(0);
-  if (tid == 0) *tkslot = __hip_atomic_fetch_add(fs.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fs.ticket_base;
-  // ---- the output tile's addresses (as payne_dense_dma3_kernel)
-  const int ntiles = p.grid_m * p.grid_n;
-  int t = blockIdx.x;
-  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order
-  const int mt = t % p.grid_m;
-  const int m0 = mt * 64, n0 = (t / p.grid_m) * 128;
-  const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
-  const bool five = wave < 4;
-  const unsigned char* src[5];
-  int dst[5];
-  bool isa[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    int q = five ? wave * 5 + j : 20 + (wave - 4) * 4 + j;
-    if (q > 35) q = 35;
-    const bool isA = q < 12;
-    isa[j] = isA;
-    const int pl = isA ? q >> 2 : (q - 12) >> 3, blk = isA ? (q & 3) : ((q - 12) & 7);
-    const int row = 16 * blk + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
-    if (isA) {
-      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
-      src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)pl * p.plane_x + (size_t)r * p.ldp) + 16 * c;
-      dst[j] = pl * 4096 + blk * 1024;
-    } else {
-      const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
-      src[j] = reinterpret_cast<const unsigned char*>(p.Wp + (size_t)pl * p.plane_w + (size_t)r * p.K) + 16 * c;
-      dst[j] = 3 * 4096 + pl * 8192 + blk * 1024;
-    }
-  }
-  // which: 0 every piece, 1 the weight pieces only, 2 the activation pieces only (sc1: written by other workgroups of this launch)
-  auto issue = [&](int stage, int k0, int which) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (j < 4 || five) {
-        if (isa[j]) {
-          if (which != 1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
-                                             (__attribute__((address_space(3))) void*)(d3_sm + stage * D3_STAGE + dst[j]), 16, 0, 16);
-        } else if (which != 2) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
-                                           (__attribute__((address_space(3))) void*)(d3_sm + stage * D3_STAGE + dst[j]), 16, 0, 0);
-        }
-      }
-  };
-  issue(0, 0, 1);                                            // stage 0's weight pieces: in flight under everything below
-  const int col = n0 + wn0 + (lane & 31);
-  const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
-  __syncthreads();
-  const long long tk = (long long)*tkslot;
-  HK_STAMP(1);
-  // ---- this workgroup's share of what the hidden-layer launch did (LDS: behind stage 0)
-  float* hk_sm = reinterpret_cast<float*>(d3_sm + D3_STAGE);
-  if (tk >= 0 && tk < fs.n_hid) {
-    hk_tile<true, NL, true>(ph, (int)tk, hk_sm, tid);
-    HK_STAMP(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through stores are out
-    __syncthreads();
-    HK_STAMP(3);
-    if (tid == 0) {
-      const int rb = ((int)tk / ph.grid_n) >> 1;              // 32-row tile -> 64-row block
-      __hip_atomic_fetch_add(fs.done + rb, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else if (tk >= fs.n_hid && tk < fs.n_hid + fs.n_prep) {
-    const int cand = ((int)tk - fs.n_hid) * 512 + tid;
-    if (pa.out && cand < ph.B) prep_candidate(pa.T, ph.theta + (size_t)cand * ph.ld_theta, pa.instr_factor, pa.out[cand]);
-  }
-  // ---- wait for this tile's 64 rows of activations
-  // (a spin that runs out must not pass silently: the tile would be computed from activations nobody published.  The whole
-  //  tile is then written as NaN -- every likelihood of these 64 candidates comes back NaN -- and the flag is set for the host)
-  __shared__ int fuse_timed_out;
-  if (tid == 0) {
-    int spins = 0, expired = 0;
-    const unsigned long long want = fs.done_target[mt];
-    while (__hip_atomic_load(fs.done + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > kFuseSpinMax) { *fs.timeout = 1; expired = 1; break; }
-    }
-    fuse_timed_out = expired;
-    HK_STAMP(4);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  const float poison = fuse_timed_out ? __builtin_nanf("") : 0.f;
-  HK_STAMP(5);
-  // ---- the output tile (payne_dense_dma3_kernel<10, 4, true> from here on)
-  auto wait_landed = [&](int younger) {
-    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (five) { if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-    else { if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-  };
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
-  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
-  struct Frag { bf16x8_t a[2][3], b[2][3]; };
-  auto frags = [&](int stage, Frag& f) {
-    const unsigned char* As = d3_sm + stage * D3_STAGE;
-    const unsigned char* Bs = As + 3 * 4096;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = 2 * ks + h;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        f.a[ks][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
-        f.b[ks][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * 8192 + Rb * 64 + 16 * (c ^ sb));
-      }
-    }
-  };
-  auto products = [&](const Frag& f, int ks) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
-  };
-  constexpr int nk = NK;
-  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
-  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;
-  issue(0, 0, 2);                                            // stage 0's activation pieces, then stages 1 and 2 whole
-#pragma unroll
-  for (int q = 1; q < AHEAD; ++q) issue(q, q * 32, 0);
-  wait_landed(AHEAD - 1);
-  asm volatile("s_barrier" ::: "memory");
-  HK_STAMP(6);
-  Frag f0, f1;
-  frags(0, f0);
-  auto head = [&](int it, Frag& fn, const Frag& fc) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(fc.a[ks][pl]), "v"(fc.b[ks][pl]));
-    {
-      const int last = (it + AHEAD < nk ? it + AHEAD : nk) - 1;
-      wait_landed(last - (it + 1));
-    }
-    asm volatile("s_barrier" ::: "memory");
-    frags((it + 1) % D3_NS, fn);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + AHEAD < nk) issue((it + AHEAD) % D3_NS, (it + AHEAD) * 32, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  int it = 0;
-#pragma unroll
-  for (; it + 2 < nk; it += 2) {
-    head(it, f1, f0);
-    products(f0, 0); products(f0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    head(it + 1, f0, f1);
-    products(f1, 0); products(f1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (it + 1 < nk) {
-    head(it, f1, f0);
-    products(f0, 0); products(f0, 1);
-    products(f1, 0);
-    if (last_both) products(f1, 1);
-  } else {
-    products(f0, 0);
-    if (last_both) products(f0, 1);
-  }
-  HK_STAMP(7);
-  if (col < p.N) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act) + poison, &p.Y[(size_t)row * p.ldy + col]);
-    }
-  }
-  HK_STAMP(15);
-}
 
 // The instantiations that exist (compiled in k_dense.hip; `extern template` elsewhere).
 #ifdef PAYNE_TU_DENSE
@@ -1388,4 +1154,3 @@ PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(DenseParams, const PrepArgs);
-PAYNE_DENSE_T __global__ void payne_dense_fused_kernel<4>(DenseParams, const PrepArgs, DenseParams, const FuseSync);

@@ -116,8 +116,6 @@ struct payne_ctx {
   int lsf_chunk = 0;                    // candidates per launch (the global form walks the batch in chunks: bounded workspace)
   std::vector<void*> lsf_owned;
   bool obs_bound = false;
-  unsigned long long* fuse_cnt = nullptr;   // PAYNE_V_DENSE_FUSED: [0] ticket, [8 .. 8 + 64) hidden tiles published per 64-row block; [80] (as int) timeout flag
-  unsigned long long fuse_tickets = 0, fuse_done[64] = {0};   // running totals of those counters (host side)
   CandState* prep = nullptr;      // [b_max] per-candidate records of the post kernel (written by the first dense launch)
   bool prep_valid = false;        // ... as of the last run_ann
   // photometry
@@ -368,20 +366,19 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     }
     if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
-    if ((opts->variant & PAYNE_V_DENSE_FUSED) && (rc = dev_alloc(c, (size_t)96, &c->fuse_cnt, c->owned))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
       // 32 768-point spectra on a geometric grid: the on-chip stages for two candidates at a time (four buffers per workgroup)
-      c->big_chip2 = T.n1 == kChip2N1 && c->H.geo && !(opts->variant & (PAYNE_V_BIG_PLAIN | PAYNE_V_BIG_FUSED | PAYNE_V_BIG_WORKSPACE));
+      c->big_chip2 = T.n1 == kChip2N1 && c->H.geo && !(opts->variant & PAYNE_V_BIG_WORKSPACE);
       if ((rc = dev_alloc(c, (size_t)c->big_grid * (c->big_chip2 ? 4 : 2) * T.n1, &c->big_ws, c->owned, false))) return bail(rc);
       if (c->big_chip2) {
         he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_chip2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kChipLdsBytes);
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipFuncSetAttribute(chip2): ") + hipGetErrorString(he)));
       }
-      c->big_tiled = !(opts->variant & PAYNE_V_BIG_PLAIN);
+      c->big_tiled = true;                 // the four-step transform where the length allows it (fft_tiled_ok); plain radix-8 passes otherwise
       // 65 536-point spectra on a geometric grid: the convolution stages stay on the compute unit (payne_post_chip_kernel)
-      c->big_chip = T.n1 == kChipN1 && c->H.geo && !(opts->variant & (PAYNE_V_BIG_PLAIN | PAYNE_V_BIG_FUSED | PAYNE_V_BIG_WORKSPACE));
+      c->big_chip = T.n1 == kChipN1 && c->H.geo && !(opts->variant & PAYNE_V_BIG_WORKSPACE);
       if (c->big_chip) {
         he = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_post_chip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kChipLdsBytes);
@@ -639,7 +636,6 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
-  set(reinterpret_cast<const void*>(payne_dense_fused_kernel<4>), d3_lds_bytes<4>());
   return e;
 }
 
@@ -709,9 +705,6 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool fr
   if ((int)grid.x > c->n_cu) PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 2, false>), grid, block, d3_lds_bytes<2>(), s, p);   // many tiles per CU
   else if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) {
     PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
-#ifdef PAYNE_EXP_OUT2X   /* timing experiment: the same launch again, its operands now wherever the first one left them */
-    hipLaunchKernelGGL((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
-#endif
   }
   else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
 }
@@ -743,9 +736,6 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
   else if (p.n_labels <= 4) {
     PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
-#ifdef PAYNE_EXP_HID2X   /* timing experiment: the same launch again (tools/exp/out2x.sh) */
-    hipLaunchKernelGGL((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
-#endif
   }
   else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
 }
@@ -761,51 +751,6 @@ struct NetRef {
 // `sed`: a joint likelihood's photometric nets ride in the first hidden-layer launch (sed_tile); *sed is cleared when they did.
 static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, double instr_factor, hipStream_t s, bool* sed = nullptr) {
   const int n = N.n_layers;
-  // PAYNE_V_DENSE_FUSED: the hidden layers and the output layer of a 3-layer net in ONE launch (payne_dense_fused_kernel)
-  if (N.spectral && n == 3 && c->fuse_cnt && out_dma3_ok(c, B, N.layers[2].n_out) && c->w_out_kp == 320 && N.layers[1].n_in <= HK_KC &&
-      N.n_labels <= 4 && (B % 64) == 0 && !(sed && *sed && sed_tile_ok(c->P.H) && !(c->opts.variant & PAYNE_V_SED_OWN_LAUNCH))) {
-    const payne_layer &L0 = N.layers[0], &L1 = N.layers[1], &L2 = N.layers[2];
-    DenseParams ph{}, po{};
-    ph.W = L1.w; ph.K = L1.n_in; ph.bias = L1.b; ph.N = L1.n_out; ph.B = B; ph.act = L1.act; ph.bias_shift = 0.f;
-    ph.Y = N.hid[0]; ph.ldy = N.ld_hid;
-    ph.Yp = c->hid_p3; ph.plane_y = (size_t)c->opts.b_max * c->ld_hid; ph.ldp = c->ld_hid;
-    ph.theta = theta; ph.ld_theta = c->ncols;
-    ph.W0 = L0.w; ph.b0 = L0.b; ph.n_labels = N.n_labels; ph.act0 = L0.act; ph.K0 = L0.n_out;
-    for (int d = 0; d < N.n_labels; ++d) { ph.xmin[d] = N.xmin[d]; ph.xden[d] = N.xden[d]; }
-    ph.grid_m = (B + 31) / 32; ph.grid_n = (ph.N + 31) / 32;
-    po.K = L2.n_in; po.bias = L2.b; po.N = L2.n_out; po.B = B; po.act = L2.act; po.bias_shift = N.out_shift;
-    po.Y = N.out; po.ldy = N.ld_out;
-    po.k_real = po.K; po.K = c->w_out_kp;
-    po.Wp = N.freq ? c->w_out_p3z : c->w_out_p3; po.plane_w = (size_t)po.N * c->w_out_kp;
-    if (N.freq) { po.bias = c->bias_z; po.bias_shift = 0.f; }
-    po.Xp = c->hid_p3; po.plane_x = (size_t)c->opts.b_max * c->ld_hid; po.ldp = c->ld_hid;
-    po.grid_m = (B + 63) / 64; po.grid_n = (po.N + 127) / 128;
-    const int grid = po.grid_m * po.grid_n;
-    if (grid <= c->n_cu && po.grid_m <= 64) {
-      PrepArgs pa{};
-      pa.T = c->T; pa.instr_factor = instr_factor;
-      pa.out = (c->prep && c->obs_bound && !(c->opts.variant & PAYNE_V_NO_PREP)) ? c->prep : nullptr;
-      FuseSync fs{};
-      fs.ticket = c->fuse_cnt; fs.done = c->fuse_cnt + 8;
-      fs.ticket_base = c->fuse_tickets;
-      for (int rb = 0; rb < 64; ++rb) fs.done_target[rb] = c->fuse_done[rb] + (rb < po.grid_m ? (unsigned long long)(2 * ph.grid_n) : 0ull);
-      fs.n_hid = ph.grid_m * ph.grid_n; fs.n_prep = pa.out ? (B + 511) / 512 : 0;
-      fs.timeout = reinterpret_cast<int*>(c->fuse_cnt + 80);
-      if (fs.n_hid + fs.n_prep <= grid) {
-        c->fuse_tickets += (unsigned long long)grid;
-        for (int rb = 0; rb < po.grid_m; ++rb) c->fuse_done[rb] += (unsigned long long)(2 * ph.grid_n);
-#ifdef PAYNE_STAMPS
-        po.stamps = g_dense_stamps; ph.stamps = nullptr;
-#endif
-        ProfScope ps(c, s, 0);
-        PAYNE_LAUNCH((payne_dense_fused_kernel<4>), dim3(grid), dim3(512), d3_lds_bytes<4>(), s, ph, pa, po, fs);
-        c->prep_valid = pa.out != nullptr;
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("fused dense launch: ") + hipGetErrorString(e));
-        return PAYNE_OK;
-      }
-    }
-  }
   for (int l = 1; l < n; ++l) {
     DenseParams p{};
     const payne_layer& L = N.layers[l];
@@ -1003,7 +948,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
       PAYNE_LAUNCH(payne_post_chip2_kernel, dim3(grid), dim3(kChipThreads), kChipLdsBytes, s, c->T, a, c->big_ws, B);
     } else if (c->big_ws) {
       const int grid = B < c->big_grid ? B : c->big_grid;
-      const int tiled = (c->big_tiled ? 1 : 0) | ((c->opts.variant & PAYNE_V_BIG_FUSED) ? 2 : 0);
+      const int tiled = c->big_tiled ? 1 : 0;
       const size_t lds = (tiled & 1) ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
       PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
@@ -1158,7 +1103,7 @@ struct payne_sampler {
   // the queue's transfers as KERNELS on mapped host memory (q_host_dev: the device's address of q_host) and its completion as a word
   // the last of them writes into it (q_flag, behind the staging block; q_seq: the value the queue in flight will write) -- the
   // host reads that word instead of synchronising the stream: hipMemcpyAsync's own enqueue (17 us) and the wake-up out of
-  // hipStreamSynchronize were most of the GPU's idle time between two queues (NOTES R4.16).  Null: PAYNE_V_QUEUE_MEMCPY.
+  // hipStreamSynchronize were most of the GPU's idle time between two queues (NOTES R4.16).  Null: the block has no device address.
   double* q_host_dev = nullptr; volatile unsigned long long* q_flag = nullptr; unsigned long long* q_flag_dev = nullptr; unsigned long long q_seq = 0;
   unsigned* q_arrivals = nullptr;         // device word: workgroups of the results' transfer that have finished (wraps to zero)
   // The queue's TURN on the device (payne_ns_queue_dev_*): the live set lives there (two copies, written in turn), the turn kernel
@@ -1275,7 +1220,7 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     payne_sampler_destroy(s);
     return fail(c, PAYNE_E_HIP, "hipHostMalloc(sampler staging)");
   }
-  if (!(c->opts.variant & PAYNE_V_QUEUE_MEMCPY)) {
+  {                                                          // (no device address for the block: hipMemcpyAsync + hipStreamSynchronize)
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, s->q_host, 0) == hipSuccess && dp) {
       s->q_host_dev = static_cast<double*>(dp);
@@ -1724,7 +1669,7 @@ extern "C" int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, c
   if (!s) return PAYNE_E_INVALID;
   payne_ctx* c = s->ctx;
   if (!live_u || !live_v || !live_logl || nlive <= 0) return fail(c, PAYNE_E_INVALID, "bad payne_ns_queue_dev_init arguments");
-  if (!s->q_host_dev) return fail(c, PAYNE_E_UNSUPPORTED, "the device-side turn needs the mapped staging block (not PAYNE_V_QUEUE_MEMCPY)");
+  if (!s->q_host_dev) return fail(c, PAYNE_E_UNSUPPORTED, "the device-side turn needs the mapped staging block");
   if (s->dq_launched != s->dq_collected) return fail(c, PAYNE_E_INVALID, "payne_ns_queue_dev_init with queues in flight");
   const int nd = s->sd.ndim, K = s->k_max;
   if (nlive + K > 2048) return fail(c, PAYNE_E_UNSUPPORTED, "nlive + queue size > 2048");

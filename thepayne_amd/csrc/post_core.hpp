@@ -1027,95 +1027,6 @@ PAYNE_HD void slots_commit(int tid, int nthr, int M, SlotRegs<SU>& R, YP Y, cons
 }
 
 // ---------------------------------------------------------------------------
-// Four-step transform whose FIRST pass applies the middle step above on the way in: the inverse transform of a
-// convolution reads the forward transform's output Z and needs Y (see rfft_taper_phase) -- a separate pass over the
-// spectrum costs one read and one write of it through the global workspace, here the pair (k, M - k) is combined in
-// registers while it is being loaded.  With k = c + B m the partner sits in column B - c at m' = 511 - m, so a tile
-// holds 8 columns c = 8t + 1 .. 8t + 8 (tile columns 0..7) and their mirrors B - c (tile columns 8..15), and one thread
-// owns butterfly i of column c together with butterfly 63 - i of column B - c: its sixteen loads are eight pairs.
-// Columns 0 and B/2 pair with themselves: a last tile takes them element by element (fft4_s1_special).
-// ---------------------------------------------------------------------------
-constexpr int kTilePairs = kTileC / 2;
-struct ColPairs {                      // column map of pair tile t
-  int t, B;
-  PAYNE_HD int operator()(int cc) const {
-    const int c = kTilePairs * t + 1 + (cc % kTilePairs);
-    return c >= B / 2 ? -1 : (cc < kTilePairs ? c : B - c);
-  }
-};
-struct ColSelf { int B; PAYNE_HD int operator()(int cc) const { return cc == 0 ? 0 : (cc == 1 ? B / 2 : -1); } };
-PAYNE_HD int fft4_pair_tiles(int B) { return (B / 2 - 1 + kTilePairs - 1) / kTilePairs; }
-
-template <bool VSINI, class GP, class LP, class TP>
-PAYNE_HD void fft4_s1_load_tapered(int tid, int nthr, GP src, LP X, int B, int t, TP tw, int tw_step, const TaperArgs& ta, int M) {
-  const float g = 0.25f / (float)M;
-  for (int idx = tid; idx < kTilePairs * 64; idx += nthr) {
-    const int p = idx % kTilePairs, i = idx / kTilePairs, c = kTilePairs * t + 1 + p;
-    if (c >= B / 2) continue;
-    const int c2 = B - c, i2 = 63 - i;
-    c32 u[8], v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      u[r] = q_ld(src, (size_t)c + (size_t)B * (i + 64 * r));
-      v[r] = q_ld(src, (size_t)c2 + (size_t)B * (i2 + 64 * r));
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {                         // u[r] is bin k, v[7 - r] is bin M - k
-      const int k = c + B * (i + 64 * r);
-      const float tk = taper_full<VSINI>(ta, k), tm = taper_full<VSINI>(ta, M - k);
-      const c32 w = q_ld(tw, (size_t)k * tw_step);
-      c32 yk, ym;
-      taper_pair(u[r], v[7 - r], w, tk * g, tm * g, yk, ym);
-      u[r] = yk; v[7 - r] = ym;
-    }
-    dft8(u);
-    dft8(v);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      q_st(X, (size_t)p * kTileLd + 8 * i + r, u[r]);
-      q_st(X, (size_t)(kTilePairs + p) * kTileLd + 8 * i2 + r, v[r]);
-    }
-  }
-}
-// columns 0 and B/2, one element per work item: Y (plain layout [slot][m]) = middle step of Z
-template <bool VSINI, class GP, class LP, class TP>
-PAYNE_HD void fft4_s1_special(int tid, int nthr, GP src, LP P, int B, TP tw, int tw_step, const TaperArgs& ta, int M) {
-  const float invM = 1.0f / (float)M, g = 0.25f * invM;
-  for (int idx = tid; idx < 2 * kTileA; idx += nthr) {
-    const int slot = idx / kTileA, m = idx - slot * kTileA;
-    const int j = (slot ? B / 2 : 0) + B * m;
-    c32 y;
-    if (j == 0) {                                        // real bins X[0] and X[M] (rfft_taper_phase)
-      const c32 z0 = q_ld(src, 0);
-      const float x0 = z0.x + z0.y, xm = taper_full<VSINI>(ta, M) * (z0.x - z0.y);
-      y = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
-    } else if (2 * j == M) {                             // the self-conjugate bin
-      y = cscale(cconj(q_ld(src, (size_t)j)), taper_full<VSINI>(ta, j) * invM);
-    } else {
-      const int k = j < M - j ? j : M - j;
-      const c32 zk = q_ld(src, (size_t)k), zmk = q_ld(src, (size_t)(M - k));
-      c32 yk, ym;
-      taper_pair(zk, zmk, q_ld(tw, (size_t)k * tw_step), taper_full<VSINI>(ta, k) * g, taper_full<VSINI>(ta, M - k) * g, yk, ym);
-      y = (j == k) ? yk : ym;
-    }
-    q_st(P, (size_t)slot * kTileLd + m, y);
-  }
-}
-// ... and the first radix-8 pass of those two columns, LDS -> LDS (what fft4_s1_load does on the way in)
-template <class LP>
-PAYNE_HD void fft4_s1_first_lds(int tid, int nthr, LP P, LP Q, int ncols) {
-  for (int idx = tid; idx < ncols * 64; idx += nthr) {
-    const int cc = idx >> 6, i = idx & 63;
-    c32 u[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = q_ld(P, (size_t)cc * kTileLd + i + 64 * r);
-    dft8(u);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q_st(Q, (size_t)cc * kTileLd + 8 * i + r, u[r]);
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Grid positions.
 // ---------------------------------------------------------------------------
 // k in [lo, hi-2] with x[k] <= v < x[k+1] (clamped at the ends), from a guess.
@@ -1398,7 +1309,7 @@ PAYNE_HD void phase_load_issue(int tid, int nthr, int npix, const float* __restr
 #pragma unroll
   for (int q = 0; q < U; ++q) {                      // clamped index: unconditional loads
     const int i0 = tid + q * nthr, i = i0 < n4 ? i0 : n4 - 1;
-#if defined(__HIP_DEVICE_COMPILE__) && !(defined(PAYNE_EXP_NT) && (PAYNE_EXP_NT & 2))
+#ifdef __HIP_DEVICE_COMPILE__
     // read once, produced by other XCDs: streaming loads (no L2 allocation)
     R.v[q][0] = __builtin_nontemporal_load(&raw[4 * i]); R.v[q][1] = __builtin_nontemporal_load(&raw[4 * i + 1]);
     R.v[q][2] = __builtin_nontemporal_load(&raw[4 * i + 2]); R.v[q][3] = __builtin_nontemporal_load(&raw[4 * i + 3]);
@@ -1652,11 +1563,7 @@ PAYNE_HD float obs_loop(int tid, int nthr, const PostTables& T, const CandState&
 #pragma unroll
     for (int q = 0; q < OU; ++q) {                       // clamped index: every load unconditional
       const int i0 = base + q * nthr, i = i0 < T.nobs ? i0 : T.nobs - 1;
-#if defined(PAYNE_EXP_OBS8)   /* timing experiment (WRONG results): 8 bytes per pixel instead of 16 -- the phase is bound by these bytes */
-      ObsRec rec; rec.lnw = T.lnobs[i]; rec.f1 = 0.5f; rec.ivar = 1e4f;
-#else
       const ObsRec rec = T.obs_rec[i];                   // one 16-byte load
-#endif
       const double lo = rec.lnw;
       if (HASF) { of1[q] = rec.f1; iv[q] = rec.ivar; }
       if (CHEB) xc[q] = T.xcheb[i];

@@ -73,9 +73,6 @@ struct DevExecT {
   // LDS tile of the four-step transform (2 x fft_tile_complex()); null: runtime-geometry passes
   c32* tile_ = nullptr;
   __device__ __forceinline__ c32* tile() const { return tile_; }
-  // the four-step transform reads the raw row itself and applies the taper while loading (fft_run_tiled_x)
-  bool fuse_ = false;
-  __device__ __forceinline__ bool fuse() const { return fuse_; }
 };
 
 __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs, const double* err, int F) {
@@ -86,17 +83,14 @@ __device__ __forceinline__ double sed_chi2(const double* mags, const double* obs
 
 // (a call, not inlined: the walk's registers must not count against the per-pixel phases' budget of 128 -- two
 // workgroups per CU -- and pinning the kernel to that budget by attribute costs the FFT passes 2.5 us of scheduling freedom)
-#ifndef PAYNE_EXP_TAIL_ATTR
-#define PAYNE_EXP_TAIL_ATTR __attribute__((noinline))
-#endif
-__device__ PAYNE_EXP_TAIL_ATTR static void walk_tail(const WalkTail* t, int b, int lane, double lnl, int step, int propose) {
+__device__ __attribute__((noinline)) static void walk_tail(const WalkTail* t, int b, int lane, double lnl, int step, int propose) {
   const WalkState W = uniform_copy(&t->w);
   rwalk_step_wave(t->sd, W, b, lane, lnl, step, 1, propose);
 }
 
 // (the walk stays behind the pointer here: by value in PostArgs it was 150 more bytes of kernel arguments whose scalar loads the
 // compiler hoists to the kernel's start -- 93 spilled scalar registers against 52 --, and handed to a call by reference a stack copy)
-__device__ PAYNE_EXP_TAIL_ATTR static void walk_tail_spec(const WalkTail* t, int b, int lane, double lnl) {
+__device__ __attribute__((noinline)) static void walk_tail_spec(const WalkTail* t, int b, int lane, double lnl) {
   const WalkState W = uniform_copy(&t->w);
   rwalk_settle_spec(W, b, lane, lnl);
 }
@@ -244,7 +238,6 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
   float* bufB = bufA + T.n1;
   DevExecT<false, false> ex;
   if (tile_lds & 1) ex.tile_ = reinterpret_cast<c32*>(big_sm);
-  ex.fuse_ = (tile_lds & 2) != 0;
   double* chi2 = red + scratch_doubles(kBigThreads) - 1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
 #ifdef PAYNE_STAMPS

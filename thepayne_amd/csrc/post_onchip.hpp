@@ -31,12 +31,6 @@ constexpr int kChipXch = 16 * 1024;                // complex slots of an exchan
 constexpr size_t kChipLdsBytes = 256 + (size_t)kChipXch * 8 + 1024 * 8 + 64 * 8;   // (alignment) | exchange buffer | W_1024 | W_65536 (fine)
 }
 #ifdef __HIP_DEVICE_COMPILE__
-// Timing experiments (tools/exp/chip_ablate.py builds twins with -DPAYNE_EXP_CHIP=<mask>; results are WRONG by design):
-// 1 radix-32 register transforms | 2 twiddles between the stages | 4 exchanges through LDS (and their barriers) | 8 the taper's pair arithmetic
-#ifndef PAYNE_EXP_CHIP
-#define PAYNE_EXP_CHIP 0
-#endif
-
 namespace payne {
 
 struct ChipLds {             // (LDS address space in the pointer types: ds_read / ds_write, not flat accesses)
@@ -109,7 +103,6 @@ __device__ __forceinline__ void chip_tw32(c32 (&u)[32]) {             // positio
 // (scheduling fences between the pieces: half of a thread's registers hold the data; left alone the scheduler pulls every table
 //  read of a stage forward and spills hundreds of registers)
 __device__ __forceinline__ void chip_dft32_A(c32 (&u)[32]) {          // natural -> permuted
-  if (PAYNE_EXP_CHIP & 1) return;
 #pragma unroll
   for (int a2 = 0; a2 < 8; ++a2) { dft4(u[a2], u[a2 + 8], u[a2 + 16], u[a2 + 24]); if (a2 & 1) __builtin_amdgcn_sched_barrier(0); }
   chip_tw32(u);                                                  // element (a2, k1) at a2 + 8 k1
@@ -118,7 +111,6 @@ __device__ __forceinline__ void chip_dft32_A(c32 (&u)[32]) {          // natural
   for (int k1 = 0; k1 < 4; ++k1) { dft8(&u[8 * k1]); __builtin_amdgcn_sched_barrier(0); }   // -> X[k1 + 4 k2] at 8 k1 + k2
 }
 __device__ __forceinline__ void chip_dft32_B(c32 (&u)[32]) {          // permuted -> natural
-  if (PAYNE_EXP_CHIP & 1) return;
 #pragma unroll
   for (int al = 0; al < 4; ++al) { dft8(&u[8 * al]); __builtin_amdgcn_sched_barrier(0); }    // over ahi -> ka at 8 alo + ka
   chip_tw32(u);                                                  // element (alo, ka) at ka + 8 alo
@@ -210,7 +202,6 @@ __device__ __forceinline__ void chip_xlo(const ChipLds& L, c32 (&u0)[32], c32 (&
 }
 template <bool HI, bool PERM>
 __device__ __forceinline__ void chip_xch(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int vt0) {
-  if (PAYNE_EXP_CHIP & 4) return;
   if constexpr (!HI) { chip_xlo<PERM>(L, u0, u1, vt0); return; }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -240,7 +231,6 @@ __device__ __forceinline__ void chip_mul2x2(c32& a, c32& b, c32 wa, c32 la, c32 
 }
 template <bool PERM>
 __device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_32768^(t k1) = W_65536^(2 t k1)
-  if (PAYNE_EXP_CHIP & 2) return;
   const int vt = chip_fresh(vt_);
 #pragma unroll
   for (int k1 = 1; k1 < 31; k1 += 2) {
@@ -253,7 +243,6 @@ __device__ __forceinline__ void chip_tw1(const ChipLds& L, c32 (&u)[32], int vt_
 }
 template <bool PERM>
 __device__ __forceinline__ void chip_tw2(const ChipLds& L, c32 (&u)[32], int vt_) {     // x W_1024^(l k2a)
-  if (PAYNE_EXP_CHIP & 2) return;
   const int l = chip_fresh(vt_) & 31;
 #pragma unroll
   for (int k = 1; k < 31; k += 2) {
@@ -323,7 +312,7 @@ __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32],
   }
   // the pairs (k, M - k), k = low + 1024 r, r < 16: taper and real-FFT split / merge
 #pragma unroll
-  for (int r = 0; r < ((PAYNE_EXP_CHIP & 8) ? 0 : 16); ++r) {
+  for (int r = 0; r < 16; ++r) {
     const int k0 = P.low + 1024 * r;
     const int k = (k0 == 0) ? 1 : k0;                              // (k = 0 is replaced below; keep its lane's arithmetic ordinary)
     float tk, tm;

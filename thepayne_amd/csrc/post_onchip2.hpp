@@ -54,7 +54,6 @@ __device__ __forceinline__ void chip2_tw16(c32 (&u)[32]) {
 // i.e. with h' = i + 4 j candidate c's value sits at 8 i + 4 c + j.  X[ka + 4 kb] = sum_i W4^(i kb) W16^(i ka) [ sum_j x[i + 4 j] W4^(j ka) ]:
 // DFT_4 over j (four contiguous registers), twiddle, DFT_4 over i (stride 8).  Out: k2a = ka + 4 kb at 8 kb + 4 c + ka.
 __device__ __forceinline__ void chip2_dft16x2_fwd(c32 (&u)[32]) {
-  if (PAYNE_EXP_CHIP & 1) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     dft4(u[8 * i], u[8 * i + 1], u[8 * i + 2], u[8 * i + 3]);
@@ -72,7 +71,6 @@ __device__ __forceinline__ void chip2_dft16x2_fwd(c32 (&u)[32]) {
 // The transposed operator: in k2a = ka + 4 kb at 8 kb + 4 c + ka, out h' = i + 4 j at 8 i + 4 c + j (the PERMUTED layout the HI
 // exchange takes):  y[i + 4 j] = sum_ka W4^(j ka) W16^(i ka) [ sum_kb X[ka + 4 kb] W4^(i kb) ].
 __device__ __forceinline__ void chip2_dft16x2_back(c32 (&u)[32]) {
-  if (PAYNE_EXP_CHIP & 1) return;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     dft4(u[q], u[q + 8], u[q + 16], u[q + 24]);
@@ -102,7 +100,6 @@ __device__ __forceinline__ c32 chip2_w32768(const ChipLds& L, int e) {          
 // x W_16384^(t' k1) = W_32768^(2 t' k1), t' = vt & 511 (registers in the layout PERM)
 template <bool PERM>
 __device__ __forceinline__ void chip2_tw1(const ChipLds& L, c32 (&u)[32], int vt_) {
-  if (PAYNE_EXP_CHIP & 2) return;
   const int t2 = 2 * (chip_fresh(vt_) & 511);
 #pragma unroll
   for (int k1 = 1; k1 < 31; k1 += 2) {
@@ -115,7 +112,6 @@ __device__ __forceinline__ void chip2_tw1(const ChipLds& L, c32 (&u)[32], int vt
 }
 // x W_512^(l k2a) = W_1024^(2 l k2a) on the register at physical position p = (c, k2a)
 __device__ __forceinline__ void chip2_tw2(const ChipLds& L, c32 (&u)[32], int vt_) {
-  if (PAYNE_EXP_CHIP & 2) return;
   const int l2 = 2 * (chip_fresh(vt_) & 31);
 #pragma unroll
   for (int p = 1; p < 32; ++p) {
@@ -174,7 +170,7 @@ __device__ __forceinline__ void chip2_taper_pairs(const ChipLds& L, c32 (&u)[32]
   }
   }
 #pragma unroll
-  for (int r = 0; r < ((PAYNE_EXP_CHIP & 8) ? 0 : 16); ++r) {
+  for (int r = 0; r < 16; ++r) {
     const int k0 = P.low + 512 * r;
     const int k = (k0 == 0) ? 1 : k0;
     float tk, tm;

@@ -19,17 +19,13 @@
 #define PAYNE_SEQ_CALL inline
 #endif
 
-// Timing experiments (tools/exp/ablate.py builds twins with -DPAYNE_EXP_SKIP=<mask>; results are WRONG by design):
-// 1 forward transforms | 2 taper phases | 4 inverse transforms | 8 resampling | 16 observed grid + chi^2 | 32 row load
-#ifndef PAYNE_EXP_SKIP
-#define PAYNE_EXP_SKIP 0
-#endif
-
 namespace payne {
 
 // scratch layout (doubles): [0, nthr) chi^2 partials | [nthr, nthr + nthr/2) mask counts (ints) | result
 PAYNE_HD int scratch_doubles(int nthr) { return nthr + nthr / 2 + 2; }
 
+template <class Ex>
+PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile);
 // M-point complex FFT by ping-pong between a and b, runtime geometry; returns where the result is.
 template <class Ex>
 PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, bool conj_last) {
@@ -53,47 +49,23 @@ PAYNE_SEQ c32* fft_run(Ex& ex, c32* a, c32* b, int M, const c32* tw, int tw_n, b
 // through the global workspace per transform.  The closing pass of one tile and the opening pass of the next
 // touch different buffers and share a barrier interval.
 //   a -> b (step 1), b -> a (step 2); the result is in a.
-//   src0 (optional): step 1 reads its input from there instead of a (the raw ANN row: SCRUB0 = NaN -> 0 on the way) --
-//   the copy of the row into the workspace is then not needed at all;
-//   TAPER: step 1 applies the convolution's middle step while it loads (fft4_s1_load_tapered): no separate taper pass.
-enum { kNoTaper = 0, kTaperGauss = 1, kTaperVsini = 2 };
-template <int TAPER, bool SCRUB0, class Ex>
-PAYNE_SEQ c32* fft_run_tiled_x(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile,
-                               const c32* src0_, const TaperArgs* ta) {
+template <class Ex>
+PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile) {
   auto a = Ex::buf(a_);
   auto b = Ex::buf(b_);
-  auto s0 = Ex::buf(const_cast<c32*>(src0_ ? src0_ : a_));
   auto tw = Ex::twid(tw_);
   auto X = Ex::lds(tile);
   auto Y = Ex::lds(tile + fft_tile_complex());
   const int B = M / kTileA;
-  // step 1: a (or src0) -> b
-  if constexpr (TAPER == kNoTaper) {
-    ex.par([&](int t, int n) { fft4_s1_load<SCRUB0>(t, n, s0, X, B, 0); });
-    for (int c0 = 0; c0 < B; c0 += kTileC) {
-      ex.par([&](int t, int n) { fft4_s1_mid(t, n, X, Y, tw, tw_n); });
-      const bool more = c0 + kTileC < B;
-      ex.par([&](int t, int n) {
-        fft4_s1_store(t, n, Y, b, tw, tw_n, ColRun{c0});
-        if (more) fft4_s1_load<SCRUB0>(t, n, s0, X, B, c0 + kTileC);
-      });
-    }
-  } else {
-    constexpr bool VS = TAPER == kTaperVsini;
-    const int tw_step = tw_n / (2 * M), nt = fft4_pair_tiles(B);
-    ex.par([&](int t, int n) { fft4_s1_load_tapered<VS>(t, n, a, X, B, 0, tw, tw_step, *ta, M); });
-    for (int pt = 0; pt < nt; ++pt) {
-      ex.par([&](int t, int n) { fft4_s1_mid(t, n, X, Y, tw, tw_n); });
-      const bool more = pt + 1 < nt;
-      ex.par([&](int t, int n) {
-        fft4_s1_store(t, n, Y, b, tw, tw_n, ColPairs{pt, B});
-        if (more) fft4_s1_load_tapered<VS>(t, n, a, X, B, pt + 1, tw, tw_step, *ta, M);
-        else fft4_s1_special<VS>(t, n, a, X, B, tw, tw_step, *ta, M);        // columns 0 and B/2 -> X (plain layout)
-      });
-    }
-    ex.par([&](int t, int n) { fft4_s1_first_lds(t, n, X, Y, 2); });
-    ex.par([&](int t, int n) { fft4_s1_mid(t, n, Y, X, tw, tw_n, 2); });
-    ex.par([&](int t, int n) { fft4_s1_store(t, n, X, b, tw, tw_n, ColSelf{B}, 2); });
+  // step 1: a -> b
+  ex.par([&](int t, int n) { fft4_s1_load(t, n, a, X, B, 0); });
+  for (int c0 = 0; c0 < B; c0 += kTileC) {
+    ex.par([&](int t, int n) { fft4_s1_mid(t, n, X, Y, tw, tw_n); });
+    const bool more = c0 + kTileC < B;
+    ex.par([&](int t, int n) {
+      fft4_s1_store(t, n, Y, b, tw, tw_n, ColRun{c0});
+      if (more) fft4_s1_load(t, n, a, X, B, c0 + kTileC);
+    });
   }
   // step 2: b -> a.  The tile buffers alternate, so the closing pass of a tile (which reads one buffer) and the
   // opening pass of the next (which fills the other) share a barrier interval as well.
@@ -117,10 +89,6 @@ PAYNE_SEQ c32* fft_run_tiled_x(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, 
     }
   }
   return a_;
-}
-template <class Ex>
-PAYNE_SEQ c32* fft_run_tiled(Ex& ex, c32* a_, c32* b_, int M, const c32* tw_, int tw_n, bool conj_last, c32* tile) {
-  return fft_run_tiled_x<kNoTaper, false>(ex, a_, b_, M, tw_, tw_n, conj_last, tile, nullptr, nullptr);
 }
 
 // The same with compile-time geometry (M points, NT threads, pass-ordered twiddles `twf`).
@@ -205,26 +173,17 @@ PAYNE_SEQ float* conv_stage(Ex& ex, const PostTables& T, const c32* twf, float* 
   if constexpr (LOG2N > 0) {
     constexpr int MF = (1 << LOG2N) / 2;
     if (M == MF) {
-      c32* z = ((PAYNE_EXP_SKIP & 1) || have_y) ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
+      c32* z = have_y ? (c32*)work : fft_fixed<MF, NT>(ex, (c32*)work, (c32*)other, twf, 0u, false);
       constexpr int PU = unroll_for((1 << LOG2N) / NT) / 4;
-      if (!(PAYNE_EXP_SKIP & 2) && !have_y) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
+      if (!have_y) ex.par([&](int t, int) { rfft_taper_phase<VSINI, PU>(t, NT, Ex::buf(z), MF, Ex::twid(twf + plan_total(MF)), 1, ta); });
       c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
       if (defer_inverse) return (float*)z;
-      float* res = (PAYNE_EXP_SKIP & 4) ? (float*)z : (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
+      float* res = (float*)fft_fixed<MF, NT>(ex, z, zo, twf, 0x80000000u, edge);
       edge = false;
       return res;
     }
   }
   const c32* tw = T.tw;
-  if (c32* tile = ex.tile())
-    if (fft_tiled_ok(M) && ex.fuse()) {
-      // global workspace: the row (when it is handed over as `src0`) is read straight into the first pass, and the
-      // middle step rides on the inverse transform's loads: 8 transfers of the spectrum per stage instead of 12
-      c32* z = src0 ? fft_run_tiled_x<kNoTaper, true>(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false, tile, (const c32*)src0, nullptr)
-                    : fft_run_tiled_x<kNoTaper, false>(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false, tile, nullptr, nullptr);
-      c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
-      return (float*)fft_run_tiled_x<VSINI ? kTaperVsini : kTaperGauss, false>(ex, z, zo, M, tw, T.nmax, true, tile, nullptr, &ta);
-    }
   c32* z = fft_run(ex, (c32*)work, (c32*)other, M, tw, T.nmax, false);
   ex.par([&](int t, int nt) { rfft_taper_phase<VSINI>(t, nt, z, M, tw, T.nmax / (2 * M), ta); });
   c32* zo = ((float*)z == work) ? (c32*)other : (c32*)work;
@@ -243,7 +202,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
                              float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr, Early early = Early()) {
   // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer.  The test reads theta: with the plain
   // executors it is made AFTER the row has been requested (a global load and its wait ahead of that request was a round trip
-  // of its own at the start of every workgroup); only the fused four-step form needs it before.
+  // of its own at the start of every workgroup); only an on-chip stage, which reads the row itself, needs it before.
   const bool maybe_direct = (out_stage != 0) && T.rot_identity;
   // rows handed over in the frequency domain (the output layer carried the forward transform): every candidate starts at the
   // taper, applied on the way from global memory to LDS (slots_issue / slots_commit) -- one that does not rotate with the taper
@@ -256,16 +215,15 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   constexpr int SU = (MFq / 2 + NT - 1) / NT;          // slots per thread (2 at 4096 points on 512 threads)
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
   constexpr int UX = LOG2N > 0 ? unroll_for((1 << LOG2N) / NT) : (NT >= 1024 ? 8 : 16);   // (1024 threads: 128 registers each)
-  // global-workspace executor with the four-step transform: the first pass of the vsini transform reads the row itself
-  const bool may_fuse = maybe_direct && row_vectorised(T.npix, raw) &&
-                        ((ex.tile() && ex.fuse() && fft_tiled_ok(T.n1 / 2)) || (ex_chip<Ex>::value && T.n1 == kChipN1));
+  // an on-chip stage reads the row itself
+  const bool may_fuse = maybe_direct && row_vectorised(T.npix, raw) && ex_chip<Ex>::value && T.n1 == kChipN1;
   bool direct = may_fuse ? (th[5] != 0.0) : false;
   const bool fused_row = may_fuse && (direct || freq_chip);
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
     SlotRegs<SU> slots;
     if (freq && !freq_chip) slots_issue<SU>(t, NT, MFq, raw, T.twf + plan_total(MFq), slots);
-    else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
+    else if (!fused_row) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     PrepRegs pr;
     if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
     double th5 = 0.0;
@@ -283,7 +241,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       }
       slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
     }
-    else if (!fused_row && !(PAYNE_EXP_SKIP & 32)) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
+    else if (!fused_row) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
   float* spec = bufA;
   float* work = bufB;
@@ -352,7 +310,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (!W.bad) {
       // (an executor that keeps the stage on the compute unit gathers the resampled points while it loads them)
       const bool gather = ex_chip<Ex>::value && T.geo && W.n2 == kChipN1;
-      if (!gather && !(PAYNE_EXP_SKIP & 8)) ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
+      if (!gather) ex.par([&](int t, int n) { phase_R_resample<UX>(t, n, T, S, W, spec, work); });
       TaperArgs ta{};
       ta.g_c2 = W.g_c2;
       bool no_edge = false;
@@ -378,7 +336,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
 #endif
     }
   }
-  if (!(PAYNE_EXP_SKIP & 16) && !tail_done) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
+  if (!tail_done) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
   // the sum of the per-wave partials: thread 0 alone, no closing barrier (it is also the only reader)
   ex.single([&](int n) {
     double s = 0.0;

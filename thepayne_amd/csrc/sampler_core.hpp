@@ -171,9 +171,6 @@ struct WalkTail { SamplerDev sd; WalkState w; };
 // normcdfinv chains in fp64) of the dimensions run side by side, the ellipsoid step is a shuffle
 // matvec, sums are wave reductions.  (One thread per chain spent 14 us per step in a ~3000-instruction
 // dependent fp64 chain; the step sits between two likelihood batches, nothing overlaps it.)
-#ifndef PAYNE_EXP_TAIL
-#define PAYNE_EXP_TAIL 0   // (timing experiments: 1 no prior transform / ln-prior, 2 no random draw, 4 no theta row)
-#endif
 constexpr int kRedrawPasses = 2;
 #ifndef PAYNE_AX_BATCH
 #define PAYNE_AX_BATCH 4
@@ -276,7 +273,6 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   double up = uc;
   bool in = false;
   int skipped = 0;
-  if (PAYNE_EXP_TAIL & 2) { in = true; up = uc * 0.999 + 0.0005; }
   for (int pass = 0; pass < kRedrawPasses && !in; ++pass) {
     const unsigned d0 = (unsigned)(pass * G + g) * 192u;
     // the random direction and radius in fp32 (v_log_f32 / v_cos_f32 / v_exp_f32 / v_rsq_f32: a draw carries 24 random
@@ -319,8 +315,8 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
   }
   if (nredraw && lane == 0) nredraw[c] = (settle ? L.nredraw0 : 0) + skipped;
   const payne_prior_dim dim = sd.dims[dl];                      // (an L2 hit; twenty registers the loop above could not spare)
-  const double vp = (PAYNE_EXP_TAIL & 1) ? up : (in ? prior_ppf(dim, sd.q0[dl], sd.q1[dl], up, sd.adv) : vc);       // outside: a harmless valid row
-  double lp = (PAYNE_EXP_TAIL & 1) ? 0.0 : wave_sum(act ? prior_ln(dim, vp) : 0.0);
+  const double vp = in ? prior_ppf(dim, sd.q0[dl], sd.q1[dl], up, sd.adv) : vc;       // outside: a harmless valid row
+  double lp = wave_sum(act ? prior_ln(dim, vp) : 0.0);
   if (L.adv_on) {                                       // priors on derived quantities: the values they need by shuffle
     const payne_adv_priors& a = sd.adv;
     const double g_ = __shfl(vp, a.dim_logg >= 0 ? a.dim_logg : 0), r_ = __shfl(vp, a.dim_logr >= 0 ? a.dim_logr : 0);
