@@ -2,6 +2,8 @@
 and random-walk proposals on the GPU, against the golden vectors frozen from the reference's
 ``prior`` class (tests/golden/g6_prior.npz), the oracle likelihood and the host sampler path."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -664,3 +666,57 @@ def test_sampling_loop_with_the_turn_on_the_device(tmp_path):
     assert desync == 0
     assert abs(ra.logz[-1] - rb.logz[-1]) < 4 * np.hypot(ra.logzerr[-1], rb.logzerr[-1]) + 0.2
     assert 0.5 < na / nb < 2.0
+
+
+def test_turn_on_the_device_is_the_same_run_statistically():
+    """Why pipeline='device' is the default loop wherever it can run: twenty seeds of it and twenty of the loop that makes the turn
+    between two proposal queues on the host, on the C2 fit (4096-pixel network, 3600 observed pixels, 512 live points, 25-step
+    random walks, multi-ellipsoid metric), to dlogz = 0.5 + the final live points.  Thresholds, all stated:
+      * ln Z: the two means differ by less than three standard errors of the difference (from the seeds' own scatter) + 0.05;
+        each loop's scatter over seeds is within a factor 1.6 of the other's and of the runs' own quoted error;
+      * every parameter: posterior means differ by less than 0.15 posterior sigma (mean over seeds; three standard errors of the
+        seed scatter allowed on top), posterior widths agree within 10 %;
+      * the device loop never re-uploaded its live set (`_dev_desync == 0`), and the default loop IS the device loop."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sampler_bench
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    from thepayne_amd.sampler import NestedSampler
+    from thepayne_amd.sampler.device import DeviceProposer
+    nlive, nseed = 512, 20
+    L, P = sampler_bench.make_problem("C2", nlive)
+    stats = {}
+    for name, pipeline in (("device", None), ("host", True)):
+        logz, err, mean, sig, desync = [], [], [], [], 0
+        for seed in range(nseed):
+            prop = DeviceProposer(L, P, k_max=nlive)
+            S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=nlive, bound='multi', sample='rwalk',
+                              walks=25, batched=True, queue_size=nlive, rstate=np.random.default_rng(1000 + seed), proposer=prop,
+                              pipeline=pipeline)
+            assert S._dev_turn == (name == "device")
+            for _ in S.sample_chunks(dlogz=0.5, maxcall=20_000_000):
+                pass
+            for _ in S.add_live_points():
+                pass
+            r = S.results
+            w = np.exp(r.logwt - r.logz[-1])
+            w /= w.sum()
+            m = (w[:, None] * r.samples).sum(axis=0)
+            mean.append(m)
+            sig.append(np.sqrt((w[:, None] * (r.samples - m) ** 2).sum(axis=0)))
+            logz.append(r.logz[-1]); err.append(r.logzerr[-1])
+            desync += S._dev_desync
+            prop.close()
+        stats[name] = dict(logz=np.array(logz), err=np.array(err), mean=np.array(mean), sig=np.array(sig), desync=desync)
+    L.GM.engine.close()
+    d, h = stats["device"], stats["host"]
+    assert d["desync"] == 0
+    se = np.sqrt(d["logz"].var(ddof=1) / nseed + h["logz"].var(ddof=1) / nseed)
+    assert abs(d["logz"].mean() - h["logz"].mean()) < 3.0 * se + 0.05, (d["logz"].mean(), h["logz"].mean(), se)
+    sd, sh, quoted = d["logz"].std(ddof=1), h["logz"].std(ddof=1), np.concatenate([d["err"], h["err"]]).mean()
+    assert 1 / 1.6 < sd / sh < 1.6 and 1 / 1.6 < sd / quoted < 1.6 and 1 / 1.6 < sh / quoted < 1.6, (sd, sh, quoted)
+    sig = 0.5 * (d["sig"].mean(axis=0) + h["sig"].mean(axis=0))
+    dm = np.abs(d["mean"].mean(axis=0) - h["mean"].mean(axis=0))
+    sem = np.sqrt(d["mean"].var(axis=0, ddof=1) / nseed + h["mean"].var(axis=0, ddof=1) / nseed)
+    assert np.all(dm < 0.15 * sig + 3.0 * sem), (dm / sig, sem / sig)
+    assert np.all(np.abs(d["sig"].mean(axis=0) / h["sig"].mean(axis=0) - 1.0) < 0.10), d["sig"].mean(axis=0) / h["sig"].mean(axis=0)

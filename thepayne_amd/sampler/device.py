@@ -277,7 +277,11 @@ class DeviceProposer(object):
 
     # ---- the queue's turn on the device (payne_ns_queue_dev_*): the live set lives there, queues follow each other without the host
     def queue_dev_init(self, live_u, live_v, live_logl, scale, loglstar):
-        """Upload the live set and the scale / threshold the first queue starts from (no queue may be in flight)."""
+        """Upload the live set and the scale / threshold the first queue starts from.  Queues still in flight (a sampling loop
+        that was abandoned without being finalised: its generator still referenced somewhere) are collected and dropped first."""
+        while getattr(self, "_dq_out", 0) > 0:
+            K, nd = self.k_max, self.ndim
+            self.queue_dev_collect((np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32)))
         u = np.ascontiguousarray(live_u, dtype=np.float64)
         v = np.ascontiguousarray(live_v, dtype=np.float64)
         l = np.ascontiguousarray(np.where(np.isnan(live_logl), -np.inf, live_logl), dtype=np.float64)
@@ -301,6 +305,7 @@ class DeviceProposer(object):
         if rc != 0:
             self.eng._err(rc, "payne_ns_queue_dev_launch")
         self._qb_dev = key
+        self._dq_out = getattr(self, "_dq_out", 0) + 1
 
     def queue_dev_collect(self, qbuf):
         """The oldest queue in flight, as rwalk_queue_end returns it, + the scale and threshold it ran under."""
@@ -313,6 +318,7 @@ class DeviceProposer(object):
                                                  C.byref(nq), stats.ctypes.data, self._dyn_used.ctypes.data)
         if rc != 0:
             self.eng._err(rc, "payne_ns_queue_dev_collect")
+        self._dq_out = getattr(self, "_dq_out", 1) - 1
         return nq.value, int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]), float(self._dyn_used[0]), float(self._dyn_used[1])
 
     # the same in three parts (MultiPopProposer interleaves the steps of several populations)

@@ -197,10 +197,19 @@ class NestedSampler(object):
         # the host, which consumes each queue for the evidence meanwhile.  The host's live SET stays the device's (checked every
         # queue: the device's threshold must lie in [the host's, the live minimum); outside that window the set is re-uploaded); start points are drawn from the device's ordering of
         # it, so a run is the host-turn run statistically, not to the bit.
+        # Default (pipeline=None): 'device' wherever it can run -- random-walk proposals from a proposer that keeps the live set on
+        # the device, native bookkeeping, nlive + queue_size <= 2048 (the turn kernel sorts the set and the queue in LDS) --, else
+        # queues launched ahead from the host's turn (True), else the serial loop.  The evidence for the switch: twenty seeds of each
+        # loop on the C2 fit give the same ln Z, the same posterior means and widths and no re-upload
+        # (tests/test_sampler_gpu.py::test_turn_on_the_device_is_the_same_run_statistically); it is 4-5 % faster end to end.
+        dev_ok = sample == 'rwalk' and hasattr(proposer, "queue_dev_launch") and native and self.nlive + self.queue_size <= 2048
+        if pipeline is None and dev_ok:
+            pipeline = 'device'
         self._dev_turn = isinstance(pipeline, str) and pipeline == 'device'
         if self._dev_turn:
-            if not (sample == 'rwalk' and hasattr(proposer, "queue_dev_launch") and native):
-                raise ValueError("pipeline='device' needs sample='rwalk', native bookkeeping and a proposer with queue_dev_launch")
+            if not dev_ok:
+                raise ValueError("pipeline='device' needs sample='rwalk', native bookkeeping, a proposer with queue_dev_launch and "
+                                 "nlive + queue_size <= 2048")
             pipeline = False
         self._dev_sync, self._dev_inflight, self._dev_desync = False, 0, 0
         self.pipeline = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native) if pipeline is None else bool(pipeline)

@@ -27,11 +27,9 @@ ALL = ['Teff', 'log(g)', '[Fe/H]', '[a/Fe]', 'Vrad', 'Vrot', 'Vmic', 'Inst_R', '
        'CarbonScale']
 
 
-def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
-        verbose=False, bound='multi', variant=0, seed=1, dlogz=0.01):
-    """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
-    bookkeeping included).  Returns {mode: {...}}.  config 'C3' = C2 + photometry in seven filters (joint fit, photscale).
-    `seed`: the sampler's random stream; `dlogz`: stopping threshold (tiny: the run ends at `maxcall`)."""
+def make_problem(config="C2", nlive=512, variant=0):
+    """(likelihood, prior) of the synthetic fit the end-to-end numbers are quoted on: the config's network and observed grid,
+    a noisy spectrum of synth.TRUTH made with the engine itself, the demo's prior box."""
     cfg = synth.CONFIGS["C2" if config == "LinNet300" else config]
     joint = bool(cfg.get("phot"))
     tmp = tempfile.mkdtemp()
@@ -65,6 +63,18 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
     fitargs['obs_flux_fit'] = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
     L = likelihood(fitargs, fitpars, rb, b_max=nlive, verbose=False, variant=variant)
     P = prior(fitargs, synth.c3_priordict() if joint else synth.demo_priordict(), fitpars, rb)
+    return L, P
+
+
+def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
+        verbose=False, bound='multi', variant=0, seed=1, dlogz=0.01):
+    """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
+    bookkeeping included).  Returns {mode: {...}}.  config 'C3' = C2 + photometry in seven filters (joint fit, photscale).
+    `seed`: the sampler's random stream; `dlogz`: stopping threshold (tiny: the run ends at `maxcall`).
+    Modes: "device_chunks" = proposals on the device, the sampler's default loop (the turn between two queues on the device where the
+    proposer offers it); "..._hostturn" = the turn made on the host, queues launched ahead; "..._serial" = every queue launched after
+    the one before is consumed; "..._devturn" = pipeline='device' asked for by name."""
+    L, P = make_problem(config, nlive, variant)
     out = {}
     for mode in modes:
         proposer = None
@@ -76,6 +86,9 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
         elif mode.endswith("_devturn"):                     # "device_chunks_devturn": the turn between two queues made on the device
             kw["pipeline"] = 'device'
             mode_ = mode[:-len("_devturn")]
+        elif mode.endswith("_hostturn"):                    # "device_chunks_hostturn": the turn on the host, the next queue launched ahead
+            kw["pipeline"] = True
+            mode_ = mode[:-len("_hostturn")]
         else:
             mode_ = mode
         if mode.startswith("device2"):                      # two chain populations in flight
