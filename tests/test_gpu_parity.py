@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from thepayne_amd import synth, nnio
+from thepayne_amd import synth, nnio, _lib
 from helpers import SPEC_PARS, theta_full, yst_problem, lnl_tol
 
 pytestmark = pytest.mark.gpu
@@ -327,8 +327,55 @@ def test_lnlike_vs_oracle_shapes(Engine, npix, nobs, H, B):
     assert np.array_equal(np.isnan(lnl), np.isnan(ref))
     ok = np.isfinite(ref)
     assert ok.sum() >= B - 2 and np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok]))
-    # rows reach the post kernel transformed where its geometry is compiled in and the vsini maps are the identity (8192: twiddles from L2)
-    assert eng.kernels_used()["rows"] == ("frequency" if npix == 8192 else "pixels"), eng.kernels_used()
+    # rows reach the post kernel transformed where its geometry is compiled in (n1 = 1024 .. 8192; 8192: twiddles from L2) -- with
+    # vsini maps that are not the identity (1000, 3000 pixels) as the transform of the RESAMPLED spectrum, the output layer's weights
+    # carrying the resampling as well -- and a 3-layer net hands the records over that say whether every candidate rotates
+    assert eng.kernels_used()["rows"] == ("frequency" if npix in (1000, 3000, 8192) else "pixels"), eng.kernels_used()
+
+
+@pytest.mark.parametrize("npix,nobs,H", [(700, 600, 32), (1500, 1200, 64), (3600, 3200, 300), (6000, 5000, 48)])
+def test_rows_of_a_resampled_grid_vs_oracle(Engine, npix, nobs, H):
+    """Model grids that are not a power of two long (what a trained network has: Payne/utils/readc3k.py:441-447 builds the grid from
+    a range and a resolution; smoothing.py:649-668 resamples it to 2^k): the output layer's restated weights carry the rotation
+    stage's static resampling AND its forward transform, the post kernel starts at the taper (n1 = 1024 .. 8192).  A candidate
+    that does not rotate needs the un-resampled pixels (ystpred.py:212-224 skips the stage): the thread that writes its record
+    says so, and the output layer and the post kernel of that batch run on pixels -- decided on the device, the same launches.
+    Against the oracle at the usual tolerances in all three cases (every candidate rotates; one does not; none does), and the
+    fall-back gives the pixel variant's numbers to the bit."""
+    raw = synth.make_yst_net(npix=npix, lam0=5150.0, R_fwhm=32000.0, H=H, seed=5, line_depth=0.2)
+    obs = synth.obs_grid(raw["wavelength"], nobs)
+    B = 24
+    th7 = synth.draw_candidates(B, seed=npix)
+    flux = O.genspec(raw, list(theta_full(th7[0])[0, :8]), outwave=obs)[1] + np.random.default_rng(1).normal(0, 0.01, nobs)
+    eflux = np.full(nobs, 0.01)
+    L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
+    eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=32)
+    pix = Engine(_net(raw), obs=(obs, flux, eflux), b_max=32, variant=_lib.V_ROWS_PIXEL)
+    for case in ("all rotate", "one does not", "none does"):
+        th = th7.copy()
+        if case == "one does not":
+            th[3, 5] = 0.0
+        if case == "none does":
+            th[:, 5] = 0.0
+        with np.errstate(all="ignore"):
+            ref = np.array([L.lnlikefn(t) for t in th])
+            ref_flux = np.array([O.genspec(raw, list(theta_full(t)[0, :8]), outwave=obs)[1] for t in th])
+        lnl = eng.lnlike_batch(theta_full(th)).cpu().numpy()
+        assert eng.kernels_used()["rows"] == "frequency"
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isnan(lnl), np.isnan(ref)) and np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok])), case
+        got = eng.predict_batch(theta_full(th), stage=2, fwhm_R=True).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref_flux)) and np.nanmax(np.abs(got - ref_flux)) <= FLUX_TOL, case
+        lp = pix.lnlike_batch(theta_full(th)).cpu().numpy()
+        assert pix.kernels_used()["rows"] == "pixels"
+        if case != "all rotate":                                     # the fall-back IS the pixel path
+            assert np.array_equal(np.nan_to_num(lnl), np.nan_to_num(lp))
+        else:
+            assert np.all(np.abs(lnl[ok] - lp[ok]) <= lnl_tol(ref[ok]))
+    # a batch after the fall-back is back on transformed rows (the word carries a sequence number, nothing is reset)
+    lnl = eng.lnlike_batch(theta_full(th7)).cpu().numpy()
+    ref = np.array([L.lnlikefn(t) for t in th7])
+    assert np.all(np.abs(lnl - ref) <= lnl_tol(ref))
 
 
 @pytest.mark.parametrize("rows", ["default", "pixels"])

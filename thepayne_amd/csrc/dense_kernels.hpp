@@ -32,6 +32,11 @@ struct DenseParams {
   unsigned short* Yp; const unsigned short* Xp; const unsigned short* Wp;
   int ldp; size_t plane_y, plane_x, plane_w;
   double xmin[PAYNE_MAX_LABELS], xden[PAYNE_MAX_LABELS];
+  // payne_dense_dma3_kernel: a second output layer the launch switches to when *sel == sel_seq (null: never) -- the pixel weights for
+  // a batch in which some candidate does not rotate, where the launch was made for rows in the frequency domain of a model grid that
+  // the rotation stage resamples (run_ann in payne_hip.hip; the hidden-layer launch's records set the word)
+  const unsigned long long* sel; unsigned long long sel_seq;
+  const unsigned short* Wp_alt; size_t plane_w_alt; const float* bias_alt; float bias_shift_alt; int N_alt, ldy_alt;
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
@@ -505,10 +510,14 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
   constexpr int D3_NS = NS, AHEAD = PIPE ? D3_NS - 1 : 1;
   static_assert((PIPE && NS >= 3) || (!PIPE && NS == 2 && NK == 0), "ring depth / schedule");
   extern __shared__ __attribute__((aligned(16))) unsigned char d3_sm[];
+  if (p.sel != nullptr && *p.sel == p.sel_seq) {             // (a scalar load and a uniform branch; launches without the word skip both)
+    p.Wp = p.Wp_alt; p.plane_w = p.plane_w_alt; p.bias = p.bias_alt; p.bias_shift = p.bias_shift_alt; p.N = p.N_alt; p.ldy = p.ldy_alt;
+  }
   const int ntiles = p.grid_m * p.grid_n;
   int t = blockIdx.x;
   if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
   const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 128;
+  if (n0 >= p.N) return;                                     // (the grid was sized for the wider of the two output layers)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
@@ -880,6 +889,10 @@ struct PrepArgs {
   // the sampler's walk: workgroups past those make the NEXT chain step's proposal for both outcomes of the one this batch evaluates
   // (rwalk_spec_wave, sampler_core.hpp; eight chains per workgroup)
   const WalkTail* spec_walk; WalkState spec_w; int spec_step, n_spec, n_sed;
+  // rows in the frequency domain of a RESAMPLED model grid (freq_rows with maps): a candidate that does not rotate needs the pixels
+  // themselves -- the thread that writes its record says so (*rot_flag = rot_seq) and the output layer and the post kernel of this
+  // batch, which read the word at their start, run on pixels (null: not such a launch)
+  unsigned long long* rot_flag; unsigned long long rot_seq;
 };
 
 // One 32 x 32 tile of a hidden layer by the first 256 threads of the workgroup (`tile`: index in the launch's grid_m x grid_n).
@@ -1113,7 +1126,10 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
       const int x = (int)blockIdx.x - pa.n_gemm;
       if (x < pa.n_prep) {
         const int cand = x * 256 + (int)threadIdx.x;
-        if (pa.out && cand < p.B) prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+        if (pa.out && cand < p.B) {
+          prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+          if (pa.rot_flag && !pa.out[cand].do_rot) *pa.rot_flag = pa.rot_seq;       // (every writer writes the same value)
+        }
       } else if (x >= pa.n_prep + pa.n_sed) {
         const int w = (x - pa.n_prep - pa.n_sed) * 4 + (int)(threadIdx.x >> 6);
         if (pa.spec_walk) rwalk_spec_wave(pa.spec_walk->sd, pa.spec_w, w, (int)threadIdx.x & 63, pa.spec_step);

@@ -122,14 +122,21 @@ inline void chip2_layout(const double* z, int n, double* out) {
         o[0] = z[2 * k]; o[1] = z[2 * k + 1]; o[2] = z[2 * kb]; o[3] = z[2 * kb + 1];
       }
 }
-// The output layer of a network (W [n][K] row-major, bias [n], spectrum = W a + bias + shift) restated for rows handed over as
+// The output layer of a network (W [npix][K] row-major, bias [npix], spectrum = W a + bias + shift) restated for rows handed over as
 // the half transform of the spectrum: layout 0 pair_layout, 1 chip_layout (n = 65536), 2 chip2_layout (n = 32768).  Wz [n][K], bz [n].
+// rs_idx / rs_frac (n entries; null: npix == n, the spectrum itself): the rotation stage's static resampling onto its power-of-two
+// log grid (resample_wave, smoothing.py:649-668: point j = pixel rs_idx[j] + rs_frac[j] towards the next) is LINEAR as well and is
+// folded in: the rows are then the transform of the RESAMPLED spectrum -- what the rotation stage transforms -- for model grids of
+// any length.
 inline void freq_rows(const float* W, const float* bias, double shift, int n, int K, std::vector<float>& Wz, std::vector<float>& bz,
-                      int layout = 0) {
+                      int layout = 0, const int* rs_idx = nullptr, const float* rs_frac = nullptr, int npix = 0) {
+  if (!rs_idx) npix = n;
   Wz.assign((size_t)n * K, 0.f); bz.assign((size_t)n, 0.f);
-  std::vector<double> v(n), z(n), zn(n);
+  std::vector<double> pix(npix), v(n), z(n), zn(n);
   for (int h = 0; h <= K; ++h) {
-    for (int i = 0; i < n; ++i) v[i] = h < K ? (double)W[(size_t)i * K + h] : (double)bias[i] + shift;
+    for (int i = 0; i < npix; ++i) pix[i] = h < K ? (double)W[(size_t)i * K + h] : (double)bias[i] + shift;
+    if (rs_idx) for (int j = 0; j < n; ++j) { const int k = rs_idx[j]; v[j] = pix[k] + (pix[k + 1] - pix[k]) * (double)rs_frac[j]; }
+    else v = pix;
     packed_half_transform(v.data(), n, zn.data());
     if (layout == 1) chip_layout(zn.data(), n, z.data());
     else if (layout == 2) chip2_layout(zn.data(), n, z.data());

@@ -77,6 +77,10 @@ struct payne_ctx {
   // the same output layer restated for rows in the frequency domain (host_tables.hpp freq_rows): what the likelihood and the
   // predictions past stage 0 run when the post kernel can start from the transform (freq_ok); raw_freq: the rows now in c->raw
   unsigned short* w_out_p3z = nullptr; const float* bias_z = nullptr; bool freq_ok = false, raw_freq = false;
+  // freq_rs: the restated layer is that of the RESAMPLED spectrum (model grids that are not a power of two long: n1 rows of n1
+  // values); a batch with a candidate that does not rotate falls back to pixels ON THE DEVICE (rot_flag: a word the records'
+  // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
+  bool freq_rs = false, freq_rs_now = false; unsigned long long* rot_flag = nullptr; unsigned long long rot_seq = 0;
   size_t post_lds = 0;
   void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
@@ -364,7 +368,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       if ((rc = dev_alloc(c, (size_t)opts->b_max * c->ld_hid, &c->hid[1], c->owned))) return bail(rc);
       if (c->w_out_p3 && (rc = dev_alloc(c, (size_t)3 * opts->b_max * c->ld_hid, &c->hid_p3, c->owned))) return bail(rc);
     }
-    if ((rc = dev_alloc(c, (size_t)opts->b_max * model->npix, &c->raw, c->owned, false))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)opts->b_max * std::max(model->npix, T.n1 <= 16384 ? T.n1 : 0), &c->raw, c->owned, false))) return bail(rc);   // (rows of n1 values: freq_rs)
     if ((rc = dev_alloc(c, (size_t)opts->b_max, &c->prep, c->owned, false))) return bail(rc);
     if (T.n1 > 16384) {                // spectrum larger than LDS: global-workspace kernel
       c->big_grid = opts->b_max < 256 ? opts->b_max : 256;
@@ -413,14 +417,22 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
     {
       const bool fixed = geom_n1 != 0 && ((c->post_tw_lds && (T.n1 == 1024 || T.n1 == 2048 || T.n1 == 4096)) || (!c->post_tw_lds && T.n1 == 8192));
       // (65 536 / 32 768 points with the stages on the compute unit: the rows in the order those kernels' registers hold the transform)
-      if ((fixed || c->big_chip || c->big_chip2) && T.rot_identity && T.n1 == model->npix && c->w_out_p3 && c->hid_p3 && !(opts->variant & PAYNE_V_ROWS_PIXEL)) {
+      // (a model grid of any other length -- what a trained network has: readc3k.py:441-447 -- is resampled by the rotation stage first,
+      //  a static linear map as well: the LDS kernels' lengths take rows of the RESAMPLED spectrum's transform, freq_rs)
+      const bool ident = T.rot_identity && T.n1 == model->npix;
+      if (((fixed || c->big_chip || c->big_chip2) && ident || (fixed && !ident)) && c->w_out_p3 && c->hid_p3 && !(opts->variant & PAYNE_V_ROWS_PIXEL)) {
         const payne_layer& L = model->layers[model->n_layers - 1];
-        const int K = L.n_in, Kp = c->w_out_kp, n = L.n_out;
-        std::vector<float> W((size_t)n * K), b((size_t)n), Wz, bz;
+        const int K = L.n_in, Kp = c->w_out_kp, n = ident ? L.n_out : T.n1;
+        std::vector<float> W((size_t)L.n_out * K), b((size_t)L.n_out), Wz, bz;
         he = hipMemcpy(W.data(), L.w, W.size() * 4, hipMemcpyDeviceToHost);
         if (he == hipSuccess) he = hipMemcpy(b.data(), L.b, b.size() * 4, hipMemcpyDeviceToHost);
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(output layer): ") + hipGetErrorString(he)));
-        freq_rows(W.data(), b.data(), -(double)kBase, n, K, Wz, bz, c->big_chip ? 1 : (c->big_chip2 ? 2 : 0));   // (rows are kept shifted by -1, as the pixel rows are)
+        if (ident) freq_rows(W.data(), b.data(), -(double)kBase, n, K, Wz, bz, c->big_chip ? 1 : (c->big_chip2 ? 2 : 0));   // (rows are kept shifted by -1, as the pixel rows are)
+        else {
+          freq_rows(W.data(), b.data(), -(double)kBase, n, K, Wz, bz, 0, c->H.rs1_idx.data(), c->H.rs1_frac.data(), L.n_out);
+          c->freq_rs = true;
+          if ((rc = dev_alloc(c, (size_t)1, &c->rot_flag, c->owned))) return bail(rc);            // (zeroed; sequence numbers start at 1)
+        }
         std::vector<float> Wp((size_t)n * Kp, 0.f);
         for (int i = 0; i < n; ++i) std::copy(Wz.begin() + (size_t)i * K, Wz.begin() + (size_t)(i + 1) * K, Wp.begin() + (size_t)i * Kp);
         const float* d_wp = nullptr;
@@ -695,7 +707,7 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool fr
   p.stamps = g_dense_stamps;
 #endif
   const dim3 block(512);
-  if (p.B % B3_TM == 0 && p.N % B3_TN == 0 && (p.B / B3_TM) * (p.N / B3_TN) >= 2 * c->n_cu && !(c->opts.variant & PAYNE_V_OUT_SMALL_TILES)) {
+  if (p.B % B3_TM == 0 && p.N % B3_TN == 0 && (p.B / B3_TM) * (p.N / B3_TN) >= 2 * c->n_cu && !(c->opts.variant & PAYNE_V_OUT_SMALL_TILES) && !p.sel) {
     // many whole 128 x 256 tiles per CU (C5): persistent workgroups, half the operand bytes per product
     p.grid_m = p.B / B3_TM; p.grid_n = p.N / B3_TN;
     PAYNE_LAUNCH(payne_dense_big3_kernel, dim3(c->n_cu), block, b3_lds_bytes(), s, p);
@@ -770,6 +782,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       PrepArgs pa{};
       pa.T = c->T; pa.instr_factor = instr_factor;
       pa.out = (N.spectral && c->prep && c->obs_bound && !(c->opts.variant & PAYNE_V_NO_PREP)) ? c->prep : nullptr;
+      if (N.freq && c->freq_rs_now) { pa.rot_flag = c->rot_flag; pa.rot_seq = c->rot_seq; }
       if (!last && sed && *sed && N.spectral && sed_tile_ok(c->P.H) && !(c->opts.variant & PAYNE_V_SED_OWN_LAUNCH)) {
         pa.P = c->P; pa.sed_mags = c->mags_ws; pa.sed_off = 8 + c->opts.npoly; pa.sed_photscale = c->opts.photscale;
         *sed = false;
@@ -786,7 +799,15 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last) launch_hidden<false>(p, pa, s);
-      else if (use3) launch_out_dma3(c, p, s, N.freq);
+      else if (use3) {
+        if (N.freq && c->freq_rs_now) {                      // rows of the resampled grid; pixels if the batch's records say so
+          p.sel = c->rot_flag; p.sel_seq = c->rot_seq;
+          p.Wp_alt = c->w_out_p3; p.plane_w_alt = (size_t)p.N * c->w_out_kp; p.bias_alt = p.bias; p.bias_shift_alt = p.bias_shift;
+          p.N_alt = p.N; p.ldy_alt = p.ldy;
+          p.N = c->T.n1; p.ldy = c->T.n1;
+        }
+        launch_out_dma3(c, p, s, N.freq);
+      }
       else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) {
         if ((c->w_out_kp % 64) == 0 && (c->opts.variant & PAYNE_V_OUT_BK64)) launch_out_dma<64>(c, p, s);
         else launch_out_dma<32>(c, p, s);
@@ -880,6 +901,11 @@ static int run_ann(payne_ctx* c, const double* theta, int B, double instr_factor
   NetRef N{c->layers, c->n_layers, c->n_labels, c->xmin, c->xden, c->hid, c->ld_hid, c->raw, c->T.npix, kBase, true};
   // (the continuum multiplies pixel by pixel; out_dma3_ok: the launch that reads the restated weights is the one that runs)
   N.freq = c->freq_ok && !pixels && !(c->has_cont && with_cont) && out_dma3_ok(c, B, c->T.npix);
+  // rows of a resampled grid need this batch's records (their writers report a candidate that does not rotate) and a first layer
+  // fused into the hidden-layer launch (>= 3 layers), and the plain post kernel behind them
+  if (N.freq && c->freq_rs && !(c->prep && c->obs_bound && !(c->opts.variant & PAYNE_V_NO_PREP) && c->n_layers >= 3 && !c->has_lsf)) N.freq = false;
+  c->freq_rs_now = N.freq && c->freq_rs;
+  if (c->freq_rs_now) ++c->rot_seq;
   c->raw_freq = N.freq; c->T.raw_freq = N.freq ? 1 : 0;
   int rc = run_net(c, N, theta, B, instr_factor, s, sed);
   if (rc || !c->has_cont || !with_cont) return rc;
@@ -930,6 +956,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = instr_factor;
   a.raw = c->raw; a.ld_raw = c->T.npix;
+  if (c->raw_freq && c->freq_rs_now) { a.ld_raw = c->T.n1; a.ld_raw_alt = c->T.npix; a.rot_flag = c->rot_flag; a.rot_seq = c->rot_seq; }
   a.out = out; a.ld_out = ld_out; a.out_stage = stage; a.lnl = lnl;
   if (with_phot) { a.mags = c->mags_ws; a.n_filters = c->P.F; a.obs_mag = c->obs_mag; a.obs_err = c->obs_err; }
   a.prep = c->prep_valid ? c->prep : nullptr;
@@ -1914,6 +1941,7 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
   if ((rc = run_ann(c, theta, B, 2.355, nullptr))) return rc;
   PostArgs a{};
   a.theta = theta; a.ld_theta = c->ncols; a.instr_factor = 2.355; a.raw = c->raw; a.ld_raw = c->T.npix;
+  if (c->raw_freq && c->freq_rs_now) { a.ld_raw = c->T.n1; a.ld_raw_alt = c->T.npix; a.rot_flag = c->rot_flag; a.rot_seq = c->rot_seq; }
   a.out_stage = -1; a.lnl = lnl; a.stamps = d; a.prep = c->prep_valid ? c->prep : nullptr;
   a.stamp_sparse = getenv("PAYNE_DIAG_SPARSE") ? 1 : 0;
   if (c->big_ws && c->big_chip) {

@@ -1392,14 +1392,18 @@ PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const f
 }
 // vsini c: back onto the ANN grid (left/right = NaN), into `spec` (skipped for identity maps:
 // the convolved buffer then IS the spectrum on the ANN grid).
+// `edges`: apply spec[0] = spec[1], spec[-1] = spec[-2] (ystpred.py:223-224; phase_rot_edges) on the way: the threads that own the
+// first and the last pixel evaluate their neighbours' values instead of their own -- no phase of its own for two stores.
 PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float* __restrict__ work,
-                             float* __restrict__ spec) {
+                             float* __restrict__ spec, bool edges = false) {
   for (int base = tid; base < T.npix; base += kU * nthr) {
     float a[kU], b[kU], f[kU];
     int jj[kU];
 #pragma unroll
     for (int q = 0; q < kU; ++q) {
-      const int i0 = base + q * nthr, i = i0 < T.npix ? i0 : T.npix - 1;
+      const int i0 = base + q * nthr;
+      int i = i0 < T.npix ? i0 : T.npix - 1;
+      if (edges) i = (i == 0) ? 1 : ((i == T.npix - 1) ? T.npix - 2 : i);
       jj[q] = T.bk1_idx[i]; f[q] = T.bk1_frac[i];
       const int j = jj[q] < 0 ? 0 : jj[q];
       a[q] = work[j]; b[q] = work[j + 1];
@@ -1641,9 +1645,10 @@ PAYNE_HD ObsFastConsts obs_fast_consts(const Window& W) {
   return c;
 }
 // is the short loop worth taking for this grid and this block size?  (the padding must not be most of the work)
+// (a padded pixel costs the short loop 13 instructions, a real one costs the general loop 30: worth it up to half as many again)
 PAYNE_HD bool obs_fast_ok(const PostTables& T, int blk) {
   const int npad = (T.nobs + blk - 1) / blk * blk;
-  return 4 * (npad - T.nobs) <= T.nobs && blk <= kObsPad;
+  return 2 * (npad - T.nobs) <= T.nobs && blk <= kObsPad;
 }
 // the OU records of one block of the thread, requested (one 16-byte load each; the table is padded past nobs)
 template <int OU>

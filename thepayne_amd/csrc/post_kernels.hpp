@@ -28,6 +28,9 @@ struct PostArgs {
   // launch of its own between two likelihood batches (null: no walk in progress)
   const WalkTail* tail; int tail_step, tail_propose;
   int tail_spec;                     // the next proposal was made ahead by this batch's hidden-layer launch (rwalk_spec_wave): the tail only settles and copies
+  // rows launched in the frequency domain of a resampled model grid: *rot_flag == rot_seq says the batch held a candidate that does
+  // not rotate and the output layer wrote PIXELS (row pitch ld_raw_alt) instead (dense_kernels.hpp PrepArgs; null: not such a launch)
+  const unsigned long long* rot_flag; unsigned long long rot_seq; int ld_raw_alt;
 };
 
 // BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
@@ -112,6 +115,8 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   // (the fixed-geometry instantiations know their length: read from the kernel arguments it was a scalar load, a wait and two
   //  branches in front of everything else the kernel asks for)
   const int n1 = LOG2N > 0 ? (1 << LOG2N) : T.n1;
+  int raw_freq = T.raw_freq, ld_raw = a.ld_raw;
+  if (a.rot_flag != nullptr && *a.rot_flag == a.rot_seq) { raw_freq = 0; ld_raw = a.ld_raw_alt; }
   float* bufA = reinterpret_cast<float*>(smem);
   float* bufB = bufA + fft_buf_floats(n1);                     // room for the padded FFT intermediates
   double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(n1));          // scratch_doubles(256)
@@ -126,7 +131,7 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   // rows handed over in the frequency domain: the first phase loads the split factors exp(-2 pi i j / 2M) slot by slot anyway
   // (slots_issue) and puts them into the LDS table itself -- here they would be 8 KB more for every workgroup to pull through an
   // L2 port that the kernel's first phase saturates (22 B/clk/CU: the row, the table and the records of two workgroups)
-  const int ntw_copy = (LOG2N > 0 && TW_LDS && T.raw_freq) ? plan_total((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : NTW;
+  const int ntw_copy = (LOG2N > 0 && TW_LDS && raw_freq) ? plan_total((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : NTW;
   if (TW_LDS) {   // the FFT's (pass-ordered) twiddles into LDS: the passes then never leave the CU
     c32* twl = reinterpret_cast<c32*>(reinterpret_cast<unsigned char*>(S) + ((sizeof(CandState) + 15) & ~(size_t)15));
     const f2g* __restrict__ g = reinterpret_cast<const f2g*>(T.twf);
@@ -166,7 +171,7 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
       //  -- the last one -- into that condition, behind the wait for the others: a second round trip)
 #pragma unroll
       for (int q = 0; q < PER; ++q) asm volatile("" : "+v"(tw_tmp[q]));
-      const int ncopy = T.raw_freq ? plan_total((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : NTW;
+      const int ncopy = raw_freq ? plan_total((1 << (LOG2N > 0 ? LOG2N : 1)) / 2) : NTW;
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int i0 = (int)threadIdx.x + q * kPostThreads;
@@ -193,7 +198,7 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs
   const CandState* prep = a.prep ? a.prep + b : nullptr;
   if (LEAN) { prep = a.prep + b; __builtin_assume(prep != nullptr); }     // LEAN is launched only with records
   run_candidate<LOG2N, kPostThreads>(ex, T, twf, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
-                                     a.raw + (size_t)b * a.ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep, early);
+                                     a.raw + (size_t)b * ld_raw, bufA, bufB, *S, red, outp, ostage, chi2, prep, early, raw_freq);
   double lnl_v = 0.0;
   if (threadIdx.x == 0 && a.lnl && ostage < 0) {
     double x2 = *chi2;

@@ -199,7 +199,9 @@ struct NoEarly { PAYNE_HD void operator()() const {} };
 template <int LOG2N, int NT, class Ex, class Early = NoEarly>
 PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const double* th, double instr_factor,
                              const float* raw, float* bufA, float* bufB, CandState& S, double* red,
-                             float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr, Early early = Early()) {
+                             float* out, int out_stage, double* chi2_out, const CandState* prep = nullptr, Early early = Early(),
+                             int raw_freq = -1) {                     // (-1: what the tables say; the LDS kernel passes what its launch resolved to)
+  const bool rawf = raw_freq < 0 ? T.raw_freq != 0 : raw_freq != 0;
   // identity vsini maps: the row goes (NaN-scrubbed) straight to the FFT buffer.  The test reads theta: with the plain
   // executors it is made AFTER the row has been requested (a global load and its wait ahead of that request was a round trip
   // of its own at the start of every workgroup); only an on-chip stage, which reads the row itself, needs it before.
@@ -209,8 +211,8 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   // of u = 0, which is 1 in every bin (and without the NaN scrub of the rotating branch: a row is all NaN or not at all, and a
   // NaN row stays NaN through the transform back)
   // (the on-chip stage of a 65 536-point spectrum takes the transformed row straight into its registers: chip_conv)
-  const bool freq_chip = ex_chip<Ex>::value && T.n1 == kChipN1 && T.raw_freq != 0;
-  const bool freq = (LOG2N > 0 && T.raw_freq != 0) || freq_chip;
+  const bool freq_chip = ex_chip<Ex>::value && T.n1 == kChipN1 && rawf;
+  const bool freq = (LOG2N > 0 && rawf) || freq_chip;
   constexpr int MFq = LOG2N > 0 ? (1 << LOG2N) / 2 : 4;
   constexpr int SU = (MFq / 2 + NT - 1) / NT;          // slots per thread (2 at 4096 points on 512 threads)
   // per-pixel loops: LOG2N > 0 knows the pixels per thread (4096 / 512 = 8); the general path unrolls by 16
@@ -227,7 +229,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     PrepRegs pr;
     if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
     double th5 = 0.0;
-    if (!may_fuse && maybe_direct) th5 = th[5];        // (requested with the others; looked at below)
+    if (!may_fuse && (maybe_direct || freq)) th5 = th[5];   // (requested with the others; looked at below)
     early();
     if (!may_fuse) direct = maybe_direct && (th5 != 0.0);
     if (prep) phase_take_prep_commit(t, pr, S);
@@ -239,7 +241,9 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
 #pragma unroll
         for (int q = 0; q < SU; ++q) { const int j = t + q * NT; if (j < MFq / 2) stc(tl, j, slots.w[q]); }
       }
-      slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), direct);
+      // (NaN -> 0 is the rotating branch's nan_to_num; with resampling maps -- rows of a resampled grid -- every candidate of the
+      //  batch rotates, or the launch would have been switched to pixels: PostArgs::rot_flag)
+      slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), th5 != 0.0);
     }
     else if (!fused_row) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
   });
@@ -271,7 +275,11 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     }
     float* dst = (conv == bufA) ? bufB : bufA;
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
-    else { ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst); }); edge = rot && out_stage != 6; }
+    else {
+      const bool er = rot && out_stage != 6 && T.npix >= 4;          // the edge rule rides along
+      ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst, er); });
+      edge = rot && out_stage != 6 && !er;
+    }
     spec = dst;
     work = conv;
     edges_pending = edge;
