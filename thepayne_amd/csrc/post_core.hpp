@@ -1394,8 +1394,36 @@ PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const f
 // the convolved buffer then IS the spectrum on the ANN grid).
 // `edges`: apply spec[0] = spec[1], spec[-1] = spec[-2] (ystpred.py:223-224; phase_rot_edges) on the way: the threads that own the
 // first and the last pixel evaluate their neighbours' values instead of their own -- no phase of its own for two stores.
+// On a geometric grid with the edge rule riding along the positions are arithmetic (pixel i sits at i (n1 - 1)/(npix - 1) of the
+// stage's grid, which spans the same ends; the two end pixels -- the only ones np.interp can find outside, by a rounding of
+// exp(log(.)) -- take their neighbours' values anyway): no map loads, a phase without a global round trip.
 PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float* __restrict__ work,
                              float* __restrict__ spec, bool edges = false) {
+  if (T.geo && edges) {
+    const double r = (double)(T.n1 - 1) / (double)(T.npix - 1);
+    const float hs = (float)(0.5 * T.dln / r);                       // half a step of the stage's grid in ln(lambda)
+    const float c1 = 2.3283064365386963e-10f * (1.0f - hs), c2 = 5.421010862427522e-20f * hs;
+    for (int base = tid; base < T.npix; base += kU * nthr) {
+      float a[kU], b[kU], F[kU];
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int i0 = base + q * nthr;
+        int i = i0 < T.npix ? i0 : T.npix - 1;
+        i = (i == 0) ? 1 : ((i == T.npix - 1) ? T.npix - 2 : i);
+        union { double d; unsigned long long u; } cv;
+        cv.d = fma((double)i, r, kPosMagic);
+        const int k = (int)((unsigned)(cv.u >> 32) - kPosMagicHi);
+        F[q] = (float)(unsigned)cv.u;
+        a[q] = work[k]; b[q] = work[k + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int i = base + q * nthr;
+        if (i < T.npix) spec[i] = fmaf(b[q] - a[q], F[q] * fmaf(F[q], c2, c1), a[q]);
+      }
+    }
+    return;
+  }
   for (int base = tid; base < T.npix; base += kU * nthr) {
     float a[kU], b[kU], f[kU];
     int jj[kU];
