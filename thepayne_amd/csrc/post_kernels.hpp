@@ -304,19 +304,38 @@ PAYNE_SEQ float* chip_conv_stage(Ex& ex, float* work, const TaperArgs& ta, bool&
 #ifndef PAYNE_TU_BIG
 __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const PostTables T, PostArgs a, float* ws, int B);
 #else
+// (anything but the usual path of a candidate -- no records, a spectrum output before the instrumental stage, a shorter window, a
+//  pixel row that does not rotate -- through the general sequence, OUT OF LINE: inlined into the kernel its dozens of branches
+//  were what the register allocator spilled around the stages' calls, 67 vector registers and 350 bytes of scratch a thread)
+__device__ __attribute__((noinline)) static void chip_general_candidate(ChipExec& ex, const PostTables& T, const PostArgs& a, int b, float* bufA,
+                                                                        float* bufB, CandState& S, double* red, double* chi2) {
+  run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
+                                 a.raw + (size_t)b * a.ld_raw, bufA, bufB, S, red,
+                                 a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
+                                 a.prep ? a.prep + b : nullptr);
+}
 __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const PostTables T, PostArgs a, float* ws, int B) {
 #ifdef __HIP_DEVICE_COMPILE__
   __shared__ double red[kChipThreads + kChipThreads / 2 + 2];
   __shared__ CandState S;
+  __shared__ ChipResample Rs;
   extern __shared__ __attribute__((aligned(16))) unsigned char chip_sm[];
-  float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
-  float* bufB = bufA + T.n1;
-  ChipExec ex;
-  ex.L = chip_lds(chip_sm);
-  chip_fill_tables(ex.L, T.tw, (int)threadIdx.x);
+  chip_fill_tables(chip_lds(chip_sm), T.tw, (int)threadIdx.x);
   __syncthreads();
   double* chi2 = red + scratch_doubles(kChipThreads) - 1;
+  const int stage = a.out_stage;
+  // what every candidate of the usual path shares (uniform)
+  const bool usual_launch = a.prep != nullptr && T.geo && T.rot_identity && T.nobs > 0 && T.n1 == kChipN1 &&
+                            (stage == -1 || stage == 2 || stage == 3) && (a.out != nullptr || T.obs_f1 != nullptr) &&
+                            row_vectorised(T.npix, a.raw) && (a.ld_raw & 3) == 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // (everything a candidate needs is derived from the kernel's arguments HERE, inside the loop: nothing but the loop's own scalars
+    //  is alive across the stages' calls, which use the whole register file)
+    const int tid = (int)threadIdx.x;
+    float* bufA = ws + (size_t)blockIdx.x * 2 * T.n1;
+    float* bufB = bufA + T.n1;
+    ChipExec ex;
+    ex.L = chip_lds(chip_sm);
 #ifdef PAYNE_STAMPS
     if (a.stamps) {                                        // diagnostic build: cycle stamps of every candidate's phases
       ex.stamps = a.stamps + (size_t)b * kStampRow;
@@ -324,10 +343,56 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const Pos
       ex.nst = 1;
     }
 #endif
-    run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor,
-                           a.raw + (size_t)b * a.ld_raw, bufA, bufB, S, red,
-                           a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
-                           a.prep ? a.prep + b : nullptr);
+    bool usual = usual_launch;
+    if (usual) {                                           // the record into LDS (a dword copy by the first waves)
+      const unsigned* src = reinterpret_cast<const unsigned*>(a.prep + b);
+      unsigned* dst = reinterpret_cast<unsigned*>(&S);
+      for (int i = tid; i < kPrepDwords; i += kChipThreads) dst[i] = src[i];
+      __syncthreads();
+      // rotation + instrumental smoothing with a 65 536-point window: both stages on the compute unit.  (A pixel row that does
+      // not rotate skips the first stage: general sequence.)
+      usual = S.do_smooth && S.w_ready && !S.W.bad && S.W.n2 == kChipN1 && (S.do_rot || T.raw_freq);
+    }
+    if (!usual) {
+      __syncthreads();
+      // (copies made HERE: what is passed by reference lives in memory, and the kernel's own copies of its arguments must not)
+      PostTables Tl = T;
+      PostArgs al = a;
+      ChipExec exl = ex;
+      chip_general_candidate(exl, Tl, al, b, bufA, bufB, S, red, chi2);
+#ifdef PAYNE_STAMPS
+      ex.nst = exl.nst;
+#endif
+    } else {
+      // ---- rotation stage (ystpred.py:211-224): the row itself in -- pixels (NaN -> 0) or, T.raw_freq, its transform in the order
+      // the taper wants it (a candidate that does not rotate: the taper of u = 0) --, the edge rule out; into bufB
+      {
+        TaperArgs ta{};
+        ta.vs_tab = T.vs_tab; ta.vs_tab_n = T.vs_tab_n;
+        ta.vs_c = S.do_rot ? S.vs_a * T.vs_val : 0.0;
+        ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
+        const bool rot = S.do_rot != 0;
+        chip_conv<true>(ex.L, a.raw + (size_t)b * a.ld_raw, bufB, ta, rot, rot && stage != 6 && stage != 7, tid, nullptr, T.raw_freq != 0);
+        ex.mark(0);
+      }
+      // ---- instrumental stage: the candidate's window (mask, Doppler shift, pow-2 log grid) gathered while loading, the result
+      // over its input
+      {
+        if (tid == 0) Rs = chip_resample_of(S.W);
+        __syncthreads();
+        TaperArgs tg{};
+        tg.g_c2 = S.W.g_c2;
+        chip_conv<false>(ex.L, bufB, bufB, tg, false, false, tid, &Rs, false);
+        ex.mark(0);
+      }
+      // ---- observed grid, blaze, chi^2
+      {
+        float* outp = a.out ? a.out + (size_t)b * a.ld_out : nullptr;
+        store_partial(tid, phase_obs<16>(tid, kChipThreads, T, S, S.W, bufB, outp, stage), red);
+        __syncthreads();
+        if (tid == 0) { double s = 0.0; for (int i = 0; i < n_slots(kChipThreads); ++i) s += red[i]; *chi2 = s; }
+      }
+    }
     if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {
       double x2 = *chi2;
       if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);
@@ -352,6 +417,12 @@ constexpr size_t kChip2WsFloatsPerGroup(int n1) { return (size_t)4 * n1; }      
 #ifndef PAYNE_TU_CHIP2
 __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const PostTables T, PostArgs a, float* ws, int B);
 #else
+__device__ __attribute__((noinline)) static void chip2_general_candidate(DevExecT<false, false>& ex, const PostTables& T, const PostArgs& a, int b,
+                                                                         float* bufA, float* bufB, CandState& S, double* red, double* chi2) {
+  run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, a.raw + (size_t)b * a.ld_raw,
+                                 bufA, bufB, S, red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, a.out_stage, chi2,
+                                 a.prep ? a.prep + b : nullptr);
+}
 __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const PostTables T, PostArgs a, float* ws, int B) {
 #ifdef __HIP_DEVICE_COMPILE__
   __shared__ double red[kChipThreads + kChipThreads / 2 + 2];
@@ -398,9 +469,13 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip2_kernel(const Po
       }
       for (int c = 0; c < ncand; ++c) {
         const int b = bb[c];
-        run_candidate<0, kChipThreads>(ex, T, T.tw, a.theta + (size_t)b * a.ld_theta, a.instr_factor, rowp[c],
-                                       buf[0][0], buf[0][1], S2[0], red, a.out ? a.out + (size_t)b * a.ld_out : nullptr, stage, chi2,
-                                       a.prep ? a.prep + b : nullptr);
+        {                                                    // (out of line, on copies made here: see payne_post_chip_kernel)
+          PostTables Tl = T;
+          PostArgs al = a;
+          al.raw = rowp[c] - (size_t)b * a.ld_raw;           // (so that the callee's row b is this one)
+          DevExecT<false, false> exl = ex;
+          chip2_general_candidate(exl, Tl, al, b, buf[0][0], buf[0][1], S2[0], red, chi2);
+        }
         if (tid == 0 && a.lnl && stage < 0) {
           double x2 = *chi2;
           if (a.mags) x2 += sed_chi2(a.mags + (size_t)b * a.n_filters, a.obs_mag, a.obs_err, a.n_filters);

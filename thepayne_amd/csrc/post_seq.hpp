@@ -298,13 +298,16 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     return;
   }
   const float* on_grid = spec;
-  Window W{};
+  // (executors whose stages are CALLS that use the whole register file -- the on-chip stages -- read the window from the record
+  //  in LDS wherever the record holds it: twenty-five registers a thread less to carry across those calls)
+  Window Wl{};
+  const Window* Wp = &Wl;
   bool tail_done = false;
   if (smooth) {
     if (S.win_ready) {                                 // mask counts known since setup
       if (edges_pending) ex.par([&](int t, int) { phase_rot_edges(t, T.npix, spec); });
-      if (S.w_ready) W = S.W;                          // ... and so is the window (prep_candidate)
-      else W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);   // by every thread
+      if (S.w_ready) { if constexpr (ex_chip<Ex>::value) Wp = &S.W; else Wl = S.W; }   // ... and so is the window (prep_candidate)
+      else Wl = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);   // by every thread
       ex.mark(0);
     } else {
       const int nthr = ex.nthreads();
@@ -313,8 +316,9 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
         if (edges_pending) phase_rot_edges(t, T.npix, spec);   // the count does not touch the spectrum
         phase_mask_count(t, n, T, S, cnt);
       });
-      W = make_window(T, S, cnt, n_slots(nthr));
+      Wl = make_window(T, S, cnt, n_slots(nthr));
     }
+    const Window& W = *Wp;
     if (!W.bad) {
       // (an executor that keeps the stage on the compute unit gathers the resampled points while it loads them)
       const bool gather = ex_chip<Ex>::value && T.geo && W.n2 == kChipN1;
@@ -344,6 +348,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
 #endif
     }
   }
+  const Window& W = *Wp;
   if (!tail_done) ex.par([&](int t, int n) { store_partial(t, phase_obs<UX>(t, n, T, S, W, on_grid, out, out_stage), red); });
   // the sum of the per-wave partials: thread 0 alone, no closing barrier (it is also the only reader)
   ex.single([&](int n) {
