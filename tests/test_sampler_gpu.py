@@ -720,3 +720,4 @@ def test_turn_on_the_device_is_the_same_run_statistically():
     sem = np.sqrt(d["mean"].var(axis=0, ddof=1) / nseed + h["mean"].var(axis=0, ddof=1) / nseed)
     assert np.all(dm < 0.15 * sig + 3.0 * sem), (dm / sig, sem / sig)
     assert np.all(np.abs(d["sig"].mean(axis=0) / h["sig"].mean(axis=0) - 1.0) < 0.10), d["sig"].mean(axis=0) / h["sig"].mean(axis=0)
+
