@@ -39,6 +39,9 @@ inline void fill_model_scalars(const HostTables& H, PostTables& T) {
   T.rot_identity = H.rot_identity;
   T.inv_lam0 = H.lam.empty() ? 0.f : (float)(1.0 / H.lam[0]);
   T.inv_dln32 = (float)H.geo_inv_dln;
+  T.bk_r = H.npix > 1 ? (double)(H.n1 - 1) / (double)(H.npix - 1) : 1.0;
+  const float hs = (float)(0.5 * H.dln / T.bk_r);                    // half a step of the stage's grid in ln(lambda)
+  T.bk_c1 = 2.3283064365386963e-10f * (1.0f - hs); T.bk_c2 = 5.421010862427522e-20f * hs;
 }
 
 // numpy.linspace(start, stop, n)

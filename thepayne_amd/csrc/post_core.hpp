@@ -213,6 +213,10 @@ struct PostTables {
   int vs_tab_n;
   int rot_identity;    // the vsini resampling maps are the identity (to fp32): skip them
   float inv_lam0, inv_dln32;  // 1/lam[0], 1/dln in fp32: the +-31-pixel position guess of the mask probe
+  // rot_back on a geometric grid (phase_rot_back): model pixel i sits at i * bk_r of the rotation stage's grid; weight constants of
+  // f (1 + hs (f - 1)) on the 32-bit fraction F as F (bk_c1 + bk_c2 F) -- made once on the host (two fp64 divisions a thread otherwise)
+  double bk_r;
+  float bk_c1, bk_c2;
   int raw_freq;        // this launch's rows are the half transform of the spectra in pair layout (host_tables.hpp freq_rows): the output
                        // layer carried the first stage's forward transform in its weights (identity vsini maps, compile-time geometry)
 };
@@ -1397,16 +1401,36 @@ PAYNE_HD void phase_rot_resample(int tid, int nthr, const PostTables& T, const f
 // On a geometric grid with the edge rule riding along the positions are arithmetic (pixel i sits at i (n1 - 1)/(npix - 1) of the
 // stage's grid, which spans the same ends; the two end pixels -- the only ones np.interp can find outside, by a rounding of
 // exp(log(.)) -- take their neighbours' values anyway): no map loads, a phase without a global round trip.
+template <int U = kU>
 PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float* __restrict__ work,
                              float* __restrict__ spec, bool edges = false) {
   if (T.geo && edges) {
-    const double r = (double)(T.n1 - 1) / (double)(T.npix - 1);
-    const float hs = (float)(0.5 * T.dln / r);                       // half a step of the stage's grid in ln(lambda)
-    const float c1 = 2.3283064365386963e-10f * (1.0f - hs), c2 = 5.421010862427522e-20f * hs;
-    for (int base = tid; base < T.npix; base += kU * nthr) {
-      float a[kU], b[kU], F[kU];
+    const double r = T.bk_r;
+    const float c1 = T.bk_c1, c2 = T.bk_c2;
+    if (U * nthr == T.n1) {
+      // one block, U points a thread, nothing conditional: points past the last pixel are copies of it in a part of the buffer
+      // (n1 floats) that nothing reads
+      const int hi = T.npix - 2;
+      float a[U], b[U], F[U];
 #pragma unroll
-      for (int q = 0; q < kU; ++q) {
+      for (int q = 0; q < U; ++q) {
+        int i = tid + q * nthr;
+        i = i < hi ? i : hi;
+        i = i > 1 ? i : 1;
+        union { double d; unsigned long long u; } cv;
+        cv.d = fma((double)i, r, kPosMagic);
+        const int k = (int)((unsigned)(cv.u >> 32) - kPosMagicHi);
+        F[q] = (float)(unsigned)cv.u;
+        a[q] = work[k]; b[q] = work[k + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) spec[tid + q * nthr] = fmaf(b[q] - a[q], F[q] * fmaf(F[q], c2, c1), a[q]);
+      return;
+    }
+    for (int base = tid; base < T.npix; base += U * nthr) {
+      float a[U], b[U], F[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
         const int i0 = base + q * nthr;
         int i = i0 < T.npix ? i0 : T.npix - 1;
         i = (i == 0) ? 1 : ((i == T.npix - 1) ? T.npix - 2 : i);
@@ -1417,18 +1441,18 @@ PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float
         a[q] = work[k]; b[q] = work[k + 1];
       }
 #pragma unroll
-      for (int q = 0; q < kU; ++q) {
+      for (int q = 0; q < U; ++q) {
         const int i = base + q * nthr;
         if (i < T.npix) spec[i] = fmaf(b[q] - a[q], F[q] * fmaf(F[q], c2, c1), a[q]);
       }
     }
     return;
   }
-  for (int base = tid; base < T.npix; base += kU * nthr) {
-    float a[kU], b[kU], f[kU];
-    int jj[kU];
+  for (int base = tid; base < T.npix; base += U * nthr) {
+    float a[U], b[U], f[U];
+    int jj[U];
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < U; ++q) {
       const int i0 = base + q * nthr;
       int i = i0 < T.npix ? i0 : T.npix - 1;
       if (edges) i = (i == 0) ? 1 : ((i == T.npix - 1) ? T.npix - 2 : i);
@@ -1437,7 +1461,7 @@ PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float
       a[q] = work[j]; b[q] = work[j + 1];
     }
 #pragma unroll
-    for (int q = 0; q < kU; ++q) {
+    for (int q = 0; q < U; ++q) {
       const int i = base + q * nthr;
       if (i < T.npix) spec[i] = (jj[q] < 0) ? nanf_() : a[q] + (b[q] - a[q]) * f[q];
     }

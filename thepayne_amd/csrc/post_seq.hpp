@@ -277,7 +277,7 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
     if (T.rot_identity) { float* t_ = dst; dst = conv; conv = t_; }
     else {
       const bool er = rot && out_stage != 6 && T.npix >= 4;          // the edge rule rides along
-      ex.par([&](int t, int n) { phase_rot_back(t, n, T, conv, dst, er); });
+      ex.par([&](int t, int n) { phase_rot_back<UX>(t, n, T, conv, dst, er); });
       edge = rot && out_stage != 6 && !er;
     }
     spec = dst;

@@ -100,3 +100,10 @@ __global__ void __launch_bounds__(NT) census_obs_general(const PostTables T, dou
   __syncthreads();
   if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < 8; ++i) s += red[i]; out[blockIdx.x] = -0.5 * s; }
 }
+// grids that are not 2^k long: the rotation stage's way back onto the model grid (C2r)
+__global__ void __launch_bounds__(NT) census_rot_back(const PostTables T) {
+  float* a = reinterpret_cast<float*>(smem);
+  float* b = a + fft_buf_floats(4096);
+  phase_rot_back<UX>((int)threadIdx.x, NT, T, a, b, true);
+  __syncthreads();
+}
