@@ -649,9 +649,15 @@ PAYNE_HD void fft_pass_fixed(int tid, SP src, DP dst, TP twf, unsigned sign, boo
   constexpr int PO = last ? 0 : P;                                 // layout we write
   static_assert(!last || P >= 32 || M < 64, "the last pass must write the plain layout");
   static_assert(NB % 32 == 0 || PI == 0 || PI >= 32, "padded reads need NB to be a multiple of the pad period");
+  // LDS stores are banked in groups of SIXTEEN lanes over 32 dwords (MI355X_MICROARCH.md, LDS table; tools/exp/lds_floor.hip reads
+  // 4 conflict cycles on every store of the plain lane order here).  The first radix-8 pass writes slot 8 i + (i >> 2) + r: sixteen
+  // consecutive butterflies land on eight slots mod 16.  With butterfly i = [m2 m1 m0 h b] on lane [h m2 m1 m0 b] a group holds
+  // i = 4 m + 2 h + b, m = 0..7, b = 0..1: slots 8 b + m -- all sixteen; the reads stay a permutation of 32 consecutive slots.
+  int lane_i = tid;
+  if constexpr (P == 1 && R == 8 && !last) lane_i = (tid & ~31) | ((tid & 14) << 1) | ((tid >> 3) & 2) | (tid & 1);
 #pragma unroll
   for (int i0 = 0; i0 < NB; i0 += NT) {
-    const int i = i0 + tid;
+    const int i = i0 + lane_i;
     if ((NB % NT) != 0 && i >= NB) break;
     const int k = i & (P - 1);
     const int ib = fft_lay<PI, RI>(i);
@@ -812,6 +818,15 @@ PAYNE_HD void taper_pair(c32 zk, c32 zmk, c32 w, float tkg, float tmg, c32& yk, 
 }
 #endif
 
+// The two neighbours base[k], base[k + 1] of U gathered points: two 4-byte reads each (the compiler pairs them in one ds_read2_b32).
+// (Measured and dropped: ONE 8-byte read at the 4-byte-aligned address -- the hardware serves it and SQ_LDS_BANK_CONFLICT reads 0
+//  where the 4-byte reads of lanes 1.14 words apart read 2 cycles each, but it stalls on alignment instead: the post kernel went
+//  from 13.4 to 19.2 us.  tools/exp/lds_floor.hip, NOTES R5.)
+template <int U>
+PAYNE_HD void ld_pairs(const float* __restrict__ base, const unsigned (&k)[U], float (&a)[U], float (&b)[U]) {
+#pragma unroll
+  for (int q = 0; q < U; ++q) { a[q] = base[k[q]]; b[q] = base[k[q] + 1]; }
+}
 PAYNE_HD c32 ld1(const c32* p, int i) { return p[i]; }
 PAYNE_HD c32 ld1(c32* p, int i) { return p[i]; }
 PAYNE_HD void st1(c32* p, int i, c32 v) { p[i] = v; }
@@ -1412,6 +1427,7 @@ PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float
       // (n1 floats) that nothing reads
       const int hi = T.npix - 2;
       float a[U], b[U], F[U];
+      unsigned k[U];
 #pragma unroll
       for (int q = 0; q < U; ++q) {
         int i = tid + q * nthr;
@@ -1419,10 +1435,10 @@ PAYNE_HD void phase_rot_back(int tid, int nthr, const PostTables& T, const float
         i = i > 1 ? i : 1;
         union { double d; unsigned long long u; } cv;
         cv.d = fma((double)i, r, kPosMagic);
-        const int k = (int)((unsigned)(cv.u >> 32) - kPosMagicHi);
+        k[q] = (unsigned)(cv.u >> 32) - kPosMagicHi;
         F[q] = (float)(unsigned)cv.u;
-        a[q] = work[k]; b[q] = work[k + 1];
       }
+      ld_pairs<U>(work, k, a, b);
 #pragma unroll
       for (int q = 0; q < U; ++q) spec[tid + q * nthr] = fmaf(b[q] - a[q], F[q] * fmaf(F[q], c2, c1), a[q]);
       return;
@@ -1567,16 +1583,17 @@ PAYNE_HD bool R_resample_fast(int tid, int nthr, const Window& W, const float* _
   const float c1 = 2.3283064365386963e-10f * (1.0f - W.hs_ann), c2 = 5.421010862427522e-20f * W.hs_ann;
   const double tm0 = fma((double)tid, W.rsA, rsBm);
   float a[RU], b[RU], F[RU];
+  unsigned k[RU];
 #pragma unroll
   for (int q = 0; q < RU; ++q) {
     union { double d; unsigned long long u; } cv;
     cv.d = fma((double)q, rsD, tm0);
     if (q == 0) cv.d = fmax(cv.d, tlo);
     if (q == RU - 1) cv.d = fmin(cv.d, thi);
-    const int k = (int)((unsigned)(cv.u >> 32) - kPosMagicHi);
+    k[q] = (unsigned)(cv.u >> 32) - kPosMagicHi;
     F[q] = (float)(unsigned)cv.u;
-    a[q] = spec[k]; b[q] = spec[k + 1];
   }
+  ld_pairs<RU>(spec, k, a, b);
   bool nan = false;
 #pragma unroll
   for (int q = 0; q < RU; ++q) {
@@ -1711,16 +1728,17 @@ PAYNE_HD void obs_fast_issue(int nthr, const PostTables& T, int base, ObsRec (&r
 template <int OU>
 PAYNE_HD void obs_fast_block(const ObsRec (&rec)[OU], const ObsFastConsts& c, const float* __restrict__ conv, float& acc, unsigned& worst) {
   float a[OU], b[OU], F[OU];
+  unsigned k[OU];
 #pragma unroll
   for (int q = 0; q < OU; ++q) {
     union { double d; unsigned long long u; } cv;
     cv.d = fma(rec[q].lnw, c.obA, c.obBm);
     const unsigned kk = (unsigned)(cv.u >> 32) - kPosMagicHi;
     worst = kk > worst ? kk : worst;
-    const unsigned k = kk < c.kmax ? kk : c.kmax;        // (a pixel that failed: any valid address)
+    k[q] = kk < c.kmax ? kk : c.kmax;                    // (a pixel that failed: any valid address)
     F[q] = (float)(unsigned)cv.u;
-    a[q] = conv[k]; b[q] = conv[k + 1];
   }
+  ld_pairs<OU>(conv, k, a, b);
 #pragma unroll
   for (int q = 0; q < OU; ++q) {
     const float w = F[q] * fmaf(F[q], c.c2, c.c1);
