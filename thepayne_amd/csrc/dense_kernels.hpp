@@ -16,6 +16,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));   // register-residen
 struct DenseParams {
   const float* X; int ldx;     // [B][ldx] activations (ignored with FUSE_L0)
   const float* W; int K;       // [N][K] row-major, K % 4 == 0
+  // payne_dense_hidden_kernel<false>: a copy of W with rows ldwd >= HK_PITCH floats apart, zero beyond K -- with X's pitch the same
+  // and its pad columns zero, both operand tiles go from global memory straight into LDS (hk_tile; null: staged through registers)
+  const float* Wd; int ldwd;
   int k_real;                  // LDS-DMA kernel: width before zero padding (0 = K): the last k-step stops there
   const float* bias;           // [N]
   float* Y; int ldy;           // [B][ldy]
@@ -934,6 +937,36 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
     const int kn = (p.K - kc < HK_KC) ? (p.K - kc) : HK_KC;        // multiple of 4
     const int kn16 = (kn + 15) & ~15;
     const int nk4 = kn16 >> 2;
+    // ---- both tiles straight into LDS (layers past the second; K <= HK_KC, padded operands) ------------------------------
+    // The tile [32][HK_PITCH] is 39 x 1 KB: one global_load_lds_dwordx4 of a wave lands 64 consecutive 16-byte chunks, lane l of
+    // transfer j bringing chunk s = 64 j + l = (row s / 78, k 4 (s % 78)) -- the SAME layout the register-staged form stores, its
+    // pad columns (k >= 304) filled with zeros of the operands' own padding instead of being skipped.  No staging registers, no
+    // 24 ds_write_b128 a thread; rows past the operand's end are clamped (their outputs are never stored).
+    bool staged = false;
+    if constexpr (!FUSE_L0) {
+      if (p.Wd != nullptr) {                                        // (uniform)
+        static_assert((32 * HK_PITCH / 4) % 64 == 0, "whole transfers");
+        constexpr int NCH = HK_PITCH / 4, NTR = 32 * NCH / 64;       // chunks a row (78), transfers a tile (39)
+#pragma unroll
+        for (int j0 = 0; j0 < NTR; j0 += 4) {
+          const int j = j0 + wave;
+          if (j < NTR) {                                            // (wave-uniform)
+            const int sl = 64 * j + lane, rr = sl / NCH, c4 = sl - rr * NCH;
+            const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1, mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wd + (size_t)nr * p.ldwd + 4 * c4),
+                                             (__attribute__((address_space(3))) void*)(Bs + 256 * j), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.X + (size_t)mr * p.ldx + 4 * c4),
+                                             (__attribute__((address_space(3))) void*)(As + 256 * j), 16, 0, 0);
+          }
+        }
+        HK_STAMP(1);
+        HK_STAMP(2);
+        HK_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my pieces have landed (and the bias values are here)
+        staged = true;
+      }
+    }
+    if (!staged) {
     // ---- stage B (weights) and A (activations or the fused first layer) -------------------
     // every global load of the chunk is issued before the first LDS store (a load->store loop
     // would pay one L2 latency per iteration)
@@ -1042,6 +1075,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
         if (!FUSE_L0) *reinterpret_cast<f32x4_t*>(&As[rr * HK_PITCH + 4 * k4]) = (kok && m0 + rr < p.B) ? va[it] : z4;
       }
     }
+    }   // (!staged)
     __syncthreads();
     HK_STAMP(3);
     // ---- the four waves split the K steps of this chunk -------------------------------------

@@ -69,6 +69,7 @@ struct payne_ctx {
   int ld_hid = 0;
   float* raw = nullptr;
   const float* w_out_pad = nullptr;     // output layer's weights [N][w_out_kp], k zero-padded to a multiple of 32 (LDS-DMA kernel)
+  const float* w_hid_pad[PAYNE_MAX_LAYERS] = {};   // hidden layers past the second: [N][ld_hid] copies, zero beyond K (hk_tile's LDS-DMA staging)
   int w_out_kp = 0;
   bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
   // 3 x bf16 planes for payne_dense_dma3_kernel: the output layer's weights [3][N][w_out_kp], the last hidden layer's output
@@ -333,6 +334,21 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       bool same = model->n_layers >= 3;
       for (int l = 1; l + 1 < model->n_layers; ++l) same = same && model->layers[l].n_out == model->layers[0].n_out;
       c->dma_ok = same;
+      // hidden layers past the second (launch_hidden<false>): operand tiles straight into LDS need rows >= HK_PITCH floats apart that
+      // may be read to their end -- the activations' buffers are (pitch ld_hid, pad columns zero while all widths are equal); the
+      // weights get a copy with the same pitch
+      const int ldh = (maxh + 31) & ~31;
+      if (same && ldh >= HK_PITCH) {
+        for (int l = 2; l + 1 < model->n_layers; ++l) {
+          const payne_layer& Lh = c->layers[l];
+          if (Lh.n_in > HK_KC) continue;
+          float* wh = nullptr;
+          if ((rc = dev_alloc(c, (size_t)Lh.n_out * ldh, &wh, c->owned))) return bail(rc);
+          he = hipMemcpy2D(wh, (size_t)ldh * 4, Lh.w, (size_t)Lh.n_in * 4, (size_t)Lh.n_in * 4, Lh.n_out, hipMemcpyDeviceToDevice);
+          if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy2D: ") + hipGetErrorString(he)));
+          c->w_hid_pad[l] = wh;
+        }
+      }
       if (same) {
         const size_t nw = (size_t)L.n_out * Kp;
         if ((rc = dev_alloc(c, 3 * nw, &c->w_out_p3, c->owned))) return bail(rc);
@@ -798,6 +814,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     } else {
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
+      if (!last && N.spectral && c->w_hid_pad[l] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[l]; p.ldwd = N.ld_hid; }
       if (!last) launch_hidden<false>(p, pa, s);
       else if (use3) {
         if (N.freq && c->freq_rs_now) {                      // rows of the resampled grid; pixels if the batch's records say so
