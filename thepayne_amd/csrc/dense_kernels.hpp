@@ -966,6 +966,99 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
         staged = true;
       }
     }
+    // ---- first launch of a net: the weight tile the same way, the fused first layer WITHOUT LDS until the tile has landed ---------
+    // (a wave's DS operations queue behind its own global_load_lds transfers: a label exchange through LDS, as in the staged form
+    //  below, would wait for the whole tile.)  Every lane fetches the labels of its own A fragment -- rows 16 i + r, labels
+    // 4 lg + g -- and encodes them itself (the same fp64 expression), the layer's MFMAs and activations fill registers, and the
+    // A tile is written once the transfers are in: what the staged form spends on 12 ds_write_b128 a thread after the layer
+    // (1 750 of the workgroup's 12 500 cycles) is gone.
+    if constexpr (FUSE_L0) {
+      if (p.Wd != nullptr && kc == 0 && p.K <= HK_KC) {             // (uniform)
+        constexpr int NLG = (NL + 3) / 4, MAXT = (HK_KC / 16 + 3) / 4;
+        constexpr int NCH = HK_PITCH / 4, NTR = 32 * NCH / 64;
+        const int ntile = kn16 >> 4;
+        double xl[2][NLG];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (m0 + 16 * i + r < p.B) ? m0 + 16 * i + r : p.B - 1;
+#pragma unroll
+          for (int lg = 0; lg < NLG; ++lg) { const int d = 4 * lg + g; xl[i][lg] = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)]; }
+        }
+        float w0t[MAXT][NLG], bzt[MAXT];
+#pragma unroll
+        for (int tt = 0; tt < MAXT; ++tt) {
+          const int tcol = wave + 4 * tt;
+          const int k = 16 * (tcol < ntile ? tcol : 0) + r;
+          const int kq = k < p.K0 ? k : p.K0 - 1;
+          bzt[tt] = p.b0[kq];
+#pragma unroll
+          for (int lg = 0; lg < NLG; ++lg) {
+            const int d = 4 * lg + g;
+            const float w = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];
+            w0t[tt][lg] = (d < p.n_labels) ? w : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < NTR; j0 += 4) {
+          const int j = j0 + wave;
+          if (j < NTR) {
+            const int sl = 64 * j + lane, rr = sl / NCH, c4 = sl - rr * NCH;
+            const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wd + (size_t)nr * p.ldwd + 4 * c4),
+                                             (__attribute__((address_space(3))) void*)(Bs + 256 * j), 16, 0, 0);
+          }
+        }
+        HK_STAMP(1);
+        float xa[2][NLG];
+#pragma unroll
+        for (int lg = 0; lg < NLG; ++lg) {
+          double xm = p.xmin[4 * lg < PAYNE_MAX_LABELS ? 4 * lg : 0], xdn = p.xden[4 * lg < PAYNE_MAX_LABELS ? 4 * lg : 0];
+#pragma unroll
+          for (int e = 1; e < 4; ++e) {
+            if (4 * lg + e < PAYNE_MAX_LABELS) { xm = (g == e) ? p.xmin[4 * lg + e] : xm; xdn = (g == e) ? p.xden[4 * lg + e] : xdn; }
+          }
+          const bool dl = 4 * lg + g < p.n_labels;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            xa[i][lg] = (dl && m0 + 16 * i + r < p.B) ? (float)((xl[i][lg] - xm) / xdn - 0.5) : 0.f;
+        }
+        HK_STAMP(2);
+        float zr[MAXT][2][4];
+        auto first_layer_regs = [&](auto actf) {
+#pragma unroll
+          for (int tt = 0; tt < MAXT; ++tt) {
+            const int tcol = wave + 4 * tt;
+            if (tcol < ntile) {             // (wave-uniform)
+              const bool live = (16 * tcol + r) < p.K0;
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                f32x4_t z = (f32x4_t){bzt[tt], bzt[tt], bzt[tt], bzt[tt]};
+#pragma unroll
+                for (int lg = 0; lg < NLG; ++lg) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][lg], w0t[tt][lg], z, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zr[tt][i][q] = live ? actf(z[q]) : 0.f;
+              }
+            }
+          }
+        };
+        if (p.act0 == PAYNE_ACT_LRELU) first_layer_regs([](float z) { return lrelu01(z); });
+        else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer_regs([](float z) { return 1.0f / (1.0f + expf(-z)); });
+        else first_layer_regs([](float z) { return z; });
+        HK_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my pieces of the weight tile have landed
+        float* const arow = As + (4 * g) * HK_PITCH + 16 * wave + r;
+#pragma unroll
+        for (int tt = 0; tt < MAXT; ++tt) {
+          if (wave + 4 * tt < ntile) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) arow[(16 * i + q) * HK_PITCH + 64 * tt] = zr[tt][i][q];
+          }
+        }
+        staged = true;
+      }
+    }
     if (!staged) {
     // ---- stage B (weights) and A (activations or the fused first layer) -------------------
     // every global load of the chunk is issued before the first LDS store (a load->store loop
@@ -1079,24 +1172,35 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
     __syncthreads();
     HK_STAMP(3);
     // ---- the four waves split the K steps of this chunk -------------------------------------
+    // (every fragment of the wave's K steps requested before its first matrix instruction -- five steps, 80 registers that the
+    //  staging has just freed: a load -> 16 MFMA -> load loop exposed one LDS round trip per step, 3 600 cycles for 2 560 of MFMA)
     const int steps = kn16 >> 4;
-    for (int s = wave; s < steps; s += 4) {
-      const int k = s * 16 + 4 * g;
-      f32x4_t a[2], b[2];
+    constexpr int MAXS = (HK_KC / 16 + 3) / 4;
+    f32x4_t fa[MAXS][2], fb[MAXS][2];
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) {
+      const int sx = wave + 4 * u;
+      const int k = (sx < steps ? sx : 0) * 16 + 4 * g;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const f32x4_t*>(&As[(16 * i + r) * HK_PITCH + k]);
-        b[i] = *reinterpret_cast<const f32x4_t*>(&Bs[(16 * i + r) * HK_PITCH + k]);
+        fa[u][i] = *reinterpret_cast<const f32x4_t*>(&As[(16 * i + r) * HK_PITCH + k]);
+        fb[u][i] = *reinterpret_cast<const f32x4_t*>(&Bs[(16 * i + r) * HK_PITCH + k]);
       }
+    }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int u = 0; u < MAXS; ++u) {
+      if (wave + 4 * u < steps) {                                   // (wave-uniform)
+        // (the four accumulators take turns: back-to-back instructions on ONE accumulator issue 40 cycles apart, on different
+        //  ones 32 -- v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md; each accumulator still adds its k in the same order)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][i][e], fb[u][j][e], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
   };

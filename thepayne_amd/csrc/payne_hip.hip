@@ -69,7 +69,7 @@ struct payne_ctx {
   int ld_hid = 0;
   float* raw = nullptr;
   const float* w_out_pad = nullptr;     // output layer's weights [N][w_out_kp], k zero-padded to a multiple of 32 (LDS-DMA kernel)
-  const float* w_hid_pad[PAYNE_MAX_LAYERS] = {};   // hidden layers past the second: [N][ld_hid] copies, zero beyond K (hk_tile's LDS-DMA staging)
+  const float* w_hid_pad[PAYNE_MAX_LAYERS] = {};   // hidden layers: [N][ld_hid] copies, zero beyond K (hk_tile's LDS-DMA staging)
   int w_out_kp = 0;
   bool dma_ok = false;                  // hidden buffers are zero beyond the last hidden width
   // 3 x bf16 planes for payne_dense_dma3_kernel: the output layer's weights [3][N][w_out_kp], the last hidden layer's output
@@ -339,7 +339,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
       // weights get a copy with the same pitch
       const int ldh = (maxh + 31) & ~31;
       if (same && ldh >= HK_PITCH) {
-        for (int l = 2; l + 1 < model->n_layers; ++l) {
+        for (int l = 1; l + 1 < model->n_layers; ++l) {
           const payne_layer& Lh = c->layers[l];
           if (Lh.n_in > HK_KC) continue;
           float* wh = nullptr;
@@ -809,6 +809,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         pa.spec_walk = static_cast<const WalkTail*>(c->spec_walk); pa.spec_w = *static_cast<const WalkState*>(c->spec_w);
         pa.spec_step = c->spec_step; c->spec_launched = true;
       }
+      if (!last && N.spectral && c->w_hid_pad[1] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[1]; p.ldwd = N.ld_hid; }
       if (last) launch_dense<64, 64, 32, true>(p, s);
       else { launch_hidden<true>(p, pa, s, c->n_cu, spec ? c->spec_K : 0); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
