@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--phot", action="store_true", help="joint fit with seven synthetic broad-band magnitudes")
     ap.add_argument("--dynamic", action="store_true", help="samplertype 'Dynamic' instead of 'Static'")
+    ap.add_argument("--host-turn", action="store_true",
+                    help="sampler['pipeline'] = 'host': the turn between two proposal queues on the host (the default makes it on the GPU)")
     ap.add_argument("--device-turn", action="store_true",
                     help="sampler['pipeline'] = 'device': the live set on the GPU, the turn between two proposal queues made there (static sampler)")
     ap.add_argument("--npix", type=int, default=4096)
@@ -76,6 +78,8 @@ def main():
                             'delta_logz_final': 0.1, 'bootstrap': 0, 'walks': 25, 'maxbatch': 4}
     if a.device_turn and not a.dynamic:
         inputdict['sampler']['pipeline'] = 'device'
+    if a.host_turn and not a.dynamic:
+        inputdict['sampler']['pipeline'] = 'host'
     inputdict['priordict'] = synth.demo_priordict()
     inputdict['priordict']['Teff'] = {'pv_uniform': [5000.0, 6500.0]}
     if a.phot:

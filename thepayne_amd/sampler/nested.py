@@ -205,6 +205,8 @@ class NestedSampler(object):
         dev_ok = sample == 'rwalk' and hasattr(proposer, "queue_dev_launch") and native and self.nlive + self.queue_size <= 2048
         if pipeline is None and dev_ok:
             pipeline = 'device'
+        if isinstance(pipeline, str) and pipeline == 'host':           # the same queues with the turn on the host
+            pipeline = True
         self._dev_turn = isinstance(pipeline, str) and pipeline == 'device'
         if self._dev_turn:
             if not dev_ok:
