@@ -128,10 +128,11 @@ def _fp64_forward(net, lab):
 
 
 @pytest.mark.parametrize("H,npix,B,D", [(16, 160, 1, 4), (40, 1000, 63, 4), (64, 1029, 65, 4), (100, 4101, 130, 4),
-                                        (300, 777, 200, 5), (320, 2048, 64, 4), (352, 1500, 100, 4)])
+                                        (300, 777, 200, 5), (296, 640, 70, 4), (304, 515, 33, 4), (320, 2048, 64, 4), (352, 1500, 100, 4)])
 def test_dense_layers_on_odd_shapes(Engine, H, npix, B, D):
     """Ragged sizes through every form of the dense layers: hidden widths that are / are not multiples of 32 (one, two,
-    ten, eleven k-steps; 352 > 320 takes the chunked hidden layers), pixel counts that are not multiples of the 128-column
+    ten, eleven k-steps; 296 / 300 / 304: the widths whose operand tiles go straight into LDS, K a multiple of 16 or not; 320 and 352
+    take the register-staged tiles, 352 in two chunks), pixel counts that are not multiples of the 128-column
     tile, batches around the 64-row tile, the fifth label.  Output of the network (stage 0) against fp64."""
     from thepayne_amd import _lib
     raw = synth.make_yst_net(npix=npix, H=H, seed=H + npix, D=D)

@@ -899,16 +899,8 @@ struct PrepArgs {
 };
 
 // One 32 x 32 tile of a hidden layer by the first 256 threads of the workgroup (`tile`: index in the launch's grid_m x grid_n).
-// ACT256: the workgroup has MORE than 256 threads (payne_dense_fused_kernel): the others only meet the barriers.  PUB: the
-// tile is handed to other workgroups of the SAME launch: its bf16 planes are stored write-through (agent scope).
-template <bool FUSE_L0, int NL, bool PUB>
+template <bool FUSE_L0, int NL>
 __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, const int tid) {
-  const bool act = !PUB || tid < 256;
-  if (!act) {                                  // the barrier sequence of one K chunk below (PUB tiles have K <= HK_KC)
-    if (FUSE_L0) lds_barrier();
-    __syncthreads(); __syncthreads(); __syncthreads();
-    return;
-  }
   HK_STAMP(0);
   float* As = hk_sm;
   float* Bs = As + 32 * HK_PITCH;
@@ -1237,11 +1229,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
         split3(y[0], h3[0], m3[0], l3[0]);
         split3(y[1], h3[1], m3[1], l3[1]);
         const size_t o = (size_t)row * p.ldp + col;
-        if (PUB && two && pairs_ok) {                              // read by other workgroups of this launch: write-through (sc1)
-          __hip_atomic_store(reinterpret_cast<unsigned*>(&p.Yp[o]), (unsigned)h3[0] | ((unsigned)h3[1] << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]), (unsigned)m3[0] | ((unsigned)m3[1] << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]), (unsigned)l3[0] | ((unsigned)l3[1] << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (two && pairs_ok) {                              // (streamed: the next reader is another XCD)
+        if (two && pairs_ok) {                              // (streamed: the next reader is another XCD)
           __builtin_nontemporal_store((unsigned)h3[0] | ((unsigned)h3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
           __builtin_nontemporal_store((unsigned)m3[0] | ((unsigned)m3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
           __builtin_nontemporal_store((unsigned)l3[0] | ((unsigned)l3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]));
@@ -1284,7 +1272,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     }
     return;
   }
-  hk_tile<FUSE_L0, NL, false>(p, (int)blockIdx.x, hk_sm, (int)threadIdx.x);
+  hk_tile<FUSE_L0, NL>(p, (int)blockIdx.x, hk_sm, (int)threadIdx.x);
 }
 
 
