@@ -673,7 +673,7 @@ def test_turn_on_the_device_is_the_same_run_statistically():
     between two proposal queues on the host, on the C2 fit (4096-pixel network, 3600 observed pixels, 512 live points, 25-step
     random walks, multi-ellipsoid metric), to dlogz = 0.5 + the final live points.  Thresholds, all stated:
       * ln Z: the two means differ by less than three standard errors of the difference (from the seeds' own scatter) + 0.05;
-        each loop's scatter over seeds is within a factor 1.6 of the other's and of the runs' own quoted error;
+        each loop's scatter over seeds is within a factor 2 of the other's and of the runs' own quoted error;
       * every parameter: posterior means differ by less than 0.15 posterior sigma (mean over seeds; three standard errors of the
         seed scatter allowed on top), posterior widths agree within 10 %;
       * the device loop never re-uploaded its live set (`_dev_desync == 0`), and the default loop IS the device loop."""
@@ -714,7 +714,9 @@ def test_turn_on_the_device_is_the_same_run_statistically():
     se = np.sqrt(d["logz"].var(ddof=1) / nseed + h["logz"].var(ddof=1) / nseed)
     assert abs(d["logz"].mean() - h["logz"].mean()) < 3.0 * se + 0.05, (d["logz"].mean(), h["logz"].mean(), se)
     sd, sh, quoted = d["logz"].std(ddof=1), h["logz"].std(ddof=1), np.concatenate([d["err"], h["err"]]).mean()
-    assert 1 / 1.6 < sd / sh < 1.6 and 1 / 1.6 < sd / quoted < 1.6 and 1 / 1.6 < sh / quoted < 1.6, (sd, sh, quoted)
+    # (two sample scatters of twenty runs each: their ratio is sqrt(F(19, 19)) -- outside [1/2, 2] once in ~400 draws; the runs are
+    #  deterministic for a build, but any change of rounding anywhere in the likelihood redraws them)
+    assert 1 / 2.0 < sd / sh < 2.0 and 1 / 2.0 < sd / quoted < 2.0 and 1 / 2.0 < sh / quoted < 2.0, (sd, sh, quoted)
     sig = 0.5 * (d["sig"].mean(axis=0) + h["sig"].mean(axis=0))
     dm = np.abs(d["mean"].mean(axis=0) - h["mean"].mean(axis=0))
     sem = np.sqrt(d["mean"].var(axis=0, ddof=1) / nseed + h["mean"].var(axis=0, ddof=1) / nseed)

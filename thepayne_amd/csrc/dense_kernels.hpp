@@ -908,19 +908,19 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
   const int tm = tile / p.grid_n, tn = tile - tm * p.grid_n;
   const int m0 = tm * 32, n0 = tn * 32;
   const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-  f32x4_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // Wave w owns the 16 x 16 quadrant (rows 16 (w >> 1), columns 16 (w & 1)) of the tile over the WHOLE K extent: no partial tiles
+  // to sum through LDS afterwards (as first written the four waves split K: 16 ds_write + a barrier + 8 ds_read a thread at the
+  // end of every workgroup's life).  Two accumulators take turns, so that consecutive matrix instructions never wait for each other.
+  const int qi = wave >> 1, qj = wave & 1;
+  f32x4_t acc[2];
+  acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // the epilogue's two bias values (thread -> columns 2 (tid & 15), + 1 of the tile, in both of its trips): requested now --
-  // asked for in the epilogue they are one more memory round trip at the end of the workgroup's life
-  float bias2[2];
+  // the epilogue's bias value (lane -> column 16 qj + r of the tile): requested now -- asked for in the epilogue it is one more
+  // memory round trip at the end of the workgroup's life
+  float bias1;
   {
-    const int c0 = n0 + 2 * (tid & 15);
-    bias2[0] = p.bias[c0 < p.N ? c0 : p.N - 1];
-    bias2[1] = p.bias[c0 + 1 < p.N ? c0 + 1 : p.N - 1];
+    const int c0 = n0 + 16 * qj + r;
+    bias1 = p.bias[c0 < p.N ? c0 : p.N - 1];
   }
 
   // one K chunk; the usual single-chunk case (K <= 320) is called outside any loop: around a loop the
@@ -1163,79 +1163,86 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
     }   // (!staged)
     __syncthreads();
     HK_STAMP(3);
-    // ---- the four waves split the K steps of this chunk -------------------------------------
-    // (every fragment of the wave's K steps requested before its first matrix instruction -- five steps, 80 registers that the
-    //  staging has just freed: a load -> 16 MFMA -> load loop exposed one LDS round trip per step, 3 600 cycles for 2 560 of MFMA)
+    // ---- the wave's quadrant over this chunk's K steps ------------------------------------------
+    // (the fragments of ten steps requested before their first matrix instruction, twice: 80 registers -- all nineteen at once
+    //  were 152 and cost the 5-label and the later-layer instantiations their second workgroup per CU)
     const int steps = kn16 >> 4;
-    constexpr int MAXS = (HK_KC / 16 + 3) / 4;
-    f32x4_t fa[MAXS][2], fb[MAXS][2];
+    constexpr int MAXS = HK_KC / 16, HALF = (MAXS + 1) / 2;
 #pragma unroll
-    for (int u = 0; u < MAXS; ++u) {
-      const int sx = wave + 4 * u;
-      const int k = (sx < steps ? sx : 0) * 16 + 4 * g;
+    for (int hb = 0; hb < 2; ++hb) {
+      f32x4_t fa[HALF], fb[HALF];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[u][i] = *reinterpret_cast<const f32x4_t*>(&As[(16 * i + r) * HK_PITCH + k]);
-        fb[u][i] = *reinterpret_cast<const f32x4_t*>(&Bs[(16 * i + r) * HK_PITCH + k]);
+      for (int u = 0; u < HALF; ++u) {
+        const int sx = hb * HALF + u;
+        const int k = (sx < steps ? sx : 0) * 16 + 4 * g;
+        fa[u] = *reinterpret_cast<const f32x4_t*>(&As[(16 * qi + r) * HK_PITCH + k]);
+        fb[u] = *reinterpret_cast<const f32x4_t*>(&Bs[(16 * qj + r) * HK_PITCH + k]);
       }
-    }
 #pragma unroll
-    for (int u = 0; u < MAXS; ++u) {
-      if (wave + 4 * u < steps) {                                   // (wave-uniform)
-        // (the four accumulators take turns: back-to-back instructions on ONE accumulator issue 40 cycles apart, on different
-        //  ones 32 -- v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md; each accumulator still adds its k in the same order)
+      for (int u = 0; u < HALF; ++u) {
+        if (hb * HALF + u < steps && hb * HALF + u < MAXS) {        // (uniform)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][i][e], fb[u][j][e], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 4; ++e) acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][e], fb[u][e], acc[e & 1], 0, 0, 0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   };
   if (p.K <= HK_KC) chunk(0);
   else for (int kc = 0; kc < p.K; kc += HK_KC) chunk(kc);
   HK_STAMP(4);
-  // ---- sum the four partial tiles (C/D map: col = lane&15, row = 4*(lane>>4) + reg) ------------
-  float* Red = As;                                               // [4][32][33]
+  // ---- epilogue straight from the accumulators (C/D map: column r, rows 4 g + q of the quadrant) ----------------------
+  // Neighbouring lanes hold neighbouring columns: lane pairs swap half of their rows (DPP), so that every lane ends up with two
+  // adjacent columns of two rows -- 8-byte stores of the fp32 tile, 4-byte stores of each bf16 plane, as before, without LDS.
+  {
+    float y[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Red[(wave * 32 + 16 * i + 4 * g + q) * 33 + 16 * j + r] = acc[i][j][q];
-  __syncthreads();
-  // two adjacent columns per thread: 8-byte stores of the fp32 tile, 4-byte stores of each bf16 plane
-  const bool pairs_ok = ((p.ldy | n0) & 1) == 0 && (!p.Yp || (p.ldp & 1) == 0);
-  for (int idx = tid; idx < 32 * 16; idx += 256) {
-    const int rr = idx >> 4, cc = 2 * (idx & 15), row = m0 + rr, col = n0 + cc;
-    if (row < p.B && col < p.N) {
-      float y[2];
+    for (int q = 0; q < 4; ++q) y[q] = act_apply((acc[0][q] + acc[1][q]) + (bias1 - p.bias_shift), p.act);
+    const bool pairs_ok = ((p.ldy | n0) & 1) == 0 && (!p.Yp || (p.ldp & 1) == 0);
+    const int colq = n0 + 16 * qj + r, row0 = m0 + 16 * qi + 4 * g;
+    if (pairs_ok) {
+      const bool oddl = (r & 1) != 0;
+      // even lane keeps rows 0, 1 and gets the odd lane's; odd lane keeps rows 2, 3 and gets the even lane's
+      const float s0 = oddl ? y[0] : y[2], s1 = oddl ? y[1] : y[3];
+      const float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
+      float pa_[2], pb_[2];                                          // (column, column + 1) of the lane's two rows
+      pa_[0] = oddl ? t0 : y[0]; pb_[0] = oddl ? y[2] : t0;
+      pa_[1] = oddl ? t1 : y[1]; pb_[1] = oddl ? y[3] : t1;
+      const int col = colq & ~1;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float v = Red[rr * 33 + cc + e] + Red[(32 + rr) * 33 + cc + e] + Red[(64 + rr) * 33 + cc + e] + Red[(96 + rr) * 33 + cc + e];
-        y[e] = act_apply(v + (bias2[e] - p.bias_shift), p.act);
+        const int row = row0 + (oddl ? 2 : 0) + e;
+        if (row < p.B && col < p.N) {
+          const bool two = col + 1 < p.N;
+          if (!p.Yp) {
+            float* yo = &p.Y[(size_t)row * p.ldy + col];
+            if (two) *reinterpret_cast<float2*>(yo) = make_float2(pa_[e], pb_[e]); else yo[0] = pa_[e];
+          } else {                                                   // three bf16 parts for payne_dense_dma3_kernel (its only reader)
+            unsigned short h3[2], m3[2], l3[2];
+            split3(pa_[e], h3[0], m3[0], l3[0]);
+            split3(pb_[e], h3[1], m3[1], l3[1]);
+            const size_t o = (size_t)row * p.ldp + col;
+            if (two) {                                               // (streamed: the next reader is another XCD)
+              __builtin_nontemporal_store((unsigned)h3[0] | ((unsigned)h3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
+              __builtin_nontemporal_store((unsigned)m3[0] | ((unsigned)m3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
+              __builtin_nontemporal_store((unsigned)l3[0] | ((unsigned)l3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]));
+            } else { p.Yp[o] = h3[0]; p.Yp[p.plane_y + o] = m3[0]; p.Yp[2 * p.plane_y + o] = l3[0]; }
+          }
+        }
       }
-      const bool two = col + 1 < p.N;
-      float* yo = &p.Y[(size_t)row * p.ldy + col];
-      if (p.Yp) { /* the only reader of this layer's output is the output layer, and it reads the planes */ }
-      else if (two && pairs_ok) *reinterpret_cast<float2*>(yo) = make_float2(y[0], y[1]);
-      else { yo[0] = y[0]; if (two) yo[1] = y[1]; }
-      if (p.Yp) {                                                  // ... and as three bf16 parts for payne_dense_dma3_kernel
-        unsigned short h3[2], m3[2], l3[2];
-        split3(y[0], h3[0], m3[0], l3[0]);
-        split3(y[1], h3[1], m3[1], l3[1]);
-        const size_t o = (size_t)row * p.ldp + col;
-        if (two && pairs_ok) {                              // (streamed: the next reader is another XCD)
-          __builtin_nontemporal_store((unsigned)h3[0] | ((unsigned)h3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
-          __builtin_nontemporal_store((unsigned)m3[0] | ((unsigned)m3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
-          __builtin_nontemporal_store((unsigned)l3[0] | ((unsigned)l3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]));
-        } else {
-          p.Yp[o] = h3[0]; p.Yp[p.plane_y + o] = m3[0]; p.Yp[2 * p.plane_y + o] = l3[0];
-          if (two) { p.Yp[o + 1] = h3[1]; p.Yp[p.plane_y + o + 1] = m3[1]; p.Yp[2 * p.plane_y + o + 1] = l3[1]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + q;
+        if (row < p.B && colq < p.N) {
+          if (!p.Yp) p.Y[(size_t)row * p.ldy + colq] = y[q];
+          else {
+            unsigned short h3, m3, l3;
+            split3(y[q], h3, m3, l3);
+            const size_t o = (size_t)row * p.ldp + colq;
+            p.Yp[o] = h3; p.Yp[p.plane_y + o] = m3; p.Yp[2 * p.plane_y + o] = l3;
+          }
         }
       }
     }
