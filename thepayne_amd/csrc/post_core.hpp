@@ -1210,10 +1210,17 @@ PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr
   // the whole row is requested before anything is computed (clamped column for the coefficients past npoly: a guarded
   // load is a branch and a wait of its own, fifteen round trips in a row as first written -- and the two workgroups that
   // run this are the last of the hidden-layer launch to finish)
+  // (one thread per candidate: every load instruction of a wave touches 64 rows = 64 cache lines, ~100 cycles of the memory pipe
+  //  each -- a fit without a blaze polynomial asks for three values, not fifteen)
   const double rv = th[4], vrot = th[5], r_in = th[7];
   double pc[12];
+  if (T.npoly > 0) {                                                  // (uniform)
 #pragma unroll
-  for (int i = 0; i < 12; ++i) pc[i] = th[i < T.npoly ? 8 + i : 7];     // (column 7 exists in every row)
+    for (int i = 0; i < 12; ++i) pc[i] = th[i < T.npoly ? 8 + i : 7];   // (column 7 exists in every row)
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pc[i] = 0.0;
+  }
   S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;       // ystpred.py:228-232
   S.dop = log(S.one_plus);
   S.do_rot = (vrot != 0.0);                                         // ystpred.py:214 (NaN passes)
