@@ -1254,20 +1254,22 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
 template <bool FUSE_L0, int NL>
 __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p, const PrepArgs pa) {
   extern __shared__ __attribute__((aligned(16))) float hk_sm[];
-  if ((int)blockIdx.x >= pa.n_gemm) {
+  // Order of the launch's workgroups = order of dispatch: the walk's proposals made ahead (the longest-lived workgroups of the launch:
+  // ~1 200 dependent fp64 instructions a wave) first, then the record writers, then the GEMM tiles, then the photometric tiles.
+  const int front = pa.n_spec + pa.n_prep, bx = (int)blockIdx.x;
+  if (bx < front || bx >= front + pa.n_gemm) {
     if constexpr (FUSE_L0) {
-      const int x = (int)blockIdx.x - pa.n_gemm;
-      if (x < pa.n_prep) {
-        const int cand = x * 256 + (int)threadIdx.x;
+      if (bx < pa.n_spec) {
+        const int w = bx * 4 + (int)(threadIdx.x >> 6);
+        if (pa.spec_walk) rwalk_spec_wave(pa.spec_walk->sd, pa.spec_w, w, (int)threadIdx.x & 63, pa.spec_step);
+      } else if (bx < front) {
+        const int cand = (bx - pa.n_spec) * 256 + (int)threadIdx.x;
         if (pa.out && cand < p.B) {
           prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
           if (pa.rot_flag && !pa.out[cand].do_rot) *pa.rot_flag = pa.rot_seq;       // (every writer writes the same value)
         }
-      } else if (x >= pa.n_prep + pa.n_sed) {
-        const int w = (x - pa.n_prep - pa.n_sed) * 4 + (int)(threadIdx.x >> 6);
-        if (pa.spec_walk) rwalk_spec_wave(pa.spec_walk->sd, pa.spec_w, w, (int)threadIdx.x & 63, pa.spec_step);
       } else if (pa.sed_mags) {
-        const int j = x - pa.n_prep, f = j % pa.P.F, blk = j / pa.P.F;
+        const int j = bx - front - pa.n_gemm, f = j % pa.P.F, blk = j / pa.P.F;
 #ifdef PAYNE_STAMPS
         unsigned long long* st = p.stamps ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
 #else
@@ -1279,7 +1281,10 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams 
     }
     return;
   }
-  hk_tile<FUSE_L0, NL>(p, (int)blockIdx.x, hk_sm, (int)threadIdx.x);
+#ifdef PAYNE_STAMPS
+  if (p.stamps) p.stamps -= (size_t)front * 16;                    // (diagnostic build: row = GEMM tile)
+#endif
+  hk_tile<FUSE_L0, NL>(p, bx - front, hk_sm, (int)threadIdx.x);
 }
 
 
