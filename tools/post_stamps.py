@@ -64,12 +64,6 @@ for rep in range(3):
 n = int(st[0, 0])
 whole = st[:, ROW - 1].astype(np.int64) - st[:, 1].astype(np.int64)
 print("whole kernel per candidate (first stamp -> kernel end): median %d cycles" % np.median(whole))
-# the launch itself: how far apart the workgroups of one XCD (workgroup index mod 8) start and end.  (s_memtime is per XCD.)
-first, last = st[:, 1].astype(np.int64), st[:, ROW - 1].astype(np.int64)
-for x in range(8):
-    f, l = first[x::8], last[x::8]
-    print("  XCD %d: %3d workgroups, starts spread over %6d cycles, ends over %6d, first start -> last end %6d (a workgroup's life: median %d)"
-          % (x, len(f), f.max() - f.min(), l.max() - l.min(), l.max() - f.min(), np.median(l - f)))
 if os.environ.get("PAYNE_DIAG_SPARSE"):
     sys.exit(0)
 d = np.diff(st[:, 1:n + 1].astype(np.int64), axis=1)
@@ -93,14 +87,13 @@ try:
     used = hs[:, 5] > 0
     h = hs[used].astype(np.int64)
     print("hidden kernel: %d workgroups stamped" % used.sum())
-    t0 = h[:, 0].min()
-    print("  entry spread (first..last workgroup start): %d cycles" % (h[:, 0].max() - t0))
+    # (the counter is per XCD: stamps of different workgroups are not comparable, only the differences inside one)
     order = [0, 1, 2, 6, 3, 4, 5]          # slot 6 = first layer done (added later, between 2 and 3)
     for (a_, b_), name in zip(zip(order[:-1], order[1:]), ["loads issued", "labels in LDS", "first layer computed",
                                                            "weight tile stored", "MFMA done", "end"]):
         dlt = h[:, b_] - h[:, a_]
         print("  %-26s median %6d  p90 %6d" % (name, np.median(dlt), np.percentile(dlt, 90)))
-    print("  whole workgroup median %d ; first start -> last end %d cycles" % (np.median(h[:, 5] - h[:, 0]), h[:, 5].max() - t0))
+    print("  whole workgroup median %d cycles" % np.median(h[:, 5] - h[:, 0]))
 except AttributeError:
     pass
 
@@ -124,11 +117,5 @@ except Exception as e:
 try:
     whole = h[:, 15] - h[:, 0]
     print("  whole workgroup p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(whole, [10, 50, 90, 100])))
-    idx = np.nonzero(used)[0]
-    for x in range(8):                      # blocks b, b+8, ... share an XCD (and its clock counter)
-        sel = (idx % 8) == x
-        t0 = h[sel, 0].min()
-        print("  XCD %d: %3d workgroups, starts spread over %6d cycles, last end at %6d" %
-              (x, sel.sum(), h[sel, 0].max() - t0, h[sel, 15].max() - t0))
 except Exception as e:
     print("dense stamps (2) failed:", e)
