@@ -460,6 +460,37 @@ def test_spectra_larger_than_lds_vs_oracle(Engine, variant):
         assert np.abs(s1 - r1).max() <= FLUX_TOL
 
 
+def test_observed_grid_on_the_compute_unit_and_its_fallbacks(Engine):
+    """65 536-point spectra, likelihood only: the instrumental stage interpolates onto the observed grid from LDS, half a spectrum at a
+    time (chip_conv_obs) -- when the observed wavelengths ascend and all lie inside the candidate's window.  The same pixels in
+    descending order, and candidates whose Doppler shift pushes the window's end inside the observed range, take the stage that
+    writes the spectrum out and the observed-grid phase behind it: same likelihoods, the oracle's NaNs."""
+    npix, nobs, lam0, R, B = 65536, 20000, 4000.0, 100000.0, 6
+    raw = synth.make_yst_net(npix=npix, lam0=lam0, R_fwhm=R, H=16, seed=33, line_depth=0.1)
+    obs = synth.obs_grid(raw["wavelength"], nobs, inset=0.0002, relative=True)
+    th7 = synth.draw_candidates(B, seed=77)
+    th7[:, 6] = np.linspace(0.6, 0.85, B) * R
+    th7[4, 4], th7[5, 4] = 250.0, -250.0                           # the window's end moves inside the observed range
+    flux = O.genspec(raw, list(theta_full(th7[:1])[0, :8]), outwave=obs)[1] + np.random.default_rng(2).normal(0, 0.01, nobs)
+    eflux = np.full(nobs, 0.01)
+    L = O.OracleLikelihood(raw, obs, flux, eflux, SPEC_PARS)
+    with np.errstate(all="ignore"):
+        ref = np.array([L.lnlikefn(t) for t in th7])
+    assert np.isfinite(ref[:4]).all()
+    eng = Engine(_net(raw), obs=(obs, flux, eflux), b_max=B)
+    lnl = eng.lnlike_batch(theta_full(th7)).cpu().numpy()
+    eng.close()
+    assert np.array_equal(np.isnan(lnl), np.isnan(ref)), (lnl, ref)
+    ok = np.isfinite(ref)
+    assert np.all(np.abs(lnl[ok] - ref[ok]) <= lnl_tol(ref[ok])), np.abs(lnl[ok] - ref[ok]).max()
+    eng = Engine(_net(raw), obs=(obs[::-1].copy(), flux[::-1].copy(), eflux[::-1].copy()), b_max=B)
+    rev = eng.lnlike_batch(theta_full(th7)).cpu().numpy()
+    eng.close()
+    assert np.array_equal(np.isnan(rev), np.isnan(ref))
+    assert np.all(np.abs(rev[ok] - ref[ok]) <= lnl_tol(ref[ok])), np.abs(rev[ok] - ref[ok]).max()
+    # an obs grid this short leaves the record table mostly padding at the block the on-chip loop walks: 2 (24576 - 20000) <= 20000 holds
+
+
 def test_full_size_properties(Engine):
     """Size-independent checks at the benchmark configuration (C2, B=512)."""
     raw, obs, flux, eflux = yst_problem("C2")

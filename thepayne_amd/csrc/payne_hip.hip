@@ -224,6 +224,7 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   c->obs_bound = false;
   for (void* p : c->lsf_owned) (void)hipFree(p);      // an LSF vector belongs to the grid it was given on
   c->lsf_owned.clear(); c->has_lsf = false; c->d_obs_wave = nullptr;
+  c->T.obs_sorted = 0;
   c->T.nobs = 0; c->T.lnobs = nullptr; c->T.obs_rec = nullptr; c->T.xcheb = nullptr; c->T.obs_f1 = nullptr; c->T.obs_ivar = nullptr;
   if (!obs || obs->nobs <= 0) return sync_tables(c);
   if (!obs->wave) return fail(c, PAYNE_E_INVALID, "obs.wave is NULL");
@@ -241,6 +242,8 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   c->T.nobs = obs->nobs;
   c->T.obs_min = c->H.obs_min;
   c->T.obs_max = c->H.obs_max;
+  c->T.obs_sorted = 1;
+  for (int i = 1; i < obs->nobs; ++i) if (!(obs->wave[i] >= obs->wave[i - 1])) { c->T.obs_sorted = 0; break; }
   c->obs_bound = true;
   return sync_tables(c);
 }

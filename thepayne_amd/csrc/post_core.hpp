@@ -217,6 +217,7 @@ struct PostTables {
   // f (1 + hs (f - 1)) on the 32-bit fraction F as F (bk_c1 + bk_c2 F) -- made once on the host (two fp64 divisions a thread otherwise)
   double bk_r;
   float bk_c1, bk_c2;
+  int obs_sorted;      // the observed wavelengths ascend (the on-chip instrumental stage walks them half a spectrum at a time)
   int raw_freq;        // this launch's rows are the half transform of the spectra in pair layout (host_tables.hpp freq_rows): the output
                        // layer carried the first stage's forward transform in its weights (identity vsini maps, compile-time geometry)
 };

@@ -319,6 +319,8 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const Pos
   __shared__ double red[kChipThreads + kChipThreads / 2 + 2];
   __shared__ CandState S;
   __shared__ ChipResample Rs;
+  __shared__ int obs_on_chip;
+  __shared__ float obs_edge;
   extern __shared__ __attribute__((aligned(16))) unsigned char chip_sm[];
   chip_fill_tables(chip_lds(chip_sm), T.tw, (int)threadIdx.x);
   __syncthreads();
@@ -378,19 +380,36 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const Pos
       // ---- instrumental stage: the candidate's window (mask, Doppler shift, pow-2 log grid) gathered while loading, the result
       // over its input
       {
-        if (tid == 0) Rs = chip_resample_of(S.W);
+        if (tid == 0) {
+          Rs = chip_resample_of(S.W);
+          // chi^2 alone, no blaze, whole blocks of records, ascending wavelengths ALL strictly inside the window (its two ends, with
+          // a margin far above what the two logarithms here and the records' own can differ by): the observed grid on the compute unit
+          int ok = (a.out == nullptr && stage == -1 && T.obs_f1 != nullptr && T.npoly == 0 && T.obs_sorted && obs_fast_ok(T, 16 * kChipThreads)) ? 1 : 0;
+          if (ok) {
+            const double t0 = fma(log(T.obs_min), S.W.obA, S.W.obB), t1 = fma(log(T.obs_max), S.W.obA, S.W.obB);
+            ok = (t0 >= 1e-3 && t1 <= (double)(S.W.n2 - 1) - 1e-3) ? 1 : 0;      // (false for NaN)
+          }
+          obs_on_chip = ok;
+        }
         __syncthreads();
         TaperArgs tg{};
         tg.g_c2 = S.W.g_c2;
-        chip_conv<false>(ex.L, bufB, bufB, tg, false, false, tid, &Rs, false);
-        ex.mark(0);
-      }
-      // ---- observed grid, blaze, chi^2
-      {
-        float* outp = a.out ? a.out + (size_t)b * a.ld_out : nullptr;
-        store_partial(tid, phase_obs<16>(tid, kChipThreads, T, S, S.W, bufB, outp, stage), red);
-        __syncthreads();
-        if (tid == 0) { double s = 0.0; for (int i = 0; i < n_slots(kChipThreads); ++i) s += red[i]; *chi2 = s; }
+        if (obs_on_chip) {
+          const int npad = (T.nobs + 16 * kChipThreads - 1) / (16 * kChipThreads) * (16 * kChipThreads);
+          const float acc = chip_conv_obs(ex.L, bufB, tg, tid, &Rs, T.obs_rec, npad, obs_fast_consts(S.W), (PAYNE_AS_LDS float*)&obs_edge);
+          ex.mark(0);
+          store_partial(tid, (double)acc, red);
+          __syncthreads();
+          if (tid == 0) { double s = 0.0; for (int i = 0; i < n_slots(kChipThreads); ++i) s += red[i]; *chi2 = s; }
+        } else {
+          chip_conv<false>(ex.L, bufB, bufB, tg, false, false, tid, &Rs, false);
+          ex.mark(0);
+          // ---- observed grid, blaze, chi^2
+          float* outp = a.out ? a.out + (size_t)b * a.ld_out : nullptr;
+          store_partial(tid, phase_obs<16>(tid, kChipThreads, T, S, S.W, bufB, outp, stage), red);
+          __syncthreads();
+          if (tid == 0) { double s = 0.0; for (int i = 0; i < n_slots(kChipThreads); ++i) s += red[i]; *chi2 = s; }
+        }
       }
     }
     if (threadIdx.x == 0 && a.lnl && a.out_stage < 0) {

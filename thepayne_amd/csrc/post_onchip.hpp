@@ -487,5 +487,82 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
   __syncthreads();                                                 // (one CU, one L1: the next phase of this workgroup reads what was just written)
 }
 
+// ---- the instrumental stage and the observed grid in ONE call: the smoothed spectrum never leaves the compute unit ---------------
+// chip_conv<false> with a gathered input, up to the inverse transform; then, instead of the store of its output and a phase that
+// gathers from it (two transfers of the spectrum through the workspace, 2 x nobs 4-byte gathers at L2 distance): the registers hold
+// the spectrum in layout L0 (thread t, register a = complex point t + 1024 a), and the exchange buffer holds exactly HALF of it --
+// registers 0..15 first (real points 0..32767), the observed pixels that fall there interpolate from LDS, then registers 16..31, the
+// rest.  The observed wavelengths ascend (PostTables::obs_sorted) and every one of them lies inside the window (the caller checks the
+// two ends): the blocks of 16 x 512 padded records are walked once, the block that straddles the middle keeps its records in
+// registers across the switch.  Same statements per pixel, same order of a thread's sum as obs_loop_fast: the same chi^2 to the bit.
+// `edge`: one LDS float (real point 32768 for the last pixel of the first half).  Returns the thread's partial sum.
+__device__ __attribute__((noinline)) float chip_conv_obs(const ChipLds L, const float* in, const TaperArgs ta, int tid, const ChipResample* rs,
+                                                        const ObsRec* __restrict__ recs, int nobs, const ObsFastConsts oc,
+                                                        PAYNE_AS_LDS float* edge) {
+  const int vt0 = 64 * (tid >> 5) + (tid & 31);
+  c32 u0[32], u1[32];
+  {
+    const ChipResample R = *rs;
+    chip_gather_t<1024>(in, R, vt0, u0);
+    chip_gather_t<1024>(in, R, vt0 + 32, u1);
+  }
+  chip_pin(u0); chip_pin(u1);
+  chip_fft_fwd(L, u0, u1, vt0);
+  chip_taper<false>(L, u0, u1, vt0, ta);
+  chip_fft_back(L, u0, u1, vt0);
+  chip_pin(u0); chip_pin(u1);
+  // z' = conj(FFT(Y)): slot s of the exchange buffer = real points 2 s, 2 s + 1 of the half
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    stc(L.xch, vt0 + 1024 * a, c32{u0[a].x, -u0[a].y});
+    stc(L.xch, vt0 + 32 + 1024 * a, c32{u1[a].x, -u1[a].y});
+  }
+  if (vt0 == 0) *edge = u0[16].x;
+  __syncthreads();
+  const PAYNE_AS_LDS float* xf = (const PAYNE_AS_LDS float*)L.xch;
+  constexpr int OU = 16, HALF = kChipM;                              // real points in a half = complex points of the stage
+  float acc = 0.f;
+  int round = 0;
+  for (int base = tid; base < nobs; base += OU * kChipThreads) {
+    ObsRec rec[OU];
+#pragma unroll
+    for (int q = 0; q < OU; ++q) rec[q] = recs[(unsigned)(base + q * kChipThreads)];
+    unsigned kk[OU]; float F[OU];
+    bool hi = false;
+#pragma unroll
+    for (int q = 0; q < OU; ++q) {
+      union { double d; unsigned long long u; } cv;
+      cv.d = fma(rec[q].lnw, oc.obA, oc.obBm);
+      const unsigned k = (unsigned)(cv.u >> 32) - kPosMagicHi;
+      kk[q] = k < oc.kmax ? k : oc.kmax;
+      F[q] = (float)(unsigned)cv.u;
+      hi = hi || kk[q] >= (unsigned)HALF;
+    }
+    for (;;) {                                                      // (at most twice: the block that straddles the middle)
+      const float ev = *edge;
+#pragma unroll
+      for (int q = 0; q < OU; ++q) {
+        const bool mine = (int)(kk[q] >> 15) == round;
+        const unsigned idx = kk[q] & (unsigned)(HALF - 1);
+        const float av = xf[idx];
+        const float bv = idx == (unsigned)(HALF - 1) ? ev : xf[idx + 1 < (unsigned)HALF ? idx + 1 : idx];
+        const float w = F[q] * fmaf(F[q], oc.c2, oc.c1);
+        const float d = fmaf(bv - av, w, av) - rec[q].f1;
+        acc = mine ? fmaf(d * d, rec[q].ivar, acc) : acc;
+      }
+      if (round == 1 || !__syncthreads_or(hi ? 1 : 0)) break;       // (uniform: everybody has finished with the first half)
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        stc(L.xch, vt0 + 1024 * a, c32{u0[16 + a].x, -u0[16 + a].y});
+        stc(L.xch, vt0 + 32 + 1024 * a, c32{u1[16 + a].x, -u1[16 + a].y});
+      }
+      __syncthreads();
+      round = 1;
+    }
+  }
+  __syncthreads();                                                 // (the exchange buffer is the next candidate's)
+  return acc;
+}
+
 }  // namespace payne
 #endif
