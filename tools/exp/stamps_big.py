@@ -11,6 +11,8 @@ cfg = synth.CONFIGS["C5"]
 B = int(os.environ.get("BATCH", "256"))
 net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
 obs = synth.obs_grid(net["wavelength"], cfg["nobs"], inset=0.0005, relative=True)
+if os.environ.get("REVERSE"):          # descending wavelengths: the observed grid as a phase of its own (no chip_conv_obs)
+    obs = obs[::-1].copy()
 eng = PayneEngine(nnio.normalize_spec_net(net), obs=(obs, np.ones(len(obs)), np.full(len(obs), 0.01)), b_max=B)
 th7 = synth.draw_candidates(B, seed=1)
 th = np.full((B, 12), np.nan); th[:, 0:6] = th7[:, 0:6]; th[:, 7] = th7[:, 6]
