@@ -217,3 +217,23 @@ def test_likelihood_post_kernels_keep_two_workgroups_per_cu(tmp_path):
     assert set(seen) == {10, 11, 12}, seen
     for log2n, (vgprs, occ) in seen.items():
         assert vgprs <= 128 and occ >= 4, (log2n, vgprs, occ)
+
+
+def test_instruction_census_of_the_post_kernels_phases(tmp_path):
+    """tools/valu_census.py (the table behind profiles/rN_c2_valu_census.txt) compiles every phase of the C2 post kernel as a kernel of
+    its own and counts the compiler's instructions: the tool still builds against the phase code, every phase is found, and the short
+    forms of the per-pixel phases stay short (the general loops they fall back to are counted beside them)."""
+    import subprocess
+    import sys
+    out = tmp_path / "census.txt"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_census.py"), "--out", str(out)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = {}
+    for line in out.read_text().splitlines():
+        f = line.split()
+        if len(f) > 2 and f[0].startswith(("census_", "payne::fft_fixed")) and f[1].isdigit():
+            rows[f[0]] = int(f[1])
+    for k in ("census_first", "census_resample", "census_resample_general", "census_taper", "census_obs", "census_obs_general"):
+        assert k in rows and rows[k] > 0, (k, rows)
+    assert rows["census_resample"] < rows["census_resample_general"] and rows["census_obs"] < rows["census_obs_general"], rows
+    assert rows["census_obs"] <= 200 and rows["census_first"] <= 200 and rows["census_resample"] <= 130, rows
