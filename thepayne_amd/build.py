@@ -17,8 +17,9 @@ LIB = os.path.join(HERE, "libpayne_hip.so")
 SOURCES = ["payne_hip.hip", "k_dense.hip", "k_post_lean.hip", "k_post_full_a.hip", "k_post_full_b.hip", "k_post_big.hip", "k_post_chip2.hip", "k_smooth.hip"]
 HEADERS = ["post_core.hpp", "post_seq.hpp", "host_tables.hpp", "ns_core.hpp", "dense_kernels.hpp", "post_kernels.hpp",
            "sed_kernel.hpp", "sed_core.hpp", "post_onchip.hpp", "post_onchip2.hpp", "sampler_kernels.hpp", "sampler_core.hpp", "select.hpp"]
+# (-amdgpu-kernarg-preload-count: a kernel's leading scalar arguments arrive in registers at wave start instead of by s_load)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-               "-DNDEBUG", "-Wall", "-Wno-unused-function"]
+               "-DNDEBUG", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 OBJDIR = os.path.join(HERE, "build")
 
 

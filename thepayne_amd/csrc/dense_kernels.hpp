@@ -44,6 +44,16 @@ struct DenseParams {
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
 };
+// leading scalar parameters of payne_dense_dma3_kernel (13 dwords: the hardware preloads up to 14) and the launch's values for them
+// ... of payne_dense_hidden_kernel (14 dwords).  p0: theta (FUSE_L0) | X;  p1: W0 | Wd;  p2: b0 | -;  i2: ld_theta + n_labels << 16 | ldx + ldwd << 16
+#define PAYNE_HK_LEAD_PARAMS const void* lead_p0, const float* lead_p1, const float* lead_p2, const float* lead_bias, unsigned lead_i0, unsigned lead_i1, \
+                             unsigned lead_i2, int lead_B, unsigned lead_i4, int lead_N
+#define PAYNE_HK_LEAD_TYPES const void*, const float*, const float*, const float*, unsigned, unsigned, unsigned, int, unsigned, int
+#define PAYNE_D3_LEAD_PARAMS const unsigned long long* lead_sel, const unsigned short* lead_Xp, const unsigned short* lead_Wp, unsigned lead_plane_x, \
+                             unsigned lead_plane_w, unsigned lead_grid, int lead_N, int lead_B, int lead_ldp, int lead_K
+#define PAYNE_D3_LEAD_TYPES const unsigned long long*, const unsigned short*, const unsigned short*, unsigned, unsigned, unsigned, int, int, int, int
+#define PAYNE_D3_LEAD_ARGS(p) (p).sel, (p).Xp, (p).Wp, (unsigned)(p).plane_x, (unsigned)(p).plane_w, ((unsigned)(p).grid_m | ((unsigned)(p).grid_n << 16)), \
+                              (p).N, (p).B, (p).ldp, (p).K
 #ifdef PAYNE_STAMPS
 #ifdef PAYNE_STAMPS_ENDS_ONLY   /* stamps 0 / 5 / 15 only: the phases in between keep their production shape */
 #define HK_STAMP(k) do { if (((k) == 0 || (k) == 5 || (k) == 15) && p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -509,7 +519,12 @@ constexpr int D3_STAGE = 3 * (64 + 128) * 64;              // bytes per stage
 // the LDS round trip; the loop is bound by the 36 KB a step brings in either way).
 template <int NS> constexpr size_t d3_lds_bytes() { return (size_t)NS * D3_STAGE; }
 template <int NK, int NS, bool PIPE>
-__global__ void __launch_bounds__(512) payne_dense_dma3_kernel(DenseParams p) {
+__global__ void __launch_bounds__(512) payne_dense_dma3_kernel(PAYNE_D3_LEAD_PARAMS, DenseParams p_) {
+  // (what the prologue's addresses hang off arrives in registers at wave start: the leading scalar parameters, preloaded --
+  //  -mllvm -amdgpu-kernarg-preload-count; read from the kernarg segment they are 400-700 cycles in front of the first request)
+  DenseParams p = p_;
+  p.sel = lead_sel; p.Xp = lead_Xp; p.Wp = lead_Wp; p.plane_x = lead_plane_x; p.plane_w = lead_plane_w;
+  p.grid_m = (int)(lead_grid & 0xffffu); p.grid_n = (int)(lead_grid >> 16); p.N = lead_N; p.B = lead_B; p.ldp = lead_ldp; p.K = lead_K;
   constexpr int D3_NS = NS, AHEAD = PIPE ? D3_NS - 1 : 1;
   static_assert((PIPE && NS >= 3) || (!PIPE && NS == 2 && NK == 0), "ring depth / schedule");
   extern __shared__ __attribute__((aligned(16))) unsigned char d3_sm[];
@@ -1252,24 +1267,37 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
 
 // NL: label slots the fused first layer loops over (4 for the usual Teff/logg/FeH/aFe nets, else PAYNE_MAX_LABELS)
 template <bool FUSE_L0, int NL>
-__global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(DenseParams p, const PrepArgs pa) {
+__global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEAD_PARAMS, DenseParams p_, const PrepArgs pa) {
   extern __shared__ __attribute__((aligned(16))) float hk_sm[];
+  // (what a workgroup's first requests hang off arrives in registers at wave start: see payne_dense_dma3_kernel.  `pa` itself stays
+  //  the kernel's argument: a modified COPY of it would have to live in scratch memory for the functions that take its tables by reference)
+  DenseParams p = p_;
+  const int pa_n_spec = (int)(lead_i0 & 0xffffu), pa_n_prep = (int)(lead_i0 >> 16), pa_n_gemm = (int)(lead_i1 & 0xffffu);
+  p.grid_n = (int)(lead_i1 >> 16);
+  p.B = lead_B; p.N = lead_N; p.K = (int)(lead_i4 & 0xffffu); p.bias = lead_bias;
+  if constexpr (FUSE_L0) {
+    p.theta = static_cast<const double*>(lead_p0); p.W0 = lead_p1; p.b0 = lead_p2;
+    p.ld_theta = (int)(lead_i2 & 0xffffu); p.n_labels = (int)(lead_i2 >> 16); p.K0 = (int)(lead_i4 >> 16);
+  } else {
+    p.X = static_cast<const float*>(lead_p0); p.Wd = lead_p1;
+    p.ldx = (int)(lead_i2 & 0xffffu); p.ldwd = (int)(lead_i2 >> 16);
+  }
   // Order of the launch's workgroups = order of dispatch: the walk's proposals made ahead (the longest-lived workgroups of the launch:
   // ~1 200 dependent fp64 instructions a wave) first, then the record writers, then the GEMM tiles, then the photometric tiles.
-  const int front = pa.n_spec + pa.n_prep, bx = (int)blockIdx.x;
-  if (bx < front || bx >= front + pa.n_gemm) {
+  const int front = pa_n_spec + pa_n_prep, bx = (int)blockIdx.x;
+  if (bx < front || bx >= front + pa_n_gemm) {
     if constexpr (FUSE_L0) {
-      if (bx < pa.n_spec) {
+      if (bx < pa_n_spec) {
         const int w = bx * 4 + (int)(threadIdx.x >> 6);
         if (pa.spec_walk) rwalk_spec_wave(pa.spec_walk->sd, pa.spec_w, w, (int)threadIdx.x & 63, pa.spec_step);
       } else if (bx < front) {
-        const int cand = (bx - pa.n_spec) * 256 + (int)threadIdx.x;
+        const int cand = (bx - pa_n_spec) * 256 + (int)threadIdx.x;
         if (pa.out && cand < p.B) {
           prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
           if (pa.rot_flag && !pa.out[cand].do_rot) *pa.rot_flag = pa.rot_seq;       // (every writer writes the same value)
         }
       } else if (pa.sed_mags) {
-        const int j = bx - front - pa.n_gemm, f = j % pa.P.F, blk = j / pa.P.F;
+        const int j = bx - front - pa_n_gemm, f = j % pa.P.F, blk = j / pa.P.F;
 #ifdef PAYNE_STAMPS
         unsigned long long* st = p.stamps ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
 #else
@@ -1302,9 +1330,9 @@ PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 10, 4, true>(DensePa
 PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 32, 0, 3, false>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 0, 3, true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 5, 3, true>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 4, true>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<10, 4, true>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(DenseParams, const PrepArgs);
-PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(DenseParams, const PrepArgs);
-PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 4, true>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<10, 4, true>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

@@ -83,7 +83,7 @@ struct payne_ctx {
   // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
   bool freq_rs = false, freq_rs_now = false; unsigned long long* rot_flag = nullptr; unsigned long long rot_seq = 0;
   size_t post_lds = 0;
-  void (*post_fn_lean)(const PostTables, PostArgs) = nullptr;   // likelihood-only instantiation (same LDS)
+  void (*post_fn_lean)(PAYNE_POST_SIG) = nullptr;   // likelihood-only instantiation (same LDS)
   bool post_tw_lds = false;
   int n_cu = 256;                       // compute units of the device (MI355X: 256)
   bool lean_available = false;          // a likelihood-only instantiation exists for this spectrum length (it can carry a walk's tail)
@@ -733,11 +733,11 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool fr
     return;
   }
   const dim3 grid(p.grid_m * p.grid_n);
-  if ((int)grid.x > c->n_cu) PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 2, false>), grid, block, d3_lds_bytes<2>(), s, p);   // many tiles per CU
+  if ((int)grid.x > c->n_cu) PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 2, false>), grid, block, d3_lds_bytes<2>(), s, PAYNE_D3_LEAD_ARGS(p), p);   // many tiles per CU
   else if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) {
-    PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+    PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
   }
-  else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, p);
+  else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
 }
 
 template <bool FUSE>
@@ -764,11 +764,17 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
 #endif
   pa.n_sed = n_sed;
   const dim3 grid(pa.n_gemm + pa.n_prep + n_sed + pa.n_spec), block(256);
-  if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
+  // the kernel's leading scalar parameters (preloaded into registers at wave start; two 16-bit values a dword)
+  const unsigned i0 = (unsigned)pa.n_spec | ((unsigned)pa.n_prep << 16), i1 = (unsigned)pa.n_gemm | ((unsigned)p.grid_n << 16);
+  const unsigned i2 = FUSE ? ((unsigned)p.ld_theta | ((unsigned)p.n_labels << 16)) : ((unsigned)p.ldx | ((unsigned)p.ldwd << 16));
+  const unsigned i4 = (unsigned)p.K | ((unsigned)(FUSE ? p.K0 : 0) << 16);
+  const void* p0 = FUSE ? static_cast<const void*>(p.theta) : static_cast<const void*>(p.X);
+  const float* p1 = FUSE ? p.W0 : p.Wd;
+  if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
   else if (p.n_labels <= 4) {
-    PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p, pa);
+    PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
   }
-  else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p, pa);
+  else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
 }
 
 // ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
@@ -1000,7 +1006,8 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
       const size_t lds = (tiled & 1) ? 2 * (size_t)fft_tile_complex() * sizeof(c32) : 0;
       PAYNE_LAUNCH(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, s, c->T, a, c->big_ws, B, tiled);
     } else {
-      PAYNE_LAUNCH(lean ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T, a);
+      PAYNE_LAUNCH(lean ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T.twf, a.raw, a.prep, a.theta,
+                   a.rot_flag, a.ld_raw, a.ld_theta, c->T.raw_freq, c->T, a);
       c->last_kernel[1] = post_kernel_label((c->opts.variant & PAYNE_V_POST_GENERIC) ? 0 : c->T.n1, c->post_tw_lds, lean && c->lean_available);
     }
   }
@@ -1976,7 +1983,8 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, nullptr, c->T, a, c->big_ws, B, tiled);
   } else {
-    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T, a);
+    hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T.twf, a.raw, a.prep, a.theta, a.rot_flag, a.ld_raw,
+                       a.ld_theta, c->T.raw_freq, c->T, a);
   }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * kStampRow * 8, hipMemcpyDeviceToHost));

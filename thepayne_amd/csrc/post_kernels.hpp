@@ -107,7 +107,14 @@ template <int LOG2N, bool TW_LDS, bool LEAN = false>
 #else
 #define PAYNE_POST_BOUNDS __launch_bounds__(kPostThreads)
 #endif
-__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const PostTables T, PostArgs a) {
+__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const float* lead_raw, const CandState* lead_prep, const double* lead_theta, const unsigned long long* lead_rot_flag, int lead_ld_raw, int lead_ld_theta, int lead_raw_freq, const PostTables T_, PostArgs a_) {
+  // The kernel's first loads hang off a handful of its arguments, and a wave waits 400-700 cycles for arguments it reads from the
+  // kernarg segment (tools/exp/kernarg_preload.hip) -- those few are the LEADING scalar parameters, which the hardware hands over
+  // in registers at wave start (-mllvm -amdgpu-kernarg-preload-count, build.py); the two records repeat them for everything else.
+  PostTables T = T_;
+  T.twf = lead_twf; T.raw_freq = lead_raw_freq;
+  PostArgs a = a_;
+  a.raw = lead_raw; a.prep = lead_prep; a.theta = lead_theta; a.rot_flag = lead_rot_flag; a.ld_raw = lead_ld_raw; a.ld_theta = lead_ld_theta;
   // T by value: its pointer members then live in the kernarg segment and are known to be
   // global (a struct read through a device pointer yields generic pointers -> flat_load,
   // which also ties every table load to the LDS wait counter)
@@ -805,8 +812,9 @@ extern template __global__ void payne_lsf_kernel<true>(const PostTables, LsfArgs
 #define PAYNE_POST_LEAN_LIST(X) X(12, true, true) X(11, true, true) X(10, true, true) X(13, false, true)
 #define PAYNE_POST_FULL_A_LIST(X) X(12, true, false) X(0, true, false)
 #define PAYNE_POST_FULL_B_LIST(X) X(10, true, false) X(11, true, false) X(13, false, false) X(0, false, false)
-#define PAYNE_POST_EXTERN(L, TW, LEAN) extern template __global__ void payne_post_kernel<L, TW, LEAN>(const PostTables, PostArgs);
-#define PAYNE_POST_DEFINE(L, TW, LEAN) template __global__ void payne_post_kernel<L, TW, LEAN>(const PostTables, PostArgs);
+#define PAYNE_POST_SIG const c32*, const float*, const CandState*, const double*, const unsigned long long*, int, int, int, const PostTables, PostArgs
+#define PAYNE_POST_EXTERN(L, TW, LEAN) extern template __global__ void payne_post_kernel<L, TW, LEAN>(PAYNE_POST_SIG);
+#define PAYNE_POST_DEFINE(L, TW, LEAN) template __global__ void payne_post_kernel<L, TW, LEAN>(PAYNE_POST_SIG);
 #ifndef PAYNE_TU_POST_LEAN
 PAYNE_POST_LEAN_LIST(PAYNE_POST_EXTERN)
 #endif
@@ -817,7 +825,7 @@ PAYNE_POST_FULL_A_LIST(PAYNE_POST_EXTERN)
 PAYNE_POST_FULL_B_LIST(PAYNE_POST_EXTERN)
 #endif
 
-typedef void (*post_kernel_fn)(const PostTables, PostArgs);
+typedef void (*post_kernel_fn)(PAYNE_POST_SIG);
 // the instantiation pick_post_kernel returns, by name (payne_last_kernel)
 static const char* post_kernel_label(int n1, bool tw_lds, bool lean) {
   if (lean) {
