@@ -34,8 +34,11 @@ struct PostArgs {
 };
 
 // BUF_LDS: the two spectrum buffers are LDS (else a global workspace); TW_LDS: so is the twiddle table.
-template <bool BUF_LDS, bool TW_LDS>
+// NTHR: the workgroup's size when the kernel knows it (0: blockDim.x -- a read of the dispatch packet's implicit arguments: one more
+// scalar load and its wait in front of the first phase's requests)
+template <bool BUF_LDS, bool TW_LDS, int NTHR = 0>
 struct DevExecT {
+  static __device__ __forceinline__ int nthr_() { if constexpr (NTHR > 0) return NTHR; else return (int)blockDim.x; }
   static constexpr bool kTwLds = TW_LDS;                     // the twiddle table handed to run_candidate is the kernel's LDS copy
 #ifdef __HIP_DEVICE_COMPILE__
   static __device__ __forceinline__ auto buf(c32* p) {
@@ -58,12 +61,12 @@ struct DevExecT {
 #endif
   template <class F>
   __device__ __forceinline__ void par(F&& f) {
-    f((int)threadIdx.x, (int)blockDim.x);
+    f((int)threadIdx.x, nthr_());
     __syncthreads();
     mark(0);
   }
   template <class F>
-  __device__ __forceinline__ void single(F&& f) { if (threadIdx.x == 0) f((int)blockDim.x); }
+  __device__ __forceinline__ void single(F&& f) { if (threadIdx.x == 0) f(nthr_()); }
   // diagnostic build: an extra cycle stamp inside a phase, written by thread `who`
   __device__ __forceinline__ void mark(int who) {
 #ifdef PAYNE_STAMPS
@@ -72,7 +75,7 @@ struct DevExecT {
     (void)who;
 #endif
   }
-  __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+  __device__ __forceinline__ int nthreads() const { return nthr_(); }
   // LDS tile of the four-step transform (2 x fft_tile_complex()); null: runtime-geometry passes
   c32* tile_ = nullptr;
   __device__ __forceinline__ c32* tile() const { return tile_; }
@@ -107,14 +110,16 @@ template <int LOG2N, bool TW_LDS, bool LEAN = false>
 #else
 #define PAYNE_POST_BOUNDS __launch_bounds__(kPostThreads)
 #endif
-__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const float* lead_raw, const CandState* lead_prep, const double* lead_theta, const unsigned long long* lead_rot_flag, int lead_ld_raw, int lead_ld_theta, int lead_raw_freq, const PostTables T_, PostArgs a_) {
+__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const float* lead_raw, const CandState* lead_prep, const double* lead_theta, const unsigned long long* lead_rot_flag, const double* lead_mags, unsigned lead_ints, const PostTables T_, PostArgs a_) {
   // The kernel's first loads hang off a handful of its arguments, and a wave waits 400-700 cycles for arguments it reads from the
   // kernarg segment (tools/exp/kernarg_preload.hip) -- those few are the LEADING scalar parameters, which the hardware hands over
   // in registers at wave start (-mllvm -amdgpu-kernarg-preload-count, build.py); the two records repeat them for everything else.
+  // (lead_ints: ld_raw | ld_theta << 17 | n_filters << 23 | raw_freq << 31 -- post_lead_ints)
   PostTables T = T_;
-  T.twf = lead_twf; T.raw_freq = lead_raw_freq;
+  T.twf = lead_twf; T.raw_freq = (int)(lead_ints >> 31);
   PostArgs a = a_;
-  a.raw = lead_raw; a.prep = lead_prep; a.theta = lead_theta; a.rot_flag = lead_rot_flag; a.ld_raw = lead_ld_raw; a.ld_theta = lead_ld_theta;
+  a.raw = lead_raw; a.prep = lead_prep; a.theta = lead_theta; a.rot_flag = lead_rot_flag; a.mags = lead_mags;
+  a.ld_raw = (int)(lead_ints & 0x1ffffu); a.ld_theta = (int)((lead_ints >> 17) & 0x3fu); a.n_filters = (int)((lead_ints >> 23) & 0xffu);
   // T by value: its pointer members then live in the kernarg segment and are known to be
   // global (a struct read through a device pointer yields generic pointers -> flat_load,
   // which also ties every table load to the LDS wait counter)
@@ -190,7 +195,7 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const f
       sed_terms[(int)threadIdx.x - 64] = (d * d) / (sed_e * sed_e);   // likelihood.py:109-112 (read by thread 0 behind the phases' barriers)
     }
   };
-  DevExecT<true, TW_LDS> ex;
+  DevExecT<true, TW_LDS, kPostThreads> ex;
 #ifdef PAYNE_STAMPS
   if (a.stamps) {
     ex.stamps = a.stamps + (size_t)b * kStampRow;
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(kBigThreads) payne_post_big_kernel(const PostT
 // 512 threads, the stage's 32 768 complex points in registers, 128 KB of LDS as the transpose buffer.  The phases around the
 // two stages (mask window, resampling, observed grid, chi^2) are the global-workspace phases of payne_post_big_kernel; a
 // candidate whose instrumental window needs a shorter transform takes that kernel's runtime-geometry passes for that stage.
-namespace payne { template <bool TW> struct ex_lds_tail<DevExecT<true, TW>> { static constexpr bool value = true; }; }
+namespace payne { template <bool TW, int N> struct ex_lds_tail<DevExecT<true, TW, N>> { static constexpr bool value = true; }; }
 struct ChipExec : DevExecT<false, false> {
 #ifdef __HIP_DEVICE_COMPILE__
   ChipLds L;
@@ -812,7 +817,12 @@ extern template __global__ void payne_lsf_kernel<true>(const PostTables, LsfArgs
 #define PAYNE_POST_LEAN_LIST(X) X(12, true, true) X(11, true, true) X(10, true, true) X(13, false, true)
 #define PAYNE_POST_FULL_A_LIST(X) X(12, true, false) X(0, true, false)
 #define PAYNE_POST_FULL_B_LIST(X) X(10, true, false) X(11, true, false) X(13, false, false) X(0, false, false)
-#define PAYNE_POST_SIG const c32*, const float*, const CandState*, const double*, const unsigned long long*, int, int, int, const PostTables, PostArgs
+#define PAYNE_POST_SIG const c32*, const float*, const CandState*, const double*, const unsigned long long*, const double*, unsigned, const PostTables, PostArgs
+// the packed leading integers: 17 + 6 + 8 + 1 bits (the LDS kernel's rows are at most 16 384 + padding floats apart; run_post checks the rest)
+static inline bool post_lead_fits(int ld_raw, int ld_theta, int n_filters) { return ld_raw >= 0 && ld_raw < (1 << 17) && ld_theta >= 0 && ld_theta < 64 && n_filters >= 0 && n_filters < 256; }
+static inline unsigned post_lead_ints(int ld_raw, int ld_theta, int n_filters, int raw_freq) {
+  return (unsigned)ld_raw | ((unsigned)ld_theta << 17) | ((unsigned)n_filters << 23) | ((unsigned)(raw_freq != 0) << 31);
+}
 #define PAYNE_POST_EXTERN(L, TW, LEAN) extern template __global__ void payne_post_kernel<L, TW, LEAN>(PAYNE_POST_SIG);
 #define PAYNE_POST_DEFINE(L, TW, LEAN) template __global__ void payne_post_kernel<L, TW, LEAN>(PAYNE_POST_SIG);
 #ifndef PAYNE_TU_POST_LEAN

@@ -224,8 +224,13 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
   ex.par([&](int t, int n) {
     RowRegsT<UX / 4> row;
     SlotRegs<SU> slots;
+    // (A kernel that can take either kind of row requests PIXEL rows late, in the commit below: with both requests in this block the
+    //  compiler's wait-count pass, which merges what may be in flight over both paths, saw the pixel path's destination registers as
+    //  pending in the OTHER path and put `s_waitcnt vmcnt(0)` in front of the slots' requests -- the kernel's own table first, THEN
+    //  the row: a second memory round trip at the start of every workgroup, 0.5 us of the C2 post kernel since round 4.)
+    constexpr bool kLatePixels = LOG2N > 0;
     if (freq && !freq_chip) slots_issue<SU>(t, NT, MFq, raw, T.twf + plan_total(MFq), slots);
-    else if (!fused_row) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
+    else if (!fused_row && !kLatePixels) phase_load_issue(t, n, T.npix, raw, row);          // in flight during the setup chains
     PrepRegs pr;
     if (prep) phase_take_prep_issue(t, prep, pr);      // per-candidate scalars were computed ahead of the kernel
     double th5 = 0.0;
@@ -245,7 +250,10 @@ PAYNE_SEQ void run_candidate(Ex& ex, const PostTables& T, const c32* twf, const 
       //  batch rotates, or the launch would have been switched to pixels: PostArgs::rot_flag)
       slots_commit<SU>(t, NT, MFq, slots, Ex::buf((c32*)bufB), vsini_taper_args(T, th5), th5 != 0.0);
     }
-    else if (!fused_row) phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
+    else if (!fused_row) {
+      if (kLatePixels) phase_load_issue(t, n, T.npix, raw, row);
+      phase_load_commit(t, n, T.npix, raw, row, direct ? bufB : bufA, direct);
+    }
   });
   float* spec = bufA;
   float* work = bufB;
