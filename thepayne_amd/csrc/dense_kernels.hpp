@@ -44,16 +44,16 @@ struct DenseParams {
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
 };
-// leading scalar parameters of payne_dense_dma3_kernel (13 dwords: the hardware preloads up to 14) and the launch's values for them
+// leading scalar parameters of payne_dense_dma3_kernel (14 dwords: all the hardware preloads) and the launch's values for them
 // ... of payne_dense_hidden_kernel (14 dwords).  p0: theta (FUSE_L0) | X;  p1: W0 | Wd;  p2: b0 | -;  i2: ld_theta + n_labels << 16 | ldx + ldwd << 16
 #define PAYNE_HK_LEAD_PARAMS const void* lead_p0, const float* lead_p1, const float* lead_p2, const float* lead_bias, unsigned lead_i0, unsigned lead_i1, \
                              unsigned lead_i2, int lead_B, unsigned lead_i4, int lead_N
 #define PAYNE_HK_LEAD_TYPES const void*, const float*, const float*, const float*, unsigned, unsigned, unsigned, int, unsigned, int
 #define PAYNE_D3_LEAD_PARAMS const unsigned long long* lead_sel, const unsigned short* lead_Xp, const unsigned short* lead_Wp, unsigned lead_plane_x, \
-                             unsigned lead_plane_w, unsigned lead_grid, int lead_N, int lead_B, int lead_ldp, int lead_K
-#define PAYNE_D3_LEAD_TYPES const unsigned long long*, const unsigned short*, const unsigned short*, unsigned, unsigned, unsigned, int, int, int, int
+                             unsigned lead_plane_w, unsigned lead_grid, int lead_N, int lead_B, int lead_ldp, int lead_K, unsigned lead_sel_seq
+#define PAYNE_D3_LEAD_TYPES const unsigned long long*, const unsigned short*, const unsigned short*, unsigned, unsigned, unsigned, int, int, int, int, unsigned
 #define PAYNE_D3_LEAD_ARGS(p) (p).sel, (p).Xp, (p).Wp, (unsigned)(p).plane_x, (unsigned)(p).plane_w, ((unsigned)(p).grid_m | ((unsigned)(p).grid_n << 16)), \
-                              (p).N, (p).B, (p).ldp, (p).K
+                              (p).N, (p).B, (p).ldp, (p).K, (unsigned)(p).sel_seq
 #ifdef PAYNE_STAMPS
 #ifdef PAYNE_STAMPS_ENDS_ONLY   /* stamps 0 / 5 / 15 only: the phases in between keep their production shape */
 #define HK_STAMP(k) do { if (((k) == 0 || (k) == 5 || (k) == 15) && p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(PAYNE_D3_LEAD_PAR
   constexpr int D3_NS = NS, AHEAD = PIPE ? D3_NS - 1 : 1;
   static_assert((PIPE && NS >= 3) || (!PIPE && NS == 2 && NK == 0), "ring depth / schedule");
   extern __shared__ __attribute__((aligned(16))) unsigned char d3_sm[];
-  if (p.sel != nullptr && *p.sel == p.sel_seq) {             // (a scalar load and a uniform branch; launches without the word skip both)
+  if (p.sel != nullptr && (unsigned)*p.sel == lead_sel_seq) {   // (a scalar load and a uniform branch; launches without the word skip both)
     p.Wp = p.Wp_alt; p.plane_w = p.plane_w_alt; p.bias = p.bias_alt; p.bias_shift = p.bias_shift_alt; p.N = p.N_alt; p.ldy = p.ldy_alt;
   }
   const int ntiles = p.grid_m * p.grid_n;

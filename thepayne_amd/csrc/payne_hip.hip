@@ -1008,7 +1008,7 @@ static int run_post(payne_ctx* c, const double* theta, int B, double instr_facto
     } else {
       if (!post_lead_fits(a.ld_raw, a.ld_theta, a.n_filters)) return fail(c, PAYNE_E_INVALID, "row pitch / theta columns / filters beyond what the post kernel's packed arguments hold");
       PAYNE_LAUNCH(lean ? c->post_fn_lean : c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, s, c->T.twf, a.raw, a.prep, a.theta,
-                   a.rot_flag, a.mags, post_lead_ints(a.ld_raw, a.ld_theta, a.n_filters, c->T.raw_freq), c->T, a);
+                   a.rot_flag, a.mags, post_lead_ints(a.ld_raw, a.ld_theta, a.n_filters, c->T.raw_freq), (unsigned)a.rot_seq, c->T, a);
       c->last_kernel[1] = post_kernel_label((c->opts.variant & PAYNE_V_POST_GENERIC) ? 0 : c->T.n1, c->post_tw_lds, lean && c->lean_available);
     }
   }
@@ -1985,7 +1985,7 @@ extern "C" int payne_diag_post_stamps(payne_ctx* c, const double* theta, int B, 
     hipLaunchKernelGGL(payne_post_big_kernel, dim3(grid), dim3(kBigThreads), lds, nullptr, c->T, a, c->big_ws, B, tiled);
   } else {
     hipLaunchKernelGGL(c->post_fn, dim3(B), dim3(kPostThreads), c->post_lds, nullptr, c->T.twf, a.raw, a.prep, a.theta, a.rot_flag, a.mags,
-                       post_lead_ints(a.ld_raw, a.ld_theta, a.n_filters, c->T.raw_freq), c->T, a);
+                       post_lead_ints(a.ld_raw, a.ld_theta, a.n_filters, c->T.raw_freq), (unsigned)a.rot_seq, c->T, a);
   }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(stamps_host, d, (size_t)B * kStampRow * 8, hipMemcpyDeviceToHost));

@@ -110,7 +110,7 @@ template <int LOG2N, bool TW_LDS, bool LEAN = false>
 #else
 #define PAYNE_POST_BOUNDS __launch_bounds__(kPostThreads)
 #endif
-__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const float* lead_raw, const CandState* lead_prep, const double* lead_theta, const unsigned long long* lead_rot_flag, const double* lead_mags, unsigned lead_ints, const PostTables T_, PostArgs a_) {
+__global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const float* lead_raw, const CandState* lead_prep, const double* lead_theta, const unsigned long long* lead_rot_flag, const double* lead_mags, unsigned lead_ints, unsigned lead_rot_seq, const PostTables T_, PostArgs a_) {
   // The kernel's first loads hang off a handful of its arguments, and a wave waits 400-700 cycles for arguments it reads from the
   // kernarg segment (tools/exp/kernarg_preload.hip) -- those few are the LEADING scalar parameters, which the hardware hands over
   // in registers at wave start (-mllvm -amdgpu-kernarg-preload-count, build.py); the two records repeat them for everything else.
@@ -128,7 +128,8 @@ __global__ void PAYNE_POST_BOUNDS payne_post_kernel(const c32* lead_twf, const f
   //  branches in front of everything else the kernel asks for)
   const int n1 = LOG2N > 0 ? (1 << LOG2N) : T.n1;
   int raw_freq = T.raw_freq, ld_raw = a.ld_raw;
-  if (a.rot_flag != nullptr && *a.rot_flag == a.rot_seq) { raw_freq = 0; ld_raw = a.ld_raw_alt; }
+  // (the batch's sequence number by its low 32 bits, a preloaded argument: the whole word sits in the record, another 400-700 cycles away)
+  if (a.rot_flag != nullptr && (unsigned)*a.rot_flag == lead_rot_seq) { raw_freq = 0; ld_raw = a.ld_raw_alt; }
   float* bufA = reinterpret_cast<float*>(smem);
   float* bufB = bufA + fft_buf_floats(n1);                     // room for the padded FFT intermediates
   double* red = reinterpret_cast<double*>(bufB + fft_buf_floats(n1));          // scratch_doubles(256)
@@ -817,7 +818,7 @@ extern template __global__ void payne_lsf_kernel<true>(const PostTables, LsfArgs
 #define PAYNE_POST_LEAN_LIST(X) X(12, true, true) X(11, true, true) X(10, true, true) X(13, false, true)
 #define PAYNE_POST_FULL_A_LIST(X) X(12, true, false) X(0, true, false)
 #define PAYNE_POST_FULL_B_LIST(X) X(10, true, false) X(11, true, false) X(13, false, false) X(0, false, false)
-#define PAYNE_POST_SIG const c32*, const float*, const CandState*, const double*, const unsigned long long*, const double*, unsigned, const PostTables, PostArgs
+#define PAYNE_POST_SIG const c32*, const float*, const CandState*, const double*, const unsigned long long*, const double*, unsigned, unsigned, const PostTables, PostArgs
 // the packed leading integers: 17 + 6 + 8 + 1 bits (the LDS kernel's rows are at most 16 384 + padding floats apart; run_post checks the rest)
 static inline bool post_lead_fits(int ld_raw, int ld_theta, int n_filters) { return ld_raw >= 0 && ld_raw < (1 << 17) && ld_theta >= 0 && ld_theta < 64 && n_filters >= 0 && n_filters < 256; }
 static inline unsigned post_lead_ints(int ld_raw, int ld_theta, int n_filters, int raw_freq) {
