@@ -1293,8 +1293,10 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
       } else if (bx < front) {
         const int cand = (bx - pa_n_spec) * 256 + (int)threadIdx.x;
         if (pa.out && cand < p.B) {
+          // (the word first, from the row itself: read back from the record just written it was a dependent memory round trip at the
+          //  end of the launch's longest-lived workgroups)
+          if (pa.rot_flag && !(p.theta[(size_t)cand * p.ld_theta + 5] != 0.0)) *pa.rot_flag = pa.rot_seq;   // ystpred.py:214 (every writer writes the same value)
           prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
-          if (pa.rot_flag && !pa.out[cand].do_rot) *pa.rot_flag = pa.rot_seq;       // (every writer writes the same value)
         }
       } else if (pa.sed_mags) {
         const int j = bx - front - pa_n_gemm, f = j % pa.P.F, blk = j / pa.P.F;
