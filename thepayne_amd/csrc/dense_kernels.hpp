@@ -19,6 +19,7 @@ struct DenseParams {
   // payne_dense_hidden_kernel<false>: a copy of W with rows ldwd >= HK_PITCH floats apart, zero beyond K -- with X's pitch the same
   // and its pad columns zero, both operand tiles go from global memory straight into LDS (hk_tile; null: staged through registers)
   const float* Wd; int ldwd;
+  int dma_tiles;               // (hidden-layer kernel, first launch: Wd is set -- handed over as a preloaded argument's bit)
   int k_real;                  // LDS-DMA kernel: width before zero padding (0 = K): the last k-step stops there
   const float* bias;           // [N]
   float* Y; int ldy;           // [B][ldy]
@@ -980,7 +981,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
     // A tile is written once the transfers are in: what the staged form spends on 12 ds_write_b128 a thread after the layer
     // (1 750 of the workgroup's 12 500 cycles) is gone.
     if constexpr (FUSE_L0) {
-      if (p.Wd != nullptr && kc == 0 && p.K <= HK_KC) {             // (uniform)
+      if (p.dma_tiles && kc == 0 && p.K <= HK_KC) {                 // (uniform)
         constexpr int NLG = (NL + 3) / 4, MAXT = (HK_KC / 16 + 3) / 4;
         constexpr int NCH = HK_PITCH / 4, NTR = 32 * NCH / 64;
         const int ntile = kn16 >> 4;
@@ -1272,7 +1273,9 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
   // (what a workgroup's first requests hang off arrives in registers at wave start: see payne_dense_dma3_kernel.  `pa` itself stays
   //  the kernel's argument: a modified COPY of it would have to live in scratch memory for the functions that take its tables by reference)
   DenseParams p = p_;
-  const int pa_n_spec = (int)(lead_i0 & 0xffffu), pa_n_prep = (int)(lead_i0 >> 16), pa_n_gemm = (int)(lead_i1 & 0xffffu);
+  const int pa_n_spec = (int)(lead_i0 & 0xffffu), pa_n_prep = (int)((lead_i0 >> 16) & 0x7fffu), pa_n_gemm = (int)(lead_i1 & 0xffffu);
+  // (bit 31: the weight tile goes straight into LDS -- known HERE, not when the record's p.Wd has arrived: the first layer's requests wait for nothing)
+  p.dma_tiles = (int)(lead_i0 >> 31);
   p.grid_n = (int)(lead_i1 >> 16);
   p.B = lead_B; p.N = lead_N; p.K = (int)(lead_i4 & 0xffffu); p.bias = lead_bias;
   if constexpr (FUSE_L0) {
@@ -1293,10 +1296,11 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
       } else if (bx < front) {
         const int cand = (bx - pa_n_spec) * 256 + (int)threadIdx.x;
         if (pa.out && cand < p.B) {
-          // (the word first, from the row itself: read back from the record just written it was a dependent memory round trip at the
+          // (the fall-back word from the row itself: read back from the record just written it was a dependent memory round trip at the
           //  end of the launch's longest-lived workgroups)
-          if (pa.rot_flag && !(p.theta[(size_t)cand * p.ld_theta + 5] != 0.0)) *pa.rot_flag = pa.rot_seq;   // ystpred.py:214 (every writer writes the same value)
+          const double vrot_row = p.theta[(size_t)cand * p.ld_theta + 5];      // (requested with the record's own reads, looked at after them)
           prep_candidate(pa.T, p.theta + (size_t)cand * p.ld_theta, pa.instr_factor, pa.out[cand]);
+          if (pa.rot_flag && !(vrot_row != 0.0)) *pa.rot_flag = pa.rot_seq;   // ystpred.py:214 (every writer writes the same value)
         }
       } else if (pa.sed_mags) {
         const int j = bx - front - pa_n_gemm, f = j % pa.P.F, blk = j / pa.P.F;

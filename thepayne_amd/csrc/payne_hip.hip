@@ -765,7 +765,8 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   pa.n_sed = n_sed;
   const dim3 grid(pa.n_gemm + pa.n_prep + n_sed + pa.n_spec), block(256);
   // the kernel's leading scalar parameters (preloaded into registers at wave start; two 16-bit values a dword)
-  const unsigned i0 = (unsigned)pa.n_spec | ((unsigned)pa.n_prep << 16), i1 = (unsigned)pa.n_gemm | ((unsigned)p.grid_n << 16);
+  p.dma_tiles = (FUSE && p.Wd != nullptr) ? 1 : 0;
+  const unsigned i0 = (unsigned)pa.n_spec | ((unsigned)pa.n_prep << 16) | ((unsigned)p.dma_tiles << 31), i1 = (unsigned)pa.n_gemm | ((unsigned)p.grid_n << 16);
   const unsigned i2 = FUSE ? ((unsigned)p.ld_theta | ((unsigned)p.n_labels << 16)) : ((unsigned)p.ldx | ((unsigned)p.ldwd << 16));
   const unsigned i4 = (unsigned)p.K | ((unsigned)(FUSE ? p.K0 : 0) << 16);
   const void* p0 = FUSE ? static_cast<const void*>(p.theta) : static_cast<const void*>(p.X);
