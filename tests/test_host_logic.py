@@ -217,6 +217,20 @@ def test_likelihood_post_kernels_keep_two_workgroups_per_cu(tmp_path):
     assert set(seen) == {10, 11, 12}, seen
     for log2n, (vgprs, occ) in seen.items():
         assert vgprs <= 128 and occ >= 4, (log2n, vgprs, occ)
+    # ... and the C2 kernel asks for its row in the SAME memory round trip as for its twiddle table: no wait for vector loads between the
+    # table's requests (the first global loads) and the slots' (non-temporal, off a preloaded base).  The compiler's wait-count pass once put
+    # `s_waitcnt vmcnt(0)` there -- a phantom hazard with the pixel-row path of the same block -- and it cost every workgroup a round
+    # trip for two rounds before anybody read the assembly (NOTES R5.12d).
+    m = re.search(r"^_Z17payne_post_kernelILi12ELb1ELb1EE\w*:.*?s_endpgm", text, re.S | re.M)
+    body = m.group(0).splitlines()
+    first_load = next(i for i, l in enumerate(body) if "global_load_dword" in l)
+    first_nt = next(i for i, l in enumerate(body) if re.search(r"global_load_dwordx4 .*s\[\d+:\d+\] nt\s*$", l))   # the slots: a preloaded base
+    assert first_load < first_nt < first_load + 200, (first_load, first_nt)
+    between = [l for l in body[first_load:first_nt] if "s_waitcnt" in l and "vmcnt" in l]
+    assert not between, between
+    # ... with the arguments its first requests hang off preloaded into registers (13 or 14 dwords)
+    pre = re.search(r"amdhsa_kernel _Z17payne_post_kernelILi12ELb1ELb1EE.*?amdhsa_user_sgpr_kernarg_preload_length (\d+)", text, re.S)
+    assert pre and int(pre.group(1)) >= 13, pre and pre.group(1)
 
 
 def test_instruction_census_of_the_post_kernels_phases(tmp_path):
