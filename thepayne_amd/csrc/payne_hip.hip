@@ -1168,6 +1168,7 @@ struct payne_sampler {
   // is ENQUEUED before the current one has finished, and the GPU goes from one to the other without the host (NOTES R4.18).
   double *lv_u[2] = {nullptr, nullptr}, *lv_v[2] = {nullptr, nullptr}, *lv_l[2] = {nullptr, nullptr};
   int lv_n = 0, lv_cur = 0;
+  bool lv_sorted = false;    // the current live set is the output of a merging turn: best first
   double* dyn = nullptr;                  // device: {scale, loglstar}
   double* dq_host[2] = {nullptr, nullptr}; double* dq_host_dev[2] = {nullptr, nullptr};      // two mapped result blocks (+ flag word each)
   unsigned long long dq_seq[2] = {0, 0};
@@ -1436,6 +1437,40 @@ __global__ void __launch_bounds__(1024) payne_stage_out_kernel(double* __restric
 // the queue's counters, the new threshold (the largest lnprob left outside the set: the last point to die), and every chain's start point, uniform among the new live
 // points (the host's splitmix of the seed).  The host replays the same queue for the evidence in its own time; its live SET is the
 // same, its slot order is not (nothing on the device depends on it).
+// The sort network's exchanges inside a wave without the LDS crossbar: lane l ^ J's value by data-parallel-primitive moves (J <= 8:
+// quad permutes, the mirrors of a half row and of a quad composed, a row rotated by 8) and gfx950's row / half swaps (J = 16, 32:
+// both copies go in, the partner's value comes back in one of them, which one by the lane's own bit).
+template <int J>
+__device__ __forceinline__ int turn_lane_xor(int v, bool upper) {
+  if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);                      // row_half_mirror: l ^ 7
+    return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true);                              // quad_perm [3,2,1,0]: ^ 3
+  } else if constexpr (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  else if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); return (int)(upper ? r[0] : r[1]); }
+  else { static_assert(J == 32, "in-wave distance"); const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); return (int)(upper ? r[0] : r[1]); }
+}
+// sum of an int over the wave, in lane 63 (an inclusive scan inside each row of 16 lanes, then the rows' totals handed on)
+template <int CTRL> __device__ __forceinline__ int turn_dpp_add(int x) { return x + __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int turn_wave_sum_to_last(int x) {
+  x = turn_dpp_add<0x111>(x); x = turn_dpp_add<0x112>(x); x = turn_dpp_add<0x114>(x); x = turn_dpp_add<0x118>(x);   // row_shr 1, 2, 4, 8
+  x = turn_dpp_add<0x142>(x); x = turn_dpp_add<0x143>(x);                                                            // row_bcast 15, 31
+  return x;
+}
+// one stage of the bitonic network at distance J < 64 inside runs of KK, "before" = larger lnprob, then smaller id
+template <int KK, int J>
+__device__ __forceinline__ void turn_cmpx(double& kv, int& iv, int i) {
+  union { double d; int w[2]; } me, pa;
+  me.d = kv;
+  const bool upper = (i & J) != 0;
+  pa.w[0] = turn_lane_xor<J>(me.w[0], upper); pa.w[1] = turn_lane_xor<J>(me.w[1], upper);
+  const int ip = turn_lane_xor<J>(iv, upper);
+  const bool mine_first = (kv > pa.d) || (kv == pa.d && iv < ip);
+  const bool want_first = (!upper) == ((i & KK) == 0);                       // the lower place of an ascending run, the upper of a descending one
+  if (mine_first != want_first) { kv = pa.d; iv = ip; }
+  if constexpr (J > 1) turn_cmpx<KK, J / 2>(kv, iv, i);
+}
 struct TurnArgs {
   const double *lu, *lv, *ll; double *ou, *ov, *ol;    // live set in / out (the same arrays when merge == 0)
   int nlive, nd, K, merge, n2;                         // n2: power of two >= nlive + K (<= 2048)
@@ -1446,124 +1481,225 @@ struct TurnArgs {
   // the finished queue's results on their way to the host from HERE (its own transfer kernel was 9 us between two queues): the
   // stores are issued first and drain under the sort; the completion word follows the kernel's last statement
   double* exp_dst; int exp_n; unsigned long long* exp_flag; unsigned long long exp_seq;
+  int live_sorted;                                     // the live set comes from a merging turn: best first (rows and lnprob)
+  int rows_lds;                                        // the launch carries nlive * nd * 16 bytes of dynamic LDS: the new live set's rows stay there for the start points
 };
+constexpr size_t kTurnRowsLdsMax = 128 * 1024;
 __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
   __shared__ double key[2048];
   __shared__ int id[2048];
-  __shared__ long long cnt[3];
+  __shared__ int wsum[3][16];
+  __shared__ int got_in_flag;
+  extern __shared__ __attribute__((aligned(16))) double turn_rows[];   // [2][nlive * nd] when a.rows_lds
   const int tid = threadIdx.x, nl = a.nlive, nd = a.nd, K = a.K;
+  // With the new rows in LDS nothing below the sort reads what this kernel stored to global memory: the barriers there need not wait
+  // for the stores to be acknowledged (1.5 us each time) -- the one in front of the completion word does.
+  const bool lds_rows = a.merge && a.rows_lds;
+  auto lds_barrier = []() {                                  // (__syncthreads also waits for the stores towards the host to be acknowledged)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  auto turn_barrier = [&]() {
+    if (lds_rows) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+    else __syncthreads();
+  };
   double scale = a.scale0, lstar = a.lstar0;
-  if (a.exp_dst) {                                           // chains | counters (contiguous from a.cu), then the scale and threshold they ran under
-    for (int e = tid; e < a.exp_n; e += 1024) a.exp_dst[e] = a.cu[e];
-    if (tid < 2) a.exp_dst[a.exp_n + tid] = a.dyn[tid];
-  }
+  // Everything the kernel reads before the sort is REQUESTED first, in one go: the keys (a counter and the lnprob it admits), the
+  // counters, the scale and threshold, the export's values (sixteen to a thread).  One value at a time -- a load, its store towards
+  // the host, the next load: the two may alias -- the export alone was 13 memory latencies end to end (3.3 us), the keys (the counter,
+  // THEN the lnprob) and the counters three more.  The export's stores go out right in front of the sort, whose exchanges and
+  // comparisons leave the memory path to them.
+  double l_in[2] = {0.0, 0.0}; int na_in[2] = {1, 1};
+  int s0 = 0, s1 = 0, s2 = 0;
   if (a.merge) {
-    if (tid < 3) cnt[tid] = 0;
-    for (int e = tid; e < a.n2; e += 1024) {
-      double v = -INFINITY; int who = (1 << 30) + e;
-      if (e < nl) { const double l = a.ll[e]; v = (l != l) ? -INFINITY : l; who = e; }
-      else if (e < nl + K) {
-        const int k = e - nl;
-        if (a.na[k] > 0) { const double l = a.cl[k]; v = (l != l) ? -INFINITY : l; who = e; }
-      }
-      key[e] = v; id[e] = who;
-    }
-    __syncthreads();
-    int s0 = 0, s1 = 0, s2 = 0;                               // (per wave first: a thousand atomics on three LDS words were 25 us of this kernel)
-    for (int k = tid; k < K; k += 1024) { s0 += a.na[k]; s1 += a.nc[k]; s2 += a.nr[k]; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
-    if ((tid & 63) == 0 && (s0 | s1 | s2)) {
-      atomicAdd((unsigned long long*)&cnt[0], (unsigned long long)s0); atomicAdd((unsigned long long*)&cnt[1], (unsigned long long)s1);
-      atomicAdd((unsigned long long*)&cnt[2], (unsigned long long)s2);
+    for (int q = 0; q < 2; ++q) {                             // (n2 <= 2048)
+      const int e = tid + q * 1024;
+      if (e < nl) l_in[q] = a.ll[e];
+      else if (e < nl + K) { l_in[q] = a.cl[e - nl]; na_in[q] = a.na[e - nl]; }
+    }
+    for (int k = tid; k < K; k += 1024) { s0 += a.na[k]; s1 += a.nc[k]; s2 += a.nr[k]; }
+  }
+  const double dyn0 = a.dyn[0], dyn1 = a.dyn[1];
+  constexpr int kExpBatch = 16;
+  double ex[kExpBatch];
+  if (a.exp_dst) {
+#pragma unroll
+    for (int q = 0; q < kExpBatch; ++q) { const int e = tid + q * 1024; ex[q] = e < a.exp_n ? a.cu[e] : 0.0; }
+  }
+  auto export_out = [&]() {                                  // chains | counters (contiguous from a.cu), then the scale and threshold they ran under
+    if (!a.exp_dst) return;
+#pragma unroll
+    for (int q = 0; q < kExpBatch; ++q) { const int e = tid + q * 1024; if (e < a.exp_n) a.exp_dst[e] = ex[q]; }
+    for (int e = tid + kExpBatch * 1024; e < a.exp_n; e += 1024) a.exp_dst[e] = a.cu[e];
+    if (tid < 2) a.exp_dst[a.exp_n + tid] = tid ? dyn1 : dyn0;
+  };
+  if (a.merge) {
+    // the queue's counters: a sum per wave (a thousand atomics on three LDS words were 25 us of this kernel), met by thread 0 below
+    s0 = turn_wave_sum_to_last(s0); s1 = turn_wave_sum_to_last(s1); s2 = turn_wave_sum_to_last(s2);
+    if ((tid & 63) == 63) { wsum[0][tid >> 6] = s0; wsum[1][tid >> 6] = s1; wsum[2][tid >> 6] = s2; }
+    if (tid == 0) got_in_flag = 0;
+    auto adapted_scale = [&]() {                               // dynesty-style, from the queue's counters
+      long long c0 = 0, c1 = 0, c2 = 0;
+      for (int w = 0; w < 16; ++w) { c0 += wsum[0][w]; c1 += wsum[1][w]; c2 += wsum[2][w]; }
+      const long long denom = c1 + c2 > 1 ? c1 + c2 : 1;
+      const double frac = (double)c0 / (double)denom;         // a redrawn (out-of-cube) proposal counts as a rejection
+      double sc = dyn0 * exp((frac - 0.5) / nd / 0.5);
+      sc = sc > 1e-4 ? sc : 1e-4;
+      return sc < 4.0 ? sc : 4.0;
+    };
+    double kv0[2]; int iv0[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * 1024;
+      kv0[q] = -INFINITY; iv0[q] = (1 << 30) + e;
+      if (e < nl + K && na_in[q] > 0) { const double l = l_in[q]; kv0[q] = (l != l) ? -INFINITY : l; iv0[q] = e; }
     }
     // bitonic sort, "before" = larger lnprob, then smaller id
     if (a.n2 <= 1024) {
-      // one element per thread, in registers: the exchanges at distances below 64 are wave shuffles (45 of the 55 stages of 1024
-      // elements), the others go through LDS -- every stage as an LDS pass with its barrier made this kernel 38 us
-      __syncthreads();
+      // One element per thread, in registers.  The exchanges at distances below 64 stay inside the wave (45 of the 55 stages of 1024
+      // elements), the others go through LDS, two buffers in turn: one barrier a stage (every stage as an LDS pass between two
+      // barriers made this kernel 38 us).
+      // A live set that comes from a merging turn arrives best first, which is the order the network's first stages (runs up to half
+      // the array) would bring it to: when it IS one half of the array its threads sit those stages out.
       const int i = tid;
-      double kv = i < a.n2 ? key[i] : -INFINITY;
-      int iv = i < a.n2 ? id[i] : 0x7fffffff;
-      for (int kk = 2; kk <= a.n2; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-          double kp; int ip;
-          if (j < 64) {
-            kp = __shfl_xor(kv, j); ip = __shfl_xor(iv, j);
-          } else {
-            __syncthreads();
-            if (i < a.n2) { key[i] = kv; id[i] = iv; }
-            __syncthreads();
-            kp = i < a.n2 ? key[i ^ j] : kv; ip = i < a.n2 ? id[i ^ j] : iv;
+      const bool half_sorted = a.live_sorted && 2 * nl == a.n2 && (nl & 63) == 0;
+      double kv = kv0[0];
+      int iv = iv0[0];
+      lds_barrier();                                          // (the flag's zero in front of its ones; the waves' counters)
+      export_out();
+      if (tid == 0) scale = adapted_scale();                  // (no part of the sort's result in it: here thread 0's wave has the time, with a sorted half)
+      int buf = 0;
+      auto lds_stages = [&](int kk, bool idle) {                // distances 64 and up
+        for (int j = kk >> 1; j >= 64; j >>= 1) {
+          double* kb = key + buf * 1024; int* ib = id + buf * 1024;
+          buf ^= 1;
+          if (i < a.n2) { kb[i] = kv; ib[i] = iv; }             // (the sorted half's threads too: their partners read them at the last level)
+          lds_barrier();
+          if (!idle) {
+            const double kp = i < a.n2 ? kb[i ^ j] : kv; const int ip = i < a.n2 ? ib[i ^ j] : iv;
+            const bool mine_first = (kv > kp) || (kv == kp && iv < ip);
+            const bool want_first = (((i & j) == 0) == ((i & kk) == 0));
+            if (mine_first != want_first) { kv = kp; iv = ip; }
           }
-          const bool mine_first = (kv > kp) || (kv == kp && iv < ip);
-          const bool want_first = (((i & j) == 0) == ((i & kk) == 0));      // the lower place of an ascending run, the upper of a descending one
-          if (mine_first != want_first) { kv = kp; iv = ip; }
         }
-      __syncthreads();
-      if (i < a.n2) { key[i] = kv; id[i] = iv; }
-    } else {
-    for (int kk = 2; kk <= a.n2; kk <<= 1)
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        __syncthreads();
-        for (int i = tid; i < a.n2; i += 1024) {
-          const int p = i ^ j;
-          if (p > i) {
-            const double ki = key[i], kp = key[p]; const int ii = id[i], ip = id[p];
-            const bool i_first = (ki > kp) || (ki == kp && ii < ip);
-            const bool up = (i & kk) == 0;                   // this run sorts "first things first"
-            if (i_first != up) { key[i] = kp; key[p] = ki; id[i] = ip; id[p] = ii; }
+      };
+      if (a.n2 == 1024) {                                       // the usual size, unrolled: the distances are compile-time constants
+#define PAYNE_TURN_LEVEL(KK) do { const bool idle = half_sorted && KK <= nl && i < nl; lds_stages(KK, idle); \
+                                  if (!idle) turn_cmpx<KK, (KK / 2 < 32 ? KK / 2 : 32)>(kv, iv, i); } while (0)
+        PAYNE_TURN_LEVEL(2); PAYNE_TURN_LEVEL(4); PAYNE_TURN_LEVEL(8); PAYNE_TURN_LEVEL(16); PAYNE_TURN_LEVEL(32);
+        PAYNE_TURN_LEVEL(64); PAYNE_TURN_LEVEL(128); PAYNE_TURN_LEVEL(256); PAYNE_TURN_LEVEL(512); PAYNE_TURN_LEVEL(1024);
+#undef PAYNE_TURN_LEVEL
+      } else {
+        for (int kk = 2; kk <= a.n2; kk <<= 1) {
+          const bool idle = half_sorted && kk <= nl && i < nl;   // (the same for a whole wave: nl is a multiple of 64 here)
+          lds_stages(kk, idle);
+          if (idle) continue;
+          for (int j = kk >> 1 < 32 ? kk >> 1 : 32; j > 0; j >>= 1) {
+            const double kp = __shfl_xor(kv, j); const int ip = __shfl_xor(iv, j);
+            const bool mine_first = (kv > kp) || (kv == kp && iv < ip);
+            const bool want_first = (((i & j) == 0) == ((i & kk) == 0));      // the lower place of an ascending run, the upper of a descending one
+            if (mine_first != want_first) { kv = kp; iv = ip; }
           }
         }
       }
+      if (buf == 1) lds_barrier();                            // (the last exchange read the first buffer, which the result goes to)
+      if (i < a.n2) { key[i] = kv; id[i] = iv; }
+      if (i < nl && iv >= nl) got_in_flag = 1;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { const int e = tid + q * 1024; if (e < a.n2) { key[e] = kv0[q]; id[e] = iv0[q]; } }
+      export_out();
+      lds_barrier();
+      if (tid == 0) scale = adapted_scale();
+      for (int kk = 2; kk <= a.n2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+          lds_barrier();
+          for (int i = tid; i < a.n2; i += 1024) {
+            const int p = i ^ j;
+            if (p > i) {
+              const double ki = key[i], kp = key[p]; const int ii = id[i], ip = id[p];
+              const bool i_first = (ki > kp) || (ki == kp && ii < ip);
+              const bool up = (i & kk) == 0;                   // this run sorts "first things first"
+              if (i_first != up) { key[i] = kp; key[p] = ki; id[i] = ip; id[p] = ii; }
+            }
+          }
+        }
+      lds_barrier();
+      for (int r = tid; r < nl; r += 1024) if (id[r] >= nl) got_in_flag = 1;
     }
-    __syncthreads();
+    lds_barrier();
     // the threshold the next queue walks under: the largest lnprob left outside the new set.  That is the lnprob D of the last point
     // to die (dynesty's loglstar; payne_ns::peek_index) OR a proposal that was turned away after the last replacement, which lies
     // between D and the new live minimum M -- any threshold in [D, M) is valid to walk under (a proposal is tested again, against the
     // worst live point of its iteration, when the host consumes it), and the host accepts exactly that window (nested.py
     // _fill_queue_dev).  If no proposal got in, nothing died and the old threshold stays.
-    int got_in = 0;
-    for (int r = tid; r < nl; r += 1024) got_in |= (id[r] >= nl) ? 1 : 0;
-    got_in = __syncthreads_or(got_in);
-    lstar = got_in ? key[nl] : a.dyn[1];
-    const long long denom = cnt[1] + cnt[2] > 1 ? cnt[1] + cnt[2] : 1;
-    const double frac = (double)cnt[0] / (double)denom;     // a redrawn (out-of-cube) proposal counts as a rejection
-    scale = a.dyn[0] * exp((frac - 0.5) / nd / 0.5);
-    scale = scale > 1e-4 ? scale : 1e-4; scale = scale < 4.0 ? scale : 4.0;
+    if (tid == 0) lstar = got_in_flag ? key[nl] : dyn1;       // (thread 0 alone writes it, and the scale)
     // the new live set, row r = the r-th best
-    for (int e = tid; e < nl * nd; e += 1024) {
-      const int r = e / nd, d = e - r * nd, who = id[r];
-      const bool live = who < nl;
-      const size_t src = (size_t)(live ? who : who - nl) * nd + d;
-      a.ou[e] = live ? a.lu[src] : a.cu[src];
-      a.ov[e] = live ? a.lv[src] : a.cv[src];
+    // (four elements' loads in flight per thread: one element at a time this loop was a dozen memory latencies end to end, 2.6 us)
+    const float inv_nd = 1.0f / (float)nd;                   // (e < 2^15, nd <= 64: (e + 0.5) / nd is never within rounding of an integer)
+    for (int e0 = tid; e0 < nl * nd; e0 += 4096) {
+      double xu[4], xv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * 1024;
+        xu[q] = 0.0; xv[q] = 0.0;
+        if (e < nl * nd) {
+          const int r = (int)(((float)e + 0.5f) * inv_nd), d = e - r * nd, who = id[r];
+          const bool live = who < nl;
+          const size_t src = (size_t)(live ? who : who - nl) * nd + d;
+          xu[q] = live ? a.lu[src] : a.cu[src];
+          xv[q] = live ? a.lv[src] : a.cv[src];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * 1024;
+        if (e < nl * nd) {
+          a.ou[e] = xu[q]; a.ov[e] = xv[q];
+          if (lds_rows) { turn_rows[e] = xu[q]; turn_rows[nl * nd + e] = xv[q]; }
+        }
+      }
     }
     for (int r = tid; r < nl; r += 1024) a.ol[r] = key[r];
-    __syncthreads();                                         // (the chains' rows are overwritten below; the new set is read back by this workgroup only)
   }
-  __syncthreads();                                           // (the export above has read the old values)
+  if (!a.merge) export_out();
+  turn_barrier();                                            // (the chains' rows are overwritten below -- the export above has read the old values --; the new set is read back by this workgroup only)
   if (tid == 0) { a.dyn[0] = scale; a.dyn[1] = lstar; }
   // start points: uniform among the live points (queue_begin_core's draw)
   auto mix = [](unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
   };
-  __syncthreads();
-  for (int k = tid; k < K; k += 1024) {                       // (K <= 1024; the slot of every chain once, through the sort's LDS)
-    const int i = (int)(mix(a.seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull)) % (unsigned long long)nl);
+  for (int k = tid; k < K; k += 1024) {                       // (K <= 1024; the slot of every chain once, through the sort's LDS -- id[] is free: the barrier above)
+    const unsigned long long r0 = mix(a.seed ^ (0xA5A5A5A5ull + (unsigned long long)k * 0x100000001B3ull));
+    const int i = (nl & (nl - 1)) == 0 ? (int)(r0 & (unsigned long long)(nl - 1)) : (int)(r0 % (unsigned long long)nl);   // (the 64-bit remainder is a routine of 200 instructions)
     id[k] = i;
-    a.cl[k] = a.ol[i];
+    a.cl[k] = a.merge ? key[i] : a.ol[i];
     a.na[k] = 0; a.nc[k] = 0; a.nr[k] = 0;
   }
-  __syncthreads();
-  for (int e = tid; e < K * nd; e += 1024) {
-    const int k = e / nd, d = e - k * nd, i = id[k];
-    a.cu[e] = a.ou[(size_t)i * nd + d];
-    a.cv[e] = a.ov[(size_t)i * nd + d];
+  turn_barrier();
+  const float inv_nd_ = 1.0f / (float)nd;
+  for (int e0 = tid; e0 < K * nd; e0 += 4096) {
+    double xu[4], xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * 1024;
+      xu[q] = 0.0; xv[q] = 0.0;
+      if (e < K * nd) {
+        const int k = (int)(((float)e + 0.5f) * inv_nd_), d = e - k * nd, i = id[k];
+        xu[q] = lds_rows ? turn_rows[i * nd + d] : a.ou[(size_t)i * nd + d];
+        xv[q] = lds_rows ? turn_rows[nl * nd + i * nd + d] : a.ov[(size_t)i * nd + d];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * 1024;
+      if (e < K * nd) { a.cu[e] = xu[q]; a.cv[e] = xv[q]; }
+    }
   }
   if (a.exp_dst) {
-    __threadfence_system();
+    // every wave's stores are acknowledged before it passes the barrier (__syncthreads waits for them); ONE system-scope release then
+    // covers them all (release fences are cumulative) -- a fence in each of the sixteen waves, each a write-back of the L2, was 6 us
     __syncthreads();
     if (tid == 0) __hip_atomic_store(a.exp_flag, a.exp_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1763,7 +1899,7 @@ extern "C" int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, c
   HIPCHK(c, hipMemcpy(s->lv_l[0], live_logl, (size_t)nlive * 8, hipMemcpyHostToDevice));
   const double d2[4] = {scale, loglstar, 0.0, 0.0};
   HIPCHK(c, hipMemcpy(s->dyn, d2, sizeof(d2), hipMemcpyHostToDevice));
-  s->lv_cur = 0; s->dq_launched = 0; s->dq_collected = 0; s->dq_exported = 0; s->dq_n_ell = 0;
+  s->lv_cur = 0; s->lv_sorted = false; s->dq_launched = 0; s->dq_collected = 0; s->dq_exported = 0; s->dq_n_ell = 0;
   return PAYNE_OK;
 }
 extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* axes_unit, int n_ell, const double* ctr, const double* ainv,
@@ -1828,7 +1964,16 @@ extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* 
     HIPCHK(c, hipMemcpy(d2, s->dyn, sizeof(d2), hipMemcpyDeviceToHost));
     ta.scale0 = d2[0]; ta.lstar0 = d2[1];
   }
-  hipLaunchKernelGGL(payne_ns_turn_kernel, dim3(1), dim3(1024), 0, st, ta);
+  size_t rows_bytes = (size_t)nl * nd * 16;
+  if (rows_bytes <= kTurnRowsLdsMax) {
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_ns_turn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)kTurnRowsLdsMax);
+    if (attr != hipSuccess) rows_bytes = 0;
+  } else rows_bytes = 0;
+  ta.rows_lds = rows_bytes ? 1 : 0;
+  ta.live_sorted = s->lv_sorted ? 1 : 0;
+  if (merge) s->lv_sorted = true;
+  hipLaunchKernelGGL(payne_ns_turn_kernel, dim3(1), dim3(1024), rows_bytes, st, ta);
   s->lv_cur = nxt;
   rwalk_begin_impl(s, du, dv, dl, K, dax, dell, 0.0, 0.0, walks, seed, dna, dnc, dnr, stream);
   s->walk.dyn = s->dyn;
