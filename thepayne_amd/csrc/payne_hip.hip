@@ -1273,6 +1273,12 @@ extern "C" int payne_sampler_create(payne_ctx* c, const payne_sampler_desc* d, i
     }
     for (int i = 0; i < PAYNE_MAX_DIM; ++i) { s->sd.q0[i] = qh[i]; s->sd.q1[i] = qh[PAYNE_MAX_DIM + i]; }
   }
+  // the descriptor as the post kernel's tail reads it: it never changes after this point, so it is published here, once (the launch
+  // that opens a walk publishes the walk's own record only -- it used to copy these 4 KB too, by one thread, in front of every queue)
+  if (hipMemcpy(&s->tail_dev->sd, &s->sd, sizeof(SamplerDev), hipMemcpyHostToDevice) != hipSuccess) {
+    payne_sampler_destroy(s);
+    return fail(c, PAYNE_E_HIP, "upload of the sampler descriptor");
+  }
   (void)hipMemset(s->inside, 0, K * 4);
   if (hipHostMalloc((void**)&s->q_host, (q_doubles(K, nd) + 8) * 8, hipHostMallocMapped) != hipSuccess) {
     payne_sampler_destroy(s);
@@ -1481,6 +1487,7 @@ struct TurnArgs {
   // the finished queue's results on their way to the host from HERE (its own transfer kernel was 9 us between two queues): the
   // stores are issued first and drain under the sort; the completion word follows the kernel's last statement
   double* exp_dst; int exp_n; unsigned long long* exp_flag; unsigned long long exp_seq;
+  const double* ax_src; double* ax_dst; int ax_n;      // a new bound (axes, centres, inverse axes) from its mapped host block: a launch of its own was 2.8 us in front of this one
   int live_sorted;                                     // the live set comes from a merging turn: best first (rows and lnprob)
   int rows_lds;                                        // the launch carries nlive * nd * 16 bytes of dynamic LDS: the new live set's rows stay there for the start points
 };
@@ -1508,17 +1515,21 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
   // the host, the next load: the two may alias -- the export alone was 13 memory latencies end to end (3.3 us), the keys (the counter,
   // THEN the lnprob) and the counters three more.  The export's stores go out right in front of the sort, whose exchanges and
   // comparisons leave the memory path to them.
-  double l_in[2] = {0.0, 0.0}; int na_in[2] = {1, 1};
+  // (Every one of these loads is unconditional, its index clamped: a load under a branch leaves the compiler without a count of the
+  // loads behind it, and it waits for ALL of them -- the bound's values included, 2 us away across the bus -- in front of the sort.)
+  double l_in[2]; int na_in[2];
   int s0 = 0, s1 = 0, s2 = 0;
-  if (a.merge) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {                             // (n2 <= 2048)
-      const int e = tid + q * 1024;
-      if (e < nl) l_in[q] = a.ll[e];
-      else if (e < nl + K) { l_in[q] = a.cl[e - nl]; na_in[q] = a.na[e - nl]; }
-    }
-    for (int k = tid; k < K; k += 1024) { s0 += a.na[k]; s1 += a.nc[k]; s2 += a.nr[k]; }
+  for (int q = 0; q < 2; ++q) {                               // (n2 <= 2048; read whether or not this turn merges: one basic block, loads in source order)
+    const int e = tid + q * 1024;
+    const bool is_live = e < nl;
+    const int k = (!is_live && e < nl + K) ? e - nl : 0;
+    const double* lp = is_live ? a.ll + e : a.cl + k;
+    l_in[q] = *lp;
+    na_in[q] = a.na[k];
   }
+  const int kc = tid < K ? tid : K - 1;
+  const int cnt0 = a.na[kc], cnt1 = a.nc[kc], cnt2 = a.nr[kc];
   const double dyn0 = a.dyn[0], dyn1 = a.dyn[1];
   constexpr int kExpBatch = 16;
   double ex[kExpBatch];
@@ -1526,6 +1537,10 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
 #pragma unroll
     for (int q = 0; q < kExpBatch; ++q) { const int e = tid + q * 1024; ex[q] = e < a.exp_n ? a.cu[e] : 0.0; }
   }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) if (tid + q * 1024 < nl) na_in[q] = 1;
+  if (tid < K) { s0 = cnt0; s1 = cnt1; s2 = cnt2; }
+  if (a.merge) for (int k = tid + 1024; k < K; k += 1024) { s0 += a.na[k]; s1 += a.nc[k]; s2 += a.nr[k]; }
   auto export_out = [&]() {                                  // chains | counters (contiguous from a.cu), then the scale and threshold they ran under
     if (!a.exp_dst) return;
 #pragma unroll
@@ -1662,6 +1677,13 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
     }
     for (int r = tid; r < nl; r += 1024) a.ol[r] = key[r];
   }
+  // a new bound: read across the bus (2 us), requested HERE -- loads return in order, whoever waits for a later one waits for these --
+  // and stored at the end, behind the chains' rows
+  double axv[2] = {0.0, 0.0};
+  if (a.ax_n > 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const int e = tid + q * 1024; if (e < a.ax_n) axv[q] = a.ax_src[e]; }
+  }
   if (!a.merge) export_out();
   turn_barrier();                                            // (the chains' rows are overwritten below -- the export above has read the old values --; the new set is read back by this workgroup only)
   if (tid == 0) { a.dyn[0] = scale; a.dyn[1] = lstar; }
@@ -1697,6 +1719,9 @@ __global__ void __launch_bounds__(1024) payne_ns_turn_kernel(TurnArgs a) {
       if (e < K * nd) { a.cu[e] = xu[q]; a.cv[e] = xv[q]; }
     }
   }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { const int e = tid + q * 1024; if (e < a.ax_n) a.ax_dst[e] = axv[q]; }
+  for (int e = tid + 2048; e < a.ax_n; e += 1024) a.ax_dst[e] = a.ax_src[e];
   if (a.exp_dst) {
     // every wave's stores are acknowledged before it passes the barrier (__syncthreads waits for them); ONE system-scope release then
     // covers them all (release fences are cumulative) -- a fence in each of the sixteen waves, each a write-back of the L2, was 6 us
@@ -1939,10 +1964,11 @@ extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* 
       std::memcpy(hax + n_ax, ctr, (size_t)n_ell * nd * 8);
       std::memcpy(hax + n_ax + (size_t)n_ell * nd, ainv, n_ax * 8);
     }
-    hipLaunchKernelGGL(payne_stage_in_kernel, dim3((unsigned)((n_ax + n_as + 1023) / 1024)), dim3(256), 0, st, dax, s->dax_host_dev[b], n_ax + n_as);
     s->dq_n_ell = n_ell;
   }
   TurnArgs ta{};
+  ta.ax_src = s->dyn; ta.ax_dst = nullptr; ta.ax_n = 0;
+  if (axes_unit) { ta.ax_src = s->dax_host_dev[b]; ta.ax_dst = dax; ta.ax_n = (int)(n_ax + n_as); }   // (up with the turn kernel)
   const int cur = s->lv_cur, nxt = merge ? cur ^ 1 : cur;
   ta.lu = s->lv_u[cur]; ta.lv = s->lv_v[cur]; ta.ll = s->lv_l[cur];
   ta.ou = s->lv_u[nxt]; ta.ov = s->lv_v[nxt]; ta.ol = s->lv_l[nxt];

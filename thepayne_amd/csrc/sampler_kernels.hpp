@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, WalkSta
   // the walk for the post kernel's tail (the steps that follow run there): written in stream order, by the launch that
   // opens the walk
   // (a queue launched without the host in between: the record carries the scale and threshold the turn kernel left)
-  if (publish && blockIdx.x == 0 && threadIdx.x == 0) { publish->sd = sd; publish->w = W; publish->w.scale = walk_scale(W); publish->w.loglstar = walk_lstar(W); publish->w.dyn = nullptr; }
+  // (publish->sd: uploaded when the sampler was created)
+  if (publish && blockIdx.x == 0 && threadIdx.x == 0) { publish->w = W; publish->w.scale = walk_scale(W); publish->w.loglstar = walk_lstar(W); publish->w.dyn = nullptr; }
   if (c >= W.K) return;                                         // the whole wave leaves together
   rwalk_step_wave(sd, W, c, lane, lnl_prop[c], step, settle, propose);
 }
