@@ -1426,11 +1426,12 @@ __global__ void __launch_bounds__(1024) payne_stage_out_kernel(double* __restric
   // (several workgroups when `arrivals` is given: the last one to arrive publishes -- atomicInc wraps the count back to zero)
   for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) dst_host[i] = src[i];
   if (blockIdx.x == 0 && src2 && (int)threadIdx.x < n2) dst_host[n + threadIdx.x] = src2[threadIdx.x];   // (the device's scale and threshold behind the block)
-  __threadfence_system();
+  // (every wave's stores are acknowledged before it passes the barrier; ONE thread's release then covers the workgroup's -- release
+  // fences are cumulative --: a fence in each of the sixteen waves, each a write-back of the L2, was 6 us in the turn kernel)
   __syncthreads();
   if (threadIdx.x == 0) {
     bool last = true;
-    if (arrivals && gridDim.x > 1) last = atomicInc(arrivals, gridDim.x - 1) == gridDim.x - 1;
+    if (arrivals && gridDim.x > 1) { __threadfence_system(); last = atomicInc(arrivals, gridDim.x - 1) == gridDim.x - 1; }
     if (last) { __threadfence_system(); __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
 }
