@@ -348,17 +348,38 @@ __device__ __forceinline__ int walk_assign_ell(const WalkState& W, int c, int la
   for (int e = 0; e < W.n_ell; ++e) {
     const double* ce = W.as_ctr + (size_t)e * nd;
     const double* ai = W.as_ainv + (size_t)e * nd * nd;
-    const double diff = uc - ce[a];
+    // (the row's elements requested together, sixteen at a time, the index clamped; the lanes' values fetched together; THEN the
+    // sums, in index order as before -- one element, its wait, one product at a time this loop was nd memory latencies per ellipsoid,
+    // 2.5 us each at twelve dimensions, in front of every queue's first likelihood batch)
+    const double ce_a = ce[a];
     double y = 0.0;
-    for (int b = 0; b < nd; ++b) y += ai[a * nd + b] * __shfl(diff, b);
+    for (int b0 = 0; b0 < nd; b0 += 16) {
+      double r[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { const int b = b0 + q < nd ? b0 + q : nd - 1; r[q] = ai[a * nd + b]; }
+      const double diff = uc - ce_a;
+      double dq[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dq[q] = __shfl(diff, (b0 + q) & 63);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (b0 + q < nd) y += r[q] * dq[q];
+    }
     const double y2 = act ? y * y : 0.0;
     double d2 = 0.0;
-    for (int b = 0; b < nd; ++b) d2 += __shfl(y2, b);
+    for (int b0 = 0; b0 < nd; b0 += 16) {
+      double t[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[q] = __shfl(y2, (b0 + q) & 63);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (b0 + q < nd) d2 += t[q];
+    }
     if (d2 < dbest) { dbest = d2; best = e; }
     if (d2 <= 1.0) {
       ++nin;
       r1 = mix64(r1);
-      if (r1 % (unsigned long long)nin == 0) pick = e;
+      // (r1 % nin == 0: the 64-bit remainder is a routine of 200 instructions; the first two cases are the usual ones)
+      const bool take = nin == 1 ? true : nin == 2 ? (r1 & 1ull) == 0 : r1 % (unsigned long long)nin == 0;
+      if (take) pick = e;
     }
   }
   if (nin == 0) pick = best;
