@@ -198,6 +198,31 @@ def test_three_bf16_parts_hold_an_fp32_value_exactly():
     assert np.all(np.abs(kept - full) <= 2.0 ** -22 * np.abs(full) + 1e-300)
 
 
+def test_turn_kernel_releases_once_and_exchanges_inside_the_wave(tmp_path):
+    """`payne_ns_turn_kernel` (the boundary between two proposal queues, one workgroup): ONE system-scope write-back in front of the
+    completion word -- a `__threadfence_system()` per wave was 6 us of its 29 --, no scratch memory (1024 threads: 128 registers), and
+    the sort network's exchanges at distances below 64 as DPP moves / row swaps in the unrolled 1024-element form (NOTES R5.12e).
+    Read off the assembly of the unit that holds it."""
+    import re
+    import subprocess
+    from thepayne_amd import build
+    asm = tmp_path / "payne_hip.s"
+    cmd = [build._hipcc()] + [f for f in build.HIPCC_FLAGS if f != "-fPIC"] + ["-I", os.path.join(build.ROOT, "include"), "-S", "--cuda-device-only",
+                                                                           os.path.join(build.CSRC, "payne_hip.hip"), "-o", str(asm)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = asm.read_text()
+    m = re.search(r"^_Z20payne_ns_turn_kernel8TurnArgs:.*?s_endpgm", text, re.S | re.M)
+    assert m
+    body = m.group(0)
+    assert body.count("buffer_wbl2") == 1, body.count("buffer_wbl2")
+    assert "scratch_" not in body
+    assert body.count("v_permlane16_swap") >= 15 and body.count("v_permlane32_swap") >= 12          # 6 resp. 5 stages x 3 dwords
+    assert body.count("ds_bpermute") <= 6                                                          # (the generic sizes' loop only)
+    m = re.search(r"^_Z22payne_stage_out_kernel\w*:.*?s_endpgm", text, re.S | re.M)
+    assert m and m.group(0).count("buffer_wbl2") <= 3, m and m.group(0).count("buffer_wbl2")
+
+
 def test_likelihood_post_kernels_keep_two_workgroups_per_cu(tmp_path):
     """The likelihood-only post kernels of the LDS-resident sizes must stay at <= 128 vector registers: at 129 the hardware runs ONE
     512-thread workgroup per compute unit instead of two and the C2 step loses 6 us (NOTES.md 3.3d; it happened three times while
