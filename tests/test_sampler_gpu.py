@@ -582,7 +582,11 @@ def test_device_advanced_priors(tmp_path, photscale):
     prop.close()
 
 
-@pytest.mark.parametrize("nlive,K", [(96, 64), (125, 125), (700, 600)])     # the last: 2048 sort slots (two elements per thread, through LDS)
+# (700, 600): 2048 sort slots (two elements per thread, through LDS); (512, 512) and (512, 300): the unrolled 1024-slot network, the live
+# half sorted from the second merge on (its threads sit the first 45 stages out), with and without padding behind the proposals;
+# (256, 256) and (128, 128): the same short cut in the loop form of the network; (96, 64) and (125, 125): no short cut (the live set is
+# not half of the slots / not whole waves)
+@pytest.mark.parametrize("nlive,K", [(96, 64), (125, 125), (700, 600), (512, 512), (512, 300), (256, 256), (128, 128)])
 def test_queue_turn_on_the_device(tmp_path, nlive, K):
     """payne_ns_queue_dev_*: the live set on the device, queues enqueued one ahead, the turn between two of them made by one
     workgroup.  Against a numpy model of the same rule, queue after queue: every returned proposal beats the threshold its queue ran
