@@ -12,7 +12,9 @@ st = (ctypes.c_ulonglong * 16)()
 lib.payne_debug_turn_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 print("rc", lib.payne_debug_turn_stamps(st))
 s = np.array(list(st), dtype=np.int64)
-names = ["start", "export issued", "keys in LDS", "counters", "sorted", "threshold+scale", "live rows gathered", "barrier", "start slots", "chain rows", "fence", "barrier", "end"]
-for k in range(1, 13):
-    print("%-22s %7d cycles (100 MHz ticks x 24?)" % (names[k], s[k] - s[k - 1]))
-print("total", s[12] - s[0])
+names = ["start", "loads requested", "counters, export's stores, scale", "sorted", "new live rows", "barrier", "start slots", "-",
+         "chain rows", "bound's values stored", "barrier", "end (release, completion word)"]
+for k in (1, 2, 3, 4, 5, 6, 8, 9, 10, 11):
+    prev = k - 1 if k != 8 else 6
+    print("%-36s %7d cycles" % (names[k], s[k] - s[prev]))
+print("total", s[11] - s[0], "cycles of the shader clock (s_memtime)")
