@@ -1169,6 +1169,7 @@ struct payne_sampler {
   double *lv_u[2] = {nullptr, nullptr}, *lv_v[2] = {nullptr, nullptr}, *lv_l[2] = {nullptr, nullptr};
   int lv_n = 0, lv_cur = 0;
   bool lv_sorted = false;    // the current live set is the output of a merging turn: best first
+  bool turn_lds_ok = false;  // this device lets payne_ns_turn_kernel have kTurnRowsLdsMax bytes of dynamic LDS (asked in payne_ns_queue_dev_init)
   double* dyn = nullptr;                  // device: {scale, loglstar}
   double* dq_host[2] = {nullptr, nullptr}; double* dq_host_dev[2] = {nullptr, nullptr};      // two mapped result blocks (+ flag word each)
   unsigned long long dq_seq[2] = {0, 0};
@@ -1925,6 +1926,9 @@ extern "C" int payne_ns_queue_dev_init(payne_sampler* s, const double* live_u, c
   HIPCHK(c, hipMemcpy(s->lv_l[0], live_logl, (size_t)nlive * 8, hipMemcpyHostToDevice));
   const double d2[4] = {scale, loglstar, 0.0, 0.0};
   HIPCHK(c, hipMemcpy(s->dyn, d2, sizeof(d2), hipMemcpyHostToDevice));
+  // (a function attribute belongs to the device it was set on: asked here, with the sampler's device current, not once per process)
+  s->turn_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_ns_turn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kTurnRowsLdsMax) == hipSuccess;
   s->lv_cur = 0; s->lv_sorted = false; s->dq_launched = 0; s->dq_collected = 0; s->dq_exported = 0; s->dq_n_ell = 0;
   return PAYNE_OK;
 }
@@ -1992,11 +1996,7 @@ extern "C" int payne_ns_queue_dev_launch(payne_sampler* s, int K, const double* 
     ta.scale0 = d2[0]; ta.lstar0 = d2[1];
   }
   size_t rows_bytes = (size_t)nl * nd * 16;
-  if (rows_bytes <= kTurnRowsLdsMax) {
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(payne_ns_turn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)kTurnRowsLdsMax);
-    if (attr != hipSuccess) rows_bytes = 0;
-  } else rows_bytes = 0;
+  if (rows_bytes > kTurnRowsLdsMax || !s->turn_lds_ok) rows_bytes = 0;
   ta.rows_lds = rows_bytes ? 1 : 0;
   ta.live_sorted = s->lv_sorted ? 1 : 0;
   if (merge) s->lv_sorted = true;

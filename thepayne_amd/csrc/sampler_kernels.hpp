@@ -51,7 +51,12 @@ __global__ void __launch_bounds__(256) payne_rwalk_kernel(SamplerDev sd, WalkSta
   // opens the walk
   // (a queue launched without the host in between: the record carries the scale and threshold the turn kernel left)
   // (publish->sd: uploaded when the sampler was created)
-  if (publish && blockIdx.x == 0 && threadIdx.x == 0) { publish->w = W; publish->w.scale = walk_scale(W); publish->w.loglstar = walk_lstar(W); publish->w.dyn = nullptr; }
+  // (the two values read FIRST, together: behind the record's stores -- which may alias them -- each was a round trip of its own on the
+  // wave that then walks chain 0, and the launch lasts as long as its slowest wave)
+  if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double sc = walk_scale(W), ls = walk_lstar(W);
+    publish->w = W; publish->w.scale = sc; publish->w.loglstar = ls; publish->w.dyn = nullptr;
+  }
   if (c >= W.K) return;                                         // the whole wave leaves together
   rwalk_step_wave(sd, W, c, lane, lnl_prop[c], step, settle, propose);
 }
