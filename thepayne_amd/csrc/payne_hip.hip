@@ -1445,20 +1445,6 @@ __global__ void __launch_bounds__(1024) payne_stage_out_kernel(double* __restric
 // the queue's counters, the new threshold (the largest lnprob left outside the set: the last point to die), and every chain's start point, uniform among the new live
 // points (the host's splitmix of the seed).  The host replays the same queue for the evidence in its own time; its live SET is the
 // same, its slot order is not (nothing on the device depends on it).
-// The sort network's exchanges inside a wave without the LDS crossbar: lane l ^ J's value by data-parallel-primitive moves (J <= 8:
-// quad permutes, the mirrors of a half row and of a quad composed, a row rotated by 8) and gfx950's row / half swaps (J = 16, 32:
-// both copies go in, the partner's value comes back in one of them, which one by the lane's own bit).
-template <int J>
-__device__ __forceinline__ int turn_lane_xor(int v, bool upper) {
-  if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
-  else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-  else if constexpr (J == 4) {
-    const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);                      // row_half_mirror: l ^ 7
-    return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true);                              // quad_perm [3,2,1,0]: ^ 3
-  } else if constexpr (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);  // row_ror:8
-  else if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); return (int)(upper ? r[0] : r[1]); }
-  else { static_assert(J == 32, "in-wave distance"); const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); return (int)(upper ? r[0] : r[1]); }
-}
 // sum of an int over the wave, in lane 63 (an inclusive scan inside each row of 16 lanes, then the rows' totals handed on)
 template <int CTRL> __device__ __forceinline__ int turn_dpp_add(int x) { return x + __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ int turn_wave_sum_to_last(int x) {
@@ -1466,14 +1452,15 @@ __device__ __forceinline__ int turn_wave_sum_to_last(int x) {
   x = turn_dpp_add<0x142>(x); x = turn_dpp_add<0x143>(x);                                                            // row_bcast 15, 31
   return x;
 }
+// (the network's exchanges at distances below 64: lane_xor_i32, sampler_core.hpp)
 // one stage of the bitonic network at distance J < 64 inside runs of KK, "before" = larger lnprob, then smaller id
 template <int KK, int J>
 __device__ __forceinline__ void turn_cmpx(double& kv, int& iv, int i) {
   union { double d; int w[2]; } me, pa;
   me.d = kv;
   const bool upper = (i & J) != 0;
-  pa.w[0] = turn_lane_xor<J>(me.w[0], upper); pa.w[1] = turn_lane_xor<J>(me.w[1], upper);
-  const int ip = turn_lane_xor<J>(iv, upper);
+  pa.w[0] = lane_xor_i32<J>(me.w[0], upper); pa.w[1] = lane_xor_i32<J>(me.w[1], upper);
+  const int ip = lane_xor_i32<J>(iv, upper);
   const bool mine_first = (kv > pa.d) || (kv == pa.d && iv < ip);
   const bool want_first = (!upper) == ((i & KK) == 0);                       // the lower place of an ascending run, the upper of a descending one
   if (mine_first != want_first) { kv = pa.d; iv = ip; }

@@ -176,9 +176,45 @@ constexpr int kRedrawPasses = 2;
 #define PAYNE_AX_BATCH 4
 #endif
 constexpr int kAxBatch = PAYNE_AX_BATCH;
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+// Lane l ^ J's value without the LDS crossbar: data-parallel-primitive moves (J <= 8: quad permutes, the mirrors of a half row and of a
+// quad composed, a row rotated by 8) and gfx950's row / half swaps (J = 16, 32: both copies go in, the partner's value comes back in one
+// of them, which one by the lane's own bit `upper` = lane & J).  A `ds_bpermute` round trip is ~130 cycles, and the sums below are chains
+// of four to six of them on the critical path of a chain step; these are the same values, so the same sums to the bit.
+template <int J>
+__device__ __forceinline__ int lane_xor_i32(int v, bool upper) {
+  if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);                      // row_half_mirror: l ^ 7
+    return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true);                              // quad_perm [3,2,1,0]: ^ 3
+  } else if constexpr (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  else if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); return (int)(upper ? r[0] : r[1]); }
+  else { static_assert(J == 32, "in-wave distance"); const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); return (int)(upper ? r[0] : r[1]); }
+}
+template <int J>
+__device__ __forceinline__ double lane_xor_f64(double x, int lane) {
+  union { double d; int w[2]; } a, b;
+  a.d = x;
+  const bool upper = (lane & J) != 0;
+  b.w[0] = lane_xor_i32<J>(a.w[0], upper); b.w[1] = lane_xor_i32<J>(a.w[1], upper);
+  return b.d;
+}
+template <int J>
+__device__ __forceinline__ float lane_xor_f32(float x, int lane) {
+  return __int_as_float(lane_xor_i32<J>(__float_as_int(x), (lane & J) != 0));
+}
+// x summed over the lanes of every aligned group of NP (a power of two, 8 .. 64), in every lane: partner distances NP/2 .. 1 in that order
+__device__ __forceinline__ float group_sum_f32(float x, int NP, int lane) {
+  if (NP >= 64) x += lane_xor_f32<32>(x, lane);
+  if (NP >= 32) x += lane_xor_f32<16>(x, lane);
+  if (NP >= 16) x += lane_xor_f32<8>(x, lane);
+  x += lane_xor_f32<4>(x, lane); x += lane_xor_f32<2>(x, lane); x += lane_xor_f32<1>(x, lane);
+  return x;
+}
+__device__ __forceinline__ double wave_sum(double x) {          // (partner distances 32, 16, .. 1 in that order)
+  const int lane = (int)(threadIdx.x & 63);
+  x += lane_xor_f64<32>(x, lane); x += lane_xor_f64<16>(x, lane); x += lane_xor_f64<8>(x, lane);
+  x += lane_xor_f64<4>(x, lane); x += lane_xor_f64<2>(x, lane); x += lane_xor_f64<1>(x, lane);
   return x;
 }
 // What a step reads from global memory before it can do anything: requested in one go -- first what hangs off the
@@ -283,7 +319,7 @@ __device__ __forceinline__ void rwalk_step_core(const SamplerDev& sd, const Walk
       z = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a)) * __builtin_amdgcn_cosf(b);   // -2 ln a = -2 ln2 log2 a; cos(2 pi b)
     }
     float n2 = z * z;
-    for (int o = NP >> 1; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);   // sum over the candidate's own lanes
+    n2 = group_sum_f32(n2, NP, lane);                              // sum over the candidate's own lanes
     const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01f(seed, c, step, d0 + 128)) / (float)nd) * __builtin_amdgcn_rsqf(n2);
     double sdot = 0.0;
 #pragma unroll
@@ -456,7 +492,7 @@ __device__ __forceinline__ void rwalk_spec_wave(const SamplerDev& sd, const Walk
       z = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a)) * __builtin_amdgcn_cosf(b);
     }
     float n2 = z * z;
-    for (int x = NP >> 1; x > 0; x >>= 1) n2 += __shfl_xor(n2, x);
+    n2 = group_sum_f32(n2, NP, lane);
     const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01f(W.seed, c, step, d0 + 128)) / (float)nd) * __builtin_amdgcn_rsqf(n2);
     double sdot = 0.0;
 #pragma unroll
@@ -484,8 +520,7 @@ __device__ __forceinline__ void rwalk_spec_wave(const SamplerDev& sd, const Walk
   if (!in) up = up_fail;
   const double vp = in ? prior_ppf(dim, q0, q1, up, sd.adv) : vc;
   double lp = act ? prior_ln(dim, vp) : 0.0;
-#pragma unroll
-  for (int x = kSpecLanes >> 1; x > 0; x >>= 1) lp += __shfl_xor(lp, x);     // (wave_sum's last four levels: the others add zeros)
+  lp += lane_xor_f64<8>(lp, lane); lp += lane_xor_f64<4>(lp, lane); lp += lane_xor_f64<2>(lp, lane); lp += lane_xor_f64<1>(lp, lane);   // (wave_sum's last four levels: the others add zeros)
   if (W.adv_on) {
     const payne_adv_priors& a = sd.adv;
     const double g_ = __shfl(vp, gb + (a.dim_logg >= 0 ? a.dim_logg : 0)), r_ = __shfl(vp, gb + (a.dim_logr >= 0 ? a.dim_logr : 0));
