@@ -480,10 +480,14 @@ def workload_text(cfg_name, d):
     return s + ", batch of %d candidate vectors per step (dynesty live points)" % d["B"]
 
 
-def end_to_end(cfg_name, B, value, calls, runs=3):
+def end_to_end(cfg_name, B, value, calls, runs=3, cpu=None, fit=True):
     """the same likelihood as the batched nested sampler sees it -- prior transform, random-walk
     proposals (device), transfers and the dead-point bookkeeping included.  `runs` runs of `calls` likelihood calls
-    each (different sampler seeds; dlogz small enough that none stops early); the median rate is quoted."""
+    each (different sampler seeds; dlogz small enough that none stops early); the median rate is quoted.
+    Beside the calls/s: ITERATIONS/s (dead points: the unit of the reference's progress line, fitstar.py:337-338, 398-401) and
+    calls per iteration, and -- `fit` -- ONE complete fit at the reference's defaults (delta_logz_final = 0.01, walks = 25,
+    fitstar.py:262-271; the remaining live points added, :410) with its wall time, next to what the CPU port's measured rate makes
+    of the same number of calls on the same cores."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import sampler_bench
@@ -495,20 +499,153 @@ def end_to_end(cfg_name, B, value, calls, runs=3):
     hv = [r["device_chunks_hostturn"] for r in both]
     hv_rates = sorted(r["evals_per_s"] for r in hv)
     hv_med = float(np.median(hv_rates))
-    return {"value": med, "unit": "likelihood-evals/s", "runs": runs, "rates": rates,
-            "calls": int(sum(r["calls"] for r in rs)), "iterations": int(sum(r["iterations"] for r in rs)),
-            "seconds": float(sum(r["seconds"] for r in rs)),
-            "frac_of_kernel_only": med / value,
-            "resyncs": int(sum(r.get("resyncs", 0) for r in rs)), "logz": [round(r["logz"], 3) for r in rs],
-            "what": "static nested sampler, %d live points, rwalk x25 on the device, bound='multi' (ellipsoid decomposition "
-                    "by recursive 2-means), dead points consumed in bulk, the sampler's default loop: the turn between two proposal "
-                    "queues made on the device, the next queue enqueued before the current one has finished "
-                    "(sampler['pipeline'] = 'device'; tests/test_sampler_gpu.py::test_turn_on_the_device_is_the_same_run_statistically); "
-                    "median of %d runs" % (B, runs),
-            # the same runs with the turn made on the host and the next queue launched ahead of the bookkeeping (pipeline=True: the
-            # default until round 5)
-            "host_turn": {"value": hv_med, "rates": hv_rates, "frac_of_kernel_only": hv_med / value,
-                          "logz": [round(r["logz"], 3) for r in hv]}}
+    n_calls, n_it, secs = int(sum(r["calls"] for r in rs)), int(sum(r["iterations"] for r in rs)), float(sum(r["seconds"] for r in rs))
+    out = {"value": med, "unit": "likelihood-evals/s", "runs": runs, "rates": rates,
+           "calls": n_calls, "iterations": n_it, "seconds": secs,
+           "iterations_per_s": float(np.median([r["iterations"] / r["seconds"] for r in rs])),
+           "calls_per_iteration": n_calls / max(1, n_it),
+           # ONE denominator: this run's headline `value` (the median block of `steps` steps of the same process)
+           "frac_of_kernel_only": med / value,
+           "resyncs": int(sum(r.get("resyncs", 0) for r in rs)), "logz": [round(r["logz"], 3) for r in rs],
+           "what": "static nested sampler, %d live points, rwalk x25 on the device, bound='multi' (ellipsoid decomposition "
+                   "by recursive 2-means), dead points consumed in bulk, the sampler's default loop: the turn between two proposal "
+                   "queues made on the device, the next queue enqueued before the current one has finished "
+                   "(sampler['pipeline'] = 'device'; tests/test_sampler_gpu.py::test_turn_on_the_device_is_the_same_run_statistically); "
+                   "median of %d runs.  A lock-step queue of K = nlive proposals is consumed under a rising threshold, so ~ln 2 of its "
+                   "calls end as dead points' replacements: `calls_per_iteration` is walks / that fraction" % (B, runs),
+           # the same runs with the turn made on the host and the next queue launched ahead of the bookkeeping (pipeline=True: the
+           # default until round 5)
+           "host_turn": {"value": hv_med, "rates": hv_rates, "frac_of_kernel_only": hv_med / value,
+                         "logz": [round(r["logz"], 3) for r in hv]}}
+    if fit:
+        try:
+            f = sampler_bench.run(cfg_name, maxcall=None, nlive=B, walks=25, modes=("device_chunks",), seed=11, dlogz=0.01,
+                                  complete=True)["device_chunks"]
+            blk = {"fit_wall_s": f["seconds"], "iterations": f["iterations"], "calls": f["calls"], "logz": round(f["logz"], 3),
+                   "logzerr": round(f["logzerr"], 3), "dlogz": 0.01, "walks": 25, "nlive": B,
+                   "iterations_per_s": f["iterations"] / max(f["seconds"], 1e-9),
+                   "what": "one complete fit: delta_logz_final = 0.01 (fitstar.py:262-271), walks = 25, the remaining live points "
+                           "added (fitstar.py:410); wall time of the sampling loop, set-up (network upload, first live points) excluded"}
+            if cpu:
+                blk["cpu_port_projected_s"] = f["calls"] / max(cpu["value"], 1e-9)
+                blk["cpu_port_projection"] = ("the fit's %d calls / (%d cores x %.0f evals/s/core of `cpu_baseline`)"
+                                              % (f["calls"], cpu["cores"], cpu["per_core"]))
+            out["fit"] = blk
+        except Exception as ex:                              # the headline must not die with a side run
+            out["fit"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    return out
+
+
+# ----------------------------------------------------------------------------
+# The line the driver parses.  Everything measured goes to bench_detail.json beside this file (the full record: notes, kernel names,
+# per-configuration roofline blocks); the LAST stdout line is the contract's fields only, numbers rounded, no prose, < 4 KB
+# (tests/test_host_logic.py::test_bench_line_is_small_and_complete).
+# ----------------------------------------------------------------------------
+LINE_LIMIT = 4096
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+
+
+def _r(x, sig=6):
+    """Numbers at `sig` significant digits (the line carries measurements, not bit patterns)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (sig, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if k in d and d[k] is not None or k in d and k in ("traffic", "vs_baseline")}
+
+
+def final_line(full):
+    """The compact record of one bench run (a dict whose JSON is the last stdout line) from the full one."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_wall", "repeats",
+                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "invalid"))
+    c = full.get("config", {})
+    out["config"] = {"workload": c.get("workload_short", c.get("workload", ""))[:160],
+                     **_pick(c, ("batch", "npix", "nobs", "stars", "kernel_variant"))}
+    if "parallelism" in c:
+        out["config"]["parallelism"] = str(c["parallelism"])[:96]
+    if full.get("n_gpus", 1) > 1 or full.get("collective_backend"):
+        out["collective_backend"] = full.get("collective_backend")
+        out["per_rank_evals_per_s"] = [_r(v, 5) for v in full.get("per_rank_evals_per_s", [])][:16]
+    rf = full.get("roofline")
+    if rf:
+        out["roofline"] = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_us_per_launch",
+                                     "alg_flops_per_launch", "alg_bytes_per_launch", "hbm_frac_counters"))
+        out["roofline"]["kernel"] = str(rf.get("kernel", ""))[:48]
+        out["roofline"].setdefault("traffic", None)
+    mk = full.get("mfma_kernel")
+    if mk:
+        out["mfma_kernel"] = {"kernel": str(mk.get("kernel", "")).split(" ")[0], **_pick(mk, ("avg_us_per_launch", "achieved_tflops",
+                                                                                              "frac_of_fp32_peak", "frac_of_bf16_peak"))}
+    if "kernels_us" in full:
+        out["kernels_us"] = {k: _r(v, 4) for k, v in full["kernels_us"].items() if v}
+    ws = full.get("whole_step")
+    if ws:
+        out["whole_step_frac_of_fp32_peak"] = _r(ws.get("frac_of_fp32_peak_on_wall_time"), 4)
+    hb = full.get("hbm")
+    if hb:
+        out["hbm"] = _pick(hb, ("achieved", "peak", "unit", "frac", "pmc_bytes_per_step", "alg_bytes_per_step"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "per_core", "kind"))
+        out["cpu_baseline"]["sample"] = cb.get("sample_short", str(cb.get("sample", ""))[:120])
+    ee = full.get("end_to_end")
+    if ee:
+        out["end_to_end"] = _pick(ee, ("value", "unit", "frac_of_kernel_only", "iterations_per_s", "calls_per_iteration", "calls",
+                                       "iterations", "runs"))
+        if "host_turn" in ee:
+            out["end_to_end"]["host_turn"] = _r(ee["host_turn"].get("value"))
+        if "fit" in ee:
+            out["end_to_end"]["fit"] = _pick(ee["fit"], ("fit_wall_s", "iterations", "calls", "logz", "logzerr", "dlogz", "walks", "nlive",
+                                                         "iterations_per_s", "cpu_port_projected_s", "error"))
+    al = full.get("also_measured")
+    if al:
+        out["also_measured"] = {}
+        for name, blk in al.items():
+            if "error" in blk:
+                out["also_measured"][name] = {"error": str(blk["error"])[:80]}
+                continue
+            e = {"value": _r(blk.get("value")), "ms_per_step": _r(blk.get("ms_per_step"), 5),
+                 "roofline_frac": _r(blk.get("roofline", {}).get("frac"), 4)}
+            if "kernels_us" in blk:
+                e["kernels_us"] = {k: _r(v, 4) for k, v in blk["kernels_us"].items() if v}
+            t = blk.get("roofline", {}).get("traffic")
+            if t:
+                e["traffic"] = _r(t, 4)
+            if "end_to_end" in blk and "value" in blk["end_to_end"]:
+                e["end_to_end"] = _r(blk["end_to_end"]["value"])
+            if "cpu_baseline" in blk:
+                e["cpu_per_core"] = _r(blk["cpu_baseline"].get("per_core"), 4)
+            out["also_measured"][name] = e
+    out["detail"] = os.path.basename(DETAIL_FILE)
+    # the line must stay parsable whatever a run adds: the optional blocks shrink, then go, until it fits
+    def slim():
+        out["also_measured"] = {n: ({"value": b.get("value"), "ms_per_step": b.get("ms_per_step"), "roofline_frac": b.get("roofline_frac")}
+                                    if "error" not in b else b) for n, b in out["also_measured"].items()}
+    steps = [slim if "also_measured" in out else None] + [(lambda k=k: out.pop(k, None)) for k in
+             ("kernels_us", "mfma_kernel", "hbm", "per_rank_evals_per_s", "also_measured")]
+    for act in steps:
+        if len(json.dumps(out)) < LINE_LIMIT:
+            break
+        if act is not None:
+            act()
+    return out
+
+
+def emit(full):
+    """Full record -> bench_detail.json; compact record -> the last stdout line."""
+    try:
+        with open(DETAIL_FILE, "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError as ex:                                    # a read-only tree must not cost the line
+        print("bench: could not write %s: %s" % (DETAIL_FILE, ex), file=sys.stderr)
+    line = json.dumps(final_line(full))
+    assert len(line) < LINE_LIMIT, len(line)
+    print(line, flush=True)
 
 
 # ----------------------------------------------------------------------------
@@ -635,13 +772,13 @@ def main():
         out["also_measured"] = also
 
     if world == 1 and not args.no_e2e and B <= 4096 and d["N"] <= 16384:
-        out["end_to_end"] = end_to_end(args.config, B, out["value"], args.e2e_calls)
+        out["end_to_end"] = end_to_end(args.config, B, out["value"], args.e2e_calls, cpu=cpu)
         if args.config == "C2" and "also_measured" in out and "value" in out["also_measured"].get("C3", {}):
             try:
-                out["also_measured"]["C3"]["end_to_end"] = end_to_end("C3", B, out["also_measured"]["C3"]["value"], args.e2e_calls)
+                out["also_measured"]["C3"]["end_to_end"] = end_to_end("C3", B, out["also_measured"]["C3"]["value"], args.e2e_calls, fit=False)
             except Exception as ex:
                 out["also_measured"]["C3"]["end_to_end"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if grouped:
         dist.destroy_process_group()
 

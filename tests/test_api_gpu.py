@@ -533,3 +533,75 @@ def test_two_documented_deviations_from_the_reference(tmp_path):
     assert np.isnan(f).all()
     _, ok = PS.getspec(inst_R=2.355 * 28000.0, outwave=tight, **kw)                       # an ordinary mask on the same net
     assert np.isfinite(ok).all()
+
+
+def _integration_block():
+    """The python block of INTEGRATION.md section 3, as text."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3. The stub a maintainer adds"):text.index("## 4. Using the batch with a sampler")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 1
+    return blocks[0]
+
+
+def test_the_documented_binding_runs_as_written(golden, monkeypatch):
+    """INTEGRATION.md section 3 is the reference-side evidence of the boundary: the ctypes stub a maintainer adds to
+    Payne/fitting/likelihood.py.  It is executed here exactly as printed there, on a stand-in for the reference's likelihood object
+    whose network carries the attribute names of Payne/predict/ystpred.py:22-38, and must reproduce the values frozen from the
+    reference (g4: 512 prior draws at C2) at SURVEY 8(d)'s tolerance.  A renamed struct field, a changed argument order or a
+    stale column map fails this test."""
+    import os
+    import types
+    from thepayne_amd import _lib
+    monkeypatch.setenv("PAYNE_HIP_LIB", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(_integration_block(), "INTEGRATION.md#3", "exec"), ns)
+    # the structures of the stub against the ones the product path binds (field names, order, types)
+    for doc, own in (("payne_layer", _lib.Layer), ("payne_model_desc", _lib.ModelDesc), ("payne_obs_desc", _lib.ObsDesc),
+                     ("payne_opts", _lib.Opts)):
+        a, b = ns[doc], own
+        assert [f[0] for f in a._fields_] == [f[0] for f in b._fields_], doc
+        assert ctypes_sizeof(a) == ctypes_sizeof(b), doc
+    g = golden("g4_lnlike_c2")
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    anns = types.SimpleNamespace(**{k: raw[k] for k in ("w_array_0", "w_array_1", "w_array_2", "b_array_0", "b_array_1", "b_array_2")},
+                                 xmin=raw["x_min"], xmax=raw["x_max"], wavelength=raw["wavelength"], resolution=raw["resolution"])
+
+    class likelihood(ns["HipLikelihood"]):                    # what the reference's class looks like to the stub
+        def __init__(self, fitargs, fitpars_i, fixedpars):
+            self.GM = types.SimpleNamespace(PP=types.SimpleNamespace(anns=anns))
+            self.fitpars_i, self.fixedpars = list(fitpars_i), dict(fixedpars)
+            self.ndim = len(self.fitpars_i)
+            self._hip_init(fitargs)
+
+    fitargs = {'obs_wave_fit': g["obs_wave"], 'obs_flux_fit': g["obs_flux"], 'obs_eflux_fit': g["obs_eflux"]}
+    L = likelihood(fitargs, SPEC_PARS, {})
+    lnl = L.lnlike_batch(g["theta"])
+    err = np.abs(lnl - g["lnlike"])
+    assert np.all(err <= lnl_tol(g["lnlike"])), (err.max(), int(np.argmax(err)))
+    # more rows than b_max, the scalar contract, parsdict as the reference leaves it
+    big = np.tile(g["theta"], (2, 1))[:700]
+    assert np.array_equal(L.lnlike_batch(big)[512:], lnl[:188])
+    assert L.lnlikefn(g["theta"][3]) == lnl[3] and L.parsdict['Teff'] == g["theta"][3, 0]
+    L._hip_close()
+    # a fixed parameter is merged like likelihood.py:47-48
+    free = [p for p in SPEC_PARS if p != 'Vrot']
+    L2 = likelihood(fitargs, free, {'Vrot': float(g["theta"][5, 5])})
+    row = np.delete(g["theta"][5], 5)
+    assert abs(L2.lnlikefn(row) - g["lnlike"][5]) <= lnl_tol(g["lnlike"][5])
+    L2._hip_close()
+    # errors come back as the library's message
+    class bad(likelihood):
+        def _hip_init(self, fitargs):
+            ns["HipLikelihood"]._hip_init(self, fitargs, b_max=0)
+    with pytest.raises(RuntimeError, match="b_max"):
+        bad(fitargs, SPEC_PARS, {})
+
+
+def ctypes_sizeof(t):
+    import ctypes
+    return ctypes.sizeof(t)

@@ -1,6 +1,7 @@
 """Host-side logic (no GPU): prior transforms / ln-priors and helpers against golden
 vectors frozen from the reference; the C-ABI library loads and exports its symbols."""
 import ctypes
+import json
 import os
 import re
 
@@ -276,3 +277,52 @@ def test_instruction_census_of_the_post_kernels_phases(tmp_path):
         assert k in rows and rows[k] > 0, (k, rows)
     assert rows["census_resample"] < rows["census_resample_general"] and rows["census_obs"] < rows["census_obs_general"], rows
     assert rows["census_obs"] <= 200 and rows["census_first"] <= 200 and rows["census_resample"] <= 130, rows
+
+
+def test_bench_line_is_small_and_complete():
+    """bench.py's LAST stdout line is what the driver parses: the contract's fields, `roofline` and `cpu_baseline` in it, numbers only,
+    under 4 KB whatever the run measured (round 5's 21 KB line was not parsed); the full record goes to bench_detail.json."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")))       # a real run's full record (21 KB)
+    full["end_to_end"].update({"iterations_per_s": 3.9e5, "calls_per_iteration": 37.1,
+                               "fit": {"fit_wall_s": 0.0812, "iterations": 27411, "calls": 1017000, "logz": -1814.2, "logzerr": 0.21,
+                                       "dlogz": 0.01, "walks": 25, "nlive": 512, "iterations_per_s": 3.4e5, "cpu_port_projected_s": 87.3,
+                                       "what": "x" * 500}})
+    line = bench.final_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT and json.loads(text) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "end_to_end", "also_measured"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["metric"] == full["metric"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=1e-4)
+    for k in ("value", "unit", "cores", "kind", "sample", "per_core"):
+        assert k in line["cpu_baseline"], k
+    for k in ("value", "frac_of_kernel_only", "iterations_per_s", "calls_per_iteration", "fit"):
+        assert k in line["end_to_end"], k
+    assert line["end_to_end"]["fit"]["fit_wall_s"] == pytest.approx(0.0812) and "what" not in line["end_to_end"]["fit"]
+    assert set(line["also_measured"]) == set(full["also_measured"])
+    for blk in line["also_measured"].values():
+        assert {"value", "ms_per_step", "roofline_frac"} <= set(blk)
+    assert "workload" in line["config"] and "model" not in line["config"]
+    # no prose: no string in the line is longer than the workload sentence
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert max(len(x) for x in strings(line)) <= 160
+    # a run that measured much more (ten more configurations, a multi-rank table) still fits: optional blocks shrink first
+    big = json.loads(json.dumps(full))
+    for i in range(30):
+        big["also_measured"]["X%d" % i] = big["also_measured"]["C5"]
+    big["n_gpus"], big["per_rank_evals_per_s"], big["collective_backend"] = 8, [1.5e7] * 8, "nccl"
+    line = bench.final_line(big)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert "roofline" in line and "cpu_baseline" in line and line["n_gpus"] == 8
+    # a side run that failed is reported, shortly
+    big["also_measured"] = {"C5": {"error": "RuntimeError: " + "y" * 900}}
+    assert len(bench.final_line(big)["also_measured"]["C5"]["error"]) <= 80

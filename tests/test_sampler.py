@@ -245,6 +245,40 @@ def test_queue_launched_ahead_is_the_queue_launched_after():
     assert abs(Sa.results.logz[-1] - (0.5 * nd * np.log(2 * np.pi) + nd * np.log(0.07))) < 5 * Sa.results.logzerr[-1] + 0.3
 
 
+def test_default_loop_is_sized_by_the_proposers_k_max_not_the_queue():
+    """The device turn (payne_ns_queue_dev_init) is sized by the proposer's k_max: the dynamic sampler builds its proposer with
+    k_max = 2 npoints, fitstar's static one with max(npoints, queue_size).  The default loop must be the device turn only where
+    nlive + k_max fits the turn kernel's 2048 slots, the host-turn loop otherwise; asked for by name it must refuse."""
+    from thepayne_amd.build import build_lib
+    build_lib()
+
+    def ll(V):
+        return -0.5 * np.sum(((V - 0.5) / 0.07) ** 2, axis=1)
+
+    class _Dev(_QueueProposer):
+        def __init__(self, ll, k_max):
+            _QueueProposer.__init__(self, ll)
+            self.k_max = k_max
+
+        def queue_dev_launch(self, *a, **k):
+            raise AssertionError("the device turn must not be chosen here")
+
+    for nlive, queue, k_max, dev in ((512, 512, 512, True), (700, 700, 1400, False), (1100, 512, 1100, False), (1024, 1024, 1024, True)):
+        S = NestedSampler(ll, lambda U: U, 3, nlive=nlive, bound='single', sample='rwalk', walks=4, batched=True, queue_size=queue,
+                          rstate=np.random.default_rng(1), proposer=_Dev(ll, k_max))
+        assert S._dev_turn == dev and (dev or S.pipeline), (nlive, queue, k_max)
+        if not dev:
+            with pytest.raises(ValueError):
+                NestedSampler(ll, lambda U: U, 3, nlive=nlive, bound='single', sample='rwalk', walks=4, batched=True, queue_size=queue,
+                              rstate=np.random.default_rng(1), proposer=_Dev(ll, k_max), pipeline='device')
+    # and such a run works through the host-turn loop (it failed with PAYNE_E_UNSUPPORTED at the first queue before)
+    prop = _Dev(ll, 1400)
+    S = NestedSampler(ll, lambda U: U, 3, nlive=700, bound='single', sample='rwalk', walks=4, batched=True, queue_size=700,
+                      rstate=np.random.default_rng(1), proposer=prop)
+    n = sum(len(r["logl"]) for r in S.sample_chunks(maxiter=900, dlogz=1e-9))
+    assert n == 900 and prop.begun >= 1
+
+
 def test_peek_predicts_the_consumed_state():
     """payne_ns_peek against payne_ns_consume on the same queue: the same live points and threshold, the same number of dead
     points; ties and -inf values included; an empty and a useless queue."""

@@ -202,7 +202,9 @@ class NestedSampler(object):
         # queues launched ahead from the host's turn (True), else the serial loop.  The evidence for the switch: twenty seeds of each
         # loop on the C2 fit give the same ln Z, the same posterior means and widths and no re-upload
         # (tests/test_sampler_gpu.py::test_turn_on_the_device_is_the_same_run_statistically); it is 4-5 % faster end to end.
-        dev_ok = sample == 'rwalk' and hasattr(proposer, "queue_dev_launch") and native and self.nlive + self.queue_size <= 2048
+        # (the turn kernel is sized by the PROPOSER's k_max, payne_ns_queue_dev_init: a Dynamic run builds its proposer with k_max = 2 npoints)
+        dev_ok = sample == 'rwalk' and hasattr(proposer, "queue_dev_launch") and native and \
+            self.nlive + max(self.queue_size, int(getattr(proposer, "k_max", self.queue_size))) <= 2048
         if pipeline is None and dev_ok:
             pipeline = 'device'
         if isinstance(pipeline, str) and pipeline == 'host':           # the same queues with the turn on the host
@@ -211,7 +213,7 @@ class NestedSampler(object):
         if self._dev_turn:
             if not dev_ok:
                 raise ValueError("pipeline='device' needs sample='rwalk', native bookkeeping, a proposer with queue_dev_launch and "
-                                 "nlive + queue_size <= 2048")
+                                 "nlive + max(queue_size, proposer.k_max) <= 2048")
             pipeline = False
         self._dev_sync, self._dev_inflight, self._dev_desync = False, 0, 0
         self.pipeline = (sample == 'rwalk' and hasattr(proposer, "rwalk_queue_begin") and native) if pipeline is None else bool(pipeline)

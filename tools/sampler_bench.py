@@ -67,10 +67,11 @@ def make_problem(config="C2", nlive=512, variant=0):
 
 
 def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device", "device_chunks", "device2_chunks"),
-        verbose=False, bound='multi', variant=0, seed=1, dlogz=0.01):
+        verbose=False, bound='multi', variant=0, seed=1, dlogz=0.01, complete=False):
     """Likelihood calls per second as the nested sampler sees them (prior transform, proposals, transfers,
     bookkeeping included).  Returns {mode: {...}}.  config 'C3' = C2 + photometry in seven filters (joint fit, photscale).
-    `seed`: the sampler's random stream; `dlogz`: stopping threshold (tiny: the run ends at `maxcall`).
+    `seed`: the sampler's random stream; `dlogz`: stopping threshold (tiny: the run ends at `maxcall`); `complete`: the run is a whole
+    fit (maxcall=None, dlogz as the reference's delta_logz_final) and the remaining live points are added inside the timed region.
     Modes: "device_chunks" = proposals on the device, the sampler's default loop (the turn between two queues on the device where the
     proposer offers it); "..._hostturn" = the turn made on the host, queues launched ahead; "..._serial" = every queue launched after
     the one before is consumed; "..._devturn" = pipeline='device' asked for by name."""
@@ -110,8 +111,12 @@ def run(config="C2", maxcall=300000, nlive=512, walks=25, modes=("host", "device
         else:
             for _ in S.sample(maxcall=maxcall, dlogz=dlogz):
                 pass
+        if complete:                                        # a whole fit: + the remaining live points (fitstar.py:410)
+            for _ in S.add_live_points():
+                pass
         dt = time.perf_counter() - t0
         out[mode] = {"calls": int(S.ncall - c0), "iterations": int(S.it - 1), "seconds": round(dt, 4),
+                     "logzerr": float(np.sqrt(max(S.logzvar, 0.0))),
                      "evals_per_s": round((S.ncall - c0) / dt), "logz": float(S.logz), "scale": float(S.scale), "max_ellipsoids": nell,
                      **({"resyncs": int(S._dev_desync)} if getattr(S, "_dev_turn", False) else {})}
         if verbose:
