@@ -40,6 +40,10 @@ def test_fit_stars_one_rank_and_two_ranks_agree(tmp_path):
     assert np.all(np.isfinite(one)) and np.all(np.isfinite(two))
     # a star's fit depends on its own seed only: which rank ran it does not matter
     np.testing.assert_allclose(one, two, rtol=1e-9, atol=1e-9)
+    # ... and the one line an 8-GPU run is compared by says so
+    import re
+    ck = [re.search(r"table checksum (\w+)", log).group(1) for log in (log1, log2)]
+    assert ck[0] == ck[1], ck
     # each star recovers its own truth (Teff = 5770 + 25 i): posterior mean within 6 sigma
     for i, row in enumerate(one):
         assert abs(row[5] - (5770.0 + 25.0 * i)) < 6.0 * row[6] + 10.0, (i, row[5], row[6])

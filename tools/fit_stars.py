@@ -65,6 +65,11 @@ def main():
                   % (i, truth_of(i)[0], row[5], row[6], row[0], row[1], int(row[3])))
         print("%d stars on %d rank(s): %.2f s, %.2f M likelihood calls/s in all"
               % (a.stars, world, dt, table[:, 3].sum() / dt / 1e6))
+        # a star's fit depends on its own seed only: the table of an 8-GPU run is the table of a 1-GPU run -- one comparison
+        import hashlib
+        print("table checksum %s (sha256 of the values at 6 decimals; to the bit: %s)  sum lnZ %.6f  calls %d"
+              % (hashlib.sha256(np.round(table, 6).tobytes()).hexdigest()[:16], hashlib.sha256(table.tobytes()).hexdigest()[:16],
+                 table[:, 0].sum(), int(table[:, 3].sum())))
     pdist.finalize()
 
 
