@@ -570,6 +570,7 @@ def final_line(full):
         out["config"]["parallelism"] = str(c["parallelism"])[:96]
     if full.get("n_gpus", 1) > 1 or full.get("collective_backend"):
         out["collective_backend"] = full.get("collective_backend")
+        out["rccl_world"] = full.get("rccl_world")
         out["per_rank_evals_per_s"] = [_r(v, 5) for v in full.get("per_rank_evals_per_s", [])][:16]
     rf = full.get("roofline")
     if rf:
