@@ -441,7 +441,8 @@ def roofline_blocks(cfg_name, res, args):
                                        "the step is under `mfma_kernel`.")
         t_out = max(per["dense_out"], 1e-9) * 1e-6
         split = not (args.variant & (4096 | 1 | 1024))          # the default output layer: six bf16 products per fp32 product
-        out["mfma_kernel"] = {"kernel": "payne_dense_dma3_kernel (output layer, 3 x bf16 split)" if split else
+        kout = res["engines"][0].kernels_used().get("out", "") if res.get("engines") else ""
+        out["mfma_kernel"] = {"kernel": ((kout or "payne_dense_dma3_kernel") + " (output layer, 3 x bf16 split)") if split else
                                         "payne_dense_dma_kernel (output layer, fp32 matrix instruction)",
                               "alg_flops_per_launch": flops["dense_out"],
                               "avg_us_per_launch": per["dense_out"],

@@ -131,6 +131,8 @@ typedef struct payne_opts {
 #define PAYNE_V_ROWS_PIXEL 262144u /* the output layer writes pixels and the post kernel transforms them itself (what runs with a continuum
                                     * network, with vsini maps that are not the identity, and for spectra other than 1k/2k/4k/8k);
                                     * default where it applies: the output layer's weights carry the first stage's forward transform */
+#define PAYNE_V_OUT_PLANES 524288u /* output layer: the weights read as three bf16 planes split at payne_ctx_create (what nets of other widths than
+                                    300 and batches with more tiles than compute units use) instead of fp32 weights split on their way into LDS */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

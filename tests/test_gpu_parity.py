@@ -29,9 +29,10 @@ def _net(raw, kind="YST1"):
 # differently shaped nets / spectra take, forced onto the C2 problem
 VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
             "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048,
-            "rows_pixel": 262144, "rows_pixel+post_full": 262144 | 8, "rows_pixel+no_prep": 262144 | 16}
+            "rows_pixel": 262144, "rows_pixel+post_full": 262144 | 8, "rows_pixel+no_prep": 262144 | 16,
+            "out_planes": 524288, "out_planes+rows_pixel": 524288 | 262144}
 # ... of which these hand the post kernel rows in the frequency domain (the output layer's weights restated: payne_hip.h, payne_last_kernel kind 4)
-FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled"}
+FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes"}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -51,6 +52,32 @@ def test_lnlike_c2_against_reference_golden(Engine, golden, variant):
     big = np.tile(theta_full(g["theta"]), (2, 1))[:700]
     lnl3 = eng.lnlike_batch(big).cpu().numpy()
     assert np.array_equal(lnl3[:512], lnl) and np.array_equal(lnl3[512:], lnl[:188])
+
+
+def test_weights_split_on_their_way_into_lds_give_the_planes_split_at_set_up(Engine, golden):
+    """The default output layer at C2 (payne_dense_dma3f_kernel) reads its weights as fp32 and splits them into the three bf16 planes
+    inside the kernel; PAYNE_V_OUT_PLANES reads planes split once at payne_ctx_create (payne_dense_dma3_kernel).  Same parts, same
+    products, same order: the network's rows -- pixels and frequency rows -- and the likelihoods are equal TO THE BIT."""
+    from thepayne_amd import _lib
+    g = golden("g4_lnlike_c2")
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    th = theta_full(g["theta"])
+    out = {}
+    for name, v in (("split_in_kernel", 0), ("planes", _lib.V_OUT_PLANES), ("split_in_kernel_px", _lib.V_ROWS_PIXEL),
+                    ("planes_px", _lib.V_OUT_PLANES | _lib.V_ROWS_PIXEL)):
+        eng = Engine(_net(raw), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=512, variant=v)
+        lnl = eng.lnlike_batch(th).cpu().numpy()
+        used = eng.kernels_used()
+        rows = eng.predict_batch(th[:70], stage=0).cpu().numpy()             # (a ragged batch: 70 rows of a 64-row tile grid)
+        out[name] = (lnl, rows, used)
+        eng.close()
+    assert "dma3f" in out["split_in_kernel"][2]["out"] and "dma3f" not in out["planes"][2]["out"], out["planes"][2]
+    for a, b in (("split_in_kernel", "planes"), ("split_in_kernel_px", "planes_px")):
+        assert np.array_equal(out[a][0], out[b][0], equal_nan=True), (a, np.nanmax(np.abs(out[a][0] - out[b][0])))
+        assert np.array_equal(out[a][1], out[b][1], equal_nan=True), a
+    err = np.abs(out["split_in_kernel"][0] - g["lnlike"])
+    assert np.all(err <= lnl_tol(g["lnlike"]))
 
 
 def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engine):
@@ -227,7 +254,7 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
     assert np.all(np.isfinite(ref)) and np.all(np.abs(lnl - ref) <= lnl_tol(ref)), np.abs(lnl - ref).max()
     # which kernels a net of this depth takes: every layer on the matrix cores, the output layer as bf16 products
     names = eng.kernels_used()
-    assert names["hidden"].startswith("payne_dense_hidden_kernel") and names["out"].startswith("payne_dense_dma3_kernel"), names
+    assert names["hidden"].startswith("payne_dense_hidden_kernel") and names["out"].startswith("payne_dense_dma3"), names
     # other shipped forms of the output layer on the same net: same likelihoods
     for v in (1, 4096, 2048):
         e2 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=v)

@@ -41,6 +41,7 @@ struct DenseParams {
   // the rotation stage resamples (run_ann in payne_hip.hip; the hidden-layer launch's records set the word)
   const unsigned long long* sel; unsigned long long sel_seq;
   const unsigned short* Wp_alt; size_t plane_w_alt; const float* bias_alt; float bias_shift_alt; int N_alt, ldy_alt;
+  const float* W_alt;          // payne_dense_dma3f_kernel: the alternative layer's weights as fp32 [N_alt][K]
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
@@ -676,6 +677,243 @@ __global__ void __launch_bounds__(512) payne_dense_dma3_kernel(PAYNE_D3_LEAD_PAR
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < p.B) __builtin_nontemporal_store(acc[r] + bv, &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(act_apply(acc[r] + bv, p.act), &p.Y[(size_t)row * p.ldy + col]);
+      }
+    }
+  }
+  HK_STAMP(15);
+}
+
+// ----------------------------------------------------------------------------
+// payne_dense_dma3f_kernel<NK>: the six-product output layer of payne_dense_dma3_kernel<NK, 4, true> with the WEIGHTS AS fp32
+// THROUGH THE PORT.  That kernel is bound by operand bytes: 36 KB of bf16 planes per 32-deep step through an L2-to-CU port that
+// delivers ~22 B/clk (1 676 of a step's ~1 700 cycles) -- and three bf16 planes are 6 bytes for what 4 bytes say.  Here the
+// weight tile of a step arrives as fp32 in REGISTERS (one 32-byte row chunk per thread, two steps ahead, three register sets in
+// rotation), is split into the same three planes by the thread that fetched it (split3: the values payne_split3_kernel writes,
+// bit for bit) and stored where the transfers of the planes used to land (same swizzle): 28 KB per step.  The ~45 vector
+// instructions and three ds_write_b128 a thread spends on it per step sit between the step's twelve matrix instructions
+// (sched_group_barrier).  Activations keep their planes (written once by the hidden-layer kernel) and their LDS transfers: twelve
+// pieces a stage, waves 0-3 two each, waves 4-7 one.
+// Per step `it` (before its products): wait for A of step it+1 and the registers of B of step it+2 (one vmcnt: both were requested
+// by step it-2, only step it-1's requests may be outstanding) -> barrier -> fragments of step it+1 -> request A of step it+3 and B
+// of step it+4 -> split B of step it+2 into its stage (free since step it-2's fragments were read) among the products of step it.
+// Weights: [N][K] fp32, K = 32 NK, zero beyond the layer's width (payne_ctx_create keeps that copy anyway).
+// ----------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void d3f_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int NK>
+__global__ void __launch_bounds__(512) payne_dense_dma3f_kernel(PAYNE_D3_LEAD_PARAMS, DenseParams p_) {
+  DenseParams p = p_;
+  p.sel = lead_sel; p.Xp = lead_Xp; p.plane_x = lead_plane_x;
+  const float* Wf = reinterpret_cast<const float*>(lead_Wp);
+  p.grid_m = (int)(lead_grid & 0xffffu); p.grid_n = (int)(lead_grid >> 16); p.N = lead_N; p.B = lead_B; p.ldp = lead_ldp; p.K = lead_K;
+  static_assert(NK >= 4, "prologue requests four steps of weights");
+  constexpr int NS = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char d3_sm[];
+  if (p.sel != nullptr && (unsigned)*p.sel == lead_sel_seq) {
+    Wf = p.W_alt; p.bias = p.bias_alt; p.bias_shift = p.bias_shift_alt; p.N = p.N_alt; p.ldy = p.ldy_alt;
+  }
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 128;
+  if (n0 >= p.N) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
+  const bool two = wave < 4;                               // A pieces this wave moves per stage: 2 (waves 0-3) or 1
+  const unsigned char* srcA[2];
+  int dstA[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int q = two ? wave * 2 + j : 8 + (wave - 4);           // 12 pieces: 3 planes x 4 blocks of 16 rows
+    const int pl = q >> 2, blk = q & 3;
+    const int row = 16 * blk + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
+    srcA[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)pl * p.plane_x + (size_t)r * p.ldp) + 16 * c;
+    dstA[j] = pl * 4096 + blk * 1024;
+  }
+  // the weight values of this thread: floats 4 (tid % 8) .. + 3 of the step's 32 in tile rows tid / 8 and tid / 8 + 64 -- a wave's
+  // load instruction reads eight whole 128-byte row segments (one 32-byte chunk per thread, i.e. two instructions that each touch
+  // half of every line, moved no fewer bytes through the port than the planes had)
+  const int brow = tid >> 3, bq = tid & 7;
+  const float* srcB0;
+  const float* srcB1;
+  {
+    const int r0 = (n0 + brow < p.N) ? n0 + brow : p.N - 1, r1 = (n0 + brow + 64 < p.N) ? n0 + brow + 64 : p.N - 1;
+    srcB0 = Wf + (size_t)r0 * p.K + 4 * bq;
+    srcB1 = Wf + (size_t)r1 * p.K + 4 * bq;
+  }
+  const int dstB0 = 3 * 4096 + brow * 64 + 16 * ((bq >> 1) ^ ((brow >> 2) & 3)) + 8 * (bq & 1);
+  const int dstB1 = dstB0 + 64 * 64;                        // (row + 64: the same swizzle, 64 rows of 64 bytes further)
+  auto issueA = [&](int stage, int k0) {                   // k0 in elements
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[0] + 2 * k0),
+                                     (__attribute__((address_space(3))) void*)(d3_sm + stage * D3_STAGE + dstA[0]), 16, 0, 0);
+    if (two)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[1] + 2 * k0),
+                                       (__attribute__((address_space(3))) void*)(d3_sm + stage * D3_STAGE + dstA[1]), 16, 0, 0);
+  };
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  struct BRegs { f32x4 lo, hi; };
+  // (the loads as statements the compiler cannot see into: with LDS transfers and register loads pending on one counter its
+  //  wait-count pass assumes they may return out of order and drains the counter -- `s_waitcnt vmcnt(0)` right behind the requests
+  //  just made, a memory round trip inside every third step.  They return in order; the waits below are counted by hand, and
+  //  `landed` ties the registers' first use to the wait in front of it.)
+  auto issueB = [&](BRegs& b, auto K0) {
+    constexpr int off = decltype(K0)::value * 4;
+    const float* s0_ = srcB0; const float* s1_ = srcB1;
+#if defined(PAYNE_EXP_D3F) && (PAYNE_EXP_D3F & 4)       /* timing twin: the weights' loads hit one line (no port traffic to speak of) */
+    const float* w_ = p_.bias;
+    asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %2, off nt"
+                 : "=&v"(b.lo), "=&v"(b.hi) : "v"(w_), "v"(s1_), "n"(off) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %2, off offset:%4 nt\n\tglobal_load_dwordx4 %1, %3, off offset:%4 nt"
+                 : "=&v"(b.lo), "=&v"(b.hi) : "v"(s0_), "v"(s1_), "n"(off) : "memory");
+#endif
+  };
+  auto landed = [&](BRegs& b) { asm volatile("" : "+v"(b.lo), "+v"(b.hi)); };
+  // (pairs: one v_cvt_pk_bf16_f32 rounds two values and leaves them packed as the plane wants them; what it rounded away, exactly:
+  //  x - float(part), the parts widened by a shift / a mask -- 11 vector instructions a pair, the values of split3 bit for bit)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto split_pair = [](float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+    f32x2_t x = {x0, x1};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+    f32x2_t r1 = {x0 - __builtin_bit_cast(float, ph << 16), x1 - __builtin_bit_cast(float, ph & 0xffff0000u)};
+    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+    f32x2_t r2 = {r1[0] - __builtin_bit_cast(float, pm << 16), r1[1] - __builtin_bit_cast(float, pm & 0xffff0000u)};
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+  };
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto splitB = [&](const BRegs& b, int stage) {
+    unsigned ph[4], pm[4], pl[4];
+#if defined(PAYNE_EXP_D3F) && (PAYNE_EXP_D3F & 1)       /* timing twin (tools/exp/d3f_ablate.py): no split arithmetic */
+    for (int j = 0; j < 4; ++j) { ph[j] = __builtin_bit_cast(unsigned, j < 2 ? b.lo[j] : b.hi[j]); pm[j] = ph[j]; pl[j] = ph[j]; }
+#else
+    split_pair(b.lo[0], b.lo[1], ph[0], pm[0], pl[0]); split_pair(b.lo[2], b.lo[3], ph[1], pm[1], pl[1]);
+    split_pair(b.hi[0], b.hi[1], ph[2], pm[2], pl[2]); split_pair(b.hi[2], b.hi[3], ph[3], pm[3], pl[3]);
+#endif
+    unsigned char* B0 = d3_sm + stage * D3_STAGE + dstB0;
+    unsigned char* B1 = d3_sm + stage * D3_STAGE + dstB1;
+    *reinterpret_cast<u32x2*>(B0) = u32x2{ph[0], ph[1]}; *reinterpret_cast<u32x2*>(B0 + 8192) = u32x2{pm[0], pm[1]};
+    *reinterpret_cast<u32x2*>(B0 + 2 * 8192) = u32x2{pl[0], pl[1]};
+    *reinterpret_cast<u32x2*>(B1) = u32x2{ph[2], ph[3]}; *reinterpret_cast<u32x2*>(B1 + 8192) = u32x2{pm[2], pm[3]};
+    *reinterpret_cast<u32x2*>(B1 + 2 * 8192) = u32x2{pl[2], pl[3]};
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
+  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
+  struct Frag { bf16x8_t a[2][3], b[2][3]; };
+  auto frags = [&](int stage, Frag& f) {
+    const unsigned char* As = d3_sm + stage * D3_STAGE;
+    const unsigned char* Bs = As + 3 * 4096;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        f.a[ks][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
+        f.b[ks][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * 8192 + Rb * 64 + 16 * (c ^ sb));
+      }
+    }
+  };
+  auto products = [&](const Frag& f, int ks) {             // smallest partial products first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][2], acc, 0, 0, 0);
+#if !(defined(PAYNE_EXP_D3F) && (PAYNE_EXP_D3F & 2))    /* timing twin: three of the six products */
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
+#endif
+  };
+  constexpr int nk = NK;
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
+  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;
+  const int col = n0 + wn0 + (lane & 31);
+  const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
+  HK_STAMP(0);
+  // ---- prologue: the request order of the steady state (step j requests A of j + 3, then B of j + 4), B of step 0 first
+  BRegs breg[3];
+  using std::integral_constant;
+  issueB(breg[0], integral_constant<int, 0>{});
+  issueA(0, 0); issueB(breg[1], integral_constant<int, 32>{});
+  issueA(1, 32); issueB(breg[2], integral_constant<int, 64>{});
+  issueA(2, 64);
+  if (two) d3f_wait_vm<3 * 2 + 4>(); else d3f_wait_vm<3 * 1 + 4>();      // B of step 0 in: A0 B1 A1 B2 A2 may be outstanding
+  landed(breg[0]);
+  splitB(breg[0], 0);
+  issueB(breg[0], integral_constant<int, 96>{});
+  if (two) d3f_wait_vm<2 * 2 + 4>(); else d3f_wait_vm<2 * 1 + 4>();      // A of step 0 and B of step 1 in: A1 B2 A2 B3 may be outstanding
+  landed(breg[1]);
+  splitB(breg[1], 1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  Frag f0, f1;
+  frags(0, f0);
+  auto head = [&](auto IT, Frag& fn, const Frag& fc) {
+    constexpr int it = decltype(IT)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(fc.a[ks][pl]), "v"(fc.b[ks][pl]));
+    // outstanding at most: what step it - 1 requested (A of it + 2, B of it + 3)
+    constexpr int youngA = (it + 2 < nk) ? 1 : 0, youngB = (it + 3 < nk) ? 2 : 0;
+    if (two) d3f_wait_vm<2 * youngA + youngB>(); else d3f_wait_vm<youngA + youngB>();
+    if constexpr (it + 2 < nk) landed(breg[(it + 2) % 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (lgkmcnt: my stores of B of step it + 1)
+#ifndef PAYNE_NO_LOOP_STAMPS
+    if (it < 13) HK_STAMP(1 + it);
+#endif
+    if constexpr (it + 1 < nk) frags((it + 1) % NS, fn);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // A wave's LDS operations queue behind its own LDS transfers (a ds_write issued after a global_load_lds does not issue until that
+  // transfer has LANDED, and the matrix instructions behind it wait with it): the split's stores go BEFORE the step's requests --
+  // first half of the products with the split among them, the stores, the requests, second half of the products.
+  auto interleave = [&]() {                                // one matrix instruction, then some of the split's vector instructions
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
+  };
+  auto step = [&](auto IT, Frag& fn, Frag& fc) {
+    constexpr int it = decltype(IT)::value;
+    head(IT, fn, fc);
+    products(fc, 0);
+    if constexpr (it + 2 < nk) { splitB(breg[(it + 2) % 3], (it + 2) % NS); interleave(); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (it + 3 < nk) issueA((it + 3) % NS, (it + 3) * 32);
+    if constexpr (it + 4 < nk) issueB(breg[(it + 4) % 3], std::integral_constant<int, (it + 4) * 32>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < nk || last_both) products(fc, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto run = [&](auto self, auto IT) -> void {
+    constexpr int it = decltype(IT)::value;
+    if constexpr (it < nk) {
+      if constexpr ((it & 1) == 0) step(IT, f1, f0); else step(IT, f0, f1);
+      self(self, std::integral_constant<int, it + 1>{});
+    }
+  };
+  run(run, std::integral_constant<int, 0>{});
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (col < p.N) {
+    const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
+    if (act_none) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(acc[r] + bv, &p.Y[(size_t)row * p.ldy + col]);
       }
     } else {
 #pragma unroll
@@ -1339,6 +1577,7 @@ PAYNE_DENSE_T __global__ void payne_dense_dma_kernel<4, 64, 5, 3, true>(DensePar
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 4, true>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<10, 4, true>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma3f_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

@@ -78,6 +78,7 @@ struct payne_ctx {
   // the same output layer restated for rows in the frequency domain (host_tables.hpp freq_rows): what the likelihood and the
   // predictions past stage 0 run when the post kernel can start from the transform (freq_ok); raw_freq: the rows now in c->raw
   unsigned short* w_out_p3z = nullptr; const float* bias_z = nullptr; bool freq_ok = false, raw_freq = false;
+  const float* w_out_padz = nullptr;    // the restated layer as fp32 [n][w_out_kp] (payne_dense_dma3f_kernel splits it on the way into LDS)
   // freq_rs: the restated layer is that of the RESAMPLED spectrum (model grids that are not a power of two long: n1 rows of n1
   // values); a batch with a candidate that does not rotate falls back to pixels ON THE DEVICE (rot_flag: a word the records'
   // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
@@ -456,7 +457,8 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
         for (int i = 0; i < n; ++i) std::copy(Wz.begin() + (size_t)i * K, Wz.begin() + (size_t)(i + 1) * K, Wp.begin() + (size_t)i * Kp);
         const float* d_wp = nullptr;
         std::vector<void*> tmp;
-        if ((rc = upload(c, Wp, &d_wp, tmp))) return bail(rc);
+        if ((rc = upload(c, Wp, &d_wp, c->owned))) return bail(rc);      // (kept: the fp32 form is what the one-tile-per-CU kernel reads)
+        c->w_out_padz = d_wp;
         const size_t nw = (size_t)n * Kp;
         rc = dev_alloc(c, 3 * nw, &c->w_out_p3z, c->owned);
         if (!rc) {
@@ -663,6 +665,7 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 4, true>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<10, 4, true>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 2, false>), d3_lds_bytes<2>());
+  set(reinterpret_cast<const void*>(payne_dense_dma3f_kernel<10>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel), b3_lds_bytes());
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
@@ -735,7 +738,16 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool fr
   const dim3 grid(p.grid_m * p.grid_n);
   if ((int)grid.x > c->n_cu) PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 2, false>), grid, block, d3_lds_bytes<2>(), s, PAYNE_D3_LEAD_ARGS(p), p);   // many tiles per CU
   else if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED)) {
-    PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
+    const float* wf = freq ? c->w_out_padz : c->w_out_pad;
+    if (wf && !(c->opts.variant & PAYNE_V_OUT_PLANES) && (!p.sel || c->w_out_pad)) {
+      // the weights as fp32 through the port, split into the planes on their way into LDS (28 instead of 36 KB a step)
+      p.W_alt = c->w_out_pad;
+      const unsigned short* keep = p.Wp;
+      p.Wp = reinterpret_cast<const unsigned short*>(wf);
+      PAYNE_LAUNCH((payne_dense_dma3f_kernel<10>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
+      p.Wp = keep;
+    }
+    else PAYNE_LAUNCH((payne_dense_dma3_kernel<10, 4, true>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
   }
   else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
 }
