@@ -47,3 +47,67 @@ def test_fit_stars_one_rank_and_two_ranks_agree(tmp_path):
     # each star recovers its own truth (Teff = 5770 + 25 i): posterior mean within 6 sigma
     for i, row in enumerate(one):
         assert abs(row[5] - (5770.0 + 25.0 * i)) < 6.0 * row[6] + 10.0, (i, row[5], row[6])
+
+
+def test_a_finished_fits_context_serves_the_next_fit_of_the_same_network(tmp_path, monkeypatch):
+    """Fits of a multi-star job share their network: the context of a finished fit (weights on the device, the output layer restated
+    in the frequency domain, tables) is kept and the next fit only binds its own spectrum (fitting/genmod.py).  The second star's
+    fit on a re-used context must be the fit on a fresh one to the last bit, the context must really be re-used, a context still
+    held by a live sampler must not be handed out, and another network / batch size must not take it."""
+    import numpy as np
+    from thepayne_amd import synth, nnio
+    from thepayne_amd.fitting import genmod
+    from thepayne_amd.fitting.fitstar import FitPayne
+    net = synth.make_yst_net(npix=1024, H=300, seed=0, line_depth=0.3)
+    ann = str(tmp_path / "ann.npz")
+    nnio.save_npz(ann, {k: (np.array([v]) if k == "resolution" else v) for k, v in net.items() if k != "kind"})
+    obs = synth.obs_grid(net["wavelength"], 900)
+    built = []
+    real_new = genmod.GenMod.new_engine
+    monkeypatch.setattr(genmod.GenMod, "new_engine", lambda self: built.append(1) or real_new(self))
+    genmod.drop_idle_engines()
+    GM = genmod.GenMod(device=0)
+    GM._initspecnn(nnpath=ann, NNtype='YST1')
+    T = synth.TRUTH
+
+    def star(i):
+        truth = [T["Teff"] + 25.0 * i, T["logg"], T["feh"], T["afe"], T["vrad"] + 0.1 * i, T["vrot"], np.nan, T["inst_R"]]
+        _, clean = GM.genspec(truth, outwave=obs)
+        return np.asarray(clean) + np.random.default_rng(1000 + i).normal(0, 0.01, len(obs))
+    fluxes = [star(i) for i in range(5)]             # (made first: the spectra's own context is not what is counted below)
+
+    def fit(i, npoints=128, keep=None):
+        flux = fluxes[i]
+        inputdict = {'spec': {'obs_wave': obs, 'obs_flux': flux, 'obs_eflux': np.full(len(obs), 0.01), 'convertair': False},
+                     'specANNpath': ann, 'NNtype': 'YST1',
+                     'sampler': {'samplertype': 'Static', 'samplerbounds': 'multi', 'samplemethod': 'rwalk', 'npoints': npoints,
+                                 'walks': 25, 'delta_logz_final': 0.5, 'flushnum': 10 ** 9, 'seed': i},
+                     'priordict': synth.demo_priordict(), 'output': str(tmp_path / ("star_%d.dat" % i))}
+        F = FitPayne(device=0)
+        S = F.run(inputdict=inputdict, verbose=False)
+        if keep is not None:
+            keep.append((F, S))
+        return S.summary(), open(inputdict['output']).read()
+
+    n0 = len(built)
+    a1, _ = fit(0)                                   # builds a context ...
+    assert len(built) == n0 + 1 and sum(len(v) for v in genmod._ENGINE_POOL.values()) == 1      # ... which waits for the next fit
+    b1, rows1 = fit(1)                               # ... and serves it
+    assert len(built) == n0 + 1
+    genmod.drop_idle_engines()
+    b2, rows2 = fit(1)                               # the same star on a context of its own
+    assert len(built) == n0 + 2
+    assert np.array_equal(b1, b2) and rows1 == rows2
+    assert abs(a1[5] - 5770.0) < 6.0 * a1[6] + 10.0 and abs(b1[5] - 5795.0) < 6.0 * b1[6] + 10.0
+    # a fit whose sampler is still alive keeps its context to itself
+    alive = []
+    fit(2, keep=alive)
+    assert sum(len(v) for v in genmod._ENGINE_POOL.values()) == 0
+    fit(3)
+    assert len(built) == n0 + 3                      # (star 2 took the idle one of the `b2` fit, star 3 had to build)
+    del alive[:]
+    # another batch size is another context
+    fit(4, npoints=64)
+    assert len(built) == n0 + 4
+    genmod.drop_idle_engines()
+    assert not genmod._ENGINE_POOL

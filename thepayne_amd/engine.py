@@ -79,6 +79,24 @@ class PayneEngine(object):
             raise RuntimeError("payne_ctx_create failed (%d): %s" % (rc, self.lib.payne_last_error(None).decode()))
         self.ncols = self.lib.payne_theta_cols(self._ctx)
         self.phot_off = 8 + self.npoly
+        # Who is using this context (fitting/genmod.py keeps idle contexts of finished fits for the next fit of the same networks:
+        # the owner GenMod and every DeviceProposer built on it hold it; the last one to let go hands it to `_on_idle`).
+        self._holders = 0
+        self._on_idle = None
+
+    def hold(self):
+        self._holders += 1
+
+    def drop(self):
+        """One holder less; the last one hands the (still open) context to `_on_idle` -- or closes it when nobody wants it."""
+        self._holders -= 1
+        if self._holders <= 0 and self.is_open():
+            cb, self._on_idle = self._on_idle, None
+            if cb is None or not cb(self):
+                self.close()
+
+    def is_open(self):
+        return getattr(self, "_ctx", None) is not None and bool(self._ctx.value)
 
     # -- descriptors -----------------------------------------------------------
     def _dev(self, a, dtype):

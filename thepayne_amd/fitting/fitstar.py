@@ -316,11 +316,9 @@ class FitPayne(object):
                     sys.stdout.flush()
             t_iter = datetime.now()
         nit = max(nit, 0)
-        for it2, results in enumerate(sampler.add_live_points()):
-            (worst, ustar, vstar, loglstar, logvol, logwt, logz, logzvar,
-             h, nc, worst_it, boundidx, bounditer, eff, delta_logz) = results
-            self._row(nit + it2, vstar, (loglstar, logvol, logwt, h, nc, logz, delta_logz))
-            ncall += nc
+        rec = sampler.add_live_points_chunk()          # (fitstar.py:410-413: the remaining live points, rows numbered from nit as there)
+        self._rows(nit, rec)
+        ncall += int(rec["nc"].sum())
         self.outff.close()
         if self.verbose:
             sys.stdout.write('\n')

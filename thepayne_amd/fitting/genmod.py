@@ -12,6 +12,54 @@ from .fitutils import polycalc
 
 speedoflight = 299792.458        # km/s, the Doppler constant of getspec (ystpred.py:232)
 
+# ---- contexts and networks kept between fits ----------------------------------------------------------------------------
+# A complete C2 fit is ~35 ms of sampling; building its context (weights uploaded, the output layer restated in the frequency
+# domain on the host, tables) was 19 ms more and reading the network file 4 ms, for every star of a multi-star job
+# (tools/fit_stars.py).  The reference reads its network once per process too (genmod.py:15-32 at likelihood set-up) -- here the
+# CONTEXT of a finished fit is kept as well: when the last holder of a fit's engine lets go (the GenMod that built it, a
+# DeviceProposer walking on it), the open context goes into a small pool keyed by everything it was built from (network file
+# identity, kind, device, batch size, blaze order, kernel variant); the next fit with the same key takes it and only binds its
+# own observed spectrum (payne_ctx_set_obs, which also drops an LSF vector).  Fits with photometry or a continuum network, and
+# networks handed over as dictionaries, build their own context as before.
+_ENGINE_POOL = {}
+_ENGINE_POOL_MAX = 2
+_NET_CACHE = {}
+_NET_CACHE_MAX = 2
+
+
+def _file_key(path):
+    import os
+    try:
+        st = os.stat(path)
+    except (OSError, TypeError, ValueError):
+        return None
+    return (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+
+
+def _pool_put(key):
+    def put(eng):
+        idle = _ENGINE_POOL.setdefault(key, [])
+        if len(idle) >= _ENGINE_POOL_MAX:
+            return False
+        idle.append(eng)
+        return True
+    return put
+
+
+def drop_idle_engines():
+    """Close every context kept for re-use (tests; before a process forks or exits)."""
+    for idle in list(_ENGINE_POOL.values()):
+        while idle:
+            try:
+                idle.pop().close()
+            except Exception:
+                pass
+    _ENGINE_POOL.clear()
+
+
+import atexit  # noqa: E402
+atexit.register(drop_idle_engines)
+
 
 class GenMod(object):
     def __init__(self, *arg, **kwargs):
@@ -32,22 +80,31 @@ class GenMod(object):
     def _initspecnn(self, nnpath=None, **kwargs):
         """genmod.py:15-32: NNtype 'YST1' -> ystpred layout, anything else -> predictspec."""
         self.NNtype = kwargs.get('NNtype', 'YST1')
-        self._spec_net = nnio.load_spec_net(nnpath, self.NNtype)
+        self._spec_key = _file_key(nnpath) if isinstance(nnpath, str) else None
+        ck = (self._spec_key, self.NNtype)
+        if self._spec_key is not None and ck in _NET_CACHE:
+            self._spec_net = _NET_CACHE[ck]
+        else:
+            self._spec_net = nnio.load_spec_net(nnpath, self.NNtype)
+            if self._spec_key is not None:
+                while len(_NET_CACHE) >= _NET_CACHE_MAX:
+                    _NET_CACHE.pop(next(iter(_NET_CACHE)))
+                _NET_CACHE[ck] = self._spec_net
         Cnnpath = kwargs.get('Cnnpath', None)              # genmod.py:28-32 (the reference's likelihood never passes it)
         self._cont_net = nnio.load_spec_net(Cnnpath, self.NNtype, rescale_teff=False) if Cnnpath is not None else None
-        self._engine = None
+        self._let_go()
 
     def _initphotnn(self, filterarray, nnpath=None):
         """genmod.py:35-43."""
         from ..predict.predictsed import _ALLFILTERS
         self.filterarray = list(filterarray) if filterarray is not None else list(_ALLFILTERS)
         self._phot = nnio.load_phot_nets(self.filterarray, nnpath)
-        self._engine = None
+        self._let_go()
 
     def configure(self, obs=None, obs_phot=None, npoly=0, photscale=False):
         """Bind the data side of the fit (observed spectrum / magnitudes, blaze order)."""
         self._obs, self._obs_phot, self._npoly, self._photscale = obs, obs_phot, int(npoly), bool(photscale)
-        self._engine = None
+        self._let_go()
         self._pred = None
 
     def new_engine(self):
@@ -59,11 +116,47 @@ class GenMod(object):
             eng.set_continuum(self._cont_net)
         return eng
 
+    def _pool_key(self):
+        """What a context of this fit was built from, or None when it is not one the pool keeps (see the module's head)."""
+        if getattr(self, "_spec_key", None) is None or self._phot is not None or getattr(self, "_cont_net", None) is not None:
+            return None
+        if self._obs is None or len(self._obs) != 3:
+            return None
+        return (self._spec_key, self.NNtype, self.device, int(self.b_max), int(self._npoly), bool(self._photscale), int(self.variant))
+
     @property
     def engine(self):
-        if self._engine is None:
-            self._engine = self.new_engine()
+        if self._engine is None or not self._engine.is_open():
+            if self._engine is not None:
+                self._let_go()
+            key, eng = self._pool_key(), None
+            idle = _ENGINE_POOL.get(key) if key is not None else None
+            while idle and eng is None:
+                cand = idle.pop()
+                try:
+                    if cand.is_open():
+                        cand.set_obs(*self._obs)
+                        eng = cand
+                except Exception:                           # a context that cannot take this spectrum: build a fresh one
+                    cand.close()
+            if eng is None:
+                eng = self.new_engine()
+            if key is not None:
+                eng._on_idle = _pool_put(key)
+            eng.hold()
+            self._engine = eng
         return self._engine
+
+    def _let_go(self):
+        eng, self._engine = getattr(self, "_engine", None), None
+        if eng is not None:
+            try:
+                eng.drop()
+            except Exception:
+                pass
+
+    def __del__(self):
+        self._let_go()
 
     # -- reference API (one parameter list) --------------------------------------
     def genspec(self, pars, outwave=None, verbose=False, modpoly=False, carbon_bool=False):

@@ -25,6 +25,7 @@ class DeviceProposer(object):
         self.like = likeobj
         self.prior = priorobj
         self.eng = engine if engine is not None else likeobj.GM.engine
+        self._held = False
         self.torch = self.eng.torch
         self.lib = self.eng.lib
         self.ndim = priorobj.ndim
@@ -59,6 +60,9 @@ class DeviceProposer(object):
         rc = self.lib.payne_sampler_create(self.eng._ctx, C.byref(d), self.k_max, C.byref(self._handle))
         if rc != 0:
             self.eng._err(rc, "payne_sampler_create")
+        if engine is None and hasattr(self.eng, "hold"):     # (the fit's own context: kept alive, and out of the idle pool, while this walks on it)
+            self.eng.hold()
+            self._held = True
         dev = self.eng.device
         f64, i32 = self.torch.float64, self.torch.int32
         self._u = self.torch.empty((self.k_max, self.ndim), dtype=f64, device=dev)
@@ -385,9 +389,13 @@ class DeviceProposer(object):
 
     def close(self):
         if self._handle.value:
-            self.torch.cuda.synchronize(self.eng.device)
+            if self.eng.is_open():
+                self.torch.cuda.synchronize(self.eng.device)
             self.lib.payne_sampler_destroy(self._handle)
             self._handle = C.c_void_p()
+        if getattr(self, "_held", False):
+            self._held = False
+            self.eng.drop()
 
     def __del__(self):
         try:
