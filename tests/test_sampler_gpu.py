@@ -672,6 +672,46 @@ def test_sampling_loop_with_the_turn_on_the_device(tmp_path):
     assert 0.5 < na / nb < 2.0
 
 
+def test_default_loop_where_the_device_turn_does_not_fit_and_an_abandoned_loop(tmp_path):
+    """(advisor, round 5) (a) The device turn is sized by the proposer's k_max: a proposer built like the dynamic sampler's (k_max = 2
+    npoints) with nlive + k_max > 2048 must take the host-turn loop by default -- it failed with PAYNE_E_UNSUPPORTED at its first queue.
+    (b) A loop abandoned with queues in flight, finalised AFTER another sampler started on the same proposer (the dynamic sampler
+    shares one across its runs), must neither collect the other sampler's queues nor raise out of its finaliser."""
+    import gc
+    from thepayne_amd.fitting.fitstar import lnprob_batch
+    from thepayne_amd.sampler import NestedSampler
+    L, P, _ = _fit_objects(tmp_path, photscale=False, b_max=1400)
+    prop = _proposer(L, P, k_max=1400)
+    S = NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=700, bound='multi', sample='rwalk', walks=5,
+                      batched=True, queue_size=700, rstate=np.random.default_rng(3), proposer=prop)
+    assert not S._dev_turn and S.pipeline
+    n = sum(len(r["logl"]) for r in S.sample_chunks(maxiter=900, dlogz=1e-9))
+    assert n == 900
+    prop.close()
+    # (b)
+    prop = _proposer(L, P, k_max=64)
+    mk = lambda seed: NestedSampler(lnprob_batch, P.priortrans_batch, L.ndim, logl_args=[L, P], nlive=64, bound='multi', sample='rwalk',
+                                    walks=5, batched=True, queue_size=64, rstate=np.random.default_rng(seed), proposer=prop)
+    A = mk(1)
+    assert A._dev_turn
+    gen = A.sample_chunks(dlogz=1e-9, maxiter=10 ** 6)
+    next(gen)                                              # queues in flight, the loop left hanging
+    assert A._dev_inflight > 0
+    B = mk(2)
+    genb = B.sample_chunks(dlogz=1e-9, maxiter=400)
+    nb = len(next(genb)["logl"])                           # B's init collected and dropped A's queues; B's own are in flight now
+    infl = B._dev_inflight
+    gen.close()                                            # A's finaliser: nothing of A's is left to collect
+    del gen
+    gc.collect()
+    assert A._dev_inflight == 0 and B._dev_inflight == infl and getattr(prop, "_dq_out", 0) == infl
+    nb += sum(len(r["logl"]) for r in genb)                # B goes on as if nothing had happened
+    assert nb == 400 and B._dev_desync == 0
+    r = B.results
+    assert np.all(np.diff(r.logl) >= 0)
+    prop.close()
+
+
 def test_turn_on_the_device_is_the_same_run_statistically():
     """Why pipeline='device' is the default loop wherever it can run: twenty seeds of it and twenty of the loop that makes the turn
     between two proposal queues on the host, on the C2 fit (4096-pixel network, 3600 observed pixels, 512 live points, 25-step

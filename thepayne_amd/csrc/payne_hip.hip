@@ -752,6 +752,13 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool fr
   else PAYNE_LAUNCH((payne_dense_dma3_kernel<0, 4, true>), grid, block, d3_lds_bytes<4>(), s, PAYNE_D3_LEAD_ARGS(p), p);
 }
 
+// The hidden-layer kernel's leading arguments carry two 16-bit values a dword (n_prep: 15 bits): what does not fit is refused
+// by run_net before anything is launched (post_lead_fits is the post kernel's counterpart).
+static bool hk_lead_fits(int B, int N, int K, int K0, int ldx, int ldwd, int ld_theta, int spec_K) {
+  const long long n_gemm = (long long)((B + 31) / 32) * ((N + 31) / 32);
+  return n_gemm <= 0xffff && (N + 31) / 32 <= 0xffff && (B + 255) / 256 <= 0x7fff && K <= 0xffff && K0 <= 0xffff && ldx <= 0xffff &&
+         ldwd <= 0xffff && ld_theta <= 0xffff && (spec_K + kSpecChainsPerWg - 1) / kSpecChainsPerWg <= 0xffff;
+}
 template <bool FUSE>
 static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu = 256, int spec_K = 0) {
   p.grid_m = (p.B + 31) / 32;
@@ -832,12 +839,16 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         pa.spec_step = c->spec_step; c->spec_launched = true;
       }
       if (!last && N.spectral && c->w_hid_pad[1] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[1]; p.ldwd = N.ld_hid; }
+      if (!last && !hk_lead_fits(p.B, p.N, p.K, p.K0, 0, p.ldwd, p.ld_theta, spec ? c->spec_K : 0))
+        return fail(c, PAYNE_E_UNSUPPORTED, "batch x hidden width beyond what the hidden-layer kernel's packed arguments hold (65 535 tiles of 32 x 32)");
       if (last) launch_dense<64, 64, 32, true>(p, s);
       else { launch_hidden<true>(p, pa, s, c->n_cu, spec ? c->spec_K : 0); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else {
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last && N.spectral && c->w_hid_pad[l] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[l]; p.ldwd = N.ld_hid; }
+      if (!last && !hk_lead_fits(p.B, p.N, p.K, 0, p.ldx, p.ldwd, 0, 0))
+        return fail(c, PAYNE_E_UNSUPPORTED, "batch x hidden width beyond what the hidden-layer kernel's packed arguments hold (65 535 tiles of 32 x 32)");
       if (!last) launch_hidden<false>(p, pa, s);
       else if (use3) {
         if (N.freq && c->freq_rs_now) {                      // rows of the resampled grid; pixels if the batch's records say so
@@ -1821,20 +1832,31 @@ static int queue_begin_core(payne_sampler* s, const double* live_u, const double
 }
 static void queue_extract(const double* hu, int K, int nd, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats);
 static bool wait_word(volatile unsigned long long* w, unsigned long long want, double seconds) {
-  // spin for the first millisecond (a C2 queue is ~1 ms: the word is usually there), then give the core away between looks -- a
-  // queue of 65 536-pixel spectra takes seconds, which one host core used to burn
+  // Spin while the wait is as long as queues have been taking (1.5 x the wait before: a C2 queue is ~1 ms, and a timer's wake-up
+  // after a 50 us sleep cost the host-turn loop 50-100 us a collect when queues ran just over a fixed 1 ms window), at least one
+  // millisecond; beyond that give the core away between looks -- a queue of 65 536-pixel spectra takes seconds, which one host
+  // core used to burn: first by yielding, from 20 ms on by sleeping.
+  static thread_local double last_wait = 1e-3;
+  const double spin_for = std::min(20e-3, std::max(1e-3, 1.5 * last_wait));
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
-  bool polite = false;
+  int polite = 0;                                            // 0 spin | 1 yield | 2 sleep
+  double dt = 0.0;
+  bool ok = true;
   while (__atomic_load_n(const_cast<const unsigned long long*>(w), __ATOMIC_ACQUIRE) != want) {
-    if (polite) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (polite == 2) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else if (polite == 1) std::this_thread::yield();
     if (polite || (++spins & 0x3FFu) == 0) {
-      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (dt > seconds) return false;
-      polite = dt > 1e-3;
+      dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dt > seconds) { ok = false; break; }
+      polite = dt > 20e-3 ? 2 : (dt > spin_for ? 1 : 0);
     }
   }
-  return true;
+  if (ok) {
+    dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    last_wait = 0.5 * last_wait + 0.5 * dt;
+  }
+  return ok;
 }
 extern "C" int payne_ns_rwalk_queue_end(payne_sampler* s, double* qu, double* qv, double* ql, int* qnc, int* nq, long long* stats) {
   if (!s) return PAYNE_E_INVALID;

@@ -286,7 +286,7 @@ class FitPayne(object):
             logl_args=[self.likeobj, self.priorobj], nlive=npoints, bound=bound, sample=samplemethod,
             bootstrap=samplerdict.get('bootstrap', 0), walks=numwalks, slices=samplerdict.get('slices', 5),
             batched=True, queue_size=samplerdict.get('queue_size', npoints),
-            pipeline=samplerdict.get('pipeline'),      # None: on with device proposals (the next queue launched ahead of the bookkeeping)
+            pipeline=samplerdict.get('pipeline'),      # None: with device proposals the turn between two queues on the device ('device'), else queues launched ahead from the host's turn
             rstate=np.random.default_rng(seed))
         self.parnames = list(self.likeobj.fitpars_i) + list(self.fitargs['fixedpars'].keys())
         self.fitargs_fixed = dict(self.fitargs['fixedpars'])

@@ -56,9 +56,10 @@ def launch_ranks(n, cmd, prepare=None, poll_s=0.05, timeout_s=None, rank0_stdout
     # devices and may wait in a collective for ever): SIGTERM becomes an exception here, and `finally` ends whoever still runs.
     def on_term(signum, frame):
         raise KeyboardInterrupt("signal %d" % signum)
-    old_term = None
+    old_term, term_set = None, False
     try:
         old_term = signal.signal(signal.SIGTERM, on_term)
+        term_set = True                      # (old_term None = a handler installed from C: it cannot be put back from here)
     except ValueError:                       # not the main thread: no handler, the finally below still covers exceptions
         pass
     try:
@@ -98,7 +99,10 @@ def launch_ranks(n, cmd, prepare=None, poll_s=0.05, timeout_s=None, rank0_stdout
         try:
             if old_int is not None:
                 signal.signal(signal.SIGINT, old_int)
-            signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
+            if term_set:                     # our handler was installed: the one before comes back (a C-level one: the default)
+                signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
+            elif old_term is not None:
+                signal.signal(signal.SIGTERM, old_term)
         except ValueError:
             pass
 

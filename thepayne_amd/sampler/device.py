@@ -293,6 +293,10 @@ class DeviceProposer(object):
         if rc != 0:
             self.eng._err(rc, "payne_ns_queue_dev_init")
         self._qb_dev = None
+        # (whose queues are in flight from here on: a sampler that finds another epoch when it comes to drain "its" queues -- an
+        #  abandoned loop finalised after another sampler started on this proposer -- has none left: they were dropped above)
+        self._dq_epoch = getattr(self, "_dq_epoch", 0) + 1
+        return self._dq_epoch
 
     def queue_dev_launch(self, K, axes_unit, ctr, ainv, walks, seed, merge=True):
         """Enqueue one queue behind whatever is in flight: [the bound, when it is not the one already on the device] + the turn

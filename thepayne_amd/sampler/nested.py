@@ -447,7 +447,7 @@ class NestedSampler(object):
         self._qbuf = self._qbufs[0]
         ctr, au, ai = self._ell_stack
         if not self._dev_sync:                     # the first queue of a loop (or after a mismatch): from the host's live set
-            prop.queue_dev_init(self.live_u, self.live_v, self.live_logl, self.scale, self.loglstar)
+            self._dev_epoch = prop.queue_dev_init(self.live_u, self.live_v, self.live_logl, self.scale, self.loglstar)
             prop.queue_dev_launch(K, self._ax_arg, ctr, ai, self.walks, self._queue_seed(), merge=False)
             self._dev_sync, self._dev_inflight = True, 1
         while self._dev_inflight < 2:              # (the bound it steps in: the one the host holds now -- a new one goes up with it)
@@ -483,6 +483,10 @@ class NestedSampler(object):
         K, nd = self.queue_size, self.ndim
         scratch = (np.empty((K, nd)), np.empty((K, nd)), np.empty(K), np.empty(K, dtype=np.int32))
         closed = not getattr(getattr(self.proposer, "_handle", None), "value", True)   # (closed before an abandoned generator was finalised)
+        # (... or re-initialised since by another sampler on the same proposer -- the dynamic sampler shares one across its runs --:
+        #  that init collected and dropped what was in flight; what is in flight now is not ours)
+        if getattr(self, "_dev_epoch", None) is not None and getattr(self.proposer, "_dq_epoch", self._dev_epoch) != self._dev_epoch:
+            closed = True
         while self._dev_inflight > 0:
             if not closed:                         # any other failure is an error: the C side would still count the queue as in flight
                 self.ncall += self.proposer.queue_dev_collect(scratch)[2]
