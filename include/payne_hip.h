@@ -133,6 +133,8 @@ typedef struct payne_opts {
                                     * default where it applies: the output layer's weights carry the first stage's forward transform */
 #define PAYNE_V_OUT_PLANES 524288u /* output layer: the weights read as three bf16 planes split at payne_ctx_create (what nets of other widths than
                                     300 and batches with more tiles than compute units use) instead of fp32 weights split on their way into LDS */
+#define PAYNE_V_OUT_BF16X3 1048576u /* output layer: operands split in three bf16 parts, six products (what batches with more tiles than
+                                     compute units and nets whose last hidden layer could not be calibrated use) instead of two fp16 parts, three products */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -30,9 +30,9 @@ def _net(raw, kind="YST1"):
 VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
             "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048,
             "rows_pixel": 262144, "rows_pixel+post_full": 262144 | 8, "rows_pixel+no_prep": 262144 | 16,
-            "out_planes": 524288, "out_planes+rows_pixel": 524288 | 262144}
+            "out_planes": 524288, "out_planes+rows_pixel": 524288 | 262144, "out_bf16x3": 1048576, "out_bf16x3+rows_pixel": 1048576 | 262144}
 # ... of which these hand the post kernel rows in the frequency domain (the output layer's weights restated: payne_hip.h, payne_last_kernel kind 4)
-FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes"}
+FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes", "out_bf16x3"}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -55,8 +55,8 @@ def test_lnlike_c2_against_reference_golden(Engine, golden, variant):
 
 
 def test_weights_split_on_their_way_into_lds_give_the_planes_split_at_set_up(Engine, golden):
-    """The default output layer at C2 (payne_dense_dma3f_kernel) reads its weights as fp32 and splits them into the three bf16 planes
-    inside the kernel; PAYNE_V_OUT_PLANES reads planes split once at payne_ctx_create (payne_dense_dma3_kernel).  Same parts, same
+    """The six-product output layer at C2 (PAYNE_V_OUT_BF16X3: payne_dense_dma3f_kernel) reads its weights as fp32 and splits them into the
+    three bf16 planes inside the kernel; PAYNE_V_OUT_PLANES reads planes split once at payne_ctx_create (payne_dense_dma3_kernel).  Same parts, same
     products, same order: the network's rows -- pixels and frequency rows -- and the likelihoods are equal TO THE BIT."""
     from thepayne_amd import _lib
     g = golden("g4_lnlike_c2")
@@ -64,7 +64,7 @@ def test_weights_split_on_their_way_into_lds_give_the_planes_split_at_set_up(Eng
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
     th = theta_full(g["theta"])
     out = {}
-    for name, v in (("split_in_kernel", 0), ("planes", _lib.V_OUT_PLANES), ("split_in_kernel_px", _lib.V_ROWS_PIXEL),
+    for name, v in (("split_in_kernel", _lib.V_OUT_BF16X3), ("planes", _lib.V_OUT_PLANES), ("split_in_kernel_px", _lib.V_OUT_BF16X3 | _lib.V_ROWS_PIXEL),
                     ("planes_px", _lib.V_OUT_PLANES | _lib.V_ROWS_PIXEL)):
         eng = Engine(_net(raw), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=512, variant=v)
         lnl = eng.lnlike_batch(th).cpu().numpy()
@@ -80,10 +80,13 @@ def test_weights_split_on_their_way_into_lds_give_the_planes_split_at_set_up(Eng
     assert np.all(err <= lnl_tol(g["lnlike"]))
 
 
-def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engine):
-    """The default output layer multiplies operands split in three bf16 parts (six exact partial products, fp32
-    accumulation); PAYNE_V_OUT_F32 is the fp32 matrix instruction.  Both against the SAME network evaluated in fp64:
-    the split form must not be less accurate than the fp32 fma chain, and both sit far inside the flux tolerance."""
+def test_output_layer_in_split_products_is_as_accurate_as_the_fp32_chain(Engine):
+    """The default output layer at C2 multiplies operands split in two fp16 parts (three exact partial products, fp32 accumulation:
+    payne_dense_dma2h_kernel; rows scaled by powers of two); PAYNE_V_OUT_BF16X3 is the three-bf16-part, six-product form,
+    PAYNE_V_OUT_F32 the fp32 matrix instruction.  All against the SAME network evaluated in fp64: the split forms must be as
+    accurate as the fp32 fma chain (whose own roundings dominate all three), pixel rows and frequency rows alike, and sit far inside
+    the flux tolerance.  Labels 15 % outside the training box on every side and NaN labels ride along: the calibrated scale of the
+    activations has room for them, and NaN rows stay NaN."""
     from thepayne_amd import _lib
     cfg = synth.CONFIGS["C2"]
     raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
@@ -91,8 +94,10 @@ def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engi
     rng = np.random.default_rng(8)
     B = 512
     lab = net["xmin"][:4] + rng.uniform(0.02, 0.98, size=(B, 4)) * (net["xmax"][:4] - net["xmin"][:4])
+    lab[:16] = net["xmin"][:4] + rng.uniform(-0.15, 1.15, size=(16, 4)) * (net["xmax"][:4] - net["xmin"][:4])
     th7 = np.column_stack([lab, np.zeros(B), np.zeros(B), np.full(B, 20000.0)])
     th = theta_full(th7)
+    th[40, 0] = np.nan
     # fp64 forward with the fp32 weights (ystpred.py:41-58): encode, two leaky-ReLU layers, linear output
     x = (lab - net["xmin"][:4]) / (net["xmax"][:4] - net["xmin"][:4]) - 0.5
     h = x.astype(np.float32).astype(np.float64)             # (the kernel encodes in fp64 and rounds to fp32)
@@ -100,17 +105,50 @@ def test_output_layer_in_six_bf16_products_is_as_accurate_as_the_fp32_chain(Engi
         h = h @ W.astype(np.float64).T + b.astype(np.float64)
         if act == _lib.ACT_LRELU:
             h = np.maximum(h, 0.01 * h)
-    errs = {}
-    for name, variant in (("split", 0), ("f32", _lib.V_OUT_F32)):
+    ok = np.ones(B, bool); ok[40] = False
+    errs, used = {}, {}
+    for name, variant in (("f16x2", 0), ("bf16x3", _lib.V_OUT_BF16X3), ("f32", _lib.V_OUT_F32)):
         eng = Engine(net, obs=None, b_max=B, variant=variant)
         got = eng.predict_batch(th, stage=0).cpu().numpy().astype(np.float64)
-        errs[name] = np.abs(got - h)
+        used[name] = eng.kernels_used()["out"]
+        assert np.all(np.isnan(got[40])) and np.all(np.isfinite(got[ok]))
+        errs[name] = np.abs(got[ok] - h[ok])
         eng.close()
-    # the hidden layers are the same fp32 kernels in both runs: their rounding is common to both errors
-    assert errs["f32"].max() <= FLUX_TOL and errs["split"].max() <= FLUX_TOL, (errs["f32"].max(), errs["split"].max())
+    assert "dma2h" in used["f16x2"] and "dma3f" in used["bf16x3"], used
+    # the hidden layers are the same fp32 kernels in all runs: their rounding is common to the errors
+    for k in errs:
+        assert errs[k].max() <= FLUX_TOL, (k, errs[k].max())
     rms = {k: float(np.sqrt(np.mean(v ** 2))) for k, v in errs.items()}
-    assert rms["split"] <= 1.25 * rms["f32"] + 1e-9, rms
-    assert errs["split"].max() <= 1.5 * errs["f32"].max() + 1e-8, (errs["split"].max(), errs["f32"].max())
+    for k in ("f16x2", "bf16x3"):
+        assert rms[k] <= 1.25 * rms["f32"] + 1e-9, rms
+        assert errs[k].max() <= 1.5 * errs["f32"].max() + 1e-8, (k, errs[k].max(), errs["f32"].max())
+
+
+def test_rows_in_the_frequency_domain_from_fp16_pairs_against_the_six_product_form(Engine, golden):
+    """The same comparison where the rows are handed over as their transform (the default at C2: the restated weights have a wide
+    range of magnitudes from row to row, which the per-row scales of the fp16 planes absorb): likelihoods and getspec outputs of
+    the two split forms against each other and against the reference's frozen values."""
+    from thepayne_amd import _lib
+    g = golden("g4_lnlike_c2")
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], seed=0)
+    th = theta_full(g["theta"])
+    res = {}
+    for name, v in (("f16x2", 0), ("bf16x3", _lib.V_OUT_BF16X3)):
+        eng = Engine(_net(raw), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=512, variant=v)
+        lnl = eng.lnlike_batch(th).cpu().numpy()
+        assert eng.kernels_used()["rows"] == "frequency"
+        spec = eng.predict_batch(th[:64], stage=2, fwhm_R=True).cpu().numpy().astype(np.float64)
+        res[name] = (lnl, spec)
+        eng.close()
+    for name, (lnl, spec) in res.items():
+        err = np.abs(lnl - g["lnlike"])
+        assert np.all(err <= lnl_tol(g["lnlike"])), (name, err.max())
+    fin = np.isfinite(res["f16x2"][1]) & np.isfinite(res["bf16x3"][1])
+    assert np.array_equal(np.isnan(res["f16x2"][1]), np.isnan(res["bf16x3"][1]))
+    assert np.abs(res["f16x2"][1] - res["bf16x3"][1])[fin].max() <= 2e-7          # (two roundings of the same fp32-class rows)
+    d = np.abs(res["f16x2"][0] - res["bf16x3"][0]); ok = np.isfinite(d)
+    assert np.all(d[ok] <= 0.25 * lnl_tol(g["lnlike"][ok]))
 
 
 @pytest.mark.parametrize("H", [300, 100])
@@ -254,7 +292,7 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
     assert np.all(np.isfinite(ref)) and np.all(np.abs(lnl - ref) <= lnl_tol(ref)), np.abs(lnl - ref).max()
     # which kernels a net of this depth takes: every layer on the matrix cores, the output layer as bf16 products
     names = eng.kernels_used()
-    assert names["hidden"].startswith("payne_dense_hidden_kernel") and names["out"].startswith("payne_dense_dma3"), names
+    assert names["hidden"].startswith("payne_dense_hidden_kernel") and names["out"].startswith("payne_dense_dma"), names
     # other shipped forms of the output layer on the same net: same likelihoods
     for v in (1, 4096, 2048):
         e2 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=v)

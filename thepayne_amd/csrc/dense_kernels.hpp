@@ -42,6 +42,10 @@ struct DenseParams {
   const unsigned long long* sel; unsigned long long sel_seq;
   const unsigned short* Wp_alt; size_t plane_w_alt; const float* bias_alt; float bias_shift_alt; int N_alt, ldy_alt;
   const float* W_alt;          // payne_dense_dma3f_kernel: the alternative layer's weights as fp32 [N_alt][K]
+  // payne_dense_dma2h_kernel (two fp16 planes an operand, three products): the hidden-layer kernel writes Yp as TWO fp16 planes of
+  // y * yp_scale when yp_half is set; the weights' planes hold W[n][k] * 2^e[n] and rscale[n] = 2^-e[n] / yp_scale undoes both
+  int yp_half; float yp_scale;
+  const float* rscale; const float* rscale_alt;
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
@@ -514,6 +518,188 @@ __global__ void __launch_bounds__(256) payne_split3_kernel(const float* __restri
   dst[i] = h; dst[plane + i] = m; dst[2 * plane + i] = l;
 }
 #endif
+
+// ----------------------------------------------------------------------------
+// Two fp16 planes an operand, three products (payne_dense_dma2h_kernel).  X = x * s (s a power of two) = h1 + h2 + rest, h1 = fp16(X),
+// h2 = fp16(X - h1): 22 significant bits of X wherever h2 is a normal number (|X| >= 2^-3), an absolute 2^-25 below.  A product
+// a b = a1 b1 + (a1 b2 + a2 b1) + a2 b2 [dropped: <= 2^-22 |a b|]: three exact 22-bit products in the fp32 accumulator of
+// v_mfma_f32_32x32x16_f16 instead of six bf16 ones -- half the matrix instructions, two thirds of the operand bytes and of the
+// fragment reads.  On the C2 network the rows come out with the rms error of the fp32 chain (1.0e-9 against 0.93e-9, rows of rms
+// 3e-3; frequency rows 4.5e-8 against 4.2e-8 on 0.135): the accumulator's own roundings dominate both (tests/test_gpu_parity.py
+// compares all forms with an fp64 product).  fp16 has five exponent bits: the weights' planes are scaled ROW BY ROW to |X| < 2^15
+// (payne_ctx_create; a row's scale comes back in the epilogue), the activations by one power of two per context, calibrated at
+// payne_ctx_create on the label box with a factor of 8 to spare (what lies beyond saturates; NaN stays NaN).
+// ----------------------------------------------------------------------------
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short f16_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void split2h(float x, float scale, unsigned short& h1, unsigned short& h2) {
+  float X = x * scale;                                     // (a power of two: exact)
+  X = (__builtin_fabsf(X) > 65504.0f) ? __builtin_copysignf(65504.0f, X) : X;      // saturate; NaN compares false and stays
+  const _Float16 a = (_Float16)X;
+  const float r = X - (float)a;                            // exact
+  h1 = f16_bits(a); h2 = f16_bits((_Float16)r);
+}
+// [rows][pitch] fp32 -> two fp16 planes of the same shape, row r scaled by scale[r] (context creation: the output layer's padded weights)
+__global__ void payne_split2h_kernel(const float* __restrict__ src, int rows, int pitch, const float* __restrict__ scale,
+                                     unsigned short* __restrict__ dst, size_t plane);
+#ifdef PAYNE_TU_DENSE
+__global__ void __launch_bounds__(256) payne_split2h_kernel(const float* __restrict__ src, int rows, int pitch, const float* __restrict__ scale,
+                                                            unsigned short* __restrict__ dst, size_t plane) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * pitch) return;
+  unsigned short h1, h2;
+  split2h(src[i], scale[i / pitch], h1, h2);
+  dst[i] = h1; dst[plane + i] = h2;
+}
+#endif
+constexpr int D2_STAGE = 2 * (64 + 128) * 64;              // bytes per stage: two planes x (64 A rows + 128 B rows) x 64 B
+constexpr size_t d2_lds_bytes() { return (size_t)4 * D2_STAGE; }
+// The schedule of payne_dense_dma3_kernel<NK, 4, true>: 24 pieces a stage, three per wave (A: 8 = 2 planes x 4 blocks of 16 rows, B: 16).
+template <int NK>
+__global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PARAMS, DenseParams p_) {
+  DenseParams p = p_;
+  p.sel = lead_sel; p.Xp = lead_Xp; p.Wp = lead_Wp; p.plane_x = lead_plane_x; p.plane_w = lead_plane_w;
+  p.grid_m = (int)(lead_grid & 0xffffu); p.grid_n = (int)(lead_grid >> 16); p.N = lead_N; p.B = lead_B; p.ldp = lead_ldp; p.K = lead_K;
+  constexpr int NS = 4, AHEAD = NS - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char d2_sm[];
+  if (p.sel != nullptr && (unsigned)*p.sel == lead_sel_seq) {
+    p.Wp = p.Wp_alt; p.plane_w = p.plane_w_alt; p.bias = p.bias_alt; p.bias_shift = p.bias_shift_alt; p.N = p.N_alt; p.ldy = p.ldy_alt;
+    p.rscale = p.rscale_alt;
+  }
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 128;
+  if (n0 >= p.N) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
+  const unsigned char* src[3];
+  int dst[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = wave * 3 + j;                            // 0..7 A (plane = q / 4), 8..23 B (plane = (q - 8) / 8)
+    const bool isA = q < 8;
+    const int pl = isA ? q >> 2 : (q - 8) >> 3, blk = isA ? (q & 3) : ((q - 8) & 7);
+    const int row = 16 * blk + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    if (isA) {
+      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)pl * p.plane_x + (size_t)r * p.ldp) + 16 * c;
+      dst[j] = pl * 4096 + blk * 1024;
+    } else {
+      const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(p.Wp + (size_t)pl * p.plane_w + (size_t)r * p.K) + 16 * c;
+      dst[j] = 2 * 4096 + pl * 8192 + blk * 1024;
+    }
+  }
+  auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
+                                       (__attribute__((address_space(3))) void*)(d2_sm + stage * D2_STAGE + dst[j]), 16, 0, 0);
+  };
+  auto wait_landed = [&](int younger) {                    // my pieces of a stage have landed once only `younger` stages' loads are outstanding
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
+  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
+  struct Frag { f16x8_t a[2][2], b[2][2]; };
+  auto frags = [&](int stage, Frag& f) {
+    const unsigned char* As = d2_sm + stage * D2_STAGE;
+    const unsigned char* Bs = As + 2 * 4096;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                       // two 16-deep matrix steps per 32-deep stage
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        f.a[ks][pl] = *reinterpret_cast<const f16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
+        f.b[ks][pl] = *reinterpret_cast<const f16x8_t*>(Bs + pl * 8192 + Rb * 64 + 16 * (c ^ sb));
+      }
+    }
+  };
+  auto products = [&](const Frag& f, int ks) {             // smallest partial products first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
+  };
+  const int nk = NK > 0 ? NK : p.K / 32;                   // padded: exact
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
+  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
+  // (the epilogue's bias and row scale, requested before the first transfer)
+  const int col = n0 + wn0 + (lane & 31);
+  const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
+  const float rs = p.rscale[col < p.N ? col : p.N - 1];
+  HK_STAMP(0);
+  const int npro = nk < AHEAD ? nk : AHEAD;
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q)
+    if (q < npro) issue(q, q * 32);
+  wait_landed(npro - 1);
+  asm volatile("s_barrier" ::: "memory");
+  Frag f0, f1;
+  frags(0, f0);
+  auto head = [&](int it, Frag& fn, const Frag& fc) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) asm volatile("" :: "v"(fc.a[ks][pl]), "v"(fc.b[ks][pl]));
+    {
+      const int last = (it + AHEAD < nk ? it + AHEAD : nk) - 1;
+      wait_landed(last - (it + 1));
+    }
+    asm volatile("s_barrier" ::: "memory");
+#ifndef PAYNE_NO_LOOP_STAMPS
+    if (it < 13) HK_STAMP(1 + it);
+#endif
+    frags((it + 1) % NS, fn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + AHEAD < nk) issue((it + AHEAD) % NS, (it + AHEAD) * 32);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int it = 0;
+#pragma unroll
+  for (; it + 2 < nk; it += 2) {
+    head(it, f1, f0);
+    products(f0, 0); products(f0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    head(it + 1, f0, f1);
+    products(f1, 0); products(f1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (it + 1 < nk) {
+    head(it, f1, f0);
+    products(f0, 0); products(f0, 1);
+    products(f1, 0);
+    if (last_both) products(f1, 1);
+  } else {
+    products(f0, 0);
+    if (last_both) products(f0, 1);
+  }
+  // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (col < p.N) {
+    const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
+    if (act_none) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(__builtin_fmaf(acc[r], rs, bv), &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) __builtin_nontemporal_store(act_apply(__builtin_fmaf(acc[r], rs, bv), p.act), &p.Y[(size_t)row * p.ldy + col]);
+      }
+    }
+  }
+  HK_STAMP(15);
+}
 
 constexpr int D3_STAGE = 3 * (64 + 128) * 64;              // bytes per stage
 // NS = 4, PIPE: one tile per CU (C2).  NS = 2, !PIPE: many tiles per CU (C5) -- two stages = 72 KB, two workgroups per CU, and per
@@ -1472,6 +1658,15 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
           if (!p.Yp) {
             float* yo = &p.Y[(size_t)row * p.ldy + col];
             if (two) *reinterpret_cast<float2*>(yo) = make_float2(pa_[e], pb_[e]); else yo[0] = pa_[e];
+          } else if (p.yp_half) {                                    // two fp16 parts for payne_dense_dma2h_kernel
+            unsigned short h2a[2], h2b[2];
+            split2h(pa_[e], p.yp_scale, h2a[0], h2b[0]);
+            split2h(pb_[e], p.yp_scale, h2a[1], h2b[1]);
+            const size_t o = (size_t)row * p.ldp + col;
+            if (two) {
+              __builtin_nontemporal_store((unsigned)h2a[0] | ((unsigned)h2a[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
+              __builtin_nontemporal_store((unsigned)h2b[0] | ((unsigned)h2b[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
+            } else { p.Yp[o] = h2a[0]; p.Yp[p.plane_y + o] = h2b[0]; }
           } else {                                                   // three bf16 parts for payne_dense_dma3_kernel (its only reader)
             unsigned short h3[2], m3[2], l3[2];
             split3(pa_[e], h3[0], m3[0], l3[0]);
@@ -1491,7 +1686,12 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
         const int row = row0 + q;
         if (row < p.B && colq < p.N) {
           if (!p.Yp) p.Y[(size_t)row * p.ldy + colq] = y[q];
-          else {
+          else if (p.yp_half) {
+            unsigned short ha, hb;
+            split2h(y[q], p.yp_scale, ha, hb);
+            const size_t o = (size_t)row * p.ldp + colq;
+            p.Yp[o] = ha; p.Yp[p.plane_y + o] = hb;
+          } else {
             unsigned short h3, m3, l3;
             split3(y[q], h3, m3, l3);
             const size_t o = (size_t)row * p.ldp + colq;
@@ -1578,6 +1778,8 @@ PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 4, true>(PAYNE_D3_LEAD_
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<10, 4, true>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma3f_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<0>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

@@ -79,6 +79,10 @@ struct payne_ctx {
   // predictions past stage 0 run when the post kernel can start from the transform (freq_ok); raw_freq: the rows now in c->raw
   unsigned short* w_out_p3z = nullptr; const float* bias_z = nullptr; bool freq_ok = false, raw_freq = false;
   const float* w_out_padz = nullptr;    // the restated layer as fp32 [n][w_out_kp] (payne_dense_dma3f_kernel splits it on the way into LDS)
+  // two fp16 planes an operand (payne_dense_dma2h_kernel): the weights' planes [2][n][w_out_kp] with row n scaled by 2^e[n], rscale[n] =
+  // 2^-e[n] / act_scale; act_scale: the power of two the last hidden layer is written with (calibrated on the label box; 0 = not available)
+  unsigned short* w_out_h2 = nullptr; unsigned short* w_out_h2z = nullptr; const float* rscale = nullptr; const float* rscalez = nullptr;
+  float act_scale = 0.f;
   // freq_rs: the restated layer is that of the RESAMPLED spectrum (model grids that are not a power of two long: n1 rows of n1
   // values); a batch with a candidate that does not rotate falls back to pixels ON THE DEVICE (rot_flag: a word the records'
   // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
@@ -284,6 +288,79 @@ extern "C" void payne_ctx_destroy(payne_ctx* c) {
 }
 
 static hipError_t set_dense_attributes();
+// ---- two fp16 planes an operand (dense_kernels.hpp split2h) -----------------------------------------------------------
+// The largest |activation| of the last hidden layer over the label box (corners, centre, 512 points of a fixed sequence, 20 % beyond
+// the box on every side), evaluated on the host in fp64 from the layers as the context holds them.  0 when the net has no hidden
+// layer or produces something that is not finite.
+static double hidden_amax(const payne_model_desc* m, std::string& why) {
+  const int nl = m->n_layers, D = m->n_labels;
+  if (nl < 3) { why = "no hidden layer pair"; return 0.0; }
+  std::vector<std::vector<float>> W(nl - 1), b(nl - 1);
+  for (int l = 0; l + 1 < nl; ++l) {
+    const payne_layer& L = m->layers[l];
+    W[l].resize((size_t)L.n_out * L.n_in); b[l].resize((size_t)L.n_out);
+    if (hipMemcpy(W[l].data(), L.w, W[l].size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(b[l].data(), L.b, b[l].size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { why = "hipMemcpy"; return 0.0; }
+  }
+  auto act = [](double z, int a) { return a == PAYNE_ACT_LRELU ? (z > 0 ? z : 0.01 * z) : (a == PAYNE_ACT_SIGMOID ? 1.0 / (1.0 + std::exp(-z)) : z); };
+  std::vector<std::vector<double>> pts;
+  for (int cidx = 0; cidx < (1 << D); ++cidx) { std::vector<double> x(D); for (int d = 0; d < D; ++d) x[d] = ((cidx >> d) & 1) ? 0.6 : -0.6; pts.push_back(x); }
+  pts.push_back(std::vector<double>(D, 0.0));
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 512; ++i) {
+    std::vector<double> x(D);
+    for (int d = 0; d < D; ++d) { st = st * 6364136223846793005ull + 1442695040888963407ull; x[d] = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 1.2; }
+    pts.push_back(x);
+  }
+  double amax = 0.0;
+  std::vector<double> a, y;
+  for (const auto& x : pts) {
+    a = x;
+    for (int l = 0; l + 1 < nl; ++l) {
+      const payne_layer& L = m->layers[l];
+      y.assign((size_t)L.n_out, 0.0);
+      for (int o = 0; o < L.n_out; ++o) {
+        double z = b[l][o];
+        const float* w = &W[l][(size_t)o * L.n_in];
+        for (int k = 0; k < L.n_in; ++k) z += (double)w[k] * a[k];
+        y[o] = act(z, L.act);
+      }
+      a.swap(y);
+    }
+    for (double v : a) { if (!std::isfinite(v)) { why = "non-finite activation"; return 0.0; } amax = std::max(amax, std::fabs(v)); }
+  }
+  return amax;
+}
+// per-row power-of-two scales of a padded weight matrix [n][kp] (host copy) and its two fp16 planes on the device
+static int make_h2_planes(payne_ctx* c, const float* d_w, const std::vector<float>& h_w, int n, int kp, float act_scale,
+                          unsigned short** planes, const float** rscale) {
+  std::vector<float> sc((size_t)n), rs((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    float mx = 0.f;
+    for (int k = 0; k < kp; ++k) mx = std::max(mx, std::fabs(h_w[(size_t)i * kp + k]));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) e = (int)std::floor(std::log2(16384.0 / (double)mx));
+    e = std::max(-100, std::min(100, e));
+    sc[i] = (float)std::ldexp(1.0, e);
+    rs[i] = (float)(std::ldexp(1.0, -e) / (double)act_scale);
+  }
+  const float* d_sc = nullptr;
+  std::vector<void*> tmp;
+  int rc = upload(c, sc, &d_sc, tmp);
+  if (!rc) rc = upload(c, rs, rscale, c->owned);
+  const size_t nw = (size_t)n * kp;
+  if (!rc) rc = dev_alloc(c, 2 * nw, planes, c->owned);
+  hipError_t he = hipSuccess;
+  if (!rc) {
+    hipLaunchKernelGGL(payne_split2h_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, nullptr, d_w, n, kp, d_sc, *planes, nw);
+    he = hipDeviceSynchronize();
+  }
+  for (void* q : tmp) (void)hipFree(q);
+  if (rc) return rc;
+  if (he != hipSuccess) return fail(c, PAYNE_E_HIP, std::string("weight split (fp16 planes): ") + hipGetErrorString(he));
+  return PAYNE_OK;
+}
+
 extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_desc* obs, const payne_phot_desc* phot,
                                 const payne_opts* opts, int device, payne_ctx** out) {
   if (!out) return fail(nullptr, PAYNE_E_INVALID, "out is NULL");
@@ -359,6 +436,16 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
         hipLaunchKernelGGL(payne_split3_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, nullptr, wp, nw, c->w_out_p3, nw);
         he = hipDeviceSynchronize();
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("weight split: ") + hipGetErrorString(he)));
+        // ... and as two fp16 planes, the activations' scale calibrated on the label box (a factor of 8 to spare below fp16's range)
+        std::string why;
+        const double amax = hidden_amax(model, why);
+        if (amax > 0.0 && amax < 1e30) {
+          c->act_scale = (float)std::ldexp(1.0, std::max(-60, std::min(60, (int)std::floor(std::log2(4096.0 / amax)))));
+          std::vector<float> hw(nw);
+          he = hipMemcpy(hw.data(), wp, nw * 4, hipMemcpyDeviceToHost);
+          if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(output layer): ") + hipGetErrorString(he)));
+          if ((rc = make_h2_planes(c, wp, hw, L.n_out, Kp, c->act_scale, &c->w_out_h2, &c->rscale))) return bail(rc);
+        }
       }
     }
     c->n_layers = model->n_layers;
@@ -469,6 +556,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
         if (rc) return bail(rc);
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("weight split: ") + hipGetErrorString(he)));
         if ((rc = upload(c, bz, &c->bias_z, c->owned))) return bail(rc);
+        if (c->w_out_h2 && (rc = make_h2_planes(c, d_wp, Wp, n, Kp, c->act_scale, &c->w_out_h2z, &c->rscalez))) return bail(rc);
         c->freq_ok = true;
       }
     }
@@ -666,6 +754,8 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<10, 4, true>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 2, false>), d3_lds_bytes<2>());
   set(reinterpret_cast<const void*>(payne_dense_dma3f_kernel<10>), d3_lds_bytes<4>());
+  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<10>), d2_lds_bytes());
+  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<0>), d2_lds_bytes());
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel), b3_lds_bytes());
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
@@ -716,6 +806,28 @@ static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
 // Output layer as six bf16 products (payne_dense_dma3_kernel): equal hidden widths.
 static bool out_dma3_ok(const payne_ctx* c, int, int) {
   return c->w_out_p3 && c->hid_p3 && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & (PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64));
+}
+// ... as three fp16-pair products (payne_dense_dma2h_kernel): one tile per compute unit at most, both weight sets present
+static bool out_dma2h_ok(const payne_ctx* c, int B, int N) {
+  return out_dma3_ok(c, B, N) && c->w_out_h2 && c->act_scale > 0.f && !(c->opts.variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES)) &&
+         ((B + 63) / 64) * ((N + 127) / 128) <= c->n_cu;
+}
+static void launch_out_dma2h(payne_ctx* c, DenseParams& p, hipStream_t s, bool freq) {
+  p.k_real = p.K;
+  p.K = c->w_out_kp;
+  p.Wp = freq ? c->w_out_h2z : c->w_out_h2; p.plane_w = (size_t)p.N * c->w_out_kp;
+  p.rscale = freq ? c->rscalez : c->rscale;
+  if (freq) { p.bias = c->bias_z; p.bias_shift = 0.f; }
+  p.Xp = c->hid_p3; p.plane_x = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
+  p.grid_m = (p.B + 63) / 64;
+  p.grid_n = (p.N + 127) / 128;
+#ifdef PAYNE_STAMPS
+  p.stamps = g_dense_stamps;
+#endif
+  const dim3 grid(p.grid_m * p.grid_n), block(512);
+  if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED))
+    PAYNE_LAUNCH((payne_dense_dma2h_kernel<10>), grid, block, d2_lds_bytes(), s, PAYNE_D3_LEAD_ARGS(p), p);
+  else PAYNE_LAUNCH((payne_dense_dma2h_kernel<0>), grid, block, d2_lds_bytes(), s, PAYNE_D3_LEAD_ARGS(p), p);
 }
 static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool freq) {
   p.k_real = p.K;
@@ -817,7 +929,13 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     p.Y = last ? N.out : N.hid[(l - 1) & 1];
     p.ldy = last ? N.ld_out : N.ld_hid;
     const bool use3 = N.spectral && out_dma3_ok(c, B, N.layers[n - 1].n_out);
-    if (use3 && l == n - 2) { p.Yp = c->hid_p3; p.plane_y = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid; }
+    // (rows of the resampled grid: the wider of the two output layers sizes the grid)
+    const int n_out_launch = (N.freq && c->freq_rs_now) ? std::max(c->T.n1, N.layers[n - 1].n_out) : N.layers[n - 1].n_out;
+    const bool use2h = use3 && out_dma2h_ok(c, B, n_out_launch) && (!N.freq || c->w_out_h2z);
+    if (use3 && l == n - 2) {
+      p.Yp = c->hid_p3; p.plane_y = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
+      if (use2h) { p.yp_half = 1; p.yp_scale = c->act_scale; }
+    }
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
       const payne_layer& L0 = N.layers[0];
@@ -856,8 +974,10 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
           p.Wp_alt = c->w_out_p3; p.plane_w_alt = (size_t)p.N * c->w_out_kp; p.bias_alt = p.bias; p.bias_shift_alt = p.bias_shift;
           p.N_alt = p.N; p.ldy_alt = p.ldy;
           p.N = c->T.n1; p.ldy = c->T.n1;
+          if (use2h) { p.Wp_alt = c->w_out_h2; p.rscale_alt = c->rscale; }
         }
-        launch_out_dma3(c, p, s, N.freq);
+        if (use2h) launch_out_dma2h(c, p, s, N.freq);
+        else launch_out_dma3(c, p, s, N.freq);
       }
       else if (N.spectral && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & PAYNE_V_OUT_GENERIC)) {
         if ((c->w_out_kp % 64) == 0 && (c->opts.variant & PAYNE_V_OUT_BK64)) launch_out_dma<64>(c, p, s);
