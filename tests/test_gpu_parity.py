@@ -156,7 +156,8 @@ def test_output_layer_on_many_big_tiles_against_fp64(Engine, H):
     """The output layer with many tiles per compute unit (C5's 65 536 pixels): payne_dense_big3_kernel -- persistent workgroups,
     128 x 256 tiles, a four-stage ring across tile boundaries, blocked tile order -- against the SAME network in fp64 and against the
     64 x 128-tile form (PAYNE_V_OUT_SMALL_TILES), which must give the same values to the last bit but the order of the k-steps'
-    partial sums (both accumulate a 32 x 32 block's six products per 16-deep step in the same order: bit-equal).  Two batch sizes:
+    partial sums (both accumulate a 32 x 32 block's six products per 16-deep step in the same order: bit-equal) -- and the default
+    there, the same kernel on two fp16 planes an operand (three products a block), against fp64.  Two batch sizes:
     512 (whole tiles: the big-tile kernel) and 500 (not a multiple of 128: the launch must fall back by itself).  H = 100: a width
     whose padded tail (128 columns) is cut at the seventh 16-deep step."""
     from thepayne_amd import _lib
@@ -168,16 +169,25 @@ def test_output_layer_on_many_big_tiles_against_fp64(Engine, H):
     lab = net["xmin"][:4] + rng.uniform(0.02, 0.98, size=(B, 4)) * (net["xmax"][:4] - net["xmin"][:4])
     th = theta_full(np.column_stack([lab, np.zeros(B), np.zeros(B), np.full(B, 60000.0)]))
     ref = _fp64_forward(net, lab)
-    got = {}
-    for name, variant in (("big", 0), ("small", _lib.V_OUT_SMALL_TILES)):
+    got, used = {}, {}
+    for name, variant in (("big_h2", 0), ("small_h2", _lib.V_OUT_SMALL_TILES), ("big", _lib.V_OUT_BF16X3),
+                          ("small", _lib.V_OUT_BF16X3 | _lib.V_OUT_SMALL_TILES)):
         eng = Engine(net, obs=None, b_max=B, variant=variant)
         got[name] = eng.predict_batch(th, stage=0).cpu().numpy()
-        if name == "big":
-            part = eng.predict_batch(th[:500], stage=0).cpu().numpy()       # 500 rows: not whole 128-row tiles
+        used[name] = eng.kernels_used()["out"]
+        if name in ("big", "big_h2"):
+            got[name + "_part"] = eng.predict_batch(th[:500], stage=0).cpu().numpy()       # 500 rows: not whole 128-row tiles
         eng.close()
-    assert np.abs(got["big"].astype(np.float64) - ref).max() <= FLUX_TOL
-    assert np.array_equal(got["big"], got["small"])
-    assert np.array_equal(part, got["small"][:500])
+    assert used["big_h2"] == "payne_dense_big3_kernel<true>" and used["big"] == "payne_dense_big3_kernel<false>", used
+    assert "dma2h" in used["small_h2"] and "dma3_kernel" in used["small"], used
+    # the tile shapes of a form give the same values to the last bit, whole tiles or not
+    for big, small in (("big", "small"), ("big_h2", "small_h2")):
+        assert np.abs(got[big].astype(np.float64) - ref).max() <= FLUX_TOL
+        assert np.array_equal(got[big], got[small])
+        assert np.array_equal(got[big + "_part"], got[small][:500])
+    # the default (two fp16 planes, three products a block) is as accurate in the mean as the six-product form
+    e2, e3 = np.abs(got["big_h2"].astype(np.float64) - ref), np.abs(got["big"].astype(np.float64) - ref)
+    assert np.sqrt(np.mean(e2 ** 2)) <= 1.25 * np.sqrt(np.mean(e3 ** 2)) + 1e-9, (e2.max(), e3.max())
 
 
 def _fp64_forward(net, lab):

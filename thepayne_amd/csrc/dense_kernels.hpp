@@ -1130,11 +1130,13 @@ __global__ void __launch_bounds__(512) payne_dense_dma3f_kernel(PAYNE_D3_LEAD_PA
 // ----------------------------------------------------------------------------
 constexpr int B3_TM = 128, B3_TN = 256, B3_NS = 4;
 constexpr int B3_A_PLANE = B3_TM * 32, B3_B_PLANE = B3_TN * 32;            // bytes per plane and stage
-constexpr int B3_STAGE = 3 * (B3_A_PLANE + B3_B_PLANE);
-constexpr size_t b3_lds_bytes() { return (size_t)B3_NS * B3_STAGE; }
-__global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p);
-#ifdef PAYNE_TU_DENSE
+constexpr int b3_stage(bool h2) { return (h2 ? 2 : 3) * (B3_A_PLANE + B3_B_PLANE); }
+constexpr size_t b3_lds_bytes(bool h2 = false) { return (size_t)B3_NS * b3_stage(h2); }
+template <bool H2>
 __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
+  // H2: operands as two fp16 planes, three products a block (see payne_dense_dma2h_kernel); else three bf16 planes, six products
+  constexpr int NPL = H2 ? 2 : 3, B3_STAGE = b3_stage(H2);
+  typedef typename std::conditional<H2, f16x8_t, bf16x8_t>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char b3_sm[];
   const int ntiles = p.grid_m * p.grid_n;
   // workgroup b sits on XCD b & 7 (round-robin dispatch); XCD x takes tiles [x per, (x + 1) per), its workgroups stride through them
@@ -1145,19 +1147,19 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
-  const bool five = wave < 4;                              // pieces this wave moves per stage: 5 (waves 0-3) or 4
+  const bool five = !H2 && wave < 4;                       // pieces this wave moves per stage: 12 NPL of them -- 5 (waves 0-3) or 4; 3 each with two planes
   // the pieces this wave moves per stage: plane, 32-row block, and where they land
   int prow[5], pdst[5], ppl[5];
   bool pA[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
-    int q = five ? wave * 5 + j : 20 + (wave - 4) * 4 + j;
-    if (q > 35) q = 35;                                    // (slot 4 of the four-piece waves: never issued)
-    pA[j] = q < 12;
-    ppl[j] = pA[j] ? q >> 2 : (q - 12) >> 3;
-    const int blk = pA[j] ? (q & 3) : ((q - 12) & 7);
+    int q = H2 ? wave * 3 + j : (five ? wave * 5 + j : 20 + (wave - 4) * 4 + j);
+    if (q > 12 * NPL - 1) q = 12 * NPL - 1;                // (slots past a wave's count: never issued)
+    pA[j] = q < 4 * NPL;
+    ppl[j] = pA[j] ? q >> 2 : (q - 4 * NPL) >> 3;
+    const int blk = pA[j] ? (q & 3) : ((q - 4 * NPL) & 7);
     prow[j] = 32 * blk + (lane >> 1);
-    pdst[j] = pA[j] ? ppl[j] * B3_A_PLANE + blk * 1024 : 3 * B3_A_PLANE + ppl[j] * B3_B_PLANE + blk * 1024;
+    pdst[j] = pA[j] ? ppl[j] * B3_A_PLANE + blk * 1024 : NPL * B3_A_PLANE + ppl[j] * B3_B_PLANE + blk * 1024;
   }
   const unsigned char* src[5];
   auto set_src = [&](int t) {
@@ -1178,7 +1180,7 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
   auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
 #pragma unroll
     for (int j = 0; j < 5; ++j)
-      if (j < 4 || five)
+      if (H2 ? j < 3 : (j < 4 || five))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
                                          (__attribute__((address_space(3))) void*)(b3_sm + stage * B3_STAGE + pdst[j]), 16, 0, 0);
   };
@@ -1191,16 +1193,16 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
     oa[i] = Ra * 32 + 16 * (h ^ ((Ra >> 4) & 1));
     ob[i] = Rb * 32 + 16 * (h ^ ((Rb >> 4) & 1));
   }
-  struct Frag { bf16x8_t a[2][3], b[2][3]; };              // one 16-deep matrix step: two row blocks, two column blocks, three planes
+  struct Frag { frag_t a[2][NPL], b[2][NPL]; };             // one 16-deep matrix step: two row blocks, two column blocks, NPL planes
   auto frags = [&](int stage, Frag& f) {
     const unsigned char* As = b3_sm + stage * B3_STAGE;
-    const unsigned char* Bs = As + 3 * B3_A_PLANE;
+    const unsigned char* Bs = As + NPL * B3_A_PLANE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        f.a[i][pl] = *reinterpret_cast<const bf16x8_t*>(As + pl * B3_A_PLANE + oa[i]);
-        f.b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * B3_B_PLANE + ob[i]);
+      for (int pl = 0; pl < NPL; ++pl) {
+        f.a[i][pl] = *reinterpret_cast<const frag_t*>(As + pl * B3_A_PLANE + oa[i]);
+        f.b[i][pl] = *reinterpret_cast<const frag_t*>(Bs + pl * B3_B_PLANE + ob[i]);
       }
   };
   auto products = [&](const Frag& f) {                     // smallest partial products first, block by block
@@ -1209,12 +1211,18 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f32x16 a = acc[i][j];
+        if constexpr (H2) {
+          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][1], f.b[j][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][0], a, 0, 0, 0);
+        } else {
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], a, 0, 0, 0);
+        }
         acc[i][j] = a;
       }
   };
@@ -1256,15 +1264,15 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bv[2];
+    float bv[2], rs[2] = {1.f, 1.f};
     for (int it = 0; it < nk; ++it, ++s) {
       // This step's stage has landed once only what was issued after it is outstanding: the requests of (up to) two younger
       // stages -- and, for three steps after an epilogue, its 64 stores, which sit among them in issue order (the counter holds 63
       // at most: "all but the youngest 63" then covers this stage's pieces, at the price of waiting for a few of the stores).
       const int younger = (rq - s - 1);                    // stages requested after this one: 2, fewer at the very end
       if (since_stores < 3) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-      else if (younger >= 2) { if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-      else if (younger == 1) { if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else if (younger >= 2) { if (H2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else if (younger == 1) { if (H2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ++since_stores;
       asm volatile("s_barrier" ::: "memory");              // everybody's pieces landed; everybody finished the step before
@@ -1277,6 +1285,7 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
         for (int j = 0; j < 2; ++j) {
           const int col = n0 + wn0 + 32 * j + (lane & 31);
           bv[j] = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
+          if constexpr (H2) rs[j] = p.rscale[col < p.N ? col : p.N - 1];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1293,14 +1302,14 @@ __global__ void __launch_bounds__(512) payne_dense_big3_kernel(DenseParams p) {
           const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           // (unconditional: the launch guarantees whole tiles -- B % 128 == 0, N % 256 == 0 --, so every wave issues exactly 64
           //  stores here, which is what the vmcnt(63) above counts on)
-          const float v = acc[i][j][r] + bv[j];
+          const float v = H2 ? __builtin_fmaf(acc[i][j][r], rs[j], bv[j]) : acc[i][j][r] + bv[j];
           __builtin_nontemporal_store(act_none ? v : act_apply(v, p.act), &p.Y[(size_t)row * p.ldy + col]);
         }
       }
     since_stores = 0;
   }
 }
-#endif
+
 
 // ----------------------------------------------------------------------------
 // Hidden layers, workgroup form: one 256-thread group per 32x32 output tile, the whole K
@@ -1780,6 +1789,8 @@ PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(PAYNE_D3_LEAD
 PAYNE_DENSE_T __global__ void payne_dense_dma3f_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<0>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<false>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

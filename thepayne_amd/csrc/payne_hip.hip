@@ -756,7 +756,8 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma3f_kernel<10>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<10>), d2_lds_bytes());
   set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<0>), d2_lds_bytes());
-  set(reinterpret_cast<const void*>(payne_dense_big3_kernel), b3_lds_bytes());
+  set(reinterpret_cast<const void*>(payne_dense_big3_kernel<false>), b3_lds_bytes(false));
+  set(reinterpret_cast<const void*>(payne_dense_big3_kernel<true>), b3_lds_bytes(true));
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
@@ -807,10 +808,15 @@ static void launch_out_dma(payne_ctx* c, DenseParams& p, hipStream_t s) {
 static bool out_dma3_ok(const payne_ctx* c, int, int) {
   return c->w_out_p3 && c->hid_p3 && c->dma_ok && c->ld_hid >= c->w_out_kp && !(c->opts.variant & (PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64));
 }
-// ... as three fp16-pair products (payne_dense_dma2h_kernel): one tile per compute unit at most, both weight sets present
-static bool out_dma2h_ok(const payne_ctx* c, int B, int N) {
-  return out_dma3_ok(c, B, N) && c->w_out_h2 && c->act_scale > 0.f && !(c->opts.variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES)) &&
-         ((B + 63) / 64) * ((N + 127) / 128) <= c->n_cu;
+// ... as three fp16-pair products: many whole 128 x 256 tiles (payne_dense_big3_kernel<true>), else 64 x 128 tiles (payne_dense_dma2h_kernel)
+static bool out_big_tiles(const payne_ctx* c, int B, int N, bool sel) {
+  return B % B3_TM == 0 && N % B3_TN == 0 && (B / B3_TM) * (N / B3_TN) >= 2 * c->n_cu && !(c->opts.variant & PAYNE_V_OUT_SMALL_TILES) && !sel;
+}
+static bool out_dma2h_ok(const payne_ctx* c, int B, int N, bool sel = false) {
+  // (whatever the batch: a candidate's rows do not depend on how many others share its batch -- many whole 128 x 256 tiles take
+  //  payne_dense_big3_kernel<true>, everything else payne_dense_dma2h_kernel, one tile a workgroup, same products in the same order)
+  (void)sel;
+  return out_dma3_ok(c, B, N) && c->w_out_h2 && c->act_scale > 0.f && !(c->opts.variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES));
 }
 static void launch_out_dma2h(payne_ctx* c, DenseParams& p, hipStream_t s, bool freq) {
   p.k_real = p.K;
@@ -819,6 +825,11 @@ static void launch_out_dma2h(payne_ctx* c, DenseParams& p, hipStream_t s, bool f
   p.rscale = freq ? c->rscalez : c->rscale;
   if (freq) { p.bias = c->bias_z; p.bias_shift = 0.f; }
   p.Xp = c->hid_p3; p.plane_x = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
+  if (out_big_tiles(c, p.B, p.N, p.sel != nullptr)) {      // many whole 128 x 256 tiles per CU (C5): persistent workgroups
+    p.grid_m = p.B / B3_TM; p.grid_n = p.N / B3_TN;
+    PAYNE_LAUNCH(payne_dense_big3_kernel<true>, dim3(c->n_cu), dim3(512), b3_lds_bytes(true), s, p);
+    return;
+  }
   p.grid_m = (p.B + 63) / 64;
   p.grid_n = (p.N + 127) / 128;
 #ifdef PAYNE_STAMPS
@@ -841,10 +852,10 @@ static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool fr
   p.stamps = g_dense_stamps;
 #endif
   const dim3 block(512);
-  if (p.B % B3_TM == 0 && p.N % B3_TN == 0 && (p.B / B3_TM) * (p.N / B3_TN) >= 2 * c->n_cu && !(c->opts.variant & PAYNE_V_OUT_SMALL_TILES) && !p.sel) {
+  if (out_big_tiles(c, p.B, p.N, p.sel != nullptr)) {
     // many whole 128 x 256 tiles per CU (C5): persistent workgroups, half the operand bytes per product
     p.grid_m = p.B / B3_TM; p.grid_n = p.N / B3_TN;
-    PAYNE_LAUNCH(payne_dense_big3_kernel, dim3(c->n_cu), block, b3_lds_bytes(), s, p);
+    PAYNE_LAUNCH(payne_dense_big3_kernel<false>, dim3(c->n_cu), block, b3_lds_bytes(false), s, p);
     return;
   }
   const dim3 grid(p.grid_m * p.grid_n);
@@ -931,7 +942,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
     const bool use3 = N.spectral && out_dma3_ok(c, B, N.layers[n - 1].n_out);
     // (rows of the resampled grid: the wider of the two output layers sizes the grid)
     const int n_out_launch = (N.freq && c->freq_rs_now) ? std::max(c->T.n1, N.layers[n - 1].n_out) : N.layers[n - 1].n_out;
-    const bool use2h = use3 && out_dma2h_ok(c, B, n_out_launch) && (!N.freq || c->w_out_h2z);
+    const bool use2h = use3 && out_dma2h_ok(c, B, n_out_launch, N.freq && c->freq_rs_now) && (!N.freq || c->w_out_h2z);
     if (use3 && l == n - 2) {
       p.Yp = c->hid_p3; p.plane_y = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
       if (use2h) { p.yp_half = 1; p.yp_scale = c->act_scale; }
