@@ -552,15 +552,25 @@ __global__ void __launch_bounds__(256) payne_split2h_kernel(const float* __restr
   dst[i] = h1; dst[plane + i] = h2;
 }
 #endif
-constexpr int D2_STAGE = 2 * (64 + 128) * 64;              // bytes per stage: two planes x (64 A rows + 128 B rows) x 64 B
-constexpr size_t d2_lds_bytes() { return (size_t)4 * D2_STAGE; }
-// The schedule of payne_dense_dma3_kernel<NK, 4, true>: 24 pieces a stage, three per wave (A: 8 = 2 planes x 4 blocks of 16 rows, B: 16).
-template <int NK>
+// Stage: two planes x (64 A rows + 128 B rows) x 2 KD bytes (KD = 32: 24 KB, four stages; KD = 64: 48 KB, three stages -- half as many
+// barrier steps for the same matrix instructions: a step's fixed cost (wait, barrier, fragment reads, requests: 300-500 cycles) is
+// as long as its six matrix instructions per wave at KD = 32).  A 1-KiB piece = 1024 / (2 KD) rows of one plane; 16-byte chunk c of
+// tile row r sits at chunk c ^ sw(r), sw = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte rows: the sixteen lanes of
+// every lane group of a fragment read (ds_read_b128) cover sixteen different 16-byte bank groups.
+template <int KD> constexpr int d2_stage() { return 2 * (64 + 128) * 2 * KD; }
+template <int KD> constexpr int d2_ns() { return KD == 64 ? 3 : 4; }
+template <int KD> constexpr size_t d2_lds_bytes() { return (size_t)d2_ns<KD>() * d2_stage<KD>(); }
+// The schedule of payne_dense_dma3_kernel<NK, 4, true>; NK: k-steps (of KD) fixed at compile time, or 0.
+template <int NK, int KD>
 __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PARAMS, DenseParams p_) {
   DenseParams p = p_;
   p.sel = lead_sel; p.Xp = lead_Xp; p.Wp = lead_Wp; p.plane_x = lead_plane_x; p.plane_w = lead_plane_w;
   p.grid_m = (int)(lead_grid & 0xffffu); p.grid_n = (int)(lead_grid >> 16); p.N = lead_N; p.B = lead_B; p.ldp = lead_ldp; p.K = lead_K;
-  constexpr int NS = 4, AHEAD = NS - 1;
+  constexpr int NS = d2_ns<KD>(), AHEAD = NS - 1, STAGE = d2_stage<KD>();
+  constexpr int ROWB = 2 * KD, CPR = ROWB / 16, RPP = 1024 / ROWB;          // bytes a row, chunks a row, rows a piece
+  constexpr int A_PLANE = 64 * ROWB, B_PLANE = 128 * ROWB, NPA = 64 / RPP, NPB = 128 / RPP, PW = 2 * (NPA + NPB) / 8;   // pieces a wave: 3 | 6
+  constexpr int KS = KD / 16;                              // 16-deep matrix steps a stage
+  auto sw = [](int row) { return KD == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   extern __shared__ __attribute__((aligned(16))) unsigned char d2_sm[];
   if (p.sel != nullptr && (unsigned)*p.sel == lead_sel_seq) {
     p.Wp = p.Wp_alt; p.plane_w = p.plane_w_alt; p.bias = p.bias_alt; p.bias_shift = p.bias_shift_alt; p.N = p.N_alt; p.ldy = p.ldy_alt;
@@ -574,52 +584,53 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
-  const unsigned char* src[3];
-  int dst[3];
+  const unsigned char* src[PW];
+  int dst[PW];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int q = wave * 3 + j;                            // 0..7 A (plane = q / 4), 8..23 B (plane = (q - 8) / 8)
-    const bool isA = q < 8;
-    const int pl = isA ? q >> 2 : (q - 8) >> 3, blk = isA ? (q & 3) : ((q - 8) & 7);
-    const int row = 16 * blk + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
+  for (int j = 0; j < PW; ++j) {
+    const int q = wave * PW + j;                           // A pieces first (plane, block), then B
+    const bool isA = q < 2 * NPA;
+    const int qq = isA ? q : q - 2 * NPA, np_ = isA ? NPA : NPB;
+    const int pl = qq / np_, blk = qq - pl * np_;
+    const int row = RPP * blk + lane / CPR;
+    const int c = (lane % CPR) ^ sw(row);                  // which 16-byte chunk of the row belongs in this lane's slot
     if (isA) {
       const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
       src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)pl * p.plane_x + (size_t)r * p.ldp) + 16 * c;
-      dst[j] = pl * 4096 + blk * 1024;
+      dst[j] = pl * A_PLANE + blk * 1024;
     } else {
       const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
       src[j] = reinterpret_cast<const unsigned char*>(p.Wp + (size_t)pl * p.plane_w + (size_t)r * p.K) + 16 * c;
-      dst[j] = 2 * 4096 + pl * 8192 + blk * 1024;
+      dst[j] = 2 * A_PLANE + pl * B_PLANE + blk * 1024;
     }
   }
   auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < PW; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
-                                       (__attribute__((address_space(3))) void*)(d2_sm + stage * D2_STAGE + dst[j]), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(d2_sm + stage * STAGE + dst[j]), 16, 0, 0);
   };
   auto wait_landed = [&](int younger) {                    // my pieces of a stage have landed once only `younger` stages' loads are outstanding
     if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int Ra = wm0 + (lane & 31), Rb = wn0 + (lane & 31), h = lane >> 5;
-  const int sa = (Ra >> 2) & 3, sb = (Rb >> 2) & 3;
-  struct Frag { f16x8_t a[2][2], b[2][2]; };
+  const int sa = sw(Ra), sb = sw(Rb);
+  struct Frag { f16x8_t a[KS][2], b[KS][2]; };
   auto frags = [&](int stage, Frag& f) {
-    const unsigned char* As = d2_sm + stage * D2_STAGE;
-    const unsigned char* Bs = As + 2 * 4096;
+    const unsigned char* As = d2_sm + stage * STAGE;
+    const unsigned char* Bs = As + 2 * A_PLANE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {                       // two 16-deep matrix steps per 32-deep stage
+    for (int ks = 0; ks < KS; ++ks) {
       const int c = 2 * ks + h;
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
-        f.a[ks][pl] = *reinterpret_cast<const f16x8_t*>(As + pl * 4096 + Ra * 64 + 16 * (c ^ sa));
-        f.b[ks][pl] = *reinterpret_cast<const f16x8_t*>(Bs + pl * 8192 + Rb * 64 + 16 * (c ^ sb));
+        f.a[ks][pl] = *reinterpret_cast<const f16x8_t*>(As + pl * A_PLANE + Ra * ROWB + 16 * (c ^ sa));
+        f.b[ks][pl] = *reinterpret_cast<const f16x8_t*>(Bs + pl * B_PLANE + Rb * ROWB + 16 * (c ^ sb));
       }
     }
   };
@@ -628,9 +639,18 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
   };
-  const int nk = NK > 0 ? NK : p.K / 32;                   // padded: exact
-  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * 32;
-  const bool last_both = __builtin_amdgcn_readfirstlane(k_tail > 16 ? 1 : 0) != 0;   // the zero-padded half of the last step is skipped
+  const int nk = NK > 0 ? NK : p.K / KD;                   // padded: exact
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * KD;
+  const int ks_last = __builtin_amdgcn_readfirstlane((k_tail + 15) >> 4);   // the zero-padded 16-deep steps of the last stage are skipped
+  auto all_products = [&](const Frag& f) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) products(f, ks);
+  };
+  auto last_products = [&](const Frag& f) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      if (ks < ks_last) products(f, ks);
+  };
   // (the epilogue's bias and row scale, requested before the first transfer)
   const int col = n0 + wn0 + (lane & 31);
   const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
@@ -639,14 +659,14 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
   const int npro = nk < AHEAD ? nk : AHEAD;
 #pragma unroll
   for (int q = 0; q < AHEAD; ++q)
-    if (q < npro) issue(q, q * 32);
+    if (q < npro) issue(q, q * KD);
   wait_landed(npro - 1);
   asm volatile("s_barrier" ::: "memory");
   Frag f0, f1;
   frags(0, f0);
   auto head = [&](int it, Frag& fn, const Frag& fc) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) asm volatile("" :: "v"(fc.a[ks][pl]), "v"(fc.b[ks][pl]));
     {
@@ -659,27 +679,25 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
 #endif
     frags((it + 1) % NS, fn);
     __builtin_amdgcn_sched_barrier(0);
-    if (it + AHEAD < nk) issue((it + AHEAD) % NS, (it + AHEAD) * 32);
+    if (it + AHEAD < nk) issue((it + AHEAD) % NS, (it + AHEAD) * KD);
     __builtin_amdgcn_sched_barrier(0);
   };
   int it = 0;
 #pragma unroll
   for (; it + 2 < nk; it += 2) {
     head(it, f1, f0);
-    products(f0, 0); products(f0, 1);
+    all_products(f0);
     __builtin_amdgcn_sched_barrier(0);
     head(it + 1, f0, f1);
-    products(f1, 0); products(f1, 1);
+    all_products(f1);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (it + 1 < nk) {
     head(it, f1, f0);
-    products(f0, 0); products(f0, 1);
-    products(f1, 0);
-    if (last_both) products(f1, 1);
+    all_products(f0);
+    last_products(f1);
   } else {
-    products(f0, 0);
-    if (last_both) products(f0, 1);
+    last_products(f0);
   }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (col < p.N) {
@@ -1787,8 +1805,9 @@ PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 4, true>(PAYNE_D3_LEAD_
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<10, 4, true>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma3_kernel<0, 2, false>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_dma3f_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<10>(PAYNE_D3_LEAD_TYPES, DenseParams);
-PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<0>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<10, 32>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<0, 32>(PAYNE_D3_LEAD_TYPES, DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<5, 64>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<false>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

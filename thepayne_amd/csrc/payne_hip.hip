@@ -754,8 +754,9 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<10, 4, true>), d3_lds_bytes<4>());
   set(reinterpret_cast<const void*>(payne_dense_dma3_kernel<0, 2, false>), d3_lds_bytes<2>());
   set(reinterpret_cast<const void*>(payne_dense_dma3f_kernel<10>), d3_lds_bytes<4>());
-  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<10>), d2_lds_bytes());
-  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<0>), d2_lds_bytes());
+  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<10, 32>), d2_lds_bytes<32>());
+  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<0, 32>), d2_lds_bytes<32>());
+  set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<5, 64>), d2_lds_bytes<64>());
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel<false>), b3_lds_bytes(false));
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel<true>), b3_lds_bytes(true));
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
@@ -836,9 +837,13 @@ static void launch_out_dma2h(payne_ctx* c, DenseParams& p, hipStream_t s, bool f
   p.stamps = g_dense_stamps;
 #endif
   const dim3 grid(p.grid_m * p.grid_n), block(512);
-  if (p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED))
-    PAYNE_LAUNCH((payne_dense_dma2h_kernel<10>), grid, block, d2_lds_bytes(), s, PAYNE_D3_LEAD_ARGS(p), p);
-  else PAYNE_LAUNCH((payne_dense_dma2h_kernel<0>), grid, block, d2_lds_bytes(), s, PAYNE_D3_LEAD_ARGS(p), p);
+  // 300-wide nets: five 64-deep steps when every tile has a compute unit to itself (C2: 144 KB of LDS a workgroup), ten 32-deep ones
+  // otherwise; other widths, and PAYNE_V_OUT_ROLLED: 32-deep steps counted at run time.  Same products in the same order in all three.
+  const bool k320 = p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED);
+  const bool deep = (int)grid.x <= c->n_cu;
+  if (k320 && deep) PAYNE_LAUNCH((payne_dense_dma2h_kernel<5, 64>), grid, block, d2_lds_bytes<64>(), s, PAYNE_D3_LEAD_ARGS(p), p);
+  else if (k320) PAYNE_LAUNCH((payne_dense_dma2h_kernel<10, 32>), grid, block, d2_lds_bytes<32>(), s, PAYNE_D3_LEAD_ARGS(p), p);
+  else PAYNE_LAUNCH((payne_dense_dma2h_kernel<0, 32>), grid, block, d2_lds_bytes<32>(), s, PAYNE_D3_LEAD_ARGS(p), p);
 }
 static void launch_out_dma3(payne_ctx* c, DenseParams& p, hipStream_t s, bool freq) {
   p.k_real = p.K;
