@@ -135,6 +135,8 @@ typedef struct payne_opts {
                                     300 and batches with more tiles than compute units use) instead of fp32 weights split on their way into LDS */
 #define PAYNE_V_OUT_BF16X3 1048576u /* output layer: operands split in three bf16 parts, six products (what batches with more tiles than
                                      compute units and nets whose last hidden layer could not be calibrated use) instead of two fp16 parts, three products */
+#define PAYNE_V_HID_F32 2097152u  /* hidden layers: the fp32 matrix instruction for the second layer too (what later layers of deeper nets and
+                                     widths other than 289..304 use) instead of products of fp16 pairs */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

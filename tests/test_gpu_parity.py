@@ -30,9 +30,10 @@ def _net(raw, kind="YST1"):
 VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "post_full": 8, "no_prep": 16,
             "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048,
             "rows_pixel": 262144, "rows_pixel+post_full": 262144 | 8, "rows_pixel+no_prep": 262144 | 16,
-            "out_planes": 524288, "out_planes+rows_pixel": 524288 | 262144, "out_bf16x3": 1048576, "out_bf16x3+rows_pixel": 1048576 | 262144}
+            "out_planes": 524288, "out_planes+rows_pixel": 524288 | 262144, "out_bf16x3": 1048576, "out_bf16x3+rows_pixel": 1048576 | 262144,
+            "hid_f32": 2097152, "hid_f32+out_bf16x3": 2097152 | 1048576}
 # ... of which these hand the post kernel rows in the frequency domain (the output layer's weights restated: payne_hip.h, payne_last_kernel kind 4)
-FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes", "out_bf16x3"}
+FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes", "out_bf16x3", "hid_f32", "hid_f32+out_bf16x3"}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -122,6 +123,44 @@ def test_output_layer_in_split_products_is_as_accurate_as_the_fp32_chain(Engine)
     for k in ("f16x2", "bf16x3"):
         assert rms[k] <= 1.25 * rms["f32"] + 1e-9, rms
         assert errs[k].max() <= 1.5 * errs["f32"].max() + 1e-8, (k, errs[k].max(), errs["f32"].max())
+
+
+def test_second_layer_on_fp16_pairs_against_fp64_and_the_fp32_instruction(Engine):
+    """The first hidden-layer launch multiplies the second layer on fp16 pairs (hk_tile_h2: the first layer transposed on the matrix
+    cores, split in registers; three v_mfma_f32_16x16x32_f16 a 32-deep step); PAYNE_V_HID_F32 keeps the fp32 matrix instruction.  With
+    an output layer that copies the second layer's units the network's rows ARE its activations: both forms against fp64, the pair form
+    as accurate as the fp32 one, for a batch that fills the machine several times over (2048 candidates = 640 tiles), thirty times --
+    every call the same bits (a 16-deep legacy instruction at the end of the chain returned wrong accumulator halves now and then while
+    this was written) --, labels outside the box and a NaN row included."""
+    from thepayne_amd import _lib
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=512, lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    raw["w_array_2"][:] = 0
+    raw["b_array_2"][:] = 0
+    for k in range(300):
+        raw["w_array_2"][k, k] = 1.0
+    net = _net(raw)
+    B = 2048
+    rng = np.random.default_rng(4)
+    lab = net["xmin"][:4] + rng.uniform(0.0, 1.0, size=(B, 4)) * (net["xmax"][:4] - net["xmin"][:4])
+    lab[:32] = net["xmin"][:4] + rng.uniform(-0.15, 1.15, size=(32, 4)) * (net["xmax"][:4] - net["xmin"][:4])
+    th = theta_full(np.column_stack([lab, np.zeros(B), np.zeros(B), np.full(B, 20000.0)]))
+    th[77, 1] = np.nan
+    ref = _fp64_forward(net, lab)[:, :300]
+    ok = np.ones(B, bool); ok[77] = False
+    err = {}
+    for name, v in (("f16x2", _lib.V_OUT_F32), ("f32", _lib.V_OUT_F32 | _lib.V_HID_F32)):
+        eng = Engine(net, obs=None, b_max=B, variant=v)
+        first = eng.predict_batch(th, stage=0).cpu().numpy()
+        for rep in range(30 if name == "f16x2" else 2):
+            again = eng.predict_batch(th, stage=0).cpu().numpy()
+            assert np.array_equal(again, first, equal_nan=True), (name, rep)
+        assert np.all(np.isnan(first[77, :300])) and np.all(np.isfinite(first[ok]))
+        err[name] = np.abs(first[ok, :300].astype(np.float64) - ref[ok])
+        eng.close()
+    rms = {k: float(np.sqrt(np.mean(v ** 2))) for k, v in err.items()}
+    assert err["f16x2"].max() <= FLUX_TOL and err["f32"].max() <= FLUX_TOL, {k: v.max() for k, v in err.items()}
+    assert rms["f16x2"] <= 1.5 * rms["f32"] + 1e-9, rms
 
 
 def test_rows_in_the_frequency_domain_from_fp16_pairs_against_the_six_product_form(Engine, golden):

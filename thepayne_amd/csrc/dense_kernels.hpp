@@ -46,6 +46,9 @@ struct DenseParams {
   // y * yp_scale when yp_half is set; the weights' planes hold W[n][k] * 2^e[n] and rscale[n] = 2^-e[n] / yp_scale undoes both
   int yp_half; float yp_scale;
   const float* rscale; const float* rscale_alt;
+  // hk_tile_h2 (first hidden-layer launch on fp16 pairs): the second layer's weights as two fp16 planes [2][N][304] (plane_wh elements
+  // apart, row n scaled by 2^e[n]), rs1[n] = 2^-e[n] / a0_scale, a0_scale: the power of two the first layer's output is split with
+  const unsigned short* Wh; size_t plane_wh; const float* rs1; float a0_scale; int h2_tiles;
 #ifdef PAYNE_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid][16] cycle stamps of the hidden-layer kernel
 #endif
@@ -538,6 +541,17 @@ __device__ __forceinline__ void split2h(float x, float scale, unsigned short& h1
   const _Float16 a = (_Float16)X;
   const float r = X - (float)a;                            // exact
   h1 = f16_bits(a); h2 = f16_bits((_Float16)r);
+}
+// Two values at once for the kernels' epilogues: v_cvt_pkrtz_f16_f32 rounds TOWARD ZERO -- h1 + h2 then hold 21 significant bits
+// instead of 22 (still below the accumulator's own roundings), a value beyond fp16's range comes out as the largest finite half by
+// itself (no clamp), NaN stays NaN -- and leaves both halves packed as the planes want them: eight vector instructions a pair.
+typedef __fp16 pkh2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float scale, unsigned& p1, unsigned& p2) {
+  const float X0 = x0 * scale, X1 = x1 * scale;
+  const pkh2_t a = __builtin_amdgcn_cvt_pkrtz(X0, X1);
+  const float r0 = X0 - (float)a[0], r1 = X1 - (float)a[1];          // exact
+  const pkh2_t b = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  p1 = __builtin_bit_cast(unsigned, a); p2 = __builtin_bit_cast(unsigned, b);
 }
 // [rows][pitch] fp32 -> two fp16 planes of the same shape, row r scaled by scale[r] (context creation: the output layer's padded weights)
 __global__ void payne_split2h_kernel(const float* __restrict__ src, int rows, int pitch, const float* __restrict__ scale,
@@ -1365,6 +1379,259 @@ struct PrepArgs {
   unsigned long long* rot_flag; unsigned long long rot_seq;
 };
 
+// The epilogue of a hidden-layer tile: the wave's 16 x 16 quadrant (C/D map: column r, rows 4 g + q) stored as the fp32 tile or as the
+// output layer's operand planes.  Neighbouring lanes hold neighbouring columns: lane pairs swap half of their rows (DPP), so that every
+// lane ends up with two adjacent columns of two rows -- 8-byte stores of the fp32 tile, 4-byte stores of each plane, without LDS.
+__device__ __forceinline__ void hk_store_quadrant(const DenseParams& p, const float (&y)[4], int m0, int n0, int qi, int qj, int r, int g) {
+  {
+    const bool pairs_ok = ((p.ldy | n0) & 1) == 0 && (!p.Yp || (p.ldp & 1) == 0);
+    const int colq = n0 + 16 * qj + r, row0 = m0 + 16 * qi + 4 * g;
+    if (pairs_ok) {
+      const bool oddl = (r & 1) != 0;
+      // even lane keeps rows 0, 1 and gets the odd lane's; odd lane keeps rows 2, 3 and gets the even lane's
+      const float s0 = oddl ? y[0] : y[2], s1 = oddl ? y[1] : y[3];
+      const float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
+      float pa_[2], pb_[2];                                          // (column, column + 1) of the lane's two rows
+      pa_[0] = oddl ? t0 : y[0]; pb_[0] = oddl ? y[2] : t0;
+      pa_[1] = oddl ? t1 : y[1]; pb_[1] = oddl ? y[3] : t1;
+      const int col = colq & ~1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int row = row0 + (oddl ? 2 : 0) + e;
+        if (row < p.B && col < p.N) {
+          const bool two = col + 1 < p.N;
+          if (!p.Yp) {
+            float* yo = &p.Y[(size_t)row * p.ldy + col];
+            if (two) *reinterpret_cast<float2*>(yo) = make_float2(pa_[e], pb_[e]); else yo[0] = pa_[e];
+          } else if (p.yp_half) {                                    // two fp16 parts for payne_dense_dma2h_kernel
+            unsigned q1, q2;
+            split2h_pair(pa_[e], pb_[e], p.yp_scale, q1, q2);
+            const size_t o = (size_t)row * p.ldp + col;
+            if (two) {
+              __builtin_nontemporal_store(q1, reinterpret_cast<unsigned*>(&p.Yp[o]));
+              __builtin_nontemporal_store(q2, reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
+            } else { p.Yp[o] = (unsigned short)(q1 & 0xffffu); p.Yp[p.plane_y + o] = (unsigned short)(q2 & 0xffffu); }
+          } else {                                                   // three bf16 parts for payne_dense_dma3_kernel (its only reader)
+            unsigned short h3[2], m3[2], l3[2];
+            split3(pa_[e], h3[0], m3[0], l3[0]);
+            split3(pb_[e], h3[1], m3[1], l3[1]);
+            const size_t o = (size_t)row * p.ldp + col;
+            if (two) {                                               // (streamed: the next reader is another XCD)
+              __builtin_nontemporal_store((unsigned)h3[0] | ((unsigned)h3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
+              __builtin_nontemporal_store((unsigned)m3[0] | ((unsigned)m3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
+              __builtin_nontemporal_store((unsigned)l3[0] | ((unsigned)l3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]));
+            } else { p.Yp[o] = h3[0]; p.Yp[p.plane_y + o] = m3[0]; p.Yp[2 * p.plane_y + o] = l3[0]; }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + q;
+        if (row < p.B && colq < p.N) {
+          if (!p.Yp) p.Y[(size_t)row * p.ldy + colq] = y[q];
+          else if (p.yp_half) {
+            unsigned q1, q2;
+            split2h_pair(y[q], 0.f, p.yp_scale, q1, q2);
+            const size_t o = (size_t)row * p.ldp + colq;
+            p.Yp[o] = (unsigned short)(q1 & 0xffffu); p.Yp[p.plane_y + o] = (unsigned short)(q2 & 0xffffu);
+          } else {
+            unsigned short h3, m3, l3;
+            split3(y[q], h3, m3, l3);
+            const size_t o = (size_t)row * p.ldp + colq;
+            p.Yp[o] = h3; p.Yp[p.plane_y + o] = m3; p.Yp[2 * p.plane_y + o] = l3;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// hk_tile_h2: the first launch of a net (label encoding + first layer + second layer) with the second layer's products on fp16 PAIRS
+// (split2h above: three v_mfma_f32_16x16x32_f16 a 32-deep step instead of eight v_mfma_f32_16x16x4_f32 -- 30 matrix instructions a
+// wave for K = 300 instead of 76).  Weight tile: two fp16 planes [32][304] straight into LDS (38 transfers of 1 KB,
+// the planes split and row-scaled at payne_ctx_create).  First layer TRANSPOSED on the matrix cores (operands swapped: D[unit][candidate]),
+// so that a lane ends up with FOUR CONSECUTIVE units of one candidate row -- split in registers, one 8-byte LDS store a plane.  Rows of
+// a plane are 608 bytes = 38 chunks of 16 bytes apart: 38 = 6 (mod 16) puts the sixteen lanes of every lane group of a fragment read
+// (ds_read_b128: lane (r, g) reads chunk 4 s + g of row r) on sixteen different 16-byte bank groups.
+// ----------------------------------------------------------------------------
+constexpr int HK2_PB = 608, HK2_PLANE = 32 * HK2_PB, HK2_K = 304;
+static_assert(4 * HK2_PLANE <= (int)HK_LDS_BYTES, "four planes in the hidden-layer launch's LDS");
+template <int NL>
+__device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_sm, const int tid) {
+  HK_STAMP(0);
+  unsigned char* As = reinterpret_cast<unsigned char*>(hk_sm);
+  unsigned char* Bs = As + 2 * HK2_PLANE;
+  const int tm = tile / p.grid_n, tn = tile - tm * p.grid_n;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int qi = wave >> 1, qj = wave & 1;
+  float bias1, rs1;
+  {
+    const int c0 = n0 + 16 * qj + r, cc = c0 < p.N ? c0 : p.N - 1;
+    bias1 = p.bias[cc]; rs1 = p.rs1[cc];
+  }
+  constexpr int NLG = (NL + 3) / 4, MAXT = (HK2_K / 16 + 3) / 4;     // label groups of four; unit blocks of 16 a wave (5)
+  constexpr int ntile = HK2_K / 16;                                   // 19
+  // labels of the candidates (B operand of the transposed first layer: lane (r, g) = xhat[candidate 16 i + r][label 4 lg + g])
+  double xl[2][NLG];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (m0 + 16 * i + r < p.B) ? m0 + 16 * i + r : p.B - 1;
+#pragma unroll
+    for (int lg = 0; lg < NLG; ++lg) { const int d = 4 * lg + g; xl[i][lg] = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)]; }
+  }
+  // first-layer weights (A operand: lane (r, g) = W0[unit 16 t + r][label 4 lg + g]) and biases (four units 16 t + 4 g + q a lane)
+  float w0t[MAXT][NLG];
+  f32x4_t bz4[MAXT];
+#pragma unroll
+  for (int tt = 0; tt < MAXT; ++tt) {
+    const int tcol = wave + 4 * tt, tc = tcol < ntile ? tcol : 0;
+    const int k = 16 * tc + r, kq = k < p.K0 ? k : p.K0 - 1;
+#pragma unroll
+    for (int lg = 0; lg < NLG; ++lg) {
+      const int d = 4 * lg + g;
+      w0t[tt][lg] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];     // (clamped address, masked below)
+    }
+    {                                                                 // (units past the layer's width are masked below: any values do)
+      const int u0 = 16 * tc + 4 * g, uq = (u0 + 4 <= p.K0) ? u0 : ((p.K0 - 4) & ~3);
+      bz4[tt] = *reinterpret_cast<const f32x4_t*>(p.b0 + (uq > 0 ? uq : 0));
+    }
+  }
+  // the weight tile: 2 planes x 19 transfers of 64 consecutive 16-byte chunks (chunk sl = (row sl / 38, chunk sl % 38))
+  {
+    constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64;               // 38 chunks a row, 19 transfers a plane
+    static_assert(32 * NCH % 64 == 0, "whole transfers");
+#pragma unroll
+    for (int j0 = 0; j0 < 2 * NTR; j0 += 4) {
+      const int j = j0 + wave;
+      if (j < 2 * NTR) {                                              // (wave-uniform)
+        const int pl = j >= NTR ? 1 : 0, jj = j - pl * NTR;
+        const int sl = 64 * jj + lane, rr = sl / NCH, c = sl - rr * NCH;
+        const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wh + (size_t)pl * p.plane_wh + (size_t)nr * HK2_K + 8 * c),
+                                         (__attribute__((address_space(3))) void*)(Bs + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
+      }
+    }
+  }
+  // (every loaded value named -- AFTER the transfers' requests -- before anything is done with it: a load whose value feeds a select the compiler otherwise sinks into a
+  //  branch of its own, with a wait behind it -- five memory round trips in a row at the start of every workgroup)
+#pragma unroll
+  for (int tt = 0; tt < MAXT; ++tt) {
+#pragma unroll
+    for (int lg = 0; lg < NLG; ++lg) asm volatile("" : "+v"(w0t[tt][lg]));
+    asm volatile("" : "+v"(bz4[tt]));
+  }
+#pragma unroll
+  for (int tt = 0; tt < MAXT; ++tt) {
+    const int tcol = wave + 4 * tt, tc = tcol < ntile ? tcol : 0;
+    const bool klive = 16 * tc + r < p.K0;
+#pragma unroll
+    for (int lg = 0; lg < NLG; ++lg) w0t[tt][lg] = (4 * lg + g < p.n_labels && klive) ? w0t[tt][lg] : 0.f;
+  }
+  HK_STAMP(1);
+  float xa[2][NLG];
+#pragma unroll
+  for (int lg = 0; lg < NLG; ++lg) {
+    double xm = p.xmin[4 * lg < PAYNE_MAX_LABELS ? 4 * lg : 0], xdn = p.xden[4 * lg < PAYNE_MAX_LABELS ? 4 * lg : 0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) {
+      if (4 * lg + e < PAYNE_MAX_LABELS) { xm = (g == e) ? p.xmin[4 * lg + e] : xm; xdn = (g == e) ? p.xden[4 * lg + e] : xdn; }
+    }
+    const bool dl = 4 * lg + g < p.n_labels;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      xa[i][lg] = (dl && m0 + 16 * i + r < p.B) ? (float)((xl[i][lg] - xm) / xdn - 0.5) : 0.f;
+  }
+  HK_STAMP(2);
+  // first layer, activation, split: two dwords a plane for every (unit block, candidate block) of this wave
+  unsigned pk[MAXT][2][2][2];                                           // [block][candidate block][plane][dword]
+  const float s0 = p.a0_scale;
+  auto first_layer = [&](auto actf) {
+#pragma unroll
+    for (int tt = 0; tt < MAXT; ++tt) {
+      const int tcol = wave + 4 * tt;
+      if (tcol < ntile) {                                             // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x4_t z = bz4[tt];
+#pragma unroll
+          for (int lg = 0; lg < NLG; ++lg) z = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[tt][lg], xa[i][lg], z, 0, 0, 0);
+          float yv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yv[q] = ((16 * tcol + 4 * g + q) < p.K0) ? actf(z[q]) : 0.f;
+          split2h_pair(yv[0], yv[1], s0, pk[tt][i][0][0], pk[tt][i][1][0]);
+          split2h_pair(yv[2], yv[3], s0, pk[tt][i][0][1], pk[tt][i][1][1]);
+        }
+      }
+    }
+  };
+  if (p.act0 == PAYNE_ACT_LRELU) first_layer([](float z) { return lrelu01(z); });
+  else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer([](float z) { return 1.0f / (1.0f + expf(-z)); });
+  else first_layer([](float z) { return z; });
+  HK_STAMP(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my pieces of the weight planes have landed
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int tt = 0; tt < MAXT; ++tt) {
+    const int tcol = wave + 4 * tt;
+    if (tcol < ntile) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          *reinterpret_cast<u32x2_t*>(As + pl * HK2_PLANE + (16 * i + r) * HK2_PB + (16 * tcol + 4 * g) * 2) = u32x2_t{pk[tt][i][pl][0], pk[tt][i][pl][1]};
+    }
+  }
+  __syncthreads();
+  HK_STAMP(3);
+  // ---- the wave's quadrant: nine 32-deep steps and one 16-deep, three products each, smallest first ---------------------------
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const unsigned char* ar = As + (16 * qi + r) * HK2_PB + 16 * g;
+  const unsigned char* br = Bs + (16 * qj + r) * HK2_PB + 16 * g;
+  constexpr int NS32 = HK2_K / 32;                                     // 9
+  f16x8_t fa[NS32][2], fb[NS32][2];
+#pragma unroll
+  for (int sx = 0; sx < NS32; ++sx)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      fa[sx][pl] = *reinterpret_cast<const f16x8_t*>(ar + pl * HK2_PLANE + 64 * sx);
+      fb[sx][pl] = *reinterpret_cast<const f16x8_t*>(br + pl * HK2_PLANE + 64 * sx);
+    }
+  // the tenth step holds k = 288 .. 303 only: lanes g = 0, 1 read their chunks, lanes g = 2, 3 (k = 304 .. 319: past the row) hold zeros
+  // (the 16-deep v_mfma_f32_16x16x16f16 in its place gave wrong accumulator halves now and then: read before its last pass had landed)
+  f16x8_t ta[2], tb[2];
+  {
+    const int gc = g < 2 ? g : 0;
+    const f16x8_t zero8 = (f16x8_t)(_Float16)0;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const f16x8_t va = *reinterpret_cast<const f16x8_t*>(As + pl * HK2_PLANE + (16 * qi + r) * HK2_PB + 64 * NS32 + 16 * gc);
+      const f16x8_t vb = *reinterpret_cast<const f16x8_t*>(Bs + pl * HK2_PLANE + (16 * qj + r) * HK2_PB + 64 * NS32 + 16 * gc);
+      ta[pl] = g < 2 ? va : zero8; tb[pl] = g < 2 ? vb : zero8;
+    }
+  }
+#pragma unroll
+  for (int sx = 0; sx < NS32; ++sx) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][1], fb[sx][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][0], fb[sx][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][0], fb[sx][0], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1], tb[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[0], acc, 0, 0, 0);
+  HK_STAMP(4);
+  {
+    float y[4];
+    const float bsh = bias1 - p.bias_shift;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[q] = act_apply(__builtin_fmaf(acc[q], rs1, bsh), p.act);
+    hk_store_quadrant(p, y, m0, n0, qi, qj, r, g);
+  }
+  HK_STAMP(5);
+}
+
 // One 32 x 32 tile of a hidden layer by the first 256 threads of the workgroup (`tile`: index in the launch's grid_m x grid_n).
 template <bool FUSE_L0, int NL>
 __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, const int tid) {
@@ -1659,74 +1926,12 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
   if (p.K <= HK_KC) chunk(0);
   else for (int kc = 0; kc < p.K; kc += HK_KC) chunk(kc);
   HK_STAMP(4);
-  // ---- epilogue straight from the accumulators (C/D map: column r, rows 4 g + q of the quadrant) ----------------------
-  // Neighbouring lanes hold neighbouring columns: lane pairs swap half of their rows (DPP), so that every lane ends up with two
-  // adjacent columns of two rows -- 8-byte stores of the fp32 tile, 4-byte stores of each bf16 plane, as before, without LDS.
+  // ---- epilogue straight from the accumulators (hk_store_quadrant) ---------------------------------------------------------
   {
     float y[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) y[q] = act_apply((acc[0][q] + acc[1][q]) + (bias1 - p.bias_shift), p.act);
-    const bool pairs_ok = ((p.ldy | n0) & 1) == 0 && (!p.Yp || (p.ldp & 1) == 0);
-    const int colq = n0 + 16 * qj + r, row0 = m0 + 16 * qi + 4 * g;
-    if (pairs_ok) {
-      const bool oddl = (r & 1) != 0;
-      // even lane keeps rows 0, 1 and gets the odd lane's; odd lane keeps rows 2, 3 and gets the even lane's
-      const float s0 = oddl ? y[0] : y[2], s1 = oddl ? y[1] : y[3];
-      const float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
-      float pa_[2], pb_[2];                                          // (column, column + 1) of the lane's two rows
-      pa_[0] = oddl ? t0 : y[0]; pb_[0] = oddl ? y[2] : t0;
-      pa_[1] = oddl ? t1 : y[1]; pb_[1] = oddl ? y[3] : t1;
-      const int col = colq & ~1;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int row = row0 + (oddl ? 2 : 0) + e;
-        if (row < p.B && col < p.N) {
-          const bool two = col + 1 < p.N;
-          if (!p.Yp) {
-            float* yo = &p.Y[(size_t)row * p.ldy + col];
-            if (two) *reinterpret_cast<float2*>(yo) = make_float2(pa_[e], pb_[e]); else yo[0] = pa_[e];
-          } else if (p.yp_half) {                                    // two fp16 parts for payne_dense_dma2h_kernel
-            unsigned short h2a[2], h2b[2];
-            split2h(pa_[e], p.yp_scale, h2a[0], h2b[0]);
-            split2h(pb_[e], p.yp_scale, h2a[1], h2b[1]);
-            const size_t o = (size_t)row * p.ldp + col;
-            if (two) {
-              __builtin_nontemporal_store((unsigned)h2a[0] | ((unsigned)h2a[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
-              __builtin_nontemporal_store((unsigned)h2b[0] | ((unsigned)h2b[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
-            } else { p.Yp[o] = h2a[0]; p.Yp[p.plane_y + o] = h2b[0]; }
-          } else {                                                   // three bf16 parts for payne_dense_dma3_kernel (its only reader)
-            unsigned short h3[2], m3[2], l3[2];
-            split3(pa_[e], h3[0], m3[0], l3[0]);
-            split3(pb_[e], h3[1], m3[1], l3[1]);
-            const size_t o = (size_t)row * p.ldp + col;
-            if (two) {                                               // (streamed: the next reader is another XCD)
-              __builtin_nontemporal_store((unsigned)h3[0] | ((unsigned)h3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[o]));
-              __builtin_nontemporal_store((unsigned)m3[0] | ((unsigned)m3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[p.plane_y + o]));
-              __builtin_nontemporal_store((unsigned)l3[0] | ((unsigned)l3[1] << 16), reinterpret_cast<unsigned*>(&p.Yp[2 * p.plane_y + o]));
-            } else { p.Yp[o] = h3[0]; p.Yp[p.plane_y + o] = m3[0]; p.Yp[2 * p.plane_y + o] = l3[0]; }
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = row0 + q;
-        if (row < p.B && colq < p.N) {
-          if (!p.Yp) p.Y[(size_t)row * p.ldy + colq] = y[q];
-          else if (p.yp_half) {
-            unsigned short ha, hb;
-            split2h(y[q], p.yp_scale, ha, hb);
-            const size_t o = (size_t)row * p.ldp + colq;
-            p.Yp[o] = ha; p.Yp[p.plane_y + o] = hb;
-          } else {
-            unsigned short h3, m3, l3;
-            split3(y[q], h3, m3, l3);
-            const size_t o = (size_t)row * p.ldp + colq;
-            p.Yp[o] = h3; p.Yp[p.plane_y + o] = m3; p.Yp[2 * p.plane_y + o] = l3;
-          }
-        }
-      }
-    }
+    hk_store_quadrant(p, y, m0, n0, qi, qj, r, g);
   }
   HK_STAMP(5);
 }
@@ -1745,7 +1950,8 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
   p.B = lead_B; p.N = lead_N; p.K = (int)(lead_i4 & 0xffffu); p.bias = lead_bias;
   if constexpr (FUSE_L0) {
     p.theta = static_cast<const double*>(lead_p0); p.W0 = lead_p1; p.b0 = lead_p2;
-    p.ld_theta = (int)(lead_i2 & 0xffffu); p.n_labels = (int)(lead_i2 >> 16); p.K0 = (int)(lead_i4 >> 16);
+    p.ld_theta = (int)(lead_i2 & 0xffffu); p.n_labels = (int)((lead_i2 >> 16) & 0xffu); p.K0 = (int)(lead_i4 >> 16);
+    p.h2_tiles = (int)(lead_i2 >> 31);                     // (the second layer on fp16 pairs: hk_tile_h2)
   } else {
     p.X = static_cast<const float*>(lead_p0); p.Wd = lead_p1;
     p.ldx = (int)(lead_i2 & 0xffffu); p.ldwd = (int)(lead_i2 >> 16);
@@ -1783,6 +1989,9 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
 #ifdef PAYNE_STAMPS
   if (p.stamps) p.stamps -= (size_t)front * 16;                    // (diagnostic build: row = GEMM tile)
 #endif
+  if constexpr (FUSE_L0) {
+    if (p.h2_tiles) { hk_tile_h2<NL>(p, bx - front, hk_sm, (int)threadIdx.x); return; }     // (uniform)
+  }
   hk_tile<FUSE_L0, NL>(p, bx - front, hk_sm, (int)threadIdx.x);
 }
 

@@ -83,6 +83,8 @@ struct payne_ctx {
   // 2^-e[n] / act_scale; act_scale: the power of two the last hidden layer is written with (calibrated on the label box; 0 = not available)
   unsigned short* w_out_h2 = nullptr; unsigned short* w_out_h2z = nullptr; const float* rscale = nullptr; const float* rscalez = nullptr;
   float act_scale = 0.f;
+  // the second layer on fp16 pairs (hk_tile_h2): its weights as two fp16 planes [2][n_out][304], rows scaled; rs1 = 2^-e / a0_scale
+  unsigned short* w1_h2 = nullptr; const float* rs1 = nullptr; float a0_scale = 0.f; int w1_rows = 0;
   // freq_rs: the restated layer is that of the RESAMPLED spectrum (model grids that are not a power of two long: n1 rows of n1
   // values); a batch with a candidate that does not rotate falls back to pixels ON THE DEVICE (rot_flag: a word the records'
   // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
@@ -292,7 +294,7 @@ static hipError_t set_dense_attributes();
 // The largest |activation| of the last hidden layer over the label box (corners, centre, 512 points of a fixed sequence, 20 % beyond
 // the box on every side), evaluated on the host in fp64 from the layers as the context holds them.  0 when the net has no hidden
 // layer or produces something that is not finite.
-static double hidden_amax(const payne_model_desc* m, std::string& why) {
+static double hidden_amax(const payne_model_desc* m, std::string& why, double* first = nullptr) {      // (*first: the same for the FIRST layer's output)
   const int nl = m->n_layers, D = m->n_labels;
   if (nl < 3) { why = "no hidden layer pair"; return 0.0; }
   std::vector<std::vector<float>> W(nl - 1), b(nl - 1);
@@ -326,6 +328,7 @@ static double hidden_amax(const payne_model_desc* m, std::string& why) {
         y[o] = act(z, L.act);
       }
       a.swap(y);
+      if (l == 0 && first) for (double v : a) { if (std::isfinite(v)) *first = std::max(*first, std::fabs(v)); else *first = 1e300; }
     }
     for (double v : a) { if (!std::isfinite(v)) { why = "non-finite activation"; return 0.0; } amax = std::max(amax, std::fabs(v)); }
   }
@@ -438,7 +441,24 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("weight split: ") + hipGetErrorString(he)));
         // ... and as two fp16 planes, the activations' scale calibrated on the label box (a factor of 8 to spare below fp16's range)
         std::string why;
-        const double amax = hidden_amax(model, why);
+        double amax0 = 0.0;
+        const double amax = hidden_amax(model, why, &amax0);
+        // the second layer's weights for hk_tile_h2: widths whose padded K is the tile's 304 columns
+        const payne_layer& L1 = model->layers[1];
+        if (amax0 > 0.0 && amax0 < 1e30 && L1.n_in > 288 && L1.n_in <= 304 && c->w_hid_pad[1] && !(opts->variant & PAYNE_V_HID_F32)) {
+          c->a0_scale = (float)std::ldexp(1.0, std::max(-60, std::min(60, (int)std::floor(std::log2(4096.0 / amax0)))));
+          std::vector<float> h1((size_t)L1.n_out * L1.n_in), hp((size_t)L1.n_out * 304, 0.f);
+          he = hipMemcpy(h1.data(), L1.w, h1.size() * 4, hipMemcpyDeviceToHost);
+          if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(second layer): ") + hipGetErrorString(he)));
+          for (int i = 0; i < L1.n_out; ++i) std::copy(h1.begin() + (size_t)i * L1.n_in, h1.begin() + (size_t)(i + 1) * L1.n_in, hp.begin() + (size_t)i * 304);
+          const float* d_hp = nullptr;
+          std::vector<void*> tmp1;
+          if ((rc = upload(c, hp, &d_hp, tmp1))) return bail(rc);
+          rc = make_h2_planes(c, d_hp, hp, L1.n_out, 304, c->a0_scale, &c->w1_h2, &c->rs1);
+          for (void* q : tmp1) (void)hipFree(q);
+          if (rc) return bail(rc);
+          c->w1_rows = L1.n_out;
+        }
         if (amax > 0.0 && amax < 1e30) {
           c->act_scale = (float)std::ldexp(1.0, std::max(-60, std::min(60, (int)std::floor(std::log2(4096.0 / amax)))));
           std::vector<float> hw(nw);
@@ -914,7 +934,7 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   // the kernel's leading scalar parameters (preloaded into registers at wave start; two 16-bit values a dword)
   p.dma_tiles = (FUSE && p.Wd != nullptr) ? 1 : 0;
   const unsigned i0 = (unsigned)pa.n_spec | ((unsigned)pa.n_prep << 16) | ((unsigned)p.dma_tiles << 31), i1 = (unsigned)pa.n_gemm | ((unsigned)p.grid_n << 16);
-  const unsigned i2 = FUSE ? ((unsigned)p.ld_theta | ((unsigned)p.n_labels << 16)) : ((unsigned)p.ldx | ((unsigned)p.ldwd << 16));
+  const unsigned i2 = FUSE ? ((unsigned)p.ld_theta | ((unsigned)p.n_labels << 16) | ((unsigned)(p.h2_tiles ? 1 : 0) << 31)) : ((unsigned)p.ldx | ((unsigned)p.ldwd << 16));
   const unsigned i4 = (unsigned)p.K | ((unsigned)(FUSE ? p.K0 : 0) << 16);
   const void* p0 = FUSE ? static_cast<const void*>(p.theta) : static_cast<const void*>(p.X);
   const float* p1 = FUSE ? p.W0 : p.Wd;
@@ -973,6 +993,9 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         pa.spec_step = c->spec_step; c->spec_launched = true;
       }
       if (!last && N.spectral && c->w_hid_pad[1] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[1]; p.ldwd = N.ld_hid; }
+      if (!last && N.spectral && p.Wd && c->w1_h2 && c->w1_rows == p.N && p.K <= 304) {       // the second layer on fp16 pairs
+        p.h2_tiles = 1; p.Wh = c->w1_h2; p.plane_wh = (size_t)c->w1_rows * 304; p.rs1 = c->rs1; p.a0_scale = c->a0_scale;
+      }
       if (!last && !hk_lead_fits(p.B, p.N, p.K, p.K0, 0, p.ldwd, p.ld_theta, spec ? c->spec_K : 0))
         return fail(c, PAYNE_E_UNSUPPORTED, "batch x hidden width beyond what the hidden-layer kernel's packed arguments hold (65 535 tiles of 32 x 32)");
       if (last) launch_dense<64, 64, 32, true>(p, s);
