@@ -1458,6 +1458,54 @@ __device__ __forceinline__ void hk_store_quadrant(const DenseParams& p, const fl
 // ----------------------------------------------------------------------------
 constexpr int HK2_PB = 608, HK2_PLANE = 32 * HK2_PB, HK2_K = 304;
 static_assert(4 * HK2_PLANE <= (int)HK_LDS_BYTES, "four planes in the hidden-layer launch's LDS");
+// The matrix phase and the epilogue of a tile whose operands sit in LDS as fp16 planes (hk_tile_h2, hk_tile_h2x): the wave's 16 x 16
+// quadrant over ten 32-deep steps (the tenth holds k = 288 .. 303 only), three products each, smallest first.
+__device__ __forceinline__ void hk_h2_quadrant(const DenseParams& p, const unsigned char* As, const unsigned char* Bs, float bias1, float rs1,
+                                               int m0, int n0, int qi, int qj, int r, int g) {
+  // ---- the wave's quadrant: nine 32-deep steps and one 16-deep, three products each, smallest first ---------------------------
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const unsigned char* ar = As + (16 * qi + r) * HK2_PB + 16 * g;
+  const unsigned char* br = Bs + (16 * qj + r) * HK2_PB + 16 * g;
+  constexpr int NS32 = HK2_K / 32;                                     // 9
+  f16x8_t fa[NS32][2], fb[NS32][2];
+#pragma unroll
+  for (int sx = 0; sx < NS32; ++sx)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      fa[sx][pl] = *reinterpret_cast<const f16x8_t*>(ar + pl * HK2_PLANE + 64 * sx);
+      fb[sx][pl] = *reinterpret_cast<const f16x8_t*>(br + pl * HK2_PLANE + 64 * sx);
+    }
+  // the tenth step holds k = 288 .. 303 only: lanes g = 0, 1 read their chunks, lanes g = 2, 3 (k = 304 .. 319: past the row) hold zeros
+  // (the 16-deep v_mfma_f32_16x16x16f16 in its place gave wrong accumulator halves now and then: read before its last pass had landed)
+  f16x8_t ta[2], tb[2];
+  {
+    const int gc = g < 2 ? g : 0;
+    const f16x8_t zero8 = (f16x8_t)(_Float16)0;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const f16x8_t va = *reinterpret_cast<const f16x8_t*>(As + pl * HK2_PLANE + (16 * qi + r) * HK2_PB + 64 * NS32 + 16 * gc);
+      const f16x8_t vb = *reinterpret_cast<const f16x8_t*>(Bs + pl * HK2_PLANE + (16 * qj + r) * HK2_PB + 64 * NS32 + 16 * gc);
+      ta[pl] = g < 2 ? va : zero8; tb[pl] = g < 2 ? vb : zero8;
+    }
+  }
+#pragma unroll
+  for (int sx = 0; sx < NS32; ++sx) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][1], fb[sx][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][0], fb[sx][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][0], fb[sx][0], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1], tb[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[0], acc, 0, 0, 0);
+  {
+    float y[4];
+    const float bsh = bias1 - p.bias_shift;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[q] = act_apply(__builtin_fmaf(acc[q], rs1, bsh), p.act);
+    hk_store_quadrant(p, y, m0, n0, qi, qj, r, g);
+  }
+}
+
 template <int NL>
 __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_sm, const int tid) {
   HK_STAMP(0);
@@ -1586,49 +1634,48 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   }
   __syncthreads();
   HK_STAMP(3);
-  // ---- the wave's quadrant: nine 32-deep steps and one 16-deep, three products each, smallest first ---------------------------
-  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const unsigned char* ar = As + (16 * qi + r) * HK2_PB + 16 * g;
-  const unsigned char* br = Bs + (16 * qj + r) * HK2_PB + 16 * g;
-  constexpr int NS32 = HK2_K / 32;                                     // 9
-  f16x8_t fa[NS32][2], fb[NS32][2];
-#pragma unroll
-  for (int sx = 0; sx < NS32; ++sx)
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      fa[sx][pl] = *reinterpret_cast<const f16x8_t*>(ar + pl * HK2_PLANE + 64 * sx);
-      fb[sx][pl] = *reinterpret_cast<const f16x8_t*>(br + pl * HK2_PLANE + 64 * sx);
-    }
-  // the tenth step holds k = 288 .. 303 only: lanes g = 0, 1 read their chunks, lanes g = 2, 3 (k = 304 .. 319: past the row) hold zeros
-  // (the 16-deep v_mfma_f32_16x16x16f16 in its place gave wrong accumulator halves now and then: read before its last pass had landed)
-  f16x8_t ta[2], tb[2];
+  hk_h2_quadrant(p, As, Bs, bias1, rs1, m0, n0, qi, qj, r, g);
+  HK_STAMP(5);
+}
+
+// hk_tile_h2x: a hidden layer past the second on fp16 pairs -- both operand tiles are planes in memory (the activations written so
+// by the launch before: Xp, pitch 304; the weights split at payne_ctx_create): 76 transfers of 1 KB, the matrix phase, the epilogue.
+__device__ __forceinline__ void hk_tile_h2x(DenseParams& p, int tile, float* hk_sm, const int tid) {
+  HK_STAMP(0);
+  unsigned char* As = reinterpret_cast<unsigned char*>(hk_sm);
+  unsigned char* Bs = As + 2 * HK2_PLANE;
+  const int tm = tile / p.grid_n, tn = tile - tm * p.grid_n;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int qi = wave >> 1, qj = wave & 1;
+  float bias1, rs1;
   {
-    const int gc = g < 2 ? g : 0;
-    const f16x8_t zero8 = (f16x8_t)(_Float16)0;
+    const int c0 = n0 + 16 * qj + r, cc = c0 < p.N ? c0 : p.N - 1;
+    bias1 = p.bias[cc]; rs1 = p.rs1[cc];
+  }
+  constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64;                 // 38 chunks a row, 19 transfers a plane
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      const f16x8_t va = *reinterpret_cast<const f16x8_t*>(As + pl * HK2_PLANE + (16 * qi + r) * HK2_PB + 64 * NS32 + 16 * gc);
-      const f16x8_t vb = *reinterpret_cast<const f16x8_t*>(Bs + pl * HK2_PLANE + (16 * qj + r) * HK2_PB + 64 * NS32 + 16 * gc);
-      ta[pl] = g < 2 ? va : zero8; tb[pl] = g < 2 ? vb : zero8;
+  for (int j0 = 0; j0 < 4 * NTR; j0 += 4) {
+    const int j = j0 + wave;                                            // (4 NTR = 76 is a multiple of four: every wave moves nineteen)
+    const int q = j / NTR, jj = j - q * NTR, pl = q & 1;                // q: 0, 1 the weights' planes; 2, 3 the activations'
+    const int sl = 64 * jj + lane, rr = sl / NCH, c = sl - rr * NCH;
+    if (q < 2) {
+      const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wh + (size_t)pl * p.plane_wh + (size_t)nr * HK2_K + 8 * c),
+                                       (__attribute__((address_space(3))) void*)(Bs + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
+    } else {
+      const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Xp + (size_t)pl * p.plane_x + (size_t)mr * HK2_K + 8 * c),
+                                       (__attribute__((address_space(3))) void*)(As + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
     }
   }
-#pragma unroll
-  for (int sx = 0; sx < NS32; ++sx) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][1], fb[sx][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][0], fb[sx][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sx][0], fb[sx][0], acc, 0, 0, 0);
-  }
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1], tb[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[0], acc, 0, 0, 0);
-  HK_STAMP(4);
-  {
-    float y[4];
-    const float bsh = bias1 - p.bias_shift;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) y[q] = act_apply(__builtin_fmaf(acc[q], rs1, bsh), p.act);
-    hk_store_quadrant(p, y, m0, n0, qi, qj, r, g);
-  }
+  HK_STAMP(1);
+  HK_STAMP(2);
+  HK_STAMP(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my pieces have landed (and the bias values are here)
+  __syncthreads();
+  HK_STAMP(3);
+  hk_h2_quadrant(p, As, Bs, bias1, rs1, m0, n0, qi, qj, r, g);
   HK_STAMP(5);
 }
 
@@ -1955,6 +2002,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
   } else {
     p.X = static_cast<const float*>(lead_p0); p.Wd = lead_p1;
     p.ldx = (int)(lead_i2 & 0xffffu); p.ldwd = (int)(lead_i2 >> 16);
+    p.h2_tiles = (int)(lead_i4 >> 31);                     // (both operands as fp16 planes: hk_tile_h2x)
   }
   // Order of the launch's workgroups = order of dispatch: the walk's proposals made ahead (the longest-lived workgroups of the launch:
   // ~1 200 dependent fp64 instructions a wave) first, then the record writers, then the GEMM tiles, then the photometric tiles.
@@ -1991,6 +2039,8 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
 #endif
   if constexpr (FUSE_L0) {
     if (p.h2_tiles) { hk_tile_h2<NL>(p, bx - front, hk_sm, (int)threadIdx.x); return; }     // (uniform)
+  } else {
+    if (p.h2_tiles) { hk_tile_h2x(p, bx - front, hk_sm, (int)threadIdx.x); return; }
   }
   hk_tile<FUSE_L0, NL>(p, bx - front, hk_sm, (int)threadIdx.x);
 }

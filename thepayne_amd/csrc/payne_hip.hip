@@ -85,6 +85,10 @@ struct payne_ctx {
   float act_scale = 0.f;
   // the second layer on fp16 pairs (hk_tile_h2): its weights as two fp16 planes [2][n_out][304], rows scaled; rs1 = 2^-e / a0_scale
   unsigned short* w1_h2 = nullptr; const float* rs1 = nullptr; float a0_scale = 0.f; int w1_rows = 0;
+  // ... and the hidden layers past the second (hk_tile_h2x): layer l's weights as planes, rs = 2^-e / hs[l - 1]; hs[l]: the power of two
+  // layer l's output is written with; hid_h2: the activations between two such layers as planes [2][b_max][304] (two buffers taking turns)
+  unsigned short* wl_h2[PAYNE_MAX_LAYERS] = {}; const float* rsl[PAYNE_MAX_LAYERS] = {}; float hs[PAYNE_MAX_LAYERS] = {};
+  unsigned short* hid_h2[2] = {nullptr, nullptr};
   // freq_rs: the restated layer is that of the RESAMPLED spectrum (model grids that are not a power of two long: n1 rows of n1
   // values); a batch with a candidate that does not rotate falls back to pixels ON THE DEVICE (rot_flag: a word the records'
   // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
@@ -294,7 +298,7 @@ static hipError_t set_dense_attributes();
 // The largest |activation| of the last hidden layer over the label box (corners, centre, 512 points of a fixed sequence, 20 % beyond
 // the box on every side), evaluated on the host in fp64 from the layers as the context holds them.  0 when the net has no hidden
 // layer or produces something that is not finite.
-static double hidden_amax(const payne_model_desc* m, std::string& why, double* first = nullptr) {      // (*first: the same for the FIRST layer's output)
+static double hidden_amax(const payne_model_desc* m, std::string& why, double* per_layer = nullptr) {      // (per_layer[l]: the same for layer l's output, l < n_layers - 1)
   const int nl = m->n_layers, D = m->n_labels;
   if (nl < 3) { why = "no hidden layer pair"; return 0.0; }
   std::vector<std::vector<float>> W(nl - 1), b(nl - 1);
@@ -328,7 +332,7 @@ static double hidden_amax(const payne_model_desc* m, std::string& why, double* f
         y[o] = act(z, L.act);
       }
       a.swap(y);
-      if (l == 0 && first) for (double v : a) { if (std::isfinite(v)) *first = std::max(*first, std::fabs(v)); else *first = 1e300; }
+      if (per_layer) for (double v : a) { if (std::isfinite(v)) per_layer[l] = std::max(per_layer[l], std::fabs(v)); else per_layer[l] = 1e300; }
     }
     for (double v : a) { if (!std::isfinite(v)) { why = "non-finite activation"; return 0.0; } amax = std::max(amax, std::fabs(v)); }
   }
@@ -441,8 +445,9 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
         if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("weight split: ") + hipGetErrorString(he)));
         // ... and as two fp16 planes, the activations' scale calibrated on the label box (a factor of 8 to spare below fp16's range)
         std::string why;
-        double amax0 = 0.0;
-        const double amax = hidden_amax(model, why, &amax0);
+        double amaxl[PAYNE_MAX_LAYERS] = {};
+        const double amax = hidden_amax(model, why, amaxl);
+        const double amax0 = amaxl[0];
         // the second layer's weights for hk_tile_h2: widths whose padded K is the tile's 304 columns
         const payne_layer& L1 = model->layers[1];
         if (amax0 > 0.0 && amax0 < 1e30 && L1.n_in > 288 && L1.n_in <= 304 && c->w_hid_pad[1] && !(opts->variant & PAYNE_V_HID_F32)) {
@@ -458,6 +463,29 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
           for (void* q : tmp1) (void)hipFree(q);
           if (rc) return bail(rc);
           c->w1_rows = L1.n_out;
+          c->hs[0] = c->a0_scale;
+          // deeper nets (LinNet: five hidden layers): the layers past the second the same way, their activations handed on as planes
+          bool deep = model->n_layers > 3;
+          for (int l = 1; l + 1 < model->n_layers; ++l) deep = deep && amaxl[l] > 0.0 && amaxl[l] < 1e30 && model->layers[l].n_out == L1.n_out;
+          if (deep) {
+            for (int l = 1; l + 1 < model->n_layers; ++l)
+              c->hs[l] = (float)std::ldexp(1.0, std::max(-60, std::min(60, (int)std::floor(std::log2(4096.0 / amaxl[l])))));
+            for (int l = 2; l + 1 < model->n_layers; ++l) {
+              const payne_layer& Ll = model->layers[l];
+              std::vector<float> hl((size_t)Ll.n_out * Ll.n_in), hq((size_t)Ll.n_out * 304, 0.f);
+              he = hipMemcpy(hl.data(), Ll.w, hl.size() * 4, hipMemcpyDeviceToHost);
+              if (he != hipSuccess) return bail(fail(c, PAYNE_E_HIP, std::string("hipMemcpy(hidden layer): ") + hipGetErrorString(he)));
+              for (int i = 0; i < Ll.n_out; ++i) std::copy(hl.begin() + (size_t)i * Ll.n_in, hl.begin() + (size_t)(i + 1) * Ll.n_in, hq.begin() + (size_t)i * 304);
+              const float* d_hq = nullptr;
+              std::vector<void*> tmp2;
+              if ((rc = upload(c, hq, &d_hq, tmp2))) return bail(rc);
+              rc = make_h2_planes(c, d_hq, hq, Ll.n_out, 304, c->hs[l - 1], &c->wl_h2[l], &c->rsl[l]);
+              for (void* q : tmp2) (void)hipFree(q);
+              if (rc) return bail(rc);
+            }
+            for (int q = 0; q < 2; ++q)
+              if ((rc = dev_alloc(c, (size_t)2 * opts->b_max * 304, &c->hid_h2[q], c->owned))) return bail(rc);
+          }
         }
         if (amax > 0.0 && amax < 1e30) {
           c->act_scale = (float)std::ldexp(1.0, std::max(-60, std::min(60, (int)std::floor(std::log2(4096.0 / amax)))));
@@ -935,7 +963,7 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   p.dma_tiles = (FUSE && p.Wd != nullptr) ? 1 : 0;
   const unsigned i0 = (unsigned)pa.n_spec | ((unsigned)pa.n_prep << 16) | ((unsigned)p.dma_tiles << 31), i1 = (unsigned)pa.n_gemm | ((unsigned)p.grid_n << 16);
   const unsigned i2 = FUSE ? ((unsigned)p.ld_theta | ((unsigned)p.n_labels << 16) | ((unsigned)(p.h2_tiles ? 1 : 0) << 31)) : ((unsigned)p.ldx | ((unsigned)p.ldwd << 16));
-  const unsigned i4 = (unsigned)p.K | ((unsigned)(FUSE ? p.K0 : 0) << 16);
+  const unsigned i4 = (unsigned)p.K | ((unsigned)(FUSE ? p.K0 : 0) << 16) | ((!FUSE && p.h2_tiles) ? 0x80000000u : 0u);
   const void* p0 = FUSE ? static_cast<const void*>(p.theta) : static_cast<const void*>(p.X);
   const float* p1 = FUSE ? p.W0 : p.Wd;
   if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
@@ -972,6 +1000,11 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       p.Yp = c->hid_p3; p.plane_y = (size_t)c->opts.b_max * c->ld_hid; p.ldp = c->ld_hid;
       if (use2h) { p.yp_half = 1; p.yp_scale = c->act_scale; }
     }
+    // hidden layers past the second on fp16 pairs (hk_tile_h2x): layer l hands its activations to layer l + 1 as planes
+    const bool chain = N.spectral && c->hid_h2[0] && c->w1_h2 && c->w1_rows == N.layers[1].n_out;
+    if (chain && !last && l + 1 <= n - 2 && c->wl_h2[l + 1]) {
+      p.Yp = c->hid_h2[(l - 1) & 1]; p.plane_y = (size_t)c->opts.b_max * 304; p.ldp = 304; p.yp_half = 1; p.yp_scale = c->hs[l];
+    }
     ProfScope ps(c, s, last ? 0 : 3);
     if (l == 1) {
       const payne_layer& L0 = N.layers[0];
@@ -1004,6 +1037,10 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
       if (!last && N.spectral && c->w_hid_pad[l] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[l]; p.ldwd = N.ld_hid; }
+      if (chain && !last && c->wl_h2[l]) {                                   // both operands as planes
+        p.h2_tiles = 1; p.Wh = c->wl_h2[l]; p.plane_wh = (size_t)N.layers[l].n_out * 304; p.rs1 = c->rsl[l];
+        p.Xp = c->hid_h2[(l - 2) & 1]; p.plane_x = (size_t)c->opts.b_max * 304;
+      }
       if (!last && !hk_lead_fits(p.B, p.N, p.K, 0, p.ldx, p.ldwd, 0, 0))
         return fail(c, PAYNE_E_UNSUPPORTED, "batch x hidden width beyond what the hidden-layer kernel's packed arguments hold (65 535 tiles of 32 x 32)");
       if (!last) launch_hidden<false>(p, pa, s);
