@@ -440,20 +440,24 @@ def roofline_blocks(cfg_name, res, args):
                                        "packed-fp32 vector peak (= the fp32 MFMA peak, 157.3 TFLOP/s). The MFMA kernel of "
                                        "the step is under `mfma_kernel`.")
         t_out = max(per["dense_out"], 1e-9) * 1e-6
-        split = not (args.variant & (4096 | 1 | 1024))          # the default output layer: six bf16 products per fp32 product
+        split = not (args.variant & (4096 | 1 | 1024))          # the default output layer: products of split operands
         kout = res["engines"][0].kernels_used().get("out", "") if res.get("engines") else ""
-        out["mfma_kernel"] = {"kernel": ((kout or "payne_dense_dma3_kernel") + " (output layer, 3 x bf16 split)") if split else
+        pairs = split and ("2h" in kout or "big3_kernel<true>" in kout)       # two fp16 parts, three products (else three bf16 parts, six)
+        nprod = 3.0 if pairs else 6.0
+        out["mfma_kernel"] = {"kernel": ((kout or "payne_dense_dma3_kernel") + (" (output layer, 2 x fp16 split, 3 products)" if pairs else
+                                                                              " (output layer, 3 x bf16 split, 6 products)")) if split else
                                         "payne_dense_dma_kernel (output layer, fp32 matrix instruction)",
                               "alg_flops_per_launch": flops["dense_out"],
                               "avg_us_per_launch": per["dense_out"],
                               "achieved_tflops": flops["dense_out"] / t_out / 1e12,
                               "frac_of_fp32_peak": flops["dense_out"] / t_out / 1e12 / PEAK_FP32_TFLOPS}
-        if split:                                                # what the matrix pipe executes: 6 bf16 flops per algorithmic flop
-            out["mfma_kernel"].update({"executed_bf16_tflops": 6.0 * flops["dense_out"] / t_out / 1e12,
-                                       "frac_of_bf16_peak": 6.0 * flops["dense_out"] / t_out / 1e12 / PEAK_BF16_TFLOPS,
-                                       "note": "fp32-accurate products as six bf16 partial products: `frac_of_fp32_peak` compares the "
-                                               "algorithmic fp32 work with what the fp32 matrix instruction could do at best, "
-                                               "`frac_of_bf16_peak` the executed bf16 work with the dense bf16 peak (2.5 PFLOP/s)"})
+        if split:                                                # what the matrix pipe executes: `nprod` 16-bit flops per algorithmic flop
+            out["mfma_kernel"].update({"executed_bf16_tflops": nprod * flops["dense_out"] / t_out / 1e12,
+                                       "frac_of_bf16_peak": nprod * flops["dense_out"] / t_out / 1e12 / PEAK_BF16_TFLOPS,
+                                       "note": "fp32-class products as %d exact partial products of 16-bit parts (fp16 pairs: three; bf16 triples: six), fp32 "
+                                               "accumulator: `frac_of_fp32_peak` compares the algorithmic fp32 work with what the fp32 matrix instruction "
+                                               "could do at best, `frac_of_bf16_peak` the executed 16-bit work with the dense fp16 / bf16 peak (2.5 PFLOP/s)"
+                                               % int(nprod)})
     out["kernels_us"] = per
     out["alg_flops_per_eval"] = W["flops_eval"]
     t_k = max(sum(per.values()), 1e-9) * 1e-6
@@ -569,6 +573,8 @@ def final_line(full):
                      **_pick(c, ("batch", "npix", "nobs", "stars", "kernel_variant"))}
     if "parallelism" in c:
         out["config"]["parallelism"] = str(c["parallelism"])[:96]
+    if "products" in c:
+        out["config"]["products"] = str(c["products"])[:64]
     if full.get("n_gpus", 1) > 1 or full.get("collective_backend"):
         out["collective_backend"] = full.get("collective_backend")
         out["rccl_world"] = full.get("rccl_world")
@@ -725,11 +731,13 @@ def main():
         "config": {"workload": workload_text(args.config, d),
                    "batch": B, "npix": d["N"], "nobs": d["nobs"], "stars": 1 if res["shard"] else world,
                    "batches_in_flight": res["S"], "kernel_variant": args.variant,
+                   "products": "fp32 matrix instruction" if args.variant & 4096 else ("3 x bf16 parts, 6 products, fp32 accumulator" if args.variant & 1048576
+                               else "2 x fp16 parts, 3 products, fp32 accumulator"),
                    "arithmetic": "fp32 storage and accumulation throughout (wavelengths, tapers, chi^2 sums, photometric nets fp64); "
-                                 "the output layer's products: " + ("v_mfma_f32_32x32x2_f32" if args.variant & 4096 else
-                                 "operands split exactly in three bf16 parts, six exact partial products, fp32 accumulator "
-                                 "(as accurate as the fp32 fma chain against an fp64 product: tests/test_gpu_parity.py; "
-                                 "--variant 4096 = the fp32 matrix instruction)"),
+                                 "the dense layers' products: " + ("v_mfma_f32_32x32x2_f32" if args.variant & 4096 else
+                                 "operands split in two fp16 parts (power-of-two scales, 21-22 significant bits), three exact partial products, "
+                                 "fp32 accumulator -- as accurate as the fp32 fma chain against an fp64 product (tests/test_gpu_parity.py); "
+                                 "--variant 1048576 = three bf16 parts, six products; 4096 / 2097152 = the fp32 matrix instruction"),
                    "parallelism": ("1 star, every batch split in %d contiguous blocks, one all_gather of lnL per step (RCCL)" % world)
                                   if res["shard"] else "1 star per GPU, no data-path collective"},
         **({"invalid": "--unchecked: a timing experiment, not a benchmark result"} if args.unchecked else {}),
