@@ -587,7 +587,7 @@ def final_line(full):
         out["roofline"].setdefault("traffic", None)
     mk = full.get("mfma_kernel")
     if mk:
-        out["mfma_kernel"] = {"kernel": str(mk.get("kernel", "")).split(" ")[0], **_pick(mk, ("avg_us_per_launch", "achieved_tflops",
+        out["mfma_kernel"] = {"kernel": str(mk.get("kernel", "")).split(" (")[0][:48], **_pick(mk, ("avg_us_per_launch", "achieved_tflops",
                                                                                               "frac_of_fp32_peak", "frac_of_bf16_peak"))}
     if "kernels_us" in full:
         out["kernels_us"] = {k: _r(v, 4) for k, v in full["kernels_us"].items() if v}

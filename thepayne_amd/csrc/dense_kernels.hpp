@@ -1497,6 +1497,7 @@ __device__ __forceinline__ void hk_h2_quadrant(const DenseParams& p, const unsig
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1], tb[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], tb[0], acc, 0, 0, 0);
+  HK_STAMP(4);
   {
     float y[4];
     const float bsh = bias1 - p.bias_shift;
