@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256) payne_split3_kernel(const float* __restri
 // 3e-3; frequency rows 4.5e-8 against 4.2e-8 on 0.135): the accumulator's own roundings dominate both (tests/test_gpu_parity.py
 // compares all forms with an fp64 product).  fp16 has five exponent bits: the weights' planes are scaled ROW BY ROW to |X| < 2^15
 // (payne_ctx_create; a row's scale comes back in the epilogue), the activations by one power of two per context, calibrated at
-// payne_ctx_create on the label box with a factor of 8 to spare (what lies beyond saturates; NaN stays NaN).
+// payne_ctx_create on the label box (corners, centre, 64 points) with a factor of 8 to spare (what lies beyond saturates; NaN stays NaN).
 // ----------------------------------------------------------------------------
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned short f16_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }

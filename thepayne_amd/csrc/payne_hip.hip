@@ -295,7 +295,7 @@ extern "C" void payne_ctx_destroy(payne_ctx* c) {
 
 static hipError_t set_dense_attributes();
 // ---- two fp16 planes an operand (dense_kernels.hpp split2h) -----------------------------------------------------------
-// The largest |activation| of the last hidden layer over the label box (corners, centre, 512 points of a fixed sequence, 20 % beyond
+// The largest |activation| of the last hidden layer over the label box (corners, centre, 64 points of a fixed sequence, 20 % beyond
 // the box on every side), evaluated on the host in fp64 from the layers as the context holds them.  0 when the net has no hidden
 // layer or produces something that is not finite.
 static double hidden_amax(const payne_model_desc* m, std::string& why, double* per_layer = nullptr) {      // (per_layer[l]: the same for layer l's output, l < n_layers - 1)
@@ -313,7 +313,7 @@ static double hidden_amax(const payne_model_desc* m, std::string& why, double* p
   for (int cidx = 0; cidx < (1 << D); ++cidx) { std::vector<double> x(D); for (int d = 0; d < D; ++d) x[d] = ((cidx >> d) & 1) ? 0.6 : -0.6; pts.push_back(x); }
   pts.push_back(std::vector<double>(D, 0.0));
   unsigned long long st = 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < 512; ++i) {
+  for (int i = 0; i < 64; ++i) {
     std::vector<double> x(D);
     for (int d = 0; d < D; ++d) { st = st * 6364136223846793005ull + 1442695040888963407ull; x[d] = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 1.2; }
     pts.push_back(x);
@@ -446,7 +446,9 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
         // ... and as two fp16 planes, the activations' scale calibrated on the label box (a factor of 8 to spare below fp16's range)
         std::string why;
         double amaxl[PAYNE_MAX_LAYERS] = {};
-        const double amax = hidden_amax(model, why, amaxl);
+        const bool want_h2 = (opts->variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES | PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64)) == 0 ||
+                             !(opts->variant & PAYNE_V_HID_F32);
+        const double amax = want_h2 ? hidden_amax(model, why, amaxl) : 0.0;
         const double amax0 = amaxl[0];
         // the second layer's weights for hk_tile_h2: widths whose padded K is the tile's 304 columns
         const payne_layer& L1 = model->layers[1];
@@ -487,7 +489,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
               if ((rc = dev_alloc(c, (size_t)2 * opts->b_max * 304, &c->hid_h2[q], c->owned))) return bail(rc);
           }
         }
-        if (amax > 0.0 && amax < 1e30) {
+        if (amax > 0.0 && amax < 1e30 && !(opts->variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES | PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64))) {
           c->act_scale = (float)std::ldexp(1.0, std::max(-60, std::min(60, (int)std::floor(std::log2(4096.0 / amax)))));
           std::vector<float> hw(nw);
           he = hipMemcpy(hw.data(), wp, nw * 4, hipMemcpyDeviceToHost);
