@@ -643,6 +643,8 @@ def test_c5_at_size(Engine):
     th7 = synth.draw_candidates(B, seed=55)
     th7[:, 6] = np.linspace(0.55, 0.9, B) * cfg["R"]
     th7[7, 6] = 1.2 * raw["resolution"] / 2.355                       # above the ANN's own resolution: NaN by contract
+    th7[2, 5] = 80.0                                                  # rotation whose taper runs past the table (u > 256): the stage with
+    #                                                                   its exact re-evaluation, i.e. the general sequence for this candidate
     rows = [list(theta_full(t)[0, :8]) for t in th7[:3]]
     clean = np.array([O.genspec(raw, r, outwave=obs)[1] for r in rows])
     flux = clean[0] + np.random.default_rng(3).normal(0, 0.01, len(obs))

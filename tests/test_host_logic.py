@@ -259,6 +259,39 @@ def test_likelihood_post_kernels_keep_two_workgroups_per_cu(tmp_path):
     assert pre and int(pre.group(1)) >= 13, pre and pre.group(1)
 
 
+def test_on_chip_stages_of_the_usual_path_never_touch_scratch_memory(tmp_path):
+    """The 65 536-point likelihood kernel calls its convolution stages as functions that use the whole register file.  A function
+    that itself CALLS something (the rotation stage's exact re-evaluation of taper bins beyond the table) keeps its live registers in
+    callee-saved ones and saves / restores those through scratch memory on every call: 63 dwords a thread each way, 258 KB a candidate,
+    a fifth of the bytes a C5 launch moved for two rounds.  The usual path's stages (rotation without the cold call: chip_conv<true,
+    false>; instrumental stage onto the observed grid: chip_conv_obs) must not touch scratch at all; the kernel itself may spill a
+    handful of registers around its calls, not more."""
+    import re
+    import subprocess
+    from thepayne_amd import build
+    asm = tmp_path / "k_post_big.s"
+    cmd = [build._hipcc()] + [f for f in build.HIPCC_FLAGS if f != "-fPIC"] + ["-I", os.path.join(build.ROOT, "include"), "-S", "--cuda-device-only",
+                                                                           os.path.join(build.CSRC, "k_post_big.hip"), "-o", str(asm)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = asm.read_text().splitlines()
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    ops = {}
+    for k, (i, name) in enumerate(starts):
+        end = starts[k + 1][0] if k + 1 < len(starts) else len(lines)
+        ops[name] = sum(1 for l in lines[i:end] if l.startswith("\t") and "scratch_" in l.split(";")[0])
+    rot = [n for n in ops if "chip_convILb1ELb0E" in n]              # chip_conv<true, false>
+    obs = [n for n in ops if "chip_conv_obs" in n]
+    assert len(rot) == 1 and len(obs) == 1, sorted(ops)
+    assert ops[rot[0]] == 0 and ops[obs[0]] <= 2, (ops[rot[0]], ops[obs[0]])
+    far = [n for n in ops if "chip_convILb1ELb1E" in n]              # (the general sequence's rotation stage keeps its call -- and its saves)
+    assert len(far) == 1 and ops[far[0]] > 100
+    kern = [n for n in ops if n.startswith("_Z22payne_post_chip_kernel")]
+    assert len(kern) == 1
+    m = re.search(r"\.name:\s+_Z22payne_post_chip_kernel\w*.*?\.vgpr_spill_count:\s+(\d+)", "\n".join(lines), re.S)
+    assert m and int(m.group(1)) <= 16, m and m.group(1)
+
+
 def test_instruction_census_of_the_post_kernels_phases(tmp_path):
     """tools/valu_census.py (the table behind profiles/rN_c2_valu_census.txt) compiles every phase of the C2 post kernel as a kernel of
     its own and counts the compiler's instructions: the tool still builds against the phase code, every phase is found, and the short

@@ -367,6 +367,11 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const Pos
       // rotation + instrumental smoothing with a 65 536-point window: both stages on the compute unit.  (A pixel row that does
       // not rotate skips the first stage: general sequence.)
       usual = S.do_smooth && S.w_ready && !S.W.bad && S.W.n2 == kChipN1 && (S.do_rot || T.raw_freq);
+      // ... and every bin of the rotation stage inside the taper table (post_onchip.hpp chip_taper_pairs: the stage without its cold call)
+      if (usual && S.do_rot) {
+        const double c64 = (S.vs_a * T.vs_val) * (1.0 / kVsTabStep);
+        usual = (double)(kChipN1 / 2) * c64 < (double)(T.vs_tab_n - 3);          // (false for NaN)
+      }
     }
     if (!usual) {
       __syncthreads();
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(kChipThreads) payne_post_chip_kernel(const Pos
         ta.vs_c = S.do_rot ? S.vs_a * T.vs_val : 0.0;
         ta.vs_c64 = ta.vs_c * (1.0 / kVsTabStep);
         const bool rot = S.do_rot != 0;
-        chip_conv<true>(ex.L, a.raw + (size_t)b * a.ld_raw, bufB, ta, rot, rot && stage != 6 && stage != 7, tid, nullptr, T.raw_freq != 0);
+        chip_conv<true, false>(ex.L, a.raw + (size_t)b * a.ld_raw, bufB, ta, rot, rot && stage != 6 && stage != 7, tid, nullptr, T.raw_freq != 0);
         ex.mark(0);
       }
       // ---- instrumental stage: the candidate's window (mask, Doppler shift, pow-2 log grid) gathered while loading, the result

@@ -294,7 +294,12 @@ __device__ __forceinline__ void chip_taper_send1(const ChipLds& L, const c32 (&u
 }
 // HAVE: the partner's values already sit in registers 16 + r (a row handed over transformed, host_tables.hpp chip_layout:
 // register 16 of thread 0 is Z[M/2])
-template <bool VSINI, bool HAVE = false>
+// FAR: a bin beyond the taper table (u >= 256: |vrot| of several tens of km/s on this grid, or NaN) is re-evaluated exactly by a CALL
+// (taper_far -> vsini_sb_exact).  A call inside a stage function keeps the stage's sixty-odd live registers in callee-saved ones, and
+// the function then saves and restores those through scratch memory on EVERY call (63 dwords a thread each way: 258 KB a candidate,
+// a fifth of the bytes the C5 launch moved) -- the likelihood kernel's usual path checks the candidate's largest bin against the
+// table first and runs the stage without that call (FAR = false); a candidate beyond the table takes the general sequence.
+template <bool VSINI, bool HAVE = false, bool FAR = true>
 __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32], int vt, const TaperArgs& ta) {
   constexpr int M = kChipM;
   const float invM = 1.0f / (float)M, g = 0.25f * invM;
@@ -316,7 +321,8 @@ __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32],
     const int k0 = P.low + 1024 * r;
     const int k = (k0 == 0) ? 1 : k0;                              // (k = 0 is replaced below; keep its lane's arithmetic ordinary)
     float tk, tm;
-    taper_full2<VSINI>(ta, k, M - k, tk, tm);
+    if constexpr (FAR) taper_full2<VSINI>(ta, k, M - k, tk, tm);
+    else { bool far_ = false; taper_at2<VSINI>(ta, k, M - k, far_, tk, tm); }
     const c32 w = chip_w65536(L, k);                               // exp(-2 pi i k / 2M)
     c32 yk, ym;
     c32& ua = u[chip_pos(true, r)];
@@ -327,7 +333,9 @@ __device__ __forceinline__ void chip_taper_pairs(const ChipLds& L, c32 (&u)[32],
     __builtin_amdgcn_sched_barrier(0);                             // one pair (two taper values) at a time
   }
   if (P.t0) {                                                      // the self-conjugate bins (rfft_taper_phase, same statements)
-    const float tM = taper_full<VSINI>(ta, M), th = taper_full<VSINI>(ta, M / 2);
+    float tM, th;
+    if constexpr (FAR) { tM = taper_full<VSINI>(ta, M); th = taper_full<VSINI>(ta, M / 2); }
+    else { bool far_ = false; tM = taper_at<VSINI>(ta, M, far_); th = taper_at<VSINI>(ta, M / 2, far_); }
     const float x0 = z0.x + z0.y, xm = tM * (z0.x - z0.y);
     u[chip_pos(true, 0)] = {0.5f * (x0 + xm) * invM, -0.5f * (x0 - xm) * invM};
     u[chip_pos(true, 16)] = cscale(cconj(zh), th * invM);          // (Y[M/2]: parked in the slot that round 2 skips for thread 0)
@@ -350,12 +358,12 @@ __device__ __forceinline__ void chip_taper_recv2(const ChipLds& L, c32 (&u)[32],
   }
   if (P.t0) u[chip_pos(true, 16)] = yh;
 }
-template <bool VSINI>
+template <bool VSINI, bool FAR = true>
 __device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid, const TaperArgs& ta) {
   const int t1 = tid + 32;                                         // (tid: the first virtual thread's index)
   chip_taper_send1(L, u0, tid); chip_taper_send1(L, u1, t1);
   __syncthreads();
-  chip_taper_pairs<VSINI>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI>(L, u1, t1, ta); chip_pin(u1);
+  chip_taper_pairs<VSINI, false, FAR>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI, false, FAR>(L, u1, t1, ta); chip_pin(u1);
   __syncthreads();
   chip_taper_send2(L, u0, tid); chip_taper_send2(L, u1, t1);
   __syncthreads();
@@ -363,10 +371,10 @@ __device__ __forceinline__ void chip_taper(const ChipLds& L, c32 (&u0)[32], c32 
   __syncthreads();
 }
 // ... of a row that arrived as its transform with every pair side by side: no first round
-template <bool VSINI>
+template <bool VSINI, bool FAR = true>
 __device__ __forceinline__ void chip_taper_have(const ChipLds& L, c32 (&u0)[32], c32 (&u1)[32], int tid, const TaperArgs& ta) {
   const int t1 = tid + 32;
-  chip_taper_pairs<VSINI, true>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI, true>(L, u1, t1, ta); chip_pin(u1);
+  chip_taper_pairs<VSINI, true, FAR>(L, u0, tid, ta); chip_pin(u0); chip_taper_pairs<VSINI, true, FAR>(L, u1, t1, ta); chip_pin(u1);
   chip_taper_send2(L, u0, tid); chip_taper_send2(L, u1, t1);
   __syncthreads();
   chip_taper_recv2(L, u0, tid); chip_pin(u0); chip_taper_recv2(L, u1, t1); chip_pin(u1);
@@ -427,7 +435,7 @@ __device__ __forceinline__ void chip_scrub(c32 (&u)[32]) {
 #pragma unroll
   for (int a = 0; a < 32; a += 4) nan_scrub8(u[a].x, u[a].y, u[a + 1].x, u[a + 1].y, u[a + 2].x, u[a + 2].y, u[a + 3].x, u[a + 3].y);
 }
-template <bool VSINI>
+template <bool VSINI, bool FAR = true>
 __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float* in, float* out, const TaperArgs ta,   // (in == out is allowed)
                                                     bool scrub, bool edge, int tid, const ChipResample* rs, bool zin) {
   typedef float f2g __attribute__((ext_vector_type(2)));
@@ -450,7 +458,7 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
     }
     if (scrub) { chip_scrub(u0); chip_scrub(u1); }
     chip_pin(u0); chip_pin(u1);
-    chip_taper_have<VSINI>(L, u0, u1, vt0, ta);
+    chip_taper_have<VSINI, FAR>(L, u0, u1, vt0, ta);
   } else {
   if (rs) {
     const ChipResample R = *rs;
@@ -469,7 +477,7 @@ __device__ __attribute__((noinline)) void chip_conv(const ChipLds L, const float
   if (scrub && !rs) { chip_scrub(u0); chip_scrub(u1); }
   chip_pin(u0); chip_pin(u1);
   chip_fft_fwd(L, u0, u1, vt0);
-  chip_taper<VSINI>(L, u0, u1, vt0, ta);
+  chip_taper<VSINI, FAR>(L, u0, u1, vt0, ta);
   }
   chip_fft_back(L, u0, u1, vt0);
   chip_pin(u0); chip_pin(u1);
