@@ -571,6 +571,23 @@ __global__ void __launch_bounds__(256) payne_split2h_kernel(const float* __restr
 // as long as its six matrix instructions per wave at KD = 32).  A 1-KiB piece = 1024 / (2 KD) rows of one plane; 16-byte chunk c of
 // tile row r sits at chunk c ^ sw(r), sw = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte rows: the sixteen lanes of
 // every lane group of a fragment read (ds_read_b128) cover sixteen different 16-byte bank groups.
+// The rows' stores: streamed (nt) -- the next reader is the post kernel, on other XCDs.  (PAYNE_EXP_ST: timing twins of other cache
+// policies, tools/exp/store_policy.py: 1 plain, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 nt.)
+__device__ __forceinline__ void d2_store_row(float* q, float v) {
+#if defined(PAYNE_EXP_ST) && PAYNE_EXP_ST == 1
+  *q = v;
+#elif defined(PAYNE_EXP_ST) && PAYNE_EXP_ST == 2
+  asm volatile("global_store_dword %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+#elif defined(PAYNE_EXP_ST) && PAYNE_EXP_ST == 3
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");
+#elif defined(PAYNE_EXP_ST) && PAYNE_EXP_ST == 4
+  asm volatile("global_store_dword %0, %1, off sc1 nt" :: "v"(q), "v"(v) : "memory");
+#elif defined(PAYNE_EXP_ST) && PAYNE_EXP_ST == 5
+  asm volatile("global_store_dword %0, %1, off sc0 nt" :: "v"(q), "v"(v) : "memory");
+#else
+  __builtin_nontemporal_store(v, q);
+#endif
+}
 template <int KD> constexpr int d2_stage() { return 2 * (64 + 128) * 2 * KD; }
 template <int KD> constexpr int d2_ns() { return KD == 64 ? 3 : 4; }
 template <int KD> constexpr size_t d2_lds_bytes() { return (size_t)d2_ns<KD>() * d2_stage<KD>(); }
@@ -720,7 +737,7 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < p.B) __builtin_nontemporal_store(__builtin_fmaf(acc[r], rs, bv), &p.Y[(size_t)row * p.ldy + col]);   // streamed: next read by other XCDs
+        if (row < p.B) d2_store_row(&p.Y[(size_t)row * p.ldy + col], __builtin_fmaf(acc[r], rs, bv));
       }
     } else {
 #pragma unroll
