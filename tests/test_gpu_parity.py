@@ -163,6 +163,37 @@ def test_second_layer_on_fp16_pairs_against_fp64_and_the_fp32_instruction(Engine
     assert rms["f16x2"] <= 1.5 * rms["f32"] + 1e-9, rms
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3])
+def test_calibrated_scales_follow_the_networks_own_magnitudes(Engine, scale):
+    """fp16 has five exponent bits: the pair forms scale every weight row and every layer's activations by powers of two found at
+    payne_ctx_create (the rows' maxima; the activations' maxima over the label box).  The same network with its hidden activations
+    blown up or shrunk -- W1, b1 times `scale`, W2 divided by it: the same function -- must come out as accurately: against fp64, and no
+    worse than the six-product / fp32-instruction forms on the same weights."""
+    from thepayne_amd import _lib
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=1024, lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=3)
+    raw["w_array_1"] = (raw["w_array_1"].astype(np.float64) * scale).astype(np.float32)
+    raw["b_array_1"] = (raw["b_array_1"].astype(np.float64) * scale).astype(np.float32)
+    raw["w_array_2"] = (raw["w_array_2"].astype(np.float64) / scale).astype(np.float32)
+    net = _net(raw)
+    B = 256
+    rng = np.random.default_rng(12)
+    lab = net["xmin"][:4] + rng.uniform(0.0, 1.0, size=(B, 4)) * (net["xmax"][:4] - net["xmin"][:4])
+    th = theta_full(np.column_stack([lab, np.zeros(B), np.zeros(B), np.full(B, 20000.0)]))
+    ref = _fp64_forward(net, lab)
+    err = {}
+    for name, v in (("pairs", 0), ("older", _lib.V_OUT_BF16X3 | _lib.V_HID_F32)):
+        eng = Engine(net, obs=None, b_max=B, variant=v)
+        got = eng.predict_batch(th, stage=0).cpu().numpy().astype(np.float64)
+        used = eng.kernels_used()
+        eng.close()
+        assert ("dma2h" in used["out"]) == (name == "pairs"), used
+        err[name] = np.abs(got - ref)
+    assert err["pairs"].max() <= FLUX_TOL and err["older"].max() <= FLUX_TOL, {k: v.max() for k, v in err.items()}
+    rms = {k: float(np.sqrt(np.mean(v ** 2))) for k, v in err.items()}
+    assert rms["pairs"] <= 1.5 * rms["older"] + 1e-9, rms
+
+
 def test_rows_in_the_frequency_domain_from_fp16_pairs_against_the_six_product_form(Engine, golden):
     """The same comparison where the rows are handed over as their transform (the default at C2: the restated weights have a wide
     range of magnitudes from row to row, which the per-row scales of the fp16 planes absorb): likelihoods and getspec outputs of
