@@ -137,6 +137,9 @@ typedef struct payne_opts {
                                      compute units and nets whose last hidden layer could not be calibrated use) instead of two fp16 parts, three products */
 #define PAYNE_V_HID_F32 2097152u  /* hidden layers: the fp32 matrix instruction for the second layer too (what later layers of deeper nets and
                                      widths other than 289..304 use) instead of products of fp16 pairs */
+#define PAYNE_V_HID_CHAIN 4194304u /* deeper nets: the hidden layers past the second in ONE launch with hand-offs inside a 32-candidate row
+                                      block (agent-scope release / acquire: measured 8 us a hop against 5.7 us a launch -- kept as a tested
+                                      variant, not a default) */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -372,7 +372,17 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
     assert np.all(np.isfinite(ref)) and np.all(np.abs(lnl - ref) <= lnl_tol(ref)), np.abs(lnl - ref).max()
     # which kernels a net of this depth takes: every layer on the matrix cores, the output layer as bf16 products
     names = eng.kernels_used()
-    assert names["hidden"].startswith("payne_dense_hidden_kernel") and names["out"].startswith("payne_dense_dma"), names
+    assert names["out"].startswith("payne_dense_dma"), names
+    assert names["hidden"] == "payne_dense_hidden_kernel<false, 4>", names
+    # LinNet's hidden layers past the second as ONE launch with hand-offs inside a row block (PAYNE_V_HID_CHAIN: measured slower than a
+    # launch per layer, kept as a variant): the same tiles, the same bits, whatever the batches before it were (the hop counters only grow)
+    if kind == "LinNet":
+        e1 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=_lib.V_HID_CHAIN)
+        assert np.array_equal(e1.lnlike_batch(thd).cpu().numpy(), lnl)
+        assert e1.kernels_used()["hidden"] == "payne_dense_chain_kernel"
+        for nrow in (5, 128, 33, 64, 1, 128):
+            assert np.array_equal(e1.lnlike_batch(thd[:nrow]).cpu().numpy(), lnl[:nrow]), nrow
+        e1.close()
     # other shipped forms of the output layer on the same net: same likelihoods
     for v in (1, 4096, 2048):
         e2 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=v)

@@ -2065,6 +2065,77 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
 
 
 
+// ----------------------------------------------------------------------------
+// payne_dense_chain_kernel (PAYNE_V_HID_CHAIN; MEASURED SLOWER than a launch per layer, kept as a tested variant: LinNet's three layers
+// 22.7 us against 3 x 5.7 -- a hop is an agent-scope release, ~6.5 us with a tile's planes freshly dirtied in the XCD's L2, + an acquire,
+// ~1.7 us, as MI355X_MICROARCH.md prices them; 15 us a hop while every thread fenced).
+// The hidden layers past the second of a deeper net (LinNet: three of them) in ONE launch.  A launch of
+// such a layer is 5.7 us of launch and first-touch latency around 0.6 us of matrix instructions; its only cross-workgroup dependency
+// is between the ten 32 x 32 tiles of one 32-candidate row block -- layer l + 1 of a row block needs layer l of the same block, of
+// nothing else.  So: the grid of one layer (row blocks x ten column tiles, every workgroup resident), each workgroup running its
+// tile of layer l (hk_tile_h2x: both operand tiles as fp16 planes straight into LDS), publishing it (planes stored, agent-scope
+// release, one atomic increment of the row block's counter for this hop) and waiting for the block's ten increments before it
+// reads the planes of layer l as the next layer's A operand (acquire).  Counters are never reset: every call adds `grid_n` to every
+// (row block, hop) counter -- row blocks past the batch's end take part with their increments only -- and a call waits for
+// `target0 + grid_n`, target0 = grid_n x (calls before this one).
+// ----------------------------------------------------------------------------
+constexpr int kChainMax = 6;
+struct ChainParams {
+  int n;                                                   // layers in the chain (hops: n - 1)
+  const unsigned short* Wh[kChainMax]; const float* rs[kChainMax]; const float* bias[kChainMax]; int act[kChainMax];
+  float out_scale[kChainMax];                              // the power of two layer i's output planes are written with
+  unsigned short* buf[2]; size_t plane_x;                  // activation planes [2][b_max][304], two buffers taking turns
+  int first_in;                                            // the buffer layer 0 of the chain reads
+  unsigned short* Yp_last; size_t plane_y_last; int ldp_last; int half_last;   // where the last layer writes (the output layer's operand planes)
+  unsigned long long* flags; unsigned long long target0;   // [grid_m_max][kChainMax] counters
+  int B, N, grid_m, grid_m_max, grid_n;
+#ifdef PAYNE_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+__global__ void __launch_bounds__(256, 1) payne_dense_chain_kernel(const ChainParams cp);
+#ifdef PAYNE_TU_DENSE
+__global__ void __launch_bounds__(256, 1) payne_dense_chain_kernel(const ChainParams cp) {
+  extern __shared__ __attribute__((aligned(16))) float hk_sm[];
+  const int tid = (int)threadIdx.x, tile = (int)blockIdx.x;
+  const int tm = tile / cp.grid_n;
+  unsigned long long* const my = cp.flags + (size_t)tm * kChainMax;
+  const bool live = tm < cp.grid_m;                        // (row blocks past the batch: counters only)
+  for (int l = 0; l < cp.n; ++l) {
+    if (l > 0 && live) {
+      if (tid == 0) {
+        const unsigned long long want = cp.target0 + (unsigned long long)cp.grid_n;
+        while (__hip_atomic_load(my + (l - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the compute unit's L1 is one: one wave's invalidate serves the workgroup)
+      }
+      __syncthreads();
+    }
+    if (live) {
+      DenseParams p{};
+      p.B = cp.B; p.N = cp.N; p.grid_m = cp.grid_m; p.grid_n = cp.grid_n;
+      p.bias = cp.bias[l]; p.rs1 = cp.rs[l]; p.act = cp.act[l]; p.bias_shift = 0.f;
+      p.Wh = cp.Wh[l]; p.plane_wh = (size_t)cp.N * HK2_K;
+      p.Xp = cp.buf[(cp.first_in + l) & 1]; p.plane_x = cp.plane_x;
+      if (l + 1 < cp.n) { p.Yp = cp.buf[(cp.first_in + l + 1) & 1]; p.plane_y = cp.plane_x; p.ldp = HK2_K; p.yp_half = 1; }
+      else { p.Yp = cp.Yp_last; p.plane_y = cp.plane_y_last; p.ldp = cp.ldp_last; p.yp_half = cp.half_last; }
+      p.yp_scale = cp.out_scale[l];
+#ifdef PAYNE_STAMPS
+      p.stamps = nullptr;
+#endif
+      hk_tile_h2x(p, tile, hk_sm, tid);
+    }
+    if (l + 1 < cp.n) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores of this layer's planes have left the compute unit ...
+      __syncthreads();                                     // ... everybody's have (and everybody has read its fragments: the next layer's transfers may land)
+      if (tid == 0) {                                      // ONE release for the workgroup (the write-back it implies is the cache's, not a thread's:
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); //  issued by all 256 threads it made a hop 15 us)
+        __hip_atomic_fetch_add(my + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+#endif
+
 // The instantiations that exist (compiled in k_dense.hip; `extern template` elsewhere).
 #ifdef PAYNE_TU_DENSE
 #define PAYNE_DENSE_T template

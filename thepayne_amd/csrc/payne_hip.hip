@@ -89,6 +89,8 @@ struct payne_ctx {
   // layer l's output is written with; hid_h2: the activations between two such layers as planes [2][b_max][304] (two buffers taking turns)
   unsigned short* wl_h2[PAYNE_MAX_LAYERS] = {}; const float* rsl[PAYNE_MAX_LAYERS] = {}; float hs[PAYNE_MAX_LAYERS] = {};
   unsigned short* hid_h2[2] = {nullptr, nullptr};
+  // payne_dense_chain_kernel: the row blocks' hop counters [ceil(b_max / 32)][kChainMax] (never reset) and the calls made so far
+  unsigned long long* chain_flags = nullptr; unsigned long long chain_calls = 0;
   // freq_rs: the restated layer is that of the RESAMPLED spectrum (model grids that are not a power of two long: n1 rows of n1
   // values); a batch with a candidate that does not rotate falls back to pixels ON THE DEVICE (rot_flag: a word the records'
   // writers set to rot_seq, read by the output layer and the post kernel of the same batch; freq_rs_now: this batch was launched so)
@@ -487,6 +489,7 @@ extern "C" int payne_ctx_create(const payne_model_desc* model, const payne_obs_d
             }
             for (int q = 0; q < 2; ++q)
               if ((rc = dev_alloc(c, (size_t)2 * opts->b_max * 304, &c->hid_h2[q], c->owned))) return bail(rc);
+            if ((rc = dev_alloc(c, (size_t)((opts->b_max + 31) / 32) * kChainMax, &c->chain_flags, c->owned))) return bail(rc);
           }
         }
         if (amax > 0.0 && amax < 1e30 && !(opts->variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES | PAYNE_V_OUT_F32 | PAYNE_V_OUT_GENERIC | PAYNE_V_OUT_BK64))) {
@@ -809,6 +812,7 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<5, 64>), d2_lds_bytes<64>());
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel<false>), b3_lds_bytes(false));
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel<true>), b3_lds_bytes(true));
+  set(reinterpret_cast<const void*>(payne_dense_chain_kernel), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
@@ -1035,6 +1039,27 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         return fail(c, PAYNE_E_UNSUPPORTED, "batch x hidden width beyond what the hidden-layer kernel's packed arguments hold (65 535 tiles of 32 x 32)");
       if (last) launch_dense<64, 64, 32, true>(p, s);
       else { launch_hidden<true>(p, pa, s, c->n_cu, spec ? c->spec_K : 0); if (N.spectral) c->prep_valid = pa.out != nullptr; }
+    } else if (!last && chain && use3 && l == 2 && n - 2 >= 3 && c->chain_flags && (c->opts.variant & PAYNE_V_HID_CHAIN) &&
+               ((c->opts.b_max + 31) / 32) * ((N.layers[2].n_out + 31) / 32) <= 2 * c->n_cu && n - 3 <= kChainMax &&
+               [&] { for (int q = 2; q <= n - 2; ++q) if (!c->wl_h2[q]) return false; return true; }()) {
+      // layers 2 .. n - 2 in ONE launch: hand-offs inside a 32-candidate row block (payne_dense_chain_kernel; opt-in: a hop costs more
+      // than a launch on this machine, NOTES R6.10)
+      ChainParams cp{};
+      cp.n = n - 3;
+      for (int q = 2; q <= n - 2; ++q) {
+        const payne_layer& Lq = N.layers[q];
+        cp.Wh[q - 2] = c->wl_h2[q]; cp.rs[q - 2] = c->rsl[q]; cp.bias[q - 2] = Lq.b; cp.act[q - 2] = Lq.act;
+        cp.out_scale[q - 2] = (q == n - 2) ? c->act_scale : c->hs[q];
+      }
+      cp.buf[0] = c->hid_h2[0]; cp.buf[1] = c->hid_h2[1]; cp.plane_x = (size_t)c->opts.b_max * 304;
+      cp.first_in = 0;                                      // (layer 1 wrote hid_h2[0]: run_net above, (l - 1) & 1 at l = 1)
+      cp.Yp_last = c->hid_p3; cp.plane_y_last = (size_t)c->opts.b_max * c->ld_hid; cp.ldp_last = c->ld_hid; cp.half_last = use2h ? 1 : 0;
+      cp.flags = c->chain_flags; cp.grid_n = (N.layers[2].n_out + 31) / 32;
+      cp.target0 = c->chain_calls * (unsigned long long)cp.grid_n;
+      cp.B = B; cp.N = N.layers[2].n_out; cp.grid_m = (B + 31) / 32; cp.grid_m_max = (c->opts.b_max + 31) / 32;
+      ++c->chain_calls;
+      PAYNE_LAUNCH(payne_dense_chain_kernel, dim3(cp.grid_m_max * cp.grid_n), dim3(256), HK_LDS_BYTES, s, cp);
+      l = n - 2;                                            // (the loop goes on with the output layer)
     } else {
       p.X = N.hid[(l - 2) & 1]; p.ldx = N.ld_hid;
       PrepArgs pa{};
