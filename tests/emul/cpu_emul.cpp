@@ -65,6 +65,7 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
   T.obs_f1 = H.has_flux ? H.obs_f1.data() : nullptr;
   T.obs_ivar = H.has_flux ? H.obs_ivar.data() : nullptr;
   T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
+  T.ln_obs_min = std::log(H.obs_min); T.ln_obs_max = std::log(H.obs_max);
   T.npoly = npoly;
   if (force_general == 1 || force_general == 2) { T.geo = 0; T.rot_identity = 0; }    // (3: the four-step transform on the geometric grid)
   // 4: the rows handed over the way the restated output layer writes them (freq_rows): their half transform in pair layout,
@@ -129,4 +130,51 @@ extern "C" int payne_emul_post(const double* wave, int npix, double r_ann, const
     }
   }
   return 0;
+}
+
+
+// prep_candidate's mask counts against the table, candidate by candidate (tests/test_emul_pipeline.py): the counts by arithmetic on
+// geometric grids (and the table path for the few whose position sits within 1e-5 of a pixel boundary) must be THE counts of the
+// brute-force comparison lam[i] (1 + rv/c) <= wl / < wh over every pixel.  Returns the number of mismatches; *n_arith: how many took
+// the arithmetic path (re-derived here: the same test prep_candidate makes).
+extern "C" int payne_emul_prep_counts(const double* wave, int npix, double r_ann, const double* obs_wave, int nobs,
+                                      const double* rv, const double* r_in, int n, double instr_factor, int* n_arith, int* first_bad) {
+  HostTables H;
+  int rc = build_model_tables(wave, npix, H);
+  if (rc) return -1;
+  std::vector<double> of(nobs, 1.0), oe(nobs, 0.01);
+  build_obs_tables(obs_wave, of.data(), oe.data(), nobs, H);
+  PostTables T;
+  std::memset(&T, 0, sizeof(T));
+  fill_model_scalars(H, T);
+  T.nobs = nobs; T.lnlam = H.lnlam.data(); T.lam = H.lam.data();
+  T.obs_min = H.obs_min; T.obs_max = H.obs_max; T.r_ann = r_ann;
+  T.ln_obs_min = std::log(H.obs_min); T.ln_obs_max = std::log(H.obs_max);
+  int bad = 0, arith = 0;
+  if (first_bad) *first_bad = -1;
+  for (int c = 0; c < n; ++c) {
+    double th[12];
+    for (int k = 0; k < 12; ++k) th[k] = 0.0;
+    th[4] = rv[c]; th[5] = 1.0; th[7] = r_in[c];
+    CandState S;
+    std::memset(&S, 0, sizeof(S));
+    prep_candidate(T, th, instr_factor, S);
+    if (!S.win_ready) continue;
+    int below = 0, notabove = 0;
+    for (int i = 0; i < npix; ++i) {
+      const double v = H.lam[i] * S.one_plus;
+      if (!(v > S.wl)) ++below;
+      if (v < S.wh) ++notabove;
+    }
+    if (T.geo) {
+      const double pad = 20.0 / (r_in[c] * instr_factor);
+      const double tl = ((T.ln_obs_min + log1p_series(pad * -1.0)) - S.dop - T.ln0) * T.geo_inv_dln;
+      const double th_ = ((T.ln_obs_max + log1p_series(pad * 1.0)) - S.dop - T.ln0) * T.geo_inv_dln;
+      const double fl = std::floor(tl), fh = std::floor(th_);
+      if ((tl - fl > 1e-5) && (tl - fl < 1.0 - 1e-5) && (th_ - fh > 1e-5) && (th_ - fh < 1.0 - 1e-5)) ++arith;
+    }
+    if (below != S.win_below || notabove != S.win_notabove) { if (!bad && first_bad) *first_bad = c; ++bad; }
+  }
+  if (n_arith) *n_arith = arith;
+  return bad;
 }

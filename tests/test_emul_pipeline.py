@@ -246,3 +246,44 @@ def test_output_layer_restated_for_rows_in_the_frequency_domain(emul, n, layout)
         assert np.abs(Wz[:, col] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
     ref = place(b.astype(np.float64) - 1.0)
     assert np.abs(bz - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_mask_counts_by_arithmetic_are_the_tables_counts():
+    """prep_candidate (the record the hidden-layer launch writes for every candidate) finds the instrumental stage's mask counts on
+    geometric grids by arithmetic -- (ln obs_min + ln(1 - 20/R) - ln(1 + rv/c) - ln lam_0) / dln, two short series, no table value: the
+    dependent memory round trip of the launch's last workgroups is gone -- wherever the position is more than 1e-5 pixel from a
+    boundary, and from the table otherwise.  Both must be THE counts of lam_i (1 + rv/c) <= wl, < wh over every pixel: 60 000 random
+    candidates on two grids, plus sweeps of R and rv fine enough to walk positions across pixel boundaries (the table path's cases)."""
+    import ctypes as C
+    import __graft_entry__ as G
+    lib = C.CDLL(G.build_emul())
+    fn = lib.payne_emul_prep_counts
+    fn.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(11)
+    for cfg_name, nobs in (("C2", 3600), ("small", None)):
+        cfg = synth.CONFIGS[cfg_name]
+        net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=8, seed=0)
+        wave = np.ascontiguousarray(net["wavelength"], dtype=np.float64)
+        obs = np.ascontiguousarray(synth.obs_grid(wave, nobs or cfg["nobs"]), dtype=np.float64)
+        n = 30000
+        rv = np.concatenate([rng.uniform(-700.0, 700.0, n - 6000), np.linspace(9.0, 9.02, 3000), np.zeros(3000)])
+        rin = np.concatenate([rng.uniform(0.4, 0.95, n - 6000) * cfg["R"], np.full(3000, 0.8 * cfg["R"]),
+                              np.linspace(0.5, 0.500004, 3000) * cfg["R"]])
+        # ... and candidates placed ON pixel boundaries: rv chosen so that the lower limit's position is an integer +- a few 1e-8 pixel
+        # (the table decides these; the arithmetic must know that it cannot)
+        lnw = np.log(wave)
+        dln = (lnw[-1] - lnw[0]) / (len(wave) - 1)
+        rs_b = 0.8 * cfg["R"] * 2.355
+        ln_wl = np.log(obs.min()) + np.log1p(-20.0 / rs_b)
+        k0 = int((ln_wl - lnw[0]) / dln)
+        kk = k0 - np.arange(1, 201)
+        dop_b = ln_wl - lnw[0] - kk * dln + rng.uniform(-3e-8, 3e-8, len(kk)) * dln
+        rv_b = 299792.458 * np.expm1(dop_b)
+        rv = np.concatenate([rv[:-200], rv_b]); rin = np.concatenate([rin[:-200], np.full(200, 0.8 * cfg["R"])])
+        rv, rin = np.ascontiguousarray(rv), np.ascontiguousarray(rin)
+        n_arith, first_bad = C.c_int(0), C.c_int(-1)
+        bad = fn(wave.ctypes.data_as(dp), len(wave), C.c_double(float(net["resolution"])), obs.ctypes.data_as(dp), len(obs),
+                 rv.ctypes.data_as(dp), rin.ctypes.data_as(dp), n, C.c_double(2.355), C.byref(n_arith), C.byref(first_bad))
+        assert bad == 0, (cfg_name, bad, first_bad.value, rv[first_bad.value], rin[first_bad.value])
+        assert 0.99 * n < n_arith.value <= n - 150, (cfg_name, n_arith.value)     # (the boundary candidates, and a few others, took the table)

@@ -255,6 +255,7 @@ static int bind_obs(payne_ctx* c, const payne_obs_desc* obs) {
   c->T.nobs = obs->nobs;
   c->T.obs_min = c->H.obs_min;
   c->T.obs_max = c->H.obs_max;
+  c->T.ln_obs_min = std::log(c->H.obs_min); c->T.ln_obs_max = std::log(c->H.obs_max);
   c->T.obs_sorted = 1;
   for (int i = 1; i < obs->nobs; ++i) if (!(obs->wave[i] >= obs->wave[i - 1])) { c->T.obs_sorted = 0; break; }
   c->obs_bound = true;

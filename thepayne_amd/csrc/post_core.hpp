@@ -202,6 +202,7 @@ struct PostTables {
   const float* obs_f1;     // [nobs] obs flux - 1
   const float* obs_ivar;   // [nobs] 1/eflux^2
   double obs_min, obs_max; // min/max of obs wave (mask_wave limits)
+  double ln_obs_min, ln_obs_max;   // their logarithms (host, fp64): prep_candidate's mask counts by arithmetic on geometric grids
   double r_ann;            // sigma-based R of the ANN
   double geo_inv_dln;      // 1/mean(d lnlam)
   int npoly;               // blaze coefficients (0: off)
@@ -1207,6 +1208,16 @@ PAYNE_HD int count_search(const PostTables& T, double op, double lim, int guess)
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (pred(mid)) lo = mid + 1; else hi = mid; }
   return lo;
 }
+// ln(1 + x) for the Doppler factor's x = rv / c by its series, no branch: sixteen terms -- |x| < 0.01 (|rv| < 3000 km/s) to an ulp
+// or two, 1e-17 relative at |x| = 0.1; NaN stays NaN.  (The library logarithm is ~100 dependent fp64 instructions on the critical path
+// of the hidden-layer launch's last workgroups.)
+PAYNE_HD double log1p_series(double x) {
+  double p = -1.0 / 16.0;
+  p = p * x + 1.0 / 15.0; p = p * x - 1.0 / 14.0; p = p * x + 1.0 / 13.0; p = p * x - 1.0 / 12.0; p = p * x + 1.0 / 11.0;
+  p = p * x - 1.0 / 10.0; p = p * x + 1.0 / 9.0; p = p * x - 1.0 / 8.0; p = p * x + 1.0 / 7.0; p = p * x - 1.0 / 6.0;
+  p = p * x + 1.0 / 5.0; p = p * x - 1.0 / 4.0; p = p * x + 1.0 / 3.0; p = p * x - 1.0 / 2.0;
+  return x + (x * x) * p;
+}
 PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr_factor, CandState& S) {
   // the whole row is requested before anything is computed (clamped column for the coefficients past npoly: a guarded
   // load is a branch and a wait of its own, fifteen round trips in a row as first written -- and the two workgroups that
@@ -1223,7 +1234,7 @@ PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr
     for (int i = 0; i < 12; ++i) pc[i] = 0.0;
   }
   S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;       // ystpred.py:228-232
-  S.dop = log(S.one_plus);
+  S.dop = log1p_series(S.one_plus - 1.0);                  // (= log(one_plus): the difference is exact)
   S.do_rot = (vrot != 0.0);                                         // ystpred.py:214 (NaN passes)
   S.vs_a = 2.0 * kPi * sqrt(vrot * vrot - 0.0);                     // smoothing.py:297,614
   const double Rs = r_in * instr_factor;                            // genmod.py:82-85
@@ -1240,6 +1251,27 @@ PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr
     const double pad = 20.0 / Rs;                                   // mask_wave, smoothing.py:631-647
     S.wl = T.obs_min * (1.0 + pad * -1.0);
     S.wh = T.obs_max * (1.0 + pad * 1.0);
+    // Geometric grids (ln lam_i = ln0 + i dln to 1e-12, verified at set-up): the two counts by ARITHMETIC.  lam_i (1 + rv/c) <= wl
+    // <=> i <= (ln wl - dop - ln0) / dln =: t, and ln wl = ln(obs_min) + ln(1 - pad) with the first term the context's and the
+    // second a short series: no logarithm, no table value, i.e. no second memory round trip in the hidden-layer launch's last
+    // workgroups (0.8 us of that launch: the twin PAYNE_EXP_PREP=1).  t is good to ~1e-9 pixel (rounding) + 1e-12 / dln (the grid's
+    // own deviation, < 3e-7 pixel): where its fraction is more than 1e-5 from an integer the count floor(t) + 1 is THE count the
+    // table gives; the rest (one candidate in 50 000) and every other grid take the table as before.
+    bool have = false;
+    if (T.geo) {
+      const double tl = ((T.ln_obs_min + log1p_series(pad * -1.0)) - S.dop - T.ln0) * T.geo_inv_dln;
+      const double th_ = ((T.ln_obs_max + log1p_series(pad * 1.0)) - S.dop - T.ln0) * T.geo_inv_dln;
+      const double fl = floor(tl), fh = floor(th_);
+      const bool safe = (tl - fl > 1e-5) && (tl - fl < 1.0 - 1e-5) && (th_ - fh > 1e-5) && (th_ - fh < 1.0 - 1e-5);   // (false for NaN)
+      if (safe) {
+        const double nn = (double)T.npix;
+        const double cl = fl + 1.0, ch = fh + 1.0;
+        S.win_below = (int)(cl < 0.0 ? 0.0 : (cl > nn ? nn : cl));
+        S.win_notabove = (int)(ch < 0.0 ? 0.0 : (ch > nn ? nn : ch));
+        have = true;
+      }
+    }
+    if (!have) {
     const float op32 = (float)S.one_plus;
     const int g_lo = probe_start(T, op32, S.wl), g_hi = probe_start(T, op32, S.wh);
     // both guesses checked with ONE round trip (four independent loads); a guess that does not bracket its limit
@@ -1249,13 +1281,22 @@ PAYNE_HD void prep_candidate(const PostTables& T, const double* th, double instr
     const bool ina = ga >= 1 && ga < n, inb = gb >= 1 && gb < n;
     const double a0 = T.lam[ina ? ga - 1 : 0] * S.one_plus, a1 = T.lam[ina ? ga : 0] * S.one_plus;
     const double b0 = T.lam[inb ? gb - 1 : 0] * S.one_plus, b1 = T.lam[inb ? gb : 0] * S.one_plus;
+#if defined(PAYNE_EXP_PREP) && (PAYNE_EXP_PREP & 1)      /* timing twin: the guesses taken on trust (no second memory round trip) */
+    const bool oka = ina && a0 == a0 + 0.0 * a1, okb = inb && b0 == b0 + 0.0 * b1;
+#else
     const bool oka = ina && !(a0 > S.wl) && (a1 > S.wl);          // pred true at ga-1, false at ga
     const bool okb = inb && (b0 < S.wh) && !(b1 < S.wh);
+#endif
     S.win_below = oka ? ga : count_search<false>(T, S.one_plus, S.wl, ga);
     S.win_notabove = okb ? gb : count_search<true>(T, S.one_plus, S.wh, gb);
+    }
     S.win_ready = 1;
+#if defined(PAYNE_EXP_PREP) && (PAYNE_EXP_PREP & 2)      /* timing twin: the window left to the post kernel */
+    S.w_ready = 0;
+#else
     W = window_from_counts(T, S.dop, S.g_a, S.win_below, S.win_notabove);
     S.w_ready = 1;
+#endif
   }
   S.W = W;
 }
@@ -1289,7 +1330,7 @@ PAYNE_HD void phase_setup(int tid, int nthr, const PostTables& T, const double* 
   if (tid == 0) {
     const double rv = th[4];
     S.one_plus = (rv != 0.0) ? (1.0 + (rv / kCDoppler)) : 1.0;   // ystpred.py:228-232
-    S.dop = log(S.one_plus);
+    S.dop = log1p_series(S.one_plus - 1.0);                  // (= log(one_plus): the difference is exact)
   }
   if (tid == lanes) {
     const double vrot = th[5];
