@@ -472,6 +472,11 @@ const char* payne_kernel_name(int which);
  * no continuum network, not PAYNE_V_ROWS_PIXEL), "pixels" otherwise.  Test and measurement aid, no reference counterpart. */
 const char* payne_last_kernel(const payne_ctx* ctx, int kind);
 
+/* out[i] = the activation `act` (PAYNE_ACT_*) of z[i], computed by the function the dense layers' epilogues call (device pointers,
+ * n values, enqueued on `stream`).  Test aid, no reference counterpart: the sigmoid of NNmodels.py:92-121 is not the library's
+ * expf + quotient here (dense_kernels.hpp sigmoid_f32), and its accuracy over the whole fp32 range is checked through this. */
+int payne_activation_batch(const float* z, int n, int act, float* out, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around every kernel
  * the batch calls enqueue (measurement aid for bench.py; no reference counterpart).
  * payne_profile(ctx, 1) clears the totals and starts recording, (ctx, 0) stops.

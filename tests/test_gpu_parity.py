@@ -390,6 +390,54 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
         assert np.all(np.abs(l2 - ref) <= lnl_tol(ref)), (v, np.abs(l2 - ref).max())
 
 
+def test_activations_over_the_whole_fp32_range():
+    """The layers' activation functions as their epilogues compute them (payne_activation_batch).  torch.sigmoid of NNmodels.py:92-121 is
+    2^n v_exp_f32(f) and v_rcp_f32 + a Newton step here, not the library's expf and quotient: within 2.5 ulp of the exact value for every
+    finite argument (2.4 measured: the exponential's 1.35, the sum's 0.5, the quotient's 0.5; the library's pair: 2), on average not
+    behind torch's own fp32 sigmoid, 1 and 0 at the infinities, NaN kept; leaky ReLU and none exact."""
+    import torch
+    from thepayne_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    z = np.concatenate([np.linspace(-110.0, 110.0, 1 << 21), rng.normal(0, 1, 1 << 18), rng.normal(0, 12, 1 << 18),
+                        np.ldexp(rng.normal(0, 1, 1 << 16), rng.integers(-140, 120, 1 << 16)),
+                        [0.0, -0.0, 87.9, -87.9, 88.0, -88.0, 88.1, -88.1, 103.9, -103.9, 1e30, -1e30, 3.4e38, -3.4e38, 1e-45, -1e-45,
+                         np.inf, -np.inf, np.nan]]).astype(np.float32)
+    zd = torch.as_tensor(z, device="cuda")
+    out = torch.empty_like(zd)
+
+    def run(act):
+        rc = lib.payne_activation_batch(zd.data_ptr(), len(z), act, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return out.cpu().numpy()
+
+    y = run(_lib.ACT_SIGMOID)
+    z64 = z.astype(np.float64)
+    with np.errstate(over="ignore", invalid="ignore"):
+        ref = 1.0 / (1.0 + np.exp(-z64))
+    fin = np.isfinite(z64)
+    assert np.isnan(y[~fin][-1]) and y[~fin][0] == 1.0 and y[~fin][1] == 0.0, y[~fin]           # +inf, -inf, NaN
+    assert np.all(np.isfinite(y[fin])) and np.all(y[fin] >= 0.0) and np.all(y[fin] <= 1.0)
+    normal = fin & (ref >= 1.2e-38)                        # (below: the exact value is a denormal, ours 0 or a denormal)
+    ulp = np.spacing(ref[normal].astype(np.float32)).astype(np.float64)
+    err = np.abs(y[normal].astype(np.float64) - ref[normal]) / ulp
+    assert err.max() <= 2.5, (err.max(), z[normal][np.argmax(err)])
+    assert np.all(y[fin & ~normal] <= 1.2e-38)
+    # not worse than the pair it replaces (torch's own fp32 sigmoid on the same arguments: the reference's arithmetic)
+    t = torch.sigmoid(zd).cpu().numpy()
+    err_t = np.abs(t[normal].astype(np.float64) - ref[normal]) / ulp
+    assert err.mean() <= err_t.mean() * 1.5 + 0.05, (err.mean(), err_t.mean())
+    # monotone where a step of the sorted block moves the exact value by more than the allowance (z < 5)
+    blk = y[: 1 << 21][z[: 1 << 21] < 5.0]
+    assert np.all(np.diff(blk) >= 0.0)
+    yl = run(_lib.ACT_LRELU)
+    with np.errstate(invalid="ignore", over="ignore"):
+        refl = np.where(z > 0, z, np.float32(0.01) * z).astype(np.float32)
+    assert np.array_equal(yl[fin], refl[fin]) and np.isnan(yl[-1]) and yl[-3] == np.inf and yl[-2] == -np.inf
+    assert np.array_equal(run(_lib.ACT_NONE)[:-1], z[:-1])
+    assert lib.payne_activation_batch(zd.data_ptr(), 4, 7, out.data_ptr(), None) != 0
+
+
 @pytest.mark.parametrize("kind,H,npix,nobs,B", [("LinNet", (50, 37, 96), 1000, 700, 19), ("LinNet", (128, 128, 128), 2048, 1800, 40),
                                                 ("SMLP", (300, 300, 300), 3000, 2500, 33), ("SMLP", (33, 65, 17), 512, 400, 7)])
 def test_torch_nets_of_any_shape_vs_oracle(Engine, kind, H, npix, nobs, B):

@@ -26,7 +26,7 @@ V_HID_F32 = 2097152
 V_HID_CHAIN = 4194304
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_set_lsf_on", "payne_ctx_destroy", "payne_last_error",
-           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name", "payne_last_kernel",
+           "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name", "payne_last_kernel", "payne_activation_batch",
            "payne_profile", "payne_profile_read",
            "payne_sampler_create", "payne_sampler_destroy", "payne_prior_transform_batch", "payne_lnprob_u_batch",
            "payne_rwalk_batch", "payne_rwalk_begin", "payne_rwalk_begin_ell", "payne_rwalk_step", "payne_sampler_counters", "payne_ns_rwalk_queue", "payne_ns_rwalk_queue_begin", "payne_ns_rwalk_queue_end", "payne_ns_rwalk_queue_turn", "payne_ns_consume", "payne_ns_peek", "payne_ns_bound", "payne_format_rows",
@@ -205,6 +205,8 @@ def load(path=None):
     lib.payne_kernel_name.restype = C.c_char_p
     lib.payne_last_kernel.argtypes = [ctxp, C.c_int]
     lib.payne_last_kernel.restype = C.c_char_p
+    lib.payne_activation_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.payne_activation_batch.restype = C.c_int
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     lib.payne_ns_bound.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, ip]
     lib.payne_ns_bound.restype = C.c_int

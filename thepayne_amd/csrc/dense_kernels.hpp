@@ -79,8 +79,24 @@ static unsigned long long* g_dense_stamps = nullptr;
 // an unrolled epilogue then serialises on them (the fused first layer spent 11 500 of 22 500 cycles
 // that way).  leaky ReLU(0.01) = max(z, 0.01 z) for every finite z, 0 and NaN (ystpred.py:57-58).
 __device__ __forceinline__ float lrelu01(float z) { return fmaxf(z, 0.01f * z); }
+// sigmoid(z) = 1 / (1 + exp(-z)) (LinNet, NNmodels.py:92-121) without the library's expf and the IEEE quotient: those are ~35
+// instructions and a chain of exec-mask branches a value, and a lane of the first launch makes forty of them -- 7 000 of the 17 600
+// cycles of a LinNet tile.  exp(t) = 2^n v_exp_f32(f), n = rint(t log2 e), f = t log2 e - n by two fmas (log2 e in two parts: f is good
+// to 2^-25 whatever t), the quotient by v_rcp_f32 + one Newton step.  Within 2.5 ulp of the exact value for every finite z, exactly 1 / 0
+// at +-inf (and past |z| = 88, where the exact value is a denormal), NaN kept.  Ten instructions, no branch.
+__device__ __forceinline__ float sigmoid_f32(float z) {
+  const float t = __builtin_amdgcn_fmed3f(-z, -88.0f, 88.0f);
+  const float n = __builtin_rintf(t * 1.44269502f);
+  float f = __builtin_fmaf(t, 1.44269502f, -n);
+  f = __builtin_fmaf(t, 1.92596299e-8f, f);
+  const float e = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+  const float d = 1.0f + e;
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  return z != z ? z : r;
+}
 __device__ __forceinline__ float act_apply(float z, int act) {
-  if (act == PAYNE_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));          // (uniform: a scalar branch)
+  if (act == PAYNE_ACT_SIGMOID) return sigmoid_f32(z);                     // (uniform: a scalar branch)
   const float l = lrelu01(z);
   return act == PAYNE_ACT_LRELU ? l : z;
 }
@@ -1634,7 +1650,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
     }
   };
   if (p.act0 == PAYNE_ACT_LRELU) first_layer([](float z) { return lrelu01(z); });
-  else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer([](float z) { return 1.0f / (1.0f + expf(-z)); });
+  else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer([](float z) { return sigmoid_f32(z); });
   else first_layer([](float z) { return z; });
   HK_STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my pieces of the weight planes have landed
@@ -1833,7 +1849,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
           }
         };
         if (p.act0 == PAYNE_ACT_LRELU) first_layer_regs([](float z) { return lrelu01(z); });
-        else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer_regs([](float z) { return 1.0f / (1.0f + expf(-z)); });
+        else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer_regs([](float z) { return sigmoid_f32(z); });
         else first_layer_regs([](float z) { return z; });
         HK_STAMP(6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my pieces of the weight tile have landed
@@ -1944,7 +1960,7 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
         }
       };
       if (p.act0 == PAYNE_ACT_LRELU) first_layer([](float z) { return lrelu01(z); });
-      else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer([](float z) { return 1.0f / (1.0f + expf(-z)); });
+      else if (p.act0 == PAYNE_ACT_SIGMOID) first_layer([](float z) { return sigmoid_f32(z); });
       else first_layer([](float z) { return z; });
     } else {
       HK_STAMP(2);

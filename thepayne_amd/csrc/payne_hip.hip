@@ -277,6 +277,16 @@ extern "C" const char* payne_kernel_name(int which) {
   }
 }
 
+__global__ void payne_activation_kernel(const float* __restrict__ z, int n, int act, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = act_apply(z[i], act);
+}
+extern "C" int payne_activation_batch(const float* z, int n, int act, float* out, void* stream) {
+  if (!z || !out || n < 0 || act < PAYNE_ACT_NONE || act > PAYNE_ACT_SIGMOID) return PAYNE_E_INVALID;
+  if (n == 0) return PAYNE_OK;
+  hipLaunchKernelGGL(payne_activation_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, n, act, out);
+  return hipGetLastError() == hipSuccess ? PAYNE_OK : PAYNE_E_HIP;
+}
 extern "C" const char* payne_last_kernel(const payne_ctx* c, int kind) {
   if (c && kind == 4) return c->raw_freq ? "frequency" : "pixels";        // what the output layer handed to the post kernel
   return (c && kind >= 0 && kind < 4) ? c->last_kernel[kind] : "";

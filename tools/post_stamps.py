@@ -32,12 +32,20 @@ def theta_full(theta7):
     return out
 
 
+def _norm(net):
+    return net["_norm"] if "_norm" in net else nnio.normalize_spec_net(net)
+
+
 def problem(cfg_name):
     """Synthetic net + observed spectrum made with the engine itself (a timing tool: no oracle here)."""
-    cfg = synth.CONFIGS[cfg_name]
-    net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
+    cfg = synth.CONFIGS["C2" if cfg_name == "LinNet300" else cfg_name]
+    if cfg_name == "LinNet300":              # the reference's default network at full width on the C2 shape (bench.py make_problem)
+        raw_ = synth.make_torch_net("LinNet", npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=(300, 300, 300), seed=21)
+        net = dict(raw_, _norm=nnio.normalize_spec_net(raw_, "LinNet"))
+    else:
+        net = synth.make_yst_net(npix=cfg["npix"], lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=0)
     obs = synth.obs_grid(net["wavelength"], cfg["nobs"])
-    e0 = PayneEngine(nnio.normalize_spec_net(net), obs=(obs,), b_max=1)
+    e0 = PayneEngine(_norm(net), obs=(obs,), b_max=1)
     T = synth.TRUTH
     truth = theta_full(np.array([[T["Teff"], T["logg"], T["feh"], T["afe"], T["vrad"], T["vrot"], T["inst_R"]]]))
     clean = e0.predict_batch(truth, stage=2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
@@ -48,8 +56,8 @@ def problem(cfg_name):
 
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C2"
 raw, obs, flux, eflux = problem(cfgname)
-B = int(os.environ.get("STAMP_BATCH", synth.CONFIGS[cfgname]["batch"]))
-eng = PayneEngine(nnio.normalize_spec_net(raw), obs=(obs, flux, eflux), b_max=B, variant=int(os.environ.get("STAMP_VARIANT", "0")))
+B = int(os.environ.get("STAMP_BATCH", synth.CONFIGS["C2" if cfgname == "LinNet300" else cfgname]["batch"]))
+eng = PayneEngine(_norm(raw), obs=(obs, flux, eflux), b_max=B, variant=int(os.environ.get("STAMP_VARIANT", "0")))
 th = eng._theta(theta_full(synth.draw_candidates(B, seed=1)), eng.ncols)
 eng.lnlike_batch(th)
 eng.torch.cuda.synchronize()
