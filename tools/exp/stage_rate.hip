@@ -74,24 +74,24 @@ __global__ void __launch_bounds__(512) k(const unsigned char* __restrict__ src, 
 }
 
 template <int MODE, int AHEAD>
-void run(const char* name, const unsigned char* src, size_t span, size_t wrap) {
+void run(const char* name, const unsigned char* src, size_t span, size_t wrap, int grid = 256) {
   float* out; unsigned long long* cyc;
   (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&cyc, 256 * 8);
   const size_t lds = (size_t)(AHEAD + 1 > 2 ? AHEAD + 1 : 2) * STAGE;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE, AHEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, AHEAD>), dim3(256), dim3(512), lds, 0, src, span, wrap, out, cyc);
+  hipLaunchKernelGGL((k<MODE, AHEAD>), dim3(grid), dim3(512), lds, 0, src, span, wrap, out, cyc);
   (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((k<MODE, AHEAD>), dim3(256), dim3(512), lds, 0, src, span, wrap, out, cyc);
+  hipLaunchKernelGGL((k<MODE, AHEAD>), dim3(grid), dim3(512), lds, 0, src, span, wrap, out, cyc);
   (void)hipEventRecord(e1, 0);
   (void)hipDeviceSynchronize();
   float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(256);
   (void)hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
-  double s = 0; for (auto v : h) s += (double)v;
-  const double per = s / 256 / NSTEP;
+  double s = 0; for (int i = 0; i < grid; ++i) s += (double)h[i];
+  const double per = s / grid / NSTEP;
   printf("%-44s %6.0f cycles per 36 KB step = %5.1f B/clk/CU; kernel %.1f us -> %.2f TB/s chip-wide\n", name, per, STAGE / per, ms * 1e3,
-         256.0 * NSTEP * STAGE / (ms * 1e-3) / 1e12);
+         (double)grid * NSTEP * STAGE / (ms * 1e-3) / 1e12);
   (void)hipFree(out); (void)hipFree(cyc);
 }
 int main() {
@@ -104,6 +104,13 @@ int main() {
     run<0, 3>("LDS-DMA, three steps ahead", d, span, wrap);
     run<1, 1>("registers, one step ahead", d, span, wrap);
     run<1, 2>("registers, two steps ahead", d, span, wrap);
+  }
+  // few workgroups (a whole net's layers by ONE workgroup per row block would be 16-32 of them): what one CU can pull when its XCD's L2 is its own
+  for (int grid : {64, 32, 16, 8}) {
+    printf("grid %d, walk wraps every 1 MB\n", grid);
+    run<0, 2>("LDS-DMA, two steps ahead", d, span, (size_t)1 << 20, grid);
+    run<0, 3>("LDS-DMA, three steps ahead", d, span, (size_t)1 << 20, grid);
+    run<1, 2>("registers, two steps ahead", d, span, (size_t)1 << 20, grid);
   }
   return 0;
 }
