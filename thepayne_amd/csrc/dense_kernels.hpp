@@ -631,30 +631,38 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 32;
-  const unsigned char* src[PW];
+  // A piece's source = a base every lane shares (operand, plane: scalar registers) + the lane's 32-bit byte offset (row, chunk), the
+  // k-step an immediate: no 64-bit vector arithmetic per address -- as first written the set-up in front of the first request was 370
+  // instructions a wave (launch_out_dma2h checks that the offsets fit).
+  const unsigned char* sbase[PW];
+  unsigned voff[PW];
   int dst[PW];
+  const int lrow = lane / CPR, lchunk = lane % CPR;
+  const unsigned pitch_a = 2u * (unsigned)p.ldp, pitch_b = 2u * (unsigned)p.K;
+  // Which pieces a wave moves is fixed by the piece's INDEX j, not worked out from the wave's number (as first written: a chain of scalar
+  // branches a piece): KD = 64: activations (plane j, block w), j = 0, 1; weights (plane (j - 2) / 2, block 2 w + (j - 2) % 2), j = 2 .. 5;
+  // KD = 32: activations (plane w / 4, block w % 4), j = 0; weights (plane j - 1, block w), j = 1, 2.  Where a piece lands in LDS is as before.
+  constexpr int PWA = 2 * NPA / 8;
+  static_assert((KD == 64 && NPA == 8 && NPB == 16 && PWA == 2) || (KD == 32 && NPA == 4 && NPB == 8 && PWA == 1), "the piece map below");
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
-    const int q = wave * PW + j;                           // A pieces first (plane, block), then B
-    const bool isA = q < 2 * NPA;
-    const int qq = isA ? q : q - 2 * NPA, np_ = isA ? NPA : NPB;
-    const int pl = qq / np_, blk = qq - pl * np_;
-    const int row = RPP * blk + lane / CPR;
-    const int c = (lane % CPR) ^ sw(row);                  // which 16-byte chunk of the row belongs in this lane's slot
-    if (isA) {
-      const int r = (m0 + row < p.B) ? m0 + row : p.B - 1;
-      src[j] = reinterpret_cast<const unsigned char*>(p.Xp + (size_t)pl * p.plane_x + (size_t)r * p.ldp) + 16 * c;
-      dst[j] = pl * A_PLANE + blk * 1024;
-    } else {
-      const int r = (n0 + row < p.N) ? n0 + row : p.N - 1;
-      src[j] = reinterpret_cast<const unsigned char*>(p.Wp + (size_t)pl * p.plane_w + (size_t)r * p.K) + 16 * c;
-      dst[j] = 2 * A_PLANE + pl * B_PLANE + blk * 1024;
-    }
+    const bool isA = j < PWA;
+    const int jb = j - PWA;
+    const int pl = isA ? (KD == 64 ? j : wave >> 2) : (KD == 64 ? jb >> 1 : jb);
+    const int blk = isA ? (KD == 64 ? wave : wave & 3) : (KD == 64 ? 2 * wave + (jb & 1) : wave);
+    const int row = RPP * blk + lrow;
+    const int c = lchunk ^ sw(row);                        // which 16-byte chunk of the row belongs in this lane's slot
+    const int top = isA ? p.B - 1 - m0 : p.N - 1 - n0;     // (scalar) last real row of the tile
+    const int r = (isA ? m0 : n0) + (row < top ? row : top);
+    sbase[j] = isA ? reinterpret_cast<const unsigned char*>(p.Xp) + 2 * (size_t)pl * p.plane_x
+                   : reinterpret_cast<const unsigned char*>(p.Wp) + 2 * (size_t)pl * p.plane_w;
+    voff[j] = (unsigned)r * (isA ? pitch_a : pitch_b) + 16u * (unsigned)c;
+    dst[j] = isA ? pl * A_PLANE + blk * 1024 : 2 * A_PLANE + pl * B_PLANE + blk * 1024;
   }
   auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
 #pragma unroll
     for (int j = 0; j < PW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + 2 * k0),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase[j] + voff[j] + 2 * k0),
                                        (__attribute__((address_space(3))) void*)(d2_sm + stage * STAGE + dst[j]), 16, 0, 0);
   };
   auto wait_landed = [&](int younger) {                    // my pieces of a stage have landed once only `younger` stages' loads are outstanding
@@ -1540,6 +1548,14 @@ __device__ __forceinline__ void hk_h2_quadrant(const DenseParams& p, const unsig
   }
 }
 
+// Register loads the compiler cannot see into (hk_tile_h2): with LDS transfers and register loads pending on one counter its wait-count
+// pass drains the counter before the first loaded value is used -- the first layer then starts when the weight planes' 39 KB have
+// landed, not when its own few values have.  Loads return in order: the wait is counted by hand (`hk2_small_landed`).
+// (`base`: the same for every lane, `off`: the lane's byte offset -- the scalar-base form, no 64-bit vector arithmetic per address)
+__device__ __forceinline__ void gload(float& v, const float* base, unsigned off) { asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gload(double& v, const double* base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gload(f32x4_t& v, const float* base, unsigned off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+
 template <int NL>
 __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_sm, const int tid) {
   HK_STAMP(0);
@@ -1547,12 +1563,14 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   unsigned char* Bs = As + 2 * HK2_PLANE;
   const int tm = tile / p.grid_n, tn = tile - tm * p.grid_n;
   const int m0 = tm * 32, n0 = tn * 32;
-  const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
   const int qi = wave >> 1, qj = wave & 1;
+  // The tile's first requests are ~50 vector instructions, not ~480: every address is a scalar base + a 32-bit lane offset, the weight
+  // transfers' (row, chunk) pairs follow from the first by a recurrence and serve both planes.
   float bias1, rs1;
   {
     const int c0 = n0 + 16 * qj + r, cc = c0 < p.N ? c0 : p.N - 1;
-    bias1 = p.bias[cc]; rs1 = p.rs1[cc];
+    gload(bias1, p.bias, 4u * (unsigned)cc); gload(rs1, p.rs1, 4u * (unsigned)cc);
   }
   constexpr int NLG = (NL + 3) / 4, MAXT = (HK2_K / 16 + 3) / 4;     // label groups of four; unit blocks of 16 a wave (5)
   constexpr int ntile = HK2_K / 16;                                   // 19
@@ -1562,7 +1580,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   for (int i = 0; i < 2; ++i) {
     const int row = (m0 + 16 * i + r < p.B) ? m0 + 16 * i + r : p.B - 1;
 #pragma unroll
-    for (int lg = 0; lg < NLG; ++lg) { const int d = 4 * lg + g; xl[i][lg] = p.theta[(size_t)row * p.ld_theta + (d < 4 ? d : 6)]; }
+    for (int lg = 0; lg < NLG; ++lg) { const int d = 4 * lg + g; gload(xl[i][lg], p.theta, 8u * ((unsigned)row * (unsigned)p.ld_theta + (unsigned)(d < 4 ? d : 6))); }
   }
   // first-layer weights (A operand: lane (r, g) = W0[unit 16 t + r][label 4 lg + g]) and biases (four units 16 t + 4 g + q a lane)
   float w0t[MAXT][NLG];
@@ -1574,31 +1592,52 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
 #pragma unroll
     for (int lg = 0; lg < NLG; ++lg) {
       const int d = 4 * lg + g;
-      w0t[tt][lg] = p.W0[(size_t)kq * p.n_labels + (d < p.n_labels ? d : 0)];     // (clamped address, masked below)
+      gload(w0t[tt][lg], p.W0, 4u * ((unsigned)kq * (unsigned)p.n_labels + (unsigned)(d < p.n_labels ? d : 0)));     // (clamped address, masked below)
     }
     {                                                                 // (units past the layer's width are masked below: any values do)
       const int u0 = 16 * tc + 4 * g, uq = (u0 + 4 <= p.K0) ? u0 : ((p.K0 - 4) & ~3);
-      bz4[tt] = *reinterpret_cast<const f32x4_t*>(p.b0 + (uq > 0 ? uq : 0));
+      gload(bz4[tt], p.b0, 4u * (unsigned)(uq > 0 ? uq : 0));
     }
   }
-  // the weight tile: 2 planes x 19 transfers of 64 consecutive 16-byte chunks (chunk sl = (row sl / 38, chunk sl % 38))
+  // the weight tile: 2 planes x 19 transfers of 64 consecutive 16-byte chunks (chunk sl = (row sl / 38, chunk sl % 38)); wave w moves
+  // transfers w, w + 4, ..: a step of four transfers is 256 chunks = 6 rows + 28 chunks on
   {
     constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64;               // 38 chunks a row, 19 transfers a plane
-    static_assert(32 * NCH % 64 == 0, "whole transfers");
+    static_assert(32 * NCH % 64 == 0 && NCH == 38 && NTR <= 4 * MAXT, "whole transfers; the recurrence's constants");
+    unsigned voff[MAXT];
+    {
+      const int sl = 64 * wave + lane;
+      int rr = sl / NCH, c = sl - rr * NCH;
 #pragma unroll
-    for (int j0 = 0; j0 < 2 * NTR; j0 += 4) {
-      const int j = j0 + wave;
-      if (j < 2 * NTR) {                                              // (wave-uniform)
-        const int pl = j >= NTR ? 1 : 0, jj = j - pl * NTR;
-        const int sl = 64 * jj + lane, rr = sl / NCH, c = sl - rr * NCH;
+      for (int q = 0; q < MAXT; ++q) {
         const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wh + (size_t)pl * p.plane_wh + (size_t)nr * HK2_K + 8 * c),
-                                         (__attribute__((address_space(3))) void*)(Bs + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
+        voff[q] = (unsigned)nr * (unsigned)(2 * HK2_K) + 16u * (unsigned)c;
+        c += 256 - 6 * NCH; rr += 6;
+        if (c >= NCH) { c -= NCH; rr += 1; }
+      }
+    }
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.Wh);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const unsigned char* wpl = wb + (size_t)pl * p.plane_wh * 2;
+#pragma unroll
+      for (int q = 0; q < MAXT; ++q) {
+        const int jj = wave + 4 * q;
+        if (q + 1 < MAXT || jj < NTR)                                   // (scalar: the last wave moves four transfers a plane, the others five)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wpl + voff[q]),
+                                           (__attribute__((address_space(3))) void*)(Bs + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
       }
     }
   }
-  // (every loaded value named -- AFTER the transfers' requests -- before anything is done with it: a load whose value feeds a select the compiler otherwise sinks into a
-  //  branch of its own, with a wait behind it -- five memory round trips in a row at the start of every workgroup)
+  // The register loads above are older than this wave's transfers (ten, the last wave's eight): they have landed once only that many
+  // operations are outstanding.  Every value named behind the wait, before anything is done with it.
+  if (wave == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  asm volatile("" : "+v"(bias1), "+v"(rs1));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int lg = 0; lg < NLG; ++lg) asm volatile("" : "+v"(xl[i][lg]));
 #pragma unroll
   for (int tt = 0; tt < MAXT; ++tt) {
 #pragma unroll
@@ -2068,6 +2107,10 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
     }
     return;
   }
+  // Nothing is outstanding on this path -- but the riders' branch above is structured into a region that flows through here, and the
+  // compiler's wait-count pass carries ITS pending loads into the tile code: a drain (`s_waitcnt vmcnt(0)`) between the fifth and the
+  // sixth of the tile's first requests.  A wait the pass can see (and that waits for nothing) clears its books.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
 #ifdef PAYNE_STAMPS
   if (p.stamps) p.stamps -= (size_t)front * 16;                    // (diagnostic build: row = GEMM tile)
 #endif

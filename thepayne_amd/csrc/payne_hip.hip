@@ -882,6 +882,10 @@ static bool out_dma2h_ok(const payne_ctx* c, int B, int N, bool sel = false) {
   // (whatever the batch: a candidate's rows do not depend on how many others share its batch -- many whole 128 x 256 tiles take
   //  payne_dense_big3_kernel<true>, everything else payne_dense_dma2h_kernel, one tile a workgroup, same products in the same order)
   (void)sel;
+  // (payne_dense_dma2h_kernel addresses an operand plane by 32-bit byte offsets: rows x pitch x 2 bytes below 2^31)
+  const unsigned long long plane_w = 2ull * (unsigned long long)std::max(N, c->T.n1) * (unsigned long long)c->w_out_kp;
+  const unsigned long long plane_x = 2ull * (unsigned long long)c->opts.b_max * (unsigned long long)c->ld_hid;
+  if (plane_w >= (1ull << 31) || plane_x >= (1ull << 31)) return false;
   return out_dma3_ok(c, B, N) && c->w_out_h2 && c->act_scale > 0.f && !(c->opts.variant & (PAYNE_V_OUT_BF16X3 | PAYNE_V_OUT_PLANES));
 }
 static void launch_out_dma2h(payne_ctx* c, DenseParams& p, hipStream_t s, bool freq) {
@@ -1043,7 +1047,8 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
         pa.spec_step = c->spec_step; c->spec_launched = true;
       }
       if (!last && N.spectral && c->w_hid_pad[1] && N.ld_hid >= HK_PITCH) { p.Wd = c->w_hid_pad[1]; p.ldwd = N.ld_hid; }
-      if (!last && N.spectral && p.Wd && c->w1_h2 && c->w1_rows == p.N && p.K <= 304) {       // the second layer on fp16 pairs
+      if (!last && N.spectral && p.Wd && c->w1_h2 && c->w1_rows == p.N && p.K <= 304 &&
+          (unsigned long long)B * (unsigned)c->ncols * 8ull < (1ull << 31)) {                // the second layer on fp16 pairs (hk_tile_h2: 32-bit byte offsets into theta)
         p.h2_tiles = 1; p.Wh = c->w1_h2; p.plane_wh = (size_t)c->w1_rows * 304; p.rs1 = c->rs1; p.a0_scale = c->a0_scale;
       }
       if (!last && !hk_lead_fits(p.B, p.N, p.K, p.K0, 0, p.ldwd, p.ld_theta, spec ? c->spec_K : 0))
