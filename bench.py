@@ -59,6 +59,10 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=15,
                     help="the block of --steps steps is timed this many times back to back (each between barriers); the MEDIAN "
                          "block is the headline, min / max ride along: a 20-step block is 0.8 ms, one clock ramp moved it 3 %%")
+    ap.add_argument("--min-timed-ms", type=float, default=120.0,
+                    help="keep timing blocks (beyond --repeats) until this much timed work has been done: an MI355X that was idle takes "
+                         "15-20 ms of work to reach its clocks (tools/exp/block_ramp.py: a 20-step block 30.7 us a step in the first 9 ms, "
+                         "28.9 from 20 ms on), and --steps 20 --repeats 15 is 9 ms in all; 0: exactly --repeats blocks")
     ap.add_argument("--force-dist", action="store_true",
                     help="one rank, but through a torch.distributed process group (RCCL, world size 1): the collectives of "
                          "the N > 1 path on a one-GPU box (tests/test_rccl_world1_gpu.py)")
@@ -269,7 +273,7 @@ def alg_work(d):
                 flops_out=2.0 * H * N)
 
 
-def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, streams=1, shard=False, repeats=1):
+def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, streams=1, shard=False, repeats=1, min_timed_s=0.0):
     """Time `steps` steps of config `cfg_name` (after `warmup`) between barriers; MAX over ranks.  Returns the numbers the
     JSON line is made of.  shard: one star, the batch split over the ranks, one all_gather of lnL per step."""
     import numpy as np
@@ -319,7 +323,10 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
     # Batches in flight on several streams have no single launch stream: their blocks are timed by the host clock alone.
     use_events = (S == 1)
     blocks, blocks_local, blocks_wall = [], [], []
-    for _ in range(max(1, repeats)):
+    # At least `repeats` blocks, and blocks until `min_timed_s` of timed work is behind (every rank sees the same MAX-reduced times, so
+    # every rank stops at the same block): a GPU that was idle is 6 % slower for its first 15-20 ms of work (clock ramp), which is the
+    # whole of fifteen 20-step blocks; the median is then taken over blocks most of which ran at the clocks the job runs at.
+    while len(blocks) < max(1, repeats) or (sum(blocks) < min_timed_s and len(blocks) < 4000):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
@@ -353,7 +360,7 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
     if not args.no_kernel_timing and not (shard and world > 1):
         # per-kernel device time (HIP events attached to the launches, on the launch stream), same steps replayed
         eng.profile(True)
-        for _ in range(steps):
+        for _ in range(max(steps, 100) if min_timed_s > 0 and dt / steps < 2e-4 else steps):   # (short steps: at least a hundred launches a kernel)
             eng.lnlike_batch(theta, out=lnl)
         torch.cuda.synchronize()
         kern = eng.profile_read()
@@ -566,7 +573,7 @@ def _pick(d, keys):
 
 def final_line(full):
     """The compact record of one bench run (a dict whose JSON is the last stdout line) from the full one."""
-    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_wall", "repeats",
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_first15", "ms_per_step_wall", "repeats",
                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "invalid"))
     c = full.get("config", {})
     out["config"] = {"workload": c.get("workload_short", c.get("workload", ""))[:160],
@@ -694,7 +701,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     res = run_config(args.config, args, args.steps, args.warmup, rank, world, local_rank, B=args.batch,
-                     streams=args.streams, shard=args.shard_batch, repeats=args.repeats)
+                     streams=args.streams, shard=args.shard_batch, repeats=args.repeats, min_timed_s=1e-3 * args.min_timed_ms)
     B, d, lnl, theta = res["B"], res["dims"], res["lnl"], res["theta"]
 
     # ---- the one collective of the multi-star job: gather per-star summaries (RCCL)
@@ -720,8 +727,10 @@ def main():
         "ms_per_step": 1e3 * res["dt"] / args.steps,
         "repeats": len(res["blocks"]), "ms_per_step_min": 1e3 * min(res["blocks"]) / args.steps,
         "ms_per_step_max": 1e3 * max(res["blocks"]) / args.steps,
+        "ms_per_step_first15": 1e3 * sorted(res["blocks"][:15])[len(res["blocks"][:15]) // 2] / args.steps,
         "ms_per_step_wall": 1e3 * res["dt_wall"] / args.steps,
-        "timing": ("median of `repeats` blocks of `steps` steps, MAX over ranks; every block sits between barrier + synchronize on both "
+        "timing": ("median of `repeats` blocks of `steps` steps (at least --repeats of them, and blocks until --min-timed-ms of timed work: "
+                   "`ms_per_step_first15` is the median of the first fifteen, which an idle GPU's clock ramp covers when blocks are short), MAX over ranks; every block sits between barrier + synchronize on both "
                    "sides and is timed by a HIP event pair on the launch stream around its steps (`value`, `ms_per_step`) and by the host "
                    "clock between the barriers (`ms_per_step_wall`: + ~55 us of synchronize / barrier edges per block)")
                   if res["timed_by"] == "hip-events" else
@@ -763,8 +772,8 @@ def main():
                                   ("LinNet300", (args.steps, args.warmup, min(args.repeats, 5))),
                                   ("C32k", (5, 2, 3)), ("C5", (3, 1, 3))):   # (C3 as long as the headline: a step is 0.04 ms)
             try:
-                r = run_config(name, args, k, w, 0, 1, local_rank, repeats=rep)
-                blk = {"value": r["evals"] / r["dt"], "unit": "likelihood-evals/s", "steps": k, "warmup": w, "repeats": rep,
+                r = run_config(name, args, k, w, 0, 1, local_rank, repeats=rep, min_timed_s=1e-3 * args.min_timed_ms)
+                blk = {"value": r["evals"] / r["dt"], "unit": "likelihood-evals/s", "steps": k, "warmup": w, "repeats": len(r["blocks"]),
                        "ms_per_step": 1e3 * r["dt"] / k, "ms_per_step_wall": 1e3 * r["dt_wall"] / k, "ms_per_step_min": 1e3 * min(r["blocks"]) / k,
                        "ms_per_step_max": 1e3 * max(r["blocks"]) / k, "workload": workload_text(name, r["dims"]),
                        "kernels": r["engines"][0].kernels_used()}
