@@ -55,9 +55,9 @@ def parse_args():
     ap.add_argument("--shard-batch", action="store_true",
                     help="N > 1: one star, each batch split over the ranks, one all_gather of lnL per step (SURVEY 8(e)-2)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also_measured` runs (C3, C5) behind the C2 headline")
-    ap.add_argument("--e2e-calls", type=int, default=2000000,
-                    help="likelihood calls per end-to-end sampler run (three runs; 2 M calls = 0.13 s a run: a 0.7 M-call run spent a third of "
-                         "its 44 ms on the clock ramp of a GPU that idled while the run was set up)")
+    ap.add_argument("--e2e-calls", type=int, default=700000,
+                    help="likelihood calls per end-to-end sampler run (three runs; a C2 run converges -- nothing left of the evidence at "
+                         "dlogz = 1e-9 -- after ~727 k calls, so longer runs do not exist)")
     ap.add_argument("--repeats", type=int, default=15,
                     help="the block of --steps steps is timed this many times back to back (each between barriers); the MEDIAN "
                          "block is the headline, min / max ride along: a 20-step block is 0.8 ms, one clock ramp moved it 3 %%")
