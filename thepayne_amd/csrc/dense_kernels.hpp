@@ -1719,27 +1719,44 @@ __device__ __forceinline__ void hk_tile_h2x(DenseParams& p, int tile, float* hk_
   unsigned char* Bs = As + 2 * HK2_PLANE;
   const int tm = tile / p.grid_n, tn = tile - tm * p.grid_n;
   const int m0 = tm * 32, n0 = tn * 32;
-  const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
   const int qi = wave >> 1, qj = wave & 1;
   float bias1, rs1;
   {
     const int c0 = n0 + 16 * qj + r, cc = c0 < p.N ? c0 : p.N - 1;
     bias1 = p.bias[cc]; rs1 = p.rs1[cc];
   }
-  constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64;                 // 38 chunks a row, 19 transfers a plane
+  // four planes (the weights' two, the activations' two) x 19 transfers of 64 consecutive 16-byte chunks; wave w moves transfers w, w + 4, ..
+  // of every plane (five, the last wave four).  A chunk's (row, column) follows from the wave's first by a recurrence -- a step of four
+  // transfers is 256 chunks = 6 rows + 28 chunks on -- and serves all four planes: scalar bases + 32-bit lane offsets (as first written:
+  // a division and 64-bit address arithmetic per transfer, ~480 vector instructions in front of the tile's only wait).
+  constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64, MAXQ = (NTR + 3) / 4;      // 38 chunks a row, 19 transfers a plane
+  static_assert(NCH == 38 && NTR == 19, "the recurrence's constants");
+  unsigned voffw[MAXQ], voffx[MAXQ];
+  {
+    const int sl = 64 * wave + lane;
+    int rr = sl / NCH, c = sl - rr * NCH;
+    const int topw = p.N - 1 - n0, topx = p.B - 1 - m0;
 #pragma unroll
-  for (int j0 = 0; j0 < 4 * NTR; j0 += 4) {
-    const int j = j0 + wave;                                            // (4 NTR = 76 is a multiple of four: every wave moves nineteen)
-    const int q = j / NTR, jj = j - q * NTR, pl = q & 1;                // q: 0, 1 the weights' planes; 2, 3 the activations'
-    const int sl = 64 * jj + lane, rr = sl / NCH, c = sl - rr * NCH;
-    if (q < 2) {
-      const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wh + (size_t)pl * p.plane_wh + (size_t)nr * HK2_K + 8 * c),
-                                       (__attribute__((address_space(3))) void*)(Bs + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
-    } else {
-      const int mr = (m0 + rr < p.B) ? m0 + rr : p.B - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Xp + (size_t)pl * p.plane_x + (size_t)mr * HK2_K + 8 * c),
-                                       (__attribute__((address_space(3))) void*)(As + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
+    for (int q = 0; q < MAXQ; ++q) {
+      voffw[q] = (unsigned)(n0 + (rr < topw ? rr : topw)) * (unsigned)(2 * HK2_K) + 16u * (unsigned)c;
+      voffx[q] = (unsigned)(m0 + (rr < topx ? rr : topx)) * (unsigned)(2 * HK2_K) + 16u * (unsigned)c;
+      c += 256 - 6 * NCH; rr += 6;
+      if (c >= NCH) { c -= NCH; rr += 1; }
+    }
+  }
+#pragma unroll
+  for (int pq = 0; pq < 4; ++pq) {                                      // 0, 1: the weights' planes; 2, 3: the activations'
+    const int pl = pq & 1;
+    const unsigned char* base = pq < 2 ? reinterpret_cast<const unsigned char*>(p.Wh) + 2 * (size_t)pl * p.plane_wh
+                                       : reinterpret_cast<const unsigned char*>(p.Xp) + 2 * (size_t)pl * p.plane_x;
+    unsigned char* dstp = (pq < 2 ? Bs : As) + pl * HK2_PLANE;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int jj = wave + 4 * q;
+      if (q + 1 < MAXQ || jj < NTR)                                     // (scalar)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (pq < 2 ? voffw[q] : voffx[q])),
+                                         (__attribute__((address_space(3))) void*)(dstp + 1024 * jj), 16, 0, 0);
     }
   }
   HK_STAMP(1);
