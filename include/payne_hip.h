@@ -140,6 +140,8 @@ typedef struct payne_opts {
 #define PAYNE_V_HID_CHAIN 4194304u /* deeper nets: the hidden layers past the second in ONE launch with hand-offs inside a 32-candidate row
                                       block (agent-scope release / acquire: measured 8 us a hop against 5.7 us a launch -- kept as a tested
                                       variant, not a default) */
+#define PAYNE_V_HID_WAVES4 8388608u /* sigmoid nets: the first launch's tiles by four waves (what leaky-ReLU nets and launches that carry
+                                      photometric tiles use) instead of eight */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -383,6 +383,24 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
         for nrow in (5, 128, 33, 64, 1, 128):
             assert np.array_equal(e1.lnlike_batch(thd[:nrow]).cpu().numpy(), lnl[:nrow]), nrow
         e1.close()
+    # a sigmoid net's first launch runs its tiles on eight waves (the first layer's forty activations a lane become twenty-four); four
+    # waves -- what leaky-ReLU nets use -- split the same arithmetic differently: the same bits
+    if kind == "LinNet":
+        e3 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=_lib.V_HID_WAVES4)
+        assert np.array_equal(e3.lnlike_batch(thd).cpu().numpy(), lnl)
+        e3.predict_batch(th[:3], stage=0); assert e3.kernels_used()["hidden"] == "payne_dense_hidden_kernel<false, 4>"
+        e3.close()
+        # (a three-layer sigmoid net: the first launch is the only hidden launch, its kernel's name says how many waves)
+        raw3 = synth.make_yst_net(npix=512, H=300, seed=5)
+        n3 = _net(raw3); n3["layers"] = [(w, b, _lib.ACT_SIGMOID if a != _lib.ACT_NONE else a) for (w, b, a) in n3["layers"]]
+        th3 = np.full((40, 12), np.nan); th3[:, :4] = thd[:40, :4]; th3[:, 4:6] = 0.0
+        outs = {}
+        for v in (0, _lib.V_HID_WAVES4):
+            e4 = Engine(n3, b_max=40, variant=v)
+            outs[v] = e4.predict_batch(th3, stage=0).cpu().numpy()
+            assert e4.kernels_used()["hidden"] == ("payne_dense_hidden_kernel<true, 4, 8>" if v == 0 else "payne_dense_hidden_kernel<true, 4>"), e4.kernels_used()
+            e4.close()
+        assert np.array_equal(outs[0], outs[_lib.V_HID_WAVES4]) and np.all(np.isfinite(outs[0]))
     # other shipped forms of the output layer on the same net: same likelihoods
     for v in (1, 4096, 2048):
         e2 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=v)

@@ -1552,11 +1552,19 @@ __device__ __forceinline__ void hk_h2_quadrant(const DenseParams& p, const unsig
 // pass drains the counter before the first loaded value is used -- the first layer then starts when the weight planes' 39 KB have
 // landed, not when its own few values have.  Loads return in order: the wait is counted by hand (`hk2_small_landed`).
 // (`base`: the same for every lane, `off`: the lane's byte offset -- the scalar-base form, no 64-bit vector arithmetic per address)
-__device__ __forceinline__ void gload(float& v, const float* base, unsigned off) { asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void gload(double& v, const double* base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void gload(f32x4_t& v, const float* base, unsigned off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+// `s_nop 4`: a vector-memory instruction that reads a scalar register a VECTOR instruction has just written (v_readlane / v_readfirstlane:
+// how the compiler brings back a scalar it parked in a vector register's lanes when scalars run short) needs five wait states in between, and
+// the compiler's hazard recognizer does not look inside an asm statement.  Found with rocgdb's precise memory faults in the stamped
+// diagnostic twin (more scalars live: `v_readlane_b32 s11, v150, 3` right in front of the labels' load, which then went through a stale
+// base); the production build happened to have its bases in preloaded registers.
+__device__ __forceinline__ void gload(float& v, const float* base, unsigned off) { asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gload(double& v, const double* base, unsigned off) { asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void gload(f32x4_t& v, const float* base, unsigned off) { asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
 
-template <int NL>
+// NW: the workgroup's waves (4 | 8).  Eight waves share the requests, the first layer and its LDS stores (three unit blocks a wave instead of
+// five: the phase is instruction-bound); the matrix phase and the epilogue are the first four waves' (one 16 x 16 quadrant each: LDS-read-bound,
+// more waves would read the same bytes), the others leave after the barrier.
+template <int NL, int NW>
 __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_sm, const int tid) {
   HK_STAMP(0);
   unsigned char* As = reinterpret_cast<unsigned char*>(hk_sm);
@@ -1572,7 +1580,8 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
     const int c0 = n0 + 16 * qj + r, cc = c0 < p.N ? c0 : p.N - 1;
     gload(bias1, p.bias, 4u * (unsigned)cc); gload(rs1, p.rs1, 4u * (unsigned)cc);
   }
-  constexpr int NLG = (NL + 3) / 4, MAXT = (HK2_K / 16 + 3) / 4;     // label groups of four; unit blocks of 16 a wave (5)
+  static_assert(NW == 4 || NW == 8, "waves a workgroup");
+  constexpr int NLG = (NL + 3) / 4, MAXT = (HK2_K / 16 + NW - 1) / NW;   // label groups of four; unit blocks of 16 a wave (5 | 3)
   constexpr int ntile = HK2_K / 16;                                   // 19
   // labels of the candidates (B operand of the transposed first layer: lane (r, g) = xhat[candidate 16 i + r][label 4 lg + g])
   double xl[2][NLG];
@@ -1587,7 +1596,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   f32x4_t bz4[MAXT];
 #pragma unroll
   for (int tt = 0; tt < MAXT; ++tt) {
-    const int tcol = wave + 4 * tt, tc = tcol < ntile ? tcol : 0;
+    const int tcol = wave + NW * tt, tc = tcol < ntile ? tcol : 0;
     const int k = 16 * tc + r, kq = k < p.K0 ? k : p.K0 - 1;
 #pragma unroll
     for (int lg = 0; lg < NLG; ++lg) {
@@ -1600,10 +1609,11 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
     }
   }
   // the weight tile: 2 planes x 19 transfers of 64 consecutive 16-byte chunks (chunk sl = (row sl / 38, chunk sl % 38)); wave w moves
-  // transfers w, w + 4, ..: a step of four transfers is 256 chunks = 6 rows + 28 chunks on
+  // transfers w, w + NW, ..: a step of NW transfers is 64 NW chunks = 6 rows + 28 chunks on (four waves; 13 rows + 18 chunks: eight)
+  constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64;                 // 38 chunks a row, 19 transfers a plane
   {
-    constexpr int NCH = HK2_PB / 16, NTR = 32 * NCH / 64;               // 38 chunks a row, 19 transfers a plane
-    static_assert(32 * NCH % 64 == 0 && NCH == 38 && NTR <= 4 * MAXT, "whole transfers; the recurrence's constants");
+    constexpr int DR = 64 * NW / NCH, DC = 64 * NW - DR * NCH;
+    static_assert(32 * NCH % 64 == 0 && NTR <= NW * MAXT && DC < NCH, "whole transfers; the recurrence's constants");
     unsigned voff[MAXT];
     {
       const int sl = 64 * wave + lane;
@@ -1612,7 +1622,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
       for (int q = 0; q < MAXT; ++q) {
         const int nr = (n0 + rr < p.N) ? n0 + rr : p.N - 1;
         voff[q] = (unsigned)nr * (unsigned)(2 * HK2_K) + 16u * (unsigned)c;
-        c += 256 - 6 * NCH; rr += 6;
+        c += DC; rr += DR;
         if (c >= NCH) { c -= NCH; rr += 1; }
       }
     }
@@ -1622,17 +1632,17 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
       const unsigned char* wpl = wb + (size_t)pl * p.plane_wh * 2;
 #pragma unroll
       for (int q = 0; q < MAXT; ++q) {
-        const int jj = wave + 4 * q;
-        if (q + 1 < MAXT || jj < NTR)                                   // (scalar: the last wave moves four transfers a plane, the others five)
+        const int jj = wave + NW * q;
+        if (q + 1 < MAXT || jj < NTR)                                   // (scalar: the last waves move one transfer a plane fewer)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wpl + voff[q]),
                                            (__attribute__((address_space(3))) void*)(Bs + pl * HK2_PLANE + 1024 * jj), 16, 0, 0);
       }
     }
   }
-  // The register loads above are older than this wave's transfers (ten, the last wave's eight): they have landed once only that many
-  // operations are outstanding.  Every value named behind the wait, before anything is done with it.
-  if (wave == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  // The register loads above are older than this wave's transfers (2 MAXT of them, two fewer for the last waves): they have landed once
+  // only that many operations are outstanding.  Every value named behind the wait, before anything is done with it.
+  if (wave + NW * (MAXT - 1) < NTR) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * MAXT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * MAXT - 2) : "memory");
   asm volatile("" : "+v"(bias1), "+v"(rs1));
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1646,7 +1656,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   }
 #pragma unroll
   for (int tt = 0; tt < MAXT; ++tt) {
-    const int tcol = wave + 4 * tt, tc = tcol < ntile ? tcol : 0;
+    const int tcol = wave + NW * tt, tc = tcol < ntile ? tcol : 0;
     const bool klive = 16 * tc + r < p.K0;
 #pragma unroll
     for (int lg = 0; lg < NLG; ++lg) w0t[tt][lg] = (4 * lg + g < p.n_labels && klive) ? w0t[tt][lg] : 0.f;
@@ -1672,7 +1682,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   auto first_layer = [&](auto actf) {
 #pragma unroll
     for (int tt = 0; tt < MAXT; ++tt) {
-      const int tcol = wave + 4 * tt;
+      const int tcol = wave + NW * tt;
       if (tcol < ntile) {                                             // (wave-uniform)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1696,7 +1706,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int tt = 0; tt < MAXT; ++tt) {
-    const int tcol = wave + 4 * tt;
+    const int tcol = wave + NW * tt;
     if (tcol < ntile) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -1707,6 +1717,7 @@ __device__ __forceinline__ void hk_tile_h2(DenseParams& p, int tile, float* hk_s
   }
   __syncthreads();
   HK_STAMP(3);
+  if (NW > 4 && wave >= 4) return;                                      // (no barrier below)
   hk_h2_quadrant(p, As, Bs, bias1, rs1, m0, n0, qi, qj, r, g);
   HK_STAMP(5);
 }
@@ -2074,8 +2085,12 @@ __device__ __forceinline__ void hk_tile(DenseParams& p, int tile, float* hk_sm, 
 }
 
 // NL: label slots the fused first layer loops over (4 for the usual Teff/logg/FeH/aFe nets, else PAYNE_MAX_LABELS)
-template <bool FUSE_L0, int NL>
-__global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEAD_PARAMS, DenseParams p_, const PrepArgs pa) {
+// NW: waves a workgroup (4; 8: the first launch of a net whose tiles are hk_tile_h2's and with which no photometric tile rides along -- those
+// count on two workgroups a CU: launch_hidden.  Everything but hk_tile_h2<NL, 8> is the first 256 threads' work).  A kernel of its own per NW:
+// with both copies of the tile code in ONE kernel the stamped diagnostic twin faulted (NOTES R6.17); with one copy a kernel it runs clean.
+template <bool FUSE_L0, int NL, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 1) payne_dense_hidden_kernel(PAYNE_HK_LEAD_PARAMS, DenseParams p_, const PrepArgs pa) {
+  static_assert(NW == 4 || (NW == 8 && FUSE_L0), "waves a workgroup");
   extern __shared__ __attribute__((aligned(16))) float hk_sm[];
   // (what a workgroup's first requests hang off arrives in registers at wave start: see payne_dense_dma3_kernel.  `pa` itself stays
   //  the kernel's argument: a modified COPY of it would have to live in scratch memory for the functions that take its tables by reference)
@@ -2099,6 +2114,7 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
   const int front = pa_n_spec + pa_n_prep, bx = (int)blockIdx.x;
   if (bx < front || bx >= front + pa_n_gemm) {
     if constexpr (FUSE_L0) {
+      if (NW > 4 && threadIdx.x >= 256) return;
       if (bx < pa_n_spec) {
         const int w = bx * 4 + (int)(threadIdx.x >> 6);
         if (pa.spec_walk) rwalk_spec_wave(pa.spec_walk->sd, pa.spec_w, w, (int)threadIdx.x & 63, pa.spec_step);
@@ -2132,11 +2148,12 @@ __global__ void __launch_bounds__(256, 1) payne_dense_hidden_kernel(PAYNE_HK_LEA
   if (p.stamps) p.stamps -= (size_t)front * 16;                    // (diagnostic build: row = GEMM tile)
 #endif
   if constexpr (FUSE_L0) {
-    if (p.h2_tiles) { hk_tile_h2<NL>(p, bx - front, hk_sm, (int)threadIdx.x); return; }     // (uniform)
+    if constexpr (NW > 4) { hk_tile_h2<NL, NW>(p, bx - front, hk_sm, (int)threadIdx.x); return; }         // (the eight-wave kernel has no other tile code)
+    else if (p.h2_tiles) { hk_tile_h2<NL, 4>(p, bx - front, hk_sm, (int)threadIdx.x); return; }           // (uniform)
   } else {
     if (p.h2_tiles) { hk_tile_h2x(p, bx - front, hk_sm, (int)threadIdx.x); return; }
   }
-  hk_tile<FUSE_L0, NL>(p, bx - front, hk_sm, (int)threadIdx.x);
+  if constexpr (NW == 4) hk_tile<FUSE_L0, NL>(p, bx - front, hk_sm, (int)threadIdx.x);
 }
 
 
@@ -2237,3 +2254,5 @@ PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<true>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4, 8>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
+PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS, 8>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

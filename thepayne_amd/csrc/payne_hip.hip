@@ -827,6 +827,8 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), HK_LDS_BYTES);
   set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<false, 4>), HK_LDS_BYTES);
+  set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, 4, 8>), HK_LDS_BYTES);
+  set(reinterpret_cast<const void*>(payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS, 8>), HK_LDS_BYTES);
   return e;
 }
 
@@ -957,7 +959,7 @@ static bool hk_lead_fits(int B, int N, int K, int K0, int ldx, int ldwd, int ld_
          ldwd <= 0xffff && ld_theta <= 0xffff && (spec_K + kSpecChainsPerWg - 1) / kSpecChainsPerWg <= 0xffff;
 }
 template <bool FUSE>
-static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu = 256, int spec_K = 0) {
+static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu = 256, int spec_K = 0, bool waves4 = false) {
   p.grid_m = (p.B + 31) / 32;
   p.grid_n = (p.N + 31) / 32;
   pa.n_gemm = p.grid_m * p.grid_n;
@@ -979,7 +981,12 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   p.stamps = FUSE ? g_hidden_stamps : nullptr;
 #endif
   pa.n_sed = n_sed;
-  const dim3 grid(pa.n_gemm + pa.n_prep + n_sed + pa.n_spec), block(256);
+  // Eight waves for hk_tile_h2's tiles where the first layer is the expensive phase -- a sigmoid net's: forty activations a lane with four
+  // waves (LinNet300: -1.2 us a step); a leaky-ReLU net's tile gains nothing (C2: 5.16 against 5.21 us) -- and no photometric tile rides
+  // along: those are sized for two workgroups a CU.  PAYNE_HK_WAVES = 4 | 8 overrides (A/B runs).
+  static const int force_waves = [] { const char* e = getenv("PAYNE_HK_WAVES"); return e ? atoi(e) : 0; }();
+  const bool wide = FUSE && p.h2_tiles && n_sed == 0 && !waves4 && (force_waves ? force_waves == 8 : p.act0 == PAYNE_ACT_SIGMOID);
+  const dim3 grid(pa.n_gemm + pa.n_prep + n_sed + pa.n_spec), block(wide ? 512 : 256);
   // the kernel's leading scalar parameters (preloaded into registers at wave start; two 16-bit values a dword)
   p.dma_tiles = (FUSE && p.Wd != nullptr) ? 1 : 0;
   const unsigned i0 = (unsigned)pa.n_spec | ((unsigned)pa.n_prep << 16) | ((unsigned)p.dma_tiles << 31), i1 = (unsigned)pa.n_gemm | ((unsigned)p.grid_n << 16);
@@ -989,9 +996,12 @@ static void launch_hidden(DenseParams& p, PrepArgs& pa, hipStream_t s, int n_cu 
   const float* p1 = FUSE ? p.W0 : p.Wd;
   if (!FUSE) PAYNE_LAUNCH((payne_dense_hidden_kernel<false, 4>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
   else if (p.n_labels <= 4) {
-    PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
+    if (wide) PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4, 8>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
+    else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, 4>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
+  } else {
+    if (wide) PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS, 8>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
+    else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
   }
-  else PAYNE_LAUNCH((payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>), grid, block, HK_LDS_BYTES, s, p0, p1, p.b0, p.bias, i0, i1, i2, p.B, i4, p.N, p, pa);
 }
 
 // ANN forward for the batch -> c->raw [B][npix] (shifted by -1)
@@ -1054,7 +1064,7 @@ static int run_net(payne_ctx* c, const NetRef& N, const double* theta, int B, do
       if (!last && !hk_lead_fits(p.B, p.N, p.K, p.K0, 0, p.ldwd, p.ld_theta, spec ? c->spec_K : 0))
         return fail(c, PAYNE_E_UNSUPPORTED, "batch x hidden width beyond what the hidden-layer kernel's packed arguments hold (65 535 tiles of 32 x 32)");
       if (last) launch_dense<64, 64, 32, true>(p, s);
-      else { launch_hidden<true>(p, pa, s, c->n_cu, spec ? c->spec_K : 0); if (N.spectral) c->prep_valid = pa.out != nullptr; }
+      else { launch_hidden<true>(p, pa, s, c->n_cu, spec ? c->spec_K : 0, (c->opts.variant & PAYNE_V_HID_WAVES4) != 0); if (N.spectral) c->prep_valid = pa.out != nullptr; }
     } else if (!last && chain && use3 && l == 2 && n - 2 >= 3 && c->chain_flags && (c->opts.variant & PAYNE_V_HID_CHAIN) &&
                ((c->opts.b_max + 31) / 32) * ((N.layers[2].n_out + 31) / 32) <= 2 * c->n_cu && n - 3 <= kChainMax &&
                [&] { for (int q = 2; q <= n - 2; ++q) if (!c->wl_h2[q]) return false; return true; }()) {
