@@ -757,7 +757,18 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (col < p.N) {
     const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
-    if (act_none) {
+    if (act_none && m0 + 64 <= p.B) {
+      // every row of the tile is a candidate's (the usual batch): a value's address = a base every lane shares (its row's start: scalar
+      // registers, one scalar add a row) + the lane's 32-bit offset (column, upper half) -- as first written a row test, a 64-bit multiply
+      // (quarter rate) and a 64-bit add per value: nine instructions a store
+      const unsigned voff = 4u * ((unsigned)(4 * (lane >> 5)) * (unsigned)p.ldy + (unsigned)col);
+      const unsigned char* yb = reinterpret_cast<const unsigned char*>(p.Y + (size_t)(m0 + wm0) * p.ldy);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned char* rowp = yb + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldy * 4;
+        d2_store_row(reinterpret_cast<float*>(const_cast<unsigned char*>(rowp + voff)), __builtin_fmaf(acc[r], rs, bv));
+      }
+    } else if (act_none) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
