@@ -391,16 +391,25 @@ def test_default_network_at_full_width_against_reference_golden(Engine, golden, 
         e3.predict_batch(th[:3], stage=0); assert e3.kernels_used()["hidden"] == "payne_dense_hidden_kernel<false, 4>"
         e3.close()
         # (a three-layer sigmoid net: the first launch is the only hidden launch, its kernel's name says how many waves)
-        raw3 = synth.make_yst_net(npix=512, H=300, seed=5)
-        n3 = _net(raw3); n3["layers"] = [(w, b, _lib.ACT_SIGMOID if a != _lib.ACT_NONE else a) for (w, b, a) in n3["layers"]]
-        th3 = np.full((40, 12), np.nan); th3[:, :4] = thd[:40, :4]; th3[:, 4:6] = 0.0
-        outs = {}
-        for v in (0, _lib.V_HID_WAVES4):
-            e4 = Engine(n3, b_max=40, variant=v)
-            outs[v] = e4.predict_batch(th3, stage=0).cpu().numpy()
-            assert e4.kernels_used()["hidden"] == ("payne_dense_hidden_kernel<true, 4, 8>" if v == 0 else "payne_dense_hidden_kernel<true, 4>"), e4.kernels_used()
-            e4.close()
-        assert np.array_equal(outs[0], outs[_lib.V_HID_WAVES4]) and np.all(np.isfinite(outs[0]))
+        for D, nl in ((4, "4"), (5, "PAYNE_MAX_LABELS")):                        # (five labels: Vmic in column 6, the kernel's other label count)
+            raw3 = synth.make_yst_net(npix=512, H=300, seed=5, D=D)
+            n3 = _net(raw3); n3["layers"] = [(w, b, _lib.ACT_SIGMOID if a != _lib.ACT_NONE else a) for (w, b, a) in n3["layers"]]
+            th3 = np.full((40, 12), np.nan); th3[:, :4] = thd[:40, :4]; th3[:, 4:6] = 0.0; th3[:, 6] = np.linspace(0.6, 2.2, 40)
+            outs = {}
+            for v in (0, _lib.V_HID_WAVES4):
+                e4 = Engine(n3, b_max=40, variant=v)
+                outs[v] = e4.predict_batch(th3, stage=0).cpu().numpy()
+                want = "payne_dense_hidden_kernel<true, %s, 8>" % nl if v == 0 else "payne_dense_hidden_kernel<true, %s>" % nl
+                assert e4.kernels_used()["hidden"] == want, e4.kernels_used()
+                e4.close()
+            assert np.array_equal(outs[0], outs[_lib.V_HID_WAVES4]) and np.all(np.isfinite(outs[0])), D
+            # ... and against the fp64 restatement of the same net
+            xs = (th3[:, [0, 1, 2, 3, 6][:D]] - n3["xmin"]) / (n3["xmax"] - n3["xmin"]) - 0.5
+            h = xs
+            for (w, b, a) in n3["layers"]:
+                z = h @ w.astype(np.float64).T + b.astype(np.float64)
+                h = 1.0 / (1.0 + np.exp(-z)) if a == _lib.ACT_SIGMOID else z
+            assert np.abs(outs[0] - h).max() <= TORCH_FP32_FLUX_TOL, (D, np.abs(outs[0] - h).max())
     # other shipped forms of the output layer on the same net: same likelihoods
     for v in (1, 4096, 2048):
         e2 = Engine(_net(raw, kind), obs=(g["obs_wave"], g["obs_flux"], g["obs_eflux"]), b_max=128, variant=v)
