@@ -658,6 +658,9 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
                    : reinterpret_cast<const unsigned char*>(p.Wp) + 2 * (size_t)pl * p.plane_w;
     voff[j] = (unsigned)r * (isA ? pitch_a : pitch_b) + 16u * (unsigned)c;
     dst[j] = isA ? pl * A_PLANE + blk * 1024 : 2 * A_PLANE + pl * B_PLANE + blk * 1024;
+#if defined(PAYNE_EXP_D2H) && (PAYNE_EXP_D2H & 1)       /* timing twin (tools/exp/d2h_ablate_time.py): every piece comes from ONE kilobyte (no L2 traffic to speak of) */
+    sbase[j] = reinterpret_cast<const unsigned char*>(p.Xp); voff[j] = 16u * (unsigned)lane;
+#endif
   }
   auto issue = [&](int stage, int k0) {                    // k0 in elements (2 bytes each)
 #pragma unroll
@@ -690,9 +693,13 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
     }
   };
   auto products = [&](const Frag& f, int ks) {             // smallest partial products first
+#if defined(PAYNE_EXP_D2H) && (PAYNE_EXP_D2H & 2)       /* timing twin: one of the three products */
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0] + f.a[ks][1], f.b[ks][0] + f.b[ks][1], acc, 0, 0, 0);
+#else
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
+#endif
   };
   const int nk = NK > 0 ? NK : p.K / KD;                   // padded: exact
   const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (nk - 1) * KD;
@@ -766,6 +773,9 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned char* rowp = yb + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldy * 4;
+#if defined(PAYNE_EXP_D2H) && (PAYNE_EXP_D2H & 4)       /* timing twin: (practically) no stores */
+        if (!(acc[r] == 12345.678f)) continue;
+#endif
         d2_store_row(reinterpret_cast<float*>(const_cast<unsigned char*>(rowp + voff)), __builtin_fmaf(acc[r], rs, bv));
       }
     } else if (act_none) {
