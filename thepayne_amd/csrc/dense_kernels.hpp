@@ -744,24 +744,8 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
     if (it + AHEAD < nk) issue((it + AHEAD) % NS, (it + AHEAD) * KD);
     __builtin_amdgcn_sched_barrier(0);
   };
-  int it = 0;
-#pragma unroll
-  for (; it + 2 < nk; it += 2) {
-    head(it, f1, f0);
-    all_products(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    head(it + 1, f0, f1);
-    all_products(f1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (it + 1 < nk) {
-    head(it, f1, f0);
-    all_products(f0);
-    last_products(f1);
-  } else {
-    last_products(f0);
-  }
   // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  auto epilogue = [&]() {
   if (col < p.N) {
     const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
     if (act_none && m0 + 64 <= p.B) {
@@ -792,6 +776,29 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
       }
     }
   }
+  };
+  int it = 0;
+#pragma unroll
+  for (; it + 2 < nk; it += 2) {
+    head(it, f1, f0);
+    all_products(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    head(it + 1, f0, f1);
+    all_products(f1);
+    __builtin_amdgcn_sched_barrier(0);
+#if defined(PAYNE_EXP_D2H) && (PAYNE_EXP_D2H & 24)      /* timing twins: half of the waves store in the middle of the k-loop and leave (what a tile finished in two
+                                                           halves would do; their later operand pieces are not requested: an upper bound) -- 8: after two stages of five, 16: after four */
+    if (it == ((PAYNE_EXP_D2H & 8) ? 0 : 2) && wave < 4) { epilogue(); return; }
+#endif
+  }
+  if (it + 1 < nk) {
+    head(it, f1, f0);
+    all_products(f0);
+    last_products(f1);
+  } else {
+    last_products(f0);
+  }
+  epilogue();
   HK_STAMP(15);
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel times of payne_dense_dma2h_kernel with pieces compiled out (-DPAYNE_EXP_D2H=bits, NO stamps: production shape;
-results are garbage, bench.py --unchecked).  bits: 1 every piece from one kilobyte, 2 one of the three products, 4 no stores.
+results are garbage, bench.py --unchecked).  bits: 1 every piece from one kilobyte, 2 one of the three products, 4 no stores, 8 / 16 half of the waves store after two / four stages of five and leave.
 
     python tools/exp/d2h_ablate_time.py [bits ...]     # default 0 1 2 4 3 7
 """
