@@ -15,7 +15,7 @@ from thepayne_amd import build  # noqa: E402
 
 which = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]
 libs = {b: (build.build_variant("st%d" % b, ["-DPAYNE_EXP_ST=%d" % b]) if b else build.build_lib()) for b in which}
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
     for b in which:
         env = dict(os.environ, PAYNE_HIP_LIB=libs[b])
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "30", "--no-cpu-baseline", "--no-e2e",
