@@ -142,6 +142,9 @@ typedef struct payne_opts {
                                       variant, not a default) */
 #define PAYNE_V_HID_WAVES4 8388608u /* sigmoid nets: the first launch's tiles by four waves (what leaky-ReLU nets and launches that carry
                                       photometric tiles use) instead of eight */
+#define PAYNE_V_OUT_WHOLE_TILE 16777216u /* output layer, one tile a compute unit: the tile's k-loop in one pass, all its rows stored at the end
+                                           (what batches with more tiles than compute units use) instead of two halves, the first one's rows
+                                           leaving under the second one's products */
 #define PAYNE_V_LSF_GLOBAL 128u  /* LSF broadening with its buffers in global memory (what spectra > 8192 px use) */
 
 typedef struct payne_ctx payne_ctx;

@@ -25,6 +25,7 @@ V_OUT_BF16X3 = 1048576
 V_HID_F32 = 2097152
 V_HID_CHAIN = 4194304
 V_HID_WAVES4 = 8388608
+V_OUT_WHOLE_TILE = 16777216
 
 SYMBOLS = ["payne_version", "payne_ctx_create", "payne_ctx_set_obs", "payne_ctx_set_continuum", "payne_ctx_set_lsf", "payne_ctx_set_lsf_on", "payne_ctx_destroy", "payne_last_error",
            "payne_theta_cols", "payne_lnlike_batch", "payne_predict_batch", "payne_smooth_batch", "payne_smooth_direct", "payne_sed_batch", "payne_bc_batch", "payne_kernel_name", "payne_last_kernel", "payne_activation_batch",

@@ -802,6 +802,203 @@ __global__ void __launch_bounds__(512) payne_dense_dma2h_kernel(PAYNE_D3_LEAD_PA
   HK_STAMP(15);
 }
 
+// ----------------------------------------------------------------------------
+// payne_dense_dma2hh_kernel<NK>: payne_dense_dma2h_kernel<NK, 64>'s tile (64 candidates x 128 outputs, one a CU) FINISHED IN TWO HALVES.
+// The rows' stores are 2.6 of that kernel's 9 us (tools/exp/d2h_ablate_time.py): every tile ends its k-loop at the same moment and 8.4 MB
+// leave at once.  Here the activations' NK stages stay resident in LDS (NK x 16 KB) while the weights stream through a ring of three
+// 16-KB slots one HALF of the tile's 128 output rows after the other: pass 1 = stages (A_q, BL_q), waves 0-3 multiply the left 64 x 64
+// (one wave a SIMD), store it and LEAVE -- stores share the counter the operand waits are counted on, a wave with stores in flight cannot
+// wait for later loads precisely --; pass 2 = stages (BR_q), waves 4-7 multiply the right half under the left half's stores.  Same operand
+// bytes (246 KB a tile), same products in the same order: the rows are payne_dense_dma2h_kernel's to the bit (tests/test_gpu_parity.py).
+// Waves 4-7 request their quarter of a pass-1 stage and all of a pass-2 stage (four 1-KB pieces either way), waves 0-3 their quarter of
+// pass 1 only; requests run two stages ahead across the passes' boundary.
+// ----------------------------------------------------------------------------
+template <int NK> constexpr size_t d2hh_lds_bytes() { return (size_t)NK * 16384 + 3 * 16384; }
+template <int NK>
+__global__ void __launch_bounds__(512) payne_dense_dma2hh_kernel(PAYNE_D3_LEAD_PARAMS, DenseParams p_) {
+  DenseParams p = p_;
+  p.sel = lead_sel; p.Xp = lead_Xp; p.Wp = lead_Wp; p.plane_x = lead_plane_x; p.plane_w = lead_plane_w;
+  p.grid_m = (int)(lead_grid & 0xffffu); p.grid_n = (int)(lead_grid >> 16); p.N = lead_N; p.B = lead_B; p.ldp = lead_ldp; p.K = lead_K;
+  constexpr int KD = 64, ROWB = 2 * KD, CPR = ROWB / 16, RPP = 1024 / ROWB;      // bytes a row, chunks a row (8), rows a piece (8)
+  constexpr int PLANE = 64 * ROWB, STAGE = 2 * PLANE;                            // a 64-row plane (8 KB); two planes: an A stage, a B-half stage
+  constexpr int NSB = 3, AHEAD = 2, KS = KD / 16, NT = 2 * NK;                   // ring slots, stages requested ahead, matrix steps a stage, stages
+  constexpr int RING = NK * STAGE;
+  auto sw = [](int row) { return (row >> 1) & 7; };
+  extern __shared__ __attribute__((aligned(16))) unsigned char d2_sm[];
+  if (p.sel != nullptr && (unsigned)*p.sel == lead_sel_seq) {
+    p.Wp = p.Wp_alt; p.plane_w = p.plane_w_alt; p.bias = p.bias_alt; p.bias_shift = p.bias_shift_alt; p.N = p.N_alt; p.ldy = p.ldy_alt;
+    p.rscale = p.rscale_alt;
+  }
+  const int ntiles = p.grid_m * p.grid_n;
+  int t = blockIdx.x;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // XCD-aware order (see payne_dense_kernel)
+  const int m0 = (t % p.grid_m) * 64, n0 = (t / p.grid_m) * 128;
+  if (n0 >= p.N) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, w4 = wave & 3;                          // which half of the tile's outputs this wave multiplies
+  const int wm0 = (w4 >> 1) * 32, wn0 = 64 * half + (w4 & 1) * 32;
+  // pieces: 8 rows x 128 bytes of one plane.  Pass 1 (every wave): activations (plane j, block wave), j = 0, 1; left weights (plane j - 2,
+  // block wave), j = 2, 3.  Pass 2 (waves 4-7): right weights (plane j / 2, block 2 w4 + j % 2), j = 0 .. 3.
+  const int lrow = lane / CPR, lchunk = lane % CPR;
+  const unsigned pitch_a = 2u * (unsigned)p.ldp, pitch_b = 2u * (unsigned)p.K;
+  const unsigned char* sb1[4]; unsigned vo1[4]; int ds1[4];
+  const unsigned char* sb2[4]; unsigned vo2[4]; int ds2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    {
+      const bool isA = j < 2;
+      const int pl = j & 1, blk = wave;
+      const int row = RPP * blk + lrow, c = lchunk ^ sw(row);
+      const int top = isA ? p.B - 1 - m0 : p.N - 1 - n0;
+      const int r = (isA ? m0 : n0) + (row < top ? row : top);
+      sb1[j] = isA ? reinterpret_cast<const unsigned char*>(p.Xp) + 2 * (size_t)pl * p.plane_x
+                   : reinterpret_cast<const unsigned char*>(p.Wp) + 2 * (size_t)pl * p.plane_w;
+      vo1[j] = (unsigned)r * (isA ? pitch_a : pitch_b) + 16u * (unsigned)c;
+      ds1[j] = pl * PLANE + blk * 1024;                                // (inside the stage's A block, or inside its ring slot)
+    }
+    {
+      const int pl = j >> 1, blk = 2 * w4 + (j & 1);
+      const int row = RPP * blk + lrow, c = lchunk ^ sw(row);
+      const int top = p.N - 1 - n0;
+      const int r = n0 + (64 + row < top ? 64 + row : top);
+      sb2[j] = reinterpret_cast<const unsigned char*>(p.Wp) + 2 * (size_t)pl * p.plane_w;
+      vo2[j] = (unsigned)r * pitch_b + 16u * (unsigned)c;
+      ds2[j] = pl * PLANE + blk * 1024;
+    }
+  }
+  // stage q of the sequence: q < NK: (A_q -> its resident block, BL_q -> ring slot q % 3); q >= NK: BR_(q - NK) -> ring slot q % 3
+  auto issue = [&](int q) {
+    if (q < NK) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb1[j] + vo1[j] + 2 * KD * q),
+                                         (__attribute__((address_space(3))) void*)(d2_sm + (j < 2 ? q * STAGE : RING + (q % NSB) * STAGE) + ds1[j]), 16, 0, 0);
+    } else if (half) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb2[j] + vo2[j] + 2 * KD * (q - NK)),
+                                         (__attribute__((address_space(3))) void*)(d2_sm + RING + (q % NSB) * STAGE + ds2[j]), 16, 0, 0);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int Ra = wm0 + (lane & 31), Rb = (w4 & 1) * 32 + (lane & 31), h = lane >> 5;      // rows inside the stage's A block / B-half slot
+  const int sa = sw(Ra), sb = sw(Rb);
+  struct Frag { f16x8_t a[KS][2], b[KS][2]; };
+  auto frags = [&](int q, Frag& f) {                          // stage q's operands of this wave's 32 x 32 block
+    const unsigned char* As = d2_sm + (q < NK ? q : q - NK) * STAGE;
+    const unsigned char* Bs = d2_sm + RING + (q % NSB) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = 2 * ks + h;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        f.a[ks][pl] = *reinterpret_cast<const f16x8_t*>(As + pl * PLANE + Ra * ROWB + 16 * (c ^ sa));
+        f.b[ks][pl] = *reinterpret_cast<const f16x8_t*>(Bs + pl * PLANE + Rb * ROWB + 16 * (c ^ sb));
+      }
+    }
+  };
+  auto products = [&](const Frag& f, int ks) {             // smallest partial products first (payne_dense_dma2h_kernel's order)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
+  };
+  const int k_tail = (p.k_real > 0 ? p.k_real : p.K) - (NK - 1) * KD;
+  const int ks_last = __builtin_amdgcn_readfirstlane((k_tail + 15) >> 4);   // the zero-padded 16-deep steps of a pass's last stage are skipped
+  auto stage_products = [&](const Frag& f, bool last) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      if (!last || ks < ks_last) products(f, ks);
+  };
+  const int col = n0 + wn0 + (lane & 31);
+  const float bv = p.bias[col < p.N ? col : p.N - 1] - p.bias_shift;
+  const float rs = p.rscale[col < p.N ? col : p.N - 1];
+  auto epilogue = [&]() {                                     // C/D map of the 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (col >= p.N) return;
+    const bool act_none = __builtin_amdgcn_readfirstlane(p.act == PAYNE_ACT_NONE ? 1 : 0) != 0;
+    if (act_none && m0 + 64 <= p.B) {
+      const unsigned voff = 4u * ((unsigned)(4 * (lane >> 5)) * (unsigned)p.ldy + (unsigned)col);
+      const unsigned char* yb = reinterpret_cast<const unsigned char*>(p.Y + (size_t)(m0 + wm0) * p.ldy);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned char* rowp = yb + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldy * 4;
+        d2_store_row(reinterpret_cast<float*>(const_cast<unsigned char*>(rowp + voff)), __builtin_fmaf(acc[r], rs, bv));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.B) {
+          const float y = __builtin_fmaf(acc[r], rs, bv);
+          __builtin_nontemporal_store(act_none ? y : act_apply(y, p.act), &p.Y[(size_t)row * p.ldy + col]);
+        }
+      }
+    }
+  };
+  HK_STAMP(0);
+  Frag f0, f1;
+  // The two halves' waves run two different programs over the same barriers (NK + 1 of them while both are there).
+  if (half == 0) {
+    // ---- waves 0-3: pass 1 -- request my quarter of its stages, multiply the left 64 x 64, store it, leave ----
+    issue(0); issue(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // stage 0 (stage 1's four pieces behind it)
+    asm volatile("s_barrier" ::: "memory");
+    frags(0, f0);
+#pragma unroll
+    for (int q = 0; q + 1 < NK; ++q) {
+      Frag& fc = (q & 1) ? f1 : f0;
+      Frag& fn = (q & 1) ? f0 : f1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage q + 1 (the next request follows the barrier)
+      asm volatile("s_barrier" ::: "memory");
+      frags(q + 1, fn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + AHEAD < NK) issue(q + AHEAD);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_products(fc, false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_barrier" ::: "memory");                  // (the barrier the other half counts on at the passes' boundary)
+    stage_products(((NK - 1) & 1) ? f1 : f0, true);
+    epilogue();
+    return;
+  }
+  // ---- waves 4-7: request my quarter of pass 1's stages and all of pass 2's; multiply the right 64 x 64 in pass 2 ----
+  issue(0); issue(1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+  for (int q = 0; q + 1 < NK; ++q) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    issue(q + AHEAD);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage NK: the right half's first
+  asm volatile("s_barrier" ::: "memory");
+  frags(NK, f0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (NK + 1 < NT) issue(NK + 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = NK; q < NT; ++q) {
+    Frag& fc = ((q - NK) & 1) ? f1 : f0;
+    Frag& fn = ((q - NK) & 1) ? f0 : f1;
+    if (q + 1 < NT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");                // (the left half's waves have left, or are about to: they are not waited for once gone)
+      frags(q + 1, fn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + AHEAD < NT) issue(q + AHEAD);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage_products(fc, q == NT - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  epilogue();
+  HK_STAMP(15);
+}
+
 constexpr int D3_STAGE = 3 * (64 + 128) * 64;              // bytes per stage
 // NS = 4, PIPE: one tile per CU (C2).  NS = 2, !PIPE: many tiles per CU (C5) -- two stages = 72 KB, two workgroups per CU, and per
 // step: wait, barrier, this step's fragments, the request for the next stage, the products (the other workgroup's products fill
@@ -2279,6 +2476,7 @@ PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<0, 32>(PAYNE_D3_LEAD_TYPE
 PAYNE_DENSE_T __global__ void payne_dense_dma2h_kernel<5, 64>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<false>(DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_big3_kernel<true>(DenseParams);
+PAYNE_DENSE_T __global__ void payne_dense_dma2hh_kernel<5>(PAYNE_D3_LEAD_TYPES, DenseParams);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<true, PAYNE_MAX_LABELS>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);
 PAYNE_DENSE_T __global__ void payne_dense_hidden_kernel<false, 4>(PAYNE_HK_LEAD_TYPES, DenseParams, const PrepArgs);

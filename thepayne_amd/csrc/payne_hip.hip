@@ -821,6 +821,7 @@ static hipError_t set_dense_attributes() {
   set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<10, 32>), d2_lds_bytes<32>());
   set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<0, 32>), d2_lds_bytes<32>());
   set(reinterpret_cast<const void*>(payne_dense_dma2h_kernel<5, 64>), d2_lds_bytes<64>());
+  set(reinterpret_cast<const void*>(payne_dense_dma2hh_kernel<5>), d2hh_lds_bytes<5>());
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel<false>), b3_lds_bytes(false));
   set(reinterpret_cast<const void*>(payne_dense_big3_kernel<true>), b3_lds_bytes(true));
   set(reinterpret_cast<const void*>(payne_dense_chain_kernel), HK_LDS_BYTES);
@@ -912,7 +913,10 @@ static void launch_out_dma2h(payne_ctx* c, DenseParams& p, hipStream_t s, bool f
   // otherwise; other widths, and PAYNE_V_OUT_ROLLED: 32-deep steps counted at run time.  Same products in the same order in all three.
   const bool k320 = p.K == 320 && !(c->opts.variant & PAYNE_V_OUT_ROLLED);
   const bool deep = (int)grid.x <= c->n_cu;
-  if (k320 && deep) PAYNE_LAUNCH((payne_dense_dma2h_kernel<5, 64>), grid, block, d2_lds_bytes<64>(), s, PAYNE_D3_LEAD_ARGS(p), p);
+  // (... finished in two halves: the left half's rows leave under the right half's products -- payne_dense_dma2hh_kernel, same rows to the bit)
+  if (k320 && deep && !(c->opts.variant & PAYNE_V_OUT_WHOLE_TILE))
+    PAYNE_LAUNCH((payne_dense_dma2hh_kernel<5>), grid, block, d2hh_lds_bytes<5>(), s, PAYNE_D3_LEAD_ARGS(p), p);
+  else if (k320 && deep) PAYNE_LAUNCH((payne_dense_dma2h_kernel<5, 64>), grid, block, d2_lds_bytes<64>(), s, PAYNE_D3_LEAD_ARGS(p), p);
   else if (k320) PAYNE_LAUNCH((payne_dense_dma2h_kernel<10, 32>), grid, block, d2_lds_bytes<32>(), s, PAYNE_D3_LEAD_ARGS(p), p);
   else PAYNE_LAUNCH((payne_dense_dma2h_kernel<0, 32>), grid, block, d2_lds_bytes<32>(), s, PAYNE_D3_LEAD_ARGS(p), p);
 }
