@@ -31,9 +31,9 @@ VARIANTS = {"default": 0, "out_generic": 1, "post_generic": 2, "tw_global": 4, "
             "post_generic+tw_global+no_prep": 2 | 4 | 16, "out_generic+post_full": 1 | 8, "out_bk64": 1024, "out_rolled": 2048, "out_bk64+rolled": 1024 | 2048, "out_f32": 4096, "out_f32+rolled": 4096 | 2048,
             "rows_pixel": 262144, "rows_pixel+post_full": 262144 | 8, "rows_pixel+no_prep": 262144 | 16,
             "out_planes": 524288, "out_planes+rows_pixel": 524288 | 262144, "out_bf16x3": 1048576, "out_bf16x3+rows_pixel": 1048576 | 262144,
-            "hid_f32": 2097152, "hid_f32+out_bf16x3": 2097152 | 1048576}
+            "hid_f32": 2097152, "hid_f32+out_bf16x3": 2097152 | 1048576, "out_whole_tile": 16777216, "out_whole_tile+rows_pixel": 16777216 | 262144}
 # ... of which these hand the post kernel rows in the frequency domain (the output layer's weights restated: payne_hip.h, payne_last_kernel kind 4)
-FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes", "out_bf16x3", "hid_f32", "hid_f32+out_bf16x3"}
+FREQ_ROWS = {"default", "post_full", "no_prep", "out_rolled", "out_planes", "out_bf16x3", "hid_f32", "hid_f32+out_bf16x3", "out_whole_tile"}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -296,6 +296,42 @@ def test_dense_layers_on_odd_shapes(Engine, H, npix, B, D):
         eng.close()
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= FLUX_TOL, (variant, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("npix,B", [(4096, 512), (4096, 100), (1000, 64), (2048, 129), (640, 7), (8192, 256)])
+def test_output_tile_in_two_halves_is_the_whole_tile_to_the_bit(Engine, npix, B):
+    """One output tile a compute unit: the tile is finished in two halves (payne_dense_dma2hh_kernel: activations resident in LDS, the weights'
+    halves streamed one after the other, the left half's rows stored under the right half's products) -- the same products in the same
+    order as the whole tile (payne_dense_dma2h_kernel<5, 64>, PAYNE_V_OUT_WHOLE_TILE): the same rows to the bit, whole and ragged tiles,
+    pixel rows and rows in the frequency domain, and the same likelihoods."""
+    from thepayne_amd import _lib
+    cfg = synth.CONFIGS["C2"]
+    raw = synth.make_yst_net(npix=npix, lam0=cfg["lam0"], R_fwhm=cfg["R"], H=300, seed=npix + B)
+    net = _net(raw)
+    obs = synth.obs_grid(raw["wavelength"], max(64, int(0.85 * npix)))
+    th = theta_full(synth.draw_candidates(B, seed=B))
+    th[0, 5] = 0.0                                                   # (a candidate that does not rotate)
+    e0 = Engine(net, obs=(obs,), b_max=B)
+    clean = e0.predict_batch(th[:1], stage=2, fwhm_R=True).cpu().numpy()[0].astype(np.float64)
+    e0.close()
+    flux = clean + np.random.default_rng(0).normal(0, 0.01, len(obs))
+    out = {}
+    for v in (0, _lib.V_OUT_WHOLE_TILE):
+        eng = Engine(net, obs=(obs, flux, np.full(len(obs), 0.01)), b_max=B, variant=v)
+        rows = eng.predict_batch(th, stage=0).cpu().numpy()
+        name0 = eng.kernels_used()["out"]
+        lnl = eng.lnlike_batch(th).cpu().numpy()
+        out[v] = (rows, lnl, name0, eng.kernels_used()["out"], eng.kernels_used()["rows"])
+        eng.close()
+    a, b = out[0], out[_lib.V_OUT_WHOLE_TILE]
+    tiles = ((B + 63) // 64) * ((npix + 127) // 128)
+    if tiles <= 256:                                                 # (a tile a compute unit: the two kernels this test is about)
+        assert a[2] == "payne_dense_dma2hh_kernel<5>" and b[2] == "payne_dense_dma2h_kernel<5, 64>", (a[2], b[2])
+    else:
+        assert a[2] == b[2], (a[2], b[2])
+    assert np.array_equal(a[0], b[0]), np.abs(a[0] - b[0]).max()
+    assert np.array_equal(np.nan_to_num(a[1]), np.nan_to_num(b[1])) and int(np.isfinite(a[1]).sum()) >= B - 4
+    assert a[4] == b[4]
 
 
 @pytest.mark.parametrize("domain", ["frequency", "pixels"])
