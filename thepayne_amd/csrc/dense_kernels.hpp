@@ -952,6 +952,7 @@ __global__ void __launch_bounds__(512) payne_dense_dma2hh_kernel(PAYNE_D3_LEAD_P
       Frag& fn = (q & 1) ? f0 : f1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage q + 1 (the next request follows the barrier)
       asm volatile("s_barrier" ::: "memory");
+      HK_STAMP(1 + q);                                       // (diagnostic build: the left half's life, by its first wave)
       frags(q + 1, fn);
       __builtin_amdgcn_sched_barrier(0);
       if (q + AHEAD < NK) issue(q + AHEAD);
@@ -961,7 +962,9 @@ __global__ void __launch_bounds__(512) payne_dense_dma2hh_kernel(PAYNE_D3_LEAD_P
     }
     asm volatile("s_barrier" ::: "memory");                  // (the barrier the other half counts on at the passes' boundary)
     stage_products(((NK - 1) & 1) ? f1 : f0, true);
+    HK_STAMP(NK);
     epilogue();
+    HK_STAMP(15);
     return;
   }
   // ---- waves 4-7: request my quarter of pass 1's stages and all of pass 2's; multiply the right 64 x 64 in pass 2 ----
