@@ -8,7 +8,8 @@ import sampler_bench as sb
 from thepayne_amd.sampler.nested import NestedSampler
 from thepayne_amd.sampler.device import DeviceProposer
 
-L, P = sb.make_problem("C2", 512, 0)
+VAR = int(sys.argv[1]) if len(sys.argv) > 1 else 0        # e.g. 131072 = PAYNE_V_NO_WALK_SPEC
+L, P = sb.make_problem("C2", 512, VAR)
 eng = L.GM.engine
 for prof in (False, True):
     prop = DeviceProposer(L, P, k_max=512)
