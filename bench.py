@@ -275,6 +275,12 @@ def alg_work(d):
                 flops_out=2.0 * H * N)
 
 
+def more_blocks(blocks, repeats, min_timed_s, cap=4000):
+    """Is another timed block due?  At least `repeats` blocks, then blocks until `min_timed_s` seconds of timed work are behind (`blocks`:
+    the MAX-over-ranks times so far, the same list on every rank, so every rank stops at the same block); never more than `cap`."""
+    return len(blocks) < max(1, repeats) or (sum(blocks) < min_timed_s and len(blocks) < cap)
+
+
 def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, streams=1, shard=False, repeats=1, min_timed_s=0.0):
     """Time `steps` steps of config `cfg_name` (after `warmup`) between barriers; MAX over ranks.  Returns the numbers the
     JSON line is made of.  shard: one star, the batch split over the ranks, one all_gather of lnL per step."""
@@ -328,7 +334,7 @@ def run_config(cfg_name, args, steps, warmup, rank, world, local_rank, B=0, stre
     # At least `repeats` blocks, and blocks until `min_timed_s` of timed work is behind (every rank sees the same MAX-reduced times, so
     # every rank stops at the same block): a GPU that was idle is 6 % slower for its first 15-20 ms of work (clock ramp), which is the
     # whole of fifteen 20-step blocks; the median is then taken over blocks most of which ran at the clocks the job runs at.
-    while len(blocks) < max(1, repeats) or (sum(blocks) < min_timed_s and len(blocks) < 4000):
+    while more_blocks(blocks, repeats, min_timed_s):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()

@@ -359,3 +359,27 @@ def test_bench_line_is_small_and_complete():
     # a side run that failed is reported, shortly
     big["also_measured"] = {"C5": {"error": "RuntimeError: " + "y" * 900}}
     assert len(bench.final_line(big)["also_measured"]["C5"]["error"]) <= 80
+
+
+def test_bench_times_blocks_until_the_clock_ramp_is_behind():
+    """bench.py's stopping rule for timed blocks: never fewer than --repeats, then until --min-timed-ms of timed work are behind (an idle
+    MI355X needs 15-20 ms of work to reach its clocks: fifteen 20-step blocks -- the driver's command -- are 9 ms), bounded."""
+    import bench
+    blocks = []
+    while bench.more_blocks(blocks, 15, 0.120):
+        blocks.append(20 * 29e-6)                                  # the driver's command: 20 steps of 29 us
+    assert len(blocks) == 207 and sum(blocks) >= 0.120 > sum(blocks[:-1])
+    blocks = []
+    while bench.more_blocks(blocks, 15, 0.120):
+        blocks.append(200 * 29e-6)                                 # the default run: fifteen blocks are 87 ms
+    assert len(blocks) == 21
+    blocks = []
+    while bench.more_blocks(blocks, 3, 0.120):
+        blocks.append(3 * 1.3e-3)                                  # C5: three steps of 1.3 ms
+    assert len(blocks) == 31
+    assert not bench.more_blocks([1.0] * 15, 15, 0.120) and bench.more_blocks([1.0] * 14, 15, 0.0) and bench.more_blocks([], 0, 0.0)
+    blocks = []
+    while bench.more_blocks(blocks, 1, 1.0, cap=50):
+        blocks.append(1e-9)
+    assert len(blocks) == 50
+
